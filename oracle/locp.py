@@ -1,0 +1,331 @@
+"""Oracle: the LOCP horizon QP (test infrastructure only).
+
+**parity unpinned** against the reference's solver: sofacontrol/scp/locp.py hands the problem to
+cvxpy (`cp.Problem(...).solve(solver=OSQP|GUROBI)`, locp.py:181,216) -- third-party, not vendored,
+versions not pinned (requirements.txt:1-5), not installable here.  What IS restated exactly is the
+problem data (locp.py:218-342): `build_qp` assembles the same stacked QP over
+w = [x_0..x_N ; u_0..u_{N-1} ; s_0..s_N] that cvxpy canonicalises.  The QP has a unique (x, u)
+solution (R > 0 and x is an affine function of u), so any correct solver pins the answer:
+
+* `solve_exact`   -- primal-dual interior point on the full sparse KKT system (scipy.sparse
+                     spsolve), run to ~1e-10; returns multipliers for `kkt_certificate`.
+* `solve_eq_only` -- closed-form dense KKT solve when no inequality is present / active.
+* `solve_osqp`    -- restatement of the published OSQP ADMM algorithm (Stellato et al. 2020,
+                     Alg. 1 with Ruiz equilibration and adaptive rho), the reference's default
+                     solver, at cvxpy's default tolerances -- shows what accuracy the reference
+                     itself delivers.
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+class QPData:
+    pass
+
+
+def build_qp(N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega, z=None, u_des=None, Qzf=None, zf=None,
+             U=None, X=None, Xf=None, dU=None, x_scale=None, tr_active=True):
+    """Stacked QP  min w'Pq w + c'w + c0  s.t.  E w = e,  G w <= h   (objective WITHOUT 1/2, as
+    cp.quad_form, locp.py:226,248).  U/X/Xf/dU are (A, b) tuples or None.
+
+    Index ranges follow locp.py: dynamics 287; TR 290-297 (all k=0..N, Fortran-order reshape so
+    column k is x_k); U 300-303 (k<N); dU 305-308 (k<N-1); X 330-333 (k=1..N); Xf 336-337;
+    x_0 = x0 340.  Terminal cost: locp.py:252 slices x[N*n_z:], which only type-checks when
+    n_x == n_z, where it equals x_N -- restated as a cost on x_N.
+    """
+    n, m = Bd[0].shape
+    nz = Qz.shape[0]
+    nx_tot, nu_tot = (N + 1) * n, N * m
+    ns = (N + 1) if tr_active else 0
+    nw = nx_tot + nu_tot + ns
+    ox, ou, os_ = 0, nx_tot, nx_tot + nu_tot
+    z = np.zeros((N + 1, nz)) if z is None else np.asarray(z).reshape(N + 1, nz)
+    u_des = np.zeros((N, m)) if u_des is None else np.asarray(u_des).reshape(N, m)
+    xs = np.ones(n) if x_scale is None else x_scale
+
+    Pq = sp.lil_matrix((nw, nw))
+    c = np.zeros(nw)
+    c0 = 0.0
+    HQH = H.T @ Qz @ H
+    for k in range(N + 1):
+        Pq[ox + k * n: ox + (k + 1) * n, ox + k * n: ox + (k + 1) * n] = HQH
+        c[ox + k * n: ox + (k + 1) * n] = -2.0 * H.T @ Qz @ z[k]
+        c0 += z[k] @ Qz @ z[k]
+    if Qzf is not None:
+        zf_ = np.zeros(nz) if zf is None else zf
+        Pq[ox + N * n: ox + (N + 1) * n, ox + N * n: ox + (N + 1) * n] += H.T @ Qzf @ H
+        c[ox + N * n: ox + (N + 1) * n] += -2.0 * H.T @ Qzf @ zf_
+        c0 += zf_ @ Qzf @ zf_
+    for k in range(N):
+        Pq[ou + k * m: ou + (k + 1) * m, ou + k * m: ou + (k + 1) * m] = R
+        c[ou + k * m: ou + (k + 1) * m] = -2.0 * R @ u_des[k]
+        c0 += u_des[k] @ R @ u_des[k]
+    if tr_active:
+        c[os_:] = omega
+
+    E = sp.lil_matrix(((N + 1) * n, nw))
+    e = np.zeros((N + 1) * n)
+    for k in range(N):
+        r0 = k * n
+        E[r0:r0 + n, ox + (k + 1) * n: ox + (k + 2) * n] = np.eye(n)
+        E[r0:r0 + n, ox + k * n: ox + (k + 1) * n] = -np.asarray(Ad[k])
+        E[r0:r0 + n, ou + k * m: ou + (k + 1) * m] = -np.asarray(Bd[k])
+        e[r0:r0 + n] = np.asarray(dd[k])
+    E[N * n:(N + 1) * n, ox: ox + n] = np.eye(n)
+    e[N * n:] = x0
+
+    G_list = []
+    h_list = []
+    if tr_active:
+        for k in range(N + 1):
+            Gk = sp.lil_matrix((2 * n + 1, nw))
+            hk = np.zeros(2 * n + 1)
+            for i in range(n):
+                Gk[2 * i, ox + k * n + i] = xs[i]
+                Gk[2 * i, os_ + k] = -1.0
+                hk[2 * i] = delta + xs[i] * xk[k, i]
+                Gk[2 * i + 1, ox + k * n + i] = -xs[i]
+                Gk[2 * i + 1, os_ + k] = -1.0
+                hk[2 * i + 1] = delta - xs[i] * xk[k, i]
+            Gk[2 * n, os_ + k] = -1.0
+            G_list.append(Gk)
+            h_list.append(hk)
+    if U is not None:
+        UA, Ub = U
+        for k in range(N):
+            Gk = sp.lil_matrix((UA.shape[0], nw))
+            Gk[:, ou + k * m: ou + (k + 1) * m] = UA
+            G_list.append(Gk)
+            h_list.append(np.asarray(Ub, dtype=float))
+    if dU is not None:
+        dA, db = dU
+        for k in range(N - 1):
+            Gk = sp.lil_matrix((dA.shape[0], nw))
+            Gk[:, ou + (k + 1) * m: ou + (k + 2) * m] = dA
+            Gk[:, ou + k * m: ou + (k + 1) * m] = -dA
+            G_list.append(Gk)
+            h_list.append(np.asarray(db, dtype=float))
+    if X is not None:
+        XA, Xb = X
+        for k in range(1, N + 1):
+            Gk = sp.lil_matrix((XA.shape[0], nw))
+            Gk[:, ox + k * n: ox + (k + 1) * n] = XA
+            G_list.append(Gk)
+            h_list.append(np.asarray(Xb, dtype=float))
+    if Xf is not None:
+        XA, Xb = Xf
+        Gk = sp.lil_matrix((XA.shape[0], nw))
+        Gk[:, ox + N * n: ox + (N + 1) * n] = XA
+        G_list.append(Gk)
+        h_list.append(np.asarray(Xb, dtype=float))
+
+    qp = QPData()
+    qp.N, qp.n, qp.m, qp.ns = N, n, m, ns
+    qp.Pq = sp.csc_matrix(Pq)
+    qp.c, qp.c0 = c, c0
+    qp.E, qp.e = sp.csc_matrix(E), e
+    if G_list:
+        qp.G = sp.csc_matrix(sp.vstack([g.tocsr() for g in G_list]))
+        qp.h = np.concatenate(h_list)
+    else:
+        qp.G = sp.csc_matrix((0, nw))
+        qp.h = np.zeros(0)
+    return qp
+
+
+def objective(qp, w):
+    return float(w @ (qp.Pq @ w) + qp.c @ w + qp.c0)
+
+
+def split(qp, w):
+    N, n, m = qp.N, qp.n, qp.m
+    x = w[:(N + 1) * n].reshape(N + 1, n)
+    u = w[(N + 1) * n:(N + 1) * n + N * m].reshape(N, m)
+    s = w[(N + 1) * n + N * m:] if qp.ns else None
+    return x, u, s
+
+
+def solve_eq_only(qp):
+    """Exact dense KKT solve ignoring inequalities (valid when none is active)."""
+    nw, ne = qp.Pq.shape[0], qp.E.shape[0]
+    # slack columns have zero Hessian: pin them with a unit diagonal (they are decoupled here)
+    P2 = (2.0 * qp.Pq).tolil()
+    if qp.ns:
+        for j in range(nw - qp.ns, nw):
+            P2[j, j] = 1.0
+    c = qp.c.copy()
+    if qp.ns:
+        c[nw - qp.ns:] = 0.0
+    K = sp.bmat([[P2, qp.E.T], [qp.E, None]], format='csc')
+    sol = spla.spsolve(K, np.concatenate((-c, qp.e)))
+    return sol[:nw], sol[nw:]
+
+
+def solve_exact(qp, tol=1e-10, max_iter=200, verbose=False):
+    """Mehrotra predictor-corrector primal-dual interior point on the full sparse KKT system.
+
+    Returns w, (y, lam), info.  Independent of the product's Riccati-structured solver: the Newton
+    systems here are solved as one sparse indefinite system by SuperLU.
+    """
+    P = (2.0 * qp.Pq).tocsc()
+    q, E, e, G, h = qp.c, qp.E, qp.e, qp.G, qp.h
+    nw, ne, ng = P.shape[0], E.shape[0], G.shape[0]
+    if ng == 0:
+        w, y = solve_eq_only(qp)
+        return w, (y, np.zeros(0)), dict(iters=0, mu=0.0)
+    GT = G.T.tocsc()
+    ET = E.T.tocsc()
+    # starting point (the heuristic of CVXOPT's coneqp): least-squares point of the KKT system
+    # with unit scaling, then shift slacks / multipliers into the positive orthant
+    K0 = sp.bmat([[P + GT @ G + 1e-13 * sp.eye(nw), ET], [E, -1e-13 * sp.eye(ne)]], format='csc')
+    sol = spla.splu(K0).solve(np.concatenate((-q + GT @ h, e)))
+    w, y = sol[:nw], sol[nw:]
+    zz = G @ w - h
+    t = -zz
+    if t.min() <= 0:
+        t = t + (1.0 - t.min())
+    lam = zz.copy()
+    if lam.min() <= 0:
+        lam = lam + (1.0 - lam.min())
+    scale_d = max(1.0, np.abs(q).max())
+    scale_p = max(1.0, np.abs(h).max() if ng else 1.0, np.abs(e).max())
+    info = {}
+    for it in range(max_iter):
+        r_d = P @ w + q + ET @ y + GT @ lam
+        r_e = E @ w - e
+        r_g = G @ w + t - h
+        mu = float(lam @ t) / ng
+        if verbose:
+            print(it, np.abs(r_d).max(), np.abs(r_e).max(), np.abs(r_g).max(), mu)
+        if (np.abs(r_d).max() <= tol * scale_d and np.abs(r_e).max() <= tol * scale_p and
+                np.abs(r_g).max() <= tol * scale_p and mu <= tol):
+            break
+        D = lam / t
+        Phi = P + GT @ sp.diags(D) @ G + 1e-13 * sp.eye(nw)
+        K = sp.bmat([[Phi, ET], [E, -1e-13 * sp.eye(ne)]], format='csc')
+        lu = spla.splu(K)
+
+        def newton(r_c):
+            rhs1 = -r_d - GT @ ((-r_c + lam * r_g) / t)
+            sol = lu.solve(np.concatenate((rhs1, -r_e)))
+            dw, dy = sol[:nw], sol[nw:]
+            dt = -r_g - G @ dw
+            dlam = (-r_c - lam * dt) / t
+            return dw, dy, dt, dlam
+
+        def step_len(v, dv):
+            neg = dv < 0
+            return min(1.0, float(np.min(-v[neg] / dv[neg]))) if neg.any() else 1.0
+
+        dw, dy, dt, dlam = newton(lam * t)
+        a_aff = min(step_len(t, dt), step_len(lam, dlam))
+        mu_aff = float((lam + a_aff * dlam) @ (t + a_aff * dt)) / ng
+        sigma = (mu_aff / mu) ** 3 if mu > 0 else 0.0
+        dw, dy, dt, dlam = newton(lam * t + dt * dlam - sigma * mu)
+        # one common primal/dual step (QP: the dual residual couples w and the multipliers)
+        a = min(step_len(t, dt), step_len(lam, dlam))
+        a = a if a >= 1.0 else 0.99 * a
+        w = w + a * dw
+        t = t + a * dt
+        y = y + a * dy
+        lam = lam + a * dlam
+        if not (np.isfinite(mu) and np.all(np.isfinite(w))):
+            break
+    info['iters'] = it
+    info['mu'] = mu
+    info['status'] = 'optimal' if it < max_iter - 1 and np.isfinite(mu) else 'failed'
+    return w, (y, lam), info
+
+
+def kkt_certificate(qp, w, y, lam):
+    """Residuals of the KKT conditions of the stacked QP (all should be ~0):
+    stationarity, equality, inequality violation, negative multipliers, complementarity."""
+    P = 2.0 * qp.Pq
+    stat = P @ w + qp.c + qp.E.T @ y + (qp.G.T @ lam if lam.size else 0.0)
+    g = qp.G @ w - qp.h if lam.size else np.zeros(0)
+    return dict(stationarity=float(np.abs(stat).max()),
+                equality=float(np.abs(qp.E @ w - qp.e).max()),
+                ineq_violation=float(np.maximum(g, 0).max()) if g.size else 0.0,
+                dual_negativity=float(np.maximum(-lam, 0).max()) if lam.size else 0.0,
+                complementarity=float(np.abs(lam * g).max()) if g.size else 0.0)
+
+
+def solve_osqp(qp, eps_abs=1e-5, eps_rel=1e-5, max_iter=10000, rho=0.1, sigma=1e-6, alpha=1.6,
+               scaling_iters=10, adaptive_rho_interval=50):
+    """Restatement of OSQP (Stellato et al. 2020): Alg. 1 ADMM, Ruiz equilibration (Alg. 2),
+    adaptive rho (sec. 5.2), equality rows weighted 1e3*rho.  Tolerances default to the values
+    cvxpy passes for OSQP (1e-5); max_iter as cvxpy (10000).  No polishing.
+    Standard form: min 1/2 x'Px + q'x  s.t.  l <= A x <= u."""
+    P = (2.0 * qp.Pq).tocsc()
+    q = qp.c.copy()
+    A = sp.vstack([qp.E, qp.G]).tocsc() if qp.G.shape[0] else qp.E.tocsc()
+    ne = qp.E.shape[0]
+    l = np.concatenate((qp.e, -np.inf * np.ones(qp.G.shape[0])))
+    u = np.concatenate((qp.e, qp.h))
+    n, m = P.shape[0], A.shape[0]
+    # Ruiz equilibration
+    D = np.ones(n); Ev = np.ones(m); cscale = 1.0
+    Ps, As, qs = P.copy(), A.copy(), q.copy()
+    for _ in range(scaling_iters):
+        colP = np.abs(Ps).max(axis=0).toarray().ravel()
+        colA = np.abs(As).max(axis=0).toarray().ravel()
+        dn = np.maximum(colP, colA)
+        dn[dn < 1e-4] = 1.0
+        dn = 1.0 / np.sqrt(np.minimum(dn, 1e4))
+        rowA = np.abs(As).max(axis=1).toarray().ravel()
+        rowA[rowA < 1e-4] = 1.0
+        en = 1.0 / np.sqrt(np.minimum(rowA, 1e4))
+        Dm, Em = sp.diags(dn), sp.diags(en)
+        Ps = (Dm @ Ps @ Dm).tocsc()
+        As = (Em @ As @ Dm).tocsc()
+        qs = dn * qs
+        D *= dn; Ev *= en
+        colmean = np.abs(Ps).max(axis=0).toarray().ravel().mean()
+        gam = 1.0 / max(colmean, np.abs(qs).max(), 1e-4)
+        gam = min(max(gam, 1e-4), 1e4)
+        Ps = Ps * gam; qs = qs * gam; cscale *= gam
+    ls, us = Ev * l, Ev * u
+    is_eq = np.zeros(m, dtype=bool); is_eq[:ne] = True
+
+    def factor(rho):
+        rv = np.where(is_eq, 1e3 * rho, rho)
+        K = sp.bmat([[Ps + sigma * sp.eye(n), As.T], [As, -sp.diags(1.0 / rv)]], format='csc')
+        return spla.splu(K), rv
+
+    lu, rv = factor(rho)
+    x = np.zeros(n); zv = np.zeros(m); y = np.zeros(m)
+    status = 'max_iter'
+    for it in range(1, max_iter + 1):
+        sol = lu.solve(np.concatenate((sigma * x - qs, zv - y / rv)))
+        xt, nu = sol[:n], sol[n:]
+        zt = zv + (nu - y) / rv
+        x = alpha * xt + (1 - alpha) * x
+        zh = alpha * zt + (1 - alpha) * zv
+        z_new = np.minimum(np.maximum(zh + y / rv, ls), us)
+        y = y + rv * (zh - z_new)
+        zv = z_new
+        if it % 10 == 0 or it == 1:
+            # unscaled residuals
+            xu = D * x
+            Ax = (A @ xu)
+            zu = zv / Ev
+            yu = Ev * y / cscale
+            r_p = np.abs(Ax - zu).max()
+            Px = P @ xu; Aty = A.T @ yu
+            r_d = np.abs(Px + q + Aty).max()
+            e_p = eps_abs + eps_rel * max(np.abs(Ax).max(), np.abs(zu).max())
+            e_d = eps_abs + eps_rel * max(np.abs(Px).max(), np.abs(Aty).max(), np.abs(q).max())
+            if r_p <= e_p and r_d <= e_d:
+                status = 'solved'
+                break
+            if it % adaptive_rho_interval == 0:
+                num = r_p / max(np.abs(Ax).max(), np.abs(zu).max(), 1e-12)
+                den = r_d / max(np.abs(Px).max(), np.abs(Aty).max(), np.abs(q).max(), 1e-12)
+                new_rho = float(np.clip(rho * np.sqrt(num / max(den, 1e-12)), 1e-6, 1e6))
+                if new_rho > 5 * rho or new_rho < rho / 5:
+                    rho = new_rho
+                    lu, rv = factor(rho)
+    w = D * x
+    ydual = Ev * y / cscale
+    return w, (ydual[:ne], ydual[ne:]), dict(iters=it, status=status)

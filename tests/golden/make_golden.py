@@ -1,0 +1,331 @@
+"""Generate golden vectors by IMPORTING THE REFERENCE (build container only).
+
+Usage:  python tests/golden/make_golden.py          (writes tests/golden/*.npz)
+
+The reference python (/root/reference) is imported through the stand-in modules of
+_ref_import.py and driven on small seeded synthetic inputs; only inputs/outputs (data) are
+stored.  The GPU box and the CI never run this script -- they read the committed .npz files.
+"""
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import _ref_import  # noqa: E402
+
+_ref_import.install()
+
+from sofacontrol.mor import pod as rpod  # noqa: E402
+from sofacontrol.tpwl import tpwl as rtpwl  # noqa: E402
+from sofacontrol.lqr import ilqr as rilqr, lqr as rlqr, traj_tracking_lqr as rtt  # noqa: E402
+from sofacontrol.scp import gusto as rgusto  # noqa: E402
+from sofacontrol.scp.models.tpwl import TPWLGuSTO  # noqa: E402
+from sofacontrol.scp import standalone as rsa  # noqa: E402
+from sofacontrol import utils as rutils  # noqa: E402
+from sofacontrol.tpwl.tpwl_utils import Target  # noqa: E402
+from sofacontrol.measurement_models import linearModel  # noqa: E402
+
+from oracle import tpwl as otpwl, locp as olocp  # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = fn(*a, **k)
+    return out, buf.getvalue()
+
+
+def small_rom(n_nodes, r, seed):
+    rng = np.random.default_rng(seed)
+    n_f = 3 * n_nodes
+    U, _ = np.linalg.qr(rng.standard_normal((n_f, r)))
+    q_ref = rng.uniform(-108, 107, n_f)
+    v_ref = 0.01 * rng.standard_normal(n_f)
+    return U, q_ref, v_ref
+
+
+def ref_tpwl(model, U, q_ref, v_ref, Hf, method='nn', discr='zoh', beta=None):
+    data = dict(q=model['q'], v=model['v'], u=model['u'], A_c=model['A_c'], B_c=model['B_c'],
+                d_c=model['d_c'], rom_info=dict(type='POD', U=U, q_ref=q_ref, v_ref=v_ref))
+    params = dict(tpwl_method=method, dist_weights={'q': model['w_q'], 'v': model['w_v']},
+                  beta_weighting=beta)
+    return rtpwl.TPWLATV(data=data, params=params, Hf=Hf, discr_method=discr)
+
+
+def g1_pod(out):
+    U, q_ref, v_ref = small_rom(100, 8, 0)
+    rng = np.random.default_rng(1)
+    rom = rpod.POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    Xq = q_ref + 5 * rng.standard_normal((5, 300))
+    Xv = rng.standard_normal((5, 300))
+    Xx = rutils.qv2x(Xq, Xv)
+    M = rng.standard_normal((300, 300))
+    Mc = sp.coo_matrix(np.where(np.abs(M) > 1.5, M, 0.0))
+    Hm = rng.standard_normal((300, 4))
+    res = dict(U=U, q_ref=q_ref, v_ref=v_ref, Xq=Xq, Xv=Xv, M=M, Hm=Hm,
+               Mc_dense=Mc.toarray(), V=rom.V, x_ref=rom.x_ref,
+               proj_q=np.stack([rom.compute_RO_state(qf=x) for x in Xq]),
+               proj_v=np.stack([rom.compute_RO_state(vf=x) for x in Xv]),
+               proj_x=np.stack([rom.compute_RO_state(xf=x) for x in Xx]),
+               UMU=rom.compute_RO_matrix(M), UM=rom.compute_RO_matrix(M, left=True),
+               MU=rom.compute_RO_matrix(M, right=True), UMcU=rom.compute_RO_matrix(Mc),
+               UH=rom.compute_RO_matrix(Hm, left=True))
+    pr = res['proj_x']
+    res['lift_q'] = np.stack([rom.compute_FO_state(q=p[8:]) for p in pr])
+    res['lift_v'] = np.stack([rom.compute_FO_state(v=p[:8]) for p in pr])
+    res['lift_x'] = np.stack([rom.compute_FO_state(x=p) for p in pr])
+    # compute_POD on low-rank + noise snapshots (n_f x n_s)
+    L = rng.standard_normal((300, 6)) * np.array([50, 20, 8, 3, 1, 0.3])
+    S = L @ rng.standard_normal((6, 40)) + 1e-3 * rng.standard_normal((300, 40))
+    for tol in (1e-2, 1e-4, 1e-7):
+        U_full, Uk, k, Sig = rpod.compute_POD(S, tol)
+        res['pod_k_%g' % tol] = k
+    res['pod_S'] = S
+    res['pod_Sigma'] = Sig
+    res['pod_Ufull_abs'] = np.abs(U_full[:, :8])
+    # snapshots helpers
+    data = dict(q=[q_ref + i * np.ones(300) for i in range(4)], v=[i * np.ones(300) for i in range(4)])
+    data['v+'] = [2.0 * i * np.ones(300) for i in range(4)]
+    for t in 'qva':
+        res['snap_' + t] = rpod.get_snapshots(data, t)
+    # singular values of the shipped Diamond POD model (data fixture) and its truncation
+    shipped = rutils.load_data(os.path.join(_ref_import.REF, 'examples/diamond/pod_model.pkl'))
+    res['shipped_Sigma'] = shipped['Sigma']
+    res['shipped_k'] = shipped['POD_info']['U'].shape[1]
+    res['shipped_tol'] = shipped['config']['pod_tolerance']
+    np.savez_compressed(os.path.join(out, 'g1_pod.npz'), **res)
+
+
+def make_problem(r, m, P, n_nodes, seed, q_scale=1.0):
+    model = otpwl.synthetic_model(r, m, P, seed=seed)
+    model['q'] = model['q'] * q_scale
+    U, q_ref, v_ref = small_rom(n_nodes, r, seed + 1)
+    tip = linearModel(nodes=[n_nodes // 2], num_nodes=n_nodes)
+    Hf = tip.C
+    return model, U, q_ref, v_ref, Hf
+
+
+def g3_tpwl(out):
+    r, m, P = 4, 3, 7
+    model, U, q_ref, v_ref, Hf = make_problem(r, m, P, 20, 10)
+    model['w_v'] = 0.5
+    rng = np.random.default_rng(11)
+    res = {}
+    tp = ref_tpwl(model, U, q_ref, v_ref, Hf)
+    X = np.concatenate((0.3 * rng.standard_normal((12, r)), 3 * rng.standard_normal((12, r))), axis=1)
+    X[3] = np.concatenate((model['v'][2], model['q'][2]))       # exactly on a point
+    res['X'] = X
+    res['nearest'] = np.array([tp.calc_nearest_point(x) for x in X])
+    tpw = ref_tpwl(model, U, q_ref, v_ref, Hf, method='weighting', beta=3.0)
+    res['weights'] = np.stack([tpw.calc_weighting_factors(x) for x in X])
+    Aw, Bw, dw = zip(*[tpw.get_jacobians(x) for x in X])
+    res['Aw'], res['Bw'], res['dw'] = np.stack(Aw), np.stack(Bw), np.stack(dw)
+    res['H'] = np.asarray(tp.H)
+    res['z_ref'] = np.asarray(tp.z_ref)
+    dt = 0.05
+    for meth in ('fe', 'be', 'bil', 'zoh'):
+        t2 = ref_tpwl(model, U, q_ref, v_ref, Hf, discr=meth)
+        quiet(t2.pre_discretize, dt)
+        res['Ad_' + meth] = np.stack(t2.A_d)
+        res['Bd_' + meth] = np.stack(t2.B_d)
+        res['dd_' + meth] = np.stack(t2.d_d)
+    quiet(tp.pre_discretize, dt)
+    u = rng.uniform(0, 800, (15, m))
+    x0 = 0.1 * rng.standard_normal(2 * r)
+    xr, zr = tp.rollout(x0, u, dt)
+    res['roll_u'], res['roll_x0'], res['roll_x'], res['roll_z'] = u, x0, xr, zr
+    gm = TPWLGuSTO(tp)
+    xc, fc = gm.get_characteristic_vals()
+    res['x_char'], res['f_char'] = xc, fc
+    res['dx_char'] = tp.get_characteristic_dx(dt)
+    f, A, B = zip(*[gm.get_continuous_dynamics(x, uu) for x, uu in zip(X, u[:12])])
+    res['fc'] = np.stack(f)
+    res['U'], res['q_ref'], res['v_ref'] = U, q_ref, v_ref
+    res['Hf'] = Hf.toarray()
+    np.savez_compressed(os.path.join(out, 'g3_tpwl.npz'), **res)
+
+
+def g4_riccati(out):
+    r, m, P = 5, 4, 9
+    model, U, q_ref, v_ref, Hf = make_problem(r, m, P, 30, 20)
+    tp = ref_tpwl(model, U, q_ref, v_ref, Hf)
+    dt = 0.05
+    quiet(tp.pre_discretize, dt)
+    rng = np.random.default_rng(21)
+    n = 2 * r
+    res = {}
+    H = np.asarray(tp.H)
+    Qz = np.diag([0, 0, 0, 100., 100., 0])
+    Q = H.T @ Qz @ H + 1e-3 * np.eye(n)
+    R = 1e-3 * np.eye(m)
+    A, B = tp.A_d[2], tp.B_d[2]
+    (L, Pm), _ = quiet(rlqr.solve_riccati, A, B, Q, R)
+    res['sr_L'], res['sr_P'] = L, Pm
+    K, Pd = rlqr.dare(A, B, Q, R)
+    res['dare_K'], res['dare_P'] = K, Pd
+    # TrajTrackingLQR (C1 shape: r=5, horizon 10)
+    tgt = Target()
+    N = 10
+    tgt.t = dt * np.arange(N + 1)
+    tgt.u = rng.uniform(0, 500, (N + 1, m))
+    tgt.x, _ = tp.rollout(0.05 * rng.standard_normal(n), tgt.u[:-1], dt)
+    cost = rutils.QuadraticCost(Q=Q, R=R)
+    tt = rtt.TrajTrackingLQR(dt, tp, cost)
+    Ktt, Ptt = tt.perform_dlqr_recursion(tgt)
+    res['tt_t'], res['tt_u'], res['tt_x'] = tgt.t, tgt.u, tgt.x
+    res['tt_K'], res['tt_P'], res['tt_xbar'], res['tt_ubar'] = Ktt, Ptt, tt.x_bar, tt.u_bar
+    res['Q'], res['R'], res['H'], res['z_ref'] = Q, R, H, np.asarray(tp.z_ref)
+    # iLQR backward pass on a fixed trajectory + full solves
+    cost = rutils.QuadraticCost(Q=Qz, R=R, Qf=10 * Qz)
+    for tag, N in (('c1', 10), ('n30', 30)):
+        il = rilqr.iLQR(dt, tp, cost, N)
+        th = np.linspace(0, 2 * np.pi * N / 100., N + 1)
+        zt = np.zeros((N + 1, 6))
+        zt[:, 3] = -2.0 * np.sin(th)
+        zt[:, 4] = 1.0 * np.sin(2 * th)
+        zt = zt + np.asarray(tp.z_ref)
+        il.set_target(zt)
+        x0 = 0.02 * rng.standard_normal(n)
+        il.rho, il.drho = 0., 0.
+        xp = np.zeros((N + 1, n)); xp[0] = x0
+        uw = rng.uniform(0, 100, (N, m))
+        (x, u, c, Aj, Bj, dj), _ = quiet(il.forward_pass, xp, uw)
+        (K, k, Q_u, Q_uu), _ = quiet(il.dlqr_recursion, x, u, Aj, Bj, dj)
+        res[tag + '_z_target'], res[tag + '_x0'], res[tag + '_uw'] = zt, x0, uw
+        res[tag + '_fp_x'], res[tag + '_fp_u'], res[tag + '_fp_cost'] = x, u, c
+        res[tag + '_K'], res[tag + '_k'], res[tag + '_Qu'], res[tag + '_Quu'] = K, k, Q_u, Q_uu
+        res[tag + '_rho_after'] = il.rho
+        (xs, us, Ks), log = quiet(il.ilqr_computation, x0, uw)
+        res[tag + '_sol_x'], res[tag + '_sol_u'], res[tag + '_sol_K'] = xs, us, Ks
+        res[tag + '_iters'] = log.count('Iteration')
+        (xs0, us0, Ks0), log = quiet(il.ilqr_computation, x0)
+        res[tag + '_sol0_x'], res[tag + '_sol0_u'], res[tag + '_sol0_K'] = xs0, us0, Ks0
+        res[tag + '_iters0'] = log.count('Iteration')
+    res['Qz'], res['Qf'] = Qz, 10 * Qz
+    np.savez_compressed(os.path.join(out, 'g4_riccati.npz'), **res)
+
+
+class InjectedLOCP:
+    """Stand-in for sofacontrol.scp.locp.LOCP (cvxpy is absent): same update/solve/get_solution
+    protocol (locp.py:98,175,192), QP data from oracle.locp.build_qp, solved exactly."""
+    log = []
+
+    def __init__(self, N, H, Qz, R, Qzf=None, U=None, X=None, Xf=None, dU=None, verbose=False,
+                 warm_start=True, x_char=None, **kwargs):
+        self.N, self.H, self.Qz, self.R, self.Qzf = N, H, Qz, R, Qzf
+        cv = lambda p: None if p is None else (np.asarray(p.A), np.asarray(p.b))
+        self.U, self.X, self.Xf, self.dU = cv(U), cv(X), cv(Xf), cv(dU)
+        self.xs = np.ones(H.shape[1]) if x_char is None else 1. / np.abs(x_char)
+
+    def update(self, Ad, Bd, dd, x0, xk, delta, omega, z=None, zf=None, u=None, full=True, **kw):
+        if full:
+            self.args = (Ad, Bd, dd, np.asarray(x0), np.asarray(xk))
+            self.z, self.zf, self.u = z, zf, u
+        self.delta, self.omega = delta, omega
+
+    def solve(self):
+        Ad, Bd, dd, x0, xk = self.args
+        qp = olocp.build_qp(self.N, self.H, self.Qz, self.R, Ad, Bd, dd, x0, xk, self.delta,
+                            self.omega, z=self.z, u_des=self.u, Qzf=self.Qzf, zf=self.zf, U=self.U,
+                            X=self.X, Xf=self.Xf, dU=self.dU, x_scale=self.xs)
+        w, _, _ = olocp.solve_exact(qp)
+        self.qp, self.w = qp, w
+        J = olocp.objective(qp, w)
+        InjectedLOCP.log.append((J, self.delta, self.omega))
+
+        class S:
+            solve_time = 0.0
+        return J, True, S
+
+    def get_solution(self):
+        return olocp.split(self.qp, self.w)
+
+
+def g6_gusto(out):
+    rgusto.LOCP = InjectedLOCP
+    res = {}
+    r, m, P = 4, 3, 7
+    model, U, q_ref, v_ref, Hf = make_problem(r, m, P, 20, 30, q_scale=0.05)
+    tp = ref_tpwl(model, U, q_ref, v_ref, Hf)
+    dt, N = 0.05, 12
+    gm = TPWLGuSTO(tp)
+    quiet(gm.pre_discretize, dt)
+    n = 2 * r
+    H = np.asarray(tp.H)
+    Qz = np.diag([0, 0, 0, 100., 100., 0])
+    R = 1e-5 * np.eye(m)
+    rng = np.random.default_rng(31)
+    x_char, f_char = gm.get_characteristic_vals()
+    # steady-state reachable amplitude of the tip for this model: used to scale the target
+    T = 3.0
+    t = np.linspace(0, T, 300)
+    th = np.linspace(0, 2 * np.pi, 300)
+    zt = np.zeros((300, 6))
+    amp = 0.15
+    zt[:, 3] = -amp * np.sin(th)
+    zt[:, 4] = 0.5 * amp * np.sin(2 * th)
+    Ubox = rutils.HyperRectangle([800.] * m, [0.] * m)
+    Hz = np.zeros((2, 6)); Hz[0, 3] = 1; Hz[1, 4] = 1
+    Hx = Hz @ H
+    Xp = rutils.Polyhedron(A=np.vstack([-Hx, Hx]), b=np.array([0.02, 0.02, 0.04, 0.03]))
+    x0 = np.zeros(n)
+    cases = dict(box=dict(U=Ubox), boxX=dict(U=Ubox, X=Xp), free=dict())
+    for tag, cons in cases.items():
+        InjectedLOCP.log = []
+        node, _ = quiet(rsa.GuSTOSolverNode, gm, N, dt, Qz, R, x0, t=t, z=zt, verbose=0,
+                        warm_start=True, convg_thresh=1e-3, jit=False, **cons)
+        xopt, uopt, zopt, topt = node.get_solution()
+        res[tag + '_xopt'], res[tag + '_uopt'], res[tag + '_zopt'] = xopt, uopt, zopt
+        res[tag + '_trace'] = np.array(InjectedLOCP.log)
+        # one warm-started receding-horizon re-solve, restating the shift of ros.py:109-114
+        t0 = 2 * dt
+        x0b = xopt[2] + 1e-3 * rng.standard_normal(n)
+        zb, zfb, ub = node.get_target(t0)
+        idx0 = np.argwhere(topt >= t0)[0, 0]
+        u_init = uopt[-1, :].reshape(1, -1).repeat(N, axis=0)
+        u_init[0:N - idx0] = uopt[idx0:, :]
+        x_init = xopt[-1, :].reshape(1, -1).repeat(N + 1, axis=0)
+        x_init[0:N + 1 - idx0] = xopt[idx0:, :]
+        InjectedLOCP.log = []
+        node.gusto.max_gusto_iters = 500
+        quiet(node.gusto.solve, x0b, u_init, x_init, z=zb, zf=zfb, u=ub)
+        x2, u2, z2, _ = node.gusto.get_solution()
+        res[tag + '_x0b'], res[tag + '_zb'] = x0b, zb
+        res[tag + '_uinit'], res[tag + '_xinit'] = u_init, x_init
+        res[tag + '_xopt2'], res[tag + '_uopt2'], res[tag + '_zopt2'] = x2, u2, z2
+        res[tag + '_trace2'] = np.array(InjectedLOCP.log)
+    # helper functions on fixed data
+    g = node.gusto
+    xa = xopt + 0.3 * x_char * rng.standard_normal(xopt.shape)
+    ua = uopt + 30.0 * rng.standard_normal(uopt.shape)
+    g.x_k, g.u_k = xopt.copy(), uopt.copy()
+    res['h_x'], res['h_u'], res['h_xk'], res['h_uk'] = xa, ua, xopt, uopt
+    res['h_tr'] = np.array([g.is_in_trust_region(xa, d)[0] for d in (1e-3, 1e-1, 10.)])
+    res['h_conv'] = g.is_converged(xa, ua)[0]
+    res['h_rho'] = g.compute_accuracy(xa, ua, 3.7)
+    g.X = Xp
+    res['h_viol'] = g.state_constraints_violated(10 * xa)[0]
+    res['x_char'], res['f_char'] = x_char, f_char
+    res['t'], res['zt'] = t, zt
+    res['Xp_A'], res['Xp_b'] = Xp.A, Xp.b
+    res['U_A'], res['U_b'] = Ubox.A, Ubox.b
+    res['H'], res['Qz'], res['R'] = H, Qz, R
+    res['get_target_z'], _, _ = node.get_target(0.37)
+    np.savez_compressed(os.path.join(out, 'g6_gusto.npz'), **res)
+
+
+if __name__ == '__main__':
+    g1_pod(HERE)
+    g3_tpwl(HERE)
+    g4_riccati(HERE)
+    g6_gusto(HERE)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,219 @@
+"""CPU: the oracle (numpy restatement) against golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  Tolerances: 1e-12 relative for direct algebra, looser where the
+reference iterates (stated per test)."""
+import numpy as np
+import pytest
+
+from oracle import pod as opod, tpwl as otpwl, lqr as olqr, locp as olocp, gusto as ogusto
+
+
+def close(a, b, rtol=1e-12, atol=1e-12):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * max(1.0, float(np.abs(b).max())))
+
+
+# ---------------------------------------------------------------- G1: POD
+def test_pod_project_lift_reduce(golden):
+    g = golden('g1_pod')
+    U, q_ref, v_ref = g['U'], g['q_ref'], g['v_ref']
+    close(opod.make_V(U), g['V'])
+    close(opod.project(U, q_ref, g['Xq']), g['proj_q'])
+    close(opod.project(U, v_ref, g['Xv']), g['proj_v'])
+    Xx = opod.qv2x(g['Xq'], g['Xv'])
+    close(opod.project_x(U, q_ref, v_ref, Xx), g['proj_x'])
+    pr = g['proj_x']
+    close(opod.lift(U, q_ref, pr[:, 8:]), g['lift_q'])
+    close(opod.lift(U, v_ref, pr[:, :8]), g['lift_v'])
+    close(opod.lift_x(U, q_ref, v_ref, pr), g['lift_x'])
+    close(opod.reduce_matrix(U, g['M']), g['UMU'])
+    close(opod.reduce_matrix(U, g['M'], left=True), g['UM'])
+    close(opod.reduce_matrix(U, g['M'], right=True), g['MU'])
+    close(opod.reduce_matrix(U, g['Mc_dense']), g['UMcU'])
+    close(opod.reduce_matrix(U, g['Hm'], left=True), g['UH'])
+
+
+def test_pod_svd_truncation_and_gramian_route(golden):
+    g = golden('g1_pod')
+    S = g['pod_S']
+    for tol in (1e-2, 1e-4, 1e-7):
+        U_full, Uk, k, Sig = opod.compute_pod(S, tol)
+        assert k == int(g['pod_k_%g' % tol])
+        # method of snapshots (the GPU route) gives the same spectrum / modes up to sign
+        U2, k2, Sig2 = opod.pod_from_gramian(S.T.copy(), tol)
+        assert k2 == k
+        # sigma_i from eig(G) carries a relative error ~ eps*(sigma_0/sigma_i)^2
+        close(Sig2[:6], g['pod_Sigma'][:6], rtol=1e-9)
+        close(Sig2[:8], g['pod_Sigma'][:8], rtol=1e-5)
+        close(np.abs(U2), np.abs(Uk), rtol=1e-6, atol=1e-8)
+    close(Sig, g['pod_Sigma'])
+    close(np.abs(U_full[:, :8]), g['pod_Ufull_abs'], rtol=1e-8, atol=1e-10)
+    # shipped Diamond model: tolerance 5e-5 keeps 36 modes (examples/diamond/pod_model.pkl)
+    assert opod.energy_truncation(g['shipped_Sigma'], float(g['shipped_tol'])) == int(g['shipped_k']) == 36
+
+
+def test_pod_snapshot_types(golden):
+    g = golden('g1_pod')
+    q_ref = g['q_ref']
+    data = dict(q=[q_ref + i * np.ones(300) for i in range(4)], v=[i * np.ones(300) for i in range(4)])
+    data['v+'] = [2.0 * i * np.ones(300) for i in range(4)]
+    for t in 'qva':
+        close(opod.get_snapshots(data, t), g['snap_' + t])
+
+
+# ---------------------------------------------------------------- G3: TPWL
+def _g3_model():
+    m = otpwl.synthetic_model(4, 3, 7, seed=10)
+    m['w_v'] = 0.5
+    return m
+
+
+def test_tpwl_nearest_weights_jacobians(golden):
+    g = golden('g3_tpwl')
+    model = _g3_model()
+    X = g['X']
+    assert np.array_equal(otpwl.nearest_points(model, X), g['nearest'])
+    assert otpwl.nearest_point(model, X[3]) == 2
+    W = np.stack([otpwl.weighting_factors(model, x, 3.0) for x in X])
+    close(W, g['weights'])
+    close(np.einsum('bi,ijk->bjk', W, model['A_c']), g['Aw'])
+    close(np.einsum('bi,ijk->bjk', W, model['B_c']), g['Bw'])
+    close(np.einsum('bi,ij->bj', W, model['d_c']), g['dw'])
+
+
+@pytest.mark.parametrize('meth', ['fe', 'be', 'bil', 'zoh'])
+def test_tpwl_discretize(golden, meth):
+    g = golden('g3_tpwl')
+    Ad, Bd, dd = otpwl.pre_discretize(_g3_model(), 0.05, meth)
+    close(Ad, g['Ad_' + meth], rtol=1e-10)
+    close(Bd, g['Bd_' + meth], rtol=1e-10)
+    close(dd, g['dd_' + meth], rtol=1e-10)
+
+
+def test_tpwl_rollout_and_characteristics(golden):
+    g = golden('g3_tpwl')
+    model = _g3_model()
+    Ad, Bd, dd = g['Ad_zoh'], g['Bd_zoh'], g['dd_zoh']
+    x = otpwl.rollout(model, Ad, Bd, dd, g['roll_x0'], g['roll_u'])
+    close(x, g['roll_x'], rtol=1e-11)
+    close((g['H'] @ x.T).T + g['z_ref'], g['roll_z'], rtol=1e-11)
+    xc, fc = otpwl.characteristic_vals(model)
+    close(xc, g['x_char'])
+    close(fc, g['f_char'])
+    close(otpwl.characteristic_dx(model, Ad, Bd, dd), g['dx_char'])
+    f = np.stack([otpwl.continuous_dynamics(model, x_, u_)[0] for x_, u_ in zip(g['X'], g['roll_u'][:12])])
+    close(f, g['fc'])
+    # H = Hf V (tpwl.py:86-89)
+    close(g['Hf'] @ opod.make_V(g['U']), g['H'])
+    close(g['Hf'] @ opod.qv2x(g['q_ref'], g['v_ref']), g['z_ref'])
+
+
+# ---------------------------------------------------------------- G4: Riccati / iLQR
+def _g4_setup(golden):
+    g = golden('g4_riccati')
+    model = otpwl.synthetic_model(5, 4, 9, seed=20)
+    Ad, Bd, dd = otpwl.pre_discretize(model, 0.05, 'zoh')
+    return g, model, Ad, Bd, dd
+
+
+def test_dare_and_fixed_point_riccati(golden):
+    g, model, Ad, Bd, dd = _g4_setup(golden)
+    L, P, _ = olqr.solve_riccati(Ad[2], Bd[2], g['Q'], g['R'])
+    close(L, g['sr_L'], rtol=1e-9)
+    close(P, g['sr_P'], rtol=1e-9)
+    K, P = olqr.dare(Ad[2], Bd[2], g['Q'], g['R'])
+    close(K, g['dare_K'], rtol=1e-9)
+    close(P, g['dare_P'], rtol=1e-9)
+
+
+def test_tvlqr_recursion(golden):
+    g, model, Ad, Bd, dd = _g4_setup(golden)
+    # reference interpolates the nominal at t_i = i*dt: these are the target samples themselves
+    xbar = g['tt_xbar']
+    close(xbar, g['tt_x'][:-1], rtol=1e-12)
+    idx = otpwl.nearest_points(model, xbar)
+    K, P = olqr.tvlqr(Ad[idx], Bd[idx], g['Q'], g['R'])
+    close(K, g['tt_K'], rtol=1e-9)
+    close(P, g['tt_P'], rtol=1e-9)
+
+
+@pytest.mark.parametrize('tag,N', [('c1', 10), ('n30', 30)])
+def test_ilqr_backward_and_full_solve(golden, tag, N):
+    g, model, Ad, Bd, dd = _g4_setup(golden)
+    il = olqr.ILQR(model, Ad, Bd, dd, g['H'], g['z_ref'], g['Qz'], g['R'], g['Qf'], N)
+    il.z_target = g[tag + '_z_target']
+    il.rho, il.drho = 0., 0.
+    xp = np.zeros((N + 1, 10)); xp[0] = g[tag + '_x0']
+    x, u, c, A, B, d = il.forward_pass(xp, g[tag + '_uw'])
+    close(x, g[tag + '_fp_x'], rtol=1e-11)
+    close(c, g[tag + '_fp_cost'], rtol=1e-11)
+    K, k, Qu, Quu = il.dlqr_recursion(x, u, A, B, d)
+    close(K, g[tag + '_K'], rtol=1e-8)
+    close(k, g[tag + '_k'], rtol=1e-8)
+    close(Qu, g[tag + '_Qu'], rtol=1e-8)
+    close(Quu, g[tag + '_Quu'], rtol=1e-8)
+    assert il.rho == float(g[tag + '_rho_after'])
+    xs, us, Ks = il.solve(g[tag + '_x0'], g[tag + '_z_target'], g[tag + '_uw'])
+    assert len(il.trace) - 1 == int(g[tag + '_iters'])
+    close(xs, g[tag + '_sol_x'], rtol=1e-7)
+    close(us, g[tag + '_sol_u'], rtol=1e-7)
+    close(Ks, g[tag + '_sol_K'], rtol=1e-7)
+    xs, us, Ks = il.solve(g[tag + '_x0'], g[tag + '_z_target'])
+    assert len(il.trace) - 1 == int(g[tag + '_iters0'])
+    close(xs, g[tag + '_sol0_x'], rtol=1e-7)
+    close(us, g[tag + '_sol0_u'], rtol=1e-7)
+
+
+# ---------------------------------------------------------------- G6: GuSTO
+def _g6_setup(golden):
+    g = golden('g6_gusto')
+    model = otpwl.synthetic_model(4, 3, 7, seed=30)
+    model['q'] = model['q'] * 0.05
+    Ad, Bd, dd = otpwl.pre_discretize(model, 0.05, 'zoh')
+    return g, model, Ad, Bd, dd
+
+
+def test_gusto_helpers(golden):
+    g, model, Ad, Bd, dd = _g6_setup(golden)
+    xs, fs = 1. / np.abs(g['x_char']), 1. / np.abs(g['f_char'])
+    x, u, xk, uk = g['h_x'], g['h_u'], g['h_xk'], g['h_uk']
+    tr = [ogusto.is_in_trust_region(x, xk, xs, d, 0.01)[0] for d in (1e-3, 1e-1, 10.)]
+    close(tr, g['h_tr'])
+    close(ogusto.is_converged(x, xk, xs, 12, 1e-3)[0], g['h_conv'])
+    close(ogusto.compute_accuracy(model, x, u, xk, uk, 3.7, 0.05, fs), g['h_rho'], rtol=1e-10)
+    close(ogusto.state_violation((g['Xp_A'], g['Xp_b']), 10 * x), g['h_viol'])
+    xc, fc = otpwl.characteristic_vals(model)
+    close(xc, g['x_char']); close(fc, g['f_char'])
+
+
+@pytest.mark.parametrize('tag', ['box', 'boxX', 'free'])
+def test_gusto_outer_loop_matches_reference_loop(golden, tag):
+    """The reference GuSTO class (imported, with this oracle's exact QP injected for cvxpy's LOCP)
+    against the restated loop: same iterates, same (J, delta, omega) sequence."""
+    g, model, Ad, Bd, dd = _g6_setup(golden)
+    N, dt = 12, 0.05
+    cons = {}
+    if tag in ('box', 'boxX'):
+        cons['U'] = (g['U_A'], g['U_b'])
+    if tag == 'boxX':
+        cons['X'] = (g['Xp_A'], g['Xp_b'])
+    from scipy.interpolate import interp1d
+    zi = interp1d(g['t'], g['zt'], axis=0, bounds_error=False, fill_value=(g['zt'][0], g['zt'][-1]))
+    x0 = np.zeros(8)
+    u_init = np.zeros((N, 3))
+    x_init = otpwl.rollout(model, Ad, Bd, dd, x0, u_init)
+    z = zi(dt * np.arange(N + 1))
+    xo, uo, zo, tr = ogusto.solve(model, Ad, Bd, dd, g['H'], N, dt, g['Qz'], g['R'], x0, u_init, x_init,
+                                  z=z, x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, **cons)
+    ref_tr = g[tag + '_trace']
+    assert len(tr) == ref_tr.shape[0]
+    close(np.array([t[:3] for t in tr]), ref_tr, rtol=1e-6)
+    close(xo, g[tag + '_xopt'], rtol=1e-6, atol=1e-8)
+    close(uo, g[tag + '_uopt'], rtol=1e-6, atol=1e-8)
+    close(zo, g[tag + '_zopt'], rtol=1e-6, atol=1e-8)
+    # warm-started re-solve (shifted previous solution, scp/ros.py:109-114)
+    x2, u2, z2, tr2 = ogusto.solve(model, Ad, Bd, dd, g['H'], N, dt, g['Qz'], g['R'], g[tag + '_x0b'],
+                                   g[tag + '_uinit'], g[tag + '_xinit'], z=g[tag + '_zb'],
+                                   x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, **cons)
+    assert len(tr2) == g[tag + '_trace2'].shape[0]
+    close(x2, g[tag + '_xopt2'], rtol=1e-5, atol=1e-7)
+    close(u2, g[tag + '_uopt2'], rtol=1e-5, atol=1e-7)
+    close(zi(0.37 + dt * np.arange(N + 1)), g['get_target_z'])
