@@ -1,0 +1,220 @@
+/*
+ * sofacontrol_hip.h -- C ABI of libsofacontrol_hip.so (MI355X / gfx950).
+ *
+ * The reference (StanfordASL/soft-robot-control) is pure Python and has no FFI of its own: the seam
+ * is its duck-typed Python protocol.  Each entry point below names the reference
+ * method it serves (file:line relative to the reference root); the Python host package
+ * (soft-robot-control_amd/sofacontrol_amd) binds these with ctypes and re-exposes the reference's
+ * class/method surface.  INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (SRH_E*); never throws; srh_last_error() gives
+ *    the message of the last failure on the calling thread;
+ *  - all arithmetic is IEEE float64 (the reference is numpy float64 throughout);
+ *  - matrices are dense row-major; "ld" arguments are leading dimensions in elements;
+ *  - `*_dev` entry points take DEVICE pointers (HBM) and a hipStream_t passed as void* (NULL = the
+ *    null stream) and are asynchronous on that stream; entry points without the suffix take HOST
+ *    pointers, stage through HBM and are synchronous on return;
+ *  - handles are owned by the caller and are not thread-safe (one host thread per handle, as the
+ *    reference's single SOFA/solver thread).
+ */
+#ifndef SOFACONTROL_HIP_H
+#define SOFACONTROL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRH_OK        0
+#define SRH_EINVAL   -1   /* bad argument (the reference raises RuntimeError / AssertionError)        */
+#define SRH_EHIP     -2   /* HIP runtime error (no device, launch failure, ...)                      */
+#define SRH_ENOMEM   -3
+#define SRH_ENUMERIC -4   /* numerical failure (non-PD matrix, QP not solved: reference returns flags) */
+
+const char *srh_last_error(void);
+int srh_version(void);
+
+/* ---- device plumbing (lets a host without torch stage buffers; not part of the reference) ---- */
+int srh_device_count(int *count);
+int srh_set_device(int device);
+int srh_malloc(void **dptr, size_t bytes);
+int srh_free(void *dptr);
+int srh_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int srh_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int srh_memset(void *dptr, int value, size_t bytes);
+int srh_sync(void);
+/* average duration in milliseconds of `iters` back-to-back launches are measured by the caller with
+ * these (hipEvent on the given stream): */
+int srh_event_create(void **ev);
+int srh_event_destroy(void *ev);
+int srh_event_record(void *ev, void *stream);
+int srh_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);   /* synchronises ev_stop */
+
+/* =====================================================================================================
+ * POD reduced-order map.          reference: sofacontrol/mor/pod.py
+ * ===================================================================================================== */
+typedef struct srom srom_t;
+
+/* POD.__init__ (pod.py:14-20): U (n_f x r) row-major, q_ref / v_ref (n_f,) or NULL (= zeros).
+ * Copies the basis to HBM and packs it into MFMA fragment order. */
+int srom_create(srom_t **h, const double *U, int64_t n_f, int r, const double *q_ref, const double *v_ref);
+int srom_destroy(srom_t *h);
+int srom_dims(const srom_t *h, int64_t *n_f, int *r);
+
+#define SROM_Q 0   /* U^T (qf - q_ref)      pod.py:46-47 */
+#define SROM_V 1   /* U^T (vf - v_ref)      pod.py:48-49 */
+#define SROM_X 2   /* V^T (xf - x_ref), x = [v; q], V = kron(I2, U)   pod.py:51-52 */
+#define SROM_RAW 3 /* U^T m (no reference subtracted): rows of a matrix, pod.py:68-72 */
+
+/* POD.compute_RO_state (pod.py:39-54), batched: X is (B x n_f) [SROM_Q/V/RAW] or (B x 2 n_f) [SROM_X],
+ * one snapshot per row (the layout of np.asarray(data['q']), pod.py:149); out is (B x r) or (B x 2r). */
+int srom_project(srom_t *h, int which, const double *X, int64_t B, double *out);
+int srom_project_dev(srom_t *h, int which, const double *X_dev, int64_t B, int64_t ldx,
+                     double *out_dev, int64_t ldo, void *stream);
+
+/* POD.compute_FO_state (pod.py:22-37), batched: Xr (B x r | B x 2r) -> out (B x n_f | B x 2 n_f). */
+int srom_lift(srom_t *h, int which, const double *Xr, int64_t B, double *out);
+int srom_lift_dev(srom_t *h, int which, const double *Xr_dev, int64_t B, int64_t ldr,
+                  double *out_dev, int64_t ldo, void *stream);
+
+/* POD.compute_RO_matrix (pod.py:56-72) for a dense row-major M (n_f x ncols):
+ *   left && right (or neither): U^T M U (r x r), needs ncols == n_f
+ *   left only : U^T M (r x ncols)           right only: M U (n_f x r), needs ncols == n_f */
+int srom_reduce_matrix(srom_t *h, const double *M, int64_t ncols, int left, int right, double *out);
+int srom_reduce_matrix_dev(srom_t *h, const double *M_dev, int64_t ncols, int left, int right,
+                           double *out_dev, void *stream);
+
+/* Snapshot Gramian G = S S^T, S (n_s x n_f) row-major, G (n_s x n_s): the method-of-snapshots route
+ * to compute_POD (pod.py:181-200: sigma_i = sqrt(eig_i(G)), U = S^T W Sigma^-1).  With S sharded by
+ * columns over ranks the partial Gramians are summed by an RCCL all-reduce in the host layer. */
+int srom_gramian_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, double *G_dev,
+                     void *stream);
+int srom_gramian(const double *S, int64_t n_s, int64_t n_f, double *G);
+/* U_k = S^T W_k  (n_f x k) for eigenvector columns W_k (n_s x k, already scaled by 1/sigma). */
+int srom_modes_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, const double *W_dev,
+                   int k, double *U_dev, void *stream);
+
+/* =====================================================================================================
+ * TPWL piecewise-affine model.    reference: sofacontrol/tpwl/tpwl.py, sofacontrol/scp/models/tpwl.py
+ * ===================================================================================================== */
+typedef struct stpwl stpwl_t;
+
+/* Tables of the P linearisation points (tpwl.py:20-41; keys 'q','v','u','A_c','B_c','d_c' of the
+ * tpwl_dict), reduced state x = [v; q], n_x = 2 r.  A_d/B_d/d_d are the pre-discretised tables
+ * (TPWLATV.pre_discretize, tpwl.py:299-322) or NULL.  w_q, w_v = dist_weights (tpwl.py:165-166). */
+int stpwl_create(stpwl_t **h, int P, int r, int n_u,
+                 const double *q, const double *v, const double *u,
+                 const double *A_c, const double *B_c, const double *d_c,
+                 const double *A_d, const double *B_d, const double *d_d,
+                 double w_q, double w_v);
+int stpwl_destroy(stpwl_t *h);
+/* install / replace the discrete tables (pre_discretize with another dt) */
+int stpwl_set_discrete(stpwl_t *h, const double *A_d, const double *B_d, const double *d_d);
+/* output model z = H x + z_ref (TPWL.set_output_model, tpwl.py:86-89); H (n_z x n_x) */
+int stpwl_set_output(stpwl_t *h, const double *H, const double *z_ref, int n_z);
+
+/* TPWL.calc_nearest_point (tpwl.py:160-168) for B states X (B x n_x): idx (B,) int32 */
+int stpwl_nearest(stpwl_t *h, const double *X, int64_t B, int32_t *idx);
+int stpwl_nearest_dev(stpwl_t *h, const double *X_dev, int64_t B, int32_t *idx_dev, void *stream);
+/* TPWLATV.get_jacobians, nn branch (tpwl.py:251-265): gathers (A,B,d)[idx] of the discrete
+ * (discrete=1) or continuous tables: A (B x n_x x n_x), Bm (B x n_x x n_u), d (B x n_x) */
+int stpwl_linearize(stpwl_t *h, const double *X, int64_t B, int discrete, double *A, double *Bm,
+                    double *d, int32_t *idx);
+/* TPWL.rollout (tpwl.py:193-216) for `batch` independent rollouts:
+ * x0 (batch x n_x), U (batch x N x n_u) -> X (batch x (N+1) x n_x), Z (batch x (N+1) x n_z) or NULL */
+int stpwl_rollout(stpwl_t *h, const double *x0, const double *U, int N, int64_t batch, double *X,
+                  double *Z);
+/* TPWLGuSTO.get_characteristic_vals (scp/models/tpwl.py:66-84): x_char, f_char (n_x,) */
+int stpwl_characteristic(stpwl_t *h, double *x_char, double *f_char);
+
+/* =====================================================================================================
+ * Riccati recursions.             reference: sofacontrol/lqr/lqr.py, sofacontrol/lqr/traj_tracking_lqr.py
+ * ===================================================================================================== */
+/* TrajTrackingLQR.perform_dlqr_recursion (traj_tracking_lqr.py:18-48) for per-step (A_i, B_i),
+ * i = 0..n-1 in forward time order, terminal P = Q: K (n x n_u x n_x), P (n+1 x n_x x n_x) or NULL. */
+int sric_tvlqr(const double *A, const double *B, int n_steps, int n_x, int n_u, const double *Q,
+               const double *R, double *K, double *P);
+/* the same with the linearisation taken from a TPWL handle at the nominal states xbar (n x n_x) */
+int sric_tvlqr_tpwl(stpwl_t *h, const double *xbar, int n_steps, const double *Q, const double *R,
+                    double *K, double *P);
+/* solve_riccati (lqr.py:6-21): fixed point until ||L - L_old||_F <= tol (reference: 1e-4);
+ * `batch` independent (A,B) pairs share Q, R.  L (batch x n_u x n_x), P (batch x n_x x n_x). */
+int sric_dare_fixed_point(const double *A, const double *B, int64_t batch, int n_x, int n_u,
+                          const double *Q, const double *R, double tol, int max_iter, double *L,
+                          double *P, int32_t *iters);
+
+/* =====================================================================================================
+ * iLQR.                           reference: sofacontrol/lqr/ilqr.py, sofacontrol/lqr/config.py
+ * ===================================================================================================== */
+typedef struct silqr_params {
+    int    max_iter;          /* config.py:3   50  */
+    double epsilon;           /* config.py:4   0.1 */
+    double alpha0, alpha_scaling, improv_lb, improv_ub, alpha_min;   /* config.py:13-17 */
+    int    counter_limit;     /* config.py:19  5   */
+    double rho0, drho0, rho_scaling, rho_increase_fp, rho_max, rho_min;  /* config.py:25-30 */
+} silqr_params;
+void silqr_default_params(silqr_params *p);
+
+/* iLQR.ilqr_computation (ilqr.py:27-107) for `batch` independent problems on one TPWL model:
+ *   x0 (batch x n_x), z_target (batch x (N+1) x n_z, absolute: includes z_ref), u_warm (batch x N x n_u)
+ *   or NULL, u_last (batch x n_u) or NULL; Q, Qf (n_z x n_z), R (n_u x n_u).
+ * Outputs x (batch x (N+1) x n_x), u (batch x N x n_u), K (batch x N x n_u x n_x), cost (batch),
+ * iters (batch). */
+int silqr_solve(stpwl_t *h, int N, int64_t batch, const double *x0, const double *z_target,
+                const double *u_warm, const double *u_last, const double *Q, const double *R,
+                const double *Qf, const silqr_params *p, double *x, double *u, double *K,
+                double *cost, int32_t *iters);
+
+/* =====================================================================================================
+ * LOCP (the horizon QP) and GuSTO. reference: sofacontrol/scp/locp.py, sofacontrol/scp/gusto.py
+ * ===================================================================================================== */
+typedef struct slocp_problem {
+    int N, n_x, n_u, n_z;
+    const double *H;        /* (n_z x n_x)                          locp.py:29          */
+    const double *Qz, *R;   /* (n_z x n_z), (n_u x n_u)             locp.py:30-31       */
+    const double *Qzf;      /* (n_z x n_z) or NULL                  locp.py:32, 251-252 */
+    const double *x_scale;  /* (n_x,) = 1/|x_char| or NULL (ones)   locp.py:47-51       */
+    int nU;  const double *UA, *Ub;    /* U.A (nU x n_u), U.b       locp.py:300-303     */
+    int nX;  const double *XA, *Xb;    /* X.A (nX x n_x), X.b       locp.py:330-333     */
+    int nXf; const double *XfA, *Xfb;  /* terminal set              locp.py:336-337     */
+    int ndU; const double *dUA, *dUb;  /* dU.A (ndU x n_u), dU.b    locp.py:305-308     */
+    int tr_active;                     /* is_tr_active              locp.py:57          */
+} slocp_problem;
+
+/* LOCP.update + solve + get_solution (locp.py:98-203) for `batch` independent QPs of one shape:
+ *   Ad (batch x N x n_x x n_x), Bd (batch x N x n_x x n_u), dd (batch x N x n_x), x0 (batch x n_x),
+ *   xk (batch x (N+1) x n_x) trust-region centre, delta/omega (batch), z (batch x (N+1) x n_z) or NULL,
+ *   zf (batch x n_z) or NULL, u_des (batch x N x n_u) or NULL.
+ * Outputs x (batch x (N+1) x n_x), u (batch x N x n_u), s (batch x (N+1)), J (batch; objective value
+ * without the 1/2, as cvxpy reports), status (batch; 0 = optimal, else the reference's `success=False`). */
+int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, const double *Bd,
+                const double *dd, const double *x0, const double *xk, const double *delta,
+                const double *omega, const double *z, const double *zf, const double *u_des,
+                double *x, double *u, double *s, double *J, int32_t *status, int32_t *iters);
+
+typedef struct sgusto_params {
+    double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh; /* gusto.py:12-22 */
+    int    max_gusto_iters;
+} sgusto_params;
+void sgusto_default_params(sgusto_params *p);
+
+/* GuSTO.solve (gusto.py:283-487) on a pre-discretised nn-TPWL model, `batch` independent rollouts:
+ *   x0 (batch x n_x), u_init (batch x N x n_u), x_init (batch x (N+1) x n_x), z (batch x (N+1) x n_z)
+ *   or NULL, zf, u_des as slocp_solve; x_char / f_char (n_x,) or NULL (ones); dt = horizon step.
+ * Outputs xopt (batch x (N+1) x n_x), uopt (batch x N x n_u), zopt (batch x (N+1) x n_z) = H xopt
+ * (gusto.py:486), iters (batch) = number of SCP iterations (LOCP solves) performed,
+ * status (batch; 0 ok, 1 = a QP could not be solved (gusto.py:357-365), 2 = omega > omega_max,
+ * 3 = max iterations), trace (batch x max_trace x 4: J, delta, omega, rho_k per iteration) or NULL. */
+int sgusto_solve(stpwl_t *h, const slocp_problem *prob, const sgusto_params *par, double dt,
+                 int64_t batch, const double *x0, const double *u_init, const double *x_init,
+                 const double *z, const double *zf, const double *u_des, const double *x_char,
+                 const double *f_char, double *xopt, double *uopt, double *zopt, int32_t *iters,
+                 int32_t *status, double *trace, int max_trace);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFACONTROL_HIP_H */

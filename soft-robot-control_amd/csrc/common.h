@@ -1,0 +1,66 @@
+// Shared helpers for libsofacontrol_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sofacontrol_hip.h"
+
+namespace srh {
+
+void set_error(const char *fmt, ...);
+
+#define SRH_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            srh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                           __LINE__);                                                         \
+            return SRH_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define SRH_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            srh::set_error(__VA_ARGS__);      \
+            return SRH_EINVAL;                \
+        }                                     \
+    } while (0)
+
+// RAII device buffer used by the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (n == 0) return SRH_OK;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); return SRH_ENOMEM; }
+        return SRH_OK;
+    }
+    int upload(const void *src, size_t n) {
+        int rc = alloc(n);
+        if (rc) return rc;
+        if (n == 0) return SRH_OK;
+        hipError_t e = hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e)); return SRH_EHIP; }
+        return SRH_OK;
+    }
+    int download(void *dst, size_t n) const {
+        if (n == 0) return SRH_OK;
+        hipError_t e = hipMemcpy(dst, p, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); return SRH_EHIP; }
+        return SRH_OK;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace srh

@@ -1,0 +1,632 @@
+// POD projection / lift / U^T M U on gfx950 (f64 MFMA 16x16x4, HBM-streaming).
+//
+// Reference arithmetic: sofacontrol/mor/pod.py:22-72 (numpy float64).  The snapshot matrix X is
+// (B x n_f) row-major; the projection out = (X - 1 ref^T) U is a tall-skinny GEMM whose cost is the
+// single read of X from HBM: 8*B*n_f bytes against 2*B*n_f*r flops (7.5 flop/B at r = 30), i.e.
+// HBM-bound as long as the f64 matrix pipe stays >~65 % busy.  Layout decisions:
+//   * X is consumed straight from HBM into MFMA A-operands: lane (row = l&15, kgrp = l>>4) loads 16
+//     consecutive doubles (128 B) of its row per 64-column chunk, so each row contributes 512 B
+//     contiguous per chunk; the k-slot -> column assignment (col = 64c + 16*kgrp + t for step t) is a
+//     permutation of the dot product and needs no shuffle;
+//   * U is pre-packed ONCE (srom_create) into the matching B-operand fragment order
+//     Ufrag[chunk][t][ntile][lane], zero padded, so a fragment is one conflict-free 512 B LDS row;
+//     chunks are staged through LDS and shared by the 4 waves of a workgroup (128 rows);
+//   * the reference subtraction (x - x_ref) is done on the A operand before the MFMA (same op order as
+//     numpy: subtract, then multiply-accumulate), x_ref chunk staged next to the U chunk;
+//   * small B (closed-loop single vector, pod.py:51-52 via tpwl/controllers.py:96) uses split-K over
+//     workgroups with a fixed-order second-stage reduction (deterministic, no atomics).
+#include "common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int KC = 64;        // columns of X per chunk
+constexpr int ROWS_WG = 128;  // rows of X per workgroup (4 waves x 2 M-tiles x 16)
+
+struct ProjArgs {
+    const double *X;      // (B x ldx)
+    int64_t ldx;
+    int64_t x_blk_off;    // column offset between the v and q blocks (SROM_X), else 0
+    const double *ref0, *ref1;  // reference per block (may be null)
+    const double *ufrag;  // packed basis
+    double *out;          // (B x ldo)
+    int64_t ldo;
+    int64_t o_blk_off;
+    double *partial;      // split-K workspace [ksplit][nblk][B][NT*16] or null
+    int64_t B;
+    int64_t n_f;
+    int r;
+    int nchunks, chunks_per_split;
+};
+
+__global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, int NT, int nchunks,
+                              double *__restrict__ ufrag) {
+    // Ufrag[c][t][nt][lane] = U[64c + 16*(lane>>4) + t][16 nt + (lane&15)]
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)nchunks * 16 * NT * 64;
+    if (idx >= total) return;
+    int lane = idx & 63;
+    int64_t rest = idx >> 6;
+    int nt = rest % NT;
+    rest /= NT;
+    int t = rest & 15;
+    int64_t c = rest >> 4;
+    int64_t i = c * KC + 16 * (lane >> 4) + t;
+    int j = 16 * nt + (lane & 15);
+    ufrag[idx] = (i < n_f && j < r) ? U[i * r + j] : 0.0;
+}
+
+__global__ void pack_ulift_kernel(const double *__restrict__ U, int64_t n_f, int r, int KS,
+                                  int64_t ntiles, double *__restrict__ ulift) {
+    // Ulift[itile][t][lane] = U[16 itile + (lane&15)][4 t + (lane>>4)]
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = ntiles * KS * 64;
+    if (idx >= total) return;
+    int lane = idx & 63;
+    int64_t rest = idx >> 6;
+    int t = rest % KS;
+    int64_t it = rest / KS;
+    int64_t i = 16 * it + (lane & 15);
+    int j = 4 * t + (lane >> 4);
+    ulift[idx] = (i < n_f && j < r) ? U[i * r + j] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------ projection
+template <int NT, bool HAS_REF, bool VEC2>
+__global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int UCH = 16 * NT * 64;         // doubles of U fragments per chunk
+    constexpr int BUF = UCH + KC;             // + reference chunk
+    double *lds = reinterpret_cast<double *>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.z;
+    const double *X = a.X + (int64_t)blk * a.x_blk_off;
+    const double *ref = blk ? a.ref1 : a.ref0;
+    const int c0 = blockIdx.y * a.chunks_per_split;
+    const int c1 = min(c0 + a.chunks_per_split, a.nchunks);
+    const int64_t rowbase = (int64_t)blockIdx.x * ROWS_WG + wave * 32;
+    const int lrow = lane & 15, kgrp = lane >> 4;
+
+    d4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const double *xrow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int64_t row = rowbase + mt * 16 + lrow;
+        if (row >= a.B) row = a.B - 1;  // clamp: result rows beyond B are never stored
+        xrow[mt] = X + row * a.ldx;
+    }
+
+    double xr[2][16];
+    auto load_x = [&](int c, double (&dst)[2][16]) {
+        const int64_t col0 = (int64_t)c * KC + 16 * kgrp;
+        if (col0 + 16 <= a.n_f) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const double *p = xrow[mt] + col0;
+                if (VEC2) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        d2 v = *reinterpret_cast<const d2 *>(p + 2 * q);
+                        dst[mt][2 * q] = v.x;
+                        dst[mt][2 * q + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) dst[mt][q] = p[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dst[mt][q] = (col0 + q < a.n_f) ? xrow[mt][col0 + q] : 0.0;
+        }
+    };
+    // stage chunk c of the packed basis (+ reference) into LDS buffer b
+    auto stage = [&](int c, int b) {
+        const d2 *src = reinterpret_cast<const d2 *>(a.ufrag + (int64_t)c * UCH);
+        d2 *dst = reinterpret_cast<d2 *>(lds + b * BUF);
+#pragma unroll
+        for (int q = 0; q < UCH / 2 / 256; ++q) dst[q * 256 + tid] = src[q * 256 + tid];
+        if (HAS_REF && tid < KC) {
+            int64_t i = (int64_t)c * KC + tid;
+            lds[b * BUF + UCH + tid] = (i < a.n_f) ? ref[i] : 0.0;
+        }
+    };
+
+    if (c0 < c1) {
+        stage(c0, 0);
+        load_x(c0, xr);
+    }
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        const int b = (c - c0) & 1;
+        double xn[2][16];
+        const bool more = (c + 1 < c1);
+        if (more) {
+            load_x(c + 1, xn);
+            stage(c + 1, b ^ 1);
+        }
+        const double *ub = lds + b * BUF;
+        if (HAS_REF) {
+            const double *rb = ub + UCH + 16 * kgrp;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                double rv = rb[q];
+                xr[0][q] -= rv;
+                xr[1][q] -= rv;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double bv = ub[(t * NT + nt) * 64 + lane];
+                acc[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[0][t], bv, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[1][t], bv, acc[1][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) xr[mt][q] = xn[mt][q];
+        }
+    }
+
+    // D layout of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg
+    const int col = lane & 15;
+    if (a.partial == nullptr) {
+        double *out = a.out + (int64_t)blk * a.o_blk_off;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                int64_t row = rowbase + mt * 16 + kgrp + 4 * reg;
+                if (row < a.B) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        int j = 16 * nt + col;
+                        if (j < a.r) out[row * a.ldo + j] = acc[mt][nt][reg];
+                    }
+                }
+            }
+    } else {
+        double *part = a.partial + (((int64_t)blockIdx.y * gridDim.z + blk) * a.B) * (NT * 16);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                int64_t row = rowbase + mt * 16 + kgrp + 4 * reg;
+                if (row < a.B) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) part[row * (NT * 16) + 16 * nt + col] = acc[mt][nt][reg];
+                }
+            }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const double *__restrict__ partial, int ksplit, int nblk, int64_t B,
+                                     int ldp, int r, double *__restrict__ out, int64_t ldo,
+                                     int64_t o_blk_off) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)nblk * B * r;
+    if (idx >= total) return;
+    int j = idx % r;
+    int64_t row = (idx / r) % B;
+    int blk = idx / ((int64_t)r * B);
+    double s = 0.0;
+    for (int k = 0; k < ksplit; ++k) s += partial[(((int64_t)k * nblk + blk) * B + row) * ldp + j];
+    out[row * ldo + (int64_t)blk * o_blk_off + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------ lift
+struct LiftArgs {
+    const double *Xr;    // (B x ldr)
+    int64_t ldr;
+    int64_t r_blk_off;
+    const double *ulift;
+    const double *ref0, *ref1;
+    double *out;
+    int64_t ldo;
+    int64_t o_blk_off;
+    int64_t B, n_f, ntiles;
+    int r;
+    int tiles_per_wg;
+};
+
+template <int NT, bool HAS_REF>
+__global__ __launch_bounds__(256) void lift_kernel(LiftArgs a) {
+    constexpr int KS = 4 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.z;
+    const double *Xr = a.Xr + (int64_t)blk * a.r_blk_off;
+    const double *ref = blk ? a.ref1 : a.ref0;
+    double *out = a.out + (int64_t)blk * a.o_blk_off;
+    const int64_t rowbase = (int64_t)blockIdx.x * ROWS_WG + wave * 32;
+    const int lrow = lane & 15, kgrp = lane >> 4;
+
+    double af[2][KS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int64_t row = rowbase + mt * 16 + lrow;
+        if (row >= a.B) row = a.B - 1;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            int j = 4 * t + kgrp;
+            af[mt][t] = (j < a.r) ? Xr[row * a.ldr + j] : 0.0;
+        }
+    }
+    const int64_t t0 = (int64_t)blockIdx.y * a.tiles_per_wg;
+    const int64_t t1 = min(t0 + (int64_t)a.tiles_per_wg, a.ntiles);
+    for (int64_t it = t0; it < t1; ++it) {
+        const double *uf = a.ulift + it * KS * 64;
+        double bf[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) bf[t] = uf[t * 64 + lane];
+        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][t], bf[t], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][t], bf[t], acc1, 0, 0, 0);
+        }
+        const int64_t i = 16 * it + (lane & 15);
+        if (i < a.n_f) {
+            const double rv = HAS_REF ? ref[i] : 0.0;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                int64_t r0 = rowbase + kgrp + 4 * reg;
+                int64_t r1 = r0 + 16;
+                if (r0 < a.B) out[r0 * a.ldo + i] = acc0[reg] + rv;
+                if (r1 < a.B) out[r1 * a.ldo + i] = acc1[reg] + rv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------- small  out = U^T T  (r x c)
+__global__ __launch_bounds__(256) void atb_partial_kernel(const double *__restrict__ U, int r,
+                                                          const double *__restrict__ T, int64_t ldt,
+                                                          int c, int64_t n_f, int rows_per_wg,
+                                                          double *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *su = reinterpret_cast<double *>(smem);   // [64][r]
+    double *st = su + 64 * r;                        // [64][c]
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t i1 = min(i0 + (int64_t)rows_per_wg, n_f);
+    const int nout = r * c;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    for (int64_t ib = i0; ib < i1; ib += 64) {
+        int nr = (int)min((int64_t)64, i1 - ib);
+        for (int e = tid; e < nr * r; e += 256) su[e] = U[ib * r + e];
+        for (int e = tid; e < nr * c; e += 256) st[e] = T[(ib + e / c) * ldt + (e % c)];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int o = tid + q * 256;
+            if (o < nout) {
+                int aa = o / c, bb = o % c;
+                double s = acc[q];
+                for (int i = 0; i < nr; ++i) s += su[i * r + aa] * st[i * c + bb];
+                acc[q] = s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        int o = tid + q * 256;
+        if (o < nout) partial[(int64_t)blockIdx.x * nout + o] = acc[q];
+    }
+}
+
+__global__ void atb_reduce_kernel(const double *__restrict__ partial, int nblk, int nout,
+                                  double *__restrict__ out, int c, int64_t ldo) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nout) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * nout + o];
+    out[(int64_t)(o / c) * ldo + (o % c)] = s;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- handle
+struct srom {
+    int64_t n_f = 0;
+    int r = 0, NT = 0, nchunks = 0;
+    int64_t ntiles = 0;
+    srh::DevBuf U, q_ref, v_ref, ufrag, ulift, work;
+    size_t work_bytes = 0;
+};
+
+static int ensure_work(srom *h, size_t bytes) {
+    if (bytes <= h->work_bytes) return SRH_OK;
+    int rc = h->work.alloc(bytes);
+    if (rc) return rc;
+    h->work_bytes = bytes;
+    return SRH_OK;
+}
+
+// split K across workgroups when there are too few row tiles to fill 256 CUs x 2
+static int proj_ksplit(const srom *h, int64_t B, int nblk, int *chunks_per_split) {
+    const int64_t rowtiles = srh::cdiv(B, ROWS_WG);
+    int ksplit = 1;
+    if (rowtiles * nblk < 512) ksplit = (int)std::min<int64_t>(h->nchunks, srh::cdiv(512, rowtiles * nblk));
+    *chunks_per_split = (int)srh::cdiv(h->nchunks, ksplit);
+    return (int)srh::cdiv(h->nchunks, *chunks_per_split);
+}
+
+template <int NT>
+static int launch_proj(const ProjArgs &a, bool has_ref, bool vec2, dim3 grid, hipStream_t s) {
+    size_t lds = 2 * (size_t)(16 * NT * 64 + KC) * sizeof(double);
+    if (has_ref) {
+        if (vec2) proj_kernel<NT, true, true><<<grid, 256, lds, s>>>(a);
+        else proj_kernel<NT, true, false><<<grid, 256, lds, s>>>(a);
+    } else {
+        if (vec2) proj_kernel<NT, false, true><<<grid, 256, lds, s>>>(a);
+        else proj_kernel<NT, false, false><<<grid, 256, lds, s>>>(a);
+    }
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
+template <int NT>
+static int launch_lift(const LiftArgs &a, bool has_ref, dim3 grid, hipStream_t s) {
+    if (has_ref) lift_kernel<NT, true><<<grid, 256, 0, s>>>(a);
+    else lift_kernel<NT, false><<<grid, 256, 0, s>>>(a);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
+extern "C" {
+
+int srom_create(srom_t **out, const double *U, int64_t n_f, int r, const double *q_ref,
+                const double *v_ref) {
+    SRH_REQUIRE(out && U, "srom_create: null argument");
+    SRH_REQUIRE(n_f > 0 && r > 0 && r <= 64, "srom_create: need n_f > 0 and 0 < r <= 64 (got %lld, %d)",
+                (long long)n_f, r);
+    srom *h = new srom();
+    h->n_f = n_f;
+    h->r = r;
+    h->NT = (r + 15) / 16;
+    h->nchunks = (int)srh::cdiv(n_f, KC);
+    h->ntiles = srh::cdiv(n_f, 16);
+    int rc;
+    std::vector<double> zeros;
+    if (!q_ref || !v_ref) zeros.assign(n_f, 0.0);
+    if ((rc = h->U.upload(U, sizeof(double) * n_f * r)) ||
+        (rc = h->q_ref.upload(q_ref ? q_ref : zeros.data(), sizeof(double) * n_f)) ||
+        (rc = h->v_ref.upload(v_ref ? v_ref : zeros.data(), sizeof(double) * n_f)) ||
+        (rc = h->ufrag.alloc(sizeof(double) * (size_t)h->nchunks * 16 * h->NT * 64)) ||
+        (rc = h->ulift.alloc(sizeof(double) * (size_t)h->ntiles * 4 * h->NT * 64))) {
+        delete h;
+        return rc;
+    }
+    int64_t tot = (int64_t)h->nchunks * 16 * h->NT * 64;
+    pack_u_kernel<<<(unsigned)srh::cdiv(tot, 256), 256>>>(h->U.as<double>(), n_f, r, h->NT, h->nchunks,
+                                                         h->ufrag.as<double>());
+    int64_t tot2 = h->ntiles * 4 * h->NT * 64;
+    pack_ulift_kernel<<<(unsigned)srh::cdiv(tot2, 256), 256>>>(h->U.as<double>(), n_f, r, 4 * h->NT,
+                                                              h->ntiles, h->ulift.as<double>());
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        srh::set_error("srom_create: packing kernels failed: %s", hipGetErrorString(e));
+        delete h;
+        return SRH_EHIP;
+    }
+    *out = h;
+    return SRH_OK;
+}
+
+int srom_destroy(srom_t *h) {
+    delete h;
+    return SRH_OK;
+}
+
+int srom_dims(const srom_t *h, int64_t *n_f, int *r) {
+    SRH_REQUIRE(h, "srom_dims: null handle");
+    if (n_f) *n_f = h->n_f;
+    if (r) *r = h->r;
+    return SRH_OK;
+}
+
+int srom_project_dev(srom_t *h, int which, const double *X, int64_t B, int64_t ldx, double *out,
+                     int64_t ldo, void *stream) {
+    SRH_REQUIRE(h && X && out, "srom_project_dev: null argument");
+    SRH_REQUIRE(which >= SROM_Q && which <= SROM_RAW, "srom_project_dev: Must specify vector type");
+    SRH_REQUIRE(B >= 0, "srom_project_dev: negative batch");
+    if (B == 0) return SRH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (which == SROM_X) ? 2 : 1;
+    SRH_REQUIRE(ldx >= nblk * h->n_f && ldo >= nblk * h->r, "srom_project_dev: leading dimension too small");
+    ProjArgs a{};
+    a.X = X;
+    a.ldx = ldx;
+    a.x_blk_off = h->n_f;
+    a.ufrag = h->ufrag.as<double>();
+    a.out = out;
+    a.ldo = ldo;
+    a.o_blk_off = h->r;
+    a.B = B;
+    a.n_f = h->n_f;
+    a.r = h->r;
+    a.nchunks = h->nchunks;
+    bool has_ref = which != SROM_RAW;
+    if (which == SROM_Q) a.ref0 = h->q_ref.as<double>();
+    if (which == SROM_V) a.ref0 = h->v_ref.as<double>();
+    if (which == SROM_X) { a.ref0 = h->v_ref.as<double>(); a.ref1 = h->q_ref.as<double>(); }
+    const int64_t rowtiles = srh::cdiv(B, ROWS_WG);
+    int ksplit = proj_ksplit(h, B, nblk, &a.chunks_per_split);
+    const int ldp = h->NT * 16;
+    if (ksplit > 1) {
+        int rc = ensure_work(h, sizeof(double) * (size_t)ksplit * nblk * B * ldp);
+        if (rc) return rc;
+        a.partial = h->work.as<double>();
+    }
+    const bool vec2 = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 2 == 0) && (h->n_f % 2 == 0);
+    dim3 grid((unsigned)rowtiles, (unsigned)ksplit, (unsigned)nblk);
+    int rc;
+    switch (h->NT) {
+        case 1: rc = launch_proj<1>(a, has_ref, vec2, grid, s); break;
+        case 2: rc = launch_proj<2>(a, has_ref, vec2, grid, s); break;
+        case 3: rc = launch_proj<3>(a, has_ref, vec2, grid, s); break;
+        default: rc = launch_proj<4>(a, has_ref, vec2, grid, s); break;
+    }
+    if (rc) return rc;
+    if (ksplit > 1) {
+        int64_t total = (int64_t)nblk * B * h->r;
+        splitk_reduce_kernel<<<(unsigned)srh::cdiv(total, 256), 256, 0, s>>>(
+            a.partial, ksplit, nblk, B, ldp, h->r, out, ldo, h->r);
+        SRH_CHECK_HIP(hipGetLastError());
+    }
+    return SRH_OK;
+}
+
+int srom_project(srom_t *h, int which, const double *X, int64_t B, double *out) {
+    SRH_REQUIRE(h && X && out, "srom_project: null argument");
+    SRH_REQUIRE(which >= SROM_Q && which <= SROM_RAW, "srom_project: Must specify vector type");
+    if (B == 0) return SRH_OK;
+    const int nblk = (which == SROM_X) ? 2 : 1;
+    srh::DevBuf dX, dO;
+    int rc;
+    if ((rc = dX.upload(X, sizeof(double) * B * nblk * h->n_f))) return rc;
+    if ((rc = dO.alloc(sizeof(double) * B * nblk * h->r))) return rc;
+    if ((rc = srom_project_dev(h, which, dX.as<double>(), B, nblk * h->n_f, dO.as<double>(), nblk * h->r, nullptr)))
+        return rc;
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    return dO.download(out, sizeof(double) * B * nblk * h->r);
+}
+
+int srom_lift_dev(srom_t *h, int which, const double *Xr, int64_t B, int64_t ldr, double *out,
+                  int64_t ldo, void *stream) {
+    SRH_REQUIRE(h && Xr && out, "srom_lift_dev: null argument");
+    SRH_REQUIRE(which >= SROM_Q && which <= SROM_RAW, "srom_lift_dev: Must specify vector type");
+    if (B == 0) return SRH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (which == SROM_X) ? 2 : 1;
+    SRH_REQUIRE(ldr >= nblk * h->r && ldo >= nblk * h->n_f, "srom_lift_dev: leading dimension too small");
+    LiftArgs a{};
+    a.Xr = Xr;
+    a.ldr = ldr;
+    a.r_blk_off = h->r;
+    a.ulift = h->ulift.as<double>();
+    a.out = out;
+    a.ldo = ldo;
+    a.o_blk_off = h->n_f;
+    a.B = B;
+    a.n_f = h->n_f;
+    a.ntiles = h->ntiles;
+    a.r = h->r;
+    bool has_ref = which != SROM_RAW;
+    if (which == SROM_Q) a.ref0 = h->q_ref.as<double>();
+    if (which == SROM_V) a.ref0 = h->v_ref.as<double>();
+    if (which == SROM_X) { a.ref0 = h->v_ref.as<double>(); a.ref1 = h->q_ref.as<double>(); }
+    const int64_t rowtiles = srh::cdiv(B, ROWS_WG);
+    int64_t ysplit = std::max<int64_t>(1, std::min<int64_t>(h->ntiles, srh::cdiv(1024, rowtiles * nblk)));
+    a.tiles_per_wg = (int)srh::cdiv(h->ntiles, ysplit);
+    ysplit = srh::cdiv(h->ntiles, a.tiles_per_wg);
+    dim3 grid((unsigned)rowtiles, (unsigned)ysplit, (unsigned)nblk);
+    switch (h->NT) {
+        case 1: return launch_lift<1>(a, has_ref, grid, s);
+        case 2: return launch_lift<2>(a, has_ref, grid, s);
+        case 3: return launch_lift<3>(a, has_ref, grid, s);
+        default: return launch_lift<4>(a, has_ref, grid, s);
+    }
+}
+
+int srom_lift(srom_t *h, int which, const double *Xr, int64_t B, double *out) {
+    SRH_REQUIRE(h && Xr && out, "srom_lift: null argument");
+    SRH_REQUIRE(which >= SROM_Q && which <= SROM_RAW, "srom_lift: Must specify vector type");
+    if (B == 0) return SRH_OK;
+    const int nblk = (which == SROM_X) ? 2 : 1;
+    srh::DevBuf dX, dO;
+    int rc;
+    if ((rc = dX.upload(Xr, sizeof(double) * B * nblk * h->r))) return rc;
+    if ((rc = dO.alloc(sizeof(double) * B * nblk * h->n_f))) return rc;
+    if ((rc = srom_lift_dev(h, which, dX.as<double>(), B, nblk * h->r, dO.as<double>(), nblk * h->n_f, nullptr)))
+        return rc;
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    return dO.download(out, sizeof(double) * B * nblk * h->n_f);
+}
+
+// out (r x c) = U^T T for T (n_f x c), c <= 64 per pass
+static int atb_dev(srom *h, const double *T, int64_t ldt, int c, double *out, int64_t ldo,
+                   double *partial, hipStream_t s) {
+    const int rows_per_wg = 256;
+    const int nblk = (int)srh::cdiv(h->n_f, rows_per_wg);
+    const int nout = h->r * c;
+    size_t lds = sizeof(double) * 64 * (size_t)(h->r + c);
+    atb_partial_kernel<<<nblk, 256, lds, s>>>(h->U.as<double>(), h->r, T, ldt, c, h->n_f, rows_per_wg, partial);
+    SRH_CHECK_HIP(hipGetLastError());
+    atb_reduce_kernel<<<(unsigned)srh::cdiv(nout, 256), 256, 0, s>>>(partial, nblk, nout, out, c, ldo);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
+int srom_reduce_matrix_dev(srom_t *h, const double *M, int64_t ncols, int left, int right, double *out,
+                           void *stream) {
+    SRH_REQUIRE(h && M && out, "srom_reduce_matrix_dev: null argument");
+    SRH_REQUIRE(ncols > 0, "srom_reduce_matrix_dev: ncols must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const bool both = (left && right) || (!left && !right);
+    const int nblk_atb = (int)srh::cdiv(h->n_f, 256);
+    if (both || right) SRH_REQUIRE(ncols == h->n_f, "srom_reduce_matrix_dev: M must be n_f x n_f");
+    if (right && !both) {
+        // M U : rows of M projected without a reference
+        return srom_project_dev(h, SROM_RAW, M, h->n_f, ncols, out, h->r, stream);
+    }
+    if (both) {
+        // T = M U (n_f x r) streamed once from HBM, then U^T T (r x r)
+        size_t tbytes = sizeof(double) * (size_t)h->n_f * h->r;
+        size_t pbytes = sizeof(double) * (size_t)nblk_atb * h->r * h->r;
+        // workspace: [split-K partials of the projection | T | atb partials]
+        int cps;
+        const int ks = proj_ksplit(h, h->n_f, 1, &cps);
+        size_t proj_ws = ks > 1 ? sizeof(double) * (size_t)ks * h->n_f * h->NT * 16 : 0;
+        int rc = ensure_work(h, proj_ws + tbytes + pbytes);
+        if (rc) return rc;
+        // the projection may use the front of the workspace for its split-K partials
+        double *T = reinterpret_cast<double *>(h->work.as<char>() + proj_ws);
+        double *part = reinterpret_cast<double *>(h->work.as<char>() + proj_ws + tbytes);
+        if ((rc = srom_project_dev(h, SROM_RAW, M, h->n_f, ncols, T, h->r, stream))) return rc;
+        return atb_dev(h, T, h->r, h->r, out, h->r, part, s);
+    }
+    // left only: U^T M (r x ncols), column panels of <= 64
+    size_t pbytes = sizeof(double) * (size_t)nblk_atb * h->r * 64;
+    int rc = ensure_work(h, pbytes);
+    if (rc) return rc;
+    for (int64_t c0 = 0; c0 < ncols; c0 += 64) {
+        int c = (int)std::min<int64_t>(64, ncols - c0);
+        if ((rc = atb_dev(h, M + c0, ncols, c, out + c0, ncols, h->work.as<double>(), s))) return rc;
+    }
+    return SRH_OK;
+}
+
+int srom_reduce_matrix(srom_t *h, const double *M, int64_t ncols, int left, int right, double *out) {
+    SRH_REQUIRE(h && M && out, "srom_reduce_matrix: null argument");
+    const bool both = (left && right) || (!left && !right);
+    srh::DevBuf dM, dO;
+    int rc;
+    if ((rc = dM.upload(M, sizeof(double) * h->n_f * ncols))) return rc;
+    size_t obytes = both ? sizeof(double) * h->r * h->r
+                         : (left ? sizeof(double) * h->r * ncols : sizeof(double) * h->n_f * h->r);
+    if ((rc = dO.alloc(obytes))) return rc;
+    if ((rc = srom_reduce_matrix_dev(h, dM.as<double>(), ncols, left, right, dO.as<double>(), nullptr))) return rc;
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    return dO.download(out, obytes);
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+"""POD reduced-order map on MI355X: same surface as sofacontrol/mor/pod.py (class POD, pod_config,
+load_POD, run_POD, get_snapshots, process_snapshots, compute_POD), arithmetic in HIP kernels."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import _lib
+from .. import utils as scutils
+
+SROM_Q, SROM_V, SROM_X, SROM_RAW = 0, 1, 2, 3
+
+
+class POD:
+    """POD object (sofacontrol/mor/pod.py:9-78).
+
+    `compute_RO_state` / `compute_FO_state` accept one vector (the reference's use) or a
+    (B, n) batch with one snapshot per row (the layout of np.asarray(data['q']), pod.py:149).
+    """
+
+    def __init__(self, POD_info):
+        self.q_ref = np.asarray(POD_info['q_ref'], dtype=np.float64)
+        self.v_ref = np.asarray(POD_info['v_ref'], dtype=np.float64)
+        self.x_ref = scutils.qv2x(self.q_ref, self.v_ref)
+        self.U = np.ascontiguousarray(POD_info['U'], dtype=np.float64)
+        self.rom_dim = self.U.shape[1]
+        self._V = None
+        self._h = C.c_void_p()
+        lib = _lib.lib()
+        _lib.check(lib.srom_create(C.byref(self._h), _lib.dptr(self.U), C.c_int64(self.U.shape[0]),
+                                   C.c_int(self.rom_dim), _lib.dptr(_lib.f64(self.q_ref)),
+                                   _lib.dptr(_lib.f64(self.v_ref))), 'srom_create')
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().srom_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def V(self):
+        """V = kron(I2, U) (pod.py:19); materialised lazily -- the kernels use the block structure."""
+        if self._V is None:
+            self._V = np.kron(np.eye(2), self.U)
+        return self._V
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _apply(self, fn, which, a, n_in, n_out, name):
+        a = np.asarray(a, dtype=np.float64)
+        single = a.ndim == 1
+        A = np.ascontiguousarray(a.reshape(1, -1) if single else a)
+        if A.ndim != 2 or A.shape[1] != n_in:
+            raise RuntimeError('%s: expected trailing dimension %d, got %s' % (name, n_in, a.shape))
+        out = np.empty((A.shape[0], n_out))
+        _lib.check(fn(self._h, C.c_int(which), _lib.dptr(A), C.c_int64(A.shape[0]), _lib.dptr(out)), name)
+        return out[0] if single else out
+
+    def compute_FO_state(self, q=None, v=None, x=None):
+        """pod.py:22-37."""
+        n_f, r = self.U.shape
+        lift = _lib.lib().srom_lift
+        if q is not None:
+            return self._apply(lift, SROM_Q, q, r, n_f, 'srom_lift')
+        elif v is not None:
+            return self._apply(lift, SROM_V, v, r, n_f, 'srom_lift')
+        elif x is not None:
+            return self._apply(lift, SROM_X, x, 2 * r, 2 * n_f, 'srom_lift')
+        raise RuntimeError('Must specify vector type')
+
+    def compute_RO_state(self, qf=None, vf=None, xf=None):
+        """pod.py:39-54."""
+        n_f, r = self.U.shape
+        proj = _lib.lib().srom_project
+        if qf is not None:
+            return self._apply(proj, SROM_Q, qf, n_f, r, 'srom_project')
+        elif vf is not None:
+            return self._apply(proj, SROM_V, vf, n_f, r, 'srom_project')
+        elif xf is not None:
+            return self._apply(proj, SROM_X, xf, 2 * n_f, 2 * r, 'srom_project')
+        raise RuntimeError('Must specify vector type')
+
+    def compute_RO_matrix(self, matrix, left=False, right=False):
+        """pod.py:56-72 (ndarray or scipy coo_matrix; coo is densified as the reference's K, D, M, S
+        are created from dense arrays, utils.py:187-206)."""
+        try:
+            from scipy.sparse import coo_matrix
+            sparse_ok = isinstance(matrix, coo_matrix)
+        except Exception:
+            sparse_ok = False
+        if not (isinstance(matrix, np.ndarray) or sparse_ok):
+            raise RuntimeError('Matrix is not numpy ndarray or sparse coo_matrix')
+        M = matrix.toarray() if sparse_ok else matrix
+        vec = (M.ndim == 1)
+        M = np.ascontiguousarray(M.reshape(-1, 1) if vec else M, dtype=np.float64)
+        n_f, r = self.U.shape
+        if M.shape[0] != n_f:
+            raise RuntimeError('matrix must have n_f rows')
+        both = (left and right) or (not left and not right)
+        if both:
+            out = np.empty((r, r))
+        elif left:
+            out = np.empty((r, M.shape[1]))
+        else:
+            out = np.empty((n_f, r))
+        _lib.check(_lib.lib().srom_reduce_matrix(self._h, _lib.dptr(M), C.c_int64(M.shape[1]),
+                                                 C.c_int(bool(left)), C.c_int(bool(right)),
+                                                 _lib.dptr(out)), 'srom_reduce_matrix')
+        return out[:, 0] if (vec and left and not right) else out
+
+    def get_info(self):
+        """pod.py:74-78."""
+        return {'q_ref': self.q_ref, 'v_ref': self.v_ref, 'U': self.U, 'type': 'POD'}
+
+
+class pod_config():
+    """pod.py:81-90."""
+
+    def __init__(self):
+        self.pod_type = 'v'
+        self.pod_tolerance = 0.0001
+        self.preprocess = []
+        self.preprocess_args = {'nbr_clusters': 0}
+
+
+def load_POD(POD_file):
+    """pod.py:93-107."""
+    if not os.path.isfile(POD_file):
+        raise RuntimeError('POD file specified is not a valid file')
+    POD_data = scutils.load_data(POD_file)
+    return POD(POD_data['POD_info'])
+
+
+def get_snapshots(data, pod_type):
+    """pod.py:144-154."""
+    if pod_type == 'q':
+        return np.asarray(data['q']) - data['q'][0]
+    elif pod_type == 'v':
+        return np.asarray(data['v'])
+    elif pod_type == 'a':
+        return np.asarray(data['v+']) - np.asarray(data['v'])
+    raise RuntimeError('pod_type must be q, v or a')
+
+
+def process_snapshots(snapshots, preprocess, args):
+    """pod.py:157-178 (clustering is an sklearn call in the reference and is outside the hot path)."""
+    if 'normalize' in preprocess:
+        snapshots = (snapshots - snapshots.min(axis=0)) / (snapshots.max(axis=0) + 1e-15 - snapshots.min(axis=0))
+    if 'substract_mean' in preprocess:
+        snapshots = snapshots - snapshots.mean(axis=0, keepdims=True)
+    if 'clustering' in preprocess and args.get('nbr_clusters', 0) > 0:
+        raise NotImplementedError('kmeans clustering preprocess is outside the hot path')
+    return snapshots
