@@ -204,11 +204,15 @@ def solve_exact(qp, tol=1e-10, max_iter=200, verbose=False):
         D = lam / t
         Phi = P + GT @ sp.diags(D) @ G + 1e-13 * sp.eye(nw)
         K = sp.bmat([[Phi, ET], [E, -1e-13 * sp.eye(ne)]], format='csc')
+        K_true = sp.bmat([[P + GT @ sp.diags(D) @ G, ET], [E, None]], format='csc')
         lu = spla.splu(K)
 
         def newton(r_c):
             rhs1 = -r_d - GT @ ((-r_c + lam * r_g) / t)
-            sol = lu.solve(np.concatenate((rhs1, -r_e)))
+            rhs = np.concatenate((rhs1, -r_e))
+            sol = lu.solve(rhs)
+            for _ in range(3):      # iterative refinement against the unregularised KKT matrix
+                sol = sol + lu.solve(rhs - K_true @ sol)
             dw, dy = sol[:nw], sol[nw:]
             dt = -r_g - G @ dw
             dlam = (-r_c - lam * dt) / t
