@@ -78,14 +78,20 @@ def test_tiny_instance_against_scipy_trust_constr():
 
 
 def test_osqp_restatement_reaches_reference_accuracy():
-    """What the reference's default solver delivers at cvxpy's tolerances (eps 1e-5): agreement with
-    the exact solution to ~1e-3 relative -- the product is held to the tighter exact answer."""
+    """What the reference's default solver delivers.  R = 1e-5 against Qz = 100 makes the QP nearly flat
+    along many input directions: ADMM at cvxpy's default eps = 1e-5 matches the optimal COST to <1 %
+    while the trajectory is still far off; at eps = 1e-7 the trajectory agrees to a few %.  The product
+    is held to the exact solution (<= 1e-4), which is tighter than what the reference itself computes."""
     case, _ = make_case(**CASES['box_only_tr_loose'])
     qp = build(case)
     w, _, _ = olocp.solve_exact(qp, tol=1e-11)
+    Je = olocp.objective(qp, w)
     wo, _, info = olocp.solve_osqp(qp)
+    assert info['status'] == 'solved'
+    assert 0.0 <= olocp.objective(qp, wo) - Je <= 1e-2 * abs(Je)
+    wo, _, info = olocp.solve_osqp(qp, eps_abs=1e-7, eps_rel=1e-7)
     assert info['status'] == 'solved'
     xe, ue, _ = olocp.split(qp, w)
     xo, uo, _ = olocp.split(qp, wo)
-    assert rel(xo, xe) <= 2e-2
-    assert abs(olocp.objective(qp, wo) - olocp.objective(qp, w)) <= 1e-3 * abs(olocp.objective(qp, w))
+    assert rel(xo, xe) <= 5e-2 and rel(uo, ue) <= 5e-2
+    assert abs(olocp.objective(qp, wo) - Je) <= 1e-5 * abs(Je)
