@@ -214,6 +214,22 @@ int sgusto_solve(stpwl_t *h, const slocp_problem *prob, const sgusto_params *par
                  const double *f_char, double *xopt, double *uopt, double *zopt, int32_t *iters,
                  int32_t *status, double *trace, int max_trace);
 
+/* Resident form of sgusto_solve: the plan owns the device copies of the problem constants and the
+ * per-rollout workspace for a fixed batch size, so that repeated receding-horizon solves (the
+ * gusto_callback of scp/ros.py:94-127) launch ONE kernel and touch no host memory.  The `_dev` entry
+ * point takes device pointers laid out as in sgusto_solve and is asynchronous on `stream`. */
+typedef struct sgusto_plan sgusto_plan_t;
+int sgusto_plan_create(sgusto_plan_t **plan, stpwl_t *h, const slocp_problem *prob, const sgusto_params *par,
+                       double dt, int64_t batch, const double *x_char, const double *f_char, int max_trace);
+int sgusto_plan_destroy(sgusto_plan_t *plan);
+int sgusto_plan_set_max_iters(sgusto_plan_t *plan, int max_gusto_iters);   /* gusto.py:142-147 */
+int sgusto_plan_solve(sgusto_plan_t *plan, const double *x0, const double *u_init, const double *x_init,
+                      const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
+                      double *zopt, int32_t *iters, int32_t *status, double *trace);
+int sgusto_plan_solve_dev(sgusto_plan_t *plan, const double *x0, const double *u_init, const double *x_init,
+                          const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
+                          double *zopt, int32_t *iters, int32_t *status, double *trace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,7 +120,14 @@ def solve(p, tol=1e-10, max_iter=60, verbose=False):
                     Hss = as_ @ (Dx[k] * as_)
                     c = Ax.T @ (Dx[k] * as_)
                     celim[k] = (c, Hss, gs)
-                    Hxx = Hxx - np.outer(c, c) / Hss
+                    # eliminate s_k; the diagonal of diag(hd) - c c^T/Hss is formed without cancellation:
+                    # (D+ + D-) - (D+ - D-)^2/Hss = [(D+ + D-)(Hss - D+ - D-) + 4 D+ D-]/Hss
+                    Dp, Dm = Dx[k][:n], Dx[k][n:2 * n]
+                    M = -np.outer(c, c) / Hss
+                    hd_naive = p.xs ** 2 * (Dp + Dm)
+                    hd_stable = p.xs ** 2 * ((Dp + Dm) * (Hss - (Dp + Dm)) + 4.0 * Dp * Dm) / Hss
+                    M[np.diag_indices(n)] = hd_stable - hd_naive
+                    Hxx = Hxx + M
                     gx = gx - c * gs / Hss
             if k == N:
                 P, pv, adj = Hxx, gx, gxd

@@ -1,0 +1,70 @@
+// Device view of a TPWL model (tables resident in HBM/L2) and workgroup-cooperative helpers.
+// Reference: sofacontrol/tpwl/tpwl.py (nearest-neighbour TPWL), sofacontrol/scp/models/tpwl.py.
+#pragma once
+#include "dev_la.h"
+
+struct TpwlDev {
+    int P, r, n, m, nz;
+    double w_q, w_v;
+    const double *qT, *vT;            // (r x P) transposed point tables (coalesced over points)
+    const double *u;                  // (P x m)
+    const double *Ac, *Bc, *dc;       // continuous tables (P x n x n), (P x n x m), (P x n)
+    const double *AcT;                // (P x n x n) transposed
+    const double *Ad, *Bd, *dd;       // discrete tables or null
+    const double *AdT;                // transposed discrete A
+    const double *BdT;                // (P x m x n) transposed discrete B
+    const double *BcT;                // (P x m x n)
+    const double *H, *z_ref;          // (nz x n), (nz) or null
+};
+
+namespace tpwl {
+
+// argmin_i w_q ||q_i - q|| + w_v ||v_i - v||, first minimum (np.argmin), for the state x (LDS or
+// global, x = [v; q]).  Executed by ONE wave (64 lanes); every lane returns the index.
+__device__ inline int nearest_wave(const TpwlDev &T, const double *__restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    double best = INFINITY;
+    int besti = 0x7fffffff;
+    for (int i0 = 0; i0 < T.P; i0 += 64) {
+        const int i = i0 + lane;
+        double d = INFINITY;
+        if (i < T.P) {
+            double sq = 0.0;
+            for (int j = 0; j < T.r; ++j) {
+                const double e = T.qT[j * T.P + i] - x[T.r + j];
+                sq = fma(e, e, sq);
+            }
+            d = T.w_q * sqrt(sq);
+            if (T.w_v != 0.0) {
+                double sv = 0.0;
+                for (int j = 0; j < T.r; ++j) {
+                    const double e = T.vT[j * T.P + i] - x[j];
+                    sv = fma(e, e, sv);
+                }
+                d += T.w_v * sqrt(sv);
+            }
+        }
+        if (d < best) { best = d; besti = i; }
+    }
+    // wave argmin with smallest-index tie break
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    return besti;
+}
+
+// nearest point for `count` states X (count x n, LDS or global) -> idx (LDS/global int array).
+// All waves of the workgroup participate; ends with __syncthreads().
+__device__ inline void nearest_many(const TpwlDev &T, const double *X, int ldx, int count, int *idx) {
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = wave; k < count; k += nw) {
+        const int i = nearest_wave(T, X + (size_t)k * ldx);
+        if ((threadIdx.x & 63) == 0) idx[k] = i;
+    }
+    __syncthreads();
+}
+
+}  // namespace tpwl

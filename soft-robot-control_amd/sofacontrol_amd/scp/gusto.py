@@ -1,0 +1,257 @@
+"""GuSTO sequential convex programming on MI355X -- surface of sofacontrol/scp/gusto.py:25-490.
+
+For a TPWL model (scp/models/tpwl.py adapter) the whole `solve` -- nearest-point linearisation along the
+trajectory, the LOCP QP (Riccati interior point), trust-region / model-accuracy / convergence tests
+and re-linearisation -- runs inside ONE persistent HIP kernel (csrc/scp.hip: gusto_kernel), one
+workgroup per rollout; `batch` independent rollouts (different x0 / targets, same model) can be solved
+by one launch with `GuSTO.solve_batch`.  Any other TemplateModel falls back to the reference's host
+loop around the device QP (`LOCP`), i.e. still no CPU arithmetic for the QP."""
+import ctypes as C
+import time
+
+import numpy as np
+
+from .. import _lib
+from .locp import LOCP, make_problem
+from .models.tpwl import TPWLGuSTO
+
+#### Default variables for GuSTO (gusto.py:12-22) ####
+DELTA0 = 1e4
+OMEGA0 = 1
+RHO = 0.1
+BETA_FAIL = 0.5
+BETA_SUCC = 2
+EPSILON = 0.01
+GAMMA_FAIL = 5
+OMEGA_MAX = 1e10
+MAX_ITERS = 500
+CONVERGE = 0.1
+
+
+class GuSTO:
+    def __init__(self, model, N, dt, Qz, R, x0, u_init, x_init, z=None, u=None, Qzf=None, zf=None, U=None, X=None,
+                 Xf=None, dU=None, verbose=0, visual=None, warm_start=True, **kwargs):
+        self.model = model
+        self.n_x = x0.shape[-1]
+        self.n_u = R.shape[0]
+        self.n_z = Qz.shape[0]
+        self.dt = dt
+        self.N = N
+        self.Qz, self.R, self.Qzf = Qz, R, Qzf
+        self.U, self.X, self.Xf, self.dU = U, X, Xf, dU
+        self.verbose = verbose
+        self.visual = visual
+        self.locp_solve_time = None
+        # gusto.py:83-119: parameters popped from kwargs
+        self.delta0 = kwargs.pop('delta0', DELTA0)
+        self.omega0 = kwargs.pop('omega0', OMEGA0)
+        self.rho = kwargs.pop('rho', RHO)
+        self.beta_fail = kwargs.pop('beta_fail', BETA_FAIL)
+        self.beta_succ = kwargs.pop('beta_succ', BETA_SUCC)
+        self.gamma_fail = kwargs.pop('gamma_fail', GAMMA_FAIL)
+        self.omega_max = kwargs.pop('omega_max', OMEGA_MAX)
+        self.epsilon = kwargs.pop('epsilon', EPSILON)
+        self.convg_thresh = kwargs.pop('convg_thresh', CONVERGE)
+        self.x_char = kwargs.pop('x_char', np.ones(self.n_x))
+        self.x_scale = 1. / np.abs(self.x_char)
+        self.f_char = kwargs.pop('f_char', np.ones(self.n_x))
+        self.f_scale = 1. / np.abs(self.f_char)
+        self.jit = kwargs.pop('jit', True)      # meaningless here; accepted for signature parity
+        user_max_iters = kwargs.pop('max_gusto_iters', MAX_ITERS)
+        self.batch = int(kwargs.pop('batch', 1))
+        self.max_trace = int(kwargs.pop('max_trace', 64))
+        self.x_k = None
+        self.u_k = None
+        self.nonlinear_observer = model.nonlinear_observer
+        self._fused = isinstance(model, TPWLGuSTO) and not self.nonlinear_observer
+        self._plan = C.c_void_p()
+        self.trace = None
+        self.iters = None
+        self.status = None
+        if self._fused:
+            model.dyn_sys._ensure_discrete(dt)
+            prob, self._keep = make_problem(N, model.H, Qz, R, Qzf, U, X, Xf, dU, None, True)
+            par = self._params(MAX_ITERS)
+            xc, fc = _lib.f64(self.x_char), _lib.f64(self.f_char)
+            _lib.check(_lib.lib().sgusto_plan_create(C.byref(self._plan), model.dyn_sys.handle, C.byref(prob),
+                                                     C.byref(par), C.c_double(dt), C.c_int64(self.batch),
+                                                     _lib.dptr(xc), _lib.dptr(fc), C.c_int(self.max_trace)),
+                       'sgusto_plan_create')
+        else:
+            self.locp = LOCP(self.N, self.model.H, self.Qz, self.R, Qzf=self.Qzf, U=self.U, X=self.X, Xf=self.Xf,
+                             dU=self.dU, verbose=(verbose == 2), warm_start=warm_start, x_char=self.x_char,
+                             nonlinear_observer=self.nonlinear_observer, **kwargs)
+        # gusto.py:142-147: the first solve may take up to MAX_ITERS, then the user's limit applies
+        self.max_gusto_iters = MAX_ITERS
+        if x0.ndim == 1:
+            self.solve(x0, u_init, x_init, z, zf, u)
+        else:
+            self.solve_batch(x0, u_init, x_init, z, zf, u)
+        self.max_gusto_iters = user_max_iters
+        if self._fused:
+            _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(user_max_iters))), 'set_max_iters')
+
+    def _params(self, max_iters):
+        return _lib.SGustoParams(float(self.delta0), float(self.omega0), float(self.rho), float(self.beta_fail),
+                                 float(self.gamma_fail), float(self.epsilon), float(self.omega_max),
+                                 float(self.convg_thresh), int(max_iters))
+
+    def __del__(self):
+        try:
+            if self._plan:
+                _lib.lib().sgusto_plan_destroy(self._plan)
+                self._plan = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def plan(self):
+        return self._plan
+
+    # ---- helper tests with the reference's names (host arrays; used by the generic loop / by users)
+    def is_converged(self, x, u):
+        dx = (1. / self.n_x) * np.sum(np.linalg.norm(np.multiply(self.x_scale, x - self.x_k), axis=1))
+        dsol = (1. / self.N) * dx
+        return dsol, bool(dsol <= self.convg_thresh)
+
+    def is_valid_iteration(self, itr):
+        return itr <= self.max_gusto_iters
+
+    def is_in_trust_region(self, x, delta):
+        max_diff = np.max(np.linalg.norm(np.multiply(self.x_scale, x - self.x_k), np.inf, axis=1))
+        if max_diff - delta > self.epsilon:
+            return max_diff, False
+        return 0.0, True
+
+    def state_constraints_violated(self, x):
+        max_violation = 0.0
+        if self.X is not None:
+            for i in range(x.shape[0]):
+                max_violation = max(max_violation, self.X.get_constraint_violation(x[i, :]))
+        return max_violation, not (max_violation > self.epsilon)
+
+    def compute_accuracy(self, x, u, J):
+        error = 0
+        approx = 0
+        for i in range(x.shape[0] - 1):
+            fk, Ak, Bk = self.model.get_continuous_dynamics(self.x_k[i, :], self.u_k[i, :])
+            f, _, _ = self.model.get_continuous_dynamics(x[i, :], u[i, :])
+            f_approx = fk + Ak @ (x[i, :] - self.x_k[i, :]) + Bk @ (u[i, :] - self.u_k[i, :])
+            error += self.dt * np.linalg.norm(np.multiply(self.f_scale, f - f_approx), 2)
+            approx += self.dt * np.linalg.norm(np.multiply(self.f_scale, f_approx), 2)
+        return error / (J + approx)
+
+    def get_traj_dynamics(self, x, u):
+        A_d, B_d, d_d = [], [], []
+        for i in range(x.shape[0] - 1):
+            A, B, d = self.model.get_discrete_dynamics(x[i, :], u[i, :], self.dt)
+            A_d.append(A); B_d.append(B); d_d.append(d)
+        return A_d, B_d, d_d
+
+    # ---- solve
+    def solve_batch(self, x0, u_init, x_init, z=None, zf=None, u=None):
+        """`batch` independent rollouts in one launch: x0 (B,n_x), u_init (B,N,n_u), x_init (B,N+1,n_x),
+        z (B,N+1,n_z) ..."""
+        if not self._fused:
+            raise RuntimeError('solve_batch needs a TPWLGuSTO model')
+        B, N, n, m, nz = self.batch, self.N, self.n_x, self.n_u, self.n_z
+        f = _lib.f64
+        x0 = f(np.asarray(x0).reshape(B, n)); u_init = f(np.asarray(u_init).reshape(B, N, m))
+        x_init = f(np.asarray(x_init).reshape(B, N + 1, n))
+        z = None if z is None else f(np.asarray(z).reshape(B, N + 1, nz))
+        zf = None if (zf is None or self.Qzf is None) else f(np.asarray(zf).reshape(B, nz))
+        u = None if u is None else f(np.asarray(u).reshape(B, N, m))
+        xo = np.empty((B, N + 1, n)); uo = np.empty((B, N, m)); zo = np.empty((B, N + 1, nz))
+        iters = np.empty(B, dtype=np.int32); status = np.empty(B, dtype=np.int32)
+        trace = np.full((B, self.max_trace, 4), np.nan) if self.max_trace > 0 else None
+        _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(self.max_gusto_iters))), 'set_max_iters')
+        t0 = time.time()
+        _lib.check(_lib.lib().sgusto_plan_solve(self._plan, _lib.dptr(x0), _lib.dptr(u_init), _lib.dptr(x_init),
+                                                _lib.dptr(z), _lib.dptr(zf), _lib.dptr(u), _lib.dptr(xo), _lib.dptr(uo),
+                                                _lib.dptr(zo), _lib.iptr(iters), _lib.iptr(status), _lib.dptr(trace)),
+                   'sgusto_plan_solve')
+        self.locp_solve_time = time.time() - t0
+        self.iters, self.status, self.trace = iters, status, trace
+        self.xopt, self.uopt, self.zopt = xo, uo, zo
+        return xo, uo, zo
+
+    def solve(self, x0, u_init, x_init, z=None, zf=None, u=None):
+        """gusto.py:283-487."""
+        if self._fused:
+            if self.batch != 1:
+                raise RuntimeError('GuSTO was built with batch=%d: use solve_batch' % self.batch)
+            xo, uo, zo = self.solve_batch(x0[None], u_init[None], x_init[None], None if z is None else z[None],
+                                          None if zf is None else zf[None], None if u is None else u[None])
+            self.xopt, self.uopt, self.zopt = xo[0], uo[0], zo[0]
+            self.x_k, self.u_k = self.xopt.copy(), self.uopt.copy()
+            st = int(self.status[0])
+            if st == 1:
+                print('Iteration {} of problem cannot be solved, see solver status for more information'.format(int(self.iters[0])))
+            elif st == 2:
+                print('omega > omega_max, solution did not converge')
+            elif st == 3:
+                print('Max iterations, solution did not converge')
+            elif self.verbose >= 1:
+                print('Solved in {} iterations/{:.3f} seconds'.format(int(self.iters[0]), self.locp_solve_time))
+            return
+        self._solve_host_loop(x0, u_init, x_init, z, zf, u)
+
+    def _solve_host_loop(self, x0, u_init, x_init, z, zf, u):
+        """The reference's loop (gusto.py:283-487) around the device QP, for generic models."""
+        t_locp = 0.0
+        itr = 0
+        self.u_k = u_init
+        self.x_k = x_init
+        A_d, B_d, d_d = self.get_traj_dynamics(self.x_k, self.u_k)
+        new_solution = True
+        Jstar_prev = delta_prev = omega_prev = np.inf
+        converged = False
+        delta, omega = self.delta0, self.omega0
+        while self.is_valid_iteration(itr) and not converged and omega <= self.omega_max:
+            self.locp.update(A_d, B_d, d_d, x0, self.x_k, delta, omega, z=z, zf=zf, u=u, full=new_solution)
+            new_solution = False
+            Jstar, success, stats = self.locp.solve()
+            if not success:
+                print('Iteration {} of problem cannot be solved, see solver status for more information'.format(itr))
+                self.xopt = np.copy(self.x_k)
+                self.uopt = np.copy(self.u_k)
+                self.zopt = np.transpose(self.model.H @ self.xopt.T)
+                return
+            t_locp += stats.solve_time
+            x_next, u_next, _ = self.locp.get_solution()
+            e_tr, tr_satisfied = self.is_in_trust_region(x_next, delta)
+            if tr_satisfied:
+                rho_k = self.compute_accuracy(x_next, u_next, Jstar)
+                if rho_k > self.rho and itr != 1:
+                    delta = self.beta_fail * delta
+                else:
+                    if delta_prev == delta and omega_prev == omega and Jstar_prev <= Jstar:
+                        delta = self.beta_fail * delta
+                    delta_prev, Jstar_prev, omega_prev = delta, Jstar, omega
+                    max_violation, X_satisfied = self.state_constraints_violated(x_next)
+                    if not X_satisfied:
+                        omega = self.gamma_fail * omega
+                    dsol, converged = self.is_converged(x_next, u_next)
+                    if not X_satisfied:
+                        converged = False
+                    new_solution = True
+            else:
+                omega = self.gamma_fail * omega
+            itr += 1
+            if new_solution:
+                self.x_k = x_next.copy()
+                self.u_k = u_next.copy()
+                if self.max_gusto_iters >= 1:
+                    A_d, B_d, d_d = self.get_traj_dynamics(self.x_k, self.u_k)
+        if omega > self.omega_max:
+            print('omega > omega_max, solution did not converge')
+        if not self.is_valid_iteration(itr - 1):
+            print('Max iterations, solution did not converge')
+        self.xopt = np.copy(self.x_k)
+        self.uopt = np.copy(self.u_k)
+        self.zopt = np.transpose(self.model.H @ self.xopt.T)
+        self.locp_solve_time = t_locp
+        self.iters = np.array([itr], dtype=np.int32)
+
+    def get_solution(self):
+        return self.xopt, self.uopt, self.zopt, self.locp_solve_time

@@ -1,0 +1,103 @@
+"""LOCP: the horizon QP of GuSTO, solved on the device -- surface of sofacontrol/scp/locp.py:9-203.
+
+The reference builds the QP in cvxpy and hands it to OSQP/GUROBI; here `solve()` launches the
+Riccati-structured interior-point kernel (csrc/locp_dev.h).  Same problem data (locp.py:218-342), same
+`update / solve / get_solution` protocol, `J*` without the 1/2 factor like cvxpy reports it."""
+import ctypes as C
+import time
+
+import numpy as np
+
+from .. import _lib
+
+
+class _Stats:
+    def __init__(self, solve_time, iters):
+        self.solve_time = solve_time
+        self.num_iters = iters
+
+
+def _poly(p):
+    if p is None:
+        return 0, None, None
+    A = np.ascontiguousarray(p.A, dtype=np.float64)
+    b = np.ascontiguousarray(p.b, dtype=np.float64)
+    return A.shape[0], A, b
+
+
+def make_problem(N, H, Qz, R, Qzf=None, U=None, X=None, Xf=None, dU=None, x_scale=None, tr_active=True):
+    """Fill a slocp_problem (include/sofacontrol_hip.h); returns (struct, keepalive list)."""
+    H = _lib.f64(H); Qz = _lib.f64(Qz); R = _lib.f64(R)
+    Qzf = _lib.f64(Qzf)
+    xs = _lib.f64(x_scale)
+    nU, UA, Ub = _poly(U)
+    nX, XA, Xb = _poly(X)
+    nXf, XfA, Xfb = _poly(Xf)
+    ndU, dUA, dUb = _poly(dU)
+    p = _lib.SLocpProblem(N, H.shape[1], R.shape[0], Qz.shape[0], _lib.dptr(H), _lib.dptr(Qz), _lib.dptr(R),
+                          _lib.dptr(Qzf), _lib.dptr(xs), nU, _lib.dptr(UA), _lib.dptr(Ub), nX, _lib.dptr(XA),
+                          _lib.dptr(Xb), nXf, _lib.dptr(XfA), _lib.dptr(Xfb), ndU, _lib.dptr(dUA), _lib.dptr(dUb),
+                          1 if tr_active else 0)
+    return p, [H, Qz, R, Qzf, xs, UA, Ub, XA, Xb, XfA, Xfb, dUA, dUb]
+
+
+class LOCP:
+    def __init__(self, N, H, Qz, R, Qzf=None, U=None, X=None, Xf=None, dU=None, verbose=False, warm_start=True,
+                 x_char=None, **kwargs):
+        self.N = N
+        self.H = np.asarray(H, dtype=np.float64)
+        self.Qz, self.R, self.Qzf = Qz, R, Qzf
+        self.U, self.X, self.Xf, self.dU = U, X, Xf, dU
+        self.verbose = verbose
+        self.warm_start = warm_start
+        self.nonlinear_observer = kwargs.pop('nonlinear_observer', False)
+        if self.nonlinear_observer:
+            raise NotImplementedError('nonlinear observer maps (SSM models) are not covered by the HIP path yet')
+        self.n_x = self.H.shape[1]
+        self.n_z = Qz.shape[0]
+        self.n_u = R.shape[0]
+        self.x_scale = np.ones(self.n_x) if x_char is None else 1. / np.abs(x_char)
+        self.tr_active = kwargs.pop('is_tr_active', True)
+        if kwargs.pop('input_nullspace', None) is not None:
+            raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
+        self.solver_args = kwargs      # OSQP/GUROBI settings have no meaning here; kept for signature parity
+        self._prob, self._keep = make_problem(N, self.H, Qz, R, Qzf, U, X, Xf, dU, self.x_scale, self.tr_active)
+        self._data = None
+        self._sol = None
+
+    def update(self, Ad, Bd, dd, x0, xk, delta, omega, z=None, zf=None, u=None, full=True, **kwargs):
+        """locp.py:98-173.  full=False only changes delta / omega (locp.py:139-141)."""
+        if full or self._data is None:
+            N, n, m = self.N, self.n_x, self.n_u
+            self._data = dict(
+                Ad=_lib.f64(np.asarray(Ad).reshape(N, n, n)), Bd=_lib.f64(np.asarray(Bd).reshape(N, n, m)),
+                dd=_lib.f64(np.asarray(dd).reshape(N, n)), x0=_lib.f64(np.asarray(x0).reshape(n)),
+                xk=None if xk is None else _lib.f64(np.asarray(xk).reshape(N + 1, n)),
+                z=None if z is None else _lib.f64(np.ravel(z)),
+                zf=None if (self.Qzf is None or zf is None) else _lib.f64(zf),
+                u=None if u is None else _lib.f64(np.ravel(u)))
+        self._delta = np.array([float(delta)])
+        self._omega = np.array([float(omega)])
+
+    def solve(self):
+        """locp.py:175-190: returns (Jstar, success, stats)."""
+        d = self._data
+        N, n, m = self.N, self.n_x, self.n_u
+        x = np.empty((N + 1, n)); u = np.empty((N, m)); s = np.empty(N + 1)
+        J = np.empty(1); status = np.empty(1, dtype=np.int32); iters = np.empty(1, dtype=np.int32)
+        t0 = time.time()
+        _lib.check(_lib.lib().slocp_solve(C.byref(self._prob), C.c_int64(1), _lib.dptr(d['Ad']), _lib.dptr(d['Bd']),
+                                          _lib.dptr(d['dd']), _lib.dptr(d['x0']), _lib.dptr(d['xk']),
+                                          _lib.dptr(self._delta), _lib.dptr(self._omega), _lib.dptr(d['z']),
+                                          _lib.dptr(d['zf']), _lib.dptr(d['u']), _lib.dptr(x), _lib.dptr(u),
+                                          _lib.dptr(s), _lib.dptr(J), _lib.iptr(status), _lib.iptr(iters)),
+                   'slocp_solve')
+        t1 = time.time()
+        if status[0] == 0:
+            self._sol = (x, u, s if self.tr_active else None)
+            return float(J[0]), True, _Stats(t1 - t0, int(iters[0]))
+        return np.inf, False, None
+
+    def get_solution(self):
+        """locp.py:192-203."""
+        return self._sol

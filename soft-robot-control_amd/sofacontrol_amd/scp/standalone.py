@@ -1,0 +1,69 @@
+"""In-process GuSTO solver node (sofacontrol/scp/standalone.py:11-120; the same logic serves the ROS
+node of scp/ros.py:48-159 minus rclpy): target interpolation, zero-input initial guess, first solve,
+and the warm-started receding-horizon callback (shift of the previous solution, ros.py:109-114)."""
+import numpy as np
+from scipy.interpolate import interp1d
+
+from .gusto import GuSTO
+
+
+def runGuSTOSolverStandAlone(model, N, dt, Qz, R, x0, t=None, z=None, u=None, Qzf=None, zf=None, U=None, X=None,
+                             Xf=None, dU=None, verbose=0, warm_start=True, **kwargs):
+    problem = GuSTOSolverNode(model, N, dt, Qz, R, x0, t=t, z=z, u=u, Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU,
+                              verbose=verbose, warm_start=warm_start, **kwargs)
+    return problem.get_solution()
+
+
+class GuSTOSolverNode():
+    def __init__(self, model, N, dt, Qz, R, x0, t=None, z=None, u=None, Qzf=None, zf=None, U=None, X=None, Xf=None,
+                 dU=None, verbose=0, warm_start=True, **kwargs):
+        self.model = model
+        self.N = N
+        self.dt = dt
+        x_char, f_char = self.model.get_characteristic_vals()
+        self.Qzf = Qzf
+        self.t = t
+        self.z = z
+        self.u = u
+        if z is not None and z.ndim == 2:
+            self.z_interp = interp1d(t, z, axis=0, bounds_error=False, fill_value=(z[0, :], z[-1, :]))
+        if u is not None and u.ndim == 2:
+            self.u_interp = interp1d(t, u, axis=0, bounds_error=False, fill_value=(u[0, :], u[-1, :]))
+        u_init = np.zeros((self.N, self.model.n_u))
+        x_init, _ = self.model.rollout(x0, u_init, self.dt)
+        z, zf, u = self.get_target(0.0)
+        self.gusto = GuSTO(model, N, dt, Qz, R, x0, u_init, x_init, z=z, u=u, Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU,
+                           verbose=verbose, warm_start=warm_start, x_char=x_char, f_char=f_char, **kwargs)
+        self.xopt, self.uopt, self.zopt, _ = self.gusto.get_solution()
+        self.topt = self.dt * np.arange(self.N + 1)
+
+    def get_solution(self):
+        self.xopt, self.uopt, self.zopt, _ = self.gusto.get_solution()
+        return self.xopt, self.uopt, self.zopt, self.topt
+
+    def get_target(self, t0):
+        """standalone.py:85-120 (constant 1-D targets are tiled per step)."""
+        t = t0 + self.dt * np.arange(self.N + 1)
+        if self.z is not None:
+            z = self.z_interp(t) if self.z.ndim == 2 else np.tile(self.z.reshape(1, -1), (self.N + 1, 1))
+        else:
+            z = None
+        zf = z[-1, :] if (self.Qzf is not None and z is not None) else None
+        if self.u is not None:
+            u = self.u_interp(t)[:self.N] if self.u.ndim == 2 else np.tile(self.u.reshape(1, -1), (self.N, 1))
+        else:
+            u = None
+        return z, zf, u
+
+    def gusto_callback(self, t0, x0):
+        """scp/ros.py:94-127 without the ROS message types: returns (t, xopt, uopt, zopt, solve_time)."""
+        z, zf, u = self.get_target(t0)
+        idx0 = np.argwhere(self.topt >= t0)[0, 0]
+        u_init = self.uopt[-1, :].reshape(1, -1).repeat(self.N, axis=0)
+        u_init[0:self.N - idx0] = self.uopt[idx0:, :]
+        x_init = self.xopt[-1, :].reshape(1, -1).repeat(self.N + 1, axis=0)
+        x_init[0:self.N + 1 - idx0] = self.xopt[idx0:, :]
+        self.gusto.solve(x0, u_init, x_init, z=z, zf=zf, u=u)
+        self.xopt, self.uopt, zopt, t_solve = self.gusto.get_solution()
+        self.topt = t0 + self.dt * np.arange(self.N + 1)
+        return self.topt, self.xopt, self.uopt, zopt, t_solve

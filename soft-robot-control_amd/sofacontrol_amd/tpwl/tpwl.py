@@ -1,0 +1,293 @@
+"""TPWL piecewise-affine reduced model on MI355X -- surface of sofacontrol/tpwl/tpwl.py (TPWL,
+TPWLATV).  The point tables live in HBM; nearest-point search, table gather and rollouts are HIP
+kernels (csrc/tpwl.hip).  Discretisation of the P stored points (pre_discretize, one-off per dt,
+tpwl.py:299-322) is done once on the host (zoh needs a matrix exponential) and uploaded."""
+import ctypes as C
+
+import numpy as np
+from scipy.linalg import expm
+
+from .. import _lib
+from .. import utils as scutils
+from ..mor import pod
+
+DISCR_METHOD = 'zoh'
+TPWL_METHOD = 'nn'
+DISCR_DICT = {'fe': 'forward Euler', 'be': 'implicit Euler', 'bil': 'bilinear transform', 'zoh': 'zero-order hold'}
+
+
+def zoh_affine(A, B, d, dt):
+    """sofacontrol/utils.py:302-335: expm([[A, B, d], [0, 0, 0]] dt)."""
+    n, m = B.shape
+    M = np.zeros((n + m + 1, n + m + 1))
+    M[:n, :n] = A
+    M[:n, n:n + m] = B
+    M[:n, n + m] = d
+    Z = expm(M * dt)
+    return Z[:n, :n], Z[:n, n:n + m], Z[:n, n + m]
+
+
+class TPWL:
+    """sofacontrol/tpwl/tpwl.py:14-216."""
+
+    def __init__(self, data, params=None, Cf=None, Hf=None, **kwargs):
+        self.tpwl_dict = data if isinstance(data, dict) else scutils.load_data(data)
+        self.num_points = len(self.tpwl_dict['q'])
+        self.discr_method = kwargs.get('discr_method', 'fe')
+        if self.tpwl_dict['rom_info']['type'] == 'POD':
+            self.rom = pod.POD(self.tpwl_dict['rom_info'])
+        else:
+            raise NotImplementedError("Unknown ROM type")
+        q = np.asarray(self.tpwl_dict['q'], dtype=np.float64)
+        u = np.asarray(self.tpwl_dict['u'], dtype=np.float64)
+        self.state_dim = q.shape[-1] * 2
+        self.input_dim = u.shape[-1]
+        if params is None:
+            params = dict()
+        self.tpwl_method = params.get('tpwl_method', TPWL_METHOD)
+        self.beta_weighting = params.get('beta_weighting', None)
+        self.dist_weights = params.get('dist_weights')
+        if self.dist_weights is None:
+            raise RuntimeError("params['dist_weights'] = {'q': .., 'v': ..} is required (tpwl.py:165-166)")
+
+        self._h = C.c_void_p()
+        f = _lib.f64
+        self._tabs = [f(q), f(self.tpwl_dict['v']), f(u), f(self.tpwl_dict['A_c']), f(self.tpwl_dict['B_c']),
+                      f(self.tpwl_dict['d_c'])]
+        _lib.check(_lib.lib().stpwl_create(
+            C.byref(self._h), C.c_int(self.num_points), C.c_int(q.shape[-1]), C.c_int(self.input_dim),
+            *[_lib.dptr(t) for t in self._tabs], None, None, None,
+            C.c_double(float(self.dist_weights['q'])), C.c_double(float(self.dist_weights['v']))), 'stpwl_create')
+
+        if Cf is not None:
+            self.set_measurement_model(Cf)
+        else:
+            self.C = None
+            self.y_ref = None
+            self.meas_dim = None
+        if Hf is not None:
+            self.set_output_model(Hf)
+        else:
+            self.H = None
+            self.z_ref = None
+            self.output_dim = None
+        self.nonlinear_observer = False
+        self.pre_discretized_dt = None
+        self.A_d = None
+        self.B_d = None
+        self.d_d = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().stpwl_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def update_state(self, x, u, dt):
+        raise NotImplementedError("update_state must be overriden by a child class")
+
+    def get_jacobians(self, x, dt=None):
+        raise NotImplementedError("get_jacobians must be overriden by a child class")
+
+    def set_measurement_model(self, Cf):
+        """tpwl.py:81-84."""
+        self.C = np.asarray(Cf @ self.rom.V)
+        self.y_ref = np.asarray(Cf @ self.rom.x_ref).ravel()
+        self.meas_dim = self.C.shape[0]
+
+    def set_output_model(self, Hf):
+        """tpwl.py:86-89: H = Hf V, z_ref = Hf x_ref (selector rows: a gather, done on the host once)."""
+        self.H = np.ascontiguousarray(np.asarray(Hf @ self.rom.V), dtype=np.float64)
+        self.z_ref = np.ascontiguousarray(np.asarray(Hf @ self.rom.x_ref).ravel(), dtype=np.float64)
+        self.output_dim = self.H.shape[0]
+        _lib.check(_lib.lib().stpwl_set_output(self._h, _lib.dptr(self.H), _lib.dptr(self.z_ref),
+                                               C.c_int(self.output_dim)), 'stpwl_set_output')
+
+    def zfyf_to_zy(self, zf=None, yf=None):
+        if zf is not None and self.z_ref is not None:
+            return zf - self.z_ref
+        elif yf is not None and self.y_ref is not None:
+            return yf - self.y_ref
+        raise RuntimeError('Need to set output or meas. model')
+
+    def zy_to_zfyf(self, z=None, y=None):
+        if z is not None and self.z_ref is not None:
+            return z + self.z_ref
+        elif y is not None and self.y_ref is not None:
+            return y + self.y_ref
+        raise RuntimeError('Need to set output or meas. model')
+
+    def x_to_zfyf(self, x, zf=False, yf=False):
+        if zf and self.H is not None:
+            return np.transpose(self.H @ x.T) + self.z_ref
+        elif yf and self.C is not None:
+            return np.transpose(self.C @ x.T) + self.y_ref
+        raise RuntimeError('Need to set output or meas. model')
+
+    def x_to_zy(self, x, z=False, y=False):
+        if z and self.H is not None:
+            return np.transpose(self.H @ x.T)
+        elif y and self.C is not None:
+            return np.transpose(self.C @ x.T)
+        raise RuntimeError('Need to set output or meas. model')
+
+    def get_state_dim(self):
+        return self.state_dim
+
+    def get_input_dim(self):
+        return self.input_dim
+
+    def get_output_dim(self):
+        return self.output_dim
+
+    def get_meas_dim(self):
+        return self.meas_dim
+
+    def get_rom_info(self):
+        return self.tpwl_dict['rom_info']
+
+    def get_sim_params(self):
+        return {'beta_weighting': self.beta_weighting, 'discr_method': self.discr_method,
+                'tpwl_method': self.tpwl_method, 'dist_weights': self.dist_weights}
+
+    def calc_nearest_point(self, x):
+        """tpwl.py:160-168 (one state) -- accepts (B, n_x) for a batch."""
+        X = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        idx = np.empty(X.shape[0], dtype=np.int32)
+        _lib.check(_lib.lib().stpwl_nearest(self._h, _lib.dptr(X), C.c_int64(X.shape[0]), _lib.iptr(idx)),
+                   'stpwl_nearest')
+        return int(idx[0]) if np.ndim(x) == 1 else idx
+
+    def rollout(self, x0, u, dt):
+        """tpwl.py:193-216; x0 (n_x,), u (N, n_u) -> x (N+1, n_x), z (N+1, n_z) (z includes z_ref).
+        Batched form: x0 (B, n_x), u (B, N, n_u)."""
+        self._ensure_discrete(dt)
+        x0a = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+        ua = np.ascontiguousarray(u, dtype=np.float64)
+        single = ua.ndim == 2
+        if single:
+            ua = ua[None]
+        Bn, N = ua.shape[0], ua.shape[1]
+        X = np.empty((Bn, N + 1, self.state_dim))
+        Z = np.empty((Bn, N + 1, self.output_dim)) if self.H is not None else None
+        _lib.check(_lib.lib().stpwl_rollout(self._h, _lib.dptr(x0a), _lib.dptr(ua), C.c_int(N), C.c_int64(Bn),
+                                            _lib.dptr(X), _lib.dptr(Z)), 'stpwl_rollout')
+        if single:
+            return X[0], (Z[0] if Z is not None else None)
+        return X, Z
+
+
+class TPWLATV(TPWL):
+    """sofacontrol/tpwl/tpwl.py:219-342."""
+
+    def __init__(self, data, params=None, Cf=None, Hf=None, **kwargs):
+        super().__init__(data, params, Cf=Cf, Hf=Hf, **kwargs)
+        self.ref_point = None
+        if self.tpwl_method != 'nn':
+            raise NotImplementedError("tpwl_method='weighting' (tpwl.py:244-250) is not covered by the HIP "
+                                      "path yet; the reference's default is 'nn' (tpwl_config.py:45)")
+
+    def update_state(self, x, u, dt):
+        A_d, B_d, d_d = self.get_jacobians(x, dt)
+        return self.update_dynamics(x, u, A_d, B_d, d_d)
+
+    def get_jacobians(self, x, dt=None, u=None):
+        """tpwl.py:236-270 (nn): (A_d, B_d, d_d)[i] if dt is given, else continuous (A_c, B_c, d_c)[i]."""
+        if dt is not None:
+            self._ensure_discrete(dt)
+        X = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        n, m = self.state_dim, self.input_dim
+        A = np.empty((1, n, n)); B = np.empty((1, n, m)); d = np.empty((1, n))
+        idx = np.empty(1, dtype=np.int32)
+        _lib.check(_lib.lib().stpwl_linearize(self._h, _lib.dptr(X), C.c_int64(1), C.c_int(dt is not None),
+                                              _lib.dptr(A), _lib.dptr(B), _lib.dptr(d), _lib.iptr(idx)),
+                   'stpwl_linearize')
+        self.ref_point = int(idx[0])
+        return A[0], B[0], d[0]
+
+    def linearize_batch(self, X, dt=None):
+        """Batched get_jacobians for X (B, n_x) -> A (B,n,n), B (B,n,m), d (B,n), idx (B,)."""
+        if dt is not None:
+            self._ensure_discrete(dt)
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Bn, n, m = X.shape[0], self.state_dim, self.input_dim
+        A = np.empty((Bn, n, n)); B = np.empty((Bn, n, m)); d = np.empty((Bn, n))
+        idx = np.empty(Bn, dtype=np.int32)
+        _lib.check(_lib.lib().stpwl_linearize(self._h, _lib.dptr(X), C.c_int64(Bn), C.c_int(dt is not None),
+                                              _lib.dptr(A), _lib.dptr(B), _lib.dptr(d), _lib.iptr(idx)),
+                   'stpwl_linearize')
+        return A, B, d, idx
+
+    def discretize_dynamics(self, A_c, B_c, d_c, dt):
+        """tpwl.py:272-297 -- one-off host computation per stored point."""
+        I = np.eye(A_c.shape[0])
+        if self.discr_method == 'fe':
+            return I + dt * A_c, dt * B_c, dt * d_c
+        elif self.discr_method == 'be':
+            A_d = np.linalg.inv(I - dt * A_c)
+            sep = np.linalg.inv(A_c) @ (A_d - I)
+            return A_d, sep @ B_c, sep @ d_c
+        elif self.discr_method == 'bil':
+            A_d = (I + 0.5 * dt * A_c) @ np.linalg.inv(I - 0.5 * dt * A_c)
+            sep = np.linalg.inv(A_c) @ (A_d - I)
+            return A_d, sep @ B_c, sep @ d_c
+        elif self.discr_method == 'zoh':
+            return zoh_affine(A_c, B_c, d_c, dt)
+        raise RuntimeError('self.discr_method must be in [fe, be, bil, zoh]')
+
+    def pre_discretize(self, dt):
+        """tpwl.py:299-322: discretise all stored points, keep them as lists (reference attribute
+        layout) and install the tables on the device."""
+        if self.tpwl_method != 'nn':
+            raise RuntimeError('tpwl method should be nn to pre-discretize')
+        print('Performing pre-discretization using {} of TPWL model with dt = {:.3f}'
+              .format(DISCR_DICT[self.discr_method], dt))
+        self.A_d, self.B_d, self.d_d = [], [], []
+        Ac, Bc, dc = self._tabs[3], self._tabs[4], self._tabs[5]
+        for i in range(self.num_points):
+            A_d, B_d, d_d = self.discretize_dynamics(Ac[i], Bc[i], dc[i], dt)
+            self.A_d.append(A_d)
+            self.B_d.append(B_d)
+            self.d_d.append(d_d)
+        self._install_discrete(dt)
+
+    def _install_discrete(self, dt):
+        Ad, Bd, dd = _lib.f64(np.stack(self.A_d)), _lib.f64(np.stack(self.B_d)), _lib.f64(np.stack(self.d_d))
+        _lib.check(_lib.lib().stpwl_set_discrete(self._h, _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)),
+                   'stpwl_set_discrete')
+        self.pre_discretized_dt = dt
+        self._device_dt = dt
+
+    def _ensure_discrete(self, dt):
+        """The device keeps ONE set of discrete tables; a call with another dt re-discretises (the
+        reference discretises per call in that case, tpwl.py:260-265)."""
+        if getattr(self, '_device_dt', None) != dt:
+            import io
+            import contextlib
+            with contextlib.redirect_stdout(io.StringIO()):
+                keep = self.pre_discretized_dt
+                self.pre_discretize(dt)
+                if keep is not None:
+                    self.pre_discretized_dt = dt
+
+    def get_characteristic_dx(self, dt):
+        """tpwl.py:324-334."""
+        x = scutils.qv2x(self._tabs[0], self._tabs[1])
+        self._ensure_discrete(dt)
+        A, B, d, _ = self.linearize_batch(x, dt)
+        dx = np.einsum('bij,bj->bi', A, x) + np.einsum('bij,bj->bi', B, self._tabs[2]) + d - x
+        return np.abs(dx).max(axis=0)
+
+    @staticmethod
+    def update_dynamics(x, u, A_d, B_d, d_d):
+        """tpwl.py:336-339 (host helper on caller-supplied arrays)."""
+        return A_d @ x + np.squeeze(B_d @ u) + d_d
+
+    def get_ref_point(self):
+        return self.ref_point

@@ -1,0 +1,46 @@
+"""Shared builders for the GPU tests: product-side objects from the seeded synthetic models."""
+import numpy as np
+import scipy.sparse as sp
+
+from oracle import tpwl as otpwl
+
+
+def small_rom(n_nodes, r, seed):
+    """Same generator as tests/golden/make_golden.py:small_rom."""
+    rng = np.random.default_rng(seed)
+    n_f = 3 * n_nodes
+    U, _ = np.linalg.qr(rng.standard_normal((n_f, r)))
+    q_ref = rng.uniform(-108, 107, n_f)
+    v_ref = 0.01 * rng.standard_normal(n_f)
+    return U, q_ref, v_ref
+
+
+def tip_selector(node, num_nodes):
+    """linearModel(nodes=[node], num_nodes).C  (sofacontrol/measurement_models.py:87-103): rows [v; q]."""
+    C = sp.lil_matrix((6, 6 * num_nodes))
+    for a in range(3):
+        C[a, 3 * node + a] = 1.0
+        C[3 + a, 3 * num_nodes + 3 * node + a] = 1.0
+    return C.tocsr()
+
+
+def product_tpwl(model, U, q_ref, v_ref, Hf, discr='zoh'):
+    from sofacontrol_amd.tpwl.tpwl import TPWLATV
+    data = dict(q=model['q'], v=model['v'], u=model['u'], A_c=model['A_c'], B_c=model['B_c'], d_c=model['d_c'],
+                rom_info=dict(type='POD', U=U, q_ref=q_ref, v_ref=v_ref))
+    params = dict(tpwl_method='nn', dist_weights={'q': model['w_q'], 'v': model['w_v']}, beta_weighting=None)
+    return TPWLATV(data=data, params=params, Hf=Hf, discr_method=discr)
+
+
+def golden_problem(r, m, P, n_nodes, seed, q_scale=1.0):
+    """Mirror of make_golden.make_problem."""
+    model = otpwl.synthetic_model(r, m, P, seed=seed)
+    model['q'] = model['q'] * q_scale
+    U, q_ref, v_ref = small_rom(n_nodes, r, seed + 1)
+    Hf = tip_selector(n_nodes // 2, n_nodes)
+    return model, U, q_ref, v_ref, Hf
+
+
+class Poly:
+    def __init__(self, A, b):
+        self.A, self.b = np.asarray(A, float), np.asarray(b, float)

@@ -1,0 +1,93 @@
+"""GPU parity: the fused GuSTO kernel against the reference GuSTO loop (golden vectors g6: imported
+reference class with the exact oracle QP injected for cvxpy) -- same iterates, same (J, delta, omega)
+sequence; <= 1e-4 relative on trajectories."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from helpers import golden_problem, product_tpwl, Poly
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def setup(golden):
+    g = golden('g6_gusto')
+    model, U, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 30, q_scale=0.05)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    from sofacontrol_amd.scp.models.tpwl import TPWLGuSTO
+    gm = TPWLGuSTO(tp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gm.pre_discretize(0.05)
+    return g, gm
+
+
+@pytest.mark.parametrize('tag', ['box', 'boxX', 'free'])
+def test_gusto_node_first_solve_and_warm_resolve(golden, tag):
+    from sofacontrol_amd.scp.standalone import GuSTOSolverNode
+    g, gm = setup(golden)
+    N, dt = 12, 0.05
+    cons = {}
+    if tag in ('box', 'boxX'):
+        cons['U'] = Poly(g['U_A'], g['U_b'])
+    if tag == 'boxX':
+        cons['X'] = Poly(g['Xp_A'], g['Xp_b'])
+    node = GuSTOSolverNode(gm, N, dt, g['Qz'], g['R'], np.zeros(8), t=g['t'], z=g['zt'], verbose=0,
+                           warm_start=True, convg_thresh=1e-3, max_trace=64, **cons)
+    xopt, uopt, zopt, topt = node.get_solution()
+    ref_tr = g[tag + '_trace']
+    assert int(node.gusto.iters[0]) == ref_tr.shape[0]
+    tr = node.gusto.trace[0, :ref_tr.shape[0], :3]
+    np.testing.assert_allclose(tr, ref_tr, rtol=1e-6)
+    assert rel(xopt, g[tag + '_xopt']) <= 1e-4 and rel(uopt, g[tag + '_uopt']) <= 1e-4
+    assert rel(zopt, g[tag + '_zopt']) <= 1e-4
+    np.testing.assert_allclose(node.get_target(0.37)[0], g['get_target_z'], rtol=0, atol=1e-13)
+    # receding-horizon callback with the shifted warm start (scp/ros.py:109-114)
+    node.gusto.max_gusto_iters = 500
+    t, x2, u2, z2, _ = node.gusto_callback(2 * dt, g[tag + '_x0b'])
+    assert int(node.gusto.iters[0]) == g[tag + '_trace2'].shape[0]
+    assert rel(x2, g[tag + '_xopt2']) <= 1e-4 and rel(u2, g[tag + '_uopt2']) <= 1e-4
+    np.testing.assert_allclose(t, 2 * dt + dt * np.arange(N + 1))
+
+
+def test_gusto_helpers_match_reference(golden):
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g, gm = setup(golden)
+    N, dt = 12, 0.05
+    x0 = np.zeros(8)
+    u_init = np.zeros((N, 3))
+    x_init, _ = gm.rollout(x0, u_init, dt)
+    gu = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=None, x_char=g['x_char'], f_char=g['f_char'],
+               convg_thresh=1e-3, max_gusto_iters=0, X=Poly(g['Xp_A'], g['Xp_b']))
+    gu.x_k, gu.u_k = g['h_xk'], g['h_uk']
+    x, u = g['h_x'], g['h_u']
+    np.testing.assert_allclose([gu.is_in_trust_region(x, d)[0] for d in (1e-3, 1e-1, 10.)], g['h_tr'], rtol=1e-12)
+    np.testing.assert_allclose(gu.is_converged(x, u)[0], g['h_conv'], rtol=1e-12)
+    np.testing.assert_allclose(gu.compute_accuracy(x, u, 3.7), g['h_rho'], rtol=1e-9)
+    np.testing.assert_allclose(gu.state_constraints_violated(10 * x)[0], g['h_viol'], rtol=1e-12)
+
+
+def test_gusto_batch_equals_single(golden):
+    """Independent rollouts in one launch give the same answer as one-at-a-time solves."""
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g, gm = setup(golden)
+    N, dt, B = 12, 0.05, 5
+    rng = np.random.default_rng(3)
+    x0 = 1e-3 * rng.standard_normal((B, 8))
+    u_init = np.zeros((B, N, 3))
+    x_init, _ = gm.rollout(x0, u_init, dt)
+    from scipy.interpolate import interp1d
+    zi = interp1d(g['t'], g['zt'], axis=0)
+    z = np.stack([zi(0.1 * b + dt * np.arange(N + 1)) for b in range(B)])
+    kw = dict(x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, U=Poly(g['U_A'], g['U_b']))
+    gb = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, batch=B, **kw)
+    for b in range(B):
+        g1 = GuSTO(gm, N, dt, g['Qz'], g['R'], x0[b], u_init[b], x_init[b], z=z[b], **kw)
+        np.testing.assert_array_equal(g1.xopt, gb.xopt[b])
+        np.testing.assert_array_equal(g1.uopt, gb.uopt[b])
+        assert int(g1.iters[0]) == int(gb.iters[b])

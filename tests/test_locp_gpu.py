@@ -1,0 +1,81 @@
+"""GPU parity: the LOCP QP kernel through the C ABI against the exact oracle solution.
+Tolerance (north star): <= 1e-4 relative on trajectories, 1e-7 relative on the optimal cost."""
+import numpy as np
+import pytest
+
+from oracle import locp as olocp
+from qp_cases import CASES, make_case
+from helpers import Poly
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def oracle_solution(case):
+    qp = olocp.build_qp(case['N'], case['H'], case['Qz'], case['R'], case['Ad'], case['Bd'], case['dd'], case['x0'],
+                        case['xk'], case['delta'], case['omega'], z=case['z'], Qzf=case.get('Qzf'), zf=case.get('zf'),
+                        U=case['U'], X=case['X'], x_scale=case['x_scale'])
+    w, _, info = olocp.solve_exact(qp, tol=1e-11)
+    assert info.get('status', 'optimal') == 'optimal'
+    return olocp.split(qp, w), olocp.objective(qp, w)
+
+
+def product_locp(case):
+    from sofacontrol_amd.scp.locp import LOCP
+    U = Poly(*case['U']) if case['U'] is not None else None
+    X = Poly(*case['X']) if case['X'] is not None else None
+    return LOCP(case['N'], case['H'], case['Qz'], case['R'], Qzf=case.get('Qzf'), U=U, X=X,
+                x_char=1. / case['x_scale'])
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_locp_matches_exact_solution(name):
+    case, _ = make_case(**CASES[name])
+    (xe, ue, se), Je = oracle_solution(case)
+    locp = product_locp(case)
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
+                case['omega'], z=case['z'], zf=case.get('zf'))
+    J, ok, stats = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
+    assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
+    np.testing.assert_allclose(s, se, rtol=0, atol=1e-4 * max(1.0, se.max()))
+    # dynamics hold exactly along the returned trajectory (equality constraints, locp.py:287, 340)
+    np.testing.assert_array_equal(x[0], case['x0'])
+    for k in range(case['N']):
+        np.testing.assert_allclose(x[k + 1], case['Ad'][k] @ x[k] + case['Bd'][k] @ u[k] + case['dd'][k], rtol=0, atol=1e-12)
+    # update(full=False) only changes delta / omega (locp.py:139-141)
+    locp.update(None, None, None, None, None, case['delta'], case['omega'], full=False)
+    J2, ok2, _ = locp.solve()
+    assert ok2 and J2 == J
+
+
+def test_locp_diamond_shape():
+    """C2 shape (n_x = 60, n_u = 4, N = 50): KKT feasibility + optimality vs the exact oracle."""
+    case, _ = make_case(r=30, m=4, P=64, N=50, seed=7, q_scale=0.02, use_X=True, u_max=1500.0, amp=0.1)
+    (xe, ue, se), Je = oracle_solution(case)
+    locp = product_locp(case)
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
+                case['omega'], z=case['z'])
+    J, ok, stats = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
+    assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
+    UA, Ub = case['U']
+    assert (UA @ u.T - Ub[:, None]).max() <= 1e-7
+
+
+def test_infeasible_qp_reports_failure():
+    """locp.py:187-190: a QP that cannot be solved returns (inf, False, None)."""
+    case, _ = make_case(**CASES['box_X'])
+    case['X'] = (case['X'][0], np.array([-1.0, -1.0, -1.0, -1.0]))    # empty set
+    locp = product_locp(case)
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
+                case['omega'], z=case['z'])
+    J, ok, stats = locp.solve()
+    assert not ok and J == np.inf and stats is None

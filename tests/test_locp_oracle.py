@@ -41,7 +41,7 @@ def test_exact_solvers_agree_and_certify(name):
     assert abs(J - olocp.objective(qp, w)) <= 1e-7 * max(1.0, abs(J))
     if name.startswith('tr_active') or name.startswith('tr_tiny'):
         assert se.max() > 1e-6 or np.max(np.abs(case['x_scale'] * (xe - case['xk']))) >= case['delta'] * 0.999
-        np.testing.assert_allclose(s, se, rtol=0, atol=1e-6 * max(1.0, se.max()))
+        np.testing.assert_allclose(s, se, rtol=0, atol=1e-4 * max(1.0, se.max()))
 
 
 def test_equality_only_closed_form():
