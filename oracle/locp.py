@@ -162,7 +162,7 @@ def solve_eq_only(qp):
     return sol[:nw], sol[nw:]
 
 
-def solve_exact(qp, tol=1e-10, max_iter=200, verbose=False):
+def solve_exact(qp, tol=1e-12, max_iter=200, verbose=False):
     """Mehrotra predictor-corrector primal-dual interior point on the full sparse KKT system.
 
     Returns w, (y, lam), info.  Independent of the product's Riccati-structured solver: the Newton
@@ -223,16 +223,15 @@ def solve_exact(qp, tol=1e-10, max_iter=200, verbose=False):
 
         def step_len(v, dv):
             neg = dv < 0
-            return min(1.0, float(np.min(-v[neg] / dv[neg]))) if neg.any() else 1.0
+            return float(np.min(-v[neg] / dv[neg])) if neg.any() else np.inf
 
         dw, dy, dt, dlam = newton(lam * t)
-        a_aff = min(step_len(t, dt), step_len(lam, dlam))
+        a_aff = min(1.0, step_len(t, dt), step_len(lam, dlam))
         mu_aff = float((lam + a_aff * dlam) @ (t + a_aff * dt)) / ng
         sigma = (mu_aff / mu) ** 3 if mu > 0 else 0.0
         dw, dy, dt, dlam = newton(lam * t + dt * dlam - sigma * mu)
         # one common primal/dual step (QP: the dual residual couples w and the multipliers)
-        a = min(step_len(t, dt), step_len(lam, dlam))
-        a = a if a >= 1.0 else 0.99 * a
+        a = min(1.0, 0.99 * min(step_len(t, dt), step_len(lam, dlam)))    # stay strictly interior
         w = w + a * dw
         t = t + a * dt
         y = y + a * dy

@@ -78,8 +78,14 @@ def _rows_x(p, k):
     return np.vstack(Ax), np.concatenate(as_), np.concatenate(h)
 
 
-def solve(p, tol=1e-10, max_iter=60, verbose=False):
-    """Returns x (N+1,n), u (N,m), s (N+1,), J, info."""
+def solve(p, tol=1e-12, max_iter=60, verbose=False, reg=1e-8):
+    """Returns x (N+1,n), u (N,m), s (N+1,), J, info.
+
+    `reg` is a dual (proximal) regularisation of the Newton systems, Friedlander & Orban style: the
+    row weights become D = lam / (t + delta lam) with delta = reg / scale_d.  It leaves the KKT point
+    unchanged (the proximal term vanishes at a fixed point) but bounds the weights of strongly active
+    rows, which keeps the explicitly formed stage Hessians (X^T D X with D ~ 1e12) from swamping the
+    1e-5-level input curvature in float64."""
     N, n, m = p.N, p.n, p.m
     rows = [None] + [_rows_x(p, k) for k in range(1, N + 1)]
     UA, Ub = (p.U if p.U is not None else (np.zeros((0, m)), np.zeros(0)))
@@ -207,54 +213,58 @@ def solve(p, tol=1e-10, max_iter=60, verbose=False):
     status = 'max_iter'
     scale_d = max(1.0, p.omega, np.abs(p.grad_x(1, 0 * x[1])).max())
     scale_p = max(1.0, abs(p.delta), np.abs(Ub).max() if nU else 1.0)
+    dreg = reg / scale_d
     it = 0
     for it in range(max_iter):
         gx, gu = row_vals(x, u, s)
         rgx = [None] + [gx[k] + tx[k] for k in range(1, N + 1)]
         rgu = [gu[k] + tu[k] for k in range(N)]
         mu = (sum(float(lx[k] @ tx[k]) for k in range(1, N + 1)) + sum(float(lu[k] @ tu[k]) for k in range(N))) / ng
-        Dx = [None] + [lx[k] / tx[k] for k in range(1, N + 1)]
-        Du = [lu[k] / tu[k] for k in range(N)]
+        ex = [None] + [tx[k] + dreg * lx[k] for k in range(1, N + 1)]      # regularised denominators
+        eu = [tu[k] + dreg * lu[k] for k in range(N)]
+        Dx = [None] + [lx[k] / ex[k] for k in range(1, N + 1)]
+        Du = [lu[k] / eu[k] for k in range(N)]
         # predictor: r_c = lam*t  ->  rho = (lam*r_g - lam*t)/t + lam  (the +lam is the G^T lam term)
-        rhox = [None] + [lx[k] + (lx[k] * rgx[k] - lx[k] * tx[k]) / tx[k] for k in range(1, N + 1)]
-        rhou = [lu[k] + (lu[k] * rgu[k] - lu[k] * tu[k]) / tu[k] for k in range(N)]
+        rhox = [None] + [lx[k] + (lx[k] * rgx[k] - lx[k] * tx[k]) / ex[k] for k in range(1, N + 1)]
+        rhou = [lu[k] + (lu[k] * rgu[k] - lu[k] * tu[k]) / eu[k] for k in range(N)]
         dx, du, ds, rd = newton(x, u, s, Dx, rhox, Du, rhou, lx, lu)
         rp = max(np.abs(cat(rgx, rgu)).max(), 0.0)
         if verbose:
             print(it, 'rd %.3e rp %.3e mu %.3e' % (rd, rp, mu))
-        if rd <= tol * scale_d and rp <= tol * scale_p and mu <= tol:
+        # gap to `tol`; the linear residuals shrink by (1 - alpha) per step and sit at their round-off
+        # floor long before: they are only required to be below 1e-9 (relative)
+        if rd <= max(tol, 1e-9) * scale_d and rp <= max(tol, 1e-9) * scale_p and mu <= tol:
             status = 'optimal'
             break
         ax, au = row_dirs(dx, du, ds)
-        dtx = [None] + [-rgx[k] - ax[k] for k in range(1, N + 1)]
-        dtu = [-rgu[k] - au[k] for k in range(N)]
-        dlx = [None] + [(-lx[k] * tx[k] - lx[k] * dtx[k]) / tx[k] for k in range(1, N + 1)]
-        dlu = [(-lu[k] * tu[k] - lu[k] * dtu[k]) / tu[k] for k in range(N)]
+        dlx = [None] + [(-lx[k] * tx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
+        dlu = [(-lu[k] * tu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]
+        dtx = [None] + [-rgx[k] - ax[k] + dreg * dlx[k] for k in range(1, N + 1)]
+        dtu = [-rgu[k] - au[k] + dreg * dlu[k] for k in range(N)]
 
         def maxstep(v, dv):
             neg = dv < 0
-            return min(1.0, float(np.min(-v[neg] / dv[neg]))) if neg.any() else 1.0
+            return float(np.min(-v[neg] / dv[neg])) if neg.any() else np.inf
 
         T, DT, Lm, DL = cat(tx, tu), cat(dtx, dtu), cat(lx, lu), cat(dlx, dlu)
-        a_aff = min(maxstep(T, DT), maxstep(Lm, DL))
+        a_aff = min(1.0, maxstep(T, DT), maxstep(Lm, DL))
         mu_aff = float((Lm + a_aff * DL) @ (T + a_aff * DT)) / ng
         sigma = (mu_aff / mu) ** 3 if mu > 0 else 0.0
         # corrector: r_c = lam*t + dt_aff*dlam_aff - sigma*mu
-        rhox = [None] + [lx[k] + (lx[k] * rgx[k] - (lx[k] * tx[k] + dtx[k] * dlx[k] - sigma * mu)) / tx[k]
+        rhox = [None] + [lx[k] + (lx[k] * rgx[k] - (lx[k] * tx[k] + dtx[k] * dlx[k] - sigma * mu)) / ex[k]
                          for k in range(1, N + 1)]
-        rhou = [lu[k] + (lu[k] * rgu[k] - (lu[k] * tu[k] + dtu[k] * dlu[k] - sigma * mu)) / tu[k]
+        rhou = [lu[k] + (lu[k] * rgu[k] - (lu[k] * tu[k] + dtu[k] * dlu[k] - sigma * mu)) / eu[k]
                 for k in range(N)]
         rcx = [None] + [lx[k] * tx[k] + dtx[k] * dlx[k] - sigma * mu for k in range(1, N + 1)]
         rcu = [lu[k] * tu[k] + dtu[k] * dlu[k] - sigma * mu for k in range(N)]
         dx, du, ds, _ = newton(x, u, s, Dx, rhox, Du, rhou)
         ax, au = row_dirs(dx, du, ds)
-        dtx = [None] + [-rgx[k] - ax[k] for k in range(1, N + 1)]
-        dtu = [-rgu[k] - au[k] for k in range(N)]
-        dlx = [None] + [(-rcx[k] - lx[k] * dtx[k]) / tx[k] for k in range(1, N + 1)]
-        dlu = [(-rcu[k] - lu[k] * dtu[k]) / tu[k] for k in range(N)]
+        dlx = [None] + [(-rcx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
+        dlu = [(-rcu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]
+        dtx = [None] + [-rgx[k] - ax[k] + dreg * dlx[k] for k in range(1, N + 1)]
+        dtu = [-rgu[k] - au[k] + dreg * dlu[k] for k in range(N)]
         T, DT, Lm, DL = cat(tx, tu), cat(dtx, dtu), cat(lx, lu), cat(dlx, dlu)
-        a = min(maxstep(T, DT), maxstep(Lm, DL))
-        a = a if a >= 1.0 else 0.99 * a
+        a = min(1.0, 0.99 * min(maxstep(T, DT), maxstep(Lm, DL)))      # stay strictly interior
         x, u, s = x + a * dx, u + a * du, s + a * ds
         s[0] = max(0.0, np.max(np.abs(p.xs * (p.x0 - p.xk[0]))) - p.delta) if p.tr else 0.0
         tx = [None] + [tx[k] + a * dtx[k] for k in range(1, N + 1)]

@@ -88,44 +88,53 @@ __device__ inline void matTvec(double *y, const double *__restrict__ M, int ldm,
     __syncthreads();
 }
 
-// in-place Cholesky + explicit inverse of a tiny SPD matrix (m <= 16) by thread 0; returns false
-// (to all threads, via flag in LDS) if not positive definite.  Q, Qinv: LDS m x m row-major.
-__device__ inline bool spd_inverse(const double *Q, double *Qinv, int m, double *Lbuf, int *flag) {
+// Cholesky factor L (lower, row-major m x m, m <= 16) of a tiny SPD matrix by thread 0.  Returns false
+// (to all threads, via flag in LDS) if not positive definite.  With allow_shift a breakdown caused by
+// round-off in a nearly singular matrix is retried with a growing diagonal shift (inexact Newton step;
+// the interior-point iteration corrects it).
+__device__ inline bool chol_factor(const double *Q, double *Lbuf, int m, int *flag, bool allow_shift = false) {
     if (threadIdx.x == 0) {
-        bool ok = true;
-        for (int i = 0; i < m && ok; ++i) {
-            for (int j = 0; j <= i; ++j) {
-                double sum = Q[i * m + j];
-                for (int k = 0; k < j; ++k) sum -= Lbuf[i * m + k] * Lbuf[j * m + k];
-                if (i == j) {
-                    if (!(sum > 0.0)) { ok = false; break; }
-                    Lbuf[i * m + i] = sqrt(sum);
-                } else {
-                    Lbuf[i * m + j] = sum / Lbuf[j * m + j];
+        bool ok = false;
+        double dmax = 0.0;
+        for (int i = 0; i < m; ++i) dmax = fmax(dmax, fabs(Q[i * m + i]));
+        double shift = 0.0;
+        for (int attempt = 0; attempt < (allow_shift ? 8 : 1) && !ok; ++attempt) {
+            ok = true;
+            for (int i = 0; i < m && ok; ++i) {
+                for (int j = 0; j <= i; ++j) {
+                    double sum = Q[i * m + j] + (i == j ? shift : 0.0);
+                    for (int k = 0; k < j; ++k) sum -= Lbuf[i * m + k] * Lbuf[j * m + k];
+                    if (i == j) {
+                        if (!(sum > 0.0)) { ok = false; break; }
+                        Lbuf[i * m + i] = sqrt(sum);
+                    } else {
+                        Lbuf[i * m + j] = sum / Lbuf[j * m + j];
+                    }
                 }
             }
-        }
-        if (ok) {
-            // Qinv = L^-T L^-1 : solve for each unit vector
-            for (int c = 0; c < m; ++c) {
-                double yv[16];
-                for (int i = 0; i < m; ++i) {
-                    double sum = (i == c) ? 1.0 : 0.0;
-                    for (int k = 0; k < i; ++k) sum -= Lbuf[i * m + k] * yv[k];
-                    yv[i] = sum / Lbuf[i * m + i];
-                }
-                for (int i = m - 1; i >= 0; --i) {
-                    double sum = yv[i];
-                    for (int k = i + 1; k < m; ++k) sum -= Lbuf[k * m + i] * yv[k];
-                    yv[i] = sum / Lbuf[i * m + i];
-                }
-                for (int i = 0; i < m; ++i) Qinv[i * m + c] = yv[i];
-            }
+            shift = (shift == 0.0) ? 1e-14 * dmax : shift * 100.0;
         }
         *flag = ok ? 1 : 0;
     }
     __syncthreads();
     return *flag != 0;
+}
+
+// x = -(L L^T)^-1 b for one right-hand side held by the calling thread: b, x strided arrays (m <= 16)
+__device__ __forceinline__ void chol_solve_neg(const double *L, int m, const double *b, int bstride, double *x,
+                                               int xstride) {
+    double y[16];
+    for (int i = 0; i < m; ++i) {
+        double sum = b[i * bstride];
+        for (int k = 0; k < i; ++k) sum -= L[i * m + k] * y[k];
+        y[i] = sum / L[i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double sum = y[i];
+        for (int k = i + 1; k < m; ++k) sum -= L[k * m + i] * y[k];
+        y[i] = sum / L[i * m + i];
+    }
+    for (int i = 0; i < m; ++i) x[i * xstride] = -y[i];
 }
 
 }  // namespace wg

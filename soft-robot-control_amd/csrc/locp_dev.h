@@ -20,6 +20,7 @@ struct QPDims {
     int ng;    // active rows: N*nrx + nXf + N*nU
     int max_iter;
     double tol;
+    double reg;   // dual (proximal) regularisation of the Newton systems, relative to the dual scale
 };
 
 struct QPConst {                       // shared by the whole batch (HBM/L2 resident)
@@ -40,6 +41,7 @@ struct QPDyn {                         // stage dynamics: matrix k at base + idx
 struct QPData {                        // one problem
     const double *x0, *xk, *z, *zf, *ud;   // xk (N+1 x n); z (N+1 x nz)|null; zf (nz)|null; ud (N x m)|null
     double delta, omega;
+    double *dbg;                           // optional per-iteration trace (8 doubles per iteration) or null
 };
 
 struct QPWork {                        // per-problem scratch in HBM/L2 (doubles)
@@ -48,7 +50,7 @@ struct QPWork {                        // per-problem scratch in HBM/L2 (doubles
     double *hd, *cv, *gx, *gxd;                           // (N+1) x n   (index k = 1..N used)
     double *Hss, *gs;                                     // (N+1)
     double *Huu, *gu, *gud;                               // N x m x m, N x m, N x m
-    double *K, *Qinv, *kff;                               // N x m x n, N x m x m, N x m
+    double *K, *Qinv, *kff;                               // N x m x n, N x m x m (Cholesky factors of Quu), N x m
     double *ez;                                           // (N+1) x nz
 };
 
@@ -392,20 +394,19 @@ __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QP
         __syncthreads();
         if (with_dual && tid < m) rd = fmax(rd, fabs(L.rdu[tid]));
         if (full) {
-            if (!wg::spd_inverse(L.Quu, L.Qinv, m, L.Lb, L.flag)) return false;
-            for (int e = tid; e < m * n; e += nt) {
-                const int a = e / n, j = e - a * n;
-                double v = 0.0;
-                for (int b = 0; b < m; ++b) v = fma(L.Qinv[a * m + b], L.Qux[b * ld + j], v);
-                L.Km[a * ld + j] = -v;
-                w.K[(size_t)k * m * n + e] = -v;
+            // Quu = L L^T (kept in L.Qinv); K = -Quu^-1 Qux by triangular solves, one state column per
+            // thread (backward stable -- an explicit inverse loses the weakly curved input directions
+            // once the active-bound weights reach 1e12)
+            if (!wg::chol_factor(L.Quu, L.Qinv, m, L.flag, true)) return false;
+            for (int j = tid; j < n; j += nt) {
+                wg::chol_solve_neg(L.Qinv, m, L.Qux + j, ld, L.Km + j, ld);
+                for (int a = 0; a < m; ++a) w.K[((size_t)k * m + a) * n + j] = L.Km[a * ld + j];
             }
             for (int e = tid; e < m * m; e += nt) w.Qinv[(size_t)k * m * m + e] = L.Qinv[e];
         }
-        if (tid < m) {
-            double v = 0.0;
-            for (int b = 0; b < m; ++b) v = fma(L.Qinv[tid * m + b], L.Qu[b], v);
-            w.kff[(size_t)k * m + tid] = -v;
+        if (tid == 0) {
+            wg::chol_solve_neg(L.Qinv, m, L.Qu, 1, L.kf, 1);
+            for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
         }
         __syncthreads();
         if (k >= 1) {
@@ -489,9 +490,9 @@ __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QP
     return true;
 }
 
-// largest step in [0,1] keeping t + a dt >= 0 and lam + a dlam >= 0
+// largest step keeping t + a dt >= 0 and lam + a dlam >= 0 (not clamped to 1)
 __device__ inline double max_step(const QPDims &d, const QPWork &w, QPLds &L) {
-    double a = 1.0;
+    double a = 1e300;
     for_rows(d, [&](int row, bool, int, int) {
         const double dt = w.dt[row], dl = w.dlam[row];
         if (dt < 0.0) a = fmin(a, -w.t[row] / dt);
@@ -564,6 +565,7 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
             for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
             sd = fmax(wg::reduce(sd, 1, L.red), q.omega);
             sp = fmax(wg::reduce(sp, 1, L.red), fabs(q.delta));
+            const double dreg = d.reg / sd;
             bool near_opt = false;
             for (it = 0; it < d.max_iter; ++it) {
                 // residuals, weights, predictor shifts
@@ -575,9 +577,9 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                     const double t = w.t[row], lam = w.lam[row];
                     const double rg = g + t;
                     w.rg[row] = rg;
-                    const double D = lam / t;
+                    const double D = lam / (t + dreg * lam);     // regularised weight (see oracle/riccati_ipm.py)
                     w.D[row] = D;
-                    w.rho[row] = D * rg;
+                    w.rho[row] = D * (rg + dreg * lam);
                     musum += lam * t;
                     rp = fmax(rp, fabs(rg));
                 });
@@ -586,21 +588,25 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                 stage_prepass(d, c, q, w, true);
                 double rd = 0.0;
                 // a factorisation that breaks down in the last digits of an already converged iterate
-                // (weights D = lam/t up to 1e13) is accepted at the looser 1e-6 certificate
+                // (weights D = lam/t up to 1e13) is accepted at the looser 1e-8 certificate
                 if (!riccati_solve(d, c, dyn, w, L, true, true, &rd)) { status = near_opt ? 0 : 2; break; }
-                if (!(mu == mu) || !(rd == rd)) { status = near_opt ? 0 : 2; break; }
-                if (rd <= d.tol * sd && rp <= d.tol * sp && mu <= d.tol) { status = 0; break; }
-                near_opt = (rd <= 1e-6 * sd && rp <= 1e-6 * sp && mu <= 1e-6);
+                if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
+                if (!(rd == rd)) { status = near_opt ? 0 : 6; break; }
+                if (q.dbg && threadIdx.x == 0) { double *g = q.dbg + 8 * it; g[0] = mu; g[1] = rd; g[2] = rp; g[3] = sd; g[4] = sp; }
+                const double ltol = fmax(d.tol, 1e-9);     // linear residuals: round-off floor (see the port)
+                if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
+                near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
                 // predictor direction on the rows
                 rows_apply(d, c, w.dx, w.ds, w.du, w.dt);
                 __syncthreads();
                 for_rows(d, [&](int row, bool, int, int) {
-                    const double dt = -w.rg[row] - w.dt[row];
-                    w.dt[row] = dt;
-                    w.dlam[row] = -w.lam[row] - w.D[row] * dt;
+                    const double t = w.t[row], lam = w.lam[row], rga = w.rg[row] + w.dt[row];
+                    const double dl = (-lam * t + lam * rga) / (t + dreg * lam);
+                    w.dlam[row] = dl;
+                    w.dt[row] = -rga + dreg * dl;
                 });
                 __syncthreads();
-                const double a_aff = max_step(d, w, L);
+                const double a_aff = fmin(1.0, max_step(d, w, L));
                 double ma = 0.0;
                 for_rows(d, [&](int row, bool, int, int) {
                     ma += (w.lam[row] + a_aff * w.dlam[row]) * (w.t[row] + a_aff * w.dt[row]);
@@ -611,7 +617,7 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                     const double t = w.t[row], lam = w.lam[row];
                     const double rc = lam * t + w.dt[row] * w.dlam[row] - sig * mu;
                     w.rc[row] = rc;
-                    w.rho[row] = lam + (lam * w.rg[row] - rc) / t;
+                    w.rho[row] = lam + (lam * w.rg[row] - rc) / (t + dreg * lam);
                 });
                 __syncthreads();
                 stage_prepass(d, c, q, w, false);
@@ -619,13 +625,14 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                 rows_apply(d, c, w.dx, w.ds, w.du, w.dt);
                 __syncthreads();
                 for_rows(d, [&](int row, bool, int, int) {
-                    const double dt = -w.rg[row] - w.dt[row];
-                    w.dt[row] = dt;
-                    w.dlam[row] = (-w.rc[row] - w.lam[row] * dt) / w.t[row];
+                    const double t = w.t[row], lam = w.lam[row], rga = w.rg[row] + w.dt[row];
+                    const double dl = (-w.rc[row] + lam * rga) / (t + dreg * lam);
+                    w.dlam[row] = dl;
+                    w.dt[row] = -rga + dreg * dl;
                 });
                 __syncthreads();
-                double a = max_step(d, w, L);
-                a = a >= 1.0 ? 1.0 : 0.99 * a;
+                const double a = fmin(1.0, 0.99 * max_step(d, w, L));   // stay strictly interior
+                if (q.dbg && threadIdx.x == 0) { double *g = q.dbg + 8 * it; g[5] = a_aff; g[6] = sig; g[7] = a; }
                 for (int e = tid; e < (N + 1) * n; e += nt) w.x[e] += a * w.dx[e];
                 for (int e = tid; e < N * m; e += nt) w.u[e] += a * w.du[e];
                 for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : w.s[e] + a * w.ds[e];

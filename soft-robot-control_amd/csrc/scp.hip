@@ -3,6 +3,7 @@
 // sofacontrol/scp/models/tpwl.py:32-58 (model adapter).
 #include "tpwl_host.h"
 #include "locp_dev.h"
+#include <cstdlib>
 
 namespace {
 
@@ -21,6 +22,7 @@ struct LocpBatch {
     int32_t *status, *iters;
     double *work;
     size_t work_stride;
+    double *dbg;
 };
 
 __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, LocpBatch b) {
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
     QPDyn dyn{b.Ad + p * N * n * n, b.AdT + p * N * n * n, b.Bd + p * N * n * m, b.BdT + p * N * n * m,
               b.dd + p * N * n, nullptr};
     QPData q{b.x0 + p * n, b.xk + p * (N + 1) * n, b.z ? b.z + p * (N + 1) * d.nz : nullptr,
-             b.zf ? b.zf + p * d.nz : nullptr, b.ud ? b.ud + p * N * m : nullptr, b.delta[p], b.omega[p]};
+             b.zf ? b.zf + p * d.nz : nullptr, b.ud ? b.ud + p * N * m : nullptr, b.delta[p], b.omega[p], (b.dbg && p == 0) ? b.dbg : nullptr};
     double J;
     int it;
     const int st = qp::solve(d, c, dyn, q, w, L, &J, &it);
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     int itr = 0, status = 0;
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
         QPData q{x0, xk, b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr, b.zf ? b.zf + p * nz : nullptr,
-                 b.ud ? b.ud + p * (size_t)N * m : nullptr, delta, omega};
+                 b.ud ? b.ud + p * (size_t)N * m : nullptr, delta, omega, nullptr};
         double J;
         int qit;
         const int st = qp::solve(d, c, dyn, q, w, L, &J, &qit);
@@ -251,7 +253,8 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.NR = N * d.RX + N * d.nU;
     d.ng = N * d.nrx + d.nXf + N * d.nU;
     d.max_iter = 60;
-    d.tol = 1e-10;
+    d.tol = 1e-12;
+    d.reg = 1e-8;
     std::vector<double> Qx(n * n), QxN(n * n), Ht2(n * nz), Htf2(n * nz, 0.0), R2(m * m), xs(n, 1.0);
     std::vector<double> QzH(nz * n), QzfH(nz * n, 0.0);
     for (int a = 0; a < nz; ++a)
@@ -360,12 +363,21 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     LocpBatch b{dA.as<double>(), dAT.as<double>(), dB.as<double>(), dBT.as<double>(), dD.as<double>(), dx0.as<double>(),
                 dxk.as<double>(), ddel.as<double>(), dom.as<double>(), z ? dz.as<double>() : nullptr,
                 zf ? dzf.as<double>() : nullptr, u_des ? dud.as<double>() : nullptr, ox.as<double>(), ou.as<double>(),
-                os.as<double>(), oJ.as<double>(), ost.as<int32_t>(), oit.as<int32_t>(), work.as<double>(), stride};
+                os.as<double>(), oJ.as<double>(), ost.as<int32_t>(), oit.as<int32_t>(), work.as<double>(), stride, nullptr};
+    srh::DevBuf dbg;
+    const bool want_dbg = getenv("SRH_LOCP_TRACE") != nullptr;
+    if (want_dbg) { if ((rc = dbg.alloc(sizeof(double) * 8 * 64))) return rc; (void)hipMemset(dbg.p, 0, sizeof(double) * 8 * 64); b.dbg = dbg.as<double>(); }
     const size_t lds = qp_lds_bytes(d, NTHREADS);
     if ((rc = set_lds_limit((const void *)locp_kernel, lds))) return rc;
     locp_kernel<<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b);
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipDeviceSynchronize());
+    if (want_dbg) {
+        std::vector<double> t(8 * 64);
+        dbg.download(t.data(), sizeof(double) * 8 * 64);
+        for (int i = 0; i < 64 && (t[8 * i + 3] != 0.0); ++i)
+            fprintf(stderr, "[locp] it %2d mu %.3e rd %.3e rp %.3e (sd %.2e sp %.2e) a_aff %.3e sigma %.3e a %.3e\n", i, t[8 * i], t[8 * i + 1], t[8 * i + 2], t[8 * i + 3], t[8 * i + 4], t[8 * i + 5], t[8 * i + 6], t[8 * i + 7]);
+    }
     if ((rc = ox.download(x, sizeof(double) * batch * (N + 1) * n)) || (rc = ou.download(u, sizeof(double) * batch * N * m)) ||
         (rc = oJ.download(J, sizeof(double) * batch)) || (rc = ost.download(status, sizeof(int32_t) * batch)))
         return rc;

@@ -1,5 +1,10 @@
 """GPU parity: the LOCP QP kernel through the C ABI against the exact oracle solution.
-Tolerance (north star): <= 1e-4 relative on trajectories, 1e-7 relative on the optimal cost."""
+Tolerance (north star): <= 1e-4 relative on trajectories, 1e-7 relative on the optimal cost.
+
+Both sides stop at the same complementarity gap (1e-12): with R = 1e-5 against Qz = 100 and weakly
+active bounds the minimiser is only determined to ~1e-3 in the flat input directions by ANY solver at
+that gap ("QP conditioning"), so the comparison is made at equal tolerance, where the
+independent sparse solver and the kernel land on the same central-path point."""
 import numpy as np
 import pytest
 
@@ -18,7 +23,7 @@ def oracle_solution(case):
     qp = olocp.build_qp(case['N'], case['H'], case['Qz'], case['R'], case['Ad'], case['Bd'], case['dd'], case['x0'],
                         case['xk'], case['delta'], case['omega'], z=case['z'], Qzf=case.get('Qzf'), zf=case.get('zf'),
                         U=case['U'], X=case['X'], x_scale=case['x_scale'])
-    w, _, info = olocp.solve_exact(qp, tol=1e-11)
+    w, _, info = olocp.solve_exact(qp, tol=1e-12)
     assert info.get('status', 'optimal') == 'optimal'
     return olocp.split(qp, w), olocp.objective(qp, w)
 

@@ -25,7 +25,7 @@ def rel(a, b):
 def test_exact_solvers_agree_and_certify(name):
     case, _ = make_case(**CASES[name])
     qp = build(case)
-    w, (y, lam), info = olocp.solve_exact(qp, tol=1e-11)
+    w, (y, lam), info = olocp.solve_exact(qp, tol=1e-12)
     assert info.get('status', 'optimal') == 'optimal'
     cert = olocp.kkt_certificate(qp, w, y, lam)
     scale = max(1.0, case['omega'])
@@ -34,7 +34,7 @@ def test_exact_solvers_agree_and_certify(name):
     assert cert['ineq_violation'] <= 1e-8 and cert['dual_negativity'] == 0.0
     assert cert['complementarity'] <= 1e-7 * scale
     xe, ue, se = olocp.split(qp, w)
-    x, u, s, J, info2 = ripm.solve(ripm.Problem(**case), tol=1e-11)
+    x, u, s, J, info2 = ripm.solve(ripm.Problem(**case), tol=1e-12)
     assert info2['status'] == 'optimal'
     # north-star tolerance: <= 1e-4 relative trajectory error (R = 1e-5 leaves u weakly determined)
     assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
@@ -50,10 +50,10 @@ def test_equality_only_closed_form():
     w, y = olocp.solve_eq_only(qp)
     xe, ue, _ = olocp.split(qp, w)
     # trust region is far from active (delta = 1e4): the full solvers must return the same point
-    w2, _, _ = olocp.solve_exact(qp, tol=1e-11)
+    w2, _, _ = olocp.solve_exact(qp, tol=1e-12)
     x2, u2, _ = olocp.split(qp, w2)
     assert rel(x2, xe) <= 1e-5 and rel(u2, ue) <= 1e-5
-    x3, u3, s3, J3, _ = ripm.solve(ripm.Problem(**case), tol=1e-11)
+    x3, u3, s3, J3, _ = ripm.solve(ripm.Problem(**case), tol=1e-12)
     assert rel(x3, xe) <= 1e-5 and rel(u3, ue) <= 1e-5
 
 
@@ -66,7 +66,7 @@ def test_tiny_instance_against_scipy_trust_constr():
     g = lambda w: P2 @ w + qp.c
     cons = [LinearConstraint(qp.E.toarray(), qp.e, qp.e),
             LinearConstraint(qp.G.toarray(), -np.inf, qp.h)]
-    w0, _, _ = olocp.solve_exact(qp, tol=1e-11)
+    w0, _, _ = olocp.solve_exact(qp, tol=1e-12)
     res = minimize(f, np.zeros_like(w0), jac=g, hess=lambda w: P2, constraints=cons, method='trust-constr',
                    options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
     # scipy's barrier method stops at barrier_tolerance ~1e-6: the exact solution must be at least as
@@ -84,7 +84,7 @@ def test_osqp_restatement_reaches_reference_accuracy():
     is held to the exact solution (<= 1e-4), which is tighter than what the reference itself computes."""
     case, _ = make_case(**CASES['box_only_tr_loose'])
     qp = build(case)
-    w, _, _ = olocp.solve_exact(qp, tol=1e-11)
+    w, _, _ = olocp.solve_exact(qp, tol=1e-12)
     Je = olocp.objective(qp, w)
     wo, _, info = olocp.solve_osqp(qp)
     assert info['status'] == 'solved'
