@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the sofacontrol hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+One "step" = one pass of the hot path over one batch of synthetic input, per GPU:
+  1. POD projection of a resident batch of full-order FEM snapshots  X (B x n_f) -> (B x r)
+     (srom_project_dev; its launches are timed with HIP events for the HBM roofline), and
+  2. R independent receding-horizon SCP solves (GuSTO on the Diamond TPWL ROM, r = 30, N = 50) started
+     from the projected states, all inside ONE persistent kernel launch (sgusto_plan_solve_dev).
+`value` = SCP iterations (LOCP solves) per second summed over rollouts and ranks; inputs are resident in
+HBM before the timed region.  Rank 0 at N = 1 also times the CPU port (oracle/) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import io
+import contextlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'soft-robot-control_amd'))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def build_model(w):
+    import scipy.sparse as sp
+    from sofacontrol_amd.tpwl.tpwl import TPWLATV
+    from sofacontrol_amd.scp.models.tpwl import TPWLGuSTO
+    n_f = w['U'].shape[0]
+    Hf = sp.lil_matrix((6, 2 * n_f))
+    for a in range(3):
+        Hf[a, 3 * 1354 + a] = 1.0
+        Hf[3 + a, n_f + 3 * 1354 + a] = 1.0
+    data = dict(w['tab'], rom_info=dict(type='POD', U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
+    tp = TPWLATV(data=data, params=dict(tpwl_method='nn', dist_weights={'q': 1.0, 'v': 0.0}), Hf=Hf.tocsr(),
+                 discr_method='zoh')
+    gm = TPWLGuSTO(tp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gm.pre_discretize(w['dt'])
+    return tp, gm
+
+
+def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows):
+    """The CPU port (oracle/: numpy restatement, reference op sequence) on a bounded sample."""
+    from oracle import gusto as ogusto, riccati_ipm as ripm, pod as opod, locp as olocp
+    import workloads as wl
+    model = dict(w['tab'], w_q=1.0, w_v=0.0)
+    N, m = w['N'], w['m']
+
+    def qp_solver(qp):
+        # stage-structured port of the kernel's algorithm (faster than the generic sparse oracle)
+        p = qp._stage_problem
+        x, u, s, J, info = ripm.solve(p)
+        return np.concatenate((x.ravel(), u.ravel(), s))
+    # oracle.gusto builds the stacked QP; hand the stage form to the port through a thin adaptor
+    orig_build = olocp.build_qp
+
+    def build_and_keep(Nn, H, Qz, R, Ad, Bd, dd, x0_, xk, delta, omega, **kw):
+        qp = orig_build(Nn, H, Qz, R, Ad, Bd, dd, x0_, xk, delta, omega, **kw)
+        qp._stage_problem = ripm.Problem(Nn, H, Qz, R, Ad, Bd, dd, x0_, xk, delta, omega, z=kw.get('z'),
+                                         u_des=kw.get('u_des'), Qzf=kw.get('Qzf'), zf=kw.get('zf'), U=kw.get('U'),
+                                         X=kw.get('X'), Xf=kw.get('Xf'), x_scale=kw.get('x_scale'))
+        return qp
+    olocp.build_qp = build_and_keep
+    try:
+        t0 = time.perf_counter()
+        iters = 0
+        for b in range(n_roll):
+            _, _, _, tr = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[b],
+                                       np.zeros((N, m)), x_init[b], z=z[b], U=(w['UA'], w['Ub']),
+                                       X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3,
+                                       qp_solver=qp_solver)
+            iters += len(tr)
+        t_scp = time.perf_counter() - t0
+    finally:
+        olocp.build_qp = orig_build
+    X = wl.snapshots(w['q_ref'], proj_rows, seed=2)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        opod.project(w['U'], w['q_ref'], X)
+    t_proj = (time.perf_counter() - t0) / reps
+    proj_gbs = (X.nbytes + w['U'].nbytes + w['q_ref'].nbytes + proj_rows * w['r'] * 8) / t_proj / 1e9
+    return dict(value=iters / t_scp, unit='SCP iterations/s', cores=os.cpu_count(), kind='port',
+                sample='%d rollout(s) of the same workload = %d SCP iterations in %.1f s (numpy port of the kernel '
+                       'algorithm inside the restated GuSTO loop); POD projection of %d snapshots: %.1f GB/s' %
+                       (n_roll, iters, t_scp, proj_rows, proj_gbs),
+                pod_projection_gbs=proj_gbs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--rollouts', type=int, default=256, help='independent SCP rollouts per GPU per step')
+    ap.add_argument('--proj-batch', type=int, default=65536, help='snapshots per GPU in the POD projection batch')
+    ap.add_argument('--proj-launches', type=int, default=4, help='projection launches per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    import workloads as wl
+    from sofacontrol_amd import _lib
+    from sofacontrol_amd.mor.pod import POD
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    from scipy.interpolate import interp1d
+
+    if _lib.device_count() < 1:
+        raise SystemExit('bench.py needs a GPU: libsofacontrol_hip.so has no CPU fallback')
+    _lib.set_device(local_rank)
+    L = _lib.lib()
+
+    w = wl.diamond_c2()
+    N, m, r, dt = w['N'], w['m'], w['r'], w['dt']
+    n, nz, n_f = 2 * r, 6, w['U'].shape[0]
+    R_, B = args.rollouts, args.proj_batch
+    rom = POD(dict(U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
+    tp, gm = build_model(w)
+    xc, fc = gm.get_characteristic_vals()
+
+    # ---- resident inputs (each rank its own shard: seeds offset by the rank)
+    X = wl.snapshots(w['q_ref'], B, seed=2 + 1000 * rank)
+    dX = _lib.DeviceBuffer.from_array(X)
+    dXr = _lib.DeviceBuffer(B * r * 8)
+    # initial reduced states of the rollouts: x0 = [0 ; U^T (q - q_ref)] of the first R snapshots
+    q0 = rom.compute_RO_state(qf=X[:R_])
+    x0 = np.concatenate((np.zeros((R_, r)), q0), axis=1)
+    del X
+    u_init = np.zeros((R_, N, m))
+    x_init, _ = tp.rollout(x0, u_init, dt)
+    zi = interp1d(w['t'], w['z'], axis=0, bounds_error=False, fill_value=(w['z'][0], w['z'][-1]))
+    phase = (np.arange(R_) + R_ * rank) * (10.0 / max(1, R_ * world))
+    z = np.stack([zi(phase[b] + dt * np.arange(N + 1)) for b in range(R_)])
+    gusto = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']),
+                  X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, batch=R_, max_trace=0)
+    d = {k: _lib.DeviceBuffer.from_array(v) for k, v in dict(x0=x0, u_init=u_init, x_init=x_init, z=z).items()}
+    o = dict(xopt=_lib.DeviceBuffer(R_ * (N + 1) * n * 8), uopt=_lib.DeviceBuffer(R_ * N * m * 8),
+             zopt=_lib.DeviceBuffer(R_ * (N + 1) * nz * 8), iters=_lib.DeviceBuffer(R_ * 4), status=_lib.DeviceBuffer(R_ * 4))
+    ev = [C.c_void_p() for _ in range(2 * args.proj_launches)]
+    for e in ev:
+        _lib.check(L.srh_event_create(C.byref(e)), 'event')
+
+    def step(timed):
+        for i in range(args.proj_launches):
+            if timed:
+                L.srh_event_record(ev[2 * i], None)
+            _lib.check(L.srom_project_dev(rom.handle, 0, dX.ptr, C.c_int64(B), C.c_int64(n_f), dXr.ptr, C.c_int64(r), None), 'project')
+            if timed:
+                L.srh_event_record(ev[2 * i + 1], None)
+        _lib.check(L.sgusto_plan_solve_dev(gusto.plan, d['x0'].ptr, d['u_init'].ptr, d['x_init'].ptr, d['z'].ptr, None, None,
+                                           o['xopt'].ptr, o['uopt'].ptr, o['zopt'].ptr, o['iters'].ptr, o['status'].ptr,
+                                           None, None), 'gusto')
+
+    def barrier():
+        _lib.sync()
+        if dist is not None:
+            dist.barrier()
+        _lib.sync()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    proj_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        _lib.sync()
+        for i in range(args.proj_launches):
+            ms = C.c_float()
+            L.srh_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms))
+            proj_ms.append(ms.value)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    iters = o['iters'].to_array((R_,), dtype=np.int32)
+    status = o['status'].to_array((R_,), dtype=np.int32)
+    it_per_step = int(iters.sum())
+    total_iters = it_per_step * args.steps
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed, float(total_iters)], dtype=torch.float64, device='cuda')
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_iters = float(t[1])
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    alg_bytes = B * n_f * 8 + n_f * r * 8 + n_f * 8 + B * r * 8
+    avg_ms = float(np.mean(proj_ms))
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    out = {
+        'metric': 'SCP iterations/sec (Diamond r=30 H=50) + POD projection GB/s vs HBM roofline',
+        'value': total_iters / elapsed, 'unit': 'SCP iterations/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'C2: Diamond n_f=4884, POD r=30 (n_x=60, n_u=4), TPWL P=64 nn/zoh, SCP horizon N=50 '
+                               'dt=0.05, U box + X box, figure-8 target; %d independent receding-horizon rollouts per GPU '
+                               'per step + POD projection of %d snapshots x %d launches' % (R_, B, args.proj_launches),
+                   'rollouts_per_gpu': R_, 'proj_batch': B, 'scp_iters_per_step_rank0': it_per_step,
+                   'solves_not_converged_rank0': int((status != 0).sum())},
+        'roofline': {'kernel': 'proj_kernel (srom_project_dev)', 'bound': 'hbm', 'achieved': achieved,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': alg_bytes},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=min(R_, 4), proj_rows=4096)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -41,6 +41,7 @@ def golden_problem(r, m, P, n_nodes, seed, q_scale=1.0):
     return model, U, q_ref, v_ref, Hf
 
 
-class Poly:
-    def __init__(self, A, b):
-        self.A, self.b = np.asarray(A, float), np.asarray(b, float)
+def Poly(A, b):
+    """The product's Polyhedron (same protocol as sofacontrol/utils.py:364-398)."""
+    from sofacontrol_amd.utils import Polyhedron
+    return Polyhedron(A, b)

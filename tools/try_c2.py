@@ -1,0 +1,46 @@
+import sys, os, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'soft-robot-control_amd'))
+import numpy as np, io, contextlib
+import workloads as wl
+from sofacontrol_amd.tpwl.tpwl import TPWLATV
+from sofacontrol_amd.scp.models.tpwl import TPWLGuSTO
+from sofacontrol_amd.scp.standalone import GuSTOSolverNode
+from sofacontrol_amd.utils import Polyhedron
+import scipy.sparse as sp
+kw = {}
+for a in sys.argv[1:]:
+    k, v = a.split('='); kw[k] = float(v)
+w = wl.diamond_c2()
+if kw:
+    w['tab'] = wl.tpwl_tables(30, 4, 64, seed=10, **kw); 
+n_f = 4884
+Hf = sp.lil_matrix((6, 2 * n_f))
+for a in range(3):
+    Hf[a, 3 * 1354 + a] = 1.0; Hf[3 + a, n_f + 3 * 1354 + a] = 1.0
+data = dict(w['tab'], rom_info=dict(type='POD', U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
+tp = TPWLATV(data=data, params=dict(tpwl_method='nn', dist_weights={'q': 1.0, 'v': 0.0}), Hf=Hf.tocsr(), discr_method='zoh')
+gm = TPWLGuSTO(tp)
+with contextlib.redirect_stdout(io.StringIO()):
+    gm.pre_discretize(w['dt'])
+x0 = np.zeros(60)
+t0 = time.time()
+node = GuSTOSolverNode(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, t=w['t'], z=w['z'], U=Polyhedron(w['UA'], w['Ub']),
+                       X=Polyhedron(w['XA'], w['Xb']), verbose=1, warm_start=True, convg_thresh=1e-3, max_trace=64)
+t1 = time.time()
+xo, uo, zo, to = node.get_solution()
+g = node.gusto
+print('first solve: iters', g.iters, 'status', g.status, 'time %.3f s' % (t1 - t0))
+print('trace J,delta,omega,rho:\n', g.trace[0, :int(g.iters[0])])
+print('u range', uo.min(), uo.max(), 'z range', zo[:, 3:5].min(0), zo[:, 3:5].max(0))
+zt, _, _ = node.get_target(0.0)
+print('tracking err max', np.abs(zo[:, 3:5] - zt[:, 3:5]).max())
+idx = tp.calc_nearest_point(xo)
+print('regions visited', np.unique(idx))
+# receding horizon
+tot_it = 0; t2 = time.time()
+for k in range(1, 11):
+    tt, xo, uo, zo, ts = node.gusto_callback(k * 10 * 0.01, xo[2] if False else node.xopt[2])
+    tot_it += int(g.iters[0])
+    print('replan', k, 'iters', int(g.iters[0]), 'status', int(g.status[0]), 'time %.4f' % ts)
+print('10 replans: %d SCP iterations in %.3f s' % (tot_it, time.time() - t2))
