@@ -39,8 +39,8 @@ def tip_selector_rows(U, node):
     return H
 
 
-def tpwl_tables(r, m, P, seed=10, q_spread=300.0, v_spread=300.0, b_scale=40.0, u_max=1500.0, k_var=0.02,
-                b_var=0.01, d_scale=0.05, s_scale=0.2):
+def tpwl_tables(r, m, P, seed=10, q_spread=300.0, v_spread=300.0, b_scale=40.0, u_max=1500.0, k_var=0.005,
+                b_var=0.003, d_scale=0.01, s_scale=0.05):
     """P linearisation points of a lightly damped second-order reduced model
     A_c = [[-(alpha I + beta K_i), -K_i], [I, 0]] with Rayleigh damping alpha = 2.5, beta = 0.01
     (examples/hardware/model.py:14-15), K_i = diag(U(50,500)) + symmetric perturbation."""
