@@ -12,8 +12,9 @@
 
 struct QPDims {
     int N, n, m, nz, nU, nX, nXf, tr;
-    int ld;    // leading dimension of n x n LDS matrices (multiple of 4)
-    int mp;    // leading dimension of n x m LDS matrices (multiple of 4)
+    int ld;    // leading dimension of the LDS matrices = NPa = roundup16(n + m)
+    int mp;    // unused (kept for layout stability)
+    int NK;    // roundup4(n): K extent of the MFMA products (zero padded rows)
     int nrx;   // inequality rows owned by x_k, k < N:  tr*(2n+1) + nX
     int RX;    // row stride per x stage: nrx + nXf
     int NR;    // total rows: N*RX + N*nU
@@ -77,35 +78,60 @@ __device__ inline void qp_carve(QPWork &w, double *base, const QPDims &d) {
 }
 
 struct QPLds {                         // LDS carve (doubles unless noted)
-    double *P, *W, *A;                 // n x ld each
-    double *B, *G;                     // n x mp
-    double *Qux, *Km;                  // m x ld
-    double *Quu, *Qinv, *Lb;           // m x m
-    double *pv, *adj, *v1, *v2, *v3;   // n each
-    double *Qu, *kf, *rdu;             // m each (padded)
+    double *P;                         // ld x ld : cost-to-go P_{k+1}, then the stage Gram matrix M = [A|B]^T P [A|B]
+    double *AB;                        // roundup16(n) x ld : [A_k | B_k], zero padded
+    double *W;                         // roundup16(n) x ld : P [A_k | B_k]
+    double *Km;                        // m x ld  : feedback gain of the stage
+    double *Quu, *Lc;                  // 16 x 16 : Quu and its Cholesky factor
+    double *pv, *adj, *v1, *v2, *hdv, *cvv;   // ld each
+    double *ypv, *yadj;                // ld each : [A|B]^T pv, [A|B]^T adj
+    double *Qu, *kf, *rdu;             // 16 each
+    double *Hm;                        // nz x ld : H
+    double *HtQ;                       // ld x 16 : 2 H^T Qz
+    double *XAl;                       // (nX + nXf) x ld
+    double *Dx;                        // 32      : X-row weights of the stage
     double *part;                      // blockDim
     double *red;                       // 16
     int *flag;                         // 4 ints
 };
 
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
-    size_t c = 3 * (size_t)d.n * d.ld + 2 * (size_t)d.n * d.mp + 2 * (size_t)d.m * d.ld + 3 * 16 * 16 +
-               5 * (size_t)d.ld + 3 * 16 + nthreads + 16 + 4;
+    const size_t nk16 = (size_t)((d.n + 15) & ~15);   // W / AB rows: whole MFMA tiles are stored
+    size_t c = (size_t)d.ld * d.ld + 2 * nk16 * d.ld + (size_t)d.m * d.ld + 2 * 256 + 8 * (size_t)d.ld + 3 * 16 +
+               (size_t)d.nz * d.ld + (size_t)d.ld * 16 + (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4;
     return c * sizeof(double);
 }
 
 __device__ inline void qp_lds_carve(QPLds &L, double *base, const QPDims &d, int nthreads) {
     double *p = base;
     auto take = [&](size_t c) { double *q = p; p += c; return q; };
-    L.P = take((size_t)d.n * d.ld); L.W = take((size_t)d.n * d.ld); L.A = take((size_t)d.n * d.ld);
-    L.B = take((size_t)d.n * d.mp); L.G = take((size_t)d.n * d.mp);
-    L.Qux = take((size_t)d.m * d.ld); L.Km = take((size_t)d.m * d.ld);
-    L.Quu = take(256); L.Qinv = take(256); L.Lb = take(256);
-    L.pv = take(d.ld); L.adj = take(d.ld); L.v1 = take(d.ld); L.v2 = take(d.ld); L.v3 = take(d.ld);
+    const size_t nk16 = (size_t)((d.n + 15) & ~15);
+    L.P = take((size_t)d.ld * d.ld); L.AB = take(nk16 * d.ld); L.W = take(nk16 * d.ld);
+    L.Km = take((size_t)d.m * d.ld);
+    L.Quu = take(256); L.Lc = take(256);
+    L.pv = take(d.ld); L.adj = take(d.ld); L.v1 = take(d.ld); L.v2 = take(d.ld); L.hdv = take(d.ld); L.cvv = take(d.ld);
+    L.ypv = take(d.ld); L.yadj = take(d.ld);
     L.Qu = take(16); L.kf = take(16); L.rdu = take(16);
+    L.Hm = take((size_t)d.nz * d.ld); L.HtQ = take((size_t)d.ld * 16);
+    L.XAl = take((size_t)(d.nX + d.nXf) * d.ld);
+    L.Dx = take(32);
     L.part = take(nthreads);
     L.red = take(16);
     L.flag = reinterpret_cast<int *>(take(4));
+}
+
+// one-off per kernel: constants into LDS, zero the padding of the MFMA operands
+__device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) {
+    const int tid = threadIdx.x, nt = blockDim.x, n = d.n, ld = d.ld;
+    for (int e = tid; e < d.ld * d.ld; e += nt) L.P[e] = 0.0;
+    for (int e = tid; e < ((d.n + 15) & ~15) * d.ld; e += nt) { L.AB[e] = 0.0; L.W[e] = 0.0; }
+    for (int e = tid; e < d.nz * n; e += nt) { const int a = e / n, j = e - a * n; L.Hm[a * ld + j] = c.H[e]; }
+    for (int e = tid; e < n * d.nz; e += nt) { const int i = e / d.nz, a = e - i * d.nz; L.HtQ[i * 16 + a] = c.HtQz2[e]; }
+    for (int e = tid; e < (d.nX + d.nXf) * n; e += nt) {
+        const int r = e / n, j = e - r * n;
+        L.XAl[r * ld + j] = r < d.nX ? c.XA[(size_t)r * n + j] : c.XfA[(size_t)(r - d.nX) * n + j];
+    }
+    __syncthreads();
 }
 
 namespace qp {
@@ -320,137 +346,213 @@ __device__ inline void stage_prepass(const QPDims &d, const QPConst &c, const QP
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ f64 MFMA product on LDS operands
+typedef double qp_d4 __attribute__((ext_vector_type(4)));
+
+// C[i][j] = sum_{k<K} Lm[k][i] * Rm[k][j]  for i < 16*MT, j < 16*NTl.  Lm, Rm: k-major rows (K x ld) in
+// LDS, K a multiple of 4 (zero padded).  Rows i >= vrows of C are stored as exact zeros.
+// v_mfma_f64_16x16x4: A lane l holds Lm^T[i=l&15][k=l>>4], B lane holds Rm[k=l>>4][j=l&15];
+// D reg q of lane l is C[row = (l>>4) + 4q][col = l&15].
+__device__ inline void mfma_atb(double *C, const double *Lm, const double *Rm, int K, int MT, int NTl, int ld,
+                                int vrows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int ntiles = MT * NTl;
+    for (int t0 = wave; t0 < ntiles; t0 += 2 * nw) {
+        const int t1 = t0 + nw;
+        const bool has1 = t1 < ntiles;
+        const int ti0 = t0 / NTl, tj0 = t0 - ti0 * NTl;
+        const int ti1 = has1 ? t1 / NTl : ti0, tj1 = has1 ? t1 - ti1 * NTl : tj0;
+        const double *la0 = Lm + kk * ld + 16 * ti0 + l16, *rb0 = Rm + kk * ld + 16 * tj0 + l16;
+        const double *la1 = Lm + kk * ld + 16 * ti1 + l16, *rb1 = Rm + kk * ld + 16 * tj1 + l16;
+        qp_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const double a0 = la0[k0 * ld], b0 = rb0[k0 * ld];
+            const double a1 = la1[k0 * ld], b1 = rb1[k0 * ld];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r0 = 16 * ti0 + kk + 4 * q;
+            C[r0 * ld + 16 * tj0 + l16] = r0 < vrows ? acc0[q] : 0.0;
+            if (has1) {
+                const int r1 = 16 * ti1 + kk + 4 * q;
+                C[r1 * ld + 16 * tj1 + l16] = r1 < vrows ? acc1[q] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// stage Hessian of x_k added to the (i,j) entry: Qx (+ terminal) + slack-eliminated trust region + X rows
+__device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, const QPLds &L, int k, int i, int j,
+                                             double Hss, int nxrows) {
+    double v = 0.0;
+    for (int a = 0; a < d.nz; ++a) v = fma(L.HtQ[i * 16 + a], L.Hm[a * d.ld + j], v);     // 2 H^T Qz H
+    if (k == d.N && c.Qzf) v += c.QxN[(size_t)i * d.n + j] - c.Qx[(size_t)i * d.n + j];
+    if (d.tr) {
+        if (i == j) v += L.hdv[i];
+        else v -= L.cvv[i] * L.cvv[j] / Hss;
+    }
+    for (int r = 0; r < nxrows; ++r) v = fma(L.XAl[r * d.ld + i] * L.Dx[r], L.XAl[r * d.ld + j], v);
+    return v;
+}
+
 // ------------------------------------------------------------------ Riccati solve of one Newton system
-// full = factorise (stores K_k, Quu_k^-1) and solve; !full = re-solve with new gradients only.
-// Returns false on a non-positive-definite Quu.  rd_out: max |reduced dual residual| (with_dual).
+// full = factorise (stores K_k and the Cholesky factor of Quu_k) and solve; !full = re-solve with new
+// gradients only.  Returns false on a non-positive-definite Quu.  rd_out: max |reduced dual residual|.
+//
+// Per stage (full): with AB = [A_k | B_k] (n x (n+m)) the two f64-MFMA products
+//     W = P_{k+1} AB            (n x (n+m))
+//     M = AB^T W = [[A^T P A, A^T P B], [B^T P A, B^T P B]]
+// give Qxx, Qux and Quu in one Gram matrix; P_k = sym(M_xx) + H_k + sym(Qux^T K) with K = -Quu^-1 Qux by
+// Cholesky solves.  P, AB, W stay in LDS for the whole horizon; A_k, B_k stream from the (L2 resident)
+// TPWL tables.
 __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, QPWork &w, QPLds &L,
                                      bool full, bool with_dual, double *rd_out) {
-    const int n = d.n, m = d.m, N = d.N, ld = d.ld, mp = d.mp;
+    const int n = d.n, m = d.m, N = d.N, ld = d.ld, NK = d.NK;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int xoff = d.tr ? 2 * n + 1 : 0;
     double rd = 0.0;
     // ---- terminal stage
     {
         const int k = N;
+        const int nxrows = d.nX + d.nXf;
+        for (int e = tid; e < n; e += nt) {
+            L.pv[e] = w.gx[(size_t)k * n + e];
+            L.adj[e] = w.gxd[(size_t)k * n + e];
+            L.hdv[e] = w.hd[(size_t)k * n + e];
+            L.cvv[e] = w.cv[(size_t)k * n + e];
+        }
+        if (tid < nxrows) L.Dx[tid] = w.D[(size_t)(k - 1) * d.RX + xoff + tid];
+        __syncthreads();
         if (full) {
             const double Hss = d.tr ? w.Hss[k] : 1.0;
-            const int nxrows = d.nX + d.nXf, xoff = d.tr ? 2 * n + 1 : 0;
-            const double *Dk = w.D + (size_t)(k - 1) * d.RX + xoff;
             for (int e = tid; e < n * n; e += nt) {
                 const int i = e / n, j = e - i * n;
-                double v = c.QxN[e];
-                if (d.tr) {
-                    if (i == j) v += w.hd[(size_t)k * n + i];
-                    else v -= w.cv[(size_t)k * n + i] * w.cv[(size_t)k * n + j] / Hss;
-                }
-                for (int r = 0; r < nxrows; ++r) {
-                    const double *row = (r < d.nX) ? c.XA + (size_t)r * n : c.XfA + (size_t)(r - d.nX) * n;
-                    v = fma(row[i] * Dk[r], row[j], v);
-                }
+                if (j < i) continue;
+                const double v = stage_hess(d, c, L, k, i, j, Hss, nxrows);
                 L.P[i * ld + j] = v;
+                L.P[j * ld + i] = v;
             }
+            for (int e = tid; e < (NK - n) * ld; e += nt) L.P[n * ld + e] = 0.0;
         }
-        for (int e = tid; e < n; e += nt) { L.pv[e] = w.gx[(size_t)k * n + e]; L.adj[e] = w.gxd[(size_t)k * n + e]; }
         __syncthreads();
     }
     for (int k = N - 1; k >= 0; --k) {
         const size_t sel = dyn.sel(k);
         const double *Ag = dyn.A + sel * n * n, *Bg = dyn.B + sel * n * m;
-        // stage A, B into LDS (A only needed for the matrix part and the transposed mat-vecs)
-        for (int e = tid; e < n * n; e += nt) { const int i = e / n, j = e - i * n; L.A[i * ld + j] = Ag[e]; }
-        for (int e = tid; e < n * mp; e += nt) { const int i = e / mp, j = e - i * mp; L.B[e] = j < m ? Bg[i * m + j] : 0.0; }
         if (full) {
+            // stage [A | B] into LDS (pad rows / columns stay zero)
+            for (int e = tid; e < n * n; e += nt) { const int i = e / n, j = e - i * n; L.AB[i * ld + j] = Ag[e]; }
+            for (int e = tid; e < n * m; e += nt) { const int i = e / m, j = e - i * m; L.AB[i * ld + n + j] = Bg[e]; }
             for (int e = tid; e < m * m; e += nt) L.Quu[e] = w.Huu[(size_t)k * m * m + e];
-        } else {
-            for (int e = tid; e < m * n; e += nt) { const int a = e / n, j = e - a * n; L.Km[a * ld + j] = w.K[(size_t)k * m * n + e]; }
-            for (int e = tid; e < m * m; e += nt) L.Qinv[e] = w.Qinv[(size_t)k * m * m + e];
-        }
-        __syncthreads();
-        if (full) {
-            wg::gemm<false>(L.W, ld, L.P, ld, L.A, ld, n, n, n);     // W = P A
-            wg::gemm<false>(L.G, mp, L.P, ld, L.B, mp, n, m, n);     // G = P B
-            // Quu += B^T G ; Qux = B^T W
-            for (int e = tid; e < m * m + m * n; e += nt) {
-                if (e < m * m) {
-                    const int a = e / m, b = e - a * m;
-                    double v = L.Quu[e];
-                    for (int i = 0; i < n; ++i) v = fma(L.B[i * mp + a], L.G[i * mp + b], v);
-                    L.Quu[e] = v;
-                } else {
-                    const int f = e - m * m, a = f / n, j = f - a * n;
-                    double v = 0.0;
-                    for (int i = 0; i < n; ++i) v = fma(L.B[i * mp + a], L.W[i * ld + j], v);
-                    L.Qux[a * ld + j] = v;
-                }
+            if (k >= 1) {
+                for (int e = tid; e < n; e += nt) { L.hdv[e] = w.hd[(size_t)k * n + e]; L.cvv[e] = w.cv[(size_t)k * n + e]; }
+                if (tid < d.nX) L.Dx[tid] = w.D[(size_t)(k - 1) * d.RX + xoff + tid];
             }
-        }
-        // Qu = gu + B^T pv ; dual residual wrt u_k = gud + B^T adj
-        for (int e = tid; e < 2 * m; e += nt) {
-            const int a = e % m;
-            const double *vec = e < m ? L.pv : L.adj;
-            double v = e < m ? w.gu[(size_t)k * m + a] : w.gud[(size_t)k * m + a];
-            for (int i = 0; i < n; ++i) v = fma(L.B[i * mp + a], vec[i], v);
-            if (e < m) L.Qu[a] = v; else L.rdu[a] = v;
-        }
-        __syncthreads();
-        if (with_dual && tid < m) rd = fmax(rd, fabs(L.rdu[tid]));
-        if (full) {
-            // Quu = L L^T (kept in L.Qinv); K = -Quu^-1 Qux by triangular solves, one state column per
-            // thread (backward stable -- an explicit inverse loses the weakly curved input directions
-            // once the active-bound weights reach 1e12)
-            if (!wg::chol_factor(L.Quu, L.Qinv, m, L.flag, true)) return false;
+            __syncthreads();
+            mfma_atb(L.W, L.P, L.AB, NK, (n + 15) >> 4, ld >> 4, ld, n);         // W = P [A|B]
+            mfma_atb(L.P, L.AB, L.W, NK, ld >> 4, ld >> 4, ld, ld);              // M = [A|B]^T W
+            // [A|B]^T pv and [A|B]^T adj : (n+m) outputs each, 4 partial sums per output
+            {
+                const int nout = 2 * (n + m), S = nt / (2 * ld) > 0 ? nt / (2 * ld) : 1;
+                const int o = tid % (2 * ld), sl = tid / (2 * ld);
+                if (sl < S && o < 2 * ld) {
+                    const int col = o % ld;
+                    const double *vec = o < ld ? L.pv : L.adj;
+                    double acc = 0.0;
+                    if (col < n + m) for (int i = sl; i < n; i += S) acc = fma(L.AB[i * ld + col], vec[i], acc);
+                    L.part[sl * 2 * ld + o] = acc;
+                }
+                __syncthreads();
+                if (tid < 2 * ld) {
+                    double r = 0.0;
+                    for (int q = 0; q < S; ++q) r += L.part[q * 2 * ld + tid];
+                    if (tid < ld) L.ypv[tid] = r; else L.yadj[tid - ld] = r;
+                }
+                (void)nout;
+            }
+            __syncthreads();
+            if (tid < m) {
+                L.Qu[tid] = w.gu[(size_t)k * m + tid] + L.ypv[n + tid];
+                L.rdu[tid] = w.gud[(size_t)k * m + tid] + L.yadj[n + tid];
+            }
+            for (int e = tid; e < m * m; e += nt) { const int a = e / m, b = e - a * m; L.Quu[e] += L.P[(n + a) * ld + n + b]; }
+            __syncthreads();
+            if (with_dual && tid < m) rd = fmax(rd, fabs(L.rdu[tid]));
+            // Quu = Lc Lc^T; K = -Quu^-1 Qux by triangular solves, one state column per thread (backward
+            // stable: an explicit inverse loses the weakly curved input directions once the active-bound
+            // weights reach 1e12).  Qux = M[n.., 0..n).
+            if (!wg::chol_factor(L.Quu, L.Lc, m, L.flag, true)) return false;
             for (int j = tid; j < n; j += nt) {
-                wg::chol_solve_neg(L.Qinv, m, L.Qux + j, ld, L.Km + j, ld);
+                wg::chol_solve_neg(L.Lc, m, L.P + n * ld + j, ld, L.Km + j, ld);
                 for (int a = 0; a < m; ++a) w.K[((size_t)k * m + a) * n + j] = L.Km[a * ld + j];
             }
-            for (int e = tid; e < m * m; e += nt) w.Qinv[(size_t)k * m * m + e] = L.Qinv[e];
-        }
-        if (tid == 0) {
-            wg::chol_solve_neg(L.Qinv, m, L.Qu, 1, L.kf, 1);
-            for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
-        }
-        __syncthreads();
-        if (k >= 1) {
-            if (full) {
-                wg::gemm<true>(L.P, ld, L.A, ld, L.W, ld, n, n, n);   // T = A^T W  (P no longer needed)
-                // P_k = sym(T) + Qx + diag(hd) - c c^T/Hss + X^T D X + sym(Qux^T K)
+            for (int e = tid; e < m * m; e += nt) w.Qinv[(size_t)k * m * m + e] = L.Lc[e];
+            if (tid == 0) {
+                wg::chol_solve_neg(L.Lc, m, L.Qu, 1, L.kf, 1);
+                for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
+            }
+            __syncthreads();
+            if (k >= 1) {
+                // P_k (in place over M): each unordered pair (i,j) is owned by one thread
                 const double Hss = d.tr ? w.Hss[k] : 1.0;
-                const int xoff = d.tr ? 2 * n + 1 : 0;
-                const double *Dk = w.D + (size_t)(k - 1) * d.RX + xoff;
                 for (int e = tid; e < n * n; e += nt) {
                     const int i = e / n, j = e - i * n;
                     if (j < i) continue;
-                    double v = 0.5 * (L.P[i * ld + j] + L.P[j * ld + i]) + c.Qx[e];
+                    double v = 0.5 * (L.P[i * ld + j] + L.P[j * ld + i]) + stage_hess(d, c, L, k, i, j, Hss, d.nX);
                     double kk = 0.0;
-                    for (int a = 0; a < m; ++a) kk += L.Qux[a * ld + i] * L.Km[a * ld + j] + L.Qux[a * ld + j] * L.Km[a * ld + i];
+                    for (int a = 0; a < m; ++a)
+                        kk += L.P[(n + a) * ld + i] * L.Km[a * ld + j] + L.P[(n + a) * ld + j] * L.Km[a * ld + i];
                     v += 0.5 * kk;
-                    if (d.tr) {
-                        if (i == j) v += w.hd[(size_t)k * n + i];
-                        else v -= w.cv[(size_t)k * n + i] * w.cv[(size_t)k * n + j] / Hss;
-                    }
-                    for (int r = 0; r < d.nX; ++r) v = fma(c.XA[(size_t)r * n + i] * Dk[r], c.XA[(size_t)r * n + j], v);
-                    L.W[i * ld + j] = v;       // W is free: use it as the output buffer (no read/write race)
-                    L.W[j * ld + i] = v;
+                    L.W[i * ld + j] = v;  // staged in W (free after the second product), copied below
+                    if (i != j) L.W[j * ld + i] = v;
                 }
+                // pv_new = gx + A^T pv + K^T Qu ; adj_new = gxd + A^T adj
+                for (int e = tid; e < 2 * n; e += nt) {
+                    const int j = e % n;
+                    if (e < n) {
+                        double v = w.gx[(size_t)k * n + j] + L.ypv[j];
+                        for (int a = 0; a < m; ++a) v = fma(L.Km[a * ld + j], L.Qu[a], v);
+                        L.v1[j] = v;
+                    } else {
+                        L.v2[j] = w.gxd[(size_t)k * n + j] + L.yadj[j];
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < n * n; e += nt) { const int i = e / n, j = e - i * n; L.P[i * ld + j] = L.W[i * ld + j]; }
+                for (int e = tid; e < (NK - n) * ld; e += nt) L.P[n * ld + e] = 0.0;
+                for (int e = tid; e < n; e += nt) { L.pv[e] = L.v1[e]; L.adj[e] = L.v2[e]; }
+                __syncthreads();
             }
-            // pv_new = gx + A^T pv + K^T Qu ; adj_new = gxd + A^T adj
-            for (int e = tid; e < 2 * n; e += nt) {
-                const int j = e % n;
-                const bool first = e < n;
-                const double *vec = first ? L.pv : L.adj;
-                double v = first ? w.gx[(size_t)k * n + j] : w.gxd[(size_t)k * n + j];
-                for (int i = 0; i < n; ++i) v = fma(L.A[i * ld + j], vec[i], v);
-                if (first) {
+        } else {
+            // vector-only re-solve: A^T pv, B^T pv straight from the L2-resident tables
+            for (int e = tid; e < m * n; e += nt) { const int a = e / n, j = e - a * n; L.Km[a * ld + j] = w.K[(size_t)k * m * n + e]; }
+            for (int e = tid; e < m * m; e += nt) L.Lc[e] = w.Qinv[(size_t)k * m * m + e];
+            wg::matTvec(L.ypv, Ag, n, n, n, L.pv, nullptr, L.part);
+            for (int a = wave; a < m; a += nw) {
+                double v = 0.0;
+                for (int i = lane; i < n; i += 64) v = fma(Bg[i * m + a], L.pv[i], v);
+                v = wg::wave_sum(v);
+                if (lane == 0) L.Qu[a] = v + w.gu[(size_t)k * m + a];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                wg::chol_solve_neg(L.Lc, m, L.Qu, 1, L.kf, 1);
+                for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
+            }
+            if (k >= 1) {
+                for (int j = tid; j < n; j += nt) {
+                    double v = w.gx[(size_t)k * n + j] + L.ypv[j];
                     for (int a = 0; a < m; ++a) v = fma(L.Km[a * ld + j], L.Qu[a], v);
                     L.v1[j] = v;
-                } else {
-                    L.v2[j] = v;
                 }
             }
             __syncthreads();
-            if (full) {
-                for (int e = tid; e < n * n; e += nt) { const int i = e / n, j = e - i * n; L.P[i * ld + j] = L.W[i * ld + j]; }
-            }
-            for (int e = tid; e < n; e += nt) { L.pv[e] = L.v1[e]; L.adj[e] = L.v2[e]; }
+            if (k >= 1) { for (int e = tid; e < n; e += nt) L.pv[e] = L.v1[e]; }
             __syncthreads();
         }
     }
@@ -464,7 +566,6 @@ __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QP
     for (int e = tid; e < n; e += nt) { L.v1[e] = 0.0; w.dx[e] = 0.0; }
     if (tid == 0) w.ds[0] = 0.0;
     __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     for (int k = 0; k < N; ++k) {
         const size_t sel = dyn.sel(k);
         // du = K dx + kff  (one wave per output row, lanes over the state)
@@ -512,6 +613,9 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
     __syncthreads();
     rollout(d, dyn, q, w.u, w.x, L);
     int status = 1, it = 0;
+    long long tm[6] = {0, 0, 0, 0, 0, 0};
+    long long t_last = wall_clock64();
+    auto lap = [&](int slot) { const long long now = wall_clock64(); tm[slot] += now - t_last; t_last = now; };
     if (d.ng == 0) {
         for (int e = tid; e < d.NR; e += nt) { w.D[e] = 0.0; w.rho[e] = 0.0; w.lam[e] = 0.0; }
         __syncthreads();
@@ -567,6 +671,7 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
             sp = fmax(wg::reduce(sp, 1, L.red), fabs(q.delta));
             const double dreg = d.reg / sd;
             bool near_opt = false;
+            lap(0);
             for (it = 0; it < d.max_iter; ++it) {
                 // residuals, weights, predictor shifts
                 rows_apply(d, c, w.x, w.s, w.u, w.rg);
@@ -585,7 +690,9 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                 });
                 const double mu = wg::reduce(musum, 0, L.red) / d.ng;
                 rp = wg::reduce(rp, 1, L.red);
+                lap(1);
                 stage_prepass(d, c, q, w, true);
+                lap(2);
                 double rd = 0.0;
                 // a factorisation that breaks down in the last digits of an already converged iterate
                 // (weights D = lam/t up to 1e13) is accepted at the looser 1e-8 certificate
@@ -596,6 +703,7 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                 const double ltol = fmax(d.tol, 1e-9);     // linear residuals: round-off floor (see the port)
                 if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
                 near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
+                lap(3);
                 // predictor direction on the rows
                 rows_apply(d, c, w.dx, w.ds, w.du, w.dt);
                 __syncthreads();
@@ -620,8 +728,11 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                     w.rho[row] = lam + (lam * w.rg[row] - rc) / (t + dreg * lam);
                 });
                 __syncthreads();
+                lap(1);
                 stage_prepass(d, c, q, w, false);
+                lap(2);
                 riccati_solve(d, c, dyn, w, L, false, false, nullptr);
+                lap(4);
                 rows_apply(d, c, w.dx, w.ds, w.du, w.dt);
                 __syncthreads();
                 for_rows(d, [&](int row, bool, int, int) {
@@ -644,12 +755,53 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
             }
         }
     }
+    lap(1);
     // final consistency: x is exactly the rollout of u
     rollout(d, dyn, q, w.u, w.x, L);
     const double J = objective(d, c, q, w.x, w.u, w.s, L);
+    lap(5);
+    if (q.dbg && threadIdx.x == 0) for (int i = 0; i < 6; ++i) q.dbg[8 * 62 + i] = (double)tm[i];
     if (J_out) *J_out = J;
     if (iters_out) *iters_out = it;
     return status;
+}
+
+// Trust-region prescreen.  The 2n+1 trust-region rows per stage are 90 % of the inequality rows, yet with
+// GuSTO's delta (1e4 initially) they are almost never active.  Solve the QP WITHOUT them first: if the
+// minimiser satisfies ||xs (x_k - xbar_k)||_inf <= delta for every k, then (x, u, s = s_0 e_0) is feasible
+// for the full QP at the same cost and therefore its minimiser (dropping satisfied constraints cannot
+// change an optimum; the slack cost omega * s >= 0 is minimal at 0) -- identical result, 10x fewer rows.
+// Otherwise the full QP is solved.
+__device__ inline int solve_prescreen(const QPDims &d, const QPConst &c, const QPDyn &dyn, const QPData &q,
+                                      double *work_base, QPWork &w, QPLds &L, double *J_out, int *iters_out) {
+    if (d.tr) {
+        QPDims dn = d;
+        dn.tr = 0;
+        dn.nrx = d.nX;
+        dn.RX = dn.nrx + d.nXf;
+        dn.NR = d.N * dn.RX + d.N * d.nU;
+        dn.ng = d.N * dn.nrx + d.nXf + d.N * d.nU;
+        QPWork wn;
+        qp_carve(wn, work_base, dn);
+        double J;
+        int it;
+        const int st = solve(dn, c, dyn, q, wn, L, &J, &it);
+        if (st == 0) {
+            double md = 0.0;
+            for (int e = threadIdx.x + d.n; e < (d.N + 1) * d.n; e += blockDim.x)
+                md = fmax(md, fabs(c.xs[e % d.n] * (wn.x[e] - q.xk[e])));
+            md = wg::reduce(md, 1, L.red);
+            if (md <= q.delta) {
+                const double s0 = slack0(d, c, q, L);
+                for (int e = threadIdx.x; e <= d.N; e += blockDim.x) w.s[e] = (e == 0) ? s0 : 0.0;
+                __syncthreads();
+                if (J_out) *J_out = J + q.omega * s0;
+                if (iters_out) *iters_out = it;
+                return 0;
+            }
+        }
+    }
+    return solve(d, c, dyn, q, w, L, J_out, iters_out);
 }
 
 }  // namespace qp

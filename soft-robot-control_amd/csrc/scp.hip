@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int NTHREADS = 256;
+constexpr int NTHREADS = 512;
 
 struct GustoPar {
     double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh, dt;
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
     extern __shared__ __attribute__((aligned(16))) char smem[];
     QPLds L;
     qp_lds_carve(L, reinterpret_cast<double *>(smem), d, NTHREADS);
+    qp_lds_init(L, d, c);
     const size_t p = blockIdx.x;
     const size_t N = d.N, n = d.n, m = d.m;
     QPWork w;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
              b.zf ? b.zf + p * d.nz : nullptr, b.ud ? b.ud + p * N * m : nullptr, b.delta[p], b.omega[p], (b.dbg && p == 0) ? b.dbg : nullptr};
     double J;
     int it;
-    const int st = qp::solve(d, c, dyn, q, w, L, &J, &it);
+    const int st = qp::solve_prescreen(d, c, dyn, q, b.work + p * b.work_stride, w, L, &J, &it);
     for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
     for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
     for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     extern __shared__ __attribute__((aligned(16))) char smem[];
     QPLds L;
     qp_lds_carve(L, reinterpret_cast<double *>(smem), d, NTHREADS);
+    qp_lds_init(L, d, c);
     const size_t p = blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                  b.ud ? b.ud + p * (size_t)N * m : nullptr, delta, omega, nullptr};
         double J;
         int qit;
-        const int st = qp::solve(d, c, dyn, q, w, L, &J, &qit);
+        const int st = qp::solve_prescreen(d, c, dyn, q, base, w, L, &J, &qit);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
         double md = 0.0;
@@ -240,14 +242,16 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
                 "LOCP: need 1 <= N, 1 <= n_x <= 128, 1 <= n_u <= 16, 1 <= n_z <= 16");
     SRH_REQUIRE(pr->ndU == 0, "LOCP: dU (input-rate) constraints are not supported by the device solver yet");
     SRH_REQUIRE(pr->nU >= 0 && pr->nX >= 0 && pr->nXf >= 0, "LOCP: negative constraint count");
+    SRH_REQUIRE(pr->nX + pr->nXf <= 32 && pr->nU <= 64, "LOCP: at most 32 state rows (X + Xf) and 64 input rows per stage");
     SRH_REQUIRE(pr->nU == 0 || (pr->UA && pr->Ub), "LOCP: U.A / U.b missing");
     SRH_REQUIRE(pr->nX == 0 || (pr->XA && pr->Xb), "LOCP: X.A / X.b missing");
     SRH_REQUIRE(pr->nXf == 0 || (pr->XfA && pr->Xfb), "LOCP: Xf.A / Xf.b missing");
     QPDims &d = C.dims;
     d.N = N; d.n = n; d.m = m; d.nz = nz; d.nU = pr->nU; d.nX = pr->nX; d.nXf = pr->nXf;
     d.tr = pr->tr_active ? 1 : 0;
-    d.ld = (n + 3) & ~3;
+    d.ld = (n + m + 15) & ~15;
     d.mp = (m + 3) & ~3;
+    d.NK = (n + 3) & ~3;
     d.nrx = d.tr * (2 * n + 1) + d.nX;
     d.RX = d.nrx + d.nXf;
     d.NR = N * d.RX + N * d.nU;
@@ -375,7 +379,8 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     if (want_dbg) {
         std::vector<double> t(8 * 64);
         dbg.download(t.data(), sizeof(double) * 8 * 64);
-        for (int i = 0; i < 64 && (t[8 * i + 3] != 0.0); ++i)
+        fprintf(stderr, "[locp] time (10ns ticks): init %.0f rows %.0f prepass %.0f ricc_full %.0f ricc_vec %.0f final %.0f\n", t[8*62], t[8*62+1], t[8*62+2], t[8*62+3], t[8*62+4], t[8*62+5]);
+        for (int i = 0; i < 62 && (t[8 * i + 3] != 0.0); ++i)
             fprintf(stderr, "[locp] it %2d mu %.3e rd %.3e rp %.3e (sd %.2e sp %.2e) a_aff %.3e sigma %.3e a %.3e\n", i, t[8 * i], t[8 * i + 1], t[8 * i + 2], t[8 * i + 3], t[8 * i + 4], t[8 * i + 5], t[8 * i + 6], t[8 * i + 7]);
     }
     if ((rc = ox.download(x, sizeof(double) * batch * (N + 1) * n)) || (rc = ou.download(u, sizeof(double) * batch * N * m)) ||
