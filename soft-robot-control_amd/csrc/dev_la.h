@@ -4,6 +4,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Address-space qualified pointers.  Generic pointers make hipcc emit FLAT loads/stores (slow path for
+// LDS, and they tie up both memory counters); typing LDS and global buffers explicitly gives ds_* and
+// global_* instructions even across non-inlined calls.
+typedef __attribute__((address_space(3))) double ld_t;
+typedef __attribute__((address_space(1))) double gd_t;
+typedef __attribute__((address_space(3))) int li_t;
+typedef __attribute__((address_space(1))) int gi_t;
+using lptr = ld_t *;
+using clptr = const ld_t *;
+using gptr = gd_t *;
+using cgptr = const gd_t *;
+using giptr = gi_t *;
+using cgiptr = const gi_t *;
+using liptr = li_t *;
+
 namespace wg {
 
 __device__ __forceinline__ int tid() { return threadIdx.x; }
@@ -26,7 +41,7 @@ __device__ __forceinline__ double wave_min(double v) {
     return v;
 }
 // op: 0 sum, 1 max, 2 min.  Result broadcast to every thread.  Deterministic (fixed tree).
-__device__ inline double reduce(double v, int op, double *scratch) {
+__device__ inline double reduce(double v, int op, lptr scratch) {
     double w = op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v));
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     __syncthreads();  // scratch may still be read from a previous reduction
@@ -37,39 +52,10 @@ __device__ inline double reduce(double v, int op, double *scratch) {
     return r;
 }
 
-// ---- GEMM on LDS operands: C (M x N) = op(A) (M x K) * B (K x N) -----------------------------
-// Row-major, leading dimensions in doubles; ldb/ldc multiples of 4 and 32-byte aligned bases so the
-// 1x4 register block can use 16-byte LDS accesses; columns N..roundup4(N) of B must be finite.
-template <bool TRANS_A>
-__device__ inline void gemm(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda,
-                            const double *__restrict__ B, int ldb, int M, int N, int K) {
-    const int nq = (N + 3) >> 2;
-    const int items = M * nq;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int i = it / nq, j0 = (it - i * nq) << 2;
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-        const double *bp = B + j0;
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-            const double a = TRANS_A ? A[k * lda + i] : A[i * lda + k];
-            const double2 b01 = *reinterpret_cast<const double2 *>(bp + k * ldb);
-            const double2 b23 = *reinterpret_cast<const double2 *>(bp + k * ldb + 2);
-            c0 = fma(a, b01.x, c0);
-            c1 = fma(a, b01.y, c1);
-            c2 = fma(a, b23.x, c2);
-            c3 = fma(a, b23.y, c3);
-        }
-        double *cp = C + i * ldc + j0;
-        *reinterpret_cast<double2 *>(cp) = double2{c0, c1};
-        *reinterpret_cast<double2 *>(cp + 2) = double2{c2, c3};
-    }
-    __syncthreads();
-}
-
 // y (len) = sum over i<rows of M[i][j] * v[i]   (i.e. y = M^T v for row-major M (rows x len)), M in
 // global/L2 (coalesced along j) or LDS; v, y in LDS.  Adds `add` if non-null.  part: (nthr) doubles.
-__device__ inline void matTvec(double *y, const double *__restrict__ M, int ldm, int rows, int len,
-                               const double *v, const double *add, double *part) {
+template <typename MP, typename AP>
+__device__ inline void matTvec(lptr y, MP M, int ldm, int rows, int len, clptr v, AP add, lptr part) {
     // threads = (slice, j): slice s handles rows s, s+S, ...
     const int S = max(1, (int)blockDim.x / len);
     const int j = threadIdx.x % len, s = threadIdx.x / len;
@@ -92,7 +78,7 @@ __device__ inline void matTvec(double *y, const double *__restrict__ M, int ldm,
 // (to all threads, via flag in LDS) if not positive definite.  With allow_shift a breakdown caused by
 // round-off in a nearly singular matrix is retried with a growing diagonal shift (inexact Newton step;
 // the interior-point iteration corrects it).
-__device__ inline bool chol_factor(const double *Q, double *Lbuf, int m, int *flag, bool allow_shift = false) {
+__device__ inline bool chol_factor(clptr Q, lptr Lbuf, int m, liptr flag, bool allow_shift = false) {
     if (threadIdx.x == 0) {
         bool ok = false;
         double dmax = 0.0;
@@ -121,8 +107,8 @@ __device__ inline bool chol_factor(const double *Q, double *Lbuf, int m, int *fl
 }
 
 // x = -(L L^T)^-1 b for one right-hand side held by the calling thread: b, x strided arrays (m <= 16)
-__device__ __forceinline__ void chol_solve_neg(const double *L, int m, const double *b, int bstride, double *x,
-                                               int xstride) {
+template <typename LP, typename BP, typename XP>
+__device__ __forceinline__ void chol_solve_neg(LP L, int m, BP b, int bstride, XP x, int xstride) {
     double y[16];
     for (int i = 0; i < m; ++i) {
         double sum = b[i * bstride];
@@ -135,6 +121,61 @@ __device__ __forceinline__ void chol_solve_neg(const double *L, int m, const dou
         y[i] = sum / L[i * m + i];
     }
     for (int i = 0; i < m; ++i) x[i * xstride] = -y[i];
+}
+
+
+// ---- register-resident Cholesky of a tiny SPD matrix (compile-time size) ------------------------
+// L (lower, row-major M x M) and the reciprocals of its diagonal; returns false if not positive
+// definite.  `shift` is added to the diagonal.
+template <int M, typename QP>
+__device__ __forceinline__ bool chol_reg(QP Q, int ldq, double shift, double (&Lr)[M * M], double (&inv)[M]) {
+    double a[M * M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) a[i * M + j] = Q[i * ldq + j] + (i == j ? shift : 0.0);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double sum = a[i * M + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sum -= Lr[i * M + k] * Lr[j * M + k];
+            if (i == j) {
+                if (!(sum > 0.0)) ok = false;
+                const double dd = sqrt(sum);
+                Lr[i * M + i] = dd;
+                inv[i] = 1.0 / dd;
+            } else {
+                Lr[i * M + j] = sum * inv[j];
+            }
+        }
+    }
+    return ok;
+}
+
+// x = -(L L^T)^-1 b with L in registers (inv = 1/diag(L))
+template <int M, typename BP, typename XP>
+__device__ __forceinline__ void chol_solve_neg_reg(const double (&Lr)[M * M], const double (&inv)[M], BP b,
+                                                   int bstride, XP x, int xstride) {
+    double y[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        double sum = b[i * bstride];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum -= Lr[i * M + k] * y[k];
+        y[i] = sum * inv[i];
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+        double sum = y[i];
+#pragma unroll
+        for (int k = i + 1; k < M; ++k) sum -= Lr[k * M + i] * y[k];
+        y[i] = sum * inv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) x[i * xstride] = -y[i];
 }
 
 }  // namespace wg

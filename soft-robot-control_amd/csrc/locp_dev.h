@@ -12,9 +12,12 @@
 
 struct QPDims {
     int N, n, m, nz, nU, nX, nXf, tr;
-    int ld;    // leading dimension of the LDS matrices = NPa = roundup16(n + m)
+    int ld;    // leading dimension of the LDS matrices = NPa + 1 (odd: row AND column accesses conflict-free)
+    int NPa;   // roundup16(n + m): extent of the stage Gram matrix
     int mp;    // unused (kept for layout stability)
     int NK;    // roundup4(n): K extent of the MFMA products (zero padded rows)
+    int NE4;   // roundup4(m + nX): extra Gram rows (-Y, +Y from the gain; sqrt(D) X rows)
+    int RW;    // rows of the AB / W panels: max(roundup16(n), NK + NE4)
     int nrx;   // inequality rows owned by x_k, k < N:  tr*(2n+1) + nX
     int RX;    // row stride per x stage: nrx + nXf
     int NR;    // total rows: N*RX + N*nU
@@ -25,34 +28,35 @@ struct QPDims {
 };
 
 struct QPConst {                       // shared by the whole batch (HBM/L2 resident)
-    const double *H, *Qz, *Qzf, *R;    // (nz x n), (nz x nz), (nz x nz)|null, (m x m)
-    const double *xs;                  // (n) trust-region scaling
-    const double *UA, *Ub, *XA, *Xb, *XfA, *Xfb;
-    const double *Qx, *QxN;            // 2 H^T Qz H, (+ 2 H^T Qzf H)      (n x n)
-    const double *HtQz2, *HtQzf2;      // 2 H^T Qz, 2 H^T Qzf               (n x nz)
-    const double *R2;                  // 2 R
+    cgptr H, Qz, Qzf, R;               // (nz x n), (nz x nz), (nz x nz)|null, (m x m)
+    cgptr xs;                          // (n) trust-region scaling
+    cgptr UA, Ub, XA, Xb, XfA, Xfb;
+    cgptr Qx, QxN;                     // 2 H^T Qz H, (+ 2 H^T Qzf H)      (n x n)
+    cgptr HtQz2, HtQzf2;               // 2 H^T Qz, 2 H^T Qzf               (n x nz)
+    cgptr R2;                          // 2 R
 };
 
 struct QPDyn {                         // stage dynamics: matrix k at base + idx[k]*size (idx null: k)
-    const double *A, *AT, *B, *BT, *d;
-    const int *idx;
+    cgptr A, AT, B, BT, d;
+    cgiptr idx;
     __device__ __forceinline__ size_t sel(int k) const { return idx ? (size_t)idx[k] : (size_t)k; }
 };
 
 struct QPData {                        // one problem
-    const double *x0, *xk, *z, *zf, *ud;   // xk (N+1 x n); z (N+1 x nz)|null; zf (nz)|null; ud (N x m)|null
+    cgptr x0, xk, z, zf, ud;               // xk (N+1 x n); z (N+1 x nz)|null; zf (nz)|null; ud (N x m)|null
     double delta, omega;
-    double *dbg;                           // optional per-iteration trace (8 doubles per iteration) or null
+    gptr dbg;                              // optional per-iteration trace (8 doubles per iteration) or null
 };
 
 struct QPWork {                        // per-problem scratch in HBM/L2 (doubles)
-    double *x, *u, *s, *dx, *du, *ds;
-    double *t, *lam, *rg, *D, *rho, *rc, *dt, *dlam;      // NR each
-    double *hd, *cv, *gx, *gxd;                           // (N+1) x n   (index k = 1..N used)
-    double *Hss, *gs;                                     // (N+1)
-    double *Huu, *gu, *gud;                               // N x m x m, N x m, N x m
-    double *K, *Qinv, *kff;                               // N x m x n, N x m x m (Cholesky factors of Quu), N x m
-    double *ez;                                           // (N+1) x nz
+    gptr x, u, s, dx, du, ds;
+    gptr t, lam, rg, D, rho, rc, dt, dlam;                // NR each
+    gptr hd, cv, gx, gxd;                                 // (N+1) x n   (index k = 1..N used)
+    gptr Hss, gs;                                         // (N+1)
+    gptr Huu, gu, gud;                                    // N x m x m, N x m, N x m
+    gptr K, Qinv, kff;                                    // N x m x n, N x m x m (Cholesky factors of Quu), N x m
+    gptr ez;                                              // (N+1) x nz
+    gptr tprof;                                        // optional phase timers (debug) or null
 };
 
 __host__ __device__ inline size_t qp_work_doubles(const QPDims &d) {
@@ -61,10 +65,10 @@ __host__ __device__ inline size_t qp_work_doubles(const QPDims &d) {
            N * m * m + 2 * N * m + N * m * n + N * m * m + N * m + (N + 1) * d.nz + 64;
 }
 
-__device__ inline void qp_carve(QPWork &w, double *base, const QPDims &d) {
+__device__ inline void qp_carve(QPWork &w, gptr base, const QPDims &d) {
     const size_t N = d.N, n = d.n, m = d.m, NR = d.NR;
-    double *p = base;
-    auto take = [&](size_t c) { double *q = p; p += c; return q; };
+    gptr p = base;
+    auto take = [&](size_t c) { gptr q = p; p += c; return q; };
     w.x = take((N + 1) * n); w.dx = take((N + 1) * n);
     w.u = take(N * m); w.du = take(N * m);
     w.s = take(N + 1); w.ds = take(N + 1);
@@ -75,41 +79,43 @@ __device__ inline void qp_carve(QPWork &w, double *base, const QPDims &d) {
     w.Huu = take(N * m * m); w.gu = take(N * m); w.gud = take(N * m);
     w.K = take(N * m * n); w.Qinv = take(N * m * m); w.kff = take(N * m);
     w.ez = take((N + 1) * d.nz);
+    w.tprof = (gptr)nullptr;
 }
 
 struct QPLds {                         // LDS carve (doubles unless noted)
-    double *P;                         // ld x ld : cost-to-go P_{k+1}, then the stage Gram matrix M = [A|B]^T P [A|B]
-    double *AB;                        // roundup16(n) x ld : [A_k | B_k], zero padded
-    double *W;                         // roundup16(n) x ld : P [A_k | B_k]
-    double *Km;                        // m x ld  : feedback gain of the stage
-    double *Quu, *Lc;                  // 16 x 16 : Quu and its Cholesky factor
-    double *pv, *adj, *v1, *v2, *hdv, *cvv;   // ld each
-    double *ypv, *yadj;                // ld each : [A|B]^T pv, [A|B]^T adj
-    double *Qu, *kf, *rdu;             // 16 each
-    double *Hm;                        // nz x ld : H
-    double *HtQ;                       // ld x 16 : 2 H^T Qz
-    double *XAl;                       // (nX + nXf) x ld
-    double *Dx;                        // 32      : X-row weights of the stage
-    double *part;                      // blockDim
-    double *red;                       // 16
-    int *flag;                         // 4 ints
+    lptr P;                         // roundup16(n) x ld : cost-to-go P_{k+1} / P_k
+    lptr AB;                        // RW x ld : [A_k | B_k], zero padded; rows NK.. = extra Gram rows (left factor)
+    lptr W;                         // RW x ld : P [A_k | B_k]; rows NK.. = extra Gram rows (right factor)
+    lptr QUX;                       // 16 x ld : [Qux | B^T P B] = B^T W
+    lptr Km;                        // m x ld  : feedback gain of the stage
+    lptr Quu, Lc;                  // 16 x 16 : Quu and its Cholesky factor
+    lptr pv, adj, v1, v2, v3, hdv, cvv;   // ld each
+    lptr ypv, yadj;                // ld each : [A|B]^T pv, [A|B]^T adj
+    lptr Qu, kf, rdu;             // 16 each
+    lptr Hm;                        // nz x ld : H
+    lptr HtQ;                       // ld x 16 : 2 H^T Qz
+    lptr XAl;                       // (nX + nXf) x ld
+    lptr Dx;                        // 32      : X-row weights of the stage
+    lptr part;                      // blockDim
+    lptr red;                       // 16
+    liptr flag;                         // 4 ints
 };
 
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
-    const size_t nk16 = (size_t)((d.n + 15) & ~15);   // W / AB rows: whole MFMA tiles are stored
-    size_t c = (size_t)d.ld * d.ld + 2 * nk16 * d.ld + (size_t)d.m * d.ld + 2 * 256 + 8 * (size_t)d.ld + 3 * 16 +
+    const size_t nk16 = (size_t)((d.n + 15) & ~15);   // whole MFMA tiles are stored
+    size_t c = nk16 * d.ld + 2 * (size_t)d.RW * d.ld + 16 * (size_t)d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
                (size_t)d.nz * d.ld + (size_t)d.ld * 16 + (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4;
     return c * sizeof(double);
 }
 
-__device__ inline void qp_lds_carve(QPLds &L, double *base, const QPDims &d, int nthreads) {
-    double *p = base;
-    auto take = [&](size_t c) { double *q = p; p += c; return q; };
+__device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nthreads) {
+    lptr p = base;
+    auto take = [&](size_t c) { lptr q = p; p += c; return q; };
     const size_t nk16 = (size_t)((d.n + 15) & ~15);
-    L.P = take((size_t)d.ld * d.ld); L.AB = take(nk16 * d.ld); L.W = take(nk16 * d.ld);
+    L.P = take(nk16 * d.ld); L.AB = take((size_t)d.RW * d.ld); L.W = take((size_t)d.RW * d.ld); L.QUX = take(16 * (size_t)d.ld);
     L.Km = take((size_t)d.m * d.ld);
     L.Quu = take(256); L.Lc = take(256);
-    L.pv = take(d.ld); L.adj = take(d.ld); L.v1 = take(d.ld); L.v2 = take(d.ld); L.hdv = take(d.ld); L.cvv = take(d.ld);
+    L.pv = take(d.ld); L.adj = take(d.ld); L.v1 = take(d.ld); L.v2 = take(d.ld); L.v3 = take(d.ld); L.hdv = take(d.ld); L.cvv = take(d.ld);
     L.ypv = take(d.ld); L.yadj = take(d.ld);
     L.Qu = take(16); L.kf = take(16); L.rdu = take(16);
     L.Hm = take((size_t)d.nz * d.ld); L.HtQ = take((size_t)d.ld * 16);
@@ -117,14 +123,15 @@ __device__ inline void qp_lds_carve(QPLds &L, double *base, const QPDims &d, int
     L.Dx = take(32);
     L.part = take(nthreads);
     L.red = take(16);
-    L.flag = reinterpret_cast<int *>(take(4));
+    L.flag = (liptr)take(4);
 }
 
 // one-off per kernel: constants into LDS, zero the padding of the MFMA operands
 __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) {
     const int tid = threadIdx.x, nt = blockDim.x, n = d.n, ld = d.ld;
-    for (int e = tid; e < d.ld * d.ld; e += nt) L.P[e] = 0.0;
-    for (int e = tid; e < ((d.n + 15) & ~15) * d.ld; e += nt) { L.AB[e] = 0.0; L.W[e] = 0.0; }
+    for (int e = tid; e < ((d.n + 15) & ~15) * d.ld; e += nt) L.P[e] = 0.0;
+    for (int e = tid; e < d.RW * d.ld; e += nt) { L.AB[e] = 0.0; L.W[e] = 0.0; }
+    for (int e = tid; e < 16 * d.ld; e += nt) L.QUX[e] = 0.0;
     for (int e = tid; e < d.nz * n; e += nt) { const int a = e / n, j = e - a * n; L.Hm[a * ld + j] = c.H[e]; }
     for (int e = tid; e < n * d.nz; e += nt) { const int i = e / d.nz, a = e - i * d.nz; L.HtQ[i * 16 + a] = c.HtQz2[e]; }
     for (int e = tid; e < (d.nX + d.nXf) * n; e += nt) {
@@ -134,11 +141,17 @@ __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) 
     __syncthreads();
 }
 
+#ifdef SRH_PROFILE
+#define SRH_LAP(x) lap(x)
+#else
+#define SRH_LAP(x) ((void)0)
+#endif
+
 namespace qp {
 
 // ------------------------------------------------------------------ inequality rows
 // value of row r of x-stage k (1..N) applied to the vector (vx, sv):  a_x . vx + a_s * sv
-__device__ __forceinline__ double xrow_dot(const QPDims &d, const QPConst &c, int k, int r, const double *vx,
+__device__ __forceinline__ double xrow_dot(const QPDims &d, const QPConst &c, int k, int r, cgptr vx,
                                            double sv) {
     const int n = d.n;
     if (d.tr) {
@@ -147,7 +160,7 @@ __device__ __forceinline__ double xrow_dot(const QPDims &d, const QPConst &c, in
         if (r == 2 * n) return -sv;
         r -= 2 * n + 1;
     }
-    const double *row = (r < d.nX) ? c.XA + (size_t)r * n : c.XfA + (size_t)(r - d.nX) * n;
+    cgptr row = (r < d.nX) ? c.XA + (size_t)r * n : c.XfA + (size_t)(r - d.nX) * n;
     double acc = 0.0;
     for (int j = 0; j < n; ++j) acc = fma(row[j], vx[j], acc);
     return acc;
@@ -180,13 +193,12 @@ __device__ __forceinline__ void for_rows(const QPDims &d, F f) {
 }
 
 // a . w for every row with w = (vx, vs, vu); out[row]
-__device__ inline void rows_apply(const QPDims &d, const QPConst &c, const double *vx, const double *vs,
-                                  const double *vu, double *out) {
+__device__ __forceinline__ void rows_apply(const QPDims &d, const QPConst &c, cgptr vx, cgptr vs, cgptr vu, gptr out) {
     for_rows(d, [&](int row, bool isU, int k, int r) {
         if (!isU) {
             out[row] = xrow_dot(d, c, k, r, vx + (size_t)k * d.n, vs[k]);
         } else {
-            const double *ua = c.UA + (size_t)r * d.m, *uk = vu + (size_t)k * d.m;
+            cgptr ua = c.UA + (size_t)r * d.m, uk = vu + (size_t)k * d.m;
             double acc = 0.0;
             for (int j = 0; j < d.m; ++j) acc = fma(ua[j], uk[j], acc);
             out[row] = acc;
@@ -198,8 +210,7 @@ __device__ __forceinline__ double row_h(const QPDims &d, const QPConst &c, const
 }
 
 // ------------------------------------------------------------------ rollout x = f(u)
-__device__ inline void rollout(const QPDims &d, const QPDyn &dyn, const QPData &q, const double *u, double *x,
-                               QPLds &L) {
+__device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, const QPData &q, cgptr u, gptr x, QPLds &L) {
     const int n = d.n, m = d.m;
     for (int e = threadIdx.x; e < n; e += blockDim.x) { L.v1[e] = q.x0[e]; x[e] = q.x0[e]; }
     __syncthreads();
@@ -208,14 +219,14 @@ __device__ inline void rollout(const QPDims &d, const QPDyn &dyn, const QPData &
         for (int e = threadIdx.x; e < m; e += blockDim.x) L.Qu[e] = u[(size_t)k * m + e];
         __syncthreads();
         wg::matTvec(L.v2, dyn.AT + i * n * n, n, n, n, L.v1, dyn.d + i * n, L.part);
-        wg::matTvec(L.v2, dyn.BT + i * m * n, n, m, n, L.Qu, L.v2, L.part);
+        wg::matTvec(L.v2, dyn.BT + i * m * n, n, m, n, L.Qu, (clptr)L.v2, L.part);
         for (int e = threadIdx.x; e < n; e += blockDim.x) { L.v1[e] = L.v2[e]; x[(size_t)(k + 1) * n + e] = L.v2[e]; }
         __syncthreads();
     }
 }
 
 // s_0 = max(0, ||xs (x0 - xbar_0)||_inf - delta)   (every thread returns it)
-__device__ inline double slack0(const QPDims &d, const QPConst &c, const QPData &q, QPLds &L) {
+__device__ __forceinline__ double slack0(const QPDims &d, const QPConst &c, const QPData &q, QPLds &L) {
     if (!d.tr) return 0.0;
     double v = 0.0;
     for (int e = threadIdx.x; e < d.n; e += blockDim.x) v = fmax(v, fabs(c.xs[e] * (q.x0[e] - q.xk[e])));
@@ -224,8 +235,8 @@ __device__ inline double slack0(const QPDims &d, const QPConst &c, const QPData 
 }
 
 // objective value (without the 1/2, as cvxpy reports): locp.py:218-263
-__device__ inline double objective(const QPDims &d, const QPConst &c, const QPData &q, const double *x,
-                                   const double *u, const double *s, QPLds &L) {
+__device__ __forceinline__ double objective(const QPDims &d, const QPConst &c, const QPData &q, cgptr x, cgptr u,
+                                       cgptr s, QPLds &L) {
     double acc = 0.0;
     const int n = d.n, nz = d.nz, m = d.m;
     for (int k = threadIdx.x; k <= d.N; k += blockDim.x) {
@@ -256,7 +267,7 @@ __device__ inline double objective(const QPDims &d, const QPConst &c, const QPDa
 // ------------------------------------------------------------------ stage pre-pass
 // From the row weights D and gradient shifts rho (and, for the dual residual, the multipliers lam)
 // build per-stage Hessian / gradient pieces with the slack s_k eliminated.
-__device__ inline void stage_prepass(const QPDims &d, const QPConst &c, const QPData &q, QPWork &w, bool with_dual) {
+__device__ __forceinline__ void stage_prepass(const QPDims &d, const QPConst &c, const QPData &q, QPWork &w, bool with_dual) {
     const int n = d.n, nz = d.nz, m = d.m, N = d.N;
     // e_k = H x_k - z_k
     for (int e = threadIdx.x; e < (N + 1) * nz; e += blockDim.x) {
@@ -268,8 +279,8 @@ __device__ inline void stage_prepass(const QPDims &d, const QPConst &c, const QP
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     for (int k = 1 + wave; k <= N; k += nw) {
-        const double *Dk = w.D + (size_t)(k - 1) * d.RX, *rk = w.rho + (size_t)(k - 1) * d.RX;
-        const double *lk = w.lam + (size_t)(k - 1) * d.RX;
+        cgptr Dk = w.D + (size_t)(k - 1) * d.RX, rk = w.rho + (size_t)(k - 1) * d.RX;
+        cgptr lk = w.lam + (size_t)(k - 1) * d.RX;
         const int nxrows = (k == N) ? d.nX + d.nXf : d.nX;
         const int xoff = d.tr ? 2 * n + 1 : 0;
         double sumD = 0.0, sumR = 0.0, sumL = 0.0;
@@ -324,7 +335,7 @@ __device__ inline void stage_prepass(const QPDims &d, const QPConst &c, const QP
         }
     }
     // input stages
-    const double *Du = w.D + (size_t)N * d.RX, *ru = w.rho + (size_t)N * d.RX, *lu = w.lam + (size_t)N * d.RX;
+    cgptr Du = w.D + (size_t)N * d.RX, ru = w.rho + (size_t)N * d.RX, lu = w.lam + (size_t)N * d.RX;
     for (int e = threadIdx.x; e < N * m * m; e += blockDim.x) {
         const int k = e / (m * m), ab = e - k * m * m, a = ab / m, b = ab - a * m;
         double v = c.R2[ab];
@@ -353,8 +364,7 @@ typedef double qp_d4 __attribute__((ext_vector_type(4)));
 // LDS, K a multiple of 4 (zero padded).  Rows i >= vrows of C are stored as exact zeros.
 // v_mfma_f64_16x16x4: A lane l holds Lm^T[i=l&15][k=l>>4], B lane holds Rm[k=l>>4][j=l&15];
 // D reg q of lane l is C[row = (l>>4) + 4q][col = l&15].
-__device__ inline void mfma_atb(double *C, const double *Lm, const double *Rm, int K, int MT, int NTl, int ld,
-                                int vrows) {
+__device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, int K, int MT, int NTl, int ld, int vrows) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
@@ -363,10 +373,25 @@ __device__ inline void mfma_atb(double *C, const double *Lm, const double *Rm, i
         const bool has1 = t1 < ntiles;
         const int ti0 = t0 / NTl, tj0 = t0 - ti0 * NTl;
         const int ti1 = has1 ? t1 / NTl : ti0, tj1 = has1 ? t1 - ti1 * NTl : tj0;
-        const double *la0 = Lm + kk * ld + 16 * ti0 + l16, *rb0 = Rm + kk * ld + 16 * tj0 + l16;
-        const double *la1 = Lm + kk * ld + 16 * ti1 + l16, *rb1 = Rm + kk * ld + 16 * tj1 + l16;
+        clptr la0 = Lm + kk * ld + 16 * ti0 + l16, rb0 = Rm + kk * ld + 16 * tj0 + l16;
+        clptr la1 = Lm + kk * ld + 16 * ti1 + l16, rb1 = Rm + kk * ld + 16 * tj1 + l16;
         qp_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < K; k0 += 4) {
+        int k0 = 0;
+        // 4 k-steps per trip: 16 independent LDS reads in flight before the 8 MFMAs consume them
+        for (; k0 + 16 <= K; k0 += 16) {
+            double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o = (k0 + 4 * u) * ld;
+                a0[u] = la0[o]; b0[u] = rb0[o]; a1[u] = la1[o]; b1[u] = rb1[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc1, 0, 0, 0);
+            }
+        }
+        for (; k0 < K; k0 += 4) {
             const double a0 = la0[k0 * ld], b0 = rb0[k0 * ld];
             const double a1 = la1[k0 * ld], b1 = rb1[k0 * ld];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
@@ -375,10 +400,10 @@ __device__ inline void mfma_atb(double *C, const double *Lm, const double *Rm, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r0 = 16 * ti0 + kk + 4 * q;
-            C[r0 * ld + 16 * tj0 + l16] = r0 < vrows ? acc0[q] : 0.0;
+            C[r0 * ldc + 16 * tj0 + l16] = r0 < vrows ? acc0[q] : 0.0;
             if (has1) {
                 const int r1 = 16 * ti1 + kk + 4 * q;
-                C[r1 * ld + 16 * tj1 + l16] = r1 < vrows ? acc1[q] : 0.0;
+                C[r1 * ldc + 16 * tj1 + l16] = r1 < vrows ? acc1[q] : 0.0;
             }
         }
     }
@@ -399,6 +424,136 @@ __device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, 
     return v;
 }
 
+
+// Gain of stage k from Quu = Lc Lc^T (Cholesky in registers, recomputed by every thread):
+//   Y = Lc^-1 Qux (m x n), K_k = -Lc^-T Y, kff_k = -Quu^-1 Qu.
+// Besides K (LDS + HBM) the thread of column j writes the extra Gram rows used by the second product:
+//   left  panel rows NK..   : -Y[:, j],  +sqrt(D_r) XA[r][j]
+//   right panel rows NK..   : +Y[:, j],  +sqrt(D_r) XA[r][j]
+// so that  A^T W + left^T right = A^T P A - Qux^T Quu^-1 Qux + X^T D X  comes out of one MFMA product,
+// exactly symmetric in the added terms.  Column n / n+1 of the right panel receive pv / adj (rows < n).
+template <int M>
+__device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &L, int k, bool extras) {
+    const int n = d.n, ld = d.ld, NK = d.NK, tid = threadIdx.x, nt = blockDim.x;
+    double Lr[M * M], inv[M];
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) dmax = fmax(dmax, fabs(L.Quu[i * M + i]));
+    bool ok = wg::chol_reg<M>(L.Quu, M, 0.0, Lr, inv);
+    // a breakdown caused by round-off in a nearly singular Quu is retried with a growing diagonal shift
+    // (inexact Newton step; the interior-point iteration corrects it)
+    double shift = 1e-14 * dmax;
+    for (int attempt = 0; attempt < 7 && !ok; ++attempt, shift *= 100.0) ok = wg::chol_reg<M>(L.Quu, M, shift, Lr, inv);
+    if (!ok) return false;          // uniform: every thread factors the same matrix
+    for (int j = tid; j <= n; j += nt) {
+        clptr b = j < n ? L.QUX + j : L.Qu;
+        const int bs = j < n ? ld : 1;
+        double y[M], x[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double sum = b[i * bs];
+#pragma unroll
+            for (int q = 0; q < i; ++q) sum -= Lr[i * M + q] * y[q];
+            y[i] = sum * inv[i];
+        }
+#pragma unroll
+        for (int i = M - 1; i >= 0; --i) {
+            double sum = y[i];
+#pragma unroll
+            for (int q = i + 1; q < M; ++q) sum -= Lr[q * M + i] * x[q];
+            x[i] = sum * inv[i];
+        }
+        if (j < n) {
+#pragma unroll
+            for (int a = 0; a < M; ++a) {
+                L.Km[a * ld + j] = -x[a];
+                w.K[((size_t)k * M + a) * n + j] = -x[a];
+            }
+            if (extras) {
+#pragma unroll
+                for (int a = 0; a < M; ++a) {
+                    L.AB[(NK + a) * ld + j] = -y[a];
+                    L.W[(NK + a) * ld + j] = y[a];
+                }
+                for (int r = 0; r < d.nX; ++r) {
+                    const double v = sqrt(L.Dx[r]) * L.XAl[r * ld + j];
+                    L.AB[(NK + M + r) * ld + j] = v;
+                    L.W[(NK + M + r) * ld + j] = v;
+                }
+                L.W[j * ld + n] = L.pv[j];
+                L.W[j * ld + n + 1] = L.adj[j];
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < M; ++a) { L.kf[a] = -x[a]; w.kff[(size_t)k * M + a] = -x[a]; }
+        }
+    }
+    // (compile-time indices only: a runtime index would push the factor into scratch memory)
+#pragma unroll
+    for (int e = 0; e < M * M; ++e)
+        if (tid == e) w.Qinv[(size_t)k * M * M + e] = (e % M <= e / M) ? Lr[e] : 0.0;
+    __syncthreads();
+    return true;
+}
+
+__device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L, int k, bool extras) {
+    switch (d.m) {
+        case 1: return stage_gain_t<1>(d, w, L, k, extras);
+        case 2: return stage_gain_t<2>(d, w, L, k, extras);
+        case 3: return stage_gain_t<3>(d, w, L, k, extras);
+        case 4: return stage_gain_t<4>(d, w, L, k, extras);
+        case 5: return stage_gain_t<5>(d, w, L, k, extras);
+        case 6: return stage_gain_t<6>(d, w, L, k, extras);
+        case 7: return stage_gain_t<7>(d, w, L, k, extras);
+        case 8: return stage_gain_t<8>(d, w, L, k, extras);
+        default: break;
+    }
+    // m > 8: factor once in LDS (thread 0), per-column solves from LDS
+    const int n = d.n, m = d.m, ld = d.ld, NK = d.NK, tid = threadIdx.x, nt = blockDim.x;
+    if (!wg::chol_factor(L.Quu, L.Lc, m, L.flag, true)) return false;
+    for (int j = tid; j <= n; j += nt) {
+        clptr b = j < n ? L.QUX + j : L.Qu;
+        const int bs = j < n ? ld : 1;
+        // forward substitution into the extra-row slots / a scratch column of W, then back substitution
+        lptr yc = j < n ? L.W + NK * ld + j : L.v3;
+        const int ys = j < n ? ld : 1;
+        for (int i = 0; i < m; ++i) {
+            double sum = b[i * bs];
+            for (int q = 0; q < i; ++q) sum -= L.Lc[i * m + q] * yc[q * ys];
+            yc[i * ys] = sum / L.Lc[i * m + i];
+        }
+        lptr xc = j < n ? L.Km + j : L.kf;
+        const int xs = j < n ? ld : 1;
+        for (int i = m - 1; i >= 0; --i) {
+            double sum = yc[i * ys];
+            for (int q = i + 1; q < m; ++q) sum -= L.Lc[q * m + i] * xc[q * xs];
+            xc[i * xs] = sum / L.Lc[i * m + i];
+        }
+        if (j < n) {
+            for (int a = 0; a < m; ++a) {
+                const double xv = -xc[a * xs];
+                xc[a * xs] = xv;
+                w.K[((size_t)k * m + a) * n + j] = xv;
+                if (extras) L.AB[(NK + a) * ld + j] = -yc[a * ys];
+            }
+            if (extras) {
+                for (int r = 0; r < d.nX; ++r) {
+                    const double v = sqrt(L.Dx[r]) * L.XAl[r * ld + j];
+                    L.AB[(NK + m + r) * ld + j] = v;
+                    L.W[(NK + m + r) * ld + j] = v;
+                }
+                L.W[j * ld + n] = L.pv[j];
+                L.W[j * ld + n + 1] = L.adj[j];
+            }
+        } else {
+            for (int a = 0; a < m; ++a) { L.kf[a] = -L.kf[a]; w.kff[(size_t)k * m + a] = L.kf[a]; }
+        }
+    }
+    for (int e = tid; e < m * m; e += nt) w.Qinv[(size_t)k * m * m + e] = L.Lc[e];
+    __syncthreads();
+    return true;
+}
+
 // ------------------------------------------------------------------ Riccati solve of one Newton system
 // full = factorise (stores K_k and the Cholesky factor of Quu_k) and solve; !full = re-solve with new
 // gradients only.  Returns false on a non-positive-definite Quu.  rd_out: max |reduced dual residual|.
@@ -409,13 +564,41 @@ __device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, 
 // give Qxx, Qux and Quu in one Gram matrix; P_k = sym(M_xx) + H_k + sym(Qux^T K) with K = -Quu^-1 Qux by
 // Cholesky solves.  P, AB, W stay in LDS for the whole horizon; A_k, B_k stream from the (L2 resident)
 // TPWL tables.
-__device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, QPWork &w, QPLds &L,
+__device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, QPWork &w, QPLds &L,
                                      bool full, bool with_dual, double *rd_out) {
-    const int n = d.n, m = d.m, N = d.N, ld = d.ld, NK = d.NK;
+    const int n = d.n, m = d.m, N = d.N, ld = d.ld, NK = d.NK, NPa = d.NPa, n16 = (d.n + 15) & ~15;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int xoff = d.tr ? 2 * n + 1 : 0;
     double rd = 0.0;
+    // register prefetch of the next stage's [A | B]: thread (ii0, jj) owns column jj of rows ii0 + q*rstep
+    constexpr int PF = 12;
+    double pre[PF];
+    const int jj = tid % NPa, ii0 = tid / NPa, rstep = nt / NPa;
+    const bool pf_on = ii0 < rstep && jj < n + m;
+#define AB_PREFETCH(kst)                                                                            \
+    do {                                                                                           \
+        const size_t sel_ = dyn.sel(kst);                                                          \
+        cgptr src_ = jj < n ? dyn.A + sel_ * n * n + jj : dyn.B + sel_ * n * m + (jj - n);         \
+        const int stride_ = jj < n ? n : m;                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < PF; ++q_) {                                        \
+            const int i_ = ii0 + q_ * rstep;                                                       \
+            pre[q_] = (pf_on && i_ < n) ? src_[(size_t)i_ * stride_] : 0.0;                        \
+        }                                                                                          \
+    } while (0)
+#define AB_STORE()                                                                                 \
+    do {                                                                                           \
+        _Pragma("unroll") for (int q_ = 0; q_ < PF; ++q_) {                                        \
+            const int i_ = ii0 + q_ * rstep;                                                       \
+            if (pf_on && i_ < n) L.AB[i_ * ld + jj] = pre[q_];                                     \
+        }                                                                                          \
+    } while (0)
+    if (full) AB_PREFETCH(N - 1);
+#ifdef SRH_PROFILE
+    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl = wall_clock64();
+    auto lap = [&](int sl) { const long long now = wall_clock64(); tp[sl] += now - tl; tl = now; };
+#endif
     // ---- terminal stage
     {
         const int k = N;
@@ -443,96 +626,79 @@ __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QP
     }
     for (int k = N - 1; k >= 0; --k) {
         const size_t sel = dyn.sel(k);
-        const double *Ag = dyn.A + sel * n * n, *Bg = dyn.B + sel * n * m;
+        cgptr Ag = dyn.A + sel * n * n, Bg = dyn.B + sel * n * m;
         if (full) {
-            // stage [A | B] into LDS (pad rows / columns stay zero)
-            for (int e = tid; e < n * n; e += nt) { const int i = e / n, j = e - i * n; L.AB[i * ld + j] = Ag[e]; }
-            for (int e = tid; e < n * m; e += nt) { const int i = e / m, j = e - i * m; L.AB[i * ld + n + j] = Bg[e]; }
+            // [A_k | B_k] was prefetched into registers during the previous stage (or just above for k = N-1)
+            AB_STORE();
             for (int e = tid; e < m * m; e += nt) L.Quu[e] = w.Huu[(size_t)k * m * m + e];
             if (k >= 1) {
                 for (int e = tid; e < n; e += nt) { L.hdv[e] = w.hd[(size_t)k * n + e]; L.cvv[e] = w.cv[(size_t)k * n + e]; }
                 if (tid < d.nX) L.Dx[tid] = w.D[(size_t)(k - 1) * d.RX + xoff + tid];
             }
             __syncthreads();
-            mfma_atb(L.W, L.P, L.AB, NK, (n + 15) >> 4, ld >> 4, ld, n);         // W = P [A|B]
-            mfma_atb(L.P, L.AB, L.W, NK, ld >> 4, ld >> 4, ld, ld);              // M = [A|B]^T W
-            // [A|B]^T pv and [A|B]^T adj : (n+m) outputs each, 4 partial sums per output
-            {
-                const int nout = 2 * (n + m), S = nt / (2 * ld) > 0 ? nt / (2 * ld) : 1;
-                const int o = tid % (2 * ld), sl = tid / (2 * ld);
-                if (sl < S && o < 2 * ld) {
-                    const int col = o % ld;
-                    const double *vec = o < ld ? L.pv : L.adj;
-                    double acc = 0.0;
-                    if (col < n + m) for (int i = sl; i < n; i += S) acc = fma(L.AB[i * ld + col], vec[i], acc);
-                    L.part[sl * 2 * ld + o] = acc;
+            SRH_LAP(0);
+            mfma_atb(L.W, ld, L.P, L.AB, NK, n16 >> 4, NPa >> 4, ld, n);          // W = P [A|B]
+            SRH_LAP(1);
+            if (k >= 1) AB_PREFETCH(k - 1);                                        // next stage's tables: in flight
+            mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16);           // [Qux | B^T P B] = B^T W
+            SRH_LAP(2);
+            // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (one wave per output), Quu += B^T P B
+            for (int o = wave; o < 2 * m; o += nw) {
+                const int a = o % m;
+                clptr vec = o < m ? L.pv : L.adj;
+                double v = 0.0;
+                for (int i = lane; i < n; i += 64) v = fma(L.AB[i * ld + n + a], vec[i], v);
+                v = wg::wave_sum(v);
+                if (lane == 0) {
+                    if (o < m) L.Qu[a] = v + w.gu[(size_t)k * m + a];
+                    else L.rdu[a] = v + w.gud[(size_t)k * m + a];
                 }
-                __syncthreads();
-                if (tid < 2 * ld) {
-                    double r = 0.0;
-                    for (int q = 0; q < S; ++q) r += L.part[q * 2 * ld + tid];
-                    if (tid < ld) L.ypv[tid] = r; else L.yadj[tid - ld] = r;
-                }
-                (void)nout;
             }
-            __syncthreads();
-            if (tid < m) {
-                L.Qu[tid] = w.gu[(size_t)k * m + tid] + L.ypv[n + tid];
-                L.rdu[tid] = w.gud[(size_t)k * m + tid] + L.yadj[n + tid];
-            }
-            for (int e = tid; e < m * m; e += nt) { const int a = e / m, b = e - a * m; L.Quu[e] += L.P[(n + a) * ld + n + b]; }
+            for (int e = tid; e < m * m; e += nt) { const int a = e / m, b = e - a * m; L.Quu[e] += L.QUX[a * ld + n + b]; }
             __syncthreads();
             if (with_dual && tid < m) rd = fmax(rd, fabs(L.rdu[tid]));
-            // Quu = Lc Lc^T; K = -Quu^-1 Qux by triangular solves, one state column per thread (backward
-            // stable: an explicit inverse loses the weakly curved input directions once the active-bound
-            // weights reach 1e12).  Qux = M[n.., 0..n).
-            if (!wg::chol_factor(L.Quu, L.Lc, m, L.flag, true)) return false;
-            for (int j = tid; j < n; j += nt) {
-                wg::chol_solve_neg(L.Lc, m, L.P + n * ld + j, ld, L.Km + j, ld);
-                for (int a = 0; a < m; ++a) w.K[((size_t)k * m + a) * n + j] = L.Km[a * ld + j];
-            }
-            for (int e = tid; e < m * m; e += nt) w.Qinv[(size_t)k * m * m + e] = L.Lc[e];
-            if (tid == 0) {
-                wg::chol_solve_neg(L.Lc, m, L.Qu, 1, L.kf, 1);
-                for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
-            }
-            __syncthreads();
+            SRH_LAP(3);
+            if (!stage_gain(d, w, L, k, k >= 1)) return false;
+            SRH_LAP(4);
             if (k >= 1) {
-                // P_k (in place over M): each unordered pair (i,j) is owned by one thread
+                // P_k = A^T W + (extra rows: -Y^T Y + X^T D X); columns n, n+1 deliver A^T pv, A^T adj
+                mfma_atb(L.P, ld, L.AB, L.W, NK + d.NE4, n16 >> 4, ((n + 2 + 15) & ~15) >> 4, ld, n16);
+                // finish in place: symmetrise, add the constant 2 H^T Qz H and the slack-eliminated trust region.
+                // Each unordered pair (i,j) is owned by one thread.
                 const double Hss = d.tr ? w.Hss[k] : 1.0;
-                for (int e = tid; e < n * n; e += nt) {
-                    const int i = e / n, j = e - i * n;
-                    if (j < i) continue;
-                    double v = 0.5 * (L.P[i * ld + j] + L.P[j * ld + i]) + stage_hess(d, c, L, k, i, j, Hss, d.nX);
-                    double kk = 0.0;
-                    for (int a = 0; a < m; ++a)
-                        kk += L.P[(n + a) * ld + i] * L.Km[a * ld + j] + L.P[(n + a) * ld + j] * L.Km[a * ld + i];
-                    v += 0.5 * kk;
-                    L.W[i * ld + j] = v;  // staged in W (free after the second product), copied below
-                    if (i != j) L.W[j * ld + i] = v;
+                const int sh = 32 - __clz(n - 1), msk = (1 << sh) - 1;          // j = e & msk, i = e >> sh
+                for (int e = tid; e < (n << sh); e += nt) {
+                    const int i = e >> sh, j = e & msk;
+                    if (j < i || j >= n) continue;
+                    double v = 0.5 * (L.P[i * ld + j] + L.P[j * ld + i]) + c.Qx[(size_t)i * n + j];
+                    if (d.tr) {
+                        if (i == j) v += L.hdv[i];
+                        else v -= L.cvv[i] * L.cvv[j] / Hss;
+                    }
+                    L.P[i * ld + j] = v;
+                    L.P[j * ld + i] = v;
                 }
                 // pv_new = gx + A^T pv + K^T Qu ; adj_new = gxd + A^T adj
                 for (int e = tid; e < 2 * n; e += nt) {
                     const int j = e % n;
                     if (e < n) {
-                        double v = w.gx[(size_t)k * n + j] + L.ypv[j];
+                        double v = w.gx[(size_t)k * n + j] + L.P[j * ld + n];
                         for (int a = 0; a < m; ++a) v = fma(L.Km[a * ld + j], L.Qu[a], v);
                         L.v1[j] = v;
                     } else {
-                        L.v2[j] = w.gxd[(size_t)k * n + j] + L.yadj[j];
+                        L.v2[j] = w.gxd[(size_t)k * n + j] + L.P[j * ld + n + 1];
                     }
                 }
                 __syncthreads();
-                for (int e = tid; e < n * n; e += nt) { const int i = e / n, j = e - i * n; L.P[i * ld + j] = L.W[i * ld + j]; }
                 for (int e = tid; e < (NK - n) * ld; e += nt) L.P[n * ld + e] = 0.0;
                 for (int e = tid; e < n; e += nt) { L.pv[e] = L.v1[e]; L.adj[e] = L.v2[e]; }
-                __syncthreads();
             }
+            SRH_LAP(5);
         } else {
             // vector-only re-solve: A^T pv, B^T pv straight from the L2-resident tables
             for (int e = tid; e < m * n; e += nt) { const int a = e / n, j = e - a * n; L.Km[a * ld + j] = w.K[(size_t)k * m * n + e]; }
             for (int e = tid; e < m * m; e += nt) L.Lc[e] = w.Qinv[(size_t)k * m * m + e];
-            wg::matTvec(L.ypv, Ag, n, n, n, L.pv, nullptr, L.part);
+            wg::matTvec(L.ypv, Ag, n, n, n, L.pv, (cgptr)nullptr, L.part);
             for (int a = wave; a < m; a += nw) {
                 double v = 0.0;
                 for (int i = lane; i < n; i += 64) v = fma(Bg[i * m + a], L.pv[i], v);
@@ -562,6 +728,7 @@ __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QP
         rd = wg::reduce(rd, 1, L.red);
         if (rd_out) *rd_out = rd;
     }
+    SRH_LAP(6);
     // ---- forward sweep: dx_0 = 0
     for (int e = tid; e < n; e += nt) { L.v1[e] = 0.0; w.dx[e] = 0.0; }
     if (tid == 0) w.ds[0] = 0.0;
@@ -576,8 +743,8 @@ __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QP
             if (lane == 0) { v += w.kff[(size_t)k * m + a]; L.kf[a] = v; w.du[(size_t)k * m + a] = v; }
         }
         __syncthreads();
-        wg::matTvec(L.v2, dyn.AT + sel * n * n, n, n, n, L.v1, nullptr, L.part);
-        wg::matTvec(L.v2, dyn.BT + sel * m * n, n, m, n, L.kf, L.v2, L.part);
+        wg::matTvec(L.v2, dyn.AT + sel * n * n, n, n, n, L.v1, (cgptr)nullptr, L.part);
+        wg::matTvec(L.v2, dyn.BT + sel * m * n, n, m, n, L.kf, (clptr)L.v2, L.part);
         for (int e = tid; e < n; e += nt) { L.v1[e] = L.v2[e]; w.dx[(size_t)(k + 1) * n + e] = L.v2[e]; }
         if (d.tr && wave == 0) {
             double v = 0.0;
@@ -588,11 +755,15 @@ __device__ inline bool riccati_solve(const QPDims &d, const QPConst &c, const QP
         __syncthreads();
     }
     if (!d.tr) { for (int k = tid; k <= N; k += nt) w.ds[k] = 0.0; __syncthreads(); }
+    SRH_LAP(7);
+#ifdef SRH_PROFILE
+    if (w.tprof && tid == 0) for (int i = 0; i < 8; ++i) w.tprof[i] += (double)tp[i];
+#endif
     return true;
 }
 
 // largest step keeping t + a dt >= 0 and lam + a dlam >= 0 (not clamped to 1)
-__device__ inline double max_step(const QPDims &d, const QPWork &w, QPLds &L) {
+__device__ __forceinline__ double max_step(const QPDims &d, const QPWork &w, QPLds &L) {
     double a = 1e300;
     for_rows(d, [&](int row, bool, int, int) {
         const double dt = w.dt[row], dl = w.dlam[row];
@@ -603,80 +774,62 @@ __device__ inline double max_step(const QPDims &d, const QPWork &w, QPLds &L) {
 }
 
 // Solve one QP.  Results in w.x, w.u, w.s.  Returns status: 0 optimal, 1 max iterations, 2 numerical failure.
-__device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, const QPData &q, QPWork &w,
-                            QPLds &L, double *J_out, int *iters_out) {
-    const int N = d.N, n = d.n, m = d.m;
+//
+// One loop drives every Newton system through a single (inlined) copy of the pre-pass and the Riccati
+// solve: mode INIT computes the least-squares starting point (unit weights), PRED the affine-scaling
+// direction (factorisation + solve), CORR the Mehrotra corrector (re-solve with the stored factors).
+// With `prescreen` the trust-region rows are dropped first (see below) and the full QP is only solved
+// when the relaxed minimiser leaves the trust region.
+__device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
+                                     QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const double s0 = slack0(d, c, q, L);
-    for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
-    for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
-    __syncthreads();
-    rollout(d, dyn, q, w.u, w.x, L);
     int status = 1, it = 0;
-    long long tm[6] = {0, 0, 0, 0, 0, 0};
-    long long t_last = wall_clock64();
-    auto lap = [&](int slot) { const long long now = wall_clock64(); tm[slot] += now - t_last; t_last = now; };
-    if (d.ng == 0) {
-        for (int e = tid; e < d.NR; e += nt) { w.D[e] = 0.0; w.rho[e] = 0.0; w.lam[e] = 0.0; }
-        __syncthreads();
-        stage_prepass(d, c, q, w, false);
-        if (!riccati_solve(d, c, dyn, w, L, true, false, nullptr)) status = 2;
-        else {
-            for (int e = tid; e < N * m; e += nt) w.u[e] += w.du[e];
-            __syncthreads();
-            status = 0;
+    double J = 0.0;
+    const int npass = (prescreen && dfull.tr) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        // Trust-region prescreen.  The 2n+1 trust-region rows per stage are 90 % of the inequality rows, yet
+        // with GuSTO's delta (1e4 initially) they are almost never active.  Pass 0 solves the QP WITHOUT
+        // them: if its minimiser satisfies ||xs (x_k - xbar_k)||_inf <= delta for every k then
+        // (x, u, s = s_0 e_0) is feasible for the full QP at the same cost and therefore its minimiser
+        // (dropping satisfied constraints cannot change an optimum; the slack cost omega*s >= 0 is minimal
+        // at 0) -- identical result, 10x fewer rows.  Otherwise pass 1 solves the full QP.
+        QPDims d = dfull;
+        if (npass == 2 && pass == 0) {
+            d.tr = 0;
+            d.nrx = d.nX;
+            d.RX = d.nrx + d.nXf;
+            d.NR = d.N * d.RX + d.N * d.nU;
+            d.ng = d.N * d.nrx + d.nXf + d.N * d.nU;
         }
-    } else {
-        // ---- starting point: unit weights, rho = a.w - h  (least-squares point), then shift
-        rows_apply(d, c, w.x, w.s, w.u, w.rg);
+        QPWork w;
+        qp_carve(w, work_base, d);
+        wout = w;
+        const int N = d.N, n = d.n, m = d.m;
+        w.tprof = (gptr)nullptr;
+        const double s0 = slack0(dfull, c, q, L);
+        for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
+        for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
         __syncthreads();
-        for_rows(d, [&](int row, bool isU, int k, int r) {
-            const double g = w.rg[row] - row_h(d, c, q, isU, k, r);
-            w.D[row] = 1.0; w.rho[row] = g; w.lam[row] = 0.0;
-        });
-        __syncthreads();
-        stage_prepass(d, c, q, w, false);
-        bool ok = riccati_solve(d, c, dyn, w, L, true, false, nullptr);
-        if (!ok) status = 2;
-        if (ok) {
-            for (int e = tid; e < (N + 1) * n; e += nt) w.x[e] += w.dx[e];
-            for (int e = tid; e < N * m; e += nt) w.u[e] += w.du[e];
-            for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : w.s[e] + w.ds[e];
-            __syncthreads();
-            rows_apply(d, c, w.x, w.s, w.u, w.rg);
-            __syncthreads();
-            double zmin = INFINITY, zmax = -INFINITY;
-            for_rows(d, [&](int row, bool isU, int k, int r) {
-                const double g = w.rg[row] - row_h(d, c, q, isU, k, r);
-                w.rg[row] = g;
-                zmin = fmin(zmin, g); zmax = fmax(zmax, g);
-            });
-            zmin = wg::reduce(zmin, 2, L.red);
-            zmax = wg::reduce(zmax, 1, L.red);
-            const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
-            for_rows(d, [&](int row, bool, int, int) {
-                const double g = w.rg[row];
-                w.t[row] = -g + sh_t; w.lam[row] = g + sh_l;
-            });
-            __syncthreads();
-            // scales for the stopping test (as oracle/riccati_ipm.py)
-            double sd = 1.0, sp = 1.0;
-            for (int e = tid; e < n; e += nt) {
-                double g = 0.0;
-                if (q.z) for (int a = 0; a < d.nz; ++a) g = fma(c.HtQz2[e * d.nz + a], -q.z[d.nz + a], g);
-                sd = fmax(sd, fabs(g));
-            }
-            for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
-            sd = fmax(wg::reduce(sd, 1, L.red), q.omega);
-            sp = fmax(wg::reduce(sp, 1, L.red), fabs(q.delta));
-            const double dreg = d.reg / sd;
-            bool near_opt = false;
-            lap(0);
-            for (it = 0; it < d.max_iter; ++it) {
-                // residuals, weights, predictor shifts
+        rollout(d, dyn, q, w.u, w.x, L);
+        status = 1;
+        it = 0;
+        enum { INIT = 0, PRED = 1, CORR = 2 };
+        int mode = INIT;
+        double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
+        bool near_opt = false;
+        while (true) {
+            // ---------------- rows: weights D and gradient shifts rho for this Newton system
+            if (mode != CORR) {
                 rows_apply(d, c, w.x, w.s, w.u, w.rg);
                 __syncthreads();
-                double musum = 0.0, rp = 0.0;
+            }
+            if (mode == INIT) {
+                for_rows(d, [&](int row, bool isU, int k, int r) {
+                    const double g = w.rg[row] - row_h(d, c, q, isU, k, r);
+                    w.D[row] = d.ng ? 1.0 : 0.0; w.rho[row] = g; w.lam[row] = 0.0;
+                });
+            } else if (mode == PRED) {
+                double musum = 0.0, rpm = 0.0;
                 for_rows(d, [&](int row, bool isU, int k, int r) {
                     const double g = w.rg[row] - row_h(d, c, q, isU, k, r);
                     const double t = w.t[row], lam = w.lam[row];
@@ -686,24 +839,71 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                     w.D[row] = D;
                     w.rho[row] = D * (rg + dreg * lam);
                     musum += lam * t;
-                    rp = fmax(rp, fabs(rg));
+                    rpm = fmax(rpm, fabs(rg));
                 });
-                const double mu = wg::reduce(musum, 0, L.red) / d.ng;
-                rp = wg::reduce(rp, 1, L.red);
-                lap(1);
-                stage_prepass(d, c, q, w, true);
-                lap(2);
-                double rd = 0.0;
+                mu = wg::reduce(musum, 0, L.red) / d.ng;
+                rp = wg::reduce(rpm, 1, L.red);
+            } else {
+                for_rows(d, [&](int row, bool, int, int) {
+                    const double t = w.t[row], lam = w.lam[row];
+                    const double rc = lam * t + w.dt[row] * w.dlam[row] - sig * mu;
+                    w.rc[row] = rc;
+                    w.rho[row] = lam + (lam * w.rg[row] - rc) / (t + dreg * lam);
+                });
+            }
+            __syncthreads();
+            // ---------------- Newton system
+            stage_prepass(d, c, q, w, mode == PRED);
+            double rd = 0.0;
+            const bool ok = riccati_solve(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
+            // ---------------- use the direction
+            if (mode == INIT) {
+                if (!ok) { status = 2; break; }
+                for (int e = tid; e < (N + 1) * n; e += nt) w.x[e] += w.dx[e];
+                for (int e = tid; e < N * m; e += nt) w.u[e] += w.du[e];
+                for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : w.s[e] + w.ds[e];
+                __syncthreads();
+                if (d.ng == 0) { status = 0; break; }      // no inequality rows: the Newton point is the solution
+                rows_apply(d, c, w.x, w.s, w.u, w.rg);
+                __syncthreads();
+                double zmin = INFINITY, zmax = -INFINITY;
+                for_rows(d, [&](int row, bool isU, int k, int r) {
+                    const double g = w.rg[row] - row_h(d, c, q, isU, k, r);
+                    w.rg[row] = g;
+                    zmin = fmin(zmin, g); zmax = fmax(zmax, g);
+                });
+                zmin = wg::reduce(zmin, 2, L.red);
+                zmax = wg::reduce(zmax, 1, L.red);
+                const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
+                for_rows(d, [&](int row, bool, int, int) {
+                    const double g = w.rg[row];
+                    w.t[row] = -g + sh_t; w.lam[row] = g + sh_l;
+                });
+                __syncthreads();
+                // scales for the stopping test (as oracle/riccati_ipm.py)
+                for (int e = tid; e < n; e += nt) {
+                    double g = 0.0;
+                    if (q.z) for (int a = 0; a < d.nz; ++a) g = fma(c.HtQz2[e * d.nz + a], -q.z[d.nz + a], g);
+                    sd = fmax(sd, fabs(g));
+                }
+                for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
+                sd = fmax(wg::reduce(sd, 1, L.red), q.omega);
+                sp = fmax(wg::reduce(sp, 1, L.red), fabs(q.delta));
+                dreg = d.reg / sd;
+                mode = PRED;
+                continue;
+            }
+            if (mode == PRED) {
                 // a factorisation that breaks down in the last digits of an already converged iterate
                 // (weights D = lam/t up to 1e13) is accepted at the looser 1e-8 certificate
-                if (!riccati_solve(d, c, dyn, w, L, true, true, &rd)) { status = near_opt ? 0 : 2; break; }
+                if (!ok) { status = near_opt ? 0 : 2; break; }
                 if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
                 if (!(rd == rd)) { status = near_opt ? 0 : 6; break; }
-                if (q.dbg && threadIdx.x == 0) { double *g = q.dbg + 8 * it; g[0] = mu; g[1] = rd; g[2] = rp; g[3] = sd; g[4] = sp; }
+                if (q.dbg && tid == 0) { gptr g = q.dbg + 8 * it; g[0] = mu; g[1] = rd; g[2] = rp; g[3] = sd; g[4] = sp; }
                 const double ltol = fmax(d.tol, 1e-9);     // linear residuals: round-off floor (see the port)
                 if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
                 near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
-                lap(3);
+                if (it >= d.max_iter) { status = 1; break; }
                 // predictor direction on the rows
                 rows_apply(d, c, w.dx, w.ds, w.du, w.dt);
                 __syncthreads();
@@ -720,88 +920,51 @@ __device__ inline int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn,
                     ma += (w.lam[row] + a_aff * w.dlam[row]) * (w.t[row] + a_aff * w.dt[row]);
                 });
                 const double mu_aff = wg::reduce(ma, 0, L.red) / d.ng;
-                const double sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
-                for_rows(d, [&](int row, bool, int, int) {
-                    const double t = w.t[row], lam = w.lam[row];
-                    const double rc = lam * t + w.dt[row] * w.dlam[row] - sig * mu;
-                    w.rc[row] = rc;
-                    w.rho[row] = lam + (lam * w.rg[row] - rc) / (t + dreg * lam);
-                });
-                __syncthreads();
-                lap(1);
-                stage_prepass(d, c, q, w, false);
-                lap(2);
-                riccati_solve(d, c, dyn, w, L, false, false, nullptr);
-                lap(4);
-                rows_apply(d, c, w.dx, w.ds, w.du, w.dt);
-                __syncthreads();
-                for_rows(d, [&](int row, bool, int, int) {
-                    const double t = w.t[row], lam = w.lam[row], rga = w.rg[row] + w.dt[row];
-                    const double dl = (-w.rc[row] + lam * rga) / (t + dreg * lam);
-                    w.dlam[row] = dl;
-                    w.dt[row] = -rga + dreg * dl;
-                });
-                __syncthreads();
-                const double a = fmin(1.0, 0.99 * max_step(d, w, L));   // stay strictly interior
-                if (q.dbg && threadIdx.x == 0) { double *g = q.dbg + 8 * it; g[5] = a_aff; g[6] = sig; g[7] = a; }
-                for (int e = tid; e < (N + 1) * n; e += nt) w.x[e] += a * w.dx[e];
-                for (int e = tid; e < N * m; e += nt) w.u[e] += a * w.du[e];
-                for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : w.s[e] + a * w.ds[e];
-                for_rows(d, [&](int row, bool, int, int) {
-                    w.t[row] += a * w.dt[row];
-                    w.lam[row] += a * w.dlam[row];
-                });
-                __syncthreads();
+                sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+                if (q.dbg && tid == 0) { gptr g = q.dbg + 8 * it; g[5] = a_aff; g[6] = sig; }
+                mode = CORR;
+                continue;
+            }
+            // mode == CORR: step
+            rows_apply(d, c, w.dx, w.ds, w.du, w.dt);
+            __syncthreads();
+            for_rows(d, [&](int row, bool, int, int) {
+                const double t = w.t[row], lam = w.lam[row], rga = w.rg[row] + w.dt[row];
+                const double dl = (-w.rc[row] + lam * rga) / (t + dreg * lam);
+                w.dlam[row] = dl;
+                w.dt[row] = -rga + dreg * dl;
+            });
+            __syncthreads();
+            const double a = fmin(1.0, 0.99 * max_step(d, w, L));   // stay strictly interior
+            if (q.dbg && tid == 0) { gptr g = q.dbg + 8 * it; g[7] = a; }
+            for (int e = tid; e < (N + 1) * n; e += nt) w.x[e] += a * w.dx[e];
+            for (int e = tid; e < N * m; e += nt) w.u[e] += a * w.du[e];
+            for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : w.s[e] + a * w.ds[e];
+            for_rows(d, [&](int row, bool, int, int) {
+                w.t[row] += a * w.dt[row];
+                w.lam[row] += a * w.dlam[row];
+            });
+            __syncthreads();
+            ++it;
+            mode = PRED;
+        }
+        // final consistency: x is exactly the rollout of u
+        rollout(d, dyn, q, w.u, w.x, L);
+        J = objective(d, c, q, w.x, w.u, w.s, L);
+        if (npass == 2 && pass == 0) {
+            if (status != 0) continue;               // relaxed QP not solved: go to the full QP
+            double md = 0.0;
+            for (int e = tid + n; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (w.x[e] - q.xk[e])));
+            md = wg::reduce(md, 1, L.red);
+            if (md <= q.delta) {                     // trust region inactive: (x, u, s0 e_0) solves the full QP
+                J += q.omega * s0;
+                break;
             }
         }
     }
-    lap(1);
-    // final consistency: x is exactly the rollout of u
-    rollout(d, dyn, q, w.u, w.x, L);
-    const double J = objective(d, c, q, w.x, w.u, w.s, L);
-    lap(5);
-    if (q.dbg && threadIdx.x == 0) for (int i = 0; i < 6; ++i) q.dbg[8 * 62 + i] = (double)tm[i];
     if (J_out) *J_out = J;
     if (iters_out) *iters_out = it;
     return status;
-}
-
-// Trust-region prescreen.  The 2n+1 trust-region rows per stage are 90 % of the inequality rows, yet with
-// GuSTO's delta (1e4 initially) they are almost never active.  Solve the QP WITHOUT them first: if the
-// minimiser satisfies ||xs (x_k - xbar_k)||_inf <= delta for every k, then (x, u, s = s_0 e_0) is feasible
-// for the full QP at the same cost and therefore its minimiser (dropping satisfied constraints cannot
-// change an optimum; the slack cost omega * s >= 0 is minimal at 0) -- identical result, 10x fewer rows.
-// Otherwise the full QP is solved.
-__device__ inline int solve_prescreen(const QPDims &d, const QPConst &c, const QPDyn &dyn, const QPData &q,
-                                      double *work_base, QPWork &w, QPLds &L, double *J_out, int *iters_out) {
-    if (d.tr) {
-        QPDims dn = d;
-        dn.tr = 0;
-        dn.nrx = d.nX;
-        dn.RX = dn.nrx + d.nXf;
-        dn.NR = d.N * dn.RX + d.N * d.nU;
-        dn.ng = d.N * dn.nrx + d.nXf + d.N * d.nU;
-        QPWork wn;
-        qp_carve(wn, work_base, dn);
-        double J;
-        int it;
-        const int st = solve(dn, c, dyn, q, wn, L, &J, &it);
-        if (st == 0) {
-            double md = 0.0;
-            for (int e = threadIdx.x + d.n; e < (d.N + 1) * d.n; e += blockDim.x)
-                md = fmax(md, fabs(c.xs[e % d.n] * (wn.x[e] - q.xk[e])));
-            md = wg::reduce(md, 1, L.red);
-            if (md <= q.delta) {
-                const double s0 = slack0(d, c, q, L);
-                for (int e = threadIdx.x; e <= d.N; e += blockDim.x) w.s[e] = (e == 0) ? s0 : 0.0;
-                __syncthreads();
-                if (J_out) *J_out = J + q.omega * s0;
-                if (iters_out) *iters_out = it;
-                return 0;
-            }
-        }
-    }
-    return solve(d, c, dyn, q, w, L, J_out, iters_out);
 }
 
 }  // namespace qp

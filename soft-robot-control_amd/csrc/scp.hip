@@ -28,19 +28,21 @@ struct LocpBatch {
 __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, LocpBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     QPLds L;
-    qp_lds_carve(L, reinterpret_cast<double *>(smem), d, NTHREADS);
+    qp_lds_carve(L, (lptr)smem, d, NTHREADS);
     qp_lds_init(L, d, c);
     const size_t p = blockIdx.x;
     const size_t N = d.N, n = d.n, m = d.m;
     QPWork w;
-    qp_carve(w, b.work + p * b.work_stride, d);
-    QPDyn dyn{b.Ad + p * N * n * n, b.AdT + p * N * n * n, b.Bd + p * N * n * m, b.BdT + p * N * n * m,
-              b.dd + p * N * n, nullptr};
-    QPData q{b.x0 + p * n, b.xk + p * (N + 1) * n, b.z ? b.z + p * (N + 1) * d.nz : nullptr,
-             b.zf ? b.zf + p * d.nz : nullptr, b.ud ? b.ud + p * N * m : nullptr, b.delta[p], b.omega[p], (b.dbg && p == 0) ? b.dbg : nullptr};
+    gptr wbase = (gptr)(b.work + p * b.work_stride);
+    qp_carve(w, wbase, d);
+    QPDyn dyn{(cgptr)(b.Ad + p * N * n * n), (cgptr)(b.AdT + p * N * n * n), (cgptr)(b.Bd + p * N * n * m),
+              (cgptr)(b.BdT + p * N * n * m), (cgptr)(b.dd + p * N * n), (cgiptr)nullptr};
+    QPData q{(cgptr)(b.x0 + p * n), (cgptr)(b.xk + p * (N + 1) * n), (cgptr)(b.z ? b.z + p * (N + 1) * d.nz : nullptr),
+             (cgptr)(b.zf ? b.zf + p * d.nz : nullptr), (cgptr)(b.ud ? b.ud + p * N * m : nullptr), b.delta[p], b.omega[p],
+             (gptr)((b.dbg && p == 0) ? b.dbg : nullptr)};
     double J;
     int it;
-    const int st = qp::solve_prescreen(d, c, dyn, q, b.work + p * b.work_stride, w, L, &J, &it);
+    const int st = qp::solve(d, c, dyn, q, wbase, L, &J, &it, true, w);
     for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
     for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
     for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
@@ -71,38 +73,38 @@ struct GustoBatch {
 __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     QPLds L;
-    qp_lds_carve(L, reinterpret_cast<double *>(smem), d, NTHREADS);
+    qp_lds_carve(L, (lptr)smem, d, NTHREADS);
     qp_lds_init(L, d, c);
     const size_t p = blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
-    double *base = b.work + p * b.work_stride;
+    gptr base = (gptr)(b.work + p * b.work_stride);
     QPWork w;
     qp_carve(w, base, d);
-    double *xk = base + qp_work_doubles(d);
-    double *uk = xk + (size_t)(N + 1) * n;
-    double *accb = uk + (size_t)N * m;                 // 2*N doubles: per-stage error / approx
-    int *idx = reinterpret_cast<int *>(accb + 2 * (size_t)N);
-    int *idx2 = idx + N;
+    gptr xk = base + qp_work_doubles(d);
+    gptr uk = xk + (size_t)(N + 1) * n;
+    gptr accb = uk + (size_t)N * m;                    // 2*N doubles: per-stage error / approx
+    giptr idx = (giptr)(accb + 2 * (size_t)N);
+    giptr idx2 = idx + N;
 
-    const double *x0 = b.x0 + p * n;
+    cgptr x0 = (cgptr)(b.x0 + p * n);
     for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = b.x_init[p * (size_t)(N + 1) * n + e];
     for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
     __syncthreads();
     tpwl::nearest_many(T, xk, n, N, idx);
 
-    QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, idx};
+    QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
     bool converged = false;
     int itr = 0, status = 0;
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
-        QPData q{x0, xk, b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr, b.zf ? b.zf + p * nz : nullptr,
-                 b.ud ? b.ud + p * (size_t)N * m : nullptr, delta, omega, nullptr};
+        QPData q{x0, xk, (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr), (cgptr)(b.zf ? b.zf + p * nz : nullptr),
+                 (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
         double J;
         int qit;
-        const int st = qp::solve_prescreen(d, c, dyn, q, base, w, L, &J, &qit);
+        const int st = qp::solve(d, c, dyn, q, base, L, &J, &qit, true, w);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
         double md = 0.0;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                 double e2 = 0.0, a2 = 0.0;
                 for (int r = lane; r < n; r += 64) {
                     double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
-                    const double *Ak = T.AcT + ia * n * n, *An = T.AcT + ib * n * n;
+                    cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
                     for (int cidx = 0; cidx < n; ++cidx) {
                         const double xo = xk[(size_t)i * n + cidx], xn = w.x[(size_t)i * n + cidx];
                         const double a = Ak[(size_t)cidx * n + r];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                         fl = fma(a, xn - xo, fl);
                         f = fma(An[(size_t)cidx * n + r], xn, f);
                     }
-                    const double *Bk = T.BcT + ia * m * n, *Bn = T.BcT + ib * m * n;
+                    cgptr Bk = T.BcT + ia * m * n, Bn = T.BcT + ib * m * n;
                     for (int cidx = 0; cidx < m; ++cidx) {
                         const double uo = uk[(size_t)i * m + cidx], un = w.u[(size_t)i * m + cidx];
                         const double bb = Bk[(size_t)cidx * n + r];
@@ -226,11 +228,12 @@ struct QPConstHost {
     QPDims dims{};
     QPConst view() const {
         QPConst c{};
-        c.H = H.as<double>(); c.Qz = Qz.as<double>(); c.Qzf = Qzf.as<double>(); c.R = R.as<double>();
-        c.xs = xs.as<double>(); c.UA = UA.as<double>(); c.Ub = Ub.as<double>(); c.XA = XA.as<double>();
-        c.Xb = Xb.as<double>(); c.XfA = XfA.as<double>(); c.Xfb = Xfb.as<double>(); c.Qx = Qx.as<double>();
-        c.QxN = QxN.as<double>(); c.HtQz2 = HtQz2.as<double>(); c.HtQzf2 = HtQzf2.as<double>();
-        c.R2 = R2.as<double>();
+        auto g = [](const srh::DevBuf &b) { return (cgptr)b.as<double>(); };
+        c.H = g(H); c.Qz = g(Qz); c.Qzf = g(Qzf); c.R = g(R);
+        c.xs = g(xs); c.UA = g(UA); c.Ub = g(Ub); c.XA = g(XA);
+        c.Xb = g(Xb); c.XfA = g(XfA); c.Xfb = g(Xfb); c.Qx = g(Qx);
+        c.QxN = g(QxN); c.HtQz2 = g(HtQz2); c.HtQzf2 = g(HtQzf2);
+        c.R2 = g(R2);
         return c;
     }
 };
@@ -249,9 +252,12 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     QPDims &d = C.dims;
     d.N = N; d.n = n; d.m = m; d.nz = nz; d.nU = pr->nU; d.nX = pr->nX; d.nXf = pr->nXf;
     d.tr = pr->tr_active ? 1 : 0;
-    d.ld = (n + m + 15) & ~15;
+    d.NPa = (n + m + 15) & ~15;
+    d.ld = d.NPa + 1;
     d.mp = (m + 3) & ~3;
     d.NK = (n + 3) & ~3;
+    d.NE4 = (m + pr->nX + 3) & ~3;
+    d.RW = std::max((n + 15) & ~15, d.NK + d.NE4);
     d.nrx = d.tr * (2 * n + 1) + d.nX;
     d.RX = d.nrx + d.nXf;
     d.NR = N * d.RX + N * d.nU;
@@ -380,6 +386,7 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
         std::vector<double> t(8 * 64);
         dbg.download(t.data(), sizeof(double) * 8 * 64);
         fprintf(stderr, "[locp] time (10ns ticks): init %.0f rows %.0f prepass %.0f ricc_full %.0f ricc_vec %.0f final %.0f\n", t[8*62], t[8*62+1], t[8*62+2], t[8*62+3], t[8*62+4], t[8*62+5]);
+        fprintf(stderr, "[locp] riccati phases (10ns ticks): load %.0f gemm1 %.0f gemm2 %.0f matvec %.0f chol+K %.0f Pnew %.0f (vec/other %.0f) fwd %.0f\n", t[8*63], t[8*63+1], t[8*63+2], t[8*63+3], t[8*63+4], t[8*63+5], t[8*63+6], t[8*63+7]);
         for (int i = 0; i < 62 && (t[8 * i + 3] != 0.0); ++i)
             fprintf(stderr, "[locp] it %2d mu %.3e rd %.3e rp %.3e (sd %.2e sp %.2e) a_aff %.3e sigma %.3e a %.3e\n", i, t[8 * i], t[8 * i + 1], t[8 * i + 2], t[8 * i + 3], t[8 * i + 4], t[8 * i + 5], t[8 * i + 6], t[8 * i + 7]);
     }

@@ -17,9 +17,9 @@ __global__ void gather_kernel(TpwlDev T, const int32_t *__restrict__ idx, int64_
                               double *__restrict__ A, double *__restrict__ Bm, double *__restrict__ d) {
     const int64_t b = blockIdx.x;
     const int i = idx[b];
-    const double *As = (discrete ? T.Ad : T.Ac) + (size_t)i * T.n * T.n;
-    const double *Bs = (discrete ? T.Bd : T.Bc) + (size_t)i * T.n * T.m;
-    const double *ds = (discrete ? T.dd : T.dc) + (size_t)i * T.n;
+    cgptr As = (discrete ? T.Ad : T.Ac) + (size_t)i * T.n * T.n;
+    cgptr Bs = (discrete ? T.Bd : T.Bc) + (size_t)i * T.n * T.m;
+    cgptr ds = (discrete ? T.dd : T.dc) + (size_t)i * T.n;
     for (int e = threadIdx.x; e < T.n * T.n; e += blockDim.x) A[b * T.n * T.n + e] = As[e];
     for (int e = threadIdx.x; e < T.n * T.m; e += blockDim.x) Bm[b * T.n * T.m + e] = Bs[e];
     for (int e = threadIdx.x; e < T.n; e += blockDim.x) d[b * T.n + e] = ds[e];
@@ -30,11 +30,11 @@ __global__ __launch_bounds__(256) void rollout_kernel(TpwlDev T, const double *_
                                                       const double *__restrict__ U, int N,
                                                       double *__restrict__ X, double *__restrict__ Z) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *xc = reinterpret_cast<double *>(smem);       // n
-    double *xn = xc + T.n;                               // n
-    double *uc = xn + T.n;                               // m
-    double *part = uc + ((T.m + 3) & ~3);                // blockDim
-    int *ip = reinterpret_cast<int *>(part + blockDim.x);
+    lptr xc = (lptr)smem;                                // n
+    lptr xn = xc + T.n;                                  // n
+    lptr uc = xn + T.n;                                  // m
+    lptr part = uc + ((T.m + 3) & ~3);                   // blockDim
+    liptr ip = (liptr)(part + blockDim.x);
     const int64_t b = blockIdx.x;
     const int n = T.n, m = T.m;
     double *Xb = X + b * (size_t)(N + 1) * n;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(TpwlDev T, const double *_
         const int i = *ip;
         // xn = A x + d  (via the transposed table: coalesced), then += B u
         wg::matTvec(xn, T.AdT + (size_t)i * n * n, n, n, n, xc, T.dd + (size_t)i * n, part);
-        wg::matTvec(xn, T.BdT + (size_t)i * m * n, n, m, n, uc, xn, part);
+        wg::matTvec(xn, T.BdT + (size_t)i * m * n, n, m, n, uc, (clptr)xn, part);
         for (int e = threadIdx.x; e < n; e += blockDim.x) { xc[e] = xn[e]; Xb[(size_t)(k + 1) * n + e] = xn[e]; }
         __syncthreads();
     }
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(TpwlDev T, const double *_
 // f_i = A_c[j] x_i + B_c[j] u_i + d_c[j] at the stored points, j = nearest(x_i)  (models/tpwl.py:77-82)
 __global__ __launch_bounds__(64) void char_kernel(TpwlDev T, double *__restrict__ xabs, double *__restrict__ fabs_) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *x = reinterpret_cast<double *>(smem);
+    lptr x = (lptr)smem;
     const int i = blockIdx.x, n = T.n, r = T.r;
     for (int e = threadIdx.x; e < n; e += 64) x[e] = e < r ? T.vT[e * T.P + i] : T.qT[(e - r) * T.P + i];
     __syncthreads();
@@ -105,12 +105,13 @@ TpwlDev stpwl::view() const {
     TpwlDev T{};
     T.P = P; T.r = r; T.n = n; T.m = m; T.nz = nz;
     T.w_q = w_q; T.w_v = w_v;
-    T.qT = qT.as<double>(); T.vT = vT.as<double>(); T.u = u.as<double>();
-    T.Ac = Ac.as<double>(); T.Bc = Bc.as<double>(); T.dc = dc.as<double>();
-    T.AcT = AcT.as<double>(); T.BcT = BcT.as<double>();
-    T.Ad = Ad.as<double>(); T.Bd = Bd.as<double>(); T.dd = dd.as<double>();
-    T.AdT = AdT.as<double>(); T.BdT = BdT.as<double>();
-    T.H = H.as<double>(); T.z_ref = z_ref.as<double>();
+    auto g = [](const srh::DevBuf &b) { return (cgptr)b.as<double>(); };
+    T.qT = g(qT); T.vT = g(vT); T.u = g(u);
+    T.Ac = g(Ac); T.Bc = g(Bc); T.dc = g(dc);
+    T.AcT = g(AcT); T.BcT = g(BcT);
+    T.Ad = g(Ad); T.Bd = g(Bd); T.dd = g(dd);
+    T.AdT = g(AdT); T.BdT = g(BdT);
+    T.H = g(H); T.z_ref = g(z_ref);
     return T;
 }
 

@@ -6,22 +6,23 @@
 struct TpwlDev {
     int P, r, n, m, nz;
     double w_q, w_v;
-    const double *qT, *vT;            // (r x P) transposed point tables (coalesced over points)
-    const double *u;                  // (P x m)
-    const double *Ac, *Bc, *dc;       // continuous tables (P x n x n), (P x n x m), (P x n)
-    const double *AcT;                // (P x n x n) transposed
-    const double *Ad, *Bd, *dd;       // discrete tables or null
-    const double *AdT;                // transposed discrete A
-    const double *BdT;                // (P x m x n) transposed discrete B
-    const double *BcT;                // (P x m x n)
-    const double *H, *z_ref;          // (nz x n), (nz) or null
+    cgptr qT, vT;            // (r x P) transposed point tables (coalesced over points)
+    cgptr u;                          // (P x m)
+    cgptr Ac, Bc, dc;       // continuous tables (P x n x n), (P x n x m), (P x n)
+    cgptr AcT;                // (P x n x n) transposed
+    cgptr Ad, Bd, dd;       // discrete tables or null
+    cgptr AdT;                // transposed discrete A
+    cgptr BdT;                // (P x m x n) transposed discrete B
+    cgptr BcT;                // (P x m x n)
+    cgptr H, z_ref;          // (nz x n), (nz) or null
 };
 
 namespace tpwl {
 
 // argmin_i w_q ||q_i - q|| + w_v ||v_i - v||, first minimum (np.argmin), for the state x (LDS or
 // global, x = [v; q]).  Executed by ONE wave (64 lanes); every lane returns the index.
-__device__ inline int nearest_wave(const TpwlDev &T, const double *__restrict__ x) {
+template <typename XP>
+__device__ inline int nearest_wave(const TpwlDev &T, XP x) {
     const int lane = threadIdx.x & 63;
     double best = INFINITY;
     int besti = 0x7fffffff;
@@ -58,7 +59,8 @@ __device__ inline int nearest_wave(const TpwlDev &T, const double *__restrict__ 
 
 // nearest point for `count` states X (count x n, LDS or global) -> idx (LDS/global int array).
 // All waves of the workgroup participate; ends with __syncthreads().
-__device__ inline void nearest_many(const TpwlDev &T, const double *X, int ldx, int count, int *idx) {
+template <typename XP, typename IP>
+__device__ inline void nearest_many(const TpwlDev &T, XP X, int ldx, int count, IP idx) {
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int k = wave; k < count; k += nw) {
         const int i = nearest_wave(T, X + (size_t)k * ldx);
