@@ -45,7 +45,7 @@ def build_model(w):
     return tp, gm
 
 
-def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows):
+def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
     """The CPU port (oracle/: numpy restatement, reference op sequence) on a bounded sample."""
     from oracle import gusto as ogusto, riccati_ipm as ripm, pod as opod, locp as olocp
     import workloads as wl
@@ -74,7 +74,7 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows):
             _, _, _, tr = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[b],
                                        np.zeros((N, m)), x_init[b], z=z[b], U=(w['UA'], w['Ub']),
                                        X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3,
-                                       qp_solver=qp_solver)
+                                       qp_solver=qp_solver, max_gusto_iters=max_iters)
             iters += len(tr)
         t_scp = time.perf_counter() - t0
     finally:
@@ -98,9 +98,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--rollouts', type=int, default=256, help='independent SCP rollouts per GPU per step')
+    ap.add_argument('--rollouts', type=int, default=512, help='independent SCP rollouts per GPU per step')
     ap.add_argument('--proj-batch', type=int, default=65536, help='snapshots per GPU in the POD projection batch')
     ap.add_argument('--proj-launches', type=int, default=4, help='projection launches per step')
+    ap.add_argument('--max-gusto-iters', type=int, default=5,
+                    help='GuSTO iteration cap per solve (the reference default is 500; its real-time drivers use 0-5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -148,7 +150,10 @@ def main():
     phase = (np.arange(R_) + R_ * rank) * (10.0 / max(1, R_ * world))
     z = np.stack([zi(phase[b] + dt * np.arange(N + 1)) for b in range(R_)])
     gusto = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']),
-                  X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, batch=R_, max_trace=0)
+                  X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, batch=R_, max_trace=0,
+                  max_gusto_iters=args.max_gusto_iters)
+    gusto.max_gusto_iters = args.max_gusto_iters
+    _lib.check(L.sgusto_plan_set_max_iters(gusto.plan, C.c_int(args.max_gusto_iters)), 'set_max_iters')
     d = {k: _lib.DeviceBuffer.from_array(v) for k, v in dict(x0=x0, u_init=u_init, x_init=x_init, z=z).items()}
     o = dict(xopt=_lib.DeviceBuffer(R_ * (N + 1) * n * 8), uopt=_lib.DeviceBuffer(R_ * N * m * 8),
              zopt=_lib.DeviceBuffer(R_ * (N + 1) * nz * 8), iters=_lib.DeviceBuffer(R_ * 4), status=_lib.DeviceBuffer(R_ * 4))
@@ -214,14 +219,15 @@ def main():
         'config': {'workload': 'C2: Diamond n_f=4884, POD r=30 (n_x=60, n_u=4), TPWL P=64 nn/zoh, SCP horizon N=50 '
                                'dt=0.05, U box + X box, figure-8 target; %d independent receding-horizon rollouts per GPU '
                                'per step + POD projection of %d snapshots x %d launches' % (R_, B, args.proj_launches),
-                   'rollouts_per_gpu': R_, 'proj_batch': B, 'scp_iters_per_step_rank0': it_per_step,
+                   'rollouts_per_gpu': R_, 'proj_batch': B, 'max_gusto_iters': args.max_gusto_iters, 'scp_iters_per_step_rank0': it_per_step,
                    'solves_not_converged_rank0': int((status != 0).sum())},
         'roofline': {'kernel': 'proj_kernel (srom_project_dev)', 'bound': 'hbm', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                      'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': alg_bytes},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=min(R_, 4), proj_rows=4096)
+        out['cpu_baseline'] = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=min(R_, 6), proj_rows=4096,
+                                           max_iters=args.max_gusto_iters)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

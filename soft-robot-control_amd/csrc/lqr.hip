@@ -1,0 +1,573 @@
+// Riccati recursions and iLQR on the device: one workgroup per problem, the cost-to-go matrix in LDS.
+// Reference: sofacontrol/lqr/traj_tracking_lqr.py:18-48 (TV-LQR), sofacontrol/lqr/lqr.py:6-21 (fixed-point
+// DARE), sofacontrol/lqr/ilqr.py:27-300 + sofacontrol/lqr/config.py (iLQR).
+#include "tpwl_host.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- tiny dense helpers (row-major, any address space, runtime sizes; one output per thread-iteration)
+// C (M x N) = alpha * op(A) * op(B) + beta * C0 ; op = transpose flag.  Ends with __syncthreads().
+template <bool TA, bool TB, typename CP, typename AP, typename BP>
+__device__ inline void mm(CP C, int ldc, AP A, int lda, BP B, int ldb, int M, int N, int K) {
+    for (int e = threadIdx.x; e < M * N; e += blockDim.x) {
+        const int i = e / N, j = e - i * N;
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double a = TA ? A[k * lda + i] : A[i * lda + k];
+            const double b = TB ? B[j * ldb + k] : B[k * ldb + j];
+            acc = fma(a, b, acc);
+        }
+        C[i * ldc + j] = acc;
+    }
+    __syncthreads();
+}
+
+// Cholesky (thread 0) + solve helper for m <= 16 on LDS
+__device__ inline bool chol16(lptr Q, lptr Lb, int m, liptr flag) { return wg::chol_factor(Q, Lb, m, flag, false); }
+
+struct LqrLds {
+    lptr P, W, T;          // n x n
+    lptr PB, BK;           // n x m (PB), m x n (K / Qux)
+    lptr Quu, Lc, Kt, Kk;  // m x m, m x m, m x n, m x n
+    lptr v1, v2, v3, v4;   // n
+    lptr u1, u2;           // m (16)
+    lptr red;
+    liptr flag;
+};
+
+__host__ __device__ inline size_t lqr_lds_doubles(int n, int m) {
+    return 3 * (size_t)n * n + 2 * (size_t)n * m + 2 * 256 + 2 * (size_t)m * n + 4 * (size_t)n + 32 + 16 + 4;
+}
+
+__device__ inline void lqr_carve(LqrLds &L, lptr base, int n, int m) {
+    lptr p = base;
+    auto take = [&](size_t c) { lptr q = p; p += c; return q; };
+    L.P = take((size_t)n * n); L.W = take((size_t)n * n); L.T = take((size_t)n * n);
+    L.PB = take((size_t)n * m); L.BK = take((size_t)n * m);
+    L.Quu = take(256); L.Lc = take(256);
+    L.Kt = take((size_t)m * n); L.Kk = take((size_t)m * n);
+    L.v1 = take(n); L.v2 = take(n); L.v3 = take(n); L.v4 = take(n);
+    L.u1 = take(16); L.u2 = take(16);
+    L.red = take(16);
+    L.flag = (liptr)take(4);
+}
+
+// K = -(R + B^T P B)^-1 B^T P A   into L.Kk (m x n); uses L.W = P A, L.PB = P B.  false if not PD.
+template <typename AP, typename BP, typename RP>
+__device__ inline bool lqr_gain(LqrLds &L, AP A, BP B, RP R, int n, int m) {
+    mm<false, false>(L.W, n, L.P, n, A, n, n, n, n);        // W = P A
+    mm<false, false>(L.PB, m, L.P, n, B, m, n, m, n);       // PB = P B
+    mm<true, false>(L.Quu, m, B, m, L.PB, m, m, m, n);      // B^T P B
+    for (int e = threadIdx.x; e < m * m; e += blockDim.x) L.Quu[e] += R[e];
+    mm<true, false>(L.Kt, n, B, m, L.W, n, m, n, n);        // B^T P A
+    if (!chol16(L.Quu, L.Lc, m, L.flag)) return false;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) wg::chol_solve_neg(L.Lc, m, L.Kt + j, n, L.Kk + j, n);
+    __syncthreads();
+    return true;
+}
+
+// ------------------------------------------------------------------ TV-LQR (traj_tracking_lqr.py:18-48)
+__global__ __launch_bounds__(NT) void tvlqr_kernel(const double *A, const double *B, const int *idx, int steps, int n,
+                                                   int m, const double *Q, const double *R, double *K, double *P,
+                                                   int *status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LqrLds L;
+    lqr_carve(L, (lptr)smem, n, m);
+    cgptr Ag = (cgptr)A, Bg = (cgptr)B, Qg = (cgptr)Q, Rg = (cgptr)R;
+    gptr Kg = (gptr)K, Pg = (gptr)P;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) { L.P[e] = Qg[e]; if (Pg) Pg[(size_t)steps * n * n + e] = Qg[e]; }
+    __syncthreads();
+    int st = 0;
+    for (int i = steps - 1; i >= 0; --i) {
+        const size_t sel = idx ? (size_t)idx[i] : (size_t)i;
+        cgptr Ai = Ag + sel * n * n, Bi = Bg + sel * n * m;
+        if (!lqr_gain(L, Ai, Bi, Rg, n, m)) { st = 2; break; }
+        for (int e = threadIdx.x; e < m * n; e += blockDim.x) Kg[(size_t)i * m * n + e] = L.Kk[e];
+        // Acl = A + B K (into T) ; P = Q + K^T R K + Acl^T P Acl
+        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+            const int r = e / n, c = e - r * n;
+            double v = Ai[e];
+            for (int a = 0; a < m; ++a) v = fma(Bi[r * m + a], L.Kk[a * n + c], v);
+            L.T[e] = v;
+        }
+        __syncthreads();
+        mm<false, false>(L.W, n, L.P, n, L.T, n, n, n, n);          // W = P Acl
+        mm<false, false>(L.Kt, n, Rg, m, L.Kk, n, m, n, m);         // R K
+        // new P (reads T, W, Kk, Kt; writes P only)
+        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+            const int r = e / n, c = e - r * n;
+            double v = Qg[e];
+            for (int a = 0; a < m; ++a) v = fma(L.Kk[a * n + r], L.Kt[a * n + c], v);
+            for (int k = 0; k < n; ++k) v = fma(L.T[k * n + r], L.W[k * n + c], v);
+            L.P[e] = v;
+            if (Pg) Pg[(size_t)i * n * n + e] = v;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *status = st;
+}
+
+// ------------------------------------------------------------------ fixed-point DARE (lqr.py:6-21)
+__global__ __launch_bounds__(NT) void dare_fp_kernel(const double *A, const double *B, int n, int m, const double *Q,
+                                                     const double *R, double tol, int max_iter, double *Lout,
+                                                     double *Pout, int *iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LqrLds L;
+    lqr_carve(L, (lptr)smem, n, m);
+    const size_t p = blockIdx.x;
+    cgptr Ag = (cgptr)A + p * n * n, Bg = (cgptr)B + p * n * m, Qg = (cgptr)Q, Rg = (cgptr)R;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) L.P[e] = 0.0;
+    __syncthreads();
+    // L = solve(R + B'PB, B'PA) with P = 0 (no sign): zeros; L_old = inf
+    bool first = true;
+    int it = 0;
+    // BK holds the previous gain (m x n) -- needs m*n <= n*m doubles
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) L.BK[e] = 0.0;
+    __syncthreads();
+    while (it < max_iter) {
+        // gain of the current P:  Kk = -(R + B'PB)^-1 B'PA  ; W = P A, Kt = B'PA
+        if (!lqr_gain(L, Ag, Bg, Rg, n, m)) break;
+        if (!first) {
+            double d2 = 0.0;
+            for (int e = threadIdx.x; e < m * n; e += blockDim.x) { const double d = L.Kk[e] - L.BK[e]; d2 = fma(d, d, d2); }
+            d2 = wg::reduce(d2, 0, L.red);
+            if (sqrt(d2) <= tol) break;
+        }
+        first = false;
+        for (int e = threadIdx.x; e < m * n; e += blockDim.x) L.BK[e] = L.Kk[e];
+        // P <- A'PA - A'PB (R+B'PB)^-1 B'PA + Q = A'W + (B'PA)' Kk + Q
+        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+            const int r = e / n, c = e - r * n;
+            double v = Qg[e];
+            for (int k = 0; k < n; ++k) v = fma(Ag[k * n + r], L.W[k * n + c], v);
+            for (int a = 0; a < m; ++a) v = fma(L.Kt[a * n + r], L.Kk[a * n + c], v);
+            L.T[e] = v;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n * n; e += blockDim.x) L.P[e] = L.T[e];
+        __syncthreads();
+        ++it;
+    }
+    for (int e = threadIdx.x; e < m * n; e += blockDim.x) Lout[p * m * n + e] = L.Kk[e];
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) Pout[p * n * n + e] = L.P[e];
+    if (threadIdx.x == 0 && iters) iters[p] = it;
+}
+
+// ------------------------------------------------------------------ iLQR (ilqr.py:27-300)
+struct IlqrArgs {
+    int N, n, m, nz;
+    silqr_params par;
+    const double *x0, *z_target, *u_warm, *u_last, *Q, *R, *Qf;
+    double *x, *u, *K, *cost;
+    int *iters;
+    double *work;          // per problem: x2 (N+1)n, u2 N m, kff N m, Qu N m, Quu N m m, K2 N m n
+    int *iwork;            // per problem: idx N, idx2 N
+    size_t work_stride;
+};
+
+__global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, n = a.n, m = a.m, nz = a.nz;
+    LqrLds L;
+    lqr_carve(L, (lptr)smem, n, m);
+    lptr HQH = L.red + 20;                    // placed after the carve: n x n
+    lptr zt = HQH + (size_t)n * n;            // nz scratch (16)
+    lptr part = zt + 16;                      // blockDim
+    const size_t p = blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    cgptr x0 = (cgptr)a.x0 + p * n, ztar = (cgptr)a.z_target + p * (size_t)(N + 1) * nz;
+    cgptr Qg = (cgptr)a.Q, Rg = (cgptr)a.R, Qfg = (cgptr)a.Qf;
+    gptr X = (gptr)a.x + p * (size_t)(N + 1) * n, U = (gptr)a.u + p * (size_t)N * m;
+    gptr Kout = (gptr)a.K + p * (size_t)N * m * n;
+    gptr wk = (gptr)a.work + p * a.work_stride;
+    gptr X2 = wk, U2 = X2 + (size_t)(N + 1) * n, kff = U2 + (size_t)N * m, Qu = kff + (size_t)N * m;
+    gptr Quu = Qu + (size_t)N * m, K2 = Quu + (size_t)N * m * m;
+    giptr idx = (giptr)a.iwork + p * 2 * (size_t)N, idx2 = idx + N;
+    const silqr_params &P_ = a.par;
+
+    // forward pass (ilqr.py:117-162): from (xp, up) with gains (Kg, kg, alpha) into (xo, uo, io); returns cost
+    auto forward = [&](cgptr xp, cgptr up, double alpha, cgptr Kg, cgptr kg, gptr xo, gptr uo, giptr io) -> double {
+        double cost = 0.0;
+        for (int e = tid; e < n; e += nt) { L.v1[e] = x0[e]; xo[e] = x0[e]; }
+        __syncthreads();
+        for (int t = 0; t < N; ++t) {
+            // u_t = u_prev + alpha k + K (x - x_prev)
+            if (tid < m) {
+                double v = up[(size_t)t * m + tid];
+                if (kg) v += alpha * kg[(size_t)t * m + tid];
+                if (Kg) for (int j = 0; j < n; ++j) v = fma(Kg[((size_t)t * m + tid) * n + j], L.v1[j] - xp[(size_t)t * n + j], v);
+                L.u1[tid] = v;
+                uo[(size_t)t * m + tid] = v;
+            }
+            if (tid >= 64 && tid < 128) {
+                const int i = tpwl::nearest_wave(T, (clptr)L.v1);
+                if (tid == 64) { io[t] = i; *L.flag = i; }
+            }
+            // z - z*  (z = H x + z_ref)
+            if (tid >= 128 && tid < 128 + nz) {
+                const int r = tid - 128;
+                double v = T.z_ref[r] - ztar[(size_t)t * nz + r];
+                for (int j = 0; j < n; ++j) v = fma(T.H[r * n + j], L.v1[j], v);
+                zt[r] = v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double c = 0.0;
+                for (int r = 0; r < nz; ++r) for (int s = 0; s < nz; ++s) c += zt[r] * Qg[r * nz + s] * zt[s];
+                double du[16];
+                for (int r = 0; r < m; ++r) du[r] = L.u1[r] - (t == 0 ? (a.u_last ? a.u_last[p * m + r] : 0.0) : uo[(size_t)(t - 1) * m + r]);
+                for (int r = 0; r < m; ++r) for (int s = 0; s < m; ++s) c += du[r] * Rg[r * m + s] * du[s];
+                cost += 0.5 * c;
+            }
+            const size_t i = (size_t)*L.flag;
+            wg::matTvec(L.v2, T.AdT + i * n * n, n, n, n, (clptr)L.v1, T.dd + i * n, part);
+            wg::matTvec(L.v2, T.BdT + i * m * n, n, m, n, (clptr)L.u1, (clptr)L.v2, part);
+            for (int e = tid; e < n; e += nt) { L.v1[e] = L.v2[e]; xo[(size_t)(t + 1) * n + e] = L.v2[e]; }
+            __syncthreads();
+        }
+        if (tid < nz) {
+            double v = T.z_ref[tid] - ztar[(size_t)N * nz + tid];
+            for (int j = 0; j < n; ++j) v = fma(T.H[tid * n + j], L.v1[j], v);
+            zt[tid] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double c = 0.0;
+            for (int r = 0; r < nz; ++r) for (int s = 0; s < nz; ++s) c += zt[r] * Qfg[r * nz + s] * zt[s];
+            cost += 0.5 * c;
+            L.red[15] = cost;
+        }
+        __syncthreads();
+        cost = L.red[15];
+        __syncthreads();
+        return cost;
+    };
+
+    double rho = P_.rho0, drho = P_.drho0;
+    auto reg_update = [&](bool increase) {       // ilqr.py:198-217 (decrease keeps drho: the reference's typo)
+        if (increase) {
+            drho = fmax(drho * P_.rho_scaling, P_.rho_scaling);
+            rho = fmax(rho * drho, P_.rho_min);
+            if (rho > P_.rho_max) rho = P_.rho_max;
+        } else {
+            const double dh = fmin(drho / P_.rho_scaling, 1.0 / P_.rho_scaling);
+            rho = rho * dh;
+            if (rho <= P_.rho_min) rho = P_.rho_min;
+        }
+    };
+
+    // c_xx = H^T Q H (constant), terminal uses Qf
+    // backward pass (ilqr.py:219-300) on the trajectory (X, U, idx); writes K2? no: Kout, kff, Qu, Quu
+    auto backward = [&]() {
+        while (true) {
+            // terminal: p = H^T Qf (z - z*), P = H^T Qf H
+            if (tid < nz) {
+                double v = T.z_ref[tid] - ztar[(size_t)N * nz + tid];
+                for (int j = 0; j < n; ++j) v = fma(T.H[tid * n + j], X[(size_t)N * n + j], v);
+                zt[tid] = v;
+            }
+            __syncthreads();
+            for (int e = tid; e < n * n; e += nt) {
+                const int r = e / n, c = e - r * n;
+                double v = 0.0, hq = 0.0;
+                for (int s = 0; s < nz; ++s) {
+                    double q1 = 0.0, q2 = 0.0;
+                    for (int s2 = 0; s2 < nz; ++s2) { q1 = fma(Qfg[s * nz + s2], T.H[s2 * n + c], q1); q2 = fma(Qg[s * nz + s2], T.H[s2 * n + c], q2); }
+                    v = fma(T.H[s * n + r], q1, v);
+                    hq = fma(T.H[s * n + r], q2, hq);
+                }
+                L.P[e] = v;
+                HQH[e] = hq;
+            }
+            for (int e = tid; e < n; e += nt) {
+                double v = 0.0;
+                for (int s = 0; s < nz; ++s) { double q1 = 0.0; for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qfg[s * nz + s2], zt[s2], q1); v = fma(T.H[s * n + e], q1, v); }
+                L.v1[e] = v;     // p
+            }
+            __syncthreads();
+            bool restart = false;
+            for (int t = N - 1; t >= 0; --t) {
+                const size_t i = (size_t)idx[t];
+                cgptr At = T.Ad + i * n * n, Bt = T.Bd + i * n * m;
+                // c_x = H^T Q (z - z*), c_u = R (u_t - u_{t-1})
+                if (tid < nz) {
+                    double v = T.z_ref[tid] - ztar[(size_t)t * nz + tid];
+                    for (int j = 0; j < n; ++j) v = fma(T.H[tid * n + j], X[(size_t)t * n + j], v);
+                    zt[tid] = v;
+                }
+                if (tid >= 64 && tid < 64 + m) {
+                    const int r = tid - 64;
+                    double v = 0.0;
+                    for (int s = 0; s < m; ++s) {
+                        const double du = U[(size_t)t * m + s] - (t == 0 ? (a.u_last ? a.u_last[p * m + s] : 0.0) : U[(size_t)(t - 1) * m + s]);
+                        v = fma(Rg[r * m + s], du, v);
+                    }
+                    L.u1[r] = v;        // c_u
+                }
+                __syncthreads();
+                mm<false, false>(L.W, n, L.P, n, At, n, n, n, n);        // P A
+                mm<false, false>(L.PB, m, L.P, n, Bt, m, n, m, n);       // P B
+                // Q_uu = R + B'PB ; Q~_uu = Q_uu + rho B'B ; Q_ux = B'PA ; Q~_ux = Q_ux + rho B'A
+                for (int e = tid; e < m * m; e += nt) {
+                    const int r = e / m, c = e - r * m;
+                    double v = Rg[e], bb = 0.0;
+                    for (int k = 0; k < n; ++k) { v = fma(Bt[k * m + r], L.PB[k * m + c], v); bb = fma(Bt[k * m + r], Bt[k * m + c], bb); }
+                    Quu[(size_t)t * m * m + e] = v;
+                    L.Quu[e] = v + rho * bb;
+                }
+                for (int e = tid; e < m * n; e += nt) {
+                    const int r = e / n, c = e - r * n;
+                    double v = 0.0, ba = 0.0;
+                    for (int k = 0; k < n; ++k) { v = fma(Bt[k * m + r], L.W[k * n + c], v); ba = fma(Bt[k * m + r], At[k * n + c], ba); }
+                    L.Kt[e] = v;                      // Q_ux
+                    L.BK[e] = v + rho * ba;           // Q~_ux
+                }
+                // Q_x = c_x + A'p ; Q_u = c_u + B'p
+                for (int e = tid; e < n + m; e += nt) {
+                    if (e < n) {
+                        double v = 0.0;
+                        for (int s = 0; s < nz; ++s) { double q1 = 0.0; for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qg[s * nz + s2], zt[s2], q1); v = fma(T.H[s * n + e], q1, v); }
+                        for (int k = 0; k < n; ++k) v = fma(At[k * n + e], L.v1[k], v);
+                        L.v2[e] = v;
+                    } else {
+                        const int r = e - n;
+                        double v = L.u1[r];
+                        for (int k = 0; k < n; ++k) v = fma(Bt[k * m + r], L.v1[k], v);
+                        L.u2[r] = v;
+                        Qu[(size_t)t * m + r] = v;
+                    }
+                }
+                __syncthreads();
+                if (!chol16(L.Quu, L.Lc, m, L.flag)) {            // not PD: raise rho, restart (ilqr.py:276-287)
+                    reg_update(true);
+                    restart = true;
+                    break;
+                }
+                for (int j = tid; j <= n; j += nt) {
+                    if (j < n) wg::chol_solve_neg(L.Lc, m, L.BK + j, n, L.Kk + j, n);
+                    else wg::chol_solve_neg(L.Lc, m, L.u2, 1, L.u1, 1);           // k (feed-forward) in u1
+                }
+                __syncthreads();
+                for (int e = tid; e < m * n; e += nt) Kout[(size_t)t * m * n + e] = L.Kk[e];
+                if (tid < m) kff[(size_t)t * m + tid] = L.u1[tid];
+                // p = Q_x + K'Quu k + K'Q_u + Q_ux' k ; P = Q_xx + K'Quu K + K'Q_ux + Q_ux'K
+                // QK = Quu K (m x n) into PB region (m*n <= n*m)
+                for (int e = tid; e < m * n; e += nt) {
+                    const int r = e / n, c = e - r * n;
+                    double v = 0.0;
+                    for (int s = 0; s < m; ++s) v = fma(Quu[(size_t)t * m * m + r * m + s], L.Kk[s * n + c], v);
+                    L.PB[e] = v;
+                }
+                if (tid < m) {
+                    double v = 0.0;
+                    for (int s = 0; s < m; ++s) v = fma(Quu[(size_t)t * m * m + tid * m + s], L.u1[s], v);
+                    zt[tid] = v;        // Quu k   (zt has 16 slots)
+                }
+                __syncthreads();
+                for (int e = tid; e < n * n; e += nt) {
+                    const int r = e / n, c = e - r * n;
+                    double v = HQH[e];
+                    for (int k = 0; k < n; ++k) v = fma(At[k * n + r], L.W[k * n + c], v);
+                    for (int s = 0; s < m; ++s) {
+                        v = fma(L.Kk[s * n + r], L.PB[s * n + c], v);
+                        v = fma(L.Kk[s * n + r], L.Kt[s * n + c], v);
+                        v = fma(L.Kt[s * n + r], L.Kk[s * n + c], v);
+                    }
+                    L.T[e] = v;
+                }
+                for (int e = tid; e < n; e += nt) {
+                    double v = L.v2[e];
+                    for (int s = 0; s < m; ++s) {
+                        v = fma(L.Kk[s * n + e], zt[s], v);
+                        v = fma(L.Kk[s * n + e], L.u2[s], v);
+                        v = fma(L.Kt[s * n + e], L.u1[s], v);
+                    }
+                    L.v3[e] = v;
+                }
+                __syncthreads();
+                for (int e = tid; e < n * n; e += nt) L.P[e] = L.T[e];
+                for (int e = tid; e < n; e += nt) L.v1[e] = L.v3[e];
+                __syncthreads();
+            }
+            if (restart) continue;
+            reg_update(false);
+            break;
+        }
+    };
+
+    // ---- ilqr_computation (ilqr.py:27-107)
+    for (int e = tid; e < (N + 1) * n; e += nt) X2[e] = (e < n) ? x0[e] : 0.0;
+    for (int e = tid; e < N * m; e += nt) U2[e] = a.u_warm ? a.u_warm[p * (size_t)N * m + e] : 0.0;
+    __syncthreads();
+    double cost = forward((cgptr)X2, (cgptr)U2, 1.0, (cgptr)nullptr, (cgptr)nullptr, X, U, idx);
+    int failed_counter = 0, it = 0;
+    bool converged = false;
+    while (!converged && it <= P_.max_iter) {
+        backward();
+        const double prev_cost = cost;
+        double alpha = P_.alpha0, new_cost = cost;
+        bool improved = false, failed = false;
+        while (!improved && !failed) {
+            improved = true;
+            new_cost = forward((cgptr)X, (cgptr)U, alpha, (cgptr)Kout, (cgptr)kff, X2, U2, idx2);
+            double dc = 0.0;
+            for (int t = tid; t < N; t += nt) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int r = 0; r < m; ++r) {
+                    s1 = fma(kff[(size_t)t * m + r], Qu[(size_t)t * m + r], s1);
+                    double q = 0.0;
+                    for (int s = 0; s < m; ++s) q = fma(Quu[(size_t)t * m * m + r * m + s], kff[(size_t)t * m + s], q);
+                    s2 = fma(kff[(size_t)t * m + r], q, s2);
+                }
+                dc += alpha * s1 + alpha * alpha * 0.5 * s2;
+            }
+            dc = wg::reduce(dc, 0, L.red);
+            const double ratio = (new_cost - prev_cost) / dc;
+            if (ratio <= P_.improv_lb || ratio > P_.improv_ub) {
+                alpha = P_.alpha_scaling * alpha;
+                improved = false;
+                if (alpha < P_.alpha_min) {
+                    reg_update(true);
+                    rho += P_.rho_increase_fp;
+                    failed = true;
+                }
+            }
+        }
+        if (!failed) {
+            __syncthreads();
+            for (int e = tid; e < (N + 1) * n; e += nt) X[e] = X2[e];
+            for (int e = tid; e < N * m; e += nt) U[e] = U2[e];
+            for (int e = tid; e < N; e += nt) idx[e] = idx2[e];
+            __syncthreads();
+            cost = new_cost;
+            converged = ((prev_cost - cost) < P_.epsilon) && ((prev_cost - cost) >= 0.0);
+            failed_counter = 0;
+        } else {
+            ++failed_counter;
+            if (failed_counter >= P_.counter_limit) converged = true;
+        }
+        ++it;
+    }
+    if (tid == 0) { a.cost[p] = cost; a.iters[p] = it; }
+}
+
+}  // namespace
+
+extern "C" {
+
+void silqr_default_params(silqr_params *p) {
+    if (!p) return;
+    p->max_iter = 50; p->epsilon = 0.1; p->alpha0 = 1.0; p->alpha_scaling = 0.5; p->improv_lb = 1e-4;
+    p->improv_ub = 100.0; p->alpha_min = 5e-2; p->counter_limit = 5; p->rho0 = 0.0; p->drho0 = 0.0;
+    p->rho_scaling = 1.5; p->rho_increase_fp = 10.0; p->rho_max = 1e5; p->rho_min = 1e-3;
+}
+
+static int tvlqr_impl(const double *dA, const double *dB, const int *didx, int n_steps, int n, int m, const double *Q,
+                      const double *R, double *K, double *P) {
+    srh::DevBuf dQ, dR, dK, dP, dS;
+    int rc;
+    if ((rc = dQ.upload(Q, sizeof(double) * n * n)) || (rc = dR.upload(R, sizeof(double) * m * m)) ||
+        (rc = dK.alloc(sizeof(double) * (size_t)n_steps * m * n)) || (rc = dP.alloc(sizeof(double) * (size_t)(n_steps + 1) * n * n)) ||
+        (rc = dS.alloc(sizeof(int))))
+        return rc;
+    const size_t lds = lqr_lds_doubles(n, m) * sizeof(double);
+    SRH_REQUIRE(lds <= 160 * 1024, "sric_tvlqr: state dimension too large for LDS");
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)tvlqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    tvlqr_kernel<<<1, NT, lds>>>(dA, dB, didx, n_steps, n, m, dQ.as<double>(), dR.as<double>(), dK.as<double>(),
+                                 dP.as<double>(), dS.as<int>());
+    SRH_CHECK_HIP(hipGetLastError());
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    int st = 0;
+    if ((rc = dS.download(&st, sizeof(int)))) return rc;
+    if (st != 0) { srh::set_error("sric_tvlqr: R + B'PB is not positive definite"); return SRH_ENUMERIC; }
+    if ((rc = dK.download(K, sizeof(double) * (size_t)n_steps * m * n))) return rc;
+    if (P) return dP.download(P, sizeof(double) * (size_t)(n_steps + 1) * n * n);
+    return SRH_OK;
+}
+
+int sric_tvlqr(const double *A, const double *B, int n_steps, int n_x, int n_u, const double *Q, const double *R,
+               double *K, double *P) {
+    SRH_REQUIRE(A && B && Q && R && K, "sric_tvlqr: null argument");
+    SRH_REQUIRE(n_steps > 0 && n_x > 0 && n_u > 0 && n_u <= 16, "sric_tvlqr: bad dimensions");
+    srh::DevBuf dA, dB;
+    int rc;
+    if ((rc = dA.upload(A, sizeof(double) * (size_t)n_steps * n_x * n_x)) || (rc = dB.upload(B, sizeof(double) * (size_t)n_steps * n_x * n_u)))
+        return rc;
+    return tvlqr_impl(dA.as<double>(), dB.as<double>(), nullptr, n_steps, n_x, n_u, Q, R, K, P);
+}
+
+int sric_tvlqr_tpwl(stpwl_t *h, const double *xbar, int n_steps, const double *Q, const double *R, double *K, double *P) {
+    SRH_REQUIRE(h && xbar && Q && R && K, "sric_tvlqr_tpwl: null argument");
+    SRH_REQUIRE(h->has_discrete, "sric_tvlqr_tpwl: model has not been pre-discretised");
+    srh::DevBuf dX, dI;
+    int rc;
+    if ((rc = dX.upload(xbar, sizeof(double) * (size_t)n_steps * h->n)) || (rc = dI.alloc(sizeof(int32_t) * n_steps))) return rc;
+    if ((rc = stpwl_nearest_dev(h, dX.as<double>(), n_steps, dI.as<int32_t>(), nullptr))) return rc;
+    return tvlqr_impl(h->Ad.as<double>(), h->Bd.as<double>(), dI.as<int>(), n_steps, h->n, h->m, Q, R, K, P);
+}
+
+int sric_dare_fixed_point(const double *A, const double *B, int64_t batch, int n_x, int n_u, const double *Q,
+                          const double *R, double tol, int max_iter, double *L, double *P, int32_t *iters) {
+    SRH_REQUIRE(A && B && Q && R && L && P, "sric_dare_fixed_point: null argument");
+    SRH_REQUIRE(batch > 0 && n_x > 0 && n_u > 0 && n_u <= 16, "sric_dare_fixed_point: bad dimensions");
+    srh::DevBuf dA, dB, dQ, dR, dL, dP, dI;
+    int rc;
+    if ((rc = dA.upload(A, sizeof(double) * batch * n_x * n_x)) || (rc = dB.upload(B, sizeof(double) * batch * n_x * n_u)) ||
+        (rc = dQ.upload(Q, sizeof(double) * n_x * n_x)) || (rc = dR.upload(R, sizeof(double) * n_u * n_u)) ||
+        (rc = dL.alloc(sizeof(double) * batch * n_u * n_x)) || (rc = dP.alloc(sizeof(double) * batch * n_x * n_x)) ||
+        (rc = dI.alloc(sizeof(int32_t) * batch)))
+        return rc;
+    const size_t lds = lqr_lds_doubles(n_x, n_u) * sizeof(double);
+    SRH_REQUIRE(lds <= 160 * 1024, "sric_dare_fixed_point: state dimension too large for LDS");
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)dare_fp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dare_fp_kernel<<<(unsigned)batch, NT, lds>>>(dA.as<double>(), dB.as<double>(), n_x, n_u, dQ.as<double>(), dR.as<double>(),
+                                                 tol, max_iter, dL.as<double>(), dP.as<double>(), dI.as<int>());
+    SRH_CHECK_HIP(hipGetLastError());
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    if ((rc = dL.download(L, sizeof(double) * batch * n_u * n_x)) || (rc = dP.download(P, sizeof(double) * batch * n_x * n_x))) return rc;
+    if (iters) return dI.download(iters, sizeof(int32_t) * batch);
+    return SRH_OK;
+}
+
+int silqr_solve(stpwl_t *h, int N, int64_t batch, const double *x0, const double *z_target, const double *u_warm,
+                const double *u_last, const double *Q, const double *R, const double *Qf, const silqr_params *p,
+                double *x, double *u, double *K, double *cost, int32_t *iters) {
+    SRH_REQUIRE(h && x0 && z_target && Q && R && Qf && x && u && K, "silqr_solve: null argument");
+    SRH_REQUIRE(h->has_discrete, "silqr_solve: model has not been pre-discretised");
+    SRH_REQUIRE(h->nz > 0, "silqr_solve: Need to set output or meas. model");
+    SRH_REQUIRE(N > 0 && batch > 0, "silqr_solve: bad dimensions");
+    const int n = h->n, m = h->m, nz = h->nz;
+    silqr_params par;
+    if (p) par = *p; else silqr_default_params(&par);
+    srh::DevBuf d0, dz, duw, dul, dQ, dR, dQf, ox, ou, oK, oc, oi, work, iwork;
+    int rc;
+    const size_t stride = (size_t)(N + 1) * n + (size_t)N * m * 3 + (size_t)N * m * m + (size_t)N * m * n + 8;
+    if ((rc = d0.upload(x0, sizeof(double) * batch * n)) || (rc = dz.upload(z_target, sizeof(double) * batch * (N + 1) * nz)) ||
+        (rc = dQ.upload(Q, sizeof(double) * nz * nz)) || (rc = dR.upload(R, sizeof(double) * m * m)) ||
+        (rc = dQf.upload(Qf, sizeof(double) * nz * nz)) || (rc = ox.alloc(sizeof(double) * batch * (N + 1) * n)) ||
+        (rc = ou.alloc(sizeof(double) * batch * N * m)) || (rc = oK.alloc(sizeof(double) * batch * N * m * n)) ||
+        (rc = oc.alloc(sizeof(double) * batch)) || (rc = oi.alloc(sizeof(int32_t) * batch)) ||
+        (rc = work.alloc(sizeof(double) * stride * batch)) || (rc = iwork.alloc(sizeof(int32_t) * 2 * N * batch)))
+        return rc;
+    if (u_warm && (rc = duw.upload(u_warm, sizeof(double) * batch * N * m))) return rc;
+    if (u_last && (rc = dul.upload(u_last, sizeof(double) * batch * m))) return rc;
+    IlqrArgs a{N, n, m, nz, par, d0.as<double>(), dz.as<double>(), u_warm ? duw.as<double>() : nullptr,
+               u_last ? dul.as<double>() : nullptr, dQ.as<double>(), dR.as<double>(), dQf.as<double>(), ox.as<double>(),
+               ou.as<double>(), oK.as<double>(), oc.as<double>(), oi.as<int>(), work.as<double>(), iwork.as<int>(), stride};
+    const size_t lds = (lqr_lds_doubles(n, m) + 20 + (size_t)n * n + 16 + NT) * sizeof(double);
+    SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ilqr_kernel<<<(unsigned)batch, NT, lds>>>(h->view(), a);
+    SRH_CHECK_HIP(hipGetLastError());
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    if ((rc = ox.download(x, sizeof(double) * batch * (N + 1) * n)) || (rc = ou.download(u, sizeof(double) * batch * N * m)) ||
+        (rc = oK.download(K, sizeof(double) * batch * N * m * n)))
+        return rc;
+    if (cost && (rc = oc.download(cost, sizeof(double) * batch))) return rc;
+    if (iters && (rc = oi.download(iters, sizeof(int32_t) * batch))) return rc;
+    return SRH_OK;
+}
+
+}  // extern "C"

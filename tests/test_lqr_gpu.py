@@ -1,0 +1,67 @@
+"""GPU parity: Riccati recursions and iLQR against the golden vectors of the imported reference (g4)."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from helpers import golden_problem, product_tpwl
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol):
+    np.testing.assert_allclose(a, b, rtol=0, atol=rtol * max(1.0, float(np.abs(b).max())))
+
+
+def setup(golden):
+    g = golden('g4_riccati')
+    model, U, q_ref, v_ref, Hf = golden_problem(5, 4, 9, 30, 20)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tp.pre_discretize(0.05)
+    return g, tp
+
+
+def test_fixed_point_riccati_and_dare(golden):
+    from sofacontrol_amd.lqr.lqr import solve_riccati, dare
+    g, tp = setup(golden)
+    L, P = solve_riccati(tp.A_d[2], tp.B_d[2], g['Q'], g['R'])
+    close(L, g['sr_L'], 1e-9); close(P, g['sr_P'], 1e-9)
+    K, P = dare(tp.A_d[2], tp.B_d[2], g['Q'], g['R'])
+    close(K, g['dare_K'], 1e-8); close(P, g['dare_P'], 1e-8)
+
+
+def test_traj_tracking_lqr(golden):
+    from sofacontrol_amd.lqr.traj_tracking_lqr import TrajTrackingLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    g, tp = setup(golden)
+
+    class Target:
+        t, x, u = g['tt_t'], g['tt_x'], g['tt_u']
+    tt = TrajTrackingLQR(0.05, tp, QuadraticCost(Q=g['Q'], R=g['R']))
+    xbar, ubar, K = tt.compute_policy(Target)
+    close(xbar, g['tt_xbar'], 1e-12); close(ubar, g['tt_ubar'], 1e-12)
+    close(K, g['tt_K'], 1e-9)
+    K2, P = tt.perform_dlqr_recursion(Target)
+    close(P, g['tt_P'], 1e-9)
+
+
+@pytest.mark.parametrize('tag,N', [('c1', 10), ('n30', 30)])
+def test_ilqr_full_solve(golden, tag, N):
+    """Full ilqr_computation: same iteration count and trajectories as the reference (tolerance 1e-6:
+    the line search compares cost ratios, trajectories agree to round-off until a decision flips)."""
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    g, tp = setup(golden)
+    il = iLQR(0.05, tp, QuadraticCost(Q=g['Qz'], R=g['R'], Qf=g['Qf']), N)
+    il.set_target(g[tag + '_z_target'])
+    x, u, K = il.ilqr_computation(g[tag + '_x0'], g[tag + '_uw'])
+    assert int(il.iters[0]) == int(g[tag + '_iters'])
+    close(x, g[tag + '_sol_x'], 1e-6); close(u, g[tag + '_sol_u'], 1e-6); close(K, g[tag + '_sol_K'], 1e-6)
+    x, u, K = il.ilqr_computation(g[tag + '_x0'])
+    assert int(il.iters[0]) == int(g[tag + '_iters0'])
+    close(x, g[tag + '_sol0_x'], 1e-6); close(u, g[tag + '_sol0_u'], 1e-6)
+    # batched: two problems in one launch equal the single solves
+    xb, ub, Kb = il.ilqr_computation(np.stack([g[tag + '_x0'], g[tag + '_x0']]))
+    np.testing.assert_array_equal(xb[0], x); np.testing.assert_array_equal(xb[1], x)
