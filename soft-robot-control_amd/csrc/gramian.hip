@@ -1,0 +1,166 @@
+// Snapshot Gramian G = S S^T (method of snapshots for compute_POD, sofacontrol/mor/pod.py:181-200) and
+// mode recovery U_k = S^T W_k, f64 MFMA.  S is (n_s x n_f) row-major (one snapshot per row, the layout of
+// np.asarray(data['q']), pod.py:149).  Compute-bound (n_s/8 flop per byte): 128 x 128 output tiles per
+// workgroup, 64 x 64 per wave (16 accumulator tiles), K streamed in 16-column chunks through a
+// double-buffered k-major LDS panel; only tiles on or above the diagonal are computed and mirrored.
+#include "common.h"
+#include "dev_la.h"
+
+namespace {
+
+typedef double g_d4 __attribute__((ext_vector_type(4)));
+constexpr int TB = 128;      // tile edge
+constexpr int KC = 16;       // K chunk
+constexpr int LDT = TB + 1;  // LDS row stride of the k-major panels
+
+__global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__ S, int64_t n_s, int64_t n_f, int64_t lds,
+                                                      double *__restrict__ G, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lptr Xi = (lptr)smem;                  // [2][KC][LDT]
+    lptr Xj = Xi + 2 * KC * LDT;           // [2][KC][LDT]
+    // linear block index -> (ti <= tj)
+    int b = blockIdx.x, ti = 0;
+    while (b >= ntile - ti) { b -= ntile - ti; ++ti; }
+    const int tj = ti + b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;        // wave sub-tile origin
+    const int lrow = tid >> 1, lhalf = tid & 1;                    // loader: row, 8-column half
+    const int64_t gi = (int64_t)ti * TB + lrow, gj = (int64_t)tj * TB + lrow;
+    const double *pi = S + (gi < n_s ? gi : 0) * lds, *pj = S + (gj < n_s ? gj : 0) * lds;
+    const bool vi = gi < n_s, vj = gj < n_s;
+
+    g_d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = g_d4{0.0, 0.0, 0.0, 0.0};
+
+    double ri[8], rj[8];
+    auto gload = [&](int64_t k0) {
+        const int64_t kb = k0 + 8 * lhalf;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool vk = kb + q < n_f;
+            ri[q] = (vi && vk) ? pi[kb + q] : 0.0;
+            rj[q] = (vj && vk) ? pj[kb + q] : 0.0;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            Xi[(buf * KC + 8 * lhalf + q) * LDT + lrow] = ri[q];
+            Xj[(buf * KC + 8 * lhalf + q) * LDT + lrow] = rj[q];
+        }
+    };
+    const int64_t nchunk = (n_f + KC - 1) / KC;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int64_t c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload((c + 1) * KC);
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = Xi[(buf * KC + ks + kk) * LDT + wr + 16 * a + l16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) bf[a] = Xj[(buf * KC + ks + kk) * LDT + wc + 16 * a + l16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    acc[a][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[cc], acc[a][cc], 0, 0, 0);
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // D: col = lane&15, row = (lane>>4) + 4*reg
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t r = (int64_t)ti * TB + wr + 16 * a + kk + 4 * q;
+                const int64_t cidx = (int64_t)tj * TB + wc + 16 * cc + l16;
+                if (r < n_s && cidx < n_s) {
+                    const double v = acc[a][cc][q];
+                    G[r * n_s + cidx] = v;
+                    if (ti != tj) G[cidx * n_s + r] = v;
+                }
+            }
+}
+
+// U (n_f x k) = S^T W, W (n_s x k), k <= 64
+__global__ __launch_bounds__(256) void modes_kernel(const double *__restrict__ S, int64_t n_s, int64_t n_f, int64_t lds,
+                                                    const double *__restrict__ W, int k, double *__restrict__ U) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lptr Ws = (lptr)smem;                 // [64 rows of s][k]
+    const int tid = threadIdx.x;
+    const int ic = tid & 63, jg = tid >> 6;            // column of S (i), group of 16 output columns
+    const int64_t i = (int64_t)blockIdx.x * 64 + ic;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    for (int64_t s0 = 0; s0 < n_s; s0 += 64) {
+        const int ns = (int)min((int64_t)64, n_s - s0);
+        for (int e = tid; e < ns * k; e += 256) Ws[e] = W[(s0 + e / k) * k + (e % k)];
+        __syncthreads();
+        if (i < n_f) {
+            for (int s = 0; s < ns; ++s) {
+                const double v = S[(s0 + s) * lds + i];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int j = jg * 16 + q;
+                    if (j < k) acc[q] = fma(v, Ws[s * k + j], acc[q]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (i < n_f) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int j = jg * 16 + q;
+            if (j < k) U[i * k + j] = acc[q];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int srom_gramian_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, double *G_dev, void *stream) {
+    SRH_REQUIRE(S_dev && G_dev, "srom_gramian_dev: null argument");
+    SRH_REQUIRE(n_s > 0 && n_f > 0 && lds >= n_f, "srom_gramian_dev: bad dimensions");
+    const int ntile = (int)srh::cdiv(n_s, TB);
+    const int64_t nblk = (int64_t)ntile * (ntile + 1) / 2;
+    const size_t lbytes = sizeof(double) * 4 * KC * LDT;
+    gramian_kernel<<<(unsigned)nblk, 256, lbytes, (hipStream_t)stream>>>(S_dev, n_s, n_f, lds, G_dev, ntile);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
+int srom_gramian(const double *S, int64_t n_s, int64_t n_f, double *G) {
+    SRH_REQUIRE(S && G, "srom_gramian: null argument");
+    srh::DevBuf dS, dG;
+    int rc;
+    if ((rc = dS.upload(S, sizeof(double) * n_s * n_f)) || (rc = dG.alloc(sizeof(double) * n_s * n_s))) return rc;
+    if ((rc = srom_gramian_dev(dS.as<double>(), n_s, n_f, n_f, dG.as<double>(), nullptr))) return rc;
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    return dG.download(G, sizeof(double) * n_s * n_s);
+}
+
+int srom_modes_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, const double *W_dev, int k, double *U_dev,
+                   void *stream) {
+    SRH_REQUIRE(S_dev && W_dev && U_dev, "srom_modes_dev: null argument");
+    SRH_REQUIRE(k > 0 && k <= 64, "srom_modes_dev: need 0 < k <= 64");
+    modes_kernel<<<(unsigned)srh::cdiv(n_f, 64), 256, sizeof(double) * 64 * k, (hipStream_t)stream>>>(S_dev, n_s, n_f, lds, W_dev, k, U_dev);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
+}  // extern "C"

@@ -155,3 +155,67 @@ def process_snapshots(snapshots, preprocess, args):
     if 'clustering' in preprocess and args.get('nbr_clusters', 0) > 0:
         raise NotImplementedError('kmeans clustering preprocess is outside the hot path')
     return snapshots
+
+
+def energy_truncation(S, tol):
+    """pod.py:192-197: smallest k >= 1 with sum(S[k:]^2) / sum(S^2) <= tol."""
+    s_square = S ** 2
+    i = 0
+    while (np.sum(s_square[i:]) / np.sum(s_square)) > tol or i == 0:
+        i += 1
+    return i
+
+
+def gramian(S_rows):
+    """G = S S^T on the device for S (n_s x n_f) with one snapshot per row."""
+    S_rows = np.ascontiguousarray(S_rows, dtype=np.float64)
+    n_s, n_f = S_rows.shape
+    G = np.empty((n_s, n_s))
+    _lib.check(_lib.lib().srom_gramian(_lib.dptr(S_rows), C.c_int64(n_s), C.c_int64(n_f), _lib.dptr(G)), 'srom_gramian')
+    return G
+
+
+def modes_from_gramian(S_rows, G, tol, rom_dim=None):
+    """Method of snapshots: eig(G) = Sigma^2, U = S^T W Sigma^-1.  The n_s x n_s symmetric eigenproblem
+    is solved by LAPACK on the host (O(n_s^3), the Gramian that feeds it is O(n_s^2 n_f) on the GPU)."""
+    w, W = np.linalg.eigh(G)
+    order = np.argsort(w)[::-1]
+    w = np.maximum(w[order], 0.0)
+    W = W[:, order]
+    Sigma = np.sqrt(w)
+    k = energy_truncation(Sigma, tol) if rom_dim is None else int(rom_dim)
+    Wk = np.ascontiguousarray(W[:, :k] / Sigma[:k])
+    return Wk, k, Sigma
+
+
+def compute_POD(snapshots, tol, rom_dim=None):
+    """pod.py:181-200 with the same arguments (snapshots is n_f x n_s) and return order
+    (U_full, U, nbModes, Sigma).  The reference takes a thin SVD; here the basis comes from the snapshot
+    Gramian (f64 MFMA kernel) -- identical subspace and singular values (up to the sign of each mode and
+    the eps*(sigma_0/sigma_i)^2 accuracy of the small singular values).  U_full is not formed (None): only
+    the kept modes are recovered (U = S^T W Sigma^-1)."""
+    S_rows = np.ascontiguousarray(np.asarray(snapshots, dtype=np.float64).T)
+    n_s, n_f = S_rows.shape
+    G = gramian(S_rows)
+    Wk, k, Sigma = modes_from_gramian(S_rows, G, tol, rom_dim)
+    dS, dW = _lib.DeviceBuffer.from_array(S_rows), _lib.DeviceBuffer.from_array(Wk)
+    dU = _lib.DeviceBuffer(n_f * k * 8)
+    _lib.check(_lib.lib().srom_modes_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), dW.ptr, C.c_int(k),
+                                         dU.ptr, None), 'srom_modes_dev')
+    _lib.sync()
+    U = dU.to_array((n_f, k))
+    return None, U, k, Sigma[:min(n_s, n_f)]
+
+
+def run_POD(snapshots_file, POD_file, config, rom_dim=None):
+    """pod.py:110-141."""
+    data = scutils.load_data(snapshots_file)
+    snapshots = get_snapshots(data, config.pod_type)
+    snapshots = process_snapshots(snapshots, config.preprocess, config.preprocess_args)
+    U_full, U, rom_dim, Sigma = compute_POD(snapshots.T, config.pod_tolerance)
+    print('Computed POD with tolerance {}, resulting in {} dimensional system'.format(config.pod_tolerance, rom_dim))
+    POD_info = {'U': U, 'q_ref': data['q'][0], 'v_ref': np.zeros(data['v'][0].shape)}
+    results = {'POD_info': POD_info, 'config': vars(config), 'Sigma': Sigma}
+    print('Saving POD data to {}'.format(POD_file))
+    scutils.save_data(POD_file, results)
+    return results

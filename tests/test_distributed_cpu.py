@@ -1,0 +1,64 @@
+"""CPU, world_size = 2, gloo: the sharded POD build (column shards -> partial Gramians -> ONE all-reduce ->
+replicated eigen-decomposition -> local mode rows) and the rollout sharding helper.  The local Gramian /
+mode kernels are replaced by numpy stand-ins here (no GPU); the exchange logic is the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from oracle import pod as opod
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, S, tol, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sofacontrol_amd.distributed import pod_from_column_shards, shard_range
+    lo, hi = shard_range(S.shape[1], rank, world)
+    U_loc, k, Sig = pod_from_column_shards(S[:, lo:hi], tol, local_gramian=lambda A: A @ A.T,
+                                           local_modes=lambda A, W: A.T @ W)
+    out[rank] = (lo, hi, U_loc, k, Sig)
+    dist.destroy_process_group()
+
+
+def test_pod_column_shards_two_ranks():
+    rng = np.random.default_rng(0)
+    n_s, n_f = 40, 301
+    L = rng.standard_normal((n_s, 6)) * np.array([50, 20, 8, 3, 1, 0.3])
+    S = L @ rng.standard_normal((6, n_f)) + 1e-3 * rng.standard_normal((n_s, n_f))
+    tol = 1e-4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, S, tol, out), nprocs=2, join=True)
+    U = np.zeros((n_f, out[0][3]))
+    for r in range(2):
+        lo, hi, U_loc, k, Sig = out[r]
+        U[lo:hi] = U_loc
+    _, U_ref, k_ref, S_ref = opod.compute_pod(S.T, tol)
+    assert out[0][3] == out[1][3] == k_ref
+    np.testing.assert_allclose(out[0][4][:6], S_ref[:6], rtol=1e-9)
+    np.testing.assert_allclose(np.abs(U), np.abs(U_ref), rtol=0, atol=1e-8)
+    np.testing.assert_allclose(U.T @ U, np.eye(k_ref), rtol=0, atol=1e-9)
+
+
+def test_shard_range_covers_everything():
+    from sofacontrol_amd.distributed import shard_range
+    for n in (0, 1, 7, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -111,3 +111,26 @@ def test_projection_round_trip_full_size():
     a, b = rom.compute_RO_state(qf=Xf[:64]), rom.compute_RO_state(qf=Xf[64:128])
     mid = rom.compute_RO_state(qf=0.5 * (Xf[:64] + Xf[64:128]))
     np.testing.assert_allclose(mid, 0.5 * (a + b), rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize('n_s,n_f', [(40, 300), (257, 1001), (300, 4884), (129, 64)])
+def test_gramian_vs_numpy(n_s, n_f):
+    from sofacontrol_amd.mor.pod import gramian
+    rng = np.random.default_rng(n_s)
+    S = rng.standard_normal((n_s, n_f)) * rng.uniform(0.1, 10.0, (n_s, 1))
+    G = gramian(S)
+    ref = S @ S.T
+    np.testing.assert_allclose(G, ref, rtol=0, atol=1e-12 * np.abs(ref).max() * 10)
+    np.testing.assert_array_equal(G, G.T)
+
+
+def test_compute_pod_gramian_route_vs_reference_svd(golden):
+    """compute_POD (pod.py:181-200): same k, singular values and modes (up to sign) as the reference's SVD."""
+    from sofacontrol_amd.mor.pod import compute_POD
+    g = golden('g1_pod')
+    for tol in (1e-2, 1e-4, 1e-7):
+        _, U, k, Sig = compute_POD(g['pod_S'], tol)
+        assert k == int(g['pod_k_%g' % tol])
+        np.testing.assert_allclose(Sig[:6], g['pod_Sigma'][:6], rtol=1e-9)
+        np.testing.assert_allclose(np.abs(U), g['pod_Ufull_abs'][:, :k], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(U.T @ U, np.eye(k), rtol=0, atol=1e-9)
