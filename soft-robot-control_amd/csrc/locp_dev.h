@@ -132,6 +132,7 @@ __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) 
     for (int e = tid; e < ((d.n + 15) & ~15) * d.ld; e += nt) L.P[e] = 0.0;
     for (int e = tid; e < d.RW * d.ld; e += nt) { L.AB[e] = 0.0; L.W[e] = 0.0; }
     for (int e = tid; e < 16 * d.ld; e += nt) L.QUX[e] = 0.0;
+    if (tid == 0) L.flag[2] = -1;
     for (int e = tid; e < d.nz * n; e += nt) { const int a = e / n, j = e - a * n; L.Hm[a * ld + j] = c.H[e]; }
     for (int e = tid; e < n * d.nz; e += nt) { const int i = e / d.nz, a = e - i * d.nz; L.HtQ[i * 16 + a] = c.HtQz2[e]; }
     for (int e = tid; e < (d.nX + d.nXf) * n; e += nt) {
@@ -554,6 +555,67 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
     return true;
 }
 
+// ---- the [A | B] panel of the current TPWL region stays in LDS: consecutive stages of a horizon mostly
+// share their region, so the 30 KB table read (and its L2 latency) is paid only when the region changes;
+// the vector sweeps take A v, A^T v, B u, B^T v from the panel instead of streaming the tables again.
+__device__ __forceinline__ void ensure_panel(const QPDims &d, const QPDyn &dyn, QPLds &L, int k) {
+    const int n = d.n, m = d.m, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
+    const int sel = (int)dyn.sel(k);
+    const bool same = dyn.idx != nullptr && L.flag[2] == sel;
+    if (same) return;                              // uniform
+    cgptr Ag = dyn.A + (size_t)sel * n * n, Bg = dyn.B + (size_t)sel * n * m;
+    const int NPa = d.NPa;
+    const int jj = tid % NPa, ii0 = tid / NPa, rstep = nt / NPa;
+    if (ii0 < rstep && jj < n + m) {
+        cgptr src = jj < n ? Ag + jj : Bg + (jj - n);
+        const int stride = jj < n ? n : m;
+        for (int i = ii0; i < n; i += rstep) L.AB[i * ld + jj] = src[(size_t)i * stride];
+    }
+    __syncthreads();
+    if (tid == 0) L.flag[2] = sel;
+    __syncthreads();
+}
+
+// y[j] = sum_{i<n} AB[i][j] v[i], j < n + m      ( [A^T v ; B^T v] )
+__device__ __forceinline__ void panel_T_vec(const QPDims &d, QPLds &L, clptr v, lptr y) {
+    const int n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, tid = threadIdx.x, nt = blockDim.x;
+    const int S = nt / NPa > 0 ? nt / NPa : 1;
+    const int col = tid % NPa, sl = tid / NPa;
+    if (sl < S) {
+        double acc = 0.0;
+        if (col < n + m) for (int i = sl; i < n; i += S) acc = fma(L.AB[i * ld + col], v[i], acc);
+        L.part[sl * NPa + col] = acc;
+    }
+    __syncthreads();
+    if (tid < NPa) {
+        double r = 0.0;
+        for (int q = 0; q < S; ++q) r += L.part[q * NPa + tid];
+        y[tid] = r;
+    }
+    __syncthreads();
+}
+
+// y[i] = sum_{j<n} AB[i][j] a[j] + sum_{j<m} AB[i][n+j] b[j], i < n      ( A a + B b )
+__device__ __forceinline__ void panel_vec(const QPDims &d, QPLds &L, clptr a, clptr b, lptr y) {
+    const int n = d.n, m = d.m, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
+    const int n16 = (n + 15) & ~15;
+    const int S = nt / n16 > 0 ? nt / n16 : 1;
+    const int row = tid % n16, sl = tid / n16;
+    if (sl < S) {
+        double acc = 0.0;
+        if (row < n)
+            for (int j = sl; j < n + m; j += S) acc = fma(L.AB[row * ld + j], j < n ? a[j] : b[j - n], acc);
+        L.part[sl * n16 + row] = acc;
+    }
+    __syncthreads();
+    if (tid < n) {
+        double r = 0.0;
+        for (int q = 0; q < S; ++q) r += L.part[q * n16 + tid];
+        y[tid] = r;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ Riccati solve of one Newton system
 // full = factorise (stores K_k and the Cholesky factor of Quu_k) and solve; !full = re-solve with new
 // gradients only.  Returns false on a non-positive-definite Quu.  rd_out: max |reduced dual residual|.
@@ -571,29 +633,6 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int xoff = d.tr ? 2 * n + 1 : 0;
     double rd = 0.0;
-    // register prefetch of the next stage's [A | B]: thread (ii0, jj) owns column jj of rows ii0 + q*rstep
-    constexpr int PF = 12;
-    double pre[PF];
-    const int jj = tid % NPa, ii0 = tid / NPa, rstep = nt / NPa;
-    const bool pf_on = ii0 < rstep && jj < n + m;
-#define AB_PREFETCH(kst)                                                                            \
-    do {                                                                                           \
-        const size_t sel_ = dyn.sel(kst);                                                          \
-        cgptr src_ = jj < n ? dyn.A + sel_ * n * n + jj : dyn.B + sel_ * n * m + (jj - n);         \
-        const int stride_ = jj < n ? n : m;                                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < PF; ++q_) {                                        \
-            const int i_ = ii0 + q_ * rstep;                                                       \
-            pre[q_] = (pf_on && i_ < n) ? src_[(size_t)i_ * stride_] : 0.0;                        \
-        }                                                                                          \
-    } while (0)
-#define AB_STORE()                                                                                 \
-    do {                                                                                           \
-        _Pragma("unroll") for (int q_ = 0; q_ < PF; ++q_) {                                        \
-            const int i_ = ii0 + q_ * rstep;                                                       \
-            if (pf_on && i_ < n) L.AB[i_ * ld + jj] = pre[q_];                                     \
-        }                                                                                          \
-    } while (0)
-    if (full) AB_PREFETCH(N - 1);
 #ifdef SRH_PROFILE
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tl = wall_clock64();
@@ -628,8 +667,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
         const size_t sel = dyn.sel(k);
         cgptr Ag = dyn.A + sel * n * n, Bg = dyn.B + sel * n * m;
         if (full) {
-            // [A_k | B_k] was prefetched into registers during the previous stage (or just above for k = N-1)
-            AB_STORE();
+            ensure_panel(d, dyn, L, k);
             for (int e = tid; e < m * m; e += nt) L.Quu[e] = w.Huu[(size_t)k * m * m + e];
             if (k >= 1) {
                 for (int e = tid; e < n; e += nt) { L.hdv[e] = w.hd[(size_t)k * n + e]; L.cvv[e] = w.cv[(size_t)k * n + e]; }
@@ -639,7 +677,6 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             SRH_LAP(0);
             mfma_atb(L.W, ld, L.P, L.AB, NK, n16 >> 4, NPa >> 4, ld, n);          // W = P [A|B]
             SRH_LAP(1);
-            if (k >= 1) AB_PREFETCH(k - 1);                                        // next stage's tables: in flight
             mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16);           // [Qux | B^T P B] = B^T W
             SRH_LAP(2);
             // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (one wave per output), Quu += B^T P B
@@ -698,13 +735,9 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             // vector-only re-solve: A^T pv, B^T pv straight from the L2-resident tables
             for (int e = tid; e < m * n; e += nt) { const int a = e / n, j = e - a * n; L.Km[a * ld + j] = w.K[(size_t)k * m * n + e]; }
             for (int e = tid; e < m * m; e += nt) L.Lc[e] = w.Qinv[(size_t)k * m * m + e];
-            wg::matTvec(L.ypv, Ag, n, n, n, L.pv, (cgptr)nullptr, L.part);
-            for (int a = wave; a < m; a += nw) {
-                double v = 0.0;
-                for (int i = lane; i < n; i += 64) v = fma(Bg[i * m + a], L.pv[i], v);
-                v = wg::wave_sum(v);
-                if (lane == 0) L.Qu[a] = v + w.gu[(size_t)k * m + a];
-            }
+            ensure_panel(d, dyn, L, k);
+            panel_T_vec(d, L, L.pv, L.ypv);                      // [A^T pv ; B^T pv]
+            if (tid < m) L.Qu[tid] = L.ypv[n + tid] + w.gu[(size_t)k * m + tid];
             __syncthreads();
             if (tid == 0) {
                 wg::chol_solve_neg(L.Lc, m, L.Qu, 1, L.kf, 1);
@@ -743,8 +776,8 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             if (lane == 0) { v += w.kff[(size_t)k * m + a]; L.kf[a] = v; w.du[(size_t)k * m + a] = v; }
         }
         __syncthreads();
-        wg::matTvec(L.v2, dyn.AT + sel * n * n, n, n, n, L.v1, (cgptr)nullptr, L.part);
-        wg::matTvec(L.v2, dyn.BT + sel * m * n, n, m, n, L.kf, (clptr)L.v2, L.part);
+        ensure_panel(d, dyn, L, k);
+        panel_vec(d, L, L.v1, L.kf, L.v2);                       // dx_{k+1} = A dx_k + B du_k
         for (int e = tid; e < n; e += nt) { L.v1[e] = L.v2[e]; w.dx[(size_t)(k + 1) * n + e] = L.v2[e]; }
         if (d.tr && wave == 0) {
             double v = 0.0;
@@ -805,7 +838,12 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         qp_carve(w, work_base, d);
         wout = w;
         const int N = d.N, n = d.n, m = d.m;
-        w.tprof = (gptr)nullptr;
+        w.tprof = q.dbg ? q.dbg + 8 * 63 : (gptr)nullptr;
+#ifdef SRH_PROFILE
+        long long tm[6] = {0, 0, 0, 0, 0, 0};
+        long long t_last = wall_clock64();
+        auto lap = [&](int slot) { const long long now = wall_clock64(); tm[slot] += now - t_last; t_last = now; };
+#endif
         const double s0 = slack0(dfull, c, q, L);
         for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
         for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
@@ -852,10 +890,13 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
                 });
             }
             __syncthreads();
+            SRH_LAP(1);
             // ---------------- Newton system
             stage_prepass(d, c, q, w, mode == PRED);
+            SRH_LAP(2);
             double rd = 0.0;
             const bool ok = riccati_solve(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
+            if (mode == CORR) SRH_LAP(4); else SRH_LAP(3);
             // ---------------- use the direction
             if (mode == INIT) {
                 if (!ok) { status = 2; break; }
@@ -948,9 +989,14 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             ++it;
             mode = PRED;
         }
+        SRH_LAP(1);
         // final consistency: x is exactly the rollout of u
         rollout(d, dyn, q, w.u, w.x, L);
         J = objective(d, c, q, w.x, w.u, w.s, L);
+        SRH_LAP(5);
+#ifdef SRH_PROFILE
+        if (q.dbg && tid == 0) for (int i = 0; i < 6; ++i) q.dbg[8 * 62 + i] = (double)tm[i];
+#endif
         if (npass == 2 && pass == 0) {
             if (status != 0) continue;               // relaxed QP not solved: go to the full QP
             double md = 0.0;
