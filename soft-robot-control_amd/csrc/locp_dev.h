@@ -99,12 +99,13 @@ struct QPLds {                         // LDS carve (doubles unless noted)
     lptr part;                      // blockDim
     lptr red;                       // 16
     liptr flag;                         // 4 ints
+    liptr idxl;                         // N ints: region of every stage (copy of dyn.idx, or 0..N-1)
 };
 
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
     const size_t nk16 = (size_t)((d.n + 15) & ~15);   // whole MFMA tiles are stored
     size_t c = nk16 * d.ld + 2 * (size_t)d.RW * d.ld + 16 * (size_t)d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
-               (size_t)d.nz * d.ld + (size_t)d.ld * 16 + (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4;
+               (size_t)d.nz * d.ld + (size_t)d.ld * 16 + (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
     return c * sizeof(double);
 }
 
@@ -124,6 +125,7 @@ __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nt
     L.part = take(nthreads);
     L.red = take(16);
     L.flag = (liptr)take(4);
+    L.idxl = (liptr)take((size_t)(d.N / 2 + 2));
 }
 
 // one-off per kernel: constants into LDS, zero the padding of the MFMA operands
@@ -216,7 +218,7 @@ __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, const
     for (int e = threadIdx.x; e < n; e += blockDim.x) { L.v1[e] = q.x0[e]; x[e] = q.x0[e]; }
     __syncthreads();
     for (int k = 0; k < d.N; ++k) {
-        const size_t i = dyn.sel(k);
+        const size_t i = (size_t)L.idxl[k];
         for (int e = threadIdx.x; e < m; e += blockDim.x) L.Qu[e] = u[(size_t)k * m + e];
         __syncthreads();
         wg::matTvec(L.v2, dyn.AT + i * n * n, n, n, n, L.v1, dyn.d + i * n, L.part);
@@ -560,7 +562,7 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
 // the vector sweeps take A v, A^T v, B u, B^T v from the panel instead of streaming the tables again.
 __device__ __forceinline__ void ensure_panel(const QPDims &d, const QPDyn &dyn, QPLds &L, int k) {
     const int n = d.n, m = d.m, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
-    const int sel = (int)dyn.sel(k);
+    const int sel = L.idxl[k];
     const bool same = dyn.idx != nullptr && L.flag[2] == sel;
     if (same) return;                              // uniform
     cgptr Ag = dyn.A + (size_t)sel * n * n, Bg = dyn.B + (size_t)sel * n * m;
@@ -664,7 +666,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
         __syncthreads();
     }
     for (int k = N - 1; k >= 0; --k) {
-        const size_t sel = dyn.sel(k);
+        const size_t sel = (size_t)L.idxl[k];
         cgptr Ag = dyn.A + sel * n * n, Bg = dyn.B + sel * n * m;
         if (full) {
             ensure_panel(d, dyn, L, k);
@@ -767,7 +769,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
     if (tid == 0) w.ds[0] = 0.0;
     __syncthreads();
     for (int k = 0; k < N; ++k) {
-        const size_t sel = dyn.sel(k);
+        const size_t sel = (size_t)L.idxl[k];
         // du = K dx + kff  (one wave per output row, lanes over the state)
         for (int a = wave; a < m; a += nw) {
             double v = 0.0;
@@ -847,6 +849,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         const double s0 = slack0(dfull, c, q, L);
         for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
         for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
+        for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
         __syncthreads();
         rollout(d, dyn, q, w.u, w.x, L);
         status = 1;
