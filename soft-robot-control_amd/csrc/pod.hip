@@ -4,10 +4,11 @@
 // (B x n_f) row-major; the projection out = (X - 1 ref^T) U is a tall-skinny GEMM whose cost is the
 // single read of X from HBM: 8*B*n_f bytes against 2*B*n_f*r flops (7.5 flop/B at r = 30), i.e.
 // HBM-bound as long as the f64 matrix pipe stays >~65 % busy.  Layout decisions:
-//   * X is consumed straight from HBM into MFMA A-operands: lane (row = l&15, kgrp = l>>4) loads 16
-//     consecutive doubles (128 B) of its row per 64-column chunk, so each row contributes 512 B
-//     contiguous per chunk; the k-slot -> column assignment (col = 64c + 16*kgrp + t for step t) is a
-//     permutation of the dot product and needs no shuffle;
+//   * X is consumed straight from HBM into MFMA A-operands: lane (row = l&15, kgrp = l>>4) loads 8
+//     16-byte pieces of its row per 64-column chunk, the four k-groups of a row reading adjacent pieces
+//     (64 contiguous bytes per row per load instruction, 512 B per row per chunk); the k-slot -> column
+//     assignment (col = 64c + 8*(t>>1) + 2*kgrp + (t&1) for step t) is a permutation of the dot product
+//     and needs no shuffle;
 //   * U is pre-packed ONCE (srom_create) into the matching B-operand fragment order
 //     Ufrag[chunk][t][ntile][lane], zero padded, so a fragment is one conflict-free 512 B LDS row;
 //     chunks are staged through LDS and shared by the 4 waves of a workgroup (128 rows);
@@ -23,7 +24,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int KC = 64;        // columns of X per chunk
-constexpr int ROWS_WG = 128;  // rows of X per workgroup (4 waves x 2 M-tiles x 16)
+#ifndef SRH_PROJ_MT
+#define SRH_PROJ_MT 2
+#endif
+constexpr int MTP = SRH_PROJ_MT;      // M-tiles (16 rows) per wave in the projection
+constexpr int ROWS_WG = 64 * MTP;     // rows of X per workgroup (4 waves x MTP M-tiles x 16)
+constexpr int LIFT_ROWS = 128;        // rows per workgroup in the lift (4 waves x 2 M-tiles x 16)
 
 struct ProjArgs {
     const double *X;      // (B x ldx)
@@ -43,7 +49,7 @@ struct ProjArgs {
 
 __global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, int NT, int nchunks,
                               double *__restrict__ ufrag) {
-    // Ufrag[c][t][nt][lane] = U[64c + 16*(lane>>4) + t][16 nt + (lane&15)]
+    // Ufrag[c][t][nt][lane] = U[64c + 8*(t>>1) + 2*(lane>>4) + (t&1)][16 nt + (lane&15)]
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)nchunks * 16 * NT * 64;
     if (idx >= total) return;
@@ -53,7 +59,7 @@ __global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, 
     rest /= NT;
     int t = rest & 15;
     int64_t c = rest >> 4;
-    int64_t i = c * KC + 16 * (lane >> 4) + t;
+    int64_t i = c * KC + 8 * (t >> 1) + 2 * (lane >> 4) + (t & 1);
     int j = 16 * nt + (lane & 15);
     ufrag[idx] = (i < n_f && j < r) ? U[i * r + j] : 0.0;
 }
@@ -87,82 +93,99 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     const double *ref = blk ? a.ref1 : a.ref0;
     const int c0 = blockIdx.y * a.chunks_per_split;
     const int c1 = min(c0 + a.chunks_per_split, a.nchunks);
-    const int64_t rowbase = (int64_t)blockIdx.x * ROWS_WG + wave * 32;
+    const int64_t rowbase = (int64_t)blockIdx.x * ROWS_WG + wave * (16 * MTP);
     const int lrow = lane & 15, kgrp = lane >> 4;
 
-    d4 acc[2][NT];
+    d4 acc[MTP][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
 
-    const double *xrow[2];
+    const double *xrow[MTP];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MTP; ++mt) {
         int64_t row = rowbase + mt * 16 + lrow;
         if (row >= a.B) row = a.B - 1;  // clamp: result rows beyond B are never stored
         xrow[mt] = X + row * a.ldx;
     }
 
-    double xr[2][16];
-    auto load_x = [&](int c, double (&dst)[2][16]) {
-        const int64_t col0 = (int64_t)c * KC + 16 * kgrp;
-        if (col0 + 16 <= a.n_f) {
+    double xr[MTP][16];
+    // register t of a lane holds column 64c + 8*(t>>1) + 2*kgrp + (t&1): the four k-groups of a row read
+    // adjacent 16-byte pieces, so one load instruction covers 64 contiguous bytes of each of its 16 rows
+    auto load_x = [&](int c, double (&dst)[MTP][16]) {
+        const int64_t col0 = (int64_t)c * KC + 2 * kgrp;
+        if ((int64_t)c * KC + KC <= a.n_f) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MTP; ++mt) {
                 const double *p = xrow[mt] + col0;
                 if (VEC2) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        d2 v = *reinterpret_cast<const d2 *>(p + 2 * q);
+                        d2 v = *reinterpret_cast<const d2 *>(p + 8 * q);
                         dst[mt][2 * q] = v.x;
                         dst[mt][2 * q + 1] = v.y;
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) dst[mt][q] = p[q];
+                    for (int q = 0; q < 8; ++q) { dst[mt][2 * q] = p[8 * q]; dst[mt][2 * q + 1] = p[8 * q + 1]; }
                 }
             }
         } else {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) dst[mt][q] = (col0 + q < a.n_f) ? xrow[mt][col0 + q] : 0.0;
+                for (int q = 0; q < 8; ++q) {
+                    const int64_t cc = col0 + 8 * q;
+                    dst[mt][2 * q] = (cc < a.n_f) ? xrow[mt][cc] : 0.0;
+                    dst[mt][2 * q + 1] = (cc + 1 < a.n_f) ? xrow[mt][cc + 1] : 0.0;
+                }
         }
     };
-    // stage chunk c of the packed basis (+ reference) into LDS buffer b
-    auto stage = [&](int c, int b) {
+    // stage chunk c of the packed basis (+ reference) into LDS buffer b: the global loads are issued BEFORE
+    // the X loads of the same chunk and written to LDS only after the MFMAs of the current chunk, so the
+    // wait for them (in-order vmcnt) never includes the X loads still in flight
+    constexpr int UQ = UCH / 2 / 256;
+    d2 ureg[UQ];
+    double refreg = 0.0;
+    auto stage_load = [&](int c) {
         const d2 *src = reinterpret_cast<const d2 *>(a.ufrag + (int64_t)c * UCH);
-        d2 *dst = reinterpret_cast<d2 *>(lds + b * BUF);
 #pragma unroll
-        for (int q = 0; q < UCH / 2 / 256; ++q) dst[q * 256 + tid] = src[q * 256 + tid];
+        for (int q = 0; q < UQ; ++q) ureg[q] = src[q * 256 + tid];
         if (HAS_REF && tid < KC) {
             int64_t i = (int64_t)c * KC + tid;
-            lds[b * BUF + UCH + tid] = (i < a.n_f) ? ref[i] : 0.0;
+            refreg = (i < a.n_f) ? ref[i] : 0.0;
         }
+    };
+    auto stage_write = [&](int b) {
+        d2 *dst = reinterpret_cast<d2 *>(lds + b * BUF);
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) dst[q * 256 + tid] = ureg[q];
+        if (HAS_REF && tid < KC) lds[b * BUF + UCH + tid] = refreg;
     };
 
     if (c0 < c1) {
-        stage(c0, 0);
+        stage_load(c0);
         load_x(c0, xr);
+        stage_write(0);
     }
     __syncthreads();
     for (int c = c0; c < c1; ++c) {
         const int b = (c - c0) & 1;
-        double xn[2][16];
+        double xn[MTP][16];
         const bool more = (c + 1 < c1);
         if (more) {
+            stage_load(c + 1);
             load_x(c + 1, xn);
-            stage(c + 1, b ^ 1);
         }
         const double *ub = lds + b * BUF;
         if (HAS_REF) {
-            const double *rb = ub + UCH + 16 * kgrp;
+            const double *rb = ub + UCH + 2 * kgrp;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                double rv = rb[q];
-                xr[0][q] -= rv;
-                xr[1][q] -= rv;
+                double rv = rb[8 * (q >> 1) + (q & 1)];
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt) xr[mt][q] -= rv;
             }
         }
 #pragma unroll
@@ -170,14 +193,16 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 double bv = ub[(t * NT + nt) * 64 + lane];
-                acc[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[0][t], bv, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[1][t], bv, acc[1][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[mt][t], bv, acc[mt][nt], 0, 0, 0);
             }
         }
+        if (more) stage_write(b ^ 1);
         __syncthreads();
         if (more) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) xr[mt][q] = xn[mt][q];
         }
@@ -188,7 +213,7 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     if (a.partial == nullptr) {
         double *out = a.out + (int64_t)blk * a.o_blk_off;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 int64_t row = rowbase + mt * 16 + kgrp + 4 * reg;
@@ -203,7 +228,7 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     } else {
         double *part = a.partial + (((int64_t)blockIdx.y * gridDim.z + blk) * a.B) * (NT * 16);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 int64_t row = rowbase + mt * 16 + kgrp + 4 * reg;
@@ -252,7 +277,7 @@ __global__ __launch_bounds__(256) void lift_kernel(LiftArgs a) {
     const double *Xr = a.Xr + (int64_t)blk * a.r_blk_off;
     const double *ref = blk ? a.ref1 : a.ref0;
     double *out = a.out + (int64_t)blk * a.o_blk_off;
-    const int64_t rowbase = (int64_t)blockIdx.x * ROWS_WG + wave * 32;
+    const int64_t rowbase = (int64_t)blockIdx.x * LIFT_ROWS + wave * 32;
     const int lrow = lane & 15, kgrp = lane >> 4;
 
     double af[2][KS];
@@ -534,7 +559,7 @@ int srom_lift_dev(srom_t *h, int which, const double *Xr, int64_t B, int64_t ldr
     if (which == SROM_Q) a.ref0 = h->q_ref.as<double>();
     if (which == SROM_V) a.ref0 = h->v_ref.as<double>();
     if (which == SROM_X) { a.ref0 = h->v_ref.as<double>(); a.ref1 = h->q_ref.as<double>(); }
-    const int64_t rowtiles = srh::cdiv(B, ROWS_WG);
+    const int64_t rowtiles = srh::cdiv(B, LIFT_ROWS);
     int64_t ysplit = std::max<int64_t>(1, std::min<int64_t>(h->ntiles, srh::cdiv(1024, rowtiles * nblk)));
     a.tiles_per_wg = (int)srh::cdiv(h->ntiles, ysplit);
     ysplit = srh::cdiv(h->ntiles, a.tiles_per_wg);
