@@ -209,6 +209,15 @@ def main():
             dist.destroy_process_group()
         return
     alg_bytes = B * n_f * 8 + n_f * r * 8 + n_f * 8 + B * r * 8
+    # HBM traffic of the same kernel at the same shape from PMC counters (separate rocprofv3 --pmc passes,
+    # corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_proj_pmc.json')))
+        if pmc.get('algorithmic_bytes_per_launch') == alg_bytes:
+            traffic = pmc['traffic_bytes_per_launch']
+    except Exception:
+        traffic = None
     avg_ms = float(np.mean(proj_ms))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     out = {
@@ -222,7 +231,7 @@ def main():
                    'rollouts_per_gpu': R_, 'proj_batch': B, 'max_gusto_iters': args.max_gusto_iters, 'scp_iters_per_step_rank0': it_per_step,
                    'solves_not_converged_rank0': int((status != 0).sum())},
         'roofline': {'kernel': 'proj_kernel (srom_project_dev)', 'bound': 'hbm', 'achieved': achieved,
-                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': alg_bytes},
     }
     if world == 1 and not args.no_cpu_baseline:
