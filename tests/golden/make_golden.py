@@ -329,3 +329,86 @@ if __name__ == '__main__':
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+class FakeGuSTOClient:
+    """Deterministic stand-in for GuSTOClientNode (needs ROS): returns a smooth analytic 'solution'."""
+    N, dt_g = 8, 0.05
+
+    def __init__(self):
+        self.done = False
+
+    def send_request(self, t0, x0, wait=True):
+        self.t0, self.x0 = float(t0), np.asarray(x0, dtype=float).copy()
+        self.done = True
+
+    def force_spin(self):
+        pass
+
+    def check_if_done(self):
+        return self.done
+
+    def force_wait(self):
+        pass
+
+    def get_solution(self, n_x, n_u):
+        t = self.t0 + self.dt_g * np.arange(self.N + 1)
+        x = np.stack([self.x0 * np.cos(3 * (tt - self.t0)) + 0.01 * np.sin(tt + np.arange(n_x)) for tt in t])
+        u = np.stack([50.0 + 40.0 * np.sin(2 * tt + np.arange(n_u)) for tt in t[:-1]])
+        return t, u, x, 0.0123
+
+
+def g8_controllers(out):
+    import sofacontrol.tpwl.controllers as ctl
+    ctl.GuSTOClientNode = FakeGuSTOClient
+    r, m, P = 4, 3, 7
+    model, U, q_ref, v_ref, Hf = make_problem(r, m, P, 20, 40, q_scale=0.05)
+    tp = ref_tpwl(model, U, q_ref, v_ref, Hf)
+    n = 2 * r
+    H = np.asarray(tp.H)
+    cost = rutils.QuadraticCost()
+    cost.Q = H.T @ np.diag([0, 0, 0, 100., 100., 0]) @ H + 1e-2 * np.eye(n)
+    cost.R = 1e-3 * np.eye(m)
+    dt = 0.01
+    (c, _) = quiet(ctl.scp, tp, cost, dt, N_replan=3, delay=0.02)
+    c.set_sim_timestep(dt)
+    rng = np.random.default_rng(41)
+    n_f = 60
+    x_ref = rutils.qv2x(q_ref, v_ref)
+    us, xs = [], []
+    steps = 14
+
+    def run():
+        for k in range(steps):
+            xf = x_ref + 0.2 * rng.standard_normal(2 * n_f)
+            xs.append(xf)
+            us.append(c.evaluate(k * dt, None, xf, np.zeros(m)))
+    quiet(run)
+    info = c.save_controller_info()
+    res = dict(x_full=np.stack(xs), u=np.stack(us), t_opt=info['t_opt'], u_opt=info['u_opt'], z_opt=info['z_opt'],
+               K=np.stack(c.K), Q=cost.Q, R=cost.R, rollout_time=info['rollout_time'], n_solves=len(info['solve_times']))
+    # ilqr controller: trajectory-tracking target
+    tgt = Target()
+    tgt.t = np.linspace(0, 0.2, 21)
+    tgt.z = np.zeros((21, 6)); tgt.z[:, 3] = -1.0 * np.sin(10 * tgt.t); tgt.z[:, 4] = 0.5 * np.sin(20 * tgt.t)
+    tgt.z = tgt.z + np.asarray(tp.z_ref)
+    tgt.Hf = Hf
+    cost2 = rutils.QuadraticCost(Q=np.diag([0, 0, 0, 100., 100., 0]), R=1e-3 * np.eye(m), Qf=np.diag([0, 0, 0, 100., 100., 0]))
+    quiet(tp.pre_discretize, 0.02)
+    (ci, _) = quiet(ctl.ilqr, tp, cost2, tgt, dt=0.02, delay=0.0)
+    ci.set_sim_timestep(0.01)
+    us2 = []
+
+    def run2():
+        for k in range(8):
+            us2.append(ci.evaluate(k * 0.01, None, xs[k], np.zeros(m)))
+    quiet(run2)
+    res['il_u'] = np.stack(us2)
+    res['il_t'], res['il_z'] = tgt.t, tgt.z
+    res['il_xbar'], res['il_ubar'] = ci.x_bar, ci.u_bar
+    np.savez_compressed(os.path.join(out, 'g8_controllers.npz'), **res)
+
+
+if __name__ == '__main__':
+    g8_controllers(HERE)
+    print('g8_controllers.npz', os.path.getsize(os.path.join(HERE, 'g8_controllers.npz')))
