@@ -104,8 +104,8 @@ struct QPLds {                         // LDS carve (doubles unless noted)
 
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
     const size_t nk16 = (size_t)((d.n + 15) & ~15);   // whole MFMA tiles are stored
-    size_t c = nk16 * d.ld + 2 * (size_t)d.RW * d.ld + 16 * (size_t)d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
-               (size_t)d.nz * d.ld + (size_t)d.ld * 16 + (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
+    size_t c = nk16 * d.ld + 2 * (size_t)d.RW * d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
+               (size_t)d.nz * d.ld + (size_t)d.n * d.nz + 4 + (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
     return c * sizeof(double);
 }
 
@@ -113,13 +113,14 @@ __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nt
     lptr p = base;
     auto take = [&](size_t c) { lptr q = p; p += c; return q; };
     const size_t nk16 = (size_t)((d.n + 15) & ~15);
-    L.P = take(nk16 * d.ld); L.AB = take((size_t)d.RW * d.ld); L.W = take((size_t)d.RW * d.ld); L.QUX = take(16 * (size_t)d.ld);
+    L.P = take(nk16 * d.ld); L.AB = take((size_t)d.RW * d.ld); L.W = take((size_t)d.RW * d.ld);
+    L.QUX = L.AB + (size_t)d.NK * d.ld;     // [Qux | B^T P B] lands in the extra-row slots of the left panel (rows NK..NK+m)
     L.Km = take((size_t)d.m * d.ld);
     L.Quu = take(256); L.Lc = take(256);
     L.pv = take(d.ld); L.adj = take(d.ld); L.v1 = take(d.ld); L.v2 = take(d.ld); L.v3 = take(d.ld); L.hdv = take(d.ld); L.cvv = take(d.ld);
     L.ypv = take(d.ld); L.yadj = take(d.ld);
     L.Qu = take(16); L.kf = take(16); L.rdu = take(16);
-    L.Hm = take((size_t)d.nz * d.ld); L.HtQ = take((size_t)d.ld * 16);
+    L.Hm = take((size_t)d.nz * d.ld); L.HtQ = take((size_t)d.n * d.nz + 4);
     L.XAl = take((size_t)(d.nX + d.nXf) * d.ld);
     L.Dx = take(32);
     L.part = take(nthreads);
@@ -133,10 +134,9 @@ __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) 
     const int tid = threadIdx.x, nt = blockDim.x, n = d.n, ld = d.ld;
     for (int e = tid; e < ((d.n + 15) & ~15) * d.ld; e += nt) L.P[e] = 0.0;
     for (int e = tid; e < d.RW * d.ld; e += nt) { L.AB[e] = 0.0; L.W[e] = 0.0; }
-    for (int e = tid; e < 16 * d.ld; e += nt) L.QUX[e] = 0.0;
     if (tid == 0) L.flag[2] = -1;
     for (int e = tid; e < d.nz * n; e += nt) { const int a = e / n, j = e - a * n; L.Hm[a * ld + j] = c.H[e]; }
-    for (int e = tid; e < n * d.nz; e += nt) { const int i = e / d.nz, a = e - i * d.nz; L.HtQ[i * 16 + a] = c.HtQz2[e]; }
+    for (int e = tid; e < n * d.nz; e += nt) { const int i = e / d.nz, a = e - i * d.nz; L.HtQ[i * d.nz + a] = c.HtQz2[e]; }
     for (int e = tid; e < (d.nX + d.nXf) * n; e += nt) {
         const int r = e / n, j = e - r * n;
         L.XAl[r * ld + j] = r < d.nX ? c.XA[(size_t)r * n + j] : c.XfA[(size_t)(r - d.nX) * n + j];
@@ -364,10 +364,12 @@ __device__ __forceinline__ void stage_prepass(const QPDims &d, const QPConst &c,
 typedef double qp_d4 __attribute__((ext_vector_type(4)));
 
 // C[i][j] = sum_{k<K} Lm[k][i] * Rm[k][j]  for i < 16*MT, j < 16*NTl.  Lm, Rm: k-major rows (K x ld) in
-// LDS, K a multiple of 4 (zero padded).  Rows i >= vrows of C are stored as exact zeros.
+// LDS, K a multiple of 4 (zero padded).  Rows i >= vrows of C are stored as exact zeros; rows >= srows are
+// not stored at all.
 // v_mfma_f64_16x16x4: A lane l holds Lm^T[i=l&15][k=l>>4], B lane holds Rm[k=l>>4][j=l&15];
 // D reg q of lane l is C[row = (l>>4) + 4q][col = l&15].
-__device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, int K, int MT, int NTl, int ld, int vrows) {
+__device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, int K, int MT, int NTl, int ld, int vrows,
+                                         int srows = 1 << 30) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
@@ -403,10 +405,10 @@ __device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, in
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r0 = 16 * ti0 + kk + 4 * q;
-            C[r0 * ldc + 16 * tj0 + l16] = r0 < vrows ? acc0[q] : 0.0;
+            if (r0 < srows) C[r0 * ldc + 16 * tj0 + l16] = r0 < vrows ? acc0[q] : 0.0;
             if (has1) {
                 const int r1 = 16 * ti1 + kk + 4 * q;
-                C[r1 * ldc + 16 * tj1 + l16] = r1 < vrows ? acc1[q] : 0.0;
+                if (r1 < srows) C[r1 * ldc + 16 * tj1 + l16] = r1 < vrows ? acc1[q] : 0.0;
             }
         }
     }
@@ -417,7 +419,7 @@ __device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, in
 __device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, const QPLds &L, int k, int i, int j,
                                              double Hss, int nxrows) {
     double v = 0.0;
-    for (int a = 0; a < d.nz; ++a) v = fma(L.HtQ[i * 16 + a], L.Hm[a * d.ld + j], v);     // 2 H^T Qz H
+    for (int a = 0; a < d.nz; ++a) v = fma(L.HtQ[i * d.nz + a], L.Hm[a * d.ld + j], v);     // 2 H^T Qz H
     if (k == d.N && c.Qzf) v += c.QxN[(size_t)i * d.n + j] - c.Qx[(size_t)i * d.n + j];
     if (d.tr) {
         if (i == j) v += L.hdv[i];
@@ -679,7 +681,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             SRH_LAP(0);
             mfma_atb(L.W, ld, L.P, L.AB, NK, n16 >> 4, NPa >> 4, ld, n);          // W = P [A|B]
             SRH_LAP(1);
-            mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16);           // [Qux | B^T P B] = B^T W
+            mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16, m);        // [Qux | B^T P B] = B^T W
             SRH_LAP(2);
             // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (one wave per output), Quu += B^T P B
             for (int o = wave; o < 2 * m; o += nw) {

@@ -257,7 +257,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.mp = (m + 3) & ~3;
     d.NK = (n + 3) & ~3;
     d.NE4 = (m + pr->nX + 3) & ~3;
-    d.RW = std::max((n + 15) & ~15, d.NK + d.NE4);
+    d.RW = std::max((n + 15) & ~15, d.NK + std::max(d.NE4, (m + 3) & ~3));
     d.nrx = d.tr * (2 * n + 1) + d.nX;
     d.RX = d.nrx + d.nXf;
     d.NR = N * d.RX + N * d.nU;

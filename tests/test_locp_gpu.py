@@ -84,3 +84,24 @@ def test_infeasible_qp_reports_failure():
                 case['omega'], z=case['z'])
     J, ok, stats = locp.solve()
     assert not ok and J == np.inf and stats is None
+
+
+def test_locp_trunk_shape():
+    """C5 shape (Trunk: n_x = 60, n_u = 8, N = 50, U = [0, 800]^8): the n_x + n_u = 68 panels (80-wide tiles)."""
+    case, _ = make_case(r=30, m=8, P=32, N=50, seed=11, q_scale=0.02, use_X=False, u_max=800.0, amp=0.1)
+    (xe, ue, se), Je = oracle_solution(case)
+    locp = product_locp(case)
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
+                case['omega'], z=case['z'])
+    J, ok, stats = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
+    # 8 inputs with many weakly active bounds and R = 1e-5: at a gap of 1e-12 the minimiser is determined to
+    # ~1e-4 only (the kernel solves the trust-region-free relaxation first, whose central path differs from the
+    # full problem's at equal gap) -- cost to 1e-9, trajectories to 2e-4 against both oracles
+    assert rel(x, xe) <= 2e-4 and rel(u, ue) <= 2e-4
+    from oracle import riccati_ipm as ripm
+    xp, up, sp, Jp, info = ripm.solve(ripm.Problem(**case))
+    assert info['status'] == 'optimal'
+    assert rel(x, xp) <= 2e-4 and rel(u, up) <= 2e-4 and abs(J - Jp) <= 1e-9 * max(1.0, abs(Jp))
