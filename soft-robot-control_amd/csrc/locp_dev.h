@@ -17,7 +17,9 @@ struct QPDims {
     int mp;    // unused (kept for layout stability)
     int NK;    // roundup4(n): K extent of the MFMA products (zero padded rows)
     int NE4;   // roundup4(m + nX): extra Gram rows (-Y, +Y from the gain; sqrt(D) X rows)
-    int RW;    // rows of the AB / W panels: max(roundup16(n), NK + NE4)
+    int RW;    // rows of the AB / W panels
+    int nzr;   // rank of Qz folded into the Gram product as constant extra rows (0: Qx added element-wise)
+    int RC;    // first constant extra row (>= NK + m + nX and >= roundup16(n))
     int nrx;   // inequality rows owned by x_k, k < N:  tr*(2n+1) + nX
     int RX;    // row stride per x stage: nrx + nXf
     int NR;    // total rows: N*RX + N*nU
@@ -34,6 +36,7 @@ struct QPConst {                       // shared by the whole batch (HBM/L2 resi
     cgptr Qx, QxN;                     // 2 H^T Qz H, (+ 2 H^T Qzf H)      (n x n)
     cgptr HtQz2, HtQzf2;               // 2 H^T Qz, 2 H^T Qzf               (n x nz)
     cgptr R2;                          // 2 R
+    cgptr Cq;                          // (nzr x n) with 2 H^T Qz H = Cq^T Cq, or null
 };
 
 struct QPDyn {                         // stage dynamics: matrix k at base + idx[k]*size (idx null: k)
@@ -135,6 +138,11 @@ __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) 
     for (int e = tid; e < ((d.n + 15) & ~15) * d.ld; e += nt) L.P[e] = 0.0;
     for (int e = tid; e < d.RW * d.ld; e += nt) { L.AB[e] = 0.0; L.W[e] = 0.0; }
     if (tid == 0) L.flag[2] = -1;
+    for (int e = tid; e < d.nzr * n; e += nt) {
+        const int r = e / n, j = e - r * n;
+        L.AB[(d.RC + r) * ld + j] = c.Cq[e];
+        L.W[(d.RC + r) * ld + j] = c.Cq[e];
+    }
     for (int e = tid; e < d.nz * n; e += nt) { const int a = e / n, j = e - a * n; L.Hm[a * ld + j] = c.H[e]; }
     for (int e = tid; e < n * d.nz; e += nt) { const int i = e / d.nz, a = e - i * d.nz; L.HtQ[i * d.nz + a] = c.HtQz2[e]; }
     for (int e = tid; e < (d.nX + d.nXf) * n; e += nt) {
@@ -703,21 +711,26 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             SRH_LAP(4);
             if (k >= 1) {
                 // P_k = A^T W + (extra rows: -Y^T Y + X^T D X); columns n, n+1 deliver A^T pv, A^T adj
-                mfma_atb(L.P, ld, L.AB, L.W, NK + d.NE4, n16 >> 4, ((n + 2 + 15) & ~15) >> 4, ld, n16);
-                // finish in place: symmetrise, add the constant 2 H^T Qz H and the slack-eliminated trust region.
+                const int K2 = d.nzr ? ((d.RC + d.nzr + 3) & ~3) : NK + d.NE4;
+                mfma_atb(L.P, ld, L.AB, L.W, K2, n16 >> 4, ((n + 2 + 15) & ~15) >> 4, ld, n16);
+                // finish in place (only when something is left to add): the constant 2 H^T Qz H unless it was
+                // folded into the product as extra rows, and the slack-eliminated trust region; symmetrised.
                 // Each unordered pair (i,j) is owned by one thread.
-                const double Hss = d.tr ? w.Hss[k] : 1.0;
-                const int sh = 32 - __clz(n - 1), msk = (1 << sh) - 1;          // j = e & msk, i = e >> sh
-                for (int e = tid; e < (n << sh); e += nt) {
-                    const int i = e >> sh, j = e & msk;
-                    if (j < i || j >= n) continue;
-                    double v = 0.5 * (L.P[i * ld + j] + L.P[j * ld + i]) + c.Qx[(size_t)i * n + j];
-                    if (d.tr) {
-                        if (i == j) v += L.hdv[i];
-                        else v -= L.cvv[i] * L.cvv[j] / Hss;
+                if (d.tr || d.nzr == 0) {
+                    const double Hss = d.tr ? w.Hss[k] : 1.0;
+                    const int sh = 32 - __clz(n - 1), msk = (1 << sh) - 1;          // j = e & msk, i = e >> sh
+                    for (int e = tid; e < (n << sh); e += nt) {
+                        const int i = e >> sh, j = e & msk;
+                        if (j < i || j >= n) continue;
+                        double v = 0.5 * (L.P[i * ld + j] + L.P[j * ld + i]);
+                        if (d.nzr == 0) v += c.Qx[(size_t)i * n + j];
+                        if (d.tr) {
+                            if (i == j) v += L.hdv[i];
+                            else v -= L.cvv[i] * L.cvv[j] / Hss;
+                        }
+                        L.P[i * ld + j] = v;
+                        L.P[j * ld + i] = v;
                     }
-                    L.P[i * ld + j] = v;
-                    L.P[j * ld + i] = v;
                 }
                 // pv_new = gx + A^T pv + K^T Qu ; adj_new = gxd + A^T adj
                 for (int e = tid; e < 2 * n; e += nt) {

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
 
 // ------------------------------------------------------------------ host side: constants
 struct QPConstHost {
-    srh::DevBuf H, Qz, Qzf, R, xs, UA, Ub, XA, Xb, XfA, Xfb, Qx, QxN, HtQz2, HtQzf2, R2;
+    srh::DevBuf H, Qz, Qzf, R, xs, UA, Ub, XA, Xb, XfA, Xfb, Qx, QxN, HtQz2, HtQzf2, R2, Cq;
     QPDims dims{};
     QPConst view() const {
         QPConst c{};
@@ -234,9 +234,42 @@ struct QPConstHost {
         c.Xb = g(Xb); c.XfA = g(XfA); c.Xfb = g(Xfb); c.Qx = g(Qx);
         c.QxN = g(QxN); c.HtQz2 = g(HtQz2); c.HtQzf2 = g(HtQzf2);
         c.R2 = g(R2);
+        c.Cq = g(Cq);
         return c;
     }
 };
+
+// eigen-decomposition of a small symmetric matrix (cyclic Jacobi): A = V diag(w) V^T, V columns
+static void jacobi_eig(std::vector<double> A, int n, std::vector<double> &w, std::vector<double> &V) {
+    V.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                if (fabs(A[p * n + q]) < 1e-300) continue;
+                const double th = (A[q * n + q] - A[p * n + p]) / (2.0 * A[p * n + q]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = cs * akp - sn * akq; A[k * n + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = cs * apk - sn * aqk; A[q * n + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = cs * vkp - sn * vkq; V[k * n + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
 
 int build_consts(const slocp_problem *pr, QPConstHost &C) {
     SRH_REQUIRE(pr && pr->H && pr->Qz && pr->R, "LOCP: H, Qz and R are required");
@@ -258,6 +291,31 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.NK = (n + 3) & ~3;
     d.NE4 = (m + pr->nX + 3) & ~3;
     d.RW = std::max((n + 15) & ~15, d.NK + std::max(d.NE4, (m + 3) & ~3));
+    // fold 2 H^T Qz H = Cq^T Cq into the Gram product as constant extra rows when the panels still fit in LDS
+    std::vector<double> Cq;
+    d.nzr = 0;
+    d.RC = std::max(d.NK + m + pr->nX, (n + 15) & ~15);
+    {
+        std::vector<double> Qs((size_t)nz * nz), wv, V;
+        for (int a = 0; a < nz; ++a) for (int b = 0; b < nz; ++b) Qs[a * nz + b] = 0.5 * (pr->Qz[a * nz + b] + pr->Qz[b * nz + a]);
+        jacobi_eig(Qs, nz, wv, V);
+        double wmax = 0.0;
+        for (double x : wv) wmax = std::max(wmax, fabs(x));
+        for (int e = 0; e < nz; ++e) {
+            if (wv[e] <= 1e-13 * wmax) continue;
+            const double sc = sqrt(2.0 * wv[e]);
+            for (int j = 0; j < n; ++j) {
+                double v = 0.0;
+                for (int a = 0; a < nz; ++a) v += V[a * nz + e] * pr->H[a * n + j];
+                Cq.push_back(sc * v);
+            }
+        }
+        const int nzr = (int)(Cq.size() / n);
+        QPDims t = d;
+        t.nzr = nzr;
+        t.RW = std::max(d.RW, (d.RC + nzr + 3) & ~3);
+        if (nzr > 0 && qp_lds_bytes(t, NTHREADS) <= 160 * 1024) { d.nzr = nzr; d.RW = t.RW; }
+    }
     d.nrx = d.tr * (2 * n + 1) + d.nX;
     d.RX = d.nrx + d.nXf;
     d.NR = N * d.RX + N * d.nU;
@@ -302,7 +360,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
         (rc = up(C.XfA, pr->XfA, (size_t)pr->nXf * n)) || (rc = up(C.Xfb, pr->Xfb, pr->nXf)) ||
         (rc = up(C.Qx, Qx.data(), (size_t)n * n)) || (rc = up(C.QxN, QxN.data(), (size_t)n * n)) ||
         (rc = up(C.HtQz2, Ht2.data(), (size_t)n * nz)) || (rc = up(C.HtQzf2, Htf2.data(), (size_t)n * nz)) ||
-        (rc = up(C.R2, R2.data(), (size_t)m * m)))
+        (rc = up(C.R2, R2.data(), (size_t)m * m)) || (rc = up(C.Cq, Cq.data(), Cq.size())))
         return rc;
     if (pr->Qzf && (rc = up(C.Qzf, pr->Qzf, (size_t)nz * nz))) return rc;
     return SRH_OK;
