@@ -110,7 +110,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('SRH_FORCE_DIST') == '1':
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -647,8 +647,8 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
     double rd = 0.0;
 #ifdef SRH_PROFILE
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tl = wall_clock64();
-    auto lap = [&](int sl) { const long long now = wall_clock64(); tp[sl] += now - tl; tl = now; };
+    long long tl = clock64();
+    auto lap = [&](int sl) { const long long now = clock64(); tp[sl] += now - tl; tl = now; };
 #endif
     // ---- terminal stage
     {
@@ -858,8 +858,8 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         w.tprof = q.dbg ? q.dbg + 8 * 63 : (gptr)nullptr;
 #ifdef SRH_PROFILE
         long long tm[6] = {0, 0, 0, 0, 0, 0};
-        long long t_last = wall_clock64();
-        auto lap = [&](int slot) { const long long now = wall_clock64(); tm[slot] += now - t_last; t_last = now; };
+        long long t_last = clock64();
+        auto lap = [&](int slot) { const long long now = clock64(); tm[slot] += now - t_last; t_last = now; };
 #endif
         const double s0 = slack0(dfull, c, q, L);
         for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
