@@ -123,6 +123,13 @@ int stpwl_nearest_dev(stpwl_t *h, const double *X_dev, int64_t B, int32_t *idx_d
  * (discrete=1) or continuous tables: A (B x n_x x n_x), Bm (B x n_x x n_u), d (B x n_x) */
 int stpwl_linearize(stpwl_t *h, const double *X, int64_t B, int discrete, double *A, double *Bm,
                     double *d, int32_t *idx);
+/* TPWL.calc_weighting_factors (tpwl.py:170-191): W (B x P) softmin weights exp(-beta d_i / d_min),
+ * normalised; one-hot at the first minimum when d_min == 0 */
+int stpwl_weights(stpwl_t *h, const double *X, int64_t B, double beta, double *W);
+/* TPWLATV.get_jacobians, weighting branch (tpwl.py:244-248): continuous A = sum_i w_i A_c[i] etc.;
+ * W (B x P) optional output of the weights */
+int stpwl_linearize_weighted(stpwl_t *h, const double *X, int64_t B, double beta, double *A, double *Bm,
+                             double *d, double *W);
 /* TPWL.rollout (tpwl.py:193-216) for `batch` independent rollouts:
  * x0 (batch x n_x), U (batch x N x n_u) -> X (batch x (N+1) x n_x), Z (batch x (N+1) x n_z) or NULL */
 int stpwl_rollout(stpwl_t *h, const double *x0, const double *U, int N, int64_t batch, double *X,

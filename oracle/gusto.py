@@ -34,11 +34,13 @@ def state_violation(X, x):
 
 
 def compute_accuracy(model, x, u, xk, uk, J, dt, fs):
-    """gusto.py:203-223 with continuous-time nearest-point dynamics (scp/models/tpwl.py:32-50)."""
+    """gusto.py:203-223 with continuous-time nearest-point dynamics (scp/models/tpwl.py:32-50);
+    `model` may also be a callable (x, u) -> (f, A, B) (TemplateModel.get_continuous_dynamics)."""
+    cont = model if callable(model) else (lambda xx, uu: otpwl.continuous_dynamics(model, xx, uu))
     err = approx = 0.0
     for i in range(x.shape[0] - 1):
-        fk, Ak, Bk = otpwl.continuous_dynamics(model, xk[i], uk[i])
-        f, _, _ = otpwl.continuous_dynamics(model, x[i], u[i])
+        fk, Ak, Bk = cont(xk[i], uk[i])
+        f, _, _ = cont(x[i], u[i])
         fa = fk + Ak @ (x[i] - xk[i]) + Bk @ (u[i] - uk[i])
         err += dt * np.linalg.norm(fs * (f - fa), 2)
         approx += dt * np.linalg.norm(fs * fa, 2)
@@ -56,6 +58,25 @@ def solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=None, u_des=
           **kw):
     """One GuSTO.solve call.  Returns xopt, uopt, zopt and a per-iteration trace of
     (J, delta, omega, rho_k, accepted, tr_ok) tuples."""
+    def get_traj(xk, uk):
+        return traj_dynamics(model, Ad, Bd, dd, xk)[:3]
+    return _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, zf, U, X, Xf, dU, x_char,
+                 f_char, qp_solver, kw)
+
+
+def solve_generic(dyn_d, dyn_c, H, N, dt, Qz, R, x0, u_init, x_init, z=None, u_des=None, Qzf=None, zf=None,
+                  U=None, X=None, Xf=None, dU=None, x_char=None, f_char=None, qp_solver=None, **kw):
+    """The same loop for a generic TemplateModel: dyn_d(x, u) -> (A_d, B_d, d_d)
+    (get_discrete_dynamics, gusto.py:225-238), dyn_c(x, u) -> (f, A, B) (get_continuous_dynamics)."""
+    def get_traj(xk, uk):
+        A, B, d = zip(*[dyn_d(xk[i], uk[i]) for i in range(xk.shape[0] - 1)])
+        return np.stack(A), np.stack(B), np.stack(d)
+    return _loop(get_traj, dyn_c, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, zf, U, X, Xf, dU, x_char,
+                 f_char, qp_solver, kw)
+
+
+def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, zf, U, X, Xf, dU, x_char, f_char,
+          qp_solver, kw):
     par = dict(DEFAULTS); par.update(kw)
     n = x0.shape[0]
     xs = 1. / np.abs(x_char) if x_char is not None else np.ones(n)
@@ -65,7 +86,7 @@ def solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=None, u_des=
             w, _, _ = olocp.solve_exact(qp)
             return w
     xk, uk = x_init.copy(), u_init.copy()
-    A_k, B_k, d_k, _ = traj_dynamics(model, Ad, Bd, dd, xk)
+    A_k, B_k, d_k = get_traj(xk, uk)
     delta, omega = par['delta0'], par['omega0']
     new_solution = True
     J_prev = d_prev = o_prev = np.inf
@@ -105,6 +126,6 @@ def solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=None, u_des=
         if new_solution:
             xk, uk = x_next.copy(), u_next.copy()
             if par['max_gusto_iters'] >= 1:
-                A_k, B_k, d_k, _ = traj_dynamics(model, Ad, Bd, dd, xk)
+                A_k, B_k, d_k = get_traj(xk, uk)
     zopt = (H @ xk.T).T
     return xk, uk, zopt, trace

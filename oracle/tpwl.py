@@ -38,6 +38,27 @@ def weighting_factors(model, x, beta):
     return w / np.sum(w)
 
 
+def weighted_jacobians(model, x, beta, dt=None, method='zoh'):
+    """sofacontrol/tpwl/tpwl.py:244-250: softmin-blended continuous tables, discretised if dt is given."""
+    w = weighting_factors(model, x, beta)
+    A = np.einsum('i,ijk->jk', w, model['A_c'])
+    B = np.einsum('i,ijk->jk', w, model['B_c'])
+    d = np.einsum('i,ij->j', w, model['d_c'])
+    if dt is not None:
+        A, B, d = discretize(A, B, d, dt, method)
+    return A, B, d
+
+
+def rollout_weighted(model, x0, u, beta, dt, method='zoh'):
+    """sofacontrol/tpwl/tpwl.py:193-216 with the weighting branch of get_jacobians at every step."""
+    x = np.zeros((u.shape[0] + 1, x0.shape[0]))
+    x[0] = x0
+    for i in range(u.shape[0]):
+        A, B, d = weighted_jacobians(model, x[i], beta, dt, method)
+        x[i + 1] = A @ x[i] + B @ u[i] + d
+    return x
+
+
 def zoh_affine(A, B, d, dt):
     """sofacontrol/utils.py:302-335 -- expm([[A, B, d], [0, 0, 0]] dt)."""
     n, m = B.shape

@@ -25,6 +25,89 @@ __global__ void gather_kernel(TpwlDev T, const int32_t *__restrict__ idx, int64_
     for (int e = threadIdx.x; e < T.n; e += blockDim.x) d[b * T.n + e] = ds[e];
 }
 
+
+// softmin weights over the stored points (tpwl.py:170-191): w_i = exp(-beta d_i / d_min) / sum_j(...),
+// one-hot at the (first) minimum when d_min == 0.  One workgroup per query state; W (B x P).
+__global__ __launch_bounds__(256) void weights_kernel(TpwlDev T, const double *__restrict__ X, int64_t B,
+                                                      double beta, double *__restrict__ W) {
+    __shared__ double rv[256];
+    __shared__ int ri[256];
+    const int64_t b = blockIdx.x;
+    const double *x = X + b * T.n;
+    double *w = W + b * T.P;
+    double best = INFINITY;
+    int besti = 0x7fffffff;
+    for (int i = threadIdx.x; i < T.P; i += blockDim.x) {
+        double sq = 0.0, sv = 0.0;
+        for (int j = 0; j < T.r; ++j) {
+            const double e = T.qT[j * T.P + i] - x[T.r + j];
+            sq = fma(e, e, sq);
+            const double f = T.vT[j * T.P + i] - x[j];
+            sv = fma(f, f, sv);
+        }
+        const double d = T.w_q * sqrt(sq) + T.w_v * sqrt(sv);
+        w[i] = d;
+        if (d < best) { best = d; besti = i; }
+    }
+    rv[threadIdx.x] = best; ri[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double ob = rv[threadIdx.x + o];
+            const int oi = ri[threadIdx.x + o];
+            if (ob < rv[threadIdx.x] || (ob == rv[threadIdx.x] && oi < ri[threadIdx.x])) {
+                rv[threadIdx.x] = ob; ri[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const double dmin = rv[0];
+    const int imin = ri[0];
+    __syncthreads();
+    if (dmin == 0.0) {
+        for (int i = threadIdx.x; i < T.P; i += blockDim.x) w[i] = (i == imin) ? 1.0 : 0.0;
+        return;
+    }
+    double part = 0.0;
+    for (int i = threadIdx.x; i < T.P; i += blockDim.x) {
+        const double e = exp(-beta * w[i] / dmin);
+        w[i] = e;
+        part += e;
+    }
+    rv[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) rv[threadIdx.x] += rv[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double tot = rv[0];
+    for (int i = threadIdx.x; i < T.P; i += blockDim.x) w[i] = w[i] / tot;
+}
+
+// weighted tables (tpwl.py:244-248): A = sum_i w_i A_c[i], B = sum_i w_i B_c[i], d = sum_i w_i d_c[i]
+__global__ __launch_bounds__(256) void blend_kernel(TpwlDev T, const double *__restrict__ W, int64_t B,
+                                                    double *__restrict__ A, double *__restrict__ Bm,
+                                                    double *__restrict__ d) {
+    const int64_t b = blockIdx.x;
+    const double *w = W + b * T.P;
+    const int nn = T.n * T.n, nm = T.n * T.m, tot = nn + nm + T.n;
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < tot; e += gridDim.y * blockDim.x) {
+        double s = 0.0;
+        if (e < nn) {
+            for (int i = 0; i < T.P; ++i) s = fma(w[i], T.Ac[(size_t)i * nn + e], s);
+            A[b * nn + e] = s;
+        } else if (e < nn + nm) {
+            const int f = e - nn;
+            for (int i = 0; i < T.P; ++i) s = fma(w[i], T.Bc[(size_t)i * nm + f], s);
+            Bm[b * nm + f] = s;
+        } else {
+            const int f = e - nn - nm;
+            for (int i = 0; i < T.P; ++i) s = fma(w[i], T.dc[(size_t)i * T.n + f], s);
+            d[b * T.n + f] = s;
+        }
+    }
+}
+
 // one workgroup per rollout: x_{k+1} = A_d[i_k] x_k + B_d[i_k] u_k + d_d[i_k], i_k = nearest(x_k)
 __global__ __launch_bounds__(256) void rollout_kernel(TpwlDev T, const double *__restrict__ x0,
                                                       const double *__restrict__ U, int N,
@@ -217,6 +300,44 @@ int stpwl_linearize(stpwl_t *h, const double *X, int64_t B, int discrete, double
         (rc = dd.download(d, sizeof(double) * B * n)))
         return rc;
     if (idx) return dI.download(idx, sizeof(int32_t) * B);
+    return SRH_OK;
+}
+
+int stpwl_weights(stpwl_t *h, const double *X, int64_t B, double beta, double *W) {
+    SRH_REQUIRE(h && X && W, "stpwl_weights: null argument");
+    if (B == 0) return SRH_OK;
+    srh::DevBuf dX, dW;
+    int rc;
+    if ((rc = dX.upload(X, sizeof(double) * B * h->n)) || (rc = dW.alloc(sizeof(double) * B * h->P))) return rc;
+    weights_kernel<<<(unsigned)B, 256>>>(h->view(), dX.as<double>(), B, beta, dW.as<double>());
+    SRH_CHECK_HIP(hipGetLastError());
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    return dW.download(W, sizeof(double) * B * h->P);
+}
+
+int stpwl_linearize_weighted(stpwl_t *h, const double *X, int64_t B, double beta, double *A, double *Bm, double *d,
+                             double *W) {
+    SRH_REQUIRE(h && X && A && Bm && d, "stpwl_linearize_weighted: null argument");
+    if (B == 0) return SRH_OK;
+    const int n = h->n, m = h->m;
+    srh::DevBuf dX, dW, dA, dB, dd;
+    int rc;
+    if ((rc = dX.upload(X, sizeof(double) * B * n)) || (rc = dW.alloc(sizeof(double) * B * h->P)) ||
+        (rc = dA.alloc(sizeof(double) * B * n * n)) || (rc = dB.alloc(sizeof(double) * B * n * m)) ||
+        (rc = dd.alloc(sizeof(double) * B * n)))
+        return rc;
+    weights_kernel<<<(unsigned)B, 256>>>(h->view(), dX.as<double>(), B, beta, dW.as<double>());
+    SRH_CHECK_HIP(hipGetLastError());
+    const int tot = n * n + n * m + n;
+    blend_kernel<<<dim3((unsigned)B, (unsigned)srh::cdiv(tot, 256)), 256>>>(h->view(), dW.as<double>(), B,
+                                                                            dA.as<double>(), dB.as<double>(),
+                                                                            dd.as<double>());
+    SRH_CHECK_HIP(hipGetLastError());
+    SRH_CHECK_HIP(hipDeviceSynchronize());
+    if ((rc = dA.download(A, sizeof(double) * B * n * n)) || (rc = dB.download(Bm, sizeof(double) * B * n * m)) ||
+        (rc = dd.download(d, sizeof(double) * B * n)))
+        return rc;
+    if (W) return dW.download(W, sizeof(double) * B * h->P);
     return SRH_OK;
 }
 

@@ -63,7 +63,8 @@ class GuSTO:
         self.x_k = None
         self.u_k = None
         self.nonlinear_observer = model.nonlinear_observer
-        self._fused = isinstance(model, TPWLGuSTO) and not self.nonlinear_observer
+        self._fused = (isinstance(model, TPWLGuSTO) and not self.nonlinear_observer and
+                       getattr(model.dyn_sys, 'tpwl_method', 'nn') == 'nn')
         self._plan = C.c_void_p()
         self.trace = None
         self.iters = None

@@ -34,6 +34,13 @@ class TPWLGuSTO(TemplateModel):
     def get_characteristic_vals(self):
         """models/tpwl.py:66-84 (one kernel over the stored points)."""
         n = self.n_x
+        if self.dyn_sys.tpwl_method != 'nn':
+            from ... import utils as scutils
+            tabs = self.dyn_sys._tabs
+            x = scutils.qv2x(tabs[0], tabs[1])
+            A, B, d, _ = self.dyn_sys.linearize_batch(x)
+            f = np.einsum('bij,bj->bi', A, x) + np.einsum('bij,bj->bi', B, tabs[2]) + d
+            return np.abs(x).max(axis=0), np.abs(f).max(axis=0)
         xc, fc = np.empty(n), np.empty(n)
         _lib.check(_lib.lib().stpwl_characteristic(self.dyn_sys.handle, _lib.dptr(xc), _lib.dptr(fc)),
                    'stpwl_characteristic')

@@ -164,9 +164,27 @@ class TPWL:
                    'stpwl_nearest')
         return int(idx[0]) if np.ndim(x) == 1 else idx
 
+    def calc_weighting_factors(self, x):
+        """tpwl.py:170-191 (one state) -- accepts (B, n_x) for a batch -> (B, P)."""
+        X = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        W = np.empty((X.shape[0], self.num_points))
+        _lib.check(_lib.lib().stpwl_weights(self._h, _lib.dptr(X), C.c_int64(X.shape[0]),
+                                            C.c_double(self.beta_weighting), _lib.dptr(W)), 'stpwl_weights')
+        return W[0] if np.ndim(x) == 1 else W
+
     def rollout(self, x0, u, dt):
         """tpwl.py:193-216; x0 (n_x,), u (N, n_u) -> x (N+1, n_x), z (N+1, n_z) (z includes z_ref).
         Batched form: x0 (B, n_x), u (B, N, n_u)."""
+        if self.tpwl_method == 'weighting':
+            # the blended model is re-discretised at every step (tpwl.py:244-250): step-wise like the reference
+            u = np.asarray(u, dtype=np.float64)
+            N = u.shape[0]
+            x = np.zeros((N + 1, self.state_dim))
+            x[0, :] = x0
+            for i in range(N):
+                x[i + 1, :] = self.update_state(x[i, :], u[i, :], dt)
+            z = self.x_to_zfyf(x, zf=True) if self.H is not None else None
+            return x, z
         self._ensure_discrete(dt)
         x0a = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
         ua = np.ascontiguousarray(u, dtype=np.float64)
@@ -189,16 +207,21 @@ class TPWLATV(TPWL):
     def __init__(self, data, params=None, Cf=None, Hf=None, **kwargs):
         super().__init__(data, params, Cf=Cf, Hf=Hf, **kwargs)
         self.ref_point = None
-        if self.tpwl_method != 'nn':
-            raise NotImplementedError("tpwl_method='weighting' (tpwl.py:244-250) is not covered by the HIP "
-                                      "path yet; the reference's default is 'nn' (tpwl_config.py:45)")
+        if self.tpwl_method not in ('nn', 'weighting'):
+            raise RuntimeError('tpwl method should be nn or weighting')
+        if self.tpwl_method == 'weighting' and self.beta_weighting is None:
+            raise RuntimeError("tpwl_method='weighting' needs params['beta_weighting']")
 
     def update_state(self, x, u, dt):
         A_d, B_d, d_d = self.get_jacobians(x, dt)
         return self.update_dynamics(x, u, A_d, B_d, d_d)
 
     def get_jacobians(self, x, dt=None, u=None):
-        """tpwl.py:236-270 (nn): (A_d, B_d, d_d)[i] if dt is given, else continuous (A_c, B_c, d_c)[i]."""
+        """tpwl.py:236-270.  nn: (A_d, B_d, d_d)[i] if dt is given, else continuous (A_c, B_c, d_c)[i];
+        weighting: softmin-blended continuous tables (device), discretised on the host when dt is given."""
+        if self.tpwl_method == 'weighting':
+            A, B, d, _ = self.linearize_batch(np.atleast_2d(x), dt)
+            return A[0], B[0], d[0]
         if dt is not None:
             self._ensure_discrete(dt)
         X = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
@@ -212,7 +235,21 @@ class TPWLATV(TPWL):
         return A[0], B[0], d[0]
 
     def linearize_batch(self, X, dt=None):
-        """Batched get_jacobians for X (B, n_x) -> A (B,n,n), B (B,n,m), d (B,n), idx (B,)."""
+        """Batched get_jacobians for X (B, n_x) -> A (B,n,n), B (B,n,m), d (B,n), idx (B,) (nn) or the
+        weights (B, P) (weighting)."""
+        if self.tpwl_method == 'weighting':
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            Bn, n, m = X.shape[0], self.state_dim, self.input_dim
+            A = np.empty((Bn, n, n)); B = np.empty((Bn, n, m)); d = np.empty((Bn, n))
+            W = np.empty((Bn, self.num_points))
+            _lib.check(_lib.lib().stpwl_linearize_weighted(self._h, _lib.dptr(X), C.c_int64(Bn),
+                                                           C.c_double(self.beta_weighting), _lib.dptr(A),
+                                                           _lib.dptr(B), _lib.dptr(d), _lib.dptr(W)),
+                       'stpwl_linearize_weighted')
+            if dt is not None:
+                for b in range(Bn):
+                    A[b], B[b], d[b] = self.discretize_dynamics(A[b], B[b], d[b], dt)
+            return A, B, d, W
         if dt is not None:
             self._ensure_discrete(dt)
         X = np.ascontiguousarray(X, dtype=np.float64)
@@ -279,7 +316,8 @@ class TPWLATV(TPWL):
     def get_characteristic_dx(self, dt):
         """tpwl.py:324-334."""
         x = scutils.qv2x(self._tabs[0], self._tabs[1])
-        self._ensure_discrete(dt)
+        if self.tpwl_method == 'nn':
+            self._ensure_discrete(dt)
         A, B, d, _ = self.linearize_batch(x, dt)
         dx = np.einsum('bij,bj->bi', A, x) + np.einsum('bij,bj->bi', B, self._tabs[2]) + d - x
         return np.abs(dx).max(axis=0)

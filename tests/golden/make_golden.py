@@ -130,6 +130,13 @@ def g3_tpwl(out):
     res['H'] = np.asarray(tp.H)
     res['z_ref'] = np.asarray(tp.z_ref)
     dt = 0.05
+    # weighting mode: discretised blended Jacobians and a step-wise rollout (tpwl.py:244-250, 193-216)
+    twz = ref_tpwl(model, U, q_ref, v_ref, Hf, method='weighting', beta=3.0, discr='zoh')
+    Adw, Bdw, ddw = zip(*[twz.get_jacobians(x, dt=dt) for x in X[:4]])
+    res['Adw'], res['Bdw'], res['ddw'] = np.stack(Adw), np.stack(Bdw), np.stack(ddw)
+    uw = np.random.default_rng(12).uniform(0, 800, (6, m))
+    xw, zw = twz.rollout(0.1 * X[1], uw, dt)
+    res['rollw_u'], res['rollw_x'], res['rollw_z'] = uw, xw, zw
     for meth in ('fe', 'be', 'bil', 'zoh'):
         t2 = ref_tpwl(model, U, q_ref, v_ref, Hf, discr=meth)
         quiet(t2.pre_discretize, dt)

@@ -24,11 +24,11 @@ def tip_selector(node, num_nodes):
     return C.tocsr()
 
 
-def product_tpwl(model, U, q_ref, v_ref, Hf, discr='zoh'):
+def product_tpwl(model, U, q_ref, v_ref, Hf, discr='zoh', method='nn', beta=None):
     from sofacontrol_amd.tpwl.tpwl import TPWLATV
     data = dict(q=model['q'], v=model['v'], u=model['u'], A_c=model['A_c'], B_c=model['B_c'], d_c=model['d_c'],
                 rom_info=dict(type='POD', U=U, q_ref=q_ref, v_ref=v_ref))
-    params = dict(tpwl_method='nn', dist_weights={'q': model['w_q'], 'v': model['w_v']}, beta_weighting=None)
+    params = dict(tpwl_method=method, dist_weights={'q': model['w_q'], 'v': model['w_v']}, beta_weighting=beta)
     return TPWLATV(data=data, params=params, Hf=Hf, discr_method=discr)
 
 

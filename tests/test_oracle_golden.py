@@ -77,6 +77,10 @@ def test_tpwl_nearest_weights_jacobians(golden):
     close(np.einsum('bi,ijk->bjk', W, model['A_c']), g['Aw'])
     close(np.einsum('bi,ijk->bjk', W, model['B_c']), g['Bw'])
     close(np.einsum('bi,ij->bj', W, model['d_c']), g['dw'])
+    for i in range(4):
+        A, B, d = otpwl.weighted_jacobians(model, X[i], 3.0, 0.05, 'zoh')
+        close(A, g['Adw'][i]); close(B, g['Bdw'][i]); close(d, g['ddw'][i])
+    close(otpwl.rollout_weighted(model, g['rollw_x'][0], g['rollw_u'], 3.0, 0.05), g['rollw_x'])
 
 
 @pytest.mark.parametrize('meth', ['fe', 'be', 'bil', 'zoh'])

@@ -79,3 +79,62 @@ def test_rollout_and_nearest_vs_oracle(r, m, P, N, batch):
         xo = otpwl.rollout(model, Ad, Bd, dd, x0[b], u[b])
         close(Xr[b], xo, 1e-10)
         close(Zr[b], (tp.H @ xo.T).T + tp.z_ref, 1e-10)
+
+
+def test_weighting_mode_golden(golden):
+    """tpwl_method='weighting' (tpwl.py:170-191, 244-250): weights, blended Jacobians, discretised blend and
+    the step-wise rollout against the imported reference."""
+    g = golden('g3_tpwl')
+    model, U, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 10)
+    model['w_v'] = 0.5
+    tw = product_tpwl(model, U, q_ref, v_ref, Hf, method='weighting', beta=3.0)
+    X = g['X']
+    W = tw.calc_weighting_factors(X)
+    close(W, g['weights'], 1e-13)
+    close(tw.calc_weighting_factors(X[3]), g['weights'][3], 1e-15)      # exactly on a point: one-hot
+    assert tw.calc_weighting_factors(X[3])[2] == 1.0
+    A, B, d, W2 = tw.linearize_batch(X)
+    close(A, g['Aw'], 1e-12); close(B, g['Bw'], 1e-12); close(d, g['dw'], 1e-12)
+    np.testing.assert_array_equal(W, W2)
+    for i in range(4):
+        Ad, Bd, dd = tw.get_jacobians(X[i], dt=0.05)
+        close(Ad, g['Adw'][i], 1e-11); close(Bd, g['Bdw'][i], 1e-11); close(dd, g['ddw'][i], 1e-11)
+    xr, zr = tw.rollout(g['rollw_x'][0], g['rollw_u'], 0.05)
+    close(xr, g['rollw_x'], 1e-10); close(zr, g['rollw_z'], 1e-10)
+    with pytest.raises(RuntimeError):
+        tw.pre_discretize(0.05)
+    with pytest.raises(RuntimeError):
+        product_tpwl(model, U, q_ref, v_ref, Hf, method='weighting', beta=None)
+
+
+def test_weighting_gusto_host_loop():
+    """GuSTO over a weighting-mode TPWL model goes through the generic host loop around the device QP and
+    agrees with the restated loop (oracle) on the same model."""
+    from oracle import gusto as ogusto, locp as olocp
+    from sofacontrol_amd.scp.models.tpwl import TPWLGuSTO
+    from sofacontrol_amd.scp.gusto import GuSTO
+    r, m, P, N, dt = 3, 2, 5, 6, 0.05
+    model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, 12, 31, q_scale=0.2)
+    tw = product_tpwl(model, U, q_ref, v_ref, Hf, method='weighting', beta=2.0)
+    gm = TPWLGuSTO(tw)
+    H = np.asarray(tw.H)
+    Qz = np.diag([0., 0., 0., 100., 100., 0.]); R = 1e-3 * np.eye(m)
+    x0 = 0.05 * np.random.default_rng(3).standard_normal(2 * r)
+    u_init = np.zeros((N, m))
+    x_init, _ = tw.rollout(x0, u_init, dt)
+    z = np.tile(H @ x0 + np.array([0, 0, 0, 0.02, -0.01, 0]), (N + 1, 1))
+    g = GuSTO(gm, N, dt, Qz, R, x0, u_init, x_init, z=z, verbose=0, max_gusto_iters=4, convg_thresh=1e-3)
+    assert not g._fused
+    xopt, uopt, zopt, _ = g.get_solution()
+
+    class OModel:
+        n_x, n_u = 2 * r, m
+    def dyn_d(x, u):
+        return otpwl.weighted_jacobians(model, x, 2.0, dt, 'zoh')
+    def dyn_c(x, u):
+        A, B, d = otpwl.weighted_jacobians(model, x, 2.0)
+        return A @ x + B @ u + d, A, B
+    xc, fc = gm.get_characteristic_vals()
+    xo, uo, _, tr = ogusto.solve_generic(dyn_d, dyn_c, H, N, dt, Qz, R, x0, u_init, x_init, z=z, x_char=xc, f_char=fc,
+                                         convg_thresh=1e-3, max_gusto_iters=4)
+    close(xopt, xo, 1e-6); close(uopt, uo, 1e-5)
