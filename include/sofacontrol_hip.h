@@ -138,6 +138,26 @@ int stpwl_rollout(stpwl_t *h, const double *x0, const double *U, int N, int64_t 
 int stpwl_characteristic(stpwl_t *h, double *x_char, double *f_char);
 
 /* =====================================================================================================
+ * Discrete EKF over the TPWL model.                        reference: sofacontrol/tpwl/observer.py:33-126
+ * State estimate x (n_x) and covariance Sigma (n_x x n_x) stay resident in HBM between steps.
+ * ===================================================================================================== */
+typedef struct sekf sekf_t;
+/* DiscreteEKFObserver.__init__ (observer.py:52-67): C (n_y x n_x) reduced measurement matrix, y_ref (n_y)
+ * or NULL, Sigma0 / W (n_x x n_x), V (n_y x n_y).  The model handle must outlive the filter. */
+int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_ref, int n_y,
+                const double *Sigma0, const double *W, const double *V);
+int sekf_destroy(sekf_t *h);
+/* initialize (observer.py:76-86): overwrite the estimate and/or the covariance (either may be NULL) */
+int sekf_set_state(sekf_t *h, const double *x, const double *Sigma);
+int sekf_get_state(sekf_t *h, double *x, double *Sigma);
+/* update = predict_state + update_state (observer.py:88-126).  u (n_u) != NULL runs the predictor with the
+ * nearest-point discrete tables of the model, or with (A_d, B_d, d_d) when given (weighting-mode models);
+ * y (n_y, full-order measurement, y_ref is subtracted) != NULL runs the filter update.  x_out (n_x) optional.
+ * Returns SRH_ENUMERIC when the innovation covariance is not positive definite. */
+int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, const double *B_d,
+              const double *d_d, double *x_out);
+
+/* =====================================================================================================
  * Riccati recursions.             reference: sofacontrol/lqr/lqr.py, sofacontrol/lqr/traj_tracking_lqr.py
  * ===================================================================================================== */
 /* TrajTrackingLQR.perform_dlqr_recursion (traj_tracking_lqr.py:18-48) for per-step (A_i, B_i),

@@ -1,0 +1,279 @@
+// Discrete extended Kalman filter over the TPWL model, state and covariance resident in HBM.
+// Reference: sofacontrol/tpwl/observer.py:33-126 (DiscreteEKFObserver): predict_state 97-106,
+// update_state 108-126.  One workgroup per filter step; every matrix of the step lives in LDS.
+#include "tpwl_host.h"
+
+struct sekf {
+    stpwl *model = nullptr;
+    int n = 0, m = 0, ny = 0;
+    srh::DevBuf C, y_ref, W, V, x, Sigma, scratch, ext;
+    size_t lds = 0;
+};
+
+namespace {
+
+struct EkfArgs {
+    TpwlDev T;
+    int n, m, ny, ld, ldy;
+    const double *C, *y_ref, *W, *V;
+    double *x, *Sigma;
+    const double *u, *y;            // inputs of the step (device)
+    const double *Aext, *Bext, *dext;   // explicit (A_d, B_d, d_d) instead of the nearest-point tables
+    int do_predict, do_update;
+    int *status;
+};
+
+constexpr int EKF_NT = 256;
+
+__global__ __launch_bounds__(EKF_NT) void ekf_kernel(EkfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = a.n, m = a.m, ny = a.ny, ld = a.ld, ldy = a.ldy;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    lptr Sg = (lptr)smem;                 // Sigma            (n x ld)
+    lptr Am = Sg + (size_t)n * ld;        // A_d, later M1 = Sigma^- C^T then K   (n x ld)
+    lptr Tm = Am + (size_t)n * ld;        // A Sigma, later C Sigma^-            (n x ld) / (ny x ld)
+    lptr Cm = Tm + (size_t)n * ld;        // C                (ny x ld)
+    lptr Sm = Cm + (size_t)ny * ld;       // S and its Cholesky factor (ny x ldy)
+    const int nv = n > ny ? n : ny;
+    lptr xv = Sm + (size_t)ny * ldy;      // state
+    lptr xn = xv + nv;                    // predicted state
+    lptr iv = xn + nv;                    // innovation
+    lptr uv = iv + nv;                    // input
+    liptr ip = (liptr)(uv + nv);
+
+    for (int e = tid; e < n * n; e += nt) Sg[(e / n) * ld + e % n] = a.Sigma[e];
+    for (int e = tid; e < n; e += nt) xv[e] = a.x[e];
+    if (a.do_predict)
+        for (int e = tid; e < m; e += nt) uv[e] = a.u[e];
+    if (tid == 0) ip[1] = 0;
+    __syncthreads();
+
+    if (a.do_predict) {
+        // ---- x^- = A x + B u + d, Sigma^- = A Sigma A^T + W                     (observer.py:104-106)
+        const double *Ag, *Bg, *dg;
+        if (a.Aext != nullptr) {
+            Ag = a.Aext; Bg = a.Bext; dg = a.dext;
+        } else {
+            if (tid < 64) {
+                const int i = tpwl::nearest_wave(a.T, xv);
+                if (tid == 0) ip[0] = i;
+            }
+            __syncthreads();
+            const int i = ip[0];
+            Ag = (const double *)a.T.Ad + (size_t)i * n * n;
+            Bg = (const double *)a.T.Bd + (size_t)i * n * m;
+            dg = (const double *)a.T.dd + (size_t)i * n;
+        }
+        for (int e = tid; e < n * n; e += nt) Am[(e / n) * ld + e % n] = Ag[e];
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Am[i * ld + k], xv[k], s);
+            double t = 0.0;
+            for (int k = 0; k < m; ++k) t = fma(Bg[i * m + k], uv[k], t);
+            xn[i] = s + t + dg[i];
+        }
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Am[i * ld + k], Sg[k * ld + j], s);
+            Tm[i * ld + j] = s;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Tm[i * ld + k], Am[j * ld + k], s);
+            Sg[i * ld + j] = s + a.W[e];
+        }
+        for (int e = tid; e < n; e += nt) xv[e] = xn[e];
+        __syncthreads();
+    }
+
+    if (a.do_update) {
+        // ---- S = C Sigma C^T + V, K = Sigma C^T S^-1, x += K (y - y_ref - C x), Sigma = (I - K C) Sigma
+        for (int e = tid; e < ny * n; e += nt) Cm[(e / n) * ld + e % n] = a.C[e];
+        __syncthreads();
+        for (int e = tid; e < n * ny; e += nt) {       // M1 = Sigma C^T  (n x ny)
+            const int i = e / ny, j = e % ny;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Sg[i * ld + k], Cm[j * ld + k], s);
+            Am[i * ld + j] = s;
+        }
+        for (int e = tid; e < ny * n; e += nt) {       // CS = C Sigma    (ny x n)
+            const int i = e / n, j = e % n;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Cm[i * ld + k], Sg[k * ld + j], s);
+            Tm[i * ld + j] = s;
+        }
+        for (int i = tid; i < ny; i += nt) {           // innovation
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Cm[i * ld + k], xv[k], s);
+            iv[i] = a.y[i] - (a.y_ref ? a.y_ref[i] : 0.0) - s;
+        }
+        __syncthreads();
+        for (int e = tid; e < ny * ny; e += nt) {      // S = C M1 + V
+            const int i = e / ny, j = e % ny;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Cm[i * ld + k], Am[k * ld + j], s);
+            Sm[i * ldy + j] = s + a.V[e];
+        }
+        __syncthreads();
+        // Cholesky of S (symmetrised lower part), right-looking, one column per step
+        for (int j = 0; j < ny; ++j) {
+            if (tid == 0) {
+                const double dj = Sm[j * ldy + j];
+                if (!(dj > 0.0)) ip[1] = 1;
+                Sm[j * ldy + j] = sqrt(dj);
+            }
+            __syncthreads();
+            const double dj = Sm[j * ldy + j];
+            for (int i = j + 1 + tid; i < ny; i += nt) Sm[i * ldy + j] = Sm[i * ldy + j] / dj;
+            __syncthreads();
+            for (int e = tid; e < (ny - j - 1) * (ny - j - 1); e += nt) {
+                const int i = j + 1 + e / (ny - j - 1), k = j + 1 + e % (ny - j - 1);
+                if (k <= i) Sm[i * ldy + k] = fma(-Sm[i * ldy + j], Sm[k * ldy + j], Sm[i * ldy + k]);
+            }
+            __syncthreads();
+        }
+        if (ip[1] != 0) {
+            if (tid == 0) *a.status = 1;
+            return;
+        }
+        // K row i: solve k S = M1_i  <=>  S k^T = M1_i^T  (S = L L^T), in place
+        for (int i = tid; i < n; i += nt) {
+            lptr row = Am + (size_t)i * ld;
+            for (int c = 0; c < ny; ++c) {
+                double s = row[c];
+                for (int k = 0; k < c; ++k) s = fma(-Sm[c * ldy + k], row[k], s);
+                row[c] = s / Sm[c * ldy + c];
+            }
+            for (int c = ny - 1; c >= 0; --c) {
+                double s = row[c];
+                for (int k = c + 1; k < ny; ++k) s = fma(-Sm[k * ldy + c], row[k], s);
+                row[c] = s / Sm[c * ldy + c];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            double s = 0.0;
+            for (int k = 0; k < ny; ++k) s = fma(Am[i * ld + k], iv[k], s);
+            xn[i] = xv[i] + s;
+        }
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            double s = 0.0;
+            for (int k = 0; k < ny; ++k) s = fma(Am[i * ld + k], Tm[k * ld + j], s);
+            a.Sigma[e] = Sg[i * ld + j] - s;
+        }
+        __syncthreads();
+        for (int e = tid; e < n; e += nt) a.x[e] = xn[e];
+    } else {
+        for (int e = tid; e < n * n; e += nt) a.Sigma[e] = Sg[(e / n) * ld + e % n];
+        for (int e = tid; e < n; e += nt) a.x[e] = xv[e];
+    }
+    if (tid == 0) *a.status = 0;
+}
+
+size_t lds_bytes(int n, int ny) {
+    const int ld = n | 1, ldy = ny | 1;
+    const int nv = n > ny ? n : ny;
+    return sizeof(double) * ((size_t)3 * n * ld + (size_t)ny * ld + (size_t)ny * ldy + 4 * (size_t)nv + 8);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_ref, int n_y, const double *Sigma0,
+                const double *W, const double *V) {
+    SRH_REQUIRE(out && model && C && Sigma0 && W && V, "sekf_create: null argument");
+    SRH_REQUIRE(n_y > 0 && n_y <= model->n, "sekf_create: need 0 < n_y <= n_x");
+    auto *h = new sekf();
+    h->model = model; h->n = model->n; h->m = model->m; h->ny = n_y;
+    h->lds = lds_bytes(h->n, n_y);
+    if (h->lds > 160 * 1024) {
+        delete h;
+        srh::set_error("sekf_create: the filter step does not fit the 160 KB LDS (n_x too large)");
+        return SRH_EINVAL;
+    }
+    const size_t n = h->n;
+    int rc;
+    if ((rc = h->C.upload(C, sizeof(double) * n_y * n)) || (rc = h->W.upload(W, sizeof(double) * n * n)) ||
+        (rc = h->V.upload(V, sizeof(double) * n_y * n_y)) || (rc = h->Sigma.upload(Sigma0, sizeof(double) * n * n)) ||
+        (rc = h->x.alloc(sizeof(double) * n)) || (rc = h->scratch.alloc(sizeof(double) * (h->m + n_y) + 64)) ||
+        (rc = h->ext.alloc(sizeof(double) * (n * n + n * h->m + n)))) {
+        delete h;
+        return rc;
+    }
+    if (y_ref && (rc = h->y_ref.upload(y_ref, sizeof(double) * n_y))) { delete h; return rc; }
+    SRH_CHECK_HIP(hipMemset(h->x.p, 0, sizeof(double) * n));
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ekf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)h->lds));
+    *out = h;
+    return SRH_OK;
+}
+
+int sekf_destroy(sekf_t *h) {
+    delete h;
+    return SRH_OK;
+}
+
+int sekf_set_state(sekf_t *h, const double *x, const double *Sigma) {
+    SRH_REQUIRE(h && (x || Sigma), "sekf_set_state: null argument");
+    int rc;
+    if (x && (rc = h->x.upload(x, sizeof(double) * h->n))) return rc;
+    if (Sigma && (rc = h->Sigma.upload(Sigma, sizeof(double) * h->n * h->n))) return rc;
+    return SRH_OK;
+}
+
+int sekf_get_state(sekf_t *h, double *x, double *Sigma) {
+    SRH_REQUIRE(h, "sekf_get_state: null argument");
+    int rc;
+    if (x && (rc = h->x.download(x, sizeof(double) * h->n))) return rc;
+    if (Sigma && (rc = h->Sigma.download(Sigma, sizeof(double) * h->n * h->n))) return rc;
+    return SRH_OK;
+}
+
+int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, const double *B_d, const double *d_d,
+              double *x_out) {
+    SRH_REQUIRE(h, "sekf_step: null argument");
+    SRH_REQUIRE(u || y, "sekf_step: need an input (predict) and/or a measurement (update)");
+    const bool ext = A_d != nullptr;
+    SRH_REQUIRE(!ext || (B_d && d_d), "sekf_step: A_d given without B_d, d_d");
+    SRH_REQUIRE(!u || ext || h->model->has_discrete, "sekf_step: model has not been pre-discretised");
+    const int n = h->n, m = h->m, ny = h->ny;
+    double *su = h->scratch.as<double>();
+    double *sy = su + m;
+    int *st = (int *)(sy + ny);
+    if (u) SRH_CHECK_HIP(hipMemcpy(su, u, sizeof(double) * m, hipMemcpyHostToDevice));
+    if (y) SRH_CHECK_HIP(hipMemcpy(sy, y, sizeof(double) * ny, hipMemcpyHostToDevice));
+    double *e = h->ext.as<double>();
+    if (ext && u) {
+        SRH_CHECK_HIP(hipMemcpy(e, A_d, sizeof(double) * n * n, hipMemcpyHostToDevice));
+        SRH_CHECK_HIP(hipMemcpy(e + (size_t)n * n, B_d, sizeof(double) * n * m, hipMemcpyHostToDevice));
+        SRH_CHECK_HIP(hipMemcpy(e + (size_t)n * n + (size_t)n * m, d_d, sizeof(double) * n, hipMemcpyHostToDevice));
+    }
+    EkfArgs a{};
+    a.T = h->model->view();
+    a.n = n; a.m = m; a.ny = ny; a.ld = n | 1; a.ldy = ny | 1;
+    a.C = h->C.as<double>(); a.y_ref = h->y_ref.p ? h->y_ref.as<double>() : nullptr;
+    a.W = h->W.as<double>(); a.V = h->V.as<double>();
+    a.x = h->x.as<double>(); a.Sigma = h->Sigma.as<double>();
+    a.u = su; a.y = sy;
+    if (ext && u) { a.Aext = e; a.Bext = e + (size_t)n * n; a.dext = e + (size_t)n * n + (size_t)n * m; }
+    a.do_predict = u != nullptr; a.do_update = y != nullptr;
+    a.status = st;
+    ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
+    SRH_CHECK_HIP(hipGetLastError());
+    int status = 0;
+    SRH_CHECK_HIP(hipMemcpy(&status, st, sizeof(int), hipMemcpyDeviceToHost));
+    if (status != 0) {
+        srh::set_error("sekf_step: innovation covariance S is not positive definite");
+        return SRH_ENUMERIC;
+    }
+    if (x_out) return h->x.download(x_out, sizeof(double) * n);
+    return SRH_OK;
+}
+
+}  // extern "C"

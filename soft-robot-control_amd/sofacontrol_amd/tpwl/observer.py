@@ -1,5 +1,11 @@
-"""Observers (sofacontrol/tpwl/observer.py).  FullStateObserver (lines 3-30) is pure bookkeeping.  The
-DiscreteEKFObserver (lines 33-126) is next-tier and not provided yet."""
+"""Observers (sofacontrol/tpwl/observer.py).  FullStateObserver (lines 3-30) is pure bookkeeping; the
+DiscreteEKFObserver (lines 33-126) keeps its estimate and covariance in HBM and runs one kernel per step
+(`sekf_step`, csrc/observer.hip)."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
 
 
 class FullStateObserver:
@@ -22,5 +28,92 @@ class FullStateObserver:
 
 
 class DiscreteEKFObserver:
-    def __init__(self, *a, **k):
-        raise NotImplementedError('DiscreteEKFObserver is next-tier (fused with the projection step); use FullStateObserver')
+    """observer.py:33-126.  `Sigma` is read back from the device on access."""
+
+    def __init__(self, dyn_sys, **kwargs):
+        self.dyn_sys = dyn_sys
+        if self.dyn_sys.C is None:
+            raise RuntimeError('Need to set meas. model in dyn_sys')
+        self.C = self.dyn_sys.C
+        self.state_dim = self.dyn_sys.get_state_dim()
+        self.meas_dim = self.C.shape[0]
+        Sigma0 = kwargs.get('Sigma0', np.eye(self.state_dim))
+        self.W = kwargs.get('W', 100 * np.eye(self.state_dim))
+        self.V = kwargs.get('V', np.eye(self.meas_dim))
+        self._h = C.c_void_p()
+        Cm, yr = _lib.f64(self.C), _lib.f64(self.dyn_sys.y_ref)
+        S0, W, V = _lib.f64(Sigma0), _lib.f64(self.W), _lib.f64(self.V)
+        _lib.check(_lib.lib().sekf_create(C.byref(self._h), self.dyn_sys.handle, _lib.dptr(Cm), _lib.dptr(yr),
+                                          C.c_int(self.meas_dim), _lib.dptr(S0), _lib.dptr(W), _lib.dptr(V)),
+                   'sekf_create')
+        self.initialize(self.dyn_sys.rom.x_ref)
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            try:
+                _lib.lib().sekf_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def get_meas_dim(self):
+        return self.meas_dim
+
+    def get_observer_params(self):
+        return {'W': self.W, 'V': self.V, 'meas_dim': self.meas_dim, 'state_dim': self.state_dim,
+                'C': self.C, 'H': self.dyn_sys.H}
+
+    @property
+    def Sigma(self):
+        S = np.empty((self.state_dim, self.state_dim))
+        _lib.check(_lib.lib().sekf_get_state(self._h, None, _lib.dptr(S)), 'sekf_get_state')
+        return S
+
+    @Sigma.setter
+    def Sigma(self, S):
+        S = _lib.f64(S)
+        _lib.check(_lib.lib().sekf_set_state(self._h, None, _lib.dptr(S)), 'sekf_set_state')
+
+    def _set_z(self):
+        if self.dyn_sys.H is not None:
+            self.z = self.dyn_sys.x_to_zfyf(self.x, zf=True)
+        else:
+            self.z = self.dyn_sys.x_to_zfyf(self.x, yf=True)
+
+    def initialize(self, xf):
+        """observer.py:76-86."""
+        self.x = self.dyn_sys.rom.compute_RO_state(xf=xf)
+        x = _lib.f64(self.x)
+        _lib.check(_lib.lib().sekf_set_state(self._h, _lib.dptr(x), None), 'sekf_set_state')
+        self._set_z()
+
+    def _step(self, u, y, dt):
+        A = B = d = None
+        if u is not None:
+            if getattr(self.dyn_sys, 'tpwl_method', 'nn') == 'nn':
+                self.dyn_sys._ensure_discrete(dt)
+            else:
+                A, B, d = [_lib.f64(a) for a in self.dyn_sys.get_jacobians(self.x, dt)]
+            u = _lib.f64(u)
+        if y is not None:
+            y = _lib.f64(y)
+        x = np.empty(self.state_dim)
+        _lib.check(_lib.lib().sekf_step(self._h, _lib.dptr(u), _lib.dptr(y), _lib.dptr(A), _lib.dptr(B),
+                                        _lib.dptr(d), _lib.dptr(x)), 'sekf_step')
+        self.x = x
+
+    def update(self, u, y, dt, **kwargs):
+        """observer.py:88-95: predictor + filter update in one kernel."""
+        self._step(u, y, dt)
+        self._set_z()
+
+    def predict_state(self, u, dt):
+        """observer.py:97-106."""
+        self._step(u, None, dt)
+
+    def update_state(self, y):
+        """observer.py:108-126."""
+        self._step(None, y, None)
+        self._set_z()
+        return self.x

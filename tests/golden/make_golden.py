@@ -338,6 +338,56 @@ if __name__ == '__main__':
             print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
+def meas_selector(nodes, num_nodes):
+    """Position rows of the listed nodes out of x = [v; q] (same structure as measurement_models.linearModel)."""
+    n_f = 3 * num_nodes
+    Cf = sp.lil_matrix((3 * len(nodes), 2 * n_f))
+    for i, nd in enumerate(nodes):
+        for a in range(3):
+            Cf[3 * i + a, n_f + 3 * nd + a] = 1.0
+    return Cf.tocsr()
+
+
+def g9_ekf(out):
+    """DiscreteEKFObserver (tpwl/observer.py:33-126) over the synthetic TPWL model."""
+    from sofacontrol.tpwl.observer import DiscreteEKFObserver
+    r, m, P, n_nodes = 4, 3, 7, 20
+    model, U, q_ref, v_ref, Hf = make_problem(r, m, P, n_nodes, 50, q_scale=0.3)
+    Cf = meas_selector([3, 9], n_nodes)
+    tp = rtpwl.TPWLATV(data=dict(q=model['q'], v=model['v'], u=model['u'], A_c=model['A_c'], B_c=model['B_c'],
+                                 d_c=model['d_c'], rom_info=dict(type='POD', U=U, q_ref=q_ref, v_ref=v_ref)),
+                       params=dict(tpwl_method='nn', dist_weights={'q': 1.0, 'v': 0.0}, beta_weighting=None),
+                       Cf=Cf, Hf=Hf, discr_method='zoh')
+    dt = 0.02
+    quiet(tp.pre_discretize, dt)
+    n = 2 * r
+    rng = np.random.default_rng(51)
+    G = rng.standard_normal((n, n))
+    W = 10 * np.eye(n) + 0.1 * (G + G.T)
+    Vn = 0.1 * np.eye(6) + 0.01 * np.diag(rng.uniform(0, 1, 6))
+    Sigma0 = 0.5 * np.eye(n)
+    ekf = DiscreteEKFObserver(tp, Sigma0=Sigma0.copy(), W=W, V=Vn)
+    res = dict(W=W, V=Vn, Sigma0=Sigma0, Cf=Cf.toarray(), x_init=ekf.x.copy(), z_init=np.asarray(ekf.z).copy())
+    xs, Ss, zs, us, ys = [], [], [], [], []
+    xt = 0.05 * rng.standard_normal(n)
+    for k in range(8):
+        u = rng.uniform(0, 500, m)
+        A, B, d = tp.get_jacobians(xt, dt)
+        xt = A @ xt + B @ u + d
+        y = np.asarray(tp.C @ xt).ravel() + tp.y_ref + 0.01 * rng.standard_normal(6)
+        ekf.update(u, y, dt)
+        us.append(u); ys.append(y); xs.append(ekf.x.copy()); Ss.append(ekf.Sigma.copy()); zs.append(np.asarray(ekf.z).copy())
+    res.update(u=np.stack(us), y=np.stack(ys), x=np.stack(xs), Sigma=np.stack(Ss), z=np.stack(zs))
+    ekf.predict_state(us[0], dt)
+    res['x_pred'], res['Sigma_pred'] = ekf.x.copy(), ekf.Sigma.copy()
+    ekf.update_state(ys[1])
+    res['x_upd'], res['Sigma_upd'] = ekf.x.copy(), ekf.Sigma.copy()
+    xf0 = np.concatenate((v_ref, q_ref)) + 0.01 * rng.standard_normal(6 * n_nodes)
+    ekf.initialize(xf0)
+    res['xf0'], res['x_reinit'] = xf0, ekf.x.copy()
+    np.savez_compressed(os.path.join(out, 'g9_ekf.npz'), **res)
+
+
 class FakeGuSTOClient:
     """Deterministic stand-in for GuSTOClientNode (needs ROS): returns a smooth analytic 'solution'."""
     N, dt_g = 8, 0.05
@@ -417,5 +467,6 @@ def g8_controllers(out):
 
 
 if __name__ == '__main__':
+    g9_ekf(HERE)
     g8_controllers(HERE)
     print('g8_controllers.npz', os.path.getsize(os.path.join(HERE, 'g8_controllers.npz')))

@@ -24,12 +24,12 @@ def tip_selector(node, num_nodes):
     return C.tocsr()
 
 
-def product_tpwl(model, U, q_ref, v_ref, Hf, discr='zoh', method='nn', beta=None):
+def product_tpwl(model, U, q_ref, v_ref, Hf, discr='zoh', method='nn', beta=None, Cf=None):
     from sofacontrol_amd.tpwl.tpwl import TPWLATV
     data = dict(q=model['q'], v=model['v'], u=model['u'], A_c=model['A_c'], B_c=model['B_c'], d_c=model['d_c'],
                 rom_info=dict(type='POD', U=U, q_ref=q_ref, v_ref=v_ref))
     params = dict(tpwl_method=method, dist_weights={'q': model['w_q'], 'v': model['w_v']}, beta_weighting=beta)
-    return TPWLATV(data=data, params=params, Hf=Hf, discr_method=discr)
+    return TPWLATV(data=data, params=params, Hf=Hf, Cf=Cf, discr_method=discr)
 
 
 def golden_problem(r, m, P, n_nodes, seed, q_scale=1.0):
@@ -45,3 +45,14 @@ def Poly(A, b):
     """The product's Polyhedron (same protocol as sofacontrol/utils.py:364-398)."""
     from sofacontrol_amd.utils import Polyhedron
     return Polyhedron(A, b)
+
+
+def meas_selector(nodes, num_nodes):
+    """Position rows of the listed nodes out of x = [v; q] (mirror of make_golden.meas_selector)."""
+    import scipy.sparse as sp
+    n_f = 3 * num_nodes
+    Cf = sp.lil_matrix((3 * len(nodes), 2 * n_f))
+    for i, nd in enumerate(nodes):
+        for a in range(3):
+            Cf[3 * i + a, n_f + 3 * nd + a] = 1.0
+    return Cf.tocsr()

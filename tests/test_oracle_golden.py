@@ -221,3 +221,28 @@ def test_gusto_outer_loop_matches_reference_loop(golden, tag):
     close(x2, g[tag + '_xopt2'], rtol=1e-5, atol=1e-7)
     close(u2, g[tag + '_uopt2'], rtol=1e-5, atol=1e-7)
     close(zi(0.37 + dt * np.arange(N + 1)), g['get_target_z'])
+
+
+# ---------------------------------------------------------------- G9: EKF observer
+def test_ekf_oracle(golden):
+    from oracle import observer as oobs
+    from helpers import golden_problem, meas_selector
+    g = golden('g9_ekf')
+    model, U, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 50, q_scale=0.3)
+    Cf = meas_selector([3, 9], 20)
+    np.testing.assert_array_equal(Cf.toarray(), g['Cf'])
+    V = np.kron(np.eye(2), U)
+    x_ref = np.concatenate((v_ref, q_ref))
+    C = Cf @ V
+    y_ref = Cf @ x_ref
+    Ad, Bd, dd = otpwl.pre_discretize(model, 0.02, 'zoh')
+    x, S = g['x_init'], g['Sigma0']
+    close(x, np.zeros(8))
+    for k in range(8):
+        x, S = oobs.predict(model, Ad, Bd, dd, x, S, g['u'][k], g['W'])
+        x, S = oobs.update(C, y_ref, x, S, g['y'][k], g['V'])
+        close(x, g['x'][k], 1e-10); close(S, g['Sigma'][k], 1e-10)
+    x, S = oobs.predict(model, Ad, Bd, dd, x, S, g['u'][0], g['W'])
+    close(x, g['x_pred'], 1e-10); close(S, g['Sigma_pred'], 1e-10)
+    x, S = oobs.update(C, y_ref, x, S, g['y'][1], g['V'])
+    close(x, g['x_upd'], 1e-10); close(S, g['Sigma_upd'], 1e-10)
