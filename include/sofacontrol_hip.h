@@ -158,6 +158,43 @@ int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, co
               const double *d_d, double *x_out);
 
 /* =====================================================================================================
+ * SSM polynomial reduced model.                                  reference: sofacontrol/SSM/ssm.py
+ * f(x,u) = r_coeff phi_rom(x) + B u;  z = w_coeff phi_ssm(x) + z_ref;  x = v_coeff phi_ssm(z - z_ref),
+ * phi = monomials of degree 1..order, graded, lexicographic with x1 first (get_poly_basis, ssm.py:158-164).
+ * ===================================================================================================== */
+typedef struct sssm sssm_t;
+#define SSSM_CONT         0   /* continuous Jacobians (get_continuous_jacobians, ssm.py:198-204)        */
+#define SSSM_FE           1   /* discretize_dynamics 'fe'  (ssm.py:279-283)                              */
+#define SSSM_BE           2   /* 'be'  (ssm.py:285-289)                                                  */
+#define SSSM_BIL          3   /* 'bil' (ssm.py:291-296)                                                  */
+#define SSSM_DISCRETE_MAP 4   /* self.discrete: Jacobians of rd_coeff phi + Bd u (ssm.py:206-218)        */
+int sssm_num_monomials(int dim, int order);
+int sssm_exponents(int dim, int order, int32_t *exps);            /* (n_mon x dim) exponent table */
+/* SSM.__init__ (ssm.py:24-71): r_coeff (n_x x n_rom), B (n_x x n_u), rd_coeff / Bd or NULL, w_coeff
+ * (n_o x n_ssm), v_coeff (n_x x n_ssm), z_ref (n_o); n_rom / n_ssm = sssm_num_monomials(n_x / n_o, order) */
+int sssm_create(sssm_t **out, int n_x, int n_u, int n_o, int rom_order, int ssm_order,
+                const double *r_coeff, const double *B, const double *rd_coeff, const double *Bd,
+                const double *w_coeff, const double *v_coeff, const double *z_ref);
+int sssm_destroy(sssm_t *h);
+/* bookkeeping performance matrix H (n_o x n_x) used by iLQR cost Hessians (ssm.py:69-70; zeros by default) */
+int sssm_set_output(sssm_t *h, const double *H);
+/* SSMDynamics.get_jacobians / get_continuous_jacobians / get_discrete_jacobians (ssm.py:198-218) for B
+ * points: X (B x n_x), U (B x n_u) -> A (B x n_x x n_x), Bm (B x n_x x n_u), d (B x n_x) */
+int sssm_linearize(sssm_t *h, const double *X, const double *U, int64_t B, int mode, double dt,
+                   double *A, double *Bm, double *d);
+/* reduced_dynamics / reduced_dynamics_discrete (ssm.py:167-178): F (B x n_x) */
+int sssm_dynamics(sssm_t *h, const double *X, const double *U, int64_t B, int discrete, double *F);
+/* reduced_to_observed C_map (ssm.py:170-171) -> Z (B x n_o, WITHOUT z_ref) and/or get_observer_jacobians
+ * (ssm.py:220-227): H (B x n_o x n_x), c = C(x) - H x (B x n_o).  Z or H may be NULL. */
+int sssm_observe(sssm_t *h, const double *X, int64_t B, double *Z, double *H, double *c);
+/* compute_RO_state (ssm.py:338-344): X = v_coeff phi(Z - z_ref) */
+int sssm_reduce(sssm_t *h, const double *Z, int64_t B, double *X);
+/* SSM.rollout (ssm.py:134-156) for `batch` rollouts: x0 (batch x n_x), U (batch x N x n_u) ->
+ * X (batch x (N+1) x n_x), Z (batch x (N+1) x n_o, includes z_ref) or NULL */
+int sssm_rollout(sssm_t *h, const double *x0, const double *U, int N, int64_t batch, int mode, double dt,
+                 double *X, double *Z);
+
+/* =====================================================================================================
  * Riccati recursions.             reference: sofacontrol/lqr/lqr.py, sofacontrol/lqr/traj_tracking_lqr.py
  * ===================================================================================================== */
 /* TrajTrackingLQR.perform_dlqr_recursion (traj_tracking_lqr.py:18-48) for per-step (A_i, B_i),

@@ -65,19 +65,26 @@ def solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=None, u_des=
 
 
 def solve_generic(dyn_d, dyn_c, H, N, dt, Qz, R, x0, u_init, x_init, z=None, u_des=None, Qzf=None, zf=None,
-                  U=None, X=None, Xf=None, dU=None, x_char=None, f_char=None, qp_solver=None, **kw):
+                  U=None, X=None, Xf=None, dU=None, x_char=None, f_char=None, qp_solver=None, obs_lin=None, **kw):
     """The same loop for a generic TemplateModel: dyn_d(x, u) -> (A_d, B_d, d_d)
-    (get_discrete_dynamics, gusto.py:225-238), dyn_c(x, u) -> (f, A, B) (get_continuous_dynamics)."""
+    (get_discrete_dynamics, gusto.py:225-238), dyn_c(x, u) -> (f, A, B) (get_continuous_dynamics);
+    obs_lin(x) -> (H_d, c_d) for models with a nonlinear observer (gusto.py:240-251, 306-310, 467-471)."""
     def get_traj(xk, uk):
         A, B, d = zip(*[dyn_d(xk[i], uk[i]) for i in range(xk.shape[0] - 1)])
         return np.stack(A), np.stack(B), np.stack(d)
     return _loop(get_traj, dyn_c, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, zf, U, X, Xf, dU, x_char,
-                 f_char, qp_solver, kw)
+                 f_char, qp_solver, kw, obs_lin)
 
 
 def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, zf, U, X, Xf, dU, x_char, f_char,
-          qp_solver, kw):
+          qp_solver, kw, obs_lin=None):
     par = dict(DEFAULTS); par.update(kw)
+
+    def get_obs(xk):
+        if obs_lin is None:
+            return None, None
+        Hs, cs = zip(*[obs_lin(xk[i]) for i in range(xk.shape[0])])
+        return np.stack(Hs), np.stack(cs)
     n = x0.shape[0]
     xs = 1. / np.abs(x_char) if x_char is not None else np.ones(n)
     fs = 1. / np.abs(f_char) if f_char is not None else np.ones(n)
@@ -87,6 +94,7 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
             return w
     xk, uk = x_init.copy(), u_init.copy()
     A_k, B_k, d_k = get_traj(xk, uk)
+    H_k, c_k = get_obs(xk)
     delta, omega = par['delta0'], par['omega0']
     new_solution = True
     J_prev = d_prev = o_prev = np.inf
@@ -95,7 +103,7 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
     trace = []
     while itr <= par['max_gusto_iters'] and not converged and omega <= par['omega_max']:
         qp = olocp.build_qp(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des,
-                            Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU, x_scale=xs)
+                            Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU, x_scale=xs, Hd=H_k, cd=c_k)
         w = qp_solver(qp)
         J = olocp.objective(qp, w)
         x_next, u_next, _ = olocp.split(qp, w)
@@ -127,5 +135,6 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
             xk, uk = x_next.copy(), u_next.copy()
             if par['max_gusto_iters'] >= 1:
                 A_k, B_k, d_k = get_traj(xk, uk)
+                H_k, c_k = get_obs(xk)
     zopt = (H @ xk.T).T
     return xk, uk, zopt, trace

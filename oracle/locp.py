@@ -25,7 +25,7 @@ class QPData:
 
 
 def build_qp(N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega, z=None, u_des=None, Qzf=None, zf=None,
-             U=None, X=None, Xf=None, dU=None, x_scale=None, tr_active=True):
+             U=None, X=None, Xf=None, dU=None, x_scale=None, tr_active=True, Hd=None, cd=None):
     """Stacked QP  min w'Pq w + c'w + c0  s.t.  E w = e,  G w <= h   (objective WITHOUT 1/2, as
     cp.quad_form, locp.py:226,248).  U/X/Xf/dU are (A, b) tuples or None.
 
@@ -33,6 +33,10 @@ def build_qp(N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega, z=None, u_des=None, 
     column k is x_k); U 300-303 (k<N); dU 305-308 (k<N-1); X 330-333 (k=1..N); Xf 336-337;
     x_0 = x0 340.  Terminal cost: locp.py:252 slices x[N*n_z:], which only type-checks when
     n_x == n_z, where it equals x_N -- restated as a cost on x_N.
+
+    Hd (N+1 x n_z x n_x), cd (N+1 x n_z): per-stage observer linearisation of the nonlinear-observer
+    branch (locp.py:231-245 objective, 312-329 state constraints X.A (Hd_k x_k + cd_k) <= X.b, k=1..N);
+    the terminal cost keeps the constant H (locp.py:251-252).
     """
     n, m = Bd[0].shape
     nz = Qz.shape[0]
@@ -47,11 +51,12 @@ def build_qp(N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega, z=None, u_des=None, 
     Pq = sp.lil_matrix((nw, nw))
     c = np.zeros(nw)
     c0 = 0.0
-    HQH = H.T @ Qz @ H
     for k in range(N + 1):
-        Pq[ox + k * n: ox + (k + 1) * n, ox + k * n: ox + (k + 1) * n] = HQH
-        c[ox + k * n: ox + (k + 1) * n] = -2.0 * H.T @ Qz @ z[k]
-        c0 += z[k] @ Qz @ z[k]
+        Hk = H if Hd is None else np.asarray(Hd[k])
+        zk = z[k] if cd is None else z[k] - np.asarray(cd[k])
+        Pq[ox + k * n: ox + (k + 1) * n, ox + k * n: ox + (k + 1) * n] = Hk.T @ Qz @ Hk
+        c[ox + k * n: ox + (k + 1) * n] = -2.0 * Hk.T @ Qz @ zk
+        c0 += zk @ Qz @ zk
     if Qzf is not None:
         zf_ = np.zeros(nz) if zf is None else zf
         Pq[ox + N * n: ox + (N + 1) * n, ox + N * n: ox + (N + 1) * n] += H.T @ Qzf @ H
@@ -110,9 +115,13 @@ def build_qp(N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega, z=None, u_des=None, 
         XA, Xb = X
         for k in range(1, N + 1):
             Gk = sp.lil_matrix((XA.shape[0], nw))
-            Gk[:, ox + k * n: ox + (k + 1) * n] = XA
+            if Hd is None:
+                Gk[:, ox + k * n: ox + (k + 1) * n] = XA
+                h_list.append(np.asarray(Xb, dtype=float))
+            else:
+                Gk[:, ox + k * n: ox + (k + 1) * n] = XA @ np.asarray(Hd[k])
+                h_list.append(np.asarray(Xb, dtype=float) - XA @ np.asarray(cd[k]))
             G_list.append(Gk)
-            h_list.append(np.asarray(Xb, dtype=float))
     if Xf is not None:
         XA, Xb = Xf
         Gk = sp.lil_matrix((XA.shape[0], nw))

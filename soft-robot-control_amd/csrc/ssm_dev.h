@@ -1,0 +1,237 @@
+// Device view of an SSM (spectral submanifold) polynomial reduced model and workgroup-cooperative helpers.
+// Reference: sofacontrol/SSM/ssm.py -- get_poly_basis 158-164, maps 167-178, Jacobians 198-235,
+// discretize_dynamics 279-301, update_dynamics 331-333.
+#pragma once
+#include "dev_la.h"
+
+struct SsmDev {
+    int n, m, no;              // reduced state, input, observed dimension
+    int nr, ns;                // monomial counts: rom basis (n variables), ssm basis (no variables)
+    const int *er, *es;        // exponent tables (nr x n), (ns x no)
+    cgptr R, Bc;               // r_coeff (n x nr), B (n x m)              continuous reduced dynamics
+    cgptr Rd, Bd;              // rd_coeff, Bd or null                      discrete reduced dynamics
+    cgptr Wc;                  // w_coeff (no x ns)  reduced -> observed (needs n == no)
+    cgptr Vc;                  // v_coeff (n x ns)   observed -> reduced
+    cgptr z_ref;               // (no)
+    cgptr H;                   // bookkeeping performance matrix (no x n) (zeros unless the user sets it)
+};
+
+// discretisation modes of sssm_linearize / rollout (ssm.py:279-301 and the `discrete` flag 212-218)
+enum { SSM_CONT = 0, SSM_FE = 1, SSM_BE = 2, SSM_BIL = 3, SSM_DISCRETE_MAP = 4 };
+
+namespace ssm {
+
+// phi_j(x) = prod_i x_i^e_ji and, if D != null, D[j][i] = d phi_j / d x_i    (all threads; ends with a sync)
+__device__ inline void basis(const int *__restrict__ ex, int nmon, int dim, clptr x, lptr phi, lptr D) {
+    for (int j = threadIdx.x; j < nmon; j += blockDim.x) {
+        const int *e = ex + (size_t)j * dim;
+        double p = 1.0;
+        for (int i = 0; i < dim; ++i) {
+            const double xi = x[i];
+            for (int k = 0; k < e[i]; ++k) p *= xi;
+        }
+        phi[j] = p;
+        if (D != nullptr) {
+            for (int i = 0; i < dim; ++i) {
+                double g = 0.0;
+                if (e[i] > 0) {
+                    g = (double)e[i];
+                    for (int l = 0; l < dim; ++l) {
+                        const int pw = e[l] - (l == i ? 1 : 0);
+                        const double xl = x[l];
+                        for (int k = 0; k < pw; ++k) g *= xl;
+                    }
+                }
+                D[(size_t)j * dim + i] = g;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// In-place Gauss-Jordan inverse with partial pivoting of the n x n matrix M (LDS, leading dimension ld);
+// Minv (LDS, ld) receives the inverse.  piv: LDS int scratch (2).  All threads; ends with a sync.
+__device__ inline void inverse(lptr M, lptr Minv, int n, int ld, liptr piv) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < n * n; e += nt) Minv[(e / n) * ld + e % n] = (e / n == e % n) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            int p = k;
+            double best = fabs(M[k * ld + k]);
+            for (int i = k + 1; i < n; ++i) {
+                const double v = fabs(M[i * ld + k]);
+                if (v > best) { best = v; p = i; }
+            }
+            piv[0] = p;
+        }
+        __syncthreads();
+        const int p = piv[0];
+        if (p != k) {
+            for (int j = tid; j < n; j += nt) {
+                double t = M[k * ld + j]; M[k * ld + j] = M[p * ld + j]; M[p * ld + j] = t;
+                t = Minv[k * ld + j]; Minv[k * ld + j] = Minv[p * ld + j]; Minv[p * ld + j] = t;
+            }
+            __syncthreads();
+        }
+        const double d = M[k * ld + k];
+        __syncthreads();
+        for (int j = tid; j < n; j += nt) { M[k * ld + j] = M[k * ld + j] / d; Minv[k * ld + j] = Minv[k * ld + j] / d; }
+        __syncthreads();
+        // eliminate column k from the other rows: thread per (row, col); the multiplier is read before any write
+        // of its column (column k of M is only written by the j == k threads after the barrier below)
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            if (i == k) continue;
+            const double f = M[i * ld + k];
+            Minv[i * ld + j] = fma(-f, Minv[k * ld + j], Minv[i * ld + j]);
+            if (j != k) M[i * ld + j] = fma(-f, M[k * ld + j], M[i * ld + j]);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) if (i != k) M[i * ld + k] = 0.0;
+        __syncthreads();
+    }
+}
+
+struct Work {
+    lptr phi;      // max(nr, ns)
+    lptr D;        // max(nr * n, ns * no)
+    lptr M1, M2, M3;   // n x ld each (discretisation scratch)
+    lptr f;        // n
+    liptr piv;
+};
+
+__host__ __device__ inline size_t work_doubles(int n, int m, int no, int nr, int ns) {
+    const int ld = n | 1;
+    const size_t nb = (size_t)(nr > ns ? nr : ns);
+    const size_t nd = (size_t)nr * n > (size_t)ns * no ? (size_t)nr * n : (size_t)ns * no;
+    return nb + nd + 3 * (size_t)n * ld + n + 4;
+}
+
+__device__ inline void carve(Work &w, lptr base, const SsmDev &S) {
+    const int ld = S.n | 1;
+    const size_t nb = (size_t)(S.nr > S.ns ? S.nr : S.ns);
+    const size_t nd = (size_t)S.nr * S.n > (size_t)S.ns * S.no ? (size_t)S.nr * S.n : (size_t)S.ns * S.no;
+    w.phi = base; w.D = w.phi + nb; w.M1 = w.D + nd; w.M2 = w.M1 + (size_t)S.n * ld; w.M3 = w.M2 + (size_t)S.n * ld;
+    w.f = w.M3 + (size_t)S.n * ld;
+    w.piv = (liptr)(w.f + S.n + 2);
+}
+
+// (A, B, d) of ssm.py:198-218 at (x, u) [LDS]: continuous Jacobians of f = R phi(x) + B u, affine remainder
+// d = f - A x - B u, then discretised per `mode`.  A (n x lda), Bm (n x m), d (n) in LDS.  Ends with a sync.
+__device__ inline void linearize(const SsmDev &S, int mode, double dt, clptr x, clptr u, Work &w, lptr A, int lda,
+                                 lptr Bm, lptr d) {
+    const int n = S.n, m = S.m, tid = threadIdx.x, nt = blockDim.x;
+    const bool dm = mode == SSM_DISCRETE_MAP;
+    cgptr Rc = dm ? S.Rd : S.R, Bg = dm ? S.Bd : S.Bc;
+    basis(S.er, S.nr, n, x, w.phi, w.D);
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e % n;
+        double s = 0.0;
+        for (int k = 0; k < S.nr; ++k) s = fma(Rc[(size_t)i * S.nr + k], w.D[(size_t)k * n + j], s);
+        A[i * lda + j] = s;
+    }
+    for (int e = tid; e < n * m; e += nt) Bm[e] = Bg[e];
+    for (int i = tid; i < n; i += nt) {
+        double s = 0.0;
+        for (int k = 0; k < S.nr; ++k) s = fma(Rc[(size_t)i * S.nr + k], w.phi[k], s);
+        double t = 0.0;
+        for (int k = 0; k < m; ++k) t = fma(Bg[i * m + k], u[k], t);
+        w.f[i] = s + t;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        double ax = 0.0, bu = 0.0;
+        for (int k = 0; k < n; ++k) ax = fma(A[i * lda + k], x[k], ax);
+        for (int k = 0; k < m; ++k) bu = fma(Bm[i * m + k], u[k], bu);
+        d[i] = w.f[i] - ax - bu;
+    }
+    __syncthreads();
+    if (mode == SSM_CONT || dm) return;
+    if (mode == SSM_FE) {                                       // I + dt A, dt B, dt d
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            A[i * lda + j] = (i == j ? 1.0 : 0.0) + dt * A[i * lda + j];
+        }
+        for (int e = tid; e < n * m; e += nt) Bm[e] = dt * Bm[e];
+        for (int e = tid; e < n; e += nt) d[e] = dt * d[e];
+        __syncthreads();
+        return;
+    }
+    // be:  A_d = inv(I - dt A);  bil: A_d = (I + dt/2 A) inv(I - dt/2 A);  sep = inv(A) (A_d - I)
+    const int ld = n | 1;
+    const double h = mode == SSM_BE ? dt : 0.5 * dt;
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e % n;
+        w.M1[i * ld + j] = (i == j ? 1.0 : 0.0) - h * A[i * lda + j];
+        w.M3[i * ld + j] = A[i * lda + j];
+    }
+    __syncthreads();
+    inverse(w.M1, w.M2, n, ld, w.piv);                           // M2 = inv(I - h A)
+    if (mode == SSM_BIL) {
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma((i == k ? 1.0 : 0.0) + h * A[i * lda + k], w.M2[k * ld + j], s);
+            w.M1[i * ld + j] = s;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) w.M2[(e / n) * ld + e % n] = w.M1[(e / n) * ld + e % n];
+        __syncthreads();
+    }
+    inverse(w.M3, w.M1, n, ld, w.piv);                           // M1 = inv(A_c)
+    for (int e = tid; e < n * n; e += nt) {                      // M3 = sep = inv(A_c) (A_d - I)
+        const int i = e / n, j = e % n;
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s = fma(w.M1[i * ld + k], w.M2[k * ld + j] - (k == j ? 1.0 : 0.0), s);
+        w.M3[i * ld + j] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += nt) A[(e / n) * lda + e % n] = w.M2[(e / n) * ld + e % n];
+    for (int i = tid; i < n; i += nt) {
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s = fma(w.M3[i * ld + k], d[k], s);
+        w.f[i] = s;
+    }
+    for (int e = tid; e < n * m; e += nt) {
+        const int i = e / m, j = e % m;
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s = fma(w.M3[i * ld + k], Bm[k * m + j], s);
+        w.M1[i * ld + j] = s;                                    // m <= n assumed for the scratch (checked on host)
+    }
+    __syncthreads();
+    for (int e = tid; e < n * m; e += nt) Bm[e] = w.M1[(e / m) * ld + e % m];
+    for (int e = tid; e < n; e += nt) d[e] = w.f[e];
+    __syncthreads();
+}
+
+// z = C_map(x) = W phi_s(x) (no z_ref); optional observer Jacobian Hj = W Dphi_s (no x n) and c = z - Hj x
+// (ssm.py:220-235).  Ends with a sync.
+__device__ inline void observe(const SsmDev &S, clptr x, Work &w, lptr z, lptr Hj, lptr c) {
+    const int n = S.n, no = S.no, tid = threadIdx.x, nt = blockDim.x;
+    basis(S.es, S.ns, no, x, w.phi, Hj != nullptr ? w.D : (lptr) nullptr);
+    for (int i = tid; i < no; i += nt) {
+        double s = 0.0;
+        for (int k = 0; k < S.ns; ++k) s = fma(S.Wc[(size_t)i * S.ns + k], w.phi[k], s);
+        z[i] = s;
+    }
+    if (Hj != nullptr) {
+        for (int e = tid; e < no * n; e += nt) {
+            const int i = e / n, j = e % n;
+            double s = 0.0;
+            for (int k = 0; k < S.ns; ++k) s = fma(S.Wc[(size_t)i * S.ns + k], w.D[(size_t)k * no + j], s);
+            Hj[e] = s;
+        }
+    }
+    __syncthreads();
+    if (Hj != nullptr && c != nullptr) {
+        for (int i = tid; i < no; i += nt) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s = fma(Hj[i * n + k], x[k], s);
+            c[i] = z[i] - s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace ssm

@@ -149,6 +149,14 @@ class GuSTO:
             A_d.append(A); B_d.append(B); d_d.append(d)
         return A_d, B_d, d_d
 
+    def get_observer_linearizations(self, x, u):
+        """gusto.py:240-251."""
+        H_d, c_d = [], []
+        for i in range(x.shape[0]):
+            H, c = self.model.get_observer_jacobians(x[i, :], None, self.dt)
+            H_d.append(H); c_d.append(c)
+        return H_d, c_d
+
     # ---- solve
     def solve_batch(self, x0, u_init, x_init, z=None, zf=None, u=None):
         """`batch` independent rollouts in one launch: x0 (B,n_x), u_init (B,N,n_u), x_init (B,N+1,n_x),
@@ -204,19 +212,24 @@ class GuSTO:
         self.u_k = u_init
         self.x_k = x_init
         A_d, B_d, d_d = self.get_traj_dynamics(self.x_k, self.u_k)
+        H_d, c_d = self.get_observer_linearizations(self.x_k, self.u_k) if self.nonlinear_observer else (None, None)
         new_solution = True
         Jstar_prev = delta_prev = omega_prev = np.inf
         converged = False
         delta, omega = self.delta0, self.omega0
         while self.is_valid_iteration(itr) and not converged and omega <= self.omega_max:
-            self.locp.update(A_d, B_d, d_d, x0, self.x_k, delta, omega, z=z, zf=zf, u=u, full=new_solution)
+            self.locp.update(A_d, B_d, d_d, x0, self.x_k, delta, omega, z=z, zf=zf, u=u, full=new_solution,
+                             Hd=H_d, cd=c_d)
             new_solution = False
             Jstar, success, stats = self.locp.solve()
             if not success:
                 print('Iteration {} of problem cannot be solved, see solver status for more information'.format(itr))
                 self.xopt = np.copy(self.x_k)
                 self.uopt = np.copy(self.u_k)
-                self.zopt = np.transpose(self.model.H @ self.xopt.T)
+                if self.nonlinear_observer:
+                    self.zopt = self.model.dyn_sys.C_map(self.xopt.T)
+                else:
+                    self.zopt = np.transpose(self.model.H @ self.xopt.T)
                 return
             t_locp += stats.solve_time
             x_next, u_next, _ = self.locp.get_solution()
@@ -244,6 +257,8 @@ class GuSTO:
                 self.u_k = u_next.copy()
                 if self.max_gusto_iters >= 1:
                     A_d, B_d, d_d = self.get_traj_dynamics(self.x_k, self.u_k)
+                    if self.nonlinear_observer:
+                        H_d, c_d = self.get_observer_linearizations(self.x_k, self.u_k)
         if omega > self.omega_max:
             print('omega > omega_max, solution did not converge')
         if not self.is_valid_iteration(itr - 1):

@@ -51,13 +51,14 @@ class LOCP:
         self.verbose = verbose
         self.warm_start = warm_start
         self.nonlinear_observer = kwargs.pop('nonlinear_observer', False)
-        if self.nonlinear_observer:
-            raise NotImplementedError('nonlinear observer maps (SSM models) are not covered by the HIP path yet')
         self.n_x = self.H.shape[1]
         self.n_z = Qz.shape[0]
         self.n_u = R.shape[0]
         self.x_scale = np.ones(self.n_x) if x_char is None else 1. / np.abs(x_char)
         self.tr_active = kwargs.pop('is_tr_active', True)
+        if self.nonlinear_observer:
+            self._init_augmented(N, Qz, R, Qzf, U, X, Xf, dU, kwargs)
+            return
         if kwargs.pop('input_nullspace', None) is not None:
             raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
         self.solver_args = kwargs      # OSQP/GUROBI settings have no meaning here; kept for signature parity
@@ -65,9 +66,54 @@ class LOCP:
         self._data = None
         self._sol = None
 
+    def _init_augmented(self, N, Qz, R, Qzf, U, X, Xf, dU, kwargs):
+        """Nonlinear-observer branch (locp.py:84-88, 231-245, 312-329): z_k = Hd_k x_k + cd_k with per-stage
+        (Hd_k, cd_k).  The kernel's QP has one constant performance matrix, so the stage outputs are carried
+        as extra states: xa_k = [x_k; zeta_k], zeta_{k+1} = Hd_{k+1} (A_k x_k + B_k u_k + d_k) + cd_{k+1},
+        H_a = [0 I], X_a = [0 X.A], Xf_a = [Xf.A 0], zero trust-region scale on zeta -- the same QP in
+        (x, u, s) after eliminating zeta."""
+        from ..utils import Polyhedron
+        if kwargs.pop('input_nullspace', None) is not None:
+            raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
+        if Qzf is not None and np.any(self.H != 0):
+            raise NotImplementedError('terminal cost through a non-zero constant H together with a nonlinear '
+                                      'observer (locp.py:251-252) is not covered')
+        self.solver_args = kwargs
+        n, nz = self.n_x, self.n_z
+        Ha = np.hstack((np.zeros((nz, n)), np.eye(nz)))
+        Xa = None if X is None else Polyhedron(np.hstack((np.zeros((X.A.shape[0], n)), X.A)), X.b)
+        Xfa = None if Xf is None else Polyhedron(np.hstack((Xf.A, np.zeros((Xf.A.shape[0], nz)))), Xf.b)
+        xs = np.concatenate((self.x_scale, np.zeros(nz)))
+        self._prob, self._keep = make_problem(N, Ha, Qz, R, None, U, Xa, Xfa, dU, xs, self.tr_active)
+        self._data = None
+        self._sol = None
+
+    def _update_augmented(self, Ad, Bd, dd, x0, xk, z, u, Hd, cd):
+        N, n, m, nz = self.N, self.n_x, self.n_u, self.n_z
+        Ad = np.asarray(Ad).reshape(N, n, n); Bd = np.asarray(Bd).reshape(N, n, m); dd = np.asarray(dd).reshape(N, n)
+        Hd = np.asarray(Hd).reshape(N + 1, nz, n); cd = np.asarray(cd).reshape(N + 1, nz)
+        na = n + nz
+        Aa = np.zeros((N, na, na)); Ba = np.zeros((N, na, m)); da = np.zeros((N, na))
+        Aa[:, :n, :n] = Ad
+        Aa[:, n:, :n] = np.einsum('kij,kjl->kil', Hd[1:], Ad)
+        Ba[:, :n] = Bd
+        Ba[:, n:] = np.einsum('kij,kjl->kil', Hd[1:], Bd)
+        da[:, :n] = dd
+        da[:, n:] = np.einsum('kij,kj->ki', Hd[1:], dd) + cd[1:]
+        x0 = np.asarray(x0).reshape(n)
+        xk = np.asarray(xk).reshape(N + 1, n)
+        self._data = dict(Ad=_lib.f64(Aa), Bd=_lib.f64(Ba), dd=_lib.f64(da),
+                          x0=_lib.f64(np.concatenate((x0, Hd[0] @ x0 + cd[0]))),
+                          xk=_lib.f64(np.hstack((xk, np.einsum('kij,kj->ki', Hd, xk) + cd))),
+                          z=None if z is None else _lib.f64(np.ravel(z)), zf=None,
+                          u=None if u is None else _lib.f64(np.ravel(u)))
+
     def update(self, Ad, Bd, dd, x0, xk, delta, omega, z=None, zf=None, u=None, full=True, **kwargs):
         """locp.py:98-173.  full=False only changes delta / omega (locp.py:139-141)."""
-        if full or self._data is None:
+        if self.nonlinear_observer and (full or self._data is None):
+            self._zf_const = 0.0 if (self.Qzf is None or zf is None) else float(np.asarray(zf) @ self.Qzf @ np.asarray(zf))
+            self._update_augmented(Ad, Bd, dd, x0, xk, z, u, kwargs.get('Hd'), kwargs.get('cd'))
+        elif full or self._data is None:
             N, n, m = self.N, self.n_x, self.n_u
             self._data = dict(
                 Ad=_lib.f64(np.asarray(Ad).reshape(N, n, n)), Bd=_lib.f64(np.asarray(Bd).reshape(N, n, m)),
@@ -83,6 +129,8 @@ class LOCP:
         """locp.py:175-190: returns (Jstar, success, stats)."""
         d = self._data
         N, n, m = self.N, self.n_x, self.n_u
+        if self.nonlinear_observer:
+            n = n + self.n_z
         x = np.empty((N + 1, n)); u = np.empty((N, m)); s = np.empty(N + 1)
         J = np.empty(1); status = np.empty(1, dtype=np.int32); iters = np.empty(1, dtype=np.int32)
         t0 = time.time()
@@ -94,6 +142,9 @@ class LOCP:
                    'slocp_solve')
         t1 = time.time()
         if status[0] == 0:
+            if self.nonlinear_observer:
+                x = np.ascontiguousarray(x[:, :self.n_x])
+                J[0] += self._zf_const
             self._sol = (x, u, s if self.tr_active else None)
             return float(J[0]), True, _Stats(t1 - t0, int(iters[0]))
         return np.inf, False, None

@@ -28,9 +28,28 @@ def install():
         np.infty = np.inf
 
     def _jit(*a, **k):
-        if a and callable(a[0]) and not k:
+        if a and callable(a[0]):
             return a[0]
         return lambda f: f
+
+    def _jacobian(f, argnums=0):
+        """Stand-in for jax.jacobian on the reference's polynomial maps: complex-step differentiation
+        (exact to rounding for polynomials; jax itself is absent from the build container)."""
+        def run(*args):
+            nums = argnums if isinstance(argnums, (tuple, list)) else (argnums,)
+            outs = []
+            for a in nums:
+                base = np.asarray(args[a], dtype=float)
+                cols = []
+                for j in range(base.shape[0]):
+                    pert = base.astype(complex)
+                    pert[j] += 1e-30j
+                    aa = list(args)
+                    aa[a] = pert
+                    cols.append(np.imag(np.asarray(f(*aa))) / 1e-30)
+                outs.append(np.stack(cols, axis=-1))
+            return tuple(outs) if isinstance(argnums, (tuple, list)) else outs[0]
+        return run
 
     _mod('osqp', OSQP=object)
     _mod('control')
@@ -41,9 +60,12 @@ def install():
     rclpy.node = _mod('rclpy.node', Node=object)
     srr = _mod('soft_robot_control_ros')
     srr.srv = _mod('soft_robot_control_ros.srv', GuSTOsrv=object)
-    jax = _mod('jax', jit=_jit)
-    jax.numpy = _mod('jax.numpy')
-    jax.scipy = _mod('jax.scipy')
+    import scipy.special
+    jax = _mod('jax', jit=_jit, jacobian=_jacobian)
+    # the reference's SSM maps only need dot / asarray / eye / linalg from jax.numpy: alias numpy
+    jax.numpy = _mod('jax.numpy', dot=np.dot, asarray=np.asarray, eye=np.eye, linalg=np.linalg, ndarray=np.ndarray,
+                     array=np.array, zeros=np.zeros)
+    jax.scipy = _mod('jax.scipy', special=scipy.special)
     cp = _mod('cvxpy')
     _mod('cvxpy.atoms')
     _mod('cvxpy.atoms.affine')

@@ -388,6 +388,72 @@ def g9_ekf(out):
     np.savez_compressed(os.path.join(out, 'g9_ekf.npz'), **res)
 
 
+def _mat(v):
+    a = np.empty((1, 1), dtype=object)
+    a[0, 0] = np.asarray(v)
+    return a
+
+
+def ref_ssm(model, discrete=False, discr='fe'):
+    """The reference's SSMDynamics on an oracle.ssm model dict (.mat-style nested arrays, ssm.py:31-52)."""
+    from sofacontrol.SSM import ssm as rssm
+    sc = lambda v: _mat(np.array([[v]]))
+    n, m = model['n'], model['m']
+    ro, so = int(model['Er'].sum(axis=1).max()), int(model['Es'].sum(axis=1).max())
+    params = dict(state_dim=sc(n), input_dim=sc(m), output_dim=sc(n), SSM_order=sc(so), ROM_order=sc(ro))
+    mdl = dict(Ts=sc(0.01), w_coeff=_mat(model['W']), v_coeff=_mat(model['V']), r_coeff=_mat(model['R']),
+               B=_mat(model['B']), rd_coeff=_mat(model['Rd']), Bd=_mat(model['Bd']))
+    return rssm.SSMDynamics(model['z_ref'].copy(), discrete=discrete, discr_method=discr, model=mdl, params=params)
+
+
+def g10_ssm(out):
+    """SSM polynomial model (SSM/ssm.py) -- reference run with numpy for jax.numpy and complex-step
+    differentiation for jax.jacobian (see _ref_import.py)."""
+    from oracle import ssm as ossm
+    from sofacontrol.scp.models.ssm import SSMGuSTO
+    res = {}
+    for tag, (n, m, ro, so) in dict(a=(4, 2, 3, 2), b=(6, 4, 3, 3)).items():
+        model = ossm.synthetic(n, m, ro, so, seed=60 + n)
+        rng = np.random.default_rng(61 + n)
+        X = 0.4 * rng.standard_normal((5, n))
+        Uu = rng.standard_normal((5, m))
+        dt = 0.01
+        s = ref_ssm(model)
+        res[tag + '_X'], res[tag + '_U'] = X, Uu
+        res[tag + '_phi_rom'] = np.stack([np.asarray(s.rom_phi(*x)) for x in X])
+        res[tag + '_phi_ssm'] = np.stack([np.asarray(s.ssm_phi(*x)) for x in X])
+        Ac, Bc, dc = zip(*[s.get_continuous_jacobians(x, u) for x, u in zip(X, Uu)])
+        res[tag + '_Ac'], res[tag + '_Bc'], res[tag + '_dc'] = np.stack(Ac), np.stack(Bc), np.stack(dc)
+        res[tag + '_f'] = np.stack([np.asarray(s.reduced_dynamics(x, u)) for x, u in zip(X, Uu)])
+        Hs, cs = zip(*[s.get_observer_jacobians(x) for x in X])
+        res[tag + '_Hobs'], res[tag + '_cobs'] = np.stack(Hs), np.stack(cs)
+        res[tag + '_zobs'] = np.stack([s.update_observer_state(x) for x in X])
+        res[tag + '_zf'] = s.x_to_zfyf(X)
+        res[tag + '_xred'] = np.stack([np.asarray(s.compute_RO_state(z)) for z in res[tag + '_zf']])
+        uu = rng.standard_normal((6, m))
+        res[tag + '_roll_u'] = uu
+        for meth in ('fe', 'be', 'bil'):
+            sm = ref_ssm(model, discr=meth)
+            A, B, d = zip(*[sm.get_jacobians(x, u, dt) for x, u in zip(X, Uu)])
+            res[tag + '_Ad_' + meth], res[tag + '_Bd_' + meth], res[tag + '_dd_' + meth] = \
+                np.stack(A), np.stack(B), np.stack(d)
+            xr, zr = sm.rollout(X[0], uu, dt)
+            res[tag + '_roll_x_' + meth], res[tag + '_roll_z_' + meth] = xr, zr
+        sd = ref_ssm(model, discrete=True)
+        A, B, d = zip(*[sd.get_jacobians(x, u, dt) for x, u in zip(X, Uu)])
+        res[tag + '_Ad_map'], res[tag + '_Bd_map'], res[tag + '_dd_map'] = np.stack(A), np.stack(B), np.stack(d)
+        xr, zr = sd.rollout(X[0], uu, dt)
+        res[tag + '_roll_x_map'], res[tag + '_roll_z_map'] = xr, zr
+        gm = SSMGuSTO(s)
+        res[tag + '_fc'] = np.stack([gm.get_continuous_dynamics(x, u)[0] for x, u in zip(X, Uu)])
+        try:
+            ref_ssm(model, discr='zoh').get_jacobians(X[0], Uu[0], dt)
+            res[tag + '_zoh_raises'] = np.array(0)
+        except RuntimeError:
+            res[tag + '_zoh_raises'] = np.array(1)
+    np.savez_compressed(os.path.join(out, 'g10_ssm.npz'), **res)
+
+
 class FakeGuSTOClient:
     """Deterministic stand-in for GuSTOClientNode (needs ROS): returns a smooth analytic 'solution'."""
     N, dt_g = 8, 0.05
@@ -468,5 +534,6 @@ def g8_controllers(out):
 
 if __name__ == '__main__':
     g9_ekf(HERE)
+    g10_ssm(HERE)
     g8_controllers(HERE)
     print('g8_controllers.npz', os.path.getsize(os.path.join(HERE, 'g8_controllers.npz')))

@@ -246,3 +246,34 @@ def test_ekf_oracle(golden):
     close(x, g['x_pred'], 1e-10); close(S, g['Sigma_pred'], 1e-10)
     x, S = oobs.update(C, y_ref, x, S, g['y'][1], g['V'])
     close(x, g['x_upd'], 1e-10); close(S, g['Sigma_upd'], 1e-10)
+
+
+# ---------------------------------------------------------------- G10: SSM polynomial model
+@pytest.mark.parametrize('tag,shape', [('a', (4, 2, 3, 2)), ('b', (6, 4, 3, 3))])
+def test_ssm_oracle(golden, tag, shape):
+    from oracle import ssm as ossm
+    g = golden('g10_ssm')
+    n, m, ro, so = shape
+    model = ossm.synthetic(n, m, ro, so, seed=60 + n)
+    X, U = g[tag + '_X'], g[tag + '_U']
+    assert model['Er'].shape[0] == g[tag + '_phi_rom'].shape[1]
+    close(np.stack([ossm.phi(model['Er'], x) for x in X]), g[tag + '_phi_rom'], 1e-14)
+    close(np.stack([ossm.phi(model['Es'], x) for x in X]), g[tag + '_phi_ssm'], 1e-14)
+    A, B, d = zip(*[ossm.continuous_jacobians(model, x, u) for x, u in zip(X, U)])
+    close(np.stack(A), g[tag + '_Ac']); close(np.stack(B), g[tag + '_Bc']); close(np.stack(d), g[tag + '_dc'])
+    close(np.stack([ossm.dynamics(model, x, u) for x, u in zip(X, U)]), g[tag + '_f'])
+    for meth in ('fe', 'be', 'bil'):
+        A, B, d = zip(*[ossm.jacobians(model, x, u, 0.01, meth) for x, u in zip(X, U)])
+        close(np.stack(A), g[tag + '_Ad_' + meth]); close(np.stack(B), g[tag + '_Bd_' + meth])
+        close(np.stack(d), g[tag + '_dd_' + meth])
+        xr, zr = ossm.rollout(model, X[0], g[tag + '_roll_u'], 0.01, meth)
+        close(xr, g[tag + '_roll_x_' + meth]); close(zr, g[tag + '_roll_z_' + meth])
+    A, B, d = zip(*[ossm.jacobians(model, x, u, 0.01, discrete=True) for x, u in zip(X, U)])
+    close(np.stack(A), g[tag + '_Ad_map']); close(np.stack(d), g[tag + '_dd_map'])
+    xr, zr = ossm.rollout(model, X[0], g[tag + '_roll_u'], 0.01, discrete=True)
+    close(xr, g[tag + '_roll_x_map']); close(zr, g[tag + '_roll_z_map'])
+    H, c = zip(*[ossm.observer_jacobians(model, x) for x in X])
+    close(np.stack(H), g[tag + '_Hobs']); close(np.stack(c), g[tag + '_cobs'])
+    close(np.stack([ossm.reduce(model, z) for z in g[tag + '_zf']]), g[tag + '_xred'])
+    with pytest.raises(RuntimeError):
+        ossm.discretize(np.eye(2), np.eye(2), np.ones(2), 0.1, 'zoh')
