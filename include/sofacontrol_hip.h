@@ -231,6 +231,13 @@ int silqr_solve(stpwl_t *h, int N, int64_t batch, const double *x0, const double
                 const double *u_warm, const double *u_last, const double *Q, const double *R,
                 const double *Qf, const silqr_params *p, double *x, double *u, double *K,
                 double *cost, int32_t *iters);
+/* The same on an SSM model: (A_t, B_t, d_t) = SSMDynamics.get_jacobians(x_t, u_t, dt) at every step of every
+ * forward pass (ilqr.py:155), z = C_map(x) + z_ref in the costs, the model's constant H in the cost
+ * Jacobians (ilqr.py:176-184).  mode = SSSM_FE / BE / BIL / DISCRETE_MAP. */
+int silqr_solve_ssm(sssm_t *h, int mode, double dt, int N, int64_t batch, const double *x0,
+                    const double *z_target, const double *u_warm, const double *u_last, const double *Q,
+                    const double *R, const double *Qf, const silqr_params *p, double *x, double *u,
+                    double *K, double *cost, int32_t *iters);
 
 /* =====================================================================================================
  * LOCP (the horizon QP) and GuSTO. reference: sofacontrol/scp/locp.py, sofacontrol/scp/gusto.py

@@ -77,8 +77,17 @@ class ILQR:
         self.z_target = None
         self.trace = []
 
+    def _z(self, x):
+        """model.x_to_zfyf(x, zf=True)."""
+        return self.H @ x + self.z_ref
+
+    def _lin(self, x, u):
+        """model.get_jacobians(x, u=u, dt=dt) (ilqr.py:155)."""
+        i = otpwl.nearest_point(self.model, x)
+        return self.Ad[i], self.Bd[i], self.dd[i]
+
     def _cost_terms(self, x, u, t, u_prev):
-        z = self.H @ x + self.z_ref
+        z = self._z(x)
         dz = z - self.z_target[t]
         du = u - u_prev
         return .5 * dz @ self.Q @ dz + .5 * du @ self.R @ du
@@ -97,10 +106,9 @@ class ILQR:
         for t in range(N):
             u[t] = u_prev[t] + alpha * k[t] + K[t] @ (x[t] - x_prev[t])
             cost += self._cost_terms(x[t], u[t], t, self.u_last if t == 0 else u[t - 1])
-            i = otpwl.nearest_point(self.model, x[t])
-            A[t], B[t], d[t] = self.Ad[i], self.Bd[i], self.dd[i]
+            A[t], B[t], d[t] = self._lin(x[t], u[t])
             x[t + 1] = A[t] @ x[t] + B[t] @ u[t] + d[t]
-        zN = self.H @ x[-1] + self.z_ref
+        zN = self._z(x[-1])
         dz = zN - self.z_target[-1]
         cost += .5 * dz @ self.Qf @ dz
         return x, u, cost, A, B, d
@@ -127,13 +135,13 @@ class ILQR:
         while True:
             Q_u = np.zeros((N, m)); Q_uu = np.zeros((N, m, m))
             K = np.zeros((N, m, n)); k = np.zeros((N, m))
-            zN = H @ x[-1] + self.z_ref
+            zN = self._z(x[-1])
             p = H.T @ self.Qf @ (zN - self.z_target[-1])
             P = H.T @ self.Qf @ H
             restart = False
             for t in reversed(range(N)):
                 u_prev = self.u_last if t == 0 else u[t - 1]
-                z = H @ x[t] + self.z_ref
+                z = self._z(x[t])
                 c_xx = H.T @ self.Q @ H
                 c_x = H.T @ self.Q @ (z - self.z_target[t])
                 c_u = self.R @ (u[t] - u_prev)
@@ -206,3 +214,23 @@ class ILQR:
             it += 1
             self.trace.append((it, cost, alpha))
         return x, u, K
+
+
+class ILQRGeneric(ILQR):
+    """The same loop for any model exposing get_jacobians / x_to_zfyf / H (e.g. the SSM model,
+    sofacontrol/SSM/ssm.py): lin_fn(x, u) -> (A_d, B_d, d_d), out_fn(x) -> z, constant H for the cost Jacobians."""
+
+    def __init__(self, lin_fn, out_fn, H, n, m, Q, R, Qf, N):
+        self.lin_fn, self.out_fn = lin_fn, out_fn
+        self.H, self.Q, self.R, self.Qf, self.N = H, Q, R, Qf, N
+        self.n, self.m = n, m
+        self.p = ILQRParams()
+        self.u_last = np.zeros(m)
+        self.z_target = None
+        self.trace = []
+
+    def _z(self, x):
+        return self.out_fn(x)
+
+    def _lin(self, x, u):
+        return self.lin_fn(x, u)

@@ -2,6 +2,7 @@
 // Reference: sofacontrol/lqr/traj_tracking_lqr.py:18-48 (TV-LQR), sofacontrol/lqr/lqr.py:6-21 (fixed-point
 // DARE), sofacontrol/lqr/ilqr.py:27-300 + sofacontrol/lqr/config.py (iLQR).
 #include "tpwl_host.h"
+#include "ssm_host.h"
 
 namespace {
 
@@ -165,9 +166,15 @@ struct IlqrArgs {
     double *work;          // per problem: x2 (N+1)n, u2 N m, kff N m, Qu N m, Quu N m m, K2 N m n
     int *iwork;            // per problem: idx N, idx2 N
     size_t work_stride;
+    double *lin;           // SSM model only, per problem: 2 x N x (n n + n m + n) per-step (A, B, d)
+    int ssm_mode;          // SSM model only: discretisation mode (ssm_dev.h)
+    double dt;
 };
 
-__global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
+// MODEL 0: prediscretised nearest-neighbour TPWL tables (T); MODEL 1: SSM polynomial model (S), linearised
+// and discretised at every step of the forward pass (ilqr.py:155: model.get_jacobians(x[t], u=u[t], dt)).
+template <int MODEL>
+__global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, n = a.n, m = a.m, nz = a.nz;
     LqrLds L;
@@ -175,6 +182,13 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
     lptr HQH = L.red + 20;                    // placed after the carve: n x n
     lptr zt = HQH + (size_t)n * n;            // nz scratch (16)
     lptr part = zt + 16;                      // blockDim
+    // SSM scratch (MODEL 1): polynomial work space, per-step (A, B, d), observed output
+    ssm::Work sw;
+    lptr Al = part + NT, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m, zs = dl + n, xl = zs + 16;
+    if constexpr (MODEL == 1) ssm::carve(sw, xl + n, S);
+    cgptr Hm = MODEL == 0 ? T.H : S.H;
+    cgptr zref = MODEL == 0 ? T.z_ref : S.z_ref;
+    const size_t lstride = (size_t)n * n + (size_t)n * m + n;
     const size_t p = blockIdx.x;
     const int tid = threadIdx.x, nt = blockDim.x;
     cgptr x0 = (cgptr)a.x0 + p * n, ztar = (cgptr)a.z_target + p * (size_t)(N + 1) * nz;
@@ -186,9 +200,28 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
     gptr Quu = Qu + (size_t)N * m, K2 = Quu + (size_t)N * m * m;
     giptr idx = (giptr)a.iwork + p * 2 * (size_t)N, idx2 = idx + N;
     const silqr_params &P_ = a.par;
+    gptr lin = MODEL == 1 ? (gptr)a.lin + p * 2 * (size_t)N * lstride : (gptr) nullptr;
+    gptr lin2 = MODEL == 1 ? lin + (size_t)N * lstride : (gptr) nullptr;
+
+    // z(x) - z*_t into zt for the state xq (LDS); all threads, ends with a sync
+    auto zerr = [&](clptr xq, int t) {
+        if constexpr (MODEL == 0) {
+            if (tid < nz) {
+                double v = zref[tid] - ztar[(size_t)t * nz + tid];
+                for (int j = 0; j < n; ++j) v = fma(Hm[tid * n + j], xq[j], v);
+                zt[tid] = v;
+            }
+            __syncthreads();
+        } else {
+            ssm::observe(S, xq, sw, zs, (lptr) nullptr, (lptr) nullptr);
+            if (tid < nz) zt[tid] = zs[tid] + zref[tid] - ztar[(size_t)t * nz + tid];
+            __syncthreads();
+        }
+    };
 
     // forward pass (ilqr.py:117-162): from (xp, up) with gains (Kg, kg, alpha) into (xo, uo, io); returns cost
-    auto forward = [&](cgptr xp, cgptr up, double alpha, cgptr Kg, cgptr kg, gptr xo, gptr uo, giptr io) -> double {
+    auto forward = [&](cgptr xp, cgptr up, double alpha, cgptr Kg, cgptr kg, gptr xo, gptr uo, giptr io,
+                       gptr lo) -> double {
         double cost = 0.0;
         for (int e = tid; e < n; e += nt) { L.v1[e] = x0[e]; xo[e] = x0[e]; }
         __syncthreads();
@@ -201,18 +234,24 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
                 L.u1[tid] = v;
                 uo[(size_t)t * m + tid] = v;
             }
-            if (tid >= 64 && tid < 128) {
-                const int i = tpwl::nearest_wave(T, (clptr)L.v1);
-                if (tid == 64) { io[t] = i; *L.flag = i; }
+            if constexpr (MODEL == 0) {
+                if (tid >= 64 && tid < 128) {
+                    const int i = tpwl::nearest_wave(T, (clptr)L.v1);
+                    if (tid == 64) { io[t] = i; *L.flag = i; }
+                }
+                // z - z*  (z = H x + z_ref)
+                if (tid >= 128 && tid < 128 + nz) {
+                    const int r = tid - 128;
+                    double v = zref[r] - ztar[(size_t)t * nz + r];
+                    for (int j = 0; j < n; ++j) v = fma(Hm[r * n + j], L.v1[j], v);
+                    zt[r] = v;
+                }
+                __syncthreads();
+            } else {
+                __syncthreads();
+                zerr((clptr)L.v1, t);
+                ssm::linearize(S, a.ssm_mode, a.dt, (clptr)L.v1, (clptr)L.u1, sw, Al, n, Bl, dl);
             }
-            // z - z*  (z = H x + z_ref)
-            if (tid >= 128 && tid < 128 + nz) {
-                const int r = tid - 128;
-                double v = T.z_ref[r] - ztar[(size_t)t * nz + r];
-                for (int j = 0; j < n; ++j) v = fma(T.H[r * n + j], L.v1[j], v);
-                zt[r] = v;
-            }
-            __syncthreads();
             if (tid == 0) {
                 double c = 0.0;
                 for (int r = 0; r < nz; ++r) for (int s = 0; s < nz; ++s) c += zt[r] * Qg[r * nz + s] * zt[s];
@@ -221,18 +260,27 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
                 for (int r = 0; r < m; ++r) for (int s = 0; s < m; ++s) c += du[r] * Rg[r * m + s] * du[s];
                 cost += 0.5 * c;
             }
-            const size_t i = (size_t)*L.flag;
-            wg::matTvec(L.v2, T.AdT + i * n * n, n, n, n, (clptr)L.v1, T.dd + i * n, part);
-            wg::matTvec(L.v2, T.BdT + i * m * n, n, m, n, (clptr)L.u1, (clptr)L.v2, part);
+            if constexpr (MODEL == 0) {
+                const size_t i = (size_t)*L.flag;
+                wg::matTvec(L.v2, T.AdT + i * n * n, n, n, n, (clptr)L.v1, T.dd + i * n, part);
+                wg::matTvec(L.v2, T.BdT + i * m * n, n, m, n, (clptr)L.u1, (clptr)L.v2, part);
+            } else {
+                gptr lt = lo + (size_t)t * lstride;
+                for (int e = tid; e < n * n; e += nt) lt[e] = Al[e];
+                for (int e = tid; e < n * m; e += nt) lt[(size_t)n * n + e] = Bl[e];
+                for (int e = tid; e < n; e += nt) lt[(size_t)n * n + (size_t)n * m + e] = dl[e];
+                for (int i = tid; i < n; i += nt) {
+                    double ax = 0.0, bu = 0.0;
+                    for (int j = 0; j < n; ++j) ax = fma(Al[i * n + j], L.v1[j], ax);
+                    for (int j = 0; j < m; ++j) bu = fma(Bl[i * m + j], L.u1[j], bu);
+                    L.v2[i] = ax + bu + dl[i];
+                }
+                __syncthreads();
+            }
             for (int e = tid; e < n; e += nt) { L.v1[e] = L.v2[e]; xo[(size_t)(t + 1) * n + e] = L.v2[e]; }
             __syncthreads();
         }
-        if (tid < nz) {
-            double v = T.z_ref[tid] - ztar[(size_t)N * nz + tid];
-            for (int j = 0; j < n; ++j) v = fma(T.H[tid * n + j], L.v1[j], v);
-            zt[tid] = v;
-        }
-        __syncthreads();
+        zerr((clptr)L.v1, N);
         if (tid == 0) {
             double c = 0.0;
             for (int r = 0; r < nz; ++r) for (int s = 0; s < nz; ++s) c += zt[r] * Qfg[r * nz + s] * zt[s];
@@ -263,40 +311,40 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
     auto backward = [&]() {
         while (true) {
             // terminal: p = H^T Qf (z - z*), P = H^T Qf H
-            if (tid < nz) {
-                double v = T.z_ref[tid] - ztar[(size_t)N * nz + tid];
-                for (int j = 0; j < n; ++j) v = fma(T.H[tid * n + j], X[(size_t)N * n + j], v);
-                zt[tid] = v;
-            }
+            for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)N * n + e];
             __syncthreads();
+            zerr((clptr)xl, N);
             for (int e = tid; e < n * n; e += nt) {
                 const int r = e / n, c = e - r * n;
                 double v = 0.0, hq = 0.0;
                 for (int s = 0; s < nz; ++s) {
                     double q1 = 0.0, q2 = 0.0;
-                    for (int s2 = 0; s2 < nz; ++s2) { q1 = fma(Qfg[s * nz + s2], T.H[s2 * n + c], q1); q2 = fma(Qg[s * nz + s2], T.H[s2 * n + c], q2); }
-                    v = fma(T.H[s * n + r], q1, v);
-                    hq = fma(T.H[s * n + r], q2, hq);
+                    for (int s2 = 0; s2 < nz; ++s2) { q1 = fma(Qfg[s * nz + s2], Hm[s2 * n + c], q1); q2 = fma(Qg[s * nz + s2], Hm[s2 * n + c], q2); }
+                    v = fma(Hm[s * n + r], q1, v);
+                    hq = fma(Hm[s * n + r], q2, hq);
                 }
                 L.P[e] = v;
                 HQH[e] = hq;
             }
             for (int e = tid; e < n; e += nt) {
                 double v = 0.0;
-                for (int s = 0; s < nz; ++s) { double q1 = 0.0; for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qfg[s * nz + s2], zt[s2], q1); v = fma(T.H[s * n + e], q1, v); }
+                for (int s = 0; s < nz; ++s) { double q1 = 0.0; for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qfg[s * nz + s2], zt[s2], q1); v = fma(Hm[s * n + e], q1, v); }
                 L.v1[e] = v;     // p
             }
             __syncthreads();
             bool restart = false;
             for (int t = N - 1; t >= 0; --t) {
-                const size_t i = (size_t)idx[t];
-                cgptr At = T.Ad + i * n * n, Bt = T.Bd + i * n * m;
-                // c_x = H^T Q (z - z*), c_u = R (u_t - u_{t-1})
-                if (tid < nz) {
-                    double v = T.z_ref[tid] - ztar[(size_t)t * nz + tid];
-                    for (int j = 0; j < n; ++j) v = fma(T.H[tid * n + j], X[(size_t)t * n + j], v);
-                    zt[tid] = v;
+                cgptr At, Bt;
+                if constexpr (MODEL == 0) {
+                    const size_t i = (size_t)idx[t];
+                    At = T.Ad + i * n * n; Bt = T.Bd + i * n * m;
+                } else {
+                    At = (cgptr)lin + (size_t)t * lstride; Bt = At + (size_t)n * n;
                 }
+                // c_x = H^T Q (z - z*), c_u = R (u_t - u_{t-1})
+                for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)t * n + e];
+                __syncthreads();
+                zerr((clptr)xl, t);
                 if (tid >= 64 && tid < 64 + m) {
                     const int r = tid - 64;
                     double v = 0.0;
@@ -328,7 +376,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
                 for (int e = tid; e < n + m; e += nt) {
                     if (e < n) {
                         double v = 0.0;
-                        for (int s = 0; s < nz; ++s) { double q1 = 0.0; for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qg[s * nz + s2], zt[s2], q1); v = fma(T.H[s * n + e], q1, v); }
+                        for (int s = 0; s < nz; ++s) { double q1 = 0.0; for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qg[s * nz + s2], zt[s2], q1); v = fma(Hm[s * n + e], q1, v); }
                         for (int k = 0; k < n; ++k) v = fma(At[k * n + e], L.v1[k], v);
                         L.v2[e] = v;
                     } else {
@@ -401,7 +449,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
     for (int e = tid; e < (N + 1) * n; e += nt) X2[e] = (e < n) ? x0[e] : 0.0;
     for (int e = tid; e < N * m; e += nt) U2[e] = a.u_warm ? a.u_warm[p * (size_t)N * m + e] : 0.0;
     __syncthreads();
-    double cost = forward((cgptr)X2, (cgptr)U2, 1.0, (cgptr)nullptr, (cgptr)nullptr, X, U, idx);
+    double cost = forward((cgptr)X2, (cgptr)U2, 1.0, (cgptr)nullptr, (cgptr)nullptr, X, U, idx, lin);
     int failed_counter = 0, it = 0;
     bool converged = false;
     while (!converged && it <= P_.max_iter) {
@@ -411,7 +459,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
         bool improved = false, failed = false;
         while (!improved && !failed) {
             improved = true;
-            new_cost = forward((cgptr)X, (cgptr)U, alpha, (cgptr)Kout, (cgptr)kff, X2, U2, idx2);
+            new_cost = forward((cgptr)X, (cgptr)U, alpha, (cgptr)Kout, (cgptr)kff, X2, U2, idx2, lin2);
             double dc = 0.0;
             for (int t = tid; t < N; t += nt) {
                 double s1 = 0.0, s2 = 0.0;
@@ -439,7 +487,11 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, IlqrArgs a) {
             __syncthreads();
             for (int e = tid; e < (N + 1) * n; e += nt) X[e] = X2[e];
             for (int e = tid; e < N * m; e += nt) U[e] = U2[e];
-            for (int e = tid; e < N; e += nt) idx[e] = idx2[e];
+            if constexpr (MODEL == 0) {
+                for (int e = tid; e < N; e += nt) idx[e] = idx2[e];
+            } else {
+                gptr tmp = lin; lin = lin2; lin2 = tmp;
+            }
             __syncthreads();
             cost = new_cost;
             converged = ((prev_cost - cost) < P_.epsilon) && ((prev_cost - cost) >= 0.0);
@@ -531,19 +583,18 @@ int sric_dare_fixed_point(const double *A, const double *B, int64_t batch, int n
     return SRH_OK;
 }
 
-int silqr_solve(stpwl_t *h, int N, int64_t batch, const double *x0, const double *z_target, const double *u_warm,
-                const double *u_last, const double *Q, const double *R, const double *Qf, const silqr_params *p,
-                double *x, double *u, double *K, double *cost, int32_t *iters) {
-    SRH_REQUIRE(h && x0 && z_target && Q && R && Qf && x && u && K, "silqr_solve: null argument");
-    SRH_REQUIRE(h->has_discrete, "silqr_solve: model has not been pre-discretised");
-    SRH_REQUIRE(h->nz > 0, "silqr_solve: Need to set output or meas. model");
-    SRH_REQUIRE(N > 0 && batch > 0, "silqr_solve: bad dimensions");
-    const int n = h->n, m = h->m, nz = h->nz;
+static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, int64_t batch, const double *x0,
+                     const double *z_target, const double *u_warm, const double *u_last, const double *Q,
+                     const double *R, const double *Qf, const silqr_params *p, double *x, double *u, double *K,
+                     double *cost, int32_t *iters) {
+    const int n = ht ? ht->n : hs->n, m = ht ? ht->m : hs->m, nz = ht ? ht->nz : hs->no;
+    SRH_REQUIRE(nz <= 16 && m <= 16, "silqr_solve: n_z and n_u must be <= 16");
     silqr_params par;
     if (p) par = *p; else silqr_default_params(&par);
-    srh::DevBuf d0, dz, duw, dul, dQ, dR, dQf, ox, ou, oK, oc, oi, work, iwork;
+    srh::DevBuf d0, dz, duw, dul, dQ, dR, dQf, ox, ou, oK, oc, oi, work, iwork, lin;
     int rc;
     const size_t stride = (size_t)(N + 1) * n + (size_t)N * m * 3 + (size_t)N * m * m + (size_t)N * m * n + 8;
+    const size_t lstride = (size_t)n * n + (size_t)n * m + n;
     if ((rc = d0.upload(x0, sizeof(double) * batch * n)) || (rc = dz.upload(z_target, sizeof(double) * batch * (N + 1) * nz)) ||
         (rc = dQ.upload(Q, sizeof(double) * nz * nz)) || (rc = dR.upload(R, sizeof(double) * m * m)) ||
         (rc = dQf.upload(Qf, sizeof(double) * nz * nz)) || (rc = ox.alloc(sizeof(double) * batch * (N + 1) * n)) ||
@@ -551,15 +602,23 @@ int silqr_solve(stpwl_t *h, int N, int64_t batch, const double *x0, const double
         (rc = oc.alloc(sizeof(double) * batch)) || (rc = oi.alloc(sizeof(int32_t) * batch)) ||
         (rc = work.alloc(sizeof(double) * stride * batch)) || (rc = iwork.alloc(sizeof(int32_t) * 2 * N * batch)))
         return rc;
+    if (hs && (rc = lin.alloc(sizeof(double) * 2 * N * lstride * batch))) return rc;
     if (u_warm && (rc = duw.upload(u_warm, sizeof(double) * batch * N * m))) return rc;
     if (u_last && (rc = dul.upload(u_last, sizeof(double) * batch * m))) return rc;
     IlqrArgs a{N, n, m, nz, par, d0.as<double>(), dz.as<double>(), u_warm ? duw.as<double>() : nullptr,
                u_last ? dul.as<double>() : nullptr, dQ.as<double>(), dR.as<double>(), dQf.as<double>(), ox.as<double>(),
-               ou.as<double>(), oK.as<double>(), oc.as<double>(), oi.as<int>(), work.as<double>(), iwork.as<int>(), stride};
-    const size_t lds = (lqr_lds_doubles(n, m) + 20 + (size_t)n * n + 16 + NT) * sizeof(double);
+               ou.as<double>(), oK.as<double>(), oc.as<double>(), oi.as<int>(), work.as<double>(), iwork.as<int>(), stride,
+               hs ? lin.as<double>() : nullptr, ssm_mode, dt};
+    size_t lds = (lqr_lds_doubles(n, m) + 20 + (size_t)n * n + 16 + NT + lstride + 16 + n) * sizeof(double);
+    if (hs) lds += sizeof(double) * ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns);
     SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
-    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ilqr_kernel<<<(unsigned)batch, NT, lds>>>(h->view(), a);
+    if (ht) {
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ilqr_kernel<0><<<(unsigned)batch, NT, lds>>>(ht->view(), SsmDev{}, a);
+    } else {
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ilqr_kernel<1><<<(unsigned)batch, NT, lds>>>(TpwlDev{}, hs->view(), a);
+    }
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipDeviceSynchronize());
     if ((rc = ox.download(x, sizeof(double) * batch * (N + 1) * n)) || (rc = ou.download(u, sizeof(double) * batch * N * m)) ||
@@ -568,6 +627,27 @@ int silqr_solve(stpwl_t *h, int N, int64_t batch, const double *x0, const double
     if (cost && (rc = oc.download(cost, sizeof(double) * batch))) return rc;
     if (iters && (rc = oi.download(iters, sizeof(int32_t) * batch))) return rc;
     return SRH_OK;
+}
+
+int silqr_solve(stpwl_t *h, int N, int64_t batch, const double *x0, const double *z_target, const double *u_warm,
+                const double *u_last, const double *Q, const double *R, const double *Qf, const silqr_params *p,
+                double *x, double *u, double *K, double *cost, int32_t *iters) {
+    SRH_REQUIRE(h && x0 && z_target && Q && R && Qf && x && u && K, "silqr_solve: null argument");
+    SRH_REQUIRE(h->has_discrete, "silqr_solve: model has not been pre-discretised");
+    SRH_REQUIRE(h->nz > 0, "silqr_solve: Need to set output or meas. model");
+    SRH_REQUIRE(N > 0 && batch > 0, "silqr_solve: bad dimensions");
+    return ilqr_impl(h, nullptr, 0, 0.0, N, batch, x0, z_target, u_warm, u_last, Q, R, Qf, p, x, u, K, cost, iters);
+}
+
+int silqr_solve_ssm(sssm_t *h, int mode, double dt, int N, int64_t batch, const double *x0, const double *z_target,
+                    const double *u_warm, const double *u_last, const double *Q, const double *R, const double *Qf,
+                    const silqr_params *p, double *x, double *u, double *K, double *cost, int32_t *iters) {
+    SRH_REQUIRE(h && x0 && z_target && Q && R && Qf && x && u && K, "silqr_solve_ssm: null argument");
+    SRH_REQUIRE(mode >= SSM_FE && mode <= SSM_DISCRETE_MAP, "self.discr_method must be in [fe, be, bil, zoh]");
+    SRH_REQUIRE(mode != SSM_DISCRETE_MAP || h->has_discrete, "silqr_solve_ssm: model has no discrete map");
+    SRH_REQUIRE(h->n == h->no, "silqr_solve_ssm: the reduced -> observed map needs n_x == n_o");
+    SRH_REQUIRE(N > 0 && batch > 0, "silqr_solve_ssm: bad dimensions");
+    return ilqr_impl(nullptr, h, mode, dt, N, batch, x0, z_target, u_warm, u_last, Q, R, Qf, p, x, u, K, cost, iters);
 }
 
 }  // extern "C"

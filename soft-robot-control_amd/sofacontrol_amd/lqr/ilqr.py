@@ -39,7 +39,10 @@ class iLQR:
 
     def ilqr_computation(self, x0, u_warmstart=None):
         """ilqr.py:27-107; batched when x0 is (B, n_x) (z_target (B, N+1, n_z), u_warmstart (B, N, n_u))."""
-        self.model._ensure_discrete(self.dt)
+        from ..SSM.ssm import SSM
+        is_ssm = isinstance(self.model, SSM)
+        if not is_ssm:
+            self.model._ensure_discrete(self.dt)
         N, n, m = self.planning_horizon, self.state_dim, self.input_dim
         x0a = _lib.f64(np.atleast_2d(x0))
         Bn = x0a.shape[0]
@@ -51,6 +54,17 @@ class iLQR:
         cost = np.empty(Bn); iters = np.empty(Bn, dtype=np.int32)
         par = self._params()
         cp = self.cost_params
+        if is_ssm:
+            # the model's bookkeeping H (zeros unless the user set it, ssm.py:69-70) enters the cost Jacobians
+            _lib.check(_lib.lib().sssm_set_output(self.model.handle, _lib.dptr(_lib.f64(self.model.H))), 'sssm_set_output')
+            _lib.check(_lib.lib().silqr_solve_ssm(self.model.handle, C.c_int(self.model._mode()), C.c_double(self.dt),
+                                                  C.c_int(N), C.c_int64(Bn), _lib.dptr(x0a), _lib.dptr(zt),
+                                                  _lib.dptr(uw), _lib.dptr(ul), _lib.dptr(_lib.f64(cp.Q)),
+                                                  _lib.dptr(_lib.f64(cp.R)), _lib.dptr(_lib.f64(cp.Qf)), C.byref(par),
+                                                  _lib.dptr(x), _lib.dptr(u), _lib.dptr(K), _lib.dptr(cost),
+                                                  _lib.iptr(iters)), 'silqr_solve_ssm')
+            self.cost, self.iters = cost, iters
+            return (x[0], u[0], K[0]) if single else (x, u, K)
         _lib.check(_lib.lib().silqr_solve(self.model.handle, C.c_int(N), C.c_int64(Bn), _lib.dptr(x0a), _lib.dptr(zt),
                                           _lib.dptr(uw), _lib.dptr(ul), _lib.dptr(_lib.f64(cp.Q)), _lib.dptr(_lib.f64(cp.R)),
                                           _lib.dptr(_lib.f64(cp.Qf)), C.byref(par), _lib.dptr(x), _lib.dptr(u),

@@ -454,6 +454,38 @@ def g10_ssm(out):
     np.savez_compressed(os.path.join(out, 'g10_ssm.npz'), **res)
 
 
+def g11_ilqr_ssm(out):
+    """iLQR (lqr/ilqr.py) over the reference's SSMDynamics (C3 shape family: SSM model, long horizon), with the
+    model's default H = 0 (ssm.py:69-70) and with H set to the linear part of the observer map."""
+    from oracle import ssm as ossm
+    res = {}
+    n, m = 6, 4
+    model = ossm.synthetic(n, m, 3, 3, seed=90)
+    rng = np.random.default_rng(91)
+    dt = 0.01
+    for tag, (meth, N, useH) in dict(h0=('be', 20, False), hw=('be', 40, True), fe=('fe', 25, True)).items():
+        s = ref_ssm(model, discr=meth)
+        if useH:
+            s.H = model['W'][:, :n].copy()
+        Qz = np.diag([100., 100., 10., 0., 0., 1.])
+        cost = rutils.QuadraticCost(Q=Qz, R=0.05 * np.eye(m), Qf=5 * Qz)
+        il = rilqr.iLQR(dt, s, cost, N)
+        th = np.linspace(0, 2 * np.pi * N / 60., N + 1)
+        zt = np.zeros((N + 1, n))
+        zt[:, 0] = 0.3 * np.sin(th)
+        zt[:, 1] = 0.2 * (1 - np.cos(th))
+        zt = zt + model['z_ref']
+        il.set_target(zt)
+        x0 = 0.05 * rng.standard_normal(n)
+        uw = 0.1 * rng.standard_normal((N, m))
+        (xs, us, Ks), log = quiet(il.ilqr_computation, x0, uw)
+        res[tag + '_z_target'], res[tag + '_x0'], res[tag + '_uw'] = zt, x0, uw
+        res[tag + '_x'], res[tag + '_u'], res[tag + '_K'] = xs, us, Ks
+        res[tag + '_iters'] = np.array(log.count('Iteration'))
+        res[tag + '_Qz'] = Qz
+    np.savez_compressed(os.path.join(out, 'g11_ilqr_ssm.npz'), **res)
+
+
 class FakeGuSTOClient:
     """Deterministic stand-in for GuSTOClientNode (needs ROS): returns a smooth analytic 'solution'."""
     N, dt_g = 8, 0.05
@@ -535,5 +567,6 @@ def g8_controllers(out):
 if __name__ == '__main__':
     g9_ekf(HERE)
     g10_ssm(HERE)
+    g11_ilqr_ssm(HERE)
     g8_controllers(HERE)
     print('g8_controllers.npz', os.path.getsize(os.path.join(HERE, 'g8_controllers.npz')))

@@ -277,3 +277,22 @@ def test_ssm_oracle(golden, tag, shape):
     close(np.stack([ossm.reduce(model, z) for z in g[tag + '_zf']]), g[tag + '_xred'])
     with pytest.raises(RuntimeError):
         ossm.discretize(np.eye(2), np.eye(2), np.ones(2), 0.1, 'zoh')
+
+
+# ---------------------------------------------------------------- G11: iLQR over the SSM model
+ILQR_SSM_CASES = dict(h0=('be', 20, False), hw=('be', 40, True), fe=('fe', 25, True))
+
+
+@pytest.mark.parametrize('tag', sorted(ILQR_SSM_CASES))
+def test_ilqr_ssm_oracle(golden, tag):
+    from oracle import ssm as ossm, lqr as olqr
+    g = golden('g11_ilqr_ssm')
+    meth, N, useH = ILQR_SSM_CASES[tag]
+    model = ossm.synthetic(6, 4, 3, 3, seed=90)
+    H = model['W'][:, :6] if useH else np.zeros((6, 6))
+    Qz = g[tag + '_Qz']
+    il = olqr.ILQRGeneric(lambda x, u: ossm.jacobians(model, x, u, 0.01, meth),
+                          lambda x: ossm.observe(model, x) + model['z_ref'], H, 6, 4, Qz, 0.05 * np.eye(4), 5 * Qz, N)
+    x, u, K = il.solve(g[tag + '_x0'], g[tag + '_z_target'], g[tag + '_uw'])
+    assert len(il.trace) - 1 == int(g[tag + '_iters'])
+    close(x, g[tag + '_x'], 1e-10); close(u, g[tag + '_u'], 1e-9); close(K, g[tag + '_K'], 1e-8)
