@@ -98,6 +98,81 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
                 pod_projection_gbs=proj_gbs)
 
 
+def secondary(L, _lib, rank, world, dist):
+    """Secondary metrics of SURVEY.md section 8(d), measured outside the timed region of the headline metric:
+    C3 iLQR iterations/s (SSM r=10, n_u=8, horizon 100), C4 per-GPU share of the snapshot Gramian (10 000
+    snapshots x 50 000/8 DoF) in TFLOP/s plus the RCCL all-reduce of the Gramian when world > 1."""
+    from oracle import ssm as ossm          # seeded synthetic model generator only (data, not compute)
+    from sofacontrol_amd.SSM.ssm import SSMDynamics
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    out = {}
+    # ---- C3
+    n, m, N, dt, Bn = 10, 8, 100, 0.01, 256
+    model = ossm.synthetic(n, m, 3, 2, seed=95)
+
+    def mat(v):
+        a = np.empty((1, 1), dtype=object); a[0, 0] = np.asarray(v); return a
+    sc = lambda v: mat(np.array([[v]]))
+    s = SSMDynamics(model['z_ref'].copy(), discrete=False, discr_method='fe',
+                    model=dict(Ts=sc(dt), w_coeff=mat(model['W']), v_coeff=mat(model['V']), r_coeff=mat(model['R']),
+                               B=mat(model['B']), rd_coeff=mat(model['Rd']), Bd=mat(model['Bd'])),
+                    params=dict(state_dim=sc(n), input_dim=sc(m), output_dim=sc(n), SSM_order=sc(2), ROM_order=sc(3)))
+    s.H = model['W'][:, :n].copy()
+    Qz = np.diag([100.] * 3 + [1.] * 7)
+    rng = np.random.default_rng(2 + rank)
+    x0 = 0.05 * rng.standard_normal((Bn, n))
+    th = np.linspace(0, 2 * np.pi, N + 1)
+    zt = np.zeros((Bn, N + 1, n))
+    zt[:, :, 0] = 0.1 * np.sin(th)[None, :] * (1 + np.arange(Bn)[:, None] / Bn)
+    zt[:, :, 1] = 0.1 * (1 - np.cos(th))[None, :]
+    zt = zt + model['z_ref']
+    il = iLQR(dt, s, QuadraticCost(Q=Qz, R=np.eye(m), Qf=Qz), N)
+    il.set_target(zt)
+    il.ilqr_computation(x0)
+    t0 = time.perf_counter()
+    il.ilqr_computation(x0)
+    t = time.perf_counter() - t0
+    out['ilqr_c3'] = {'workload': 'C3 shape: SSM n_x=10 (285 monomials), n_u=8, horizon 100, %d problems, host buffers '
+                                  '(PCIe copies inside the time)' % Bn,
+                      'iterations_per_s': float(il.iters.sum()) / t, 'ms': t * 1e3, 'iterations': int(il.iters.sum())}
+    # ---- C4 (per-GPU column shard)
+    n_s, n_f = 10000, 50000 // 8
+    S = np.random.default_rng(7 + rank).standard_normal((n_s, n_f))
+    dS = _lib.DeviceBuffer.from_array(S)
+    del S
+    if dist is not None:
+        import torch
+        G = torch.empty((n_s, n_s), dtype=torch.float64, device='cuda')
+        gptr = C.c_void_p(G.data_ptr())
+    else:
+        dG = _lib.DeviceBuffer(n_s * n_s * 8)
+        gptr = dG.ptr
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.srh_event_create(C.byref(e0)); L.srh_event_create(C.byref(e1))
+    _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), gptr, None), 'gramian')
+    _lib.sync()
+    L.srh_event_record(e0, None)
+    _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), gptr, None), 'gramian')
+    L.srh_event_record(e1, None)
+    _lib.sync()
+    ms = C.c_float()
+    L.srh_event_elapsed_ms(e0, e1, C.byref(ms))
+    flop = float(n_s) * (n_s + 128) * n_f          # executed: upper triangle of 128 x 128 tiles, 2 flop per MAC
+    out['gramian_c4'] = {'workload': 'C4 per-GPU shard: S %d x %d f64, G = S S^T' % (n_s, n_f), 'ms': ms.value,
+                         'tflops_executed': flop / (ms.value * 1e-3) / 1e12,
+                         'frac_of_f64_mfma_peak': flop / (ms.value * 1e-3) / 1e12 / 78.6}
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        dist.all_reduce(G)
+        torch.cuda.synchronize()
+        out['gramian_c4']['allreduce_ms'] = (time.perf_counter() - t0) * 1e3
+        out['gramian_c4']['allreduce_bytes'] = n_s * n_s * 8
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -109,6 +184,7 @@ def main():
     ap.add_argument('--max-gusto-iters', type=int, default=5,
                     help='GuSTO iteration cap per solve (the reference default is 500; its real-time drivers use 0-5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary metrics (iLQR C3, Gramian C4)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -209,6 +285,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         total_iters = float(t[1])
+    sec = None
+    if not args.no_secondary:
+        for b in list(d.values()) + list(o.values()) + [dX, dXr]:
+            b.free()
+        try:
+            sec = secondary(L, _lib, rank, world, dist)
+        except Exception as exc:      # never lose the headline line to a secondary measurement
+            sec = {'error': repr(exc)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -242,6 +326,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=min(R_, 24), proj_rows=4096,
                                            max_iters=args.max_gusto_iters)
+    if sec is not None:
+        out['secondary'] = sec
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
