@@ -23,11 +23,12 @@ def _hip_local_gramian(S_shard):
     return gramian(S_shard)
 
 
-def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian=None, local_modes=None):
+def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian=None, local_modes=None,
+                           local_eigh=None):
     """Distributed method-of-snapshots POD.
 
     S_shard: this rank's (n_s x n_f_local) block of snapshot columns (numpy).  Returns
-    (U_local (n_f_local x k), k, Sigma).  `local_gramian` / `local_modes` default to the HIP kernels; the
+    (U_local (n_f_local x k), k, Sigma).  `local_gramian` / `local_eigh` / `local_modes` default to the device; the
     CPU (gloo) tests inject numpy stand-ins to exercise the sharding / reduction logic without a GPU."""
     import torch
     import torch.distributed as dist
@@ -41,7 +42,7 @@ def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)      # the one exchange step of the path
         G = t.cpu().numpy()
-    Wk, k, Sigma = _pod.modes_from_gramian(None, G, tol, rom_dim)
+    Wk, k, Sigma = _pod.modes_from_gramian(None, G, tol, rom_dim, eigh=local_eigh)
     if local_modes is not None:
         U_local = local_modes(S_shard, Wk)
     else:

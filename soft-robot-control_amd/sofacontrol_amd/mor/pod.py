@@ -175,13 +175,20 @@ def gramian(S_rows):
     return G
 
 
-def modes_from_gramian(S_rows, G, tol, rom_dim=None):
-    """Method of snapshots: eig(G) = Sigma^2, U = S^T W Sigma^-1.  The n_s x n_s symmetric eigenproblem
-    is solved by LAPACK on the host (O(n_s^3), the Gramian that feeds it is O(n_s^2 n_f) on the GPU)."""
-    w, W = np.linalg.eigh(G)
-    order = np.argsort(w)[::-1]
-    w = np.maximum(w[order], 0.0)
-    W = W[:, order]
+def _device_eigh(G):
+    """(w ascending, W with eigenvectors as columns) of the symmetric G through srom_eigh_dev."""
+    n_s = G.shape[0]
+    dG, dw = _lib.DeviceBuffer.from_array(np.ascontiguousarray(G, dtype=np.float64)), _lib.DeviceBuffer(n_s * 8)
+    _lib.check(_lib.lib().srom_eigh_dev(dG.ptr, C.c_int64(n_s), dw.ptr, None), 'srom_eigh_dev')
+    return dw.to_array((n_s,)), dG.to_array((n_s, n_s)).T
+
+
+def modes_from_gramian(S_rows, G, tol, rom_dim=None, eigh=None):
+    """Method of snapshots for a Gramian that is already on the host (e.g. after the all-reduce of the
+    column-sharded build): eig(G) = Sigma^2 by the device eigensolver, W_k = leading eigenvectors / Sigma."""
+    w, W = (eigh or _device_eigh)(G)
+    w = np.maximum(w[::-1], 0.0)
+    W = W[:, ::-1]
     Sigma = np.sqrt(w)
     k = energy_truncation(Sigma, tol) if rom_dim is None else int(rom_dim)
     Wk = np.ascontiguousarray(W[:, :k] / Sigma[:k])
@@ -196,12 +203,20 @@ def compute_POD(snapshots, tol, rom_dim=None):
     the kept modes are recovered (U = S^T W Sigma^-1)."""
     S_rows = np.ascontiguousarray(np.asarray(snapshots, dtype=np.float64).T)
     n_s, n_f = S_rows.shape
-    G = gramian(S_rows)
-    Wk, k, Sigma = modes_from_gramian(S_rows, G, tol, rom_dim)
-    dS, dW = _lib.DeviceBuffer.from_array(S_rows), _lib.DeviceBuffer.from_array(Wk)
-    dU = _lib.DeviceBuffer(n_f * k * 8)
-    _lib.check(_lib.lib().srom_modes_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), dW.ptr, C.c_int(k),
-                                         dU.ptr, None), 'srom_modes_dev')
+    L = _lib.lib()
+    # everything stays in HBM: Gramian (MFMA kernel) -> eigh (rocSOLVER) -> mode selection -> U = S^T W Sigma^-1;
+    # only the n_s eigenvalues cross to the host for the energy truncation
+    dS = _lib.DeviceBuffer.from_array(S_rows)
+    dG, dw = _lib.DeviceBuffer(n_s * n_s * 8), _lib.DeviceBuffer(n_s * 8)
+    _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), dG.ptr, None), 'srom_gramian_dev')
+    _lib.check(L.srom_eigh_dev(dG.ptr, C.c_int64(n_s), dw.ptr, None), 'srom_eigh_dev')
+    w = dw.to_array((n_s,))
+    Sigma = np.sqrt(np.maximum(w[::-1], 0.0))
+    k = energy_truncation(Sigma, tol) if rom_dim is None else int(rom_dim)
+    dW, dU = _lib.DeviceBuffer(n_s * k * 8), _lib.DeviceBuffer(n_f * k * 8)
+    _lib.check(L.srom_select_modes_dev(dG.ptr, dw.ptr, C.c_int64(n_s), C.c_int(k), dW.ptr, None), 'srom_select_modes_dev')
+    _lib.check(L.srom_modes_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), dW.ptr, C.c_int(k),
+                                dU.ptr, None), 'srom_modes_dev')
     _lib.sync()
     U = dU.to_array((n_f, k))
     return None, U, k, Sigma[:min(n_s, n_f)]

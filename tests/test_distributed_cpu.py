@@ -27,7 +27,7 @@ def _worker(rank, world, port, S, tol, out):
     from sofacontrol_amd.distributed import pod_from_column_shards, shard_range
     lo, hi = shard_range(S.shape[1], rank, world)
     U_loc, k, Sig = pod_from_column_shards(S[:, lo:hi], tol, local_gramian=lambda A: A @ A.T,
-                                           local_modes=lambda A, W: A.T @ W)
+                                           local_modes=lambda A, W: A.T @ W, local_eigh=np.linalg.eigh)
     out[rank] = (lo, hi, U_loc, k, Sig)
     dist.destroy_process_group()
 
