@@ -105,3 +105,31 @@ def test_locp_trunk_shape():
     xp, up, sp, Jp, info = ripm.solve(ripm.Problem(**case))
     assert info['status'] == 'optimal'
     assert rel(x, xp) <= 2e-4 and rel(u, up) <= 2e-4 and abs(J - Jp) <= 1e-7 * max(1.0, abs(Jp))
+
+
+@pytest.mark.parametrize('terminal', [False, True])
+def test_linear_mpc_no_trust_region(terminal):
+    """LOCP(is_tr_active=False) (locp.py:57; the linear-MPC baselines of baselines/ros.py) and the MPCSolver
+    mirror: constant (A, B, d), U box + X box, optional terminal cost, vs the exact oracle solution."""
+    from sofacontrol_amd.baselines.mpc import MPCSolver
+    from sofacontrol_amd.utils import QuadraticCost
+    from sofacontrol_amd.tpwl.tpwl_utils import Target
+    case, extra = make_case(seed=41, terminal=terminal, N=15)
+    A, B, d = extra['Ad_tab'][2], extra['Bd_tab'][2], extra['dd_tab'][2]
+    N = case['N']
+    qp = olocp.build_qp(N, case['H'], case['Qz'], case['R'], [A] * N, [B] * N, [d] * N, case['x0'], None, 0, 0,
+                        z=case['z'], Qzf=case.get('Qzf'), zf=case.get('zf'), U=case['U'], X=case['X'], tr_active=False)
+    w, _, info = olocp.solve_exact(qp, tol=1e-12)
+    xe, ue, _ = olocp.split(qp, w)
+    Je = olocp.objective(qp, w)
+
+    class M:
+        H = case['H']; A_d = A; B_d = B; d_d = d
+    tgt = Target(); tgt.t = extra['dt'] * np.arange(N + 1); tgt.z = case['z']; tgt.u = None
+    mpc = MPCSolver(M, N, extra['dt'], QuadraticCost(Q=case['Qz'], R=case['R'], Qf=case.get('Qzf')), case['x0'], tgt,
+                    U=Poly(*case['U']), X=Poly(*case['X']))
+    x, u, z, t = mpc.get_solution()
+    assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
+    assert abs(mpc.Jstar - Je) <= 1e-7 * max(1.0, abs(Je))
+    assert mpc.locp.get_solution()[2] is None            # no slack variables without the trust region
+    np.testing.assert_allclose(z, x @ case['H'].T, atol=1e-14)
