@@ -86,3 +86,84 @@ def arr2np(x, dim, squeeze=False):
 def np2arr(x):
     """sofacontrol/utils.py:428-431."""
     return x.flatten().tolist()
+
+
+class Point:
+    """sofacontrol/utils.py:19-39."""
+
+    def __init__(self):
+        self.step = None
+        self.t = None
+        self.q = None
+        self.v = None
+        self.u = None
+        self.H = None
+        self.K = None
+        self.D = None
+        self.M = None
+        self.S = None
+        self.f = None
+        self.b = None
+        self.q_next = None
+        self.v_next = None
+        self.dt = None
+
+
+class SnapshotData:
+    """sofacontrol/utils.py:42-107: container filled by the open-loop data collection."""
+
+    def __init__(self, save_dynamics=True):
+        self.save_dynamics = save_dynamics
+        keys = ['t', 'q', 'v', 'u'] + (['H', 'K', 'D', 'M', 'S', 'b', 'f'] if save_dynamics else []) + ['q+', 'v+']
+        self.dict = {k: [] for k in keys}
+        self.dict['dt'] = -1
+
+    def add_point(self, point):
+        if self.dict['dt'] == -1:
+            self.dict['dt'] = point.dt
+        self.dict['t'].append(point.t)
+        self.dict['q'].append(point.q)
+        self.dict['v'].append(point.v)
+        self.dict['u'].append(point.u)
+        self.dict['q+'].append(point.q_next)
+        self.dict['v+'].append(point.v_next)
+        if self.save_dynamics:
+            for k in ('K', 'D', 'M', 'b', 'f', 'H', 'S'):
+                self.dict[k].append(getattr(point, k))
+
+    def save_snapshot(self, *args):
+        return True
+
+    def simulation_end(self, filename):
+        dict_lists_to_array(self.dict)
+        save_data(filename, self.dict)
+
+
+def dict_lists_to_array(d):
+    """sofacontrol/utils.py:338-344."""
+    for key in d:
+        if type(d[key]) == list:
+            d[key] = np.asarray(d[key])
+
+
+def extract_AB(K, D, M, H):
+    """sofacontrol/utils.py:251-284 for reduced (dense r x r) matrices: A = [[-M^-1 D, -M^-1 K], [I, 0]],
+    B = [[M^-1 H], [0]].  One-off r x r algebra per TPWL point; the O(n_f^2) work is the U^T . U reduction that
+    produced K, D, M (POD.compute_RO_matrix on the device)."""
+    K, D, M, H = (np.asarray(a.toarray() if hasattr(a, 'toarray') else a, dtype=np.float64) for a in (K, D, M, H))
+    Minv = np.linalg.inv(M)
+    A11, A12, Ht = -(Minv @ D), -(Minv @ K), Minv @ H
+    A = np.block([[A11, A12], [np.eye(A11.shape[0]), np.zeros(A12.shape)]])
+    B = np.block([[Ht], [np.zeros(Ht.shape)]])
+    return A, B
+
+
+def extract_AB_d(S, K, H, dt):
+    """sofacontrol/utils.py:287-299 (ThieffryKruszewskiEtAl2019 discrete derivation)."""
+    Sinv = np.linalg.inv(S)
+    SinvK, SinvH = Sinv @ K, Sinv @ H
+    dim = K.shape[0]
+    I = np.eye(dim)
+    A = np.block([[I - dt ** 2 * SinvK, -dt * SinvK], [dt * I - dt ** 3 * SinvK, I - dt ** 2 * SinvK]])
+    B = np.block([[dt * SinvH], [dt ** 2 * SinvH]])
+    return A, B

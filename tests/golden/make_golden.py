@@ -486,6 +486,40 @@ def g11_ilqr_ssm(out):
     np.savez_compressed(os.path.join(out, 'g11_ilqr_ssm.npz'), **res)
 
 
+def g12_assembly(out):
+    """TPWLSnapshotData.add_point / add_continuous_TPWL / add_discrete_TPWL / evaluate_point_dist
+    (tpwl/tpwl_utils.py:84-117, 170-196, 263-290) on synthetic full-order points."""
+    from sofacontrol.tpwl.tpwl_utils import TPWLSnapshotData
+    from types import SimpleNamespace
+    n_nodes, r, m = 30, 5, 3
+    U, q_ref, v_ref = small_rom(n_nodes, r, 120)
+    n_f = 3 * n_nodes
+    rom = rpod.POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    cfg = SimpleNamespace(eval_type='distance', save_continuous_TPWL=True, save_discrete_TPWL=True,
+                          TPWL_weighting_factors={'q': 1.0, 'v': 0.2}, TPWL_separate_calculation=False,
+                          TPWL_threshold=1.0, TPWL_type='ATV', discr_type='zoh')
+    data = TPWLSnapshotData(rom, cfg)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import assembly_points
+    res = {}
+    pts = []
+    for d in assembly_points(n_f, m, q_ref, 121):
+        p = rutils.Point()
+        for k, v in d.items():
+            setattr(p, k, v)
+        pts.append(p)
+    res['eval0'] = np.array(data.evaluate_point(pts[0], None))
+    quiet(data.add_point, pts[0])
+    res['eval1'] = np.array(data.evaluate_point(pts[1], pts[0]))
+    quiet(data.add_point, pts[1])
+    near = rutils.Point(); near.q = pts[1].q + 1e-3; near.v = pts[1].v
+    res['eval_near'] = np.array(data.evaluate_point(near, pts[1]))
+    quiet(data.add_point, pts[2])
+    for k in ('q', 'v', 'K', 'D', 'M', 'S', 'H', 'b', 'f', 'q+', 'v+', 'A_c', 'B_c', 'd_c', 'A_d', 'B_d', 'd_d'):
+        res['out_' + k] = np.asarray(data.dict[k])
+    np.savez_compressed(os.path.join(out, 'g12_assembly.npz'), **res)
+
+
 class FakeGuSTOClient:
     """Deterministic stand-in for GuSTOClientNode (needs ROS): returns a smooth analytic 'solution'."""
     N, dt_g = 8, 0.05
@@ -568,5 +602,6 @@ if __name__ == '__main__':
     g9_ekf(HERE)
     g10_ssm(HERE)
     g11_ilqr_ssm(HERE)
+    g12_assembly(HERE)
     g8_controllers(HERE)
     print('g8_controllers.npz', os.path.getsize(os.path.join(HERE, 'g8_controllers.npz')))

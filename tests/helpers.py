@@ -56,3 +56,22 @@ def meas_selector(nodes, num_nodes):
         for a in range(3):
             Cf[3 * i + a, n_f + 3 * nd + a] = 1.0
     return Cf.tocsr()
+
+
+def assembly_points(n_f, m, q_ref, seed, count=3):
+    """Seeded synthetic full-order points (K, D, M, S, H, b, f, q, v, q+, v+, u) shared by the golden generator
+    (g12_assembly) and the parity test, so that only the outputs are stored."""
+    rng = np.random.default_rng(seed)
+    pts = []
+    for i in range(count):
+        G = rng.standard_normal((n_f, n_f))
+        K = G @ G.T / n_f + 5 * np.eye(n_f)
+        D = 0.01 * K + 0.5 * np.eye(n_f)
+        M = np.diag(rng.uniform(0.5, 2.0, n_f))
+        S = M + 0.01 * D + 1e-4 * K
+        H = rng.standard_normal((n_f, m))
+        b = rng.standard_normal(n_f); f = rng.standard_normal(n_f)
+        q = q_ref + rng.standard_normal(n_f); v = 0.1 * rng.standard_normal(n_f)
+        pts.append(dict(K=K, D=D, M=M, S=S, H=H, b=b, f=f, q=q, v=v, q_next=q + 0.01 * v,
+                        v_next=v + 0.01 * rng.standard_normal(n_f), u=rng.uniform(0, 100, m), t=0.01 * i, dt=0.01))
+    return pts

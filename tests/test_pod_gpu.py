@@ -134,3 +134,42 @@ def test_compute_pod_gramian_route_vs_reference_svd(golden):
         np.testing.assert_allclose(Sig[:6], g['pod_Sigma'][:6], rtol=1e-9)
         np.testing.assert_allclose(np.abs(U), g['pod_Ufull_abs'][:, :k], rtol=0, atol=1e-8)
         np.testing.assert_allclose(U.T @ U, np.eye(k), rtol=0, atol=1e-9)
+
+
+def test_tpwl_assembly_golden(golden):
+    """TPWLSnapshotData.add_point / add_continuous_TPWL / add_discrete_TPWL / evaluate_point_dist
+    (tpwl/tpwl_utils.py:84-117, 170-196, 263-290): full-order points reduced on the device, model assembled."""
+    import io, contextlib
+    from types import SimpleNamespace
+    from helpers import small_rom, assembly_points
+    from sofacontrol_amd.mor.pod import POD
+    from sofacontrol_amd.tpwl.tpwl_utils import TPWLSnapshotData
+    from sofacontrol_amd.utils import Point
+    g = golden('g12_assembly')
+    n_nodes, r, m = 30, 5, 3
+    U, q_ref, v_ref = small_rom(n_nodes, r, 120)
+    rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    cfg = SimpleNamespace(eval_type='distance', save_continuous_TPWL=True, save_discrete_TPWL=True,
+                          TPWL_weighting_factors={'q': 1.0, 'v': 0.2}, TPWL_separate_calculation=False,
+                          TPWL_threshold=1.0, TPWL_type='ATV', discr_type='zoh')
+    data = TPWLSnapshotData(rom, cfg)
+    pts = []
+    for d in assembly_points(3 * n_nodes, m, q_ref, 121):
+        p = Point()
+        for k, v in d.items():
+            setattr(p, k, v)
+        pts.append(p)
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert data.evaluate_point(pts[0], None) == bool(g['eval0'])
+        data.add_point(pts[0])
+        assert data.evaluate_point(pts[1], pts[0]) == bool(g['eval1'])
+        data.add_point(pts[1])
+        near = Point(); near.q = pts[1].q + 1e-3; near.v = pts[1].v
+        assert data.evaluate_point(near, pts[1]) == bool(g['eval_near'])
+        data.add_point(pts[2])
+    for k in ('q', 'v', 'K', 'D', 'M', 'S', 'H', 'b', 'f', 'q+', 'v+'):
+        ref = g['out_' + k]
+        np.testing.assert_allclose(np.asarray(data.dict[k]), ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max()))
+    for k in ('A_c', 'B_c', 'd_c', 'A_d', 'B_d', 'd_d'):
+        ref = g['out_' + k]
+        np.testing.assert_allclose(np.asarray(data.dict[k]), ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
