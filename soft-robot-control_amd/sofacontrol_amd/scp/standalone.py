@@ -67,3 +67,36 @@ class GuSTOSolverNode():
         self.xopt, self.uopt, zopt, t_solve = self.gusto.get_solution()
         self.topt = t0 + self.dt * np.arange(self.N + 1)
         return self.topt, self.xopt, self.uopt, zopt, t_solve
+
+    def gusto_service(self, request, response=None):
+        """The GuSTOsrv wire format (dependencies/ros/GuSTOsrv.srv:1-40, scp/ros.py:94-127): request fields `t0`
+        (float64) and `x0` (float64[], flat); response fields `t, xopt, uopt, zopt` (float64[], row-major
+        flattened, utils.np2arr) and `solve_time`.  Any object with those attributes works (a ROS2 message on
+        a robot, GuSTOsrvRequest / GuSTOsrvResponse below without ROS)."""
+        from ..utils import arr2np, np2arr
+        if response is None:
+            response = GuSTOsrvResponse()
+        x0 = arr2np(request.x0, self.model.n_x, squeeze=True)
+        t, xopt, uopt, zopt, t_solve = self.gusto_callback(request.t0, x0)
+        response.t = np2arr(t)
+        response.xopt = np2arr(xopt)
+        response.uopt = np2arr(uopt)
+        response.zopt = np2arr(zopt)
+        response.solve_time = float(t_solve)
+        return response
+
+
+class GuSTOsrvRequest:
+    """Request half of dependencies/ros/GuSTOsrv.srv (only t0, x0 are read by the solver node)."""
+
+    def __init__(self, t0=0.0, x0=()):
+        self.horizon = self.n_u = self.n_x = self.n_z = 0
+        self.t0 = float(t0)
+        self.x0 = list(np.asarray(x0, dtype=np.float64).ravel())
+        self.u_init, self.x_init, self.z, self.zf, self.u = [], [], [], [], []
+
+
+class GuSTOsrvResponse:
+    def __init__(self):
+        self.t, self.xopt, self.uopt, self.zopt = [], [], [], []
+        self.solve_time = 0.0

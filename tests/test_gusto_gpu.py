@@ -53,6 +53,19 @@ def test_gusto_node_first_solve_and_warm_resolve(golden, tag):
     assert int(node.gusto.iters[0]) == g[tag + '_trace2'].shape[0]
     assert rel(x2, g[tag + '_xopt2']) <= 1e-4 and rel(u2, g[tag + '_uopt2']) <= 1e-4
     np.testing.assert_allclose(t, 2 * dt + dt * np.arange(N + 1))
+    if tag == 'box':
+        # the same request through the GuSTOsrv wire format (flat float64 lists, GuSTOsrv.srv / scp/ros.py:94-127)
+        from sofacontrol_amd.scp.standalone import GuSTOsrvRequest
+        node2 = GuSTOSolverNode(gm, N, dt, g['Qz'], g['R'], np.zeros(8), t=g['t'], z=g['zt'], verbose=0,
+                                warm_start=True, convg_thresh=1e-3, max_trace=64, **cons)
+        node2.gusto.max_gusto_iters = 500
+        resp = node2.gusto_service(GuSTOsrvRequest(2 * dt, g[tag + '_x0b']))
+        assert isinstance(resp.xopt, list) and len(resp.xopt) == (N + 1) * 8 and len(resp.uopt) == N * 3
+        np.testing.assert_array_equal(np.array(resp.xopt).reshape(N + 1, 8), x2)
+        np.testing.assert_array_equal(np.array(resp.uopt).reshape(N, 3), u2)
+        np.testing.assert_array_equal(np.array(resp.zopt).reshape(N + 1, -1), z2)
+        np.testing.assert_array_equal(np.array(resp.t), t)
+        assert resp.solve_time >= 0.0
 
 
 def test_gusto_helpers_match_reference(golden):
