@@ -95,8 +95,6 @@ struct QPLds {                         // LDS carve (doubles unless noted)
     lptr pv, adj, v1, v2, v3, hdv, cvv;   // ld each
     lptr ypv, yadj;                // ld each : [A|B]^T pv, [A|B]^T adj
     lptr Qu, kf, rdu;             // 16 each
-    lptr Hm;                        // nz x ld : H
-    lptr HtQ;                       // ld x 16 : 2 H^T Qz
     lptr XAl;                       // (nX + nXf) x ld
     lptr Dx;                        // 32      : X-row weights of the stage
     lptr part;                      // blockDim
@@ -108,7 +106,7 @@ struct QPLds {                         // LDS carve (doubles unless noted)
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
     const size_t nk16 = (size_t)((d.n + 15) & ~15);   // whole MFMA tiles are stored
     size_t c = nk16 * d.ld + 2 * (size_t)d.RW * d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
-               (size_t)d.nz * d.ld + (size_t)d.n * d.nz + 4 + (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
+               (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
     return c * sizeof(double);
 }
 
@@ -123,7 +121,6 @@ __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nt
     L.pv = take(d.ld); L.adj = take(d.ld); L.v1 = take(d.ld); L.v2 = take(d.ld); L.v3 = take(d.ld); L.hdv = take(d.ld); L.cvv = take(d.ld);
     L.ypv = take(d.ld); L.yadj = take(d.ld);
     L.Qu = take(16); L.kf = take(16); L.rdu = take(16);
-    L.Hm = take((size_t)d.nz * d.ld); L.HtQ = take((size_t)d.n * d.nz + 4);
     L.XAl = take((size_t)(d.nX + d.nXf) * d.ld);
     L.Dx = take(32);
     L.part = take(nthreads);
@@ -143,8 +140,6 @@ __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) 
         L.AB[(d.RC + r) * ld + j] = c.Cq[e];
         L.W[(d.RC + r) * ld + j] = c.Cq[e];
     }
-    for (int e = tid; e < d.nz * n; e += nt) { const int a = e / n, j = e - a * n; L.Hm[a * ld + j] = c.H[e]; }
-    for (int e = tid; e < n * d.nz; e += nt) { const int i = e / d.nz, a = e - i * d.nz; L.HtQ[i * d.nz + a] = c.HtQz2[e]; }
     for (int e = tid; e < (d.nX + d.nXf) * n; e += nt) {
         const int r = e / n, j = e - r * n;
         L.XAl[r * ld + j] = r < d.nX ? c.XA[(size_t)r * n + j] : c.XfA[(size_t)(r - d.nX) * n + j];
@@ -427,7 +422,7 @@ __device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, in
 __device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, const QPLds &L, int k, int i, int j,
                                              double Hss, int nxrows) {
     double v = 0.0;
-    for (int a = 0; a < d.nz; ++a) v = fma(L.HtQ[i * d.nz + a], L.Hm[a * d.ld + j], v);     // 2 H^T Qz H
+    for (int a = 0; a < d.nz; ++a) v = fma(c.HtQz2[i * d.nz + a], c.H[a * d.n + j], v);     // 2 H^T Qz H (terminal stage only)
     if (k == d.N && c.Qzf) v += c.QxN[(size_t)i * d.n + j] - c.Qx[(size_t)i * d.n + j];
     if (d.tr) {
         if (i == j) v += L.hdv[i];

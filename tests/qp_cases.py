@@ -5,7 +5,7 @@ from oracle import tpwl as otpwl, gusto as ogusto
 
 
 def make_case(r=4, m=3, P=7, N=12, seed=30, q_scale=0.05, delta=1e4, omega=1.0, use_U=True, use_X=True,
-              amp=0.15, dt=0.05, x0_scale=1e-4, u_max=800.0, xk_input=0.0, terminal=False):
+              amp=0.15, dt=0.05, x0_scale=1e-4, u_max=800.0, xk_input=0.0, terminal=False, x_box=1.0):
     model = otpwl.synthetic_model(r, m, P, seed=seed)
     model['q'] = model['q'] * q_scale
     Ad, Bd, dd = otpwl.pre_discretize(model, dt, 'zoh')
@@ -27,7 +27,7 @@ def make_case(r=4, m=3, P=7, N=12, seed=30, q_scale=0.05, delta=1e4, omega=1.0, 
     Ub = np.tile([u_max, 0.], m)
     Hz = np.zeros((2, 6)); Hz[0, 3] = 1; Hz[1, 4] = 1
     Hx = Hz @ H
-    X = (np.vstack([-Hx, Hx]), np.array([0.02, 0.02, 0.04, 0.03])) if use_X else None
+    X = (np.vstack([-Hx, Hx]), x_box * np.array([0.02, 0.02, 0.04, 0.03])) if use_X else None
     case = dict(N=N, H=H, Qz=Qz, R=R, Ad=A_k, Bd=B_k, dd=d_k, x0=x0, xk=xk, delta=delta, omega=omega, z=z,
                 U=(UA, Ub) if use_U else None, X=X, x_scale=1. / np.abs(xc))
     if terminal:

@@ -86,9 +86,11 @@ def test_infeasible_qp_reports_failure():
     assert not ok and J == np.inf and stats is None
 
 
-def test_locp_trunk_shape():
-    """C5 shape (Trunk: n_x = 60, n_u = 8, N = 50, U = [0, 800]^8): the n_x + n_u = 68 panels (80-wide tiles)."""
-    case, _ = make_case(r=30, m=8, P=32, N=50, seed=11, q_scale=0.02, use_X=False, u_max=800.0, amp=0.1)
+@pytest.mark.parametrize('use_X', [False, True])
+def test_locp_trunk_shape(use_X):
+    """C5 shape (Trunk: n_x = 60, n_u = 8, N = 50, U = [0, 800]^8; examples/trunk/trunk.py:309-316 has X = None,
+    the X-box variant exercises the LDS budget): the n_x + n_u = 68 panels (80-wide tiles)."""
+    case, _ = make_case(r=30, m=8, P=32, N=50, seed=11, q_scale=0.02, use_X=use_X, u_max=800.0, amp=0.1, x_box=4.0)
     (xe, ue, se), Je = oracle_solution(case)
     locp = product_locp(case)
     locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
