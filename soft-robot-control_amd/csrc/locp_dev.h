@@ -15,6 +15,8 @@ struct QPDims {
     int ld;    // leading dimension of the LDS matrices = NPa + 1 (odd: row AND column accesses conflict-free)
     int NPa;   // roundup16(n + m): extent of the stage Gram matrix
     int mp;    // unused (kept for layout stability)
+    int split; // 1: the W panel holds half of the rows at a time (n_x > 64, see riccati_solve); 0: whole W in LDS
+    int WR;    // rows of the W panel (RW, or 48 in split mode)
     int NK;    // roundup4(n): K extent of the MFMA products (zero padded rows)
     int NE4;   // roundup4(m + nX): extra Gram rows (-Y, +Y from the gain; sqrt(D) X rows)
     int RW;    // rows of the AB / W panels
@@ -104,8 +106,8 @@ struct QPLds {                         // LDS carve (doubles unless noted)
 };
 
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
-    const size_t nk16 = (size_t)((d.n + 15) & ~15);   // whole MFMA tiles are stored
-    size_t c = nk16 * d.ld + 2 * (size_t)d.RW * d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
+    const size_t nk16 = d.split ? (size_t)d.NK : (size_t)((d.n + 15) & ~15);   // whole MFMA tiles are stored (masked in split mode)
+    size_t c = nk16 * d.ld + ((size_t)d.RW + d.WR) * d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
                (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
     return c * sizeof(double);
 }
@@ -113,8 +115,8 @@ __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
 __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nthreads) {
     lptr p = base;
     auto take = [&](size_t c) { lptr q = p; p += c; return q; };
-    const size_t nk16 = (size_t)((d.n + 15) & ~15);
-    L.P = take(nk16 * d.ld); L.AB = take((size_t)d.RW * d.ld); L.W = take((size_t)d.RW * d.ld);
+    const size_t nk16 = d.split ? (size_t)d.NK : (size_t)((d.n + 15) & ~15);
+    L.P = take(nk16 * d.ld); L.AB = take((size_t)d.RW * d.ld); L.W = take((size_t)d.WR * d.ld);
     L.QUX = L.AB + (size_t)d.NK * d.ld;     // [Qux | B^T P B] lands in the extra-row slots of the left panel (rows NK..NK+m)
     L.Km = take((size_t)d.m * d.ld);
     L.Quu = take(256); L.Lc = take(256);
@@ -132,13 +134,14 @@ __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nt
 // one-off per kernel: constants into LDS, zero the padding of the MFMA operands
 __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) {
     const int tid = threadIdx.x, nt = blockDim.x, n = d.n, ld = d.ld;
-    for (int e = tid; e < ((d.n + 15) & ~15) * d.ld; e += nt) L.P[e] = 0.0;
-    for (int e = tid; e < d.RW * d.ld; e += nt) { L.AB[e] = 0.0; L.W[e] = 0.0; }
+    for (int e = tid; e < (d.split ? d.NK : ((d.n + 15) & ~15)) * d.ld; e += nt) L.P[e] = 0.0;
+    for (int e = tid; e < d.RW * d.ld; e += nt) L.AB[e] = 0.0;
+    for (int e = tid; e < d.WR * d.ld; e += nt) L.W[e] = 0.0;
     if (tid == 0) L.flag[2] = -1;
     for (int e = tid; e < d.nzr * n; e += nt) {
         const int r = e / n, j = e - r * n;
         L.AB[(d.RC + r) * ld + j] = c.Cq[e];
-        L.W[(d.RC + r) * ld + j] = c.Cq[e];
+        if (!d.split) L.W[(d.RC + r) * ld + j] = c.Cq[e];
     }
     for (int e = tid; e < (d.nX + d.nXf) * n; e += nt) {
         const int r = e / n, j = e - r * n;
@@ -418,6 +421,56 @@ __device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, in
     __syncthreads();
 }
 
+// Register-resident variant for products that are accumulated over several passes (split mode): tile
+// t = wave + r * (number of waves), r < NR, of the MT x NTl tile grid lives in acc[r].
+//   acc[r] += sum_{k<K} Lm[k][i] * Rm[k][j]      (no barrier inside)
+template <int NR>
+__device__ __forceinline__ void mfma_acc(qp_d4 (&acc)[NR], clptr Lm, clptr Rm, int K, int MT, int NTl, int ld) {
+    static_assert(NR % 2 == 0, "tiles are processed in pairs");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int ntiles = MT * NTl;
+#pragma unroll
+    for (int r = 0; r < NR; r += 2) {
+        const int t0 = wave + r * nw, t1 = t0 + nw;
+        if (t0 < ntiles) {                             // wave-uniform
+            const bool has1 = t1 < ntiles;
+            const int ti0 = t0 / NTl, tj0 = t0 - ti0 * NTl;
+            const int ti1 = has1 ? t1 / NTl : ti0, tj1 = has1 ? t1 - ti1 * NTl : tj0;
+            clptr la0 = Lm + kk * ld + 16 * ti0 + l16, rb0 = Rm + kk * ld + 16 * tj0 + l16;
+            clptr la1 = Lm + kk * ld + 16 * ti1 + l16, rb1 = Rm + kk * ld + 16 * tj1 + l16;
+            qp_d4 c0 = acc[r], c1 = acc[r + 1];
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                const double a0 = la0[k0 * ld], b0 = rb0[k0 * ld];
+                const double a1 = la1[k0 * ld], b1 = rb1[k0 * ld];
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+                if (has1) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+            }
+            acc[r] = c0;
+            acc[r + 1] = c1;
+        }
+    }
+}
+
+// C rows < srows of the accumulated tiles (no barrier inside)
+template <int NR>
+__device__ __forceinline__ void mfma_put(const qp_d4 (&acc)[NR], lptr C, int ldc, int MT, int NTl, int srows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int ntiles = MT * NTl;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int t = wave + r * nw;
+        if (t >= ntiles) continue;
+        const int ti = t / NTl, tj = t - ti * NTl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r0 = 16 * ti + kk + 4 * q;
+            if (r0 < srows) C[r0 * ldc + 16 * tj + l16] = acc[r][q];
+        }
+    }
+}
+
 // stage Hessian of x_k added to the (i,j) entry: Qx (+ terminal) + slack-eliminated trust region + X rows
 __device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, const QPLds &L, int k, int i, int j,
                                              double Hss, int nxrows) {
@@ -440,9 +493,10 @@ __device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, 
 //   right panel rows NK..   : +Y[:, j],  +sqrt(D_r) XA[r][j]
 // so that  A^T W + left^T right = A^T P A - Qux^T Quu^-1 Qux + X^T D X  comes out of one MFMA product,
 // exactly symmetric in the added terms.  Column n / n+1 of the right panel receive pv / adj (rows < n).
-template <int M>
+template <int M, bool SPLIT>
 __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &L, int k, bool extras) {
     const int n = d.n, ld = d.ld, NK = d.NK, tid = threadIdx.x, nt = blockDim.x;
+    const int wb = SPLIT ? 0 : NK;            // first extra row of the right panel
     double Lr[M * M], inv[M];
     double dmax = 0.0;
 #pragma unroll
@@ -481,15 +535,17 @@ __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &
 #pragma unroll
                 for (int a = 0; a < M; ++a) {
                     L.AB[(NK + a) * ld + j] = -y[a];
-                    L.W[(NK + a) * ld + j] = y[a];
+                    L.W[(wb + a) * ld + j] = y[a];
                 }
                 for (int r = 0; r < d.nX; ++r) {
                     const double v = sqrt(L.Dx[r]) * L.XAl[r * ld + j];
                     L.AB[(NK + M + r) * ld + j] = v;
-                    L.W[(NK + M + r) * ld + j] = v;
+                    L.W[(wb + M + r) * ld + j] = v;
                 }
-                L.W[j * ld + n] = L.pv[j];
-                L.W[j * ld + n + 1] = L.adj[j];
+                if (!SPLIT) {
+                    L.W[j * ld + n] = L.pv[j];
+                    L.W[j * ld + n + 1] = L.adj[j];
+                }
             }
         } else {
 #pragma unroll
@@ -504,26 +560,28 @@ __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &
     return true;
 }
 
+template <bool SPLIT>
 __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L, int k, bool extras) {
     switch (d.m) {
-        case 1: return stage_gain_t<1>(d, w, L, k, extras);
-        case 2: return stage_gain_t<2>(d, w, L, k, extras);
-        case 3: return stage_gain_t<3>(d, w, L, k, extras);
-        case 4: return stage_gain_t<4>(d, w, L, k, extras);
-        case 5: return stage_gain_t<5>(d, w, L, k, extras);
-        case 6: return stage_gain_t<6>(d, w, L, k, extras);
-        case 7: return stage_gain_t<7>(d, w, L, k, extras);
-        case 8: return stage_gain_t<8>(d, w, L, k, extras);
+        case 1: return stage_gain_t<1, SPLIT>(d, w, L, k, extras);
+        case 2: return stage_gain_t<2, SPLIT>(d, w, L, k, extras);
+        case 3: return stage_gain_t<3, SPLIT>(d, w, L, k, extras);
+        case 4: return stage_gain_t<4, SPLIT>(d, w, L, k, extras);
+        case 5: return stage_gain_t<5, SPLIT>(d, w, L, k, extras);
+        case 6: return stage_gain_t<6, SPLIT>(d, w, L, k, extras);
+        case 7: return stage_gain_t<7, SPLIT>(d, w, L, k, extras);
+        case 8: return stage_gain_t<8, SPLIT>(d, w, L, k, extras);
         default: break;
     }
     // m > 8: factor once in LDS (thread 0), per-column solves from LDS
     const int n = d.n, m = d.m, ld = d.ld, NK = d.NK, tid = threadIdx.x, nt = blockDim.x;
+    const int wb = SPLIT ? 0 : NK;
     if (!wg::chol_factor(L.Quu, L.Lc, m, L.flag, true)) return false;
     for (int j = tid; j <= n; j += nt) {
         clptr b = j < n ? L.QUX + j : L.Qu;
         const int bs = j < n ? ld : 1;
         // forward substitution into the extra-row slots / a scratch column of W, then back substitution
-        lptr yc = j < n ? L.W + NK * ld + j : L.v3;
+        lptr yc = j < n ? L.W + wb * ld + j : L.v3;
         const int ys = j < n ? ld : 1;
         for (int i = 0; i < m; ++i) {
             double sum = b[i * bs];
@@ -548,10 +606,12 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
                 for (int r = 0; r < d.nX; ++r) {
                     const double v = sqrt(L.Dx[r]) * L.XAl[r * ld + j];
                     L.AB[(NK + m + r) * ld + j] = v;
-                    L.W[(NK + m + r) * ld + j] = v;
+                    L.W[(wb + m + r) * ld + j] = v;
                 }
-                L.W[j * ld + n] = L.pv[j];
-                L.W[j * ld + n + 1] = L.adj[j];
+                if (!SPLIT) {
+                    L.W[j * ld + n] = L.pv[j];
+                    L.W[j * ld + n + 1] = L.adj[j];
+                }
             }
         } else {
             for (int a = 0; a < m; ++a) { L.kf[a] = -L.kf[a]; w.kff[(size_t)k * m + a] = L.kf[a]; }
@@ -633,6 +693,7 @@ __device__ __forceinline__ void panel_vec(const QPDims &d, QPLds &L, clptr a, cl
 // give Qxx, Qux and Quu in one Gram matrix; P_k = sym(M_xx) + H_k + sym(Qux^T K) with K = -Quu^-1 Qux by
 // Cholesky solves.  P, AB, W stay in LDS for the whole horizon; A_k, B_k stream from the (L2 resident)
 // TPWL tables.
+template <bool SPLIT>
 __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, QPWork &w, QPLds &L,
                                      bool full, bool with_dual, double *rd_out) {
     const int n = d.n, m = d.m, N = d.N, ld = d.ld, NK = d.NK, NPa = d.NPa, n16 = (d.n + 15) & ~15;
@@ -682,9 +743,30 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             }
             __syncthreads();
             SRH_LAP(0);
-            mfma_atb(L.W, ld, L.P, L.AB, NK, n16 >> 4, NPa >> 4, ld, n);          // W = P [A|B]
-            SRH_LAP(1);
-            mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16, m);        // [Qux | B^T P B] = B^T W
+            // split mode (n_x > 64: P, AB and W do not fit LDS together): W = P [A|B] is produced 48 rows at a
+            // time; the Gram products that contract over the rows of W accumulate in MFMA registers across the
+            // two halves, so only half of W is ever resident
+            qp_d4 accP[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            if constexpr (SPLIT) {
+                qp_d4 accQ[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+                for (int h = 0; h < 2; ++h) {
+                    const int r0 = 48 * h;
+                    const int rows = h == 0 ? (NK < 48 ? NK : 48) : NK - 48;
+                    if (rows <= 0) break;
+                    const int rt = (rows + 15) >> 4;
+                    mfma_atb(L.W, ld, L.P + r0, L.AB, NK, rt, NPa >> 4, ld, n - r0, 16 * rt);   // W_h = P[r0.., :] [A|B]
+                    mfma_acc<2>(accQ, L.AB + (size_t)r0 * ld + n, L.W, rows, 1, NPa >> 4, ld);
+                    if (k >= 1) mfma_acc<4>(accP, L.AB + (size_t)r0 * ld, L.W, rows, n16 >> 4, n16 >> 4, ld);
+                    __syncthreads();
+                }
+                SRH_LAP(1);
+                mfma_put<2>(accQ, L.QUX, ld, 1, NPa >> 4, m);
+                __syncthreads();
+            } else {
+                mfma_atb(L.W, ld, L.P, L.AB, NK, n16 >> 4, NPa >> 4, ld, n);          // W = P [A|B]
+                SRH_LAP(1);
+                mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16, m);        // [Qux | B^T P B] = B^T W
+            }
             SRH_LAP(2);
             // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (one wave per output), Quu += B^T P B
             for (int o = wave; o < 2 * m; o += nw) {
@@ -702,12 +784,28 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             __syncthreads();
             if (with_dual && tid < m) rd = fmax(rd, fabs(L.rdu[tid]));
             SRH_LAP(3);
-            if (!stage_gain(d, w, L, k, k >= 1)) return false;
+            if (!stage_gain<SPLIT>(d, w, L, k, k >= 1)) return false;
             SRH_LAP(4);
             if (k >= 1) {
                 // P_k = A^T W + (extra rows: -Y^T Y + X^T D X); columns n, n+1 deliver A^T pv, A^T adj
                 const int K2 = d.nzr ? ((d.RC + d.nzr + 3) & ~3) : NK + d.NE4;
-                mfma_atb(L.P, ld, L.AB, L.W, K2, n16 >> 4, ((n + 2 + 15) & ~15) >> 4, ld, n16);
+                if constexpr (SPLIT) {
+                    // extra Gram rows: the gain wrote +Y / sqrt(D) X into W rows 0..; constant Cq rows copied from
+                    // the left panel, the rest of the K extent zeroed; A^T pv, A^T adj by panel mat-vecs
+                    const int KE = K2 - NK;
+                    for (int e = tid; e < (KE - m - d.nX) * n16; e += nt) {
+                        const int r = m + d.nX + e / n16, j = e % n16;
+                        const bool cq = d.nzr && NK + r >= d.RC && NK + r < d.RC + d.nzr;
+                        L.W[r * ld + j] = cq ? L.AB[(NK + r) * ld + j] : 0.0;
+                    }
+                    __syncthreads();
+                    mfma_acc<4>(accP, L.AB + (size_t)NK * ld, L.W, KE, n16 >> 4, n16 >> 4, ld);
+                    mfma_put<4>(accP, L.P, ld, n16 >> 4, n16 >> 4, n);
+                    panel_T_vec(d, L, L.pv, L.ypv);
+                    panel_T_vec(d, L, L.adj, L.yadj);
+                } else {
+                    mfma_atb(L.P, ld, L.AB, L.W, K2, n16 >> 4, ((n + 2 + 15) & ~15) >> 4, ld, n16);
+                }
                 // finish in place (only when something is left to add): the constant 2 H^T Qz H unless it was
                 // folded into the product as extra rows, and the slack-eliminated trust region; symmetrised.
                 // Each unordered pair (i,j) is owned by one thread.
@@ -731,11 +829,11 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                 for (int e = tid; e < 2 * n; e += nt) {
                     const int j = e % n;
                     if (e < n) {
-                        double v = w.gx[(size_t)k * n + j] + L.P[j * ld + n];
+                        double v = w.gx[(size_t)k * n + j] + (SPLIT ? L.ypv[j] : L.P[j * ld + n]);
                         for (int a = 0; a < m; ++a) v = fma(L.Km[a * ld + j], L.Qu[a], v);
                         L.v1[j] = v;
                     } else {
-                        L.v2[j] = w.gxd[(size_t)k * n + j] + L.P[j * ld + n + 1];
+                        L.v2[j] = w.gxd[(size_t)k * n + j] + (SPLIT ? L.yadj[j] : L.P[j * ld + n + 1]);
                     }
                 }
                 __syncthreads();
@@ -825,6 +923,7 @@ __device__ __forceinline__ double max_step(const QPDims &d, const QPWork &w, QPL
 // direction (factorisation + solve), CORR the Mehrotra corrector (re-solve with the stored factors).
 // With `prescreen` the trust-region rows are dropped first (see below) and the full QP is only solved
 // when the relaxed minimiser leaves the trust region.
+template <bool SPLIT>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                      QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -908,7 +1007,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             stage_prepass(d, c, q, w, mode == PRED);
             SRH_LAP(2);
             double rd = 0.0;
-            const bool ok = riccati_solve(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
+            const bool ok = riccati_solve<SPLIT>(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
             if (mode == CORR) SRH_LAP(4); else SRH_LAP(3);
             // ---------------- use the direction
             if (mode == INIT) {

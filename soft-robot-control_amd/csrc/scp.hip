@@ -25,6 +25,7 @@ struct LocpBatch {
     double *dbg;
 };
 
+template <bool SPLIT>
 __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, LocpBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     QPLds L;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
              (gptr)((b.dbg && p == 0) ? b.dbg : nullptr)};
     double J;
     int it;
-    const int st = qp::solve(d, c, dyn, q, wbase, L, &J, &it, true, w);
+    const int st = qp::solve<SPLIT>(d, c, dyn, q, wbase, L, &J, &it, true, w);
     for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
     for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
     for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
@@ -70,6 +71,7 @@ struct GustoBatch {
     size_t work_stride;
 };
 
+template <bool SPLIT>
 __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     QPLds L;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                  (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
         double J;
         int qit;
-        const int st = qp::solve(d, c, dyn, q, base, L, &J, &qit, true, w);
+        const int st = qp::solve<SPLIT>(d, c, dyn, q, base, L, &J, &qit, true, w);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
         double md = 0.0;
@@ -290,11 +292,9 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.mp = (m + 3) & ~3;
     d.NK = (n + 3) & ~3;
     d.NE4 = (m + pr->nX + 3) & ~3;
-    d.RW = std::max((n + 15) & ~15, d.NK + std::max(d.NE4, (m + 3) & ~3));
-    // fold 2 H^T Qz H = Cq^T Cq into the Gram product as constant extra rows when the panels still fit in LDS
+    d.split = 0; d.WR = 0; d.nzr = 0; d.RC = 0; d.RW = 0;
+    // 2 H^T Qz H = Cq^T Cq: constant extra rows of the Gram product when the panels still fit in LDS
     std::vector<double> Cq;
-    d.nzr = 0;
-    d.RC = std::max(d.NK + m + pr->nX, (n + 15) & ~15);
     {
         std::vector<double> Qs((size_t)nz * nz), wv, V;
         for (int a = 0; a < nz; ++a) for (int b = 0; b < nz; ++b) Qs[a * nz + b] = 0.5 * (pr->Qz[a * nz + b] + pr->Qz[b * nz + a]);
@@ -310,11 +310,32 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
                 Cq.push_back(sc * v);
             }
         }
-        const int nzr = (int)(Cq.size() / n);
+    }
+    const int nzr_full = (int)(Cq.size() / n);
+    // layout: whole W panel in LDS when it fits, else the split variant (W holds 48 rows at a time)
+    auto layout = [&](int split, int nzr) {
         QPDims t = d;
+        t.split = split;
         t.nzr = nzr;
-        t.RW = std::max(d.RW, (d.RC + nzr + 3) & ~3);
-        if (nzr > 0 && qp_lds_bytes(t, NTHREADS) <= 160 * 1024) { d.nzr = nzr; d.RW = t.RW; }
+        t.RC = std::max(t.NK + m + pr->nX, (n + 15) & ~15);
+        t.RW = std::max((n + 15) & ~15, t.NK + std::max(t.NE4, (m + 3) & ~3));
+        if (nzr > 0) t.RW = std::max(t.RW, (t.RC + nzr + 3) & ~3);
+        t.WR = split ? 48 : t.RW;
+        return t;
+    };
+    {
+        const size_t lim = 160 * 1024;
+        QPDims best = layout(0, 0);
+        bool found = false;
+        for (int split = 0; split < 2 && !found; ++split) {
+            for (int nzr : {nzr_full, 0}) {
+                QPDims t = layout(split, nzr);
+                const int KE = (nzr ? ((t.RC + nzr + 3) & ~3) : t.NK + t.NE4) - t.NK;
+                if (split && (t.NK <= 48 || t.NK > 96 || KE > 48)) continue;
+                if (qp_lds_bytes(t, NTHREADS) <= lim) { best = t; found = true; break; }
+            }
+        }
+        d = best;
     }
     d.nrx = d.tr * (2 * n + 1) + d.nX;
     d.RX = d.nrx + d.nXf;
@@ -436,8 +457,13 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     const bool want_dbg = getenv("SRH_LOCP_TRACE") != nullptr;
     if (want_dbg) { if ((rc = dbg.alloc(sizeof(double) * 8 * 64))) return rc; (void)hipMemset(dbg.p, 0, sizeof(double) * 8 * 64); b.dbg = dbg.as<double>(); }
     const size_t lds = qp_lds_bytes(d, NTHREADS);
-    if ((rc = set_lds_limit((const void *)locp_kernel, lds))) return rc;
-    locp_kernel<<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b);
+    if (d.split) {
+        if ((rc = set_lds_limit((const void *)locp_kernel<true>, lds))) return rc;
+        locp_kernel<true><<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b);
+    } else {
+        if ((rc = set_lds_limit((const void *)locp_kernel<false>, lds))) return rc;
+        locp_kernel<false><<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b);
+    }
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipDeviceSynchronize());
     if (want_dbg) {
@@ -487,7 +513,8 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
         (rc = pl->zopt.alloc(sizeof(double) * batch * (N + 1) * nz)) || (rc = pl->iters.alloc(sizeof(int32_t) * batch)) ||
         (rc = pl->status.alloc(sizeof(int32_t) * batch)) ||
         (rc = pl->trace.alloc(sizeof(double) * batch * (size_t)std::max(1, max_trace) * 4)) ||
-        (rc = set_lds_limit((const void *)gusto_kernel, pl->lds))) {
+        (rc = d.split ? set_lds_limit((const void *)gusto_kernel<true>, pl->lds)
+                      : set_lds_limit((const void *)gusto_kernel<false>, pl->lds))) {
         delete pl;
         return rc;
     }
@@ -515,7 +542,10 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
                  pl->work.as<double>(), pl->work_stride};
     GustoPar par = pl->par;
     if (!trace) par.max_trace = 0;
-    gusto_kernel<<<(unsigned)pl->batch, NTHREADS, pl->lds, (hipStream_t)stream>>>(pl->C.dims, pl->C.view(), pl->model->view(), par, b);
+    if (pl->C.dims.split)
+        gusto_kernel<true><<<(unsigned)pl->batch, NTHREADS, pl->lds, (hipStream_t)stream>>>(pl->C.dims, pl->C.view(), pl->model->view(), par, b);
+    else
+        gusto_kernel<false><<<(unsigned)pl->batch, NTHREADS, pl->lds, (hipStream_t)stream>>>(pl->C.dims, pl->C.view(), pl->model->view(), par, b);
     SRH_CHECK_HIP(hipGetLastError());
     return SRH_OK;
 }

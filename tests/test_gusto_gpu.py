@@ -104,3 +104,36 @@ def test_gusto_batch_equals_single(golden):
         np.testing.assert_array_equal(g1.xopt, gb.xopt[b])
         np.testing.assert_array_equal(g1.uopt, gb.uopt[b])
         assert int(g1.iters[0]) == int(gb.iters[b])
+
+
+def test_gusto_r36_split_panel_vs_oracle():
+    """The fused GuSTO kernel at n_x = 72 (r = 36, the reference's shipped Diamond basis size): split-panel QP
+    path inside the persistent SCP kernel, against the restated loop around the exact QP oracle."""
+    from oracle import tpwl as otpwl, gusto as ogusto, locp as olocp
+    from sofacontrol_amd.scp.models.tpwl import TPWLGuSTO
+    from sofacontrol_amd.scp.gusto import GuSTO
+    r, m, P, N, dt = 36, 4, 8, 12, 0.05
+    model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, 40, 33, q_scale=0.2)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    gm = TPWLGuSTO(tp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gm.pre_discretize(dt)
+    Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    Qz = np.diag([0, 0, 0, 100., 100., 0]); R = 1e-5 * np.eye(m)
+    H = np.asarray(tp.H)
+    th = np.linspace(0, 1.0, N + 1)
+    z = np.zeros((N + 1, 6)); z[:, 3] = -0.01 * np.sin(th); z[:, 4] = 0.005 * np.sin(2 * th)
+    UA = np.kron(np.eye(m), np.array([[1.], [-1.]])); Ub = np.tile([800., 0.], m)
+    x0 = np.zeros(2 * r)
+    u_init = np.zeros((N, m))
+    x_init = otpwl.rollout(model, Ad, Bd, dd, x0, u_init)
+    xc, fc = otpwl.characteristic_vals(model)
+    g = GuSTO(gm, N, dt, Qz, R, x0, u_init, x_init, z=z, U=Poly(UA, Ub), x_char=xc, f_char=fc, convg_thresh=1e-3,
+              max_gusto_iters=4, max_trace=16)
+    assert g._fused
+    xo, uo, zo, _ = g.get_solution()
+    xe, ue, ze, tr = ogusto.solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=z, U=(UA, Ub), x_char=xc,
+                                  f_char=fc, convg_thresh=1e-3, max_gusto_iters=500)
+    assert int(g.iters[0]) == len(tr)
+    np.testing.assert_allclose(g.trace[0, :len(tr), 0], [t[0] for t in tr], rtol=1e-6)
+    assert rel(xo, xe) <= 1e-4 and rel(uo, ue) <= 1e-4

@@ -135,3 +135,21 @@ def test_linear_mpc_no_trust_region(terminal):
     assert abs(mpc.Jstar - Je) <= 1e-7 * max(1.0, abs(Je))
     assert mpc.locp.get_solution()[2] is None            # no slack variables without the trust region
     np.testing.assert_allclose(z, x @ case['H'].T, atol=1e-14)
+
+
+@pytest.mark.parametrize('m,use_X', [(4, True), (4, False), (8, False)])
+def test_locp_r36_split_panel(m, use_X):
+    """n_x = 72 (the POD basis the reference ships for the Diamond at tol 5e-5 has r = 36): P, [A|B] and W no longer
+    fit LDS together; the kernel produces W 48 rows at a time and accumulates the Gram products in MFMA registers."""
+    case, _ = make_case(r=36, m=m, P=16, N=30, seed=17, q_scale=0.02, use_X=use_X, u_max=800.0, amp=0.1, x_box=4.0)
+    (xe, ue, se), Je = oracle_solution(case)
+    locp = product_locp(case)
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
+                case['omega'], z=case['z'])
+    J, ok, stats = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
+    assert rel(x, xe) <= 2e-4 and rel(u, ue) <= 2e-4
+    for k in range(case['N']):
+        np.testing.assert_allclose(x[k + 1], case['Ad'][k] @ x[k] + case['Bd'][k] @ u[k] + case['dd'][k], rtol=0, atol=1e-12)
