@@ -179,13 +179,14 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     const int N = a.N, n = a.n, m = a.m, nz = a.nz;
     LqrLds L;
     lqr_carve(L, (lptr)smem, n, m);
-    lptr HQH = L.red + 20;                    // placed after the carve: n x n
-    lptr zt = HQH + (size_t)n * n;            // nz scratch (16)
+    lptr QH = L.red + 20;                     // placed after the carve: Q H (nz x n); c_xx = H^T (Q H) on the fly
+    lptr zt = QH + (size_t)16 * n;            // nz scratch (16)
     lptr part = zt + 16;                      // blockDim
     // SSM scratch (MODEL 1): polynomial work space, per-step (A, B, d), observed output
     ssm::Work sw;
-    lptr Al = part + NT, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m, zs = dl + n, xl = zs + 16;
-    if constexpr (MODEL == 1) ssm::carve(sw, xl + n, S);
+    lptr zs = part + NT, xl = zs + 16;        // observed output, a state vector (both models)
+    lptr Al = xl + n, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m;      // MODEL 1 only (not allocated for MODEL 0)
+    if constexpr (MODEL == 1) ssm::carve(sw, dl + n, S);
     cgptr Hm = MODEL == 0 ? T.H : S.H;
     cgptr zref = MODEL == 0 ? T.z_ref : S.z_ref;
     const size_t lstride = (size_t)n * n + (size_t)n * m + n;
@@ -316,15 +317,19 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
             zerr((clptr)xl, N);
             for (int e = tid; e < n * n; e += nt) {
                 const int r = e / n, c = e - r * n;
-                double v = 0.0, hq = 0.0;
+                double v = 0.0;
                 for (int s = 0; s < nz; ++s) {
-                    double q1 = 0.0, q2 = 0.0;
-                    for (int s2 = 0; s2 < nz; ++s2) { q1 = fma(Qfg[s * nz + s2], Hm[s2 * n + c], q1); q2 = fma(Qg[s * nz + s2], Hm[s2 * n + c], q2); }
+                    double q1 = 0.0;
+                    for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qfg[s * nz + s2], Hm[s2 * n + c], q1);
                     v = fma(Hm[s * n + r], q1, v);
-                    hq = fma(Hm[s * n + r], q2, hq);
                 }
                 L.P[e] = v;
-                HQH[e] = hq;
+            }
+            for (int e = tid; e < nz * n; e += nt) {
+                const int s = e / n, c = e - s * n;
+                double q2 = 0.0;
+                for (int s2 = 0; s2 < nz; ++s2) q2 = fma(Qg[s * nz + s2], Hm[s2 * n + c], q2);
+                QH[e] = q2;
             }
             for (int e = tid; e < n; e += nt) {
                 double v = 0.0;
@@ -416,7 +421,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 __syncthreads();
                 for (int e = tid; e < n * n; e += nt) {
                     const int r = e / n, c = e - r * n;
-                    double v = HQH[e];
+                    double v = 0.0;
+                    for (int s = 0; s < nz; ++s) v = fma(Hm[s * n + r], QH[s * n + c], v);
                     for (int k = 0; k < n; ++k) v = fma(At[k * n + r], L.W[k * n + c], v);
                     for (int s = 0; s < m; ++s) {
                         v = fma(L.Kk[s * n + r], L.PB[s * n + c], v);
@@ -609,8 +615,8 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
                u_last ? dul.as<double>() : nullptr, dQ.as<double>(), dR.as<double>(), dQf.as<double>(), ox.as<double>(),
                ou.as<double>(), oK.as<double>(), oc.as<double>(), oi.as<int>(), work.as<double>(), iwork.as<int>(), stride,
                hs ? lin.as<double>() : nullptr, ssm_mode, dt};
-    size_t lds = (lqr_lds_doubles(n, m) + 20 + (size_t)n * n + 16 + NT + lstride + 16 + n) * sizeof(double);
-    if (hs) lds += sizeof(double) * ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns);
+    size_t lds = (lqr_lds_doubles(n, m) + 20 + (size_t)16 * n + 16 + NT + 16 + n) * sizeof(double);
+    if (hs) lds += sizeof(double) * (lstride + ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns));
     SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
     if (ht) {
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -65,3 +65,32 @@ def test_ilqr_full_solve(golden, tag, N):
     # batched: two problems in one launch equal the single solves
     xb, ub, Kb = il.ilqr_computation(np.stack([g[tag + '_x0'], g[tag + '_x0']]))
     np.testing.assert_array_equal(xb[0], x); np.testing.assert_array_equal(xb[1], x)
+
+
+@pytest.mark.parametrize('r,m', [(30, 4), (36, 4)])
+def test_ilqr_diamond_sizes_vs_oracle(r, m):
+    """iLQR at the Diamond state sizes (n_x = 60 and the shipped r = 36 basis, n_x = 72) against the oracle loop."""
+    import io, contextlib
+    from oracle import lqr as olqr, tpwl as otpwl
+    from helpers import golden_problem, product_tpwl
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    P, N, dt = 8, 15, 0.05
+    model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, 40, 55, q_scale=0.2)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tp.pre_discretize(dt)
+    Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    H, z_ref = np.asarray(tp.H), np.asarray(tp.z_ref)
+    Qz = np.diag([0., 0., 0., 100., 100., 10.]); R = 1e-3 * np.eye(m)
+    th = np.linspace(0, 1.0, N + 1)
+    zt = np.zeros((N + 1, 6)); zt[:, 3] = -0.02 * np.sin(th); zt[:, 4] = 0.01 * np.sin(2 * th)
+    zt = zt + z_ref
+    x0 = 1e-3 * np.random.default_rng(1).standard_normal(2 * r)
+    il = iLQR(dt, tp, QuadraticCost(Q=Qz, R=R, Qf=10 * Qz), N)
+    il.set_target(zt)
+    x, u, K = il.ilqr_computation(x0)
+    o = olqr.ILQR(model, Ad, Bd, dd, H, z_ref, Qz, R, 10 * Qz, N)
+    xo, uo, Ko = o.solve(x0, zt)
+    assert int(il.iters[0]) == len(o.trace) - 1
+    close(x, xo, 1e-6); close(u, uo, 1e-6); close(K, Ko, 1e-5)
