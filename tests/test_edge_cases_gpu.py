@@ -1,0 +1,149 @@
+"""GPU edge cases along the hot path: empty / single-row / ragged (non tile-multiple) shapes and the smallest
+problems each kernel accepts, each against the oracle."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from oracle import pod as opod, tpwl as otpwl, locp as olocp, lqr as olqr
+from helpers import golden_problem, product_tpwl, small_rom, Poly
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-11):
+    np.testing.assert_allclose(a, b, rtol=0, atol=rtol * max(1.0, float(np.abs(b).max()) if np.size(b) else 1.0))
+
+
+def quiet(fn, *a):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a)
+
+
+@pytest.mark.parametrize('n_nodes,r', [(1, 1), (7, 3), (43, 17), (100, 33)])
+def test_projection_ragged_shapes(n_nodes, r):
+    from sofacontrol_amd.mor.pod import POD
+    U, q_ref, v_ref = small_rom(n_nodes, r, 5)
+    rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    rng = np.random.default_rng(1)
+    for B in (0, 1, 2, 129):
+        X = q_ref + rng.standard_normal((B, 3 * n_nodes))
+        got = rom.compute_RO_state(qf=X)
+        assert got.shape == (B, r)
+        if B:
+            close(got, opod.project(U, q_ref, X))
+            close(rom.compute_FO_state(q=got), got @ U.T + q_ref)
+    x = np.concatenate((v_ref, q_ref)) + rng.standard_normal(6 * n_nodes)
+    V = np.kron(np.eye(2), U)
+    close(rom.compute_RO_state(xf=x), V.T @ (x - np.concatenate((v_ref, q_ref))))
+    with pytest.raises(RuntimeError):
+        rom.compute_RO_state()
+
+
+@pytest.mark.parametrize('n_s,n_f', [(1, 5), (3, 200), (130, 77), (257, 1000)])
+def test_gramian_ragged(n_s, n_f):
+    from sofacontrol_amd.mor.pod import gramian
+    S = np.random.default_rng(2).standard_normal((n_s, n_f))
+    G = gramian(S)
+    close(G, S @ S.T, 1e-12)
+    np.testing.assert_array_equal(G, G.T)
+
+
+def test_tpwl_single_point_and_empty_rollout():
+    model, U, q_ref, v_ref, Hf = golden_problem(3, 2, 1, 10, 8)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    quiet(tp.pre_discretize, 0.05)
+    x = np.random.default_rng(0).standard_normal(6)
+    assert tp.calc_nearest_point(x) == 0
+    A, B, d = tp.get_jacobians(x, dt=0.05)
+    np.testing.assert_array_equal(A, tp.A_d[0])
+    X, Z = tp.rollout(x, np.zeros((0, 2)), 0.05)
+    assert X.shape == (1, 6) and Z.shape == (1, 6)
+    np.testing.assert_array_equal(X[0], x)
+    close(Z[0], tp.H @ x + tp.z_ref)
+    assert tp.calc_nearest_point(np.zeros((0, 6))).shape == (0,)
+
+
+def test_locp_smallest_problem():
+    """N = 1, n_u = 1, n_z = 1, one U row, one X row, trust region on."""
+    from sofacontrol_amd.scp.locp import LOCP
+    rng = np.random.default_rng(4)
+    n = 2
+    A = np.array([[0.9, 0.1], [0.0, 0.8]]); B = np.array([[0.0], [0.5]]); d = np.array([0.01, 0.0])
+    H = np.array([[1.0, 0.0]]); Qz = np.array([[10.0]]); R = np.array([[1e-2]])
+    x0 = np.array([0.1, -0.2]); xk = np.stack([x0, A @ x0 + d]); z = np.array([[0.0], [0.3]])
+    U = (np.array([[1.0]]), np.array([0.4])); X = (np.array([[0.0, 1.0]]), np.array([0.05]))
+    qp = olocp.build_qp(1, H, Qz, R, [A], [B], [d], x0, xk, 0.5, 2.0, z=z, U=U, X=X)
+    w, _, info = olocp.solve_exact(qp, tol=1e-12)
+    xe, ue, se = olocp.split(qp, w)
+    locp = LOCP(1, H, Qz, R, U=Poly(*U), X=Poly(*X))
+    locp.update([A], [B], [d], x0, xk, 0.5, 2.0, z=z)
+    J, ok, _ = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    close(x, xe, 1e-7); close(u, ue, 1e-7)
+    assert abs(J - olocp.objective(qp, w)) <= 1e-8 * max(1.0, abs(J))
+
+
+def test_gusto_zero_iterations_limit(golden):
+    """max_gusto_iters = 0 after the constructor solve: exactly one QP per call (gusto.py:163-172)."""
+    from sofacontrol_amd.scp.models.tpwl import TPWLGuSTO
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g = golden('g6_gusto')
+    model, U, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 30, q_scale=0.05)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    gm = TPWLGuSTO(tp)
+    quiet(gm.pre_discretize, 0.05)
+    N, dt = 12, 0.05
+    x0 = np.zeros(8); u_init = np.zeros((N, 3))
+    x_init, _ = gm.rollout(x0, u_init, dt)
+    from scipy.interpolate import interp1d
+    z = interp1d(g['t'], g['zt'], axis=0)(dt * np.arange(N + 1))
+    gu = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, x_char=g['x_char'], f_char=g['f_char'],
+               convg_thresh=1e-3, max_gusto_iters=0, U=Poly(g['U_A'], g['U_b']))
+    gu.solve(x0, u_init, x_init, z=z)
+    assert int(gu.iters[0]) == 1
+
+
+def test_ilqr_horizon_one():
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    model, U, q_ref, v_ref, Hf = golden_problem(3, 2, 4, 10, 9, q_scale=0.1)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    quiet(tp.pre_discretize, 0.05)
+    Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    Qz = np.diag([0., 0., 0., 50., 50., 5.]); R = 1e-2 * np.eye(2)
+    zt = np.asarray(tp.z_ref) + np.array([[0, 0, 0, 0.01, 0.0, 0], [0, 0, 0, 0.02, -0.01, 0]])
+    x0 = 1e-3 * np.ones(6)
+    il = iLQR(0.05, tp, QuadraticCost(Q=Qz, R=R, Qf=Qz), 1)
+    il.set_target(zt)
+    x, u, K = il.ilqr_computation(x0)
+    o = olqr.ILQR(model, Ad, Bd, dd, np.asarray(tp.H), np.asarray(tp.z_ref), Qz, R, Qz, 1)
+    xo, uo, Ko = o.solve(x0, zt)
+    assert int(il.iters[0]) == len(o.trace) - 1
+    close(x, xo, 1e-8); close(u, uo, 1e-7)
+
+
+def test_errors_are_loud():
+    """Bad arguments come back as HipError (RuntimeError) with the C ABI's message, never a silent result."""
+    from sofacontrol_amd import _lib
+    from sofacontrol_amd.mor.pod import POD
+    U, q_ref, v_ref = small_rom(5, 2, 1)
+    rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    with pytest.raises(Exception):
+        rom.compute_RO_state(qf=np.zeros(7))          # wrong length
+    model, U, q_ref, v_ref, Hf = golden_problem(3, 2, 4, 10, 9)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.utils import QuadraticCost, Polyhedron
+    from sofacontrol_amd.scp.locp import LOCP
+    locp = LOCP(3, np.eye(2), np.eye(2), np.eye(1), dU=Polyhedron(np.eye(1), np.ones(1)))
+    locp.update([np.eye(2)] * 3, [np.ones((2, 1))] * 3, [np.zeros(2)] * 3, np.zeros(2), np.zeros((4, 2)), 1.0, 1.0)
+    with pytest.raises(RuntimeError, match='dU'):
+        locp.solve()                                   # input-rate constraints are rejected, not ignored
+    il = iLQR(0.05, tp, QuadraticCost(Q=np.eye(6), R=np.eye(2), Qf=np.eye(6)), 5)
+    il.params.do_linesearch = False
+    il.set_target(np.zeros((6, 6)))
+    with pytest.raises(NotImplementedError):
+        il.ilqr_computation(np.zeros(6))
