@@ -98,6 +98,41 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
                 pod_projection_gbs=proj_gbs)
 
 
+def closed_loop_latency(w, rom, tp):
+    """Per-simulation-step pieces of the closed loop (closed_loop_controller.py:65-86, controllers.py:96-98):
+    projection of ONE full state through the host-pointer API (PCIe both ways inside the time) and one EKF
+    predict + update step.  Latency bound: reported in microseconds, not GB/s."""
+    from sofacontrol_amd.tpwl.observer import DiscreteEKFObserver
+    import scipy.sparse as sp
+    n_f, r = w['U'].shape
+    rng = np.random.default_rng(5)
+    x = np.concatenate((w['v_ref'], w['q_ref'])) + rng.standard_normal(2 * n_f)
+    for _ in range(20):
+        rom.compute_RO_state(xf=x)
+    t0 = time.perf_counter()
+    reps = 300
+    for _ in range(reps):
+        rom.compute_RO_state(xf=x)
+    t_proj = (time.perf_counter() - t0) / reps
+    nodes = np.arange(0, 10 * 150, 150)
+    Cf = sp.lil_matrix((30, 2 * n_f))
+    for i, nd in enumerate(nodes):
+        for a in range(3):
+            Cf[3 * i + a, n_f + 3 * nd + a] = 1.0
+    tp.set_measurement_model(Cf.tocsr())
+    ekf = DiscreteEKFObserver(tp)
+    u = np.full(w['m'], 100.0)
+    y = tp.y_ref + 0.01 * rng.standard_normal(30)
+    for _ in range(10):
+        ekf.update(u, y, w['dt'])
+    t0 = time.perf_counter()
+    for _ in range(100):
+        ekf.update(u, y, w['dt'])
+    t_ekf = (time.perf_counter() - t0) / 100
+    return {'project_one_state_us': t_proj * 1e6, 'ekf_step_us': t_ekf * 1e6,
+            'workload': 'one full state (2 x %d) -> 2r = %d; EKF n_x = %d, n_y = 30; host-pointer API' % (n_f, 2 * r, 2 * r)}
+
+
 def secondary(L, _lib, rank, world, dist):
     """Secondary metrics of SURVEY.md section 8(d), measured outside the timed region of the headline metric:
     C3 iLQR iterations/s (SSM r=10, n_u=8, horizon 100), C4 per-GPU share of the snapshot Gramian (10 000
@@ -291,6 +326,8 @@ def main():
             b.free()
         try:
             sec = secondary(L, _lib, rank, world, dist)
+            if rank == 0:
+                sec['closed_loop_step'] = closed_loop_latency(w, rom, tp)
         except Exception as exc:      # never lose the headline line to a secondary measurement
             sec = {'error': repr(exc)}
     if rank != 0:

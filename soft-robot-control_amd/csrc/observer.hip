@@ -8,6 +8,12 @@ struct sekf {
     int n = 0, m = 0, ny = 0;
     srh::DevBuf C, y_ref, W, V, x, Sigma, scratch, ext;
     size_t lds = 0;
+    // pinned host mirrors of the per-step input (u, y) and output (x, status): one copy each way per step
+    double *pin_in = nullptr, *pin_out = nullptr;
+    ~sekf() {
+        if (pin_in) (void)hipHostFree(pin_in);
+        if (pin_out) (void)hipHostFree(pin_out);
+    }
 };
 
 namespace {
@@ -208,6 +214,8 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
     }
     if (y_ref && (rc = h->y_ref.upload(y_ref, sizeof(double) * n_y))) { delete h; return rc; }
     SRH_CHECK_HIP(hipMemset(h->x.p, 0, sizeof(double) * n));
+    SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_in, sizeof(double) * (h->m + n_y) + 64, hipHostMallocDefault));
+    SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (n + 2), hipHostMallocDefault));
     SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ekf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)h->lds));
     *out = h;
@@ -243,11 +251,13 @@ int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, co
     SRH_REQUIRE(!ext || (B_d && d_d), "sekf_step: A_d given without B_d, d_d");
     SRH_REQUIRE(!u || ext || h->model->has_discrete, "sekf_step: model has not been pre-discretised");
     const int n = h->n, m = h->m, ny = h->ny;
+    // scratch layout (device): [u (m) | y (ny) | status (int, 8 bytes) ]; x lives in h->x
     double *su = h->scratch.as<double>();
     double *sy = su + m;
     int *st = (int *)(sy + ny);
-    if (u) SRH_CHECK_HIP(hipMemcpy(su, u, sizeof(double) * m, hipMemcpyHostToDevice));
-    if (y) SRH_CHECK_HIP(hipMemcpy(sy, y, sizeof(double) * ny, hipMemcpyHostToDevice));
+    if (u) memcpy(h->pin_in, u, sizeof(double) * m);
+    if (y) memcpy(h->pin_in + m, y, sizeof(double) * ny);
+    SRH_CHECK_HIP(hipMemcpyAsync(su, h->pin_in, sizeof(double) * (m + ny), hipMemcpyHostToDevice, nullptr));
     double *e = h->ext.as<double>();
     if (ext && u) {
         SRH_CHECK_HIP(hipMemcpy(e, A_d, sizeof(double) * n * n, hipMemcpyHostToDevice));
@@ -266,13 +276,16 @@ int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, co
     a.status = st;
     ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
     SRH_CHECK_HIP(hipGetLastError());
+    SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out, h->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
+    SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out + n, st, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     int status = 0;
-    SRH_CHECK_HIP(hipMemcpy(&status, st, sizeof(int), hipMemcpyDeviceToHost));
+    memcpy(&status, h->pin_out + n, sizeof(int));
     if (status != 0) {
         srh::set_error("sekf_step: innovation covariance S is not positive definite");
         return SRH_ENUMERIC;
     }
-    if (x_out) return h->x.download(x_out, sizeof(double) * n);
+    if (x_out) memcpy(x_out, h->pin_out, sizeof(double) * n);
     return SRH_OK;
 }
 

@@ -375,7 +375,40 @@ struct srom {
     int64_t ntiles = 0;
     srh::DevBuf U, q_ref, v_ref, ufrag, ulift, work;
     size_t work_bytes = 0;
+    // per-simulation-step calls (one state in, one reduced state out) reuse these instead of paying
+    // hipMalloc / hipFree and a pageable-memory copy per call: device staging + pinned host mirrors
+    static constexpr size_t STAGE_BYTES = 1 << 20;
+    void *st_dev_in = nullptr, *st_dev_out = nullptr, *st_host_in = nullptr, *st_host_out = nullptr;
+    ~srom() {
+        if (st_dev_in) (void)hipFree(st_dev_in);
+        if (st_dev_out) (void)hipFree(st_dev_out);
+        if (st_host_in) (void)hipHostFree(st_host_in);
+        if (st_host_out) (void)hipHostFree(st_host_out);
+    }
 };
+
+static int ensure_staging(srom *h) {
+    if (h->st_dev_in) return SRH_OK;
+    SRH_CHECK_HIP(hipMalloc(&h->st_dev_in, srom::STAGE_BYTES));
+    SRH_CHECK_HIP(hipMalloc(&h->st_dev_out, srom::STAGE_BYTES));
+    SRH_CHECK_HIP(hipHostMalloc(&h->st_host_in, srom::STAGE_BYTES, hipHostMallocDefault));
+    SRH_CHECK_HIP(hipHostMalloc(&h->st_host_out, srom::STAGE_BYTES, hipHostMallocDefault));
+    return SRH_OK;
+}
+
+// small host-pointer call through the staging buffers: fn(dev_in, dev_out) enqueues the kernels on stream 0
+template <typename F>
+static int staged_call(srom *h, const double *in, size_t in_bytes, double *out, size_t out_bytes, F fn) {
+    int rc = ensure_staging(h);
+    if (rc) return rc;
+    memcpy(h->st_host_in, in, in_bytes);
+    SRH_CHECK_HIP(hipMemcpyAsync(h->st_dev_in, h->st_host_in, in_bytes, hipMemcpyHostToDevice, nullptr));
+    if ((rc = fn((const double *)h->st_dev_in, (double *)h->st_dev_out))) return rc;
+    SRH_CHECK_HIP(hipMemcpyAsync(h->st_host_out, h->st_dev_out, out_bytes, hipMemcpyDeviceToHost, nullptr));
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    memcpy(out, h->st_host_out, out_bytes);
+    return SRH_OK;
+}
 
 static int ensure_work(srom *h, size_t bytes) {
     if (bytes <= h->work_bytes) return SRH_OK;
@@ -525,6 +558,11 @@ int srom_project(srom_t *h, int which, const double *X, int64_t B, double *out) 
     SRH_REQUIRE(which >= SROM_Q && which <= SROM_RAW, "srom_project: Must specify vector type");
     if (B == 0) return SRH_OK;
     const int nblk = (which == SROM_X) ? 2 : 1;
+    const size_t inb = sizeof(double) * B * nblk * h->n_f, outb = sizeof(double) * B * nblk * h->r;
+    if (inb <= srom::STAGE_BYTES && outb <= srom::STAGE_BYTES)
+        return staged_call(h, X, inb, out, outb, [&](const double *di, double *dout) {
+            return srom_project_dev(h, which, di, B, nblk * h->n_f, dout, nblk * h->r, nullptr);
+        });
     srh::DevBuf dX, dO;
     int rc;
     if ((rc = dX.upload(X, sizeof(double) * B * nblk * h->n_f))) return rc;
@@ -577,6 +615,11 @@ int srom_lift(srom_t *h, int which, const double *Xr, int64_t B, double *out) {
     SRH_REQUIRE(which >= SROM_Q && which <= SROM_RAW, "srom_lift: Must specify vector type");
     if (B == 0) return SRH_OK;
     const int nblk = (which == SROM_X) ? 2 : 1;
+    const size_t inb = sizeof(double) * B * nblk * h->r, outb = sizeof(double) * B * nblk * h->n_f;
+    if (inb <= srom::STAGE_BYTES && outb <= srom::STAGE_BYTES)
+        return staged_call(h, Xr, inb, out, outb, [&](const double *di, double *dout) {
+            return srom_lift_dev(h, which, di, B, nblk * h->r, dout, nblk * h->n_f, nullptr);
+        });
     srh::DevBuf dX, dO;
     int rc;
     if ((rc = dX.upload(Xr, sizeof(double) * B * nblk * h->r))) return rc;
