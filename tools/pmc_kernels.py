@@ -1,0 +1,23 @@
+"""Launches the two MFMA kernels of the path (POD projection, snapshot Gramian) at their bench shapes for
+rocprofv3 --pmc passes (profiles/r01_mfma_util.*)."""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, 'soft-robot-control_amd'); sys.path.insert(0, '.')
+import workloads as wl
+from sofacontrol_amd import _lib
+from sofacontrol_amd.mor.pod import POD
+w = wl.diamond_c2()
+L = _lib.lib()
+rom = POD(dict(U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
+n_f, r = w['U'].shape
+B = 65536
+dX = _lib.DeviceBuffer.from_array(wl.snapshots(w['q_ref'], B, seed=2)); dXr = _lib.DeviceBuffer(B * r * 8)
+for _ in range(6):
+    _lib.check(L.srom_project_dev(rom.handle, 0, dX.ptr, C.c_int64(B), C.c_int64(n_f), dXr.ptr, C.c_int64(r), None), 'project')
+_lib.sync()
+n_s, nf2 = 10000, 6250
+dS = _lib.DeviceBuffer.from_array(np.random.default_rng(7).standard_normal((n_s, nf2))); dG = _lib.DeviceBuffer(n_s * n_s * 8)
+for _ in range(4):
+    _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(nf2), C.c_int64(nf2), dG.ptr, None), 'gramian')
+_lib.sync()
+print('done')
