@@ -25,10 +25,10 @@ __global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;        // wave sub-tile origin
-    const int lrow = tid >> 1, lhalf = tid & 1;                    // loader: row, 8-column half
-    const int64_t gi = (int64_t)ti * TB + lrow, gj = (int64_t)tj * TB + lrow;
-    const double *pi = S + (gi < n_s ? gi : 0) * lds, *pj = S + (gj < n_s ? gj : 0) * lds;
-    const bool vi = gi < n_s, vj = gj < n_s;
+    // loader: 16 consecutive lanes read the 16 columns (128 B) of one row of the chunk -- a wave instruction
+    // covers 4 rows x 128 B, fully coalesced (one 8-byte element per lane; per-lane rows r4 + 16 q, q < 8)
+    const int lc = tid & 15, r4 = tid >> 4;
+    const int64_t gi0 = (int64_t)ti * TB + r4, gj0 = (int64_t)tj * TB + r4;
 
     g_d4 acc[4][4];
 #pragma unroll
@@ -38,19 +38,21 @@ __global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__
 
     double ri[8], rj[8];
     auto gload = [&](int64_t k0) {
-        const int64_t kb = k0 + 8 * lhalf;
+        const int64_t kc = k0 + lc;
+        const bool vk = kc < n_f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const bool vk = kb + q < n_f;
-            ri[q] = (vi && vk) ? pi[kb + q] : 0.0;
-            rj[q] = (vj && vk) ? pj[kb + q] : 0.0;
+            const int64_t a = gi0 + 16 * q, b2 = gj0 + 16 * q;
+            ri[q] = (vk && a < n_s) ? S[a * lds + kc] : 0.0;
+            rj[q] = (vk && b2 < n_s) ? S[b2 * lds + kc] : 0.0;
         }
     };
+    // k-major panel: element (row, k) at [k][row]; the 16 lanes of a store group differ in k: LDT odd -> all banks
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            Xi[(buf * KC + 8 * lhalf + q) * LDT + lrow] = ri[q];
-            Xj[(buf * KC + 8 * lhalf + q) * LDT + lrow] = rj[q];
+            Xi[(buf * KC + lc) * LDT + r4 + 16 * q] = ri[q];
+            Xj[(buf * KC + lc) * LDT + r4 + 16 * q] = rj[q];
         }
     };
     const int64_t nchunk = (n_f + KC - 1) / KC;
