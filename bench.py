@@ -199,6 +199,7 @@ def secondary(L, _lib, rank, world, dist):
                          'frac_of_f64_mfma_peak': flop / (ms.value * 1e-3) / 1e12 / 78.6}
     if dist is not None:
         import torch
+        dist.all_reduce(G)                      # untimed: RCCL sets up its channels for this size
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
         dist.all_reduce(G)
