@@ -178,4 +178,60 @@ __device__ __forceinline__ void chol_solve_neg_reg(const double (&Lr)[M * M], co
     for (int i = 0; i < M; ++i) x[i * xstride] = -y[i];
 }
 
+// ------------------------------------------------------------------ f64 MFMA product on LDS operands
+typedef double qp_d4 __attribute__((ext_vector_type(4)));
+
+// C[i][j] = sum_{k<K} Lm[k][i] * Rm[k][j]  for i < 16*MT, j < 16*NTl.  Lm, Rm: k-major rows (K x ld) in
+// LDS, K a multiple of 4 (zero padded).  Rows i >= vrows of C are stored as exact zeros; rows >= srows are
+// not stored at all.
+// v_mfma_f64_16x16x4: A lane l holds Lm^T[i=l&15][k=l>>4], B lane holds Rm[k=l>>4][j=l&15];
+// D reg q of lane l is C[row = (l>>4) + 4q][col = l&15].
+__device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, int K, int MT, int NTl, int ld, int vrows,
+                                         int srows = 1 << 30) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int ntiles = MT * NTl;
+    for (int t0 = wave; t0 < ntiles; t0 += 2 * nw) {
+        const int t1 = t0 + nw;
+        const bool has1 = t1 < ntiles;
+        const int ti0 = t0 / NTl, tj0 = t0 - ti0 * NTl;
+        const int ti1 = has1 ? t1 / NTl : ti0, tj1 = has1 ? t1 - ti1 * NTl : tj0;
+        clptr la0 = Lm + kk * ld + 16 * ti0 + l16, rb0 = Rm + kk * ld + 16 * tj0 + l16;
+        clptr la1 = Lm + kk * ld + 16 * ti1 + l16, rb1 = Rm + kk * ld + 16 * tj1 + l16;
+        qp_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        int k0 = 0;
+        // 4 k-steps per trip: 16 independent LDS reads in flight before the 8 MFMAs consume them
+        for (; k0 + 16 <= K; k0 += 16) {
+            double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o = (k0 + 4 * u) * ld;
+                a0[u] = la0[o]; b0[u] = rb0[o]; a1[u] = la1[o]; b1[u] = rb1[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc1, 0, 0, 0);
+            }
+        }
+        for (; k0 < K; k0 += 4) {
+            const double a0 = la0[k0 * ld], b0 = rb0[k0 * ld];
+            const double a1 = la1[k0 * ld], b1 = rb1[k0 * ld];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r0 = 16 * ti0 + kk + 4 * q;
+            if (r0 < srows) C[r0 * ldc + 16 * tj0 + l16] = r0 < vrows ? acc0[q] : 0.0;
+            if (has1) {
+                const int r1 = 16 * ti1 + kk + 4 * q;
+                if (r1 < srows) C[r1 * ldc + 16 * tj1 + l16] = r1 < vrows ? acc1[q] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+
 }  // namespace wg

@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 512;
 
 // ---- tiny dense helpers (row-major, any address space, runtime sizes; one output per thread-iteration)
 // C (M x N) = alpha * op(A) * op(B) + beta * C0 ; op = transpose flag.  Ends with __syncthreads().
@@ -15,7 +15,20 @@ __device__ inline void mm(CP C, int ldc, AP A, int lda, BP B, int ldb, int M, in
     for (int e = threadIdx.x; e < M * N; e += blockDim.x) {
         const int i = e / N, j = e - i * N;
         double acc = 0.0;
-        for (int k = 0; k < K; ++k) {
+        int k = 0;
+        // 8 independent operand pairs in flight per trip: with one or two waves per SIMD the dependent
+        // load -> fma chain of a rolled loop is bound by the LDS / L2 latency of every single k
+        for (; k + 8 <= K; k += 8) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                av[q] = TA ? A[(k + q) * lda + i] : A[i * lda + k + q];
+                bv[q] = TB ? B[j * ldb + k + q] : B[(k + q) * ldb + j];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
+        }
+        for (; k < K; ++k) {
             const double a = TA ? A[k * lda + i] : A[i * lda + k];
             const double b = TB ? B[j * ldb + k] : B[k * ldb + j];
             acc = fma(a, b, acc);
@@ -38,14 +51,17 @@ struct LqrLds {
     liptr flag;
 };
 
-__host__ __device__ inline size_t lqr_lds_doubles(int n, int m) {
-    return 3 * (size_t)n * n + 2 * (size_t)n * m + 2 * 256 + 2 * (size_t)m * n + 4 * (size_t)n + 32 + 16 + 4;
+// nn: doubles of each of the three square work matrices (n * n; 256 when the MFMA panels replace them)
+__host__ __device__ inline size_t lqr_lds_doubles(int n, int m, size_t nn = 0) {
+    if (nn == 0) nn = (size_t)n * n;
+    return 3 * nn + 2 * (size_t)n * m + 2 * 256 + 2 * (size_t)m * n + 4 * (size_t)n + 32 + 16 + 4;
 }
 
-__device__ inline void lqr_carve(LqrLds &L, lptr base, int n, int m) {
+__device__ inline void lqr_carve(LqrLds &L, lptr base, int n, int m, size_t nn = 0) {
+    if (nn == 0) nn = (size_t)n * n;
     lptr p = base;
     auto take = [&](size_t c) { lptr q = p; p += c; return q; };
-    L.P = take((size_t)n * n); L.W = take((size_t)n * n); L.T = take((size_t)n * n);
+    L.P = take(nn); L.W = take(nn); L.T = take(nn);
     L.PB = take((size_t)n * m); L.BK = take((size_t)n * m);
     L.Quu = take(256); L.Lc = take(256);
     L.Kt = take((size_t)m * n); L.Kk = take((size_t)m * n);
@@ -156,6 +172,42 @@ __global__ __launch_bounds__(NT) void dare_fp_kernel(const double *A, const doub
     if (threadIdx.x == 0 && iters) iters[p] = it;
 }
 
+// K = -Q~uu^-1 Q~ux (columns of L.BK -> L.Kk), k = -Q~uu^-1 Q_u (L.u2 -> L.u1) with the Cholesky factor of the
+// tiny Q~uu recomputed in registers by every thread (no serial thread-0 phase, no barrier before the solves).
+// Returns false (uniformly) if Q~uu is not positive definite.
+template <int M>
+__device__ __forceinline__ bool ilqr_gain_t(LqrLds &L, int n) {
+    double Lr[M * M], inv[M];
+    if (!wg::chol_reg<M>(L.Quu, M, 0.0, Lr, inv)) return false;
+    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
+        if (j < n) wg::chol_solve_neg_reg<M>(Lr, inv, L.BK + j, n, L.Kk + j, n);
+        else wg::chol_solve_neg_reg<M>(Lr, inv, L.u2, 1, L.u1, 1);
+    }
+    __syncthreads();
+    return true;
+}
+
+__device__ __forceinline__ bool ilqr_gain(LqrLds &L, int n, int m) {
+    switch (m) {
+        case 1: return ilqr_gain_t<1>(L, n);
+        case 2: return ilqr_gain_t<2>(L, n);
+        case 3: return ilqr_gain_t<3>(L, n);
+        case 4: return ilqr_gain_t<4>(L, n);
+        case 5: return ilqr_gain_t<5>(L, n);
+        case 6: return ilqr_gain_t<6>(L, n);
+        case 7: return ilqr_gain_t<7>(L, n);
+        case 8: return ilqr_gain_t<8>(L, n);
+        default: break;
+    }
+    if (!chol16(L.Quu, L.Lc, m, L.flag)) return false;
+    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
+        if (j < n) wg::chol_solve_neg(L.Lc, m, L.BK + j, n, L.Kk + j, n);
+        else wg::chol_solve_neg(L.Lc, m, L.u2, 1, L.u1, 1);
+    }
+    __syncthreads();
+    return true;
+}
+
 // ------------------------------------------------------------------ iLQR (ilqr.py:27-300)
 struct IlqrArgs {
     int N, n, m, nz;
@@ -168,6 +220,9 @@ struct IlqrArgs {
     size_t work_stride;
     double *lin;           // SSM model only, per problem: 2 x N x (n n + n m + n) per-step (A, B, d)
     int ssm_mode;          // SSM model only: discretisation mode (ssm_dev.h)
+    int stage_ab;          // 1: the backward pass stages (A_t, B_t) in LDS
+    size_t panel_off;      // doubles from the start of LDS to the MFMA panels
+    int mfma;              // 1: backward pass on f64 MFMA products over padded LDS panels (n_x + n_u panels fit LDS)
     double dt;
 };
 
@@ -178,7 +233,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, n = a.n, m = a.m, nz = a.nz;
     LqrLds L;
-    lqr_carve(L, (lptr)smem, n, m);
+    lqr_carve(L, (lptr)smem, n, m, a.mfma ? 256 : 0);
     lptr QH = L.red + 20;                     // placed after the carve: Q H (nz x n); c_xx = H^T (Q H) on the fly
     lptr zt = QH + (size_t)16 * n;            // nz scratch (16)
     lptr part = zt + 16;                      // blockDim
@@ -187,6 +242,10 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     lptr zs = part + NT, xl = zs + 16;        // observed output, a state vector (both models)
     lptr Al = xl + n, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m;      // MODEL 1 only (not allocated for MODEL 0)
     if constexpr (MODEL == 1) ssm::carve(sw, dl + n, S);
+    // MFMA backward pass: padded panels P / G, [A|B], W = P [A|B] (NPa x ld each) and B^T [A|B] (16 x ld)
+    const int NPa = (n + m + 15) & ~15, ldp = NPa + 1, NK4 = (n + 3) & ~3, n16 = (n + 15) & ~15;
+    lptr Pm = (lptr)smem + a.panel_off, ABm = Pm + (size_t)NPa * ldp, Wm = ABm + (size_t)NPa * ldp, RBm = Wm + (size_t)NPa * ldp;
+    lptr Hl = RBm + (size_t)16 * ldp, qz = Hl + (size_t)16 * n;      // H (nz x n) and Q (z - z*) in LDS (MFMA path)
     cgptr Hm = MODEL == 0 ? T.H : S.H;
     cgptr zref = MODEL == 0 ? T.z_ref : S.z_ref;
     const size_t lstride = (size_t)n * n + (size_t)n * m + n;
@@ -337,15 +396,9 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 L.v1[e] = v;     // p
             }
             __syncthreads();
-            bool restart = false;
-            for (int t = N - 1; t >= 0; --t) {
-                cgptr At, Bt;
-                if constexpr (MODEL == 0) {
-                    const size_t i = (size_t)idx[t];
-                    At = T.Ad + i * n * n; Bt = T.Bd + i * n * m;
-                } else {
-                    At = (cgptr)lin + (size_t)t * lstride; Bt = At + (size_t)n * n;
-                }
+            // one backward stage on (A_t, B_t) -- in LDS when the staging panels fit (a.stage_ab), else straight from
+            // the HBM tables / per-step linearisations; returns false when Q~_uu is not positive definite
+            auto stage = [&](auto At, auto Bt, int t) -> bool {
                 // c_x = H^T Q (z - z*), c_u = R (u_t - u_{t-1})
                 for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)t * n + e];
                 __syncthreads();
@@ -395,8 +448,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 __syncthreads();
                 if (!chol16(L.Quu, L.Lc, m, L.flag)) {            // not PD: raise rho, restart (ilqr.py:276-287)
                     reg_update(true);
-                    restart = true;
-                    break;
+                    return false;
                 }
                 for (int j = tid; j <= n; j += nt) {
                     if (j < n) wg::chol_solve_neg(L.Lc, m, L.BK + j, n, L.Kk + j, n);
@@ -423,7 +475,17 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     const int r = e / n, c = e - r * n;
                     double v = 0.0;
                     for (int s = 0; s < nz; ++s) v = fma(Hm[s * n + r], QH[s * n + c], v);
-                    for (int k = 0; k < n; ++k) v = fma(At[k * n + r], L.W[k * n + c], v);
+                    {
+                        int k = 0;
+                        for (; k + 8 <= n; k += 8) {
+                            double av[8], bv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { av[q] = At[(k + q) * n + r]; bv[q] = L.W[(k + q) * n + c]; }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v = fma(av[q], bv[q], v);
+                        }
+                        for (; k < n; ++k) v = fma(At[k * n + r], L.W[k * n + c], v);
+                    }
                     for (int s = 0; s < m; ++s) {
                         v = fma(L.Kk[s * n + r], L.PB[s * n + c], v);
                         v = fma(L.Kk[s * n + r], L.Kt[s * n + c], v);
@@ -444,6 +506,172 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 for (int e = tid; e < n * n; e += nt) L.P[e] = L.T[e];
                 for (int e = tid; e < n; e += nt) L.v1[e] = L.v3[e];
                 __syncthreads();
+                return true;
+            };
+            bool restart = false;
+            for (int t = N - 1; t >= 0; --t) {
+                cgptr Ag, Bg;
+                if constexpr (MODEL == 0) {
+                    const size_t i = (size_t)idx[t];
+                    Ag = T.Ad + i * n * n; Bg = T.Bd + i * n * m;
+                } else {
+                    Ag = (cgptr)lin + (size_t)t * lstride; Bg = Ag + (size_t)n * n;
+                }
+                bool ok;
+                if (a.stage_ab) {
+                    for (int e = tid; e < n * n; e += nt) Al[e] = Ag[e];
+                    for (int e = tid; e < n * m; e += nt) Bl[e] = Bg[e];
+                    __syncthreads();
+                    ok = stage((clptr)Al, (clptr)Bl, t);
+                } else {
+                    ok = stage(Ag, Bg, t);
+                }
+                if (!ok) { restart = true; break; }
+            }
+            if (restart) continue;
+            reg_update(false);
+            break;
+        }
+    };
+
+    // backward pass on f64 MFMA products (same algebra as `backward`): with AB = [A_t | B_t]
+    //   W = P AB;  G = AB^T W = [[A'PA, A'PB], [B'PA, B'PB]] (written over P);  RB = B^T AB = [B'A | B'B]
+    // give Q_xx - c_xx, Q_ux, Q_uu - R and the rho-regularised variants; the rank-n_u corrections of P stay VALU.
+    auto backward_m = [&]() {
+        while (true) {
+            for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)N * n + e];
+            for (int e = tid; e < NPa * ldp; e += nt) { Pm[e] = 0.0; ABm[e] = 0.0; }
+            __syncthreads();
+            zerr((clptr)xl, N);
+            for (int e = tid; e < n * n; e += nt) {
+                const int r = e / n, c = e - r * n;
+                double v = 0.0;
+                for (int s = 0; s < nz; ++s) {
+                    double q1 = 0.0;
+                    for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qfg[s * nz + s2], Hm[s2 * n + c], q1);
+                    v = fma(Hm[s * n + r], q1, v);
+                }
+                Pm[r * ldp + c] = v;
+            }
+            for (int e = tid; e < nz * n; e += nt) {
+                const int s = e / n, c = e - s * n;
+                double q2 = 0.0;
+                for (int s2 = 0; s2 < nz; ++s2) q2 = fma(Qg[s * nz + s2], Hm[s2 * n + c], q2);
+                QH[e] = q2;
+                Hl[e] = Hm[e];
+            }
+            for (int e = tid; e < n; e += nt) {
+                double v = 0.0;
+                for (int s = 0; s < nz; ++s) { double q1 = 0.0; for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qfg[s * nz + s2], zt[s2], q1); v = fma(Hm[s * n + e], q1, v); }
+                L.v1[e] = v;     // p
+            }
+            __syncthreads();
+            bool restart = false;
+            for (int t = N - 1; t >= 0; --t) {
+                cgptr Ag, Bg;
+                if constexpr (MODEL == 0) {
+                    const size_t i = (size_t)idx[t];
+                    Ag = T.Ad + i * n * n; Bg = T.Bd + i * n * m;
+                } else {
+                    Ag = (cgptr)lin + (size_t)t * lstride; Bg = Ag + (size_t)n * n;
+                }
+                for (int e = tid; e < n * n; e += nt) ABm[(e / n) * ldp + e % n] = Ag[e];
+                for (int e = tid; e < n * m; e += nt) ABm[(e / m) * ldp + n + e % m] = Bg[e];
+                for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)t * n + e];
+                __syncthreads();
+                zerr((clptr)xl, t);
+                if (tid >= 64 && tid < 64 + m) {
+                    const int r = tid - 64;
+                    double v = 0.0;
+                    for (int s = 0; s < m; ++s) {
+                        const double du = U[(size_t)t * m + s] - (t == 0 ? (a.u_last ? a.u_last[p * m + s] : 0.0) : U[(size_t)(t - 1) * m + s]);
+                        v = fma(Rg[r * m + s], du, v);
+                    }
+                    L.u1[r] = v;        // c_u
+                }
+                if (tid < nz) {
+                    double q1 = 0.0;
+                    for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qg[tid * nz + s2], zt[s2], q1);
+                    qz[tid] = q1;
+                }
+                wg::mfma_atb(Wm, ldp, Pm, ABm, NK4, n16 >> 4, NPa >> 4, ldp, n);              // W = P [A|B]
+                wg::mfma_atb(Pm, ldp, ABm, Wm, NK4, NPa >> 4, NPa >> 4, ldp, NPa);           // G = [A|B]^T W  (over P)
+                wg::mfma_atb(RBm, ldp, ABm + n, ABm, NK4, 1, NPa >> 4, ldp, 16, m);           // [B'A | B'B]
+                // Q_uu = R + B'PB ; Q~_uu = Q_uu + rho B'B ; Q_ux = B'PA ; Q~_ux = Q_ux + rho B'A
+                for (int e = tid; e < m * m; e += nt) {
+                    const int r = e / m, c = e - r * m;
+                    const double v = Rg[e] + Pm[(n + r) * ldp + n + c];
+                    Quu[(size_t)t * m * m + e] = v;
+                    L.T[e] = v;                       // unregularised Q_uu stays in LDS for the updates below
+                    L.Quu[e] = v + rho * RBm[r * ldp + n + c];
+                }
+                for (int e = tid; e < m * n; e += nt) {
+                    const int r = e / n, c = e - r * n;
+                    const double v = Pm[(n + r) * ldp + c];
+                    L.Kt[e] = v;                      // Q_ux
+                    L.BK[e] = v + rho * RBm[r * ldp + c];
+                }
+                // Q_x = c_x + A'p ; Q_u = c_u + B'p   (columns of the panel: odd leading dimension, conflict free)
+                for (int e = tid; e < n + m; e += nt) {
+                    double v = 0.0;
+                    for (int k = 0; k < n; ++k) v = fma(ABm[k * ldp + e], L.v1[k], v);
+                    if (e < n) {
+                        for (int s = 0; s < nz; ++s) v = fma(Hl[s * n + e], qz[s], v);     // c_x = H^T (Q (z - z*))
+                        L.v2[e] = v;
+                    } else {
+                        v += L.u1[e - n];
+                        L.u2[e - n] = v;
+                        Qu[(size_t)t * m + e - n] = v;
+                    }
+                }
+                __syncthreads();
+                // the Q_ux rows of G are consumed: rows n.. of P must be zero again (K padding of the next product)
+                for (int e = tid; e < (NPa - n) * ldp; e += nt) Pm[n * ldp + e] = 0.0;
+                if (!ilqr_gain(L, n, m)) {                        // not PD: raise rho, restart (ilqr.py:276-287)
+                    __syncthreads();
+                    reg_update(true);
+                    restart = true;
+                    break;
+                }
+                for (int e = tid; e < m * n; e += nt) Kout[(size_t)t * m * n + e] = L.Kk[e];
+                if (tid < m) kff[(size_t)t * m + tid] = L.u1[tid];
+                // QK = Quu K (m x n) into PB ; zt = Quu k
+                for (int e = tid; e < m * n; e += nt) {
+                    const int r = e / n, c = e - r * n;
+                    double v = 0.0;
+                    for (int s = 0; s < m; ++s) v = fma(L.T[r * m + s], L.Kk[s * n + c], v);
+                    L.PB[e] = v;
+                }
+                if (tid < m) {
+                    double v = 0.0;
+                    for (int s = 0; s < m; ++s) v = fma(L.T[tid * m + s], L.u1[s], v);
+                    zt[tid] = v;
+                }
+                __syncthreads();
+                // P = c_xx + A'PA + K'Quu K + K'Q_ux + Q_ux'K  (in place over the A'PA block of G)
+                for (int e = tid; e < n * n; e += nt) {
+                    const int r = e / n, c = e - r * n;
+                    double v = Pm[r * ldp + c];
+                    for (int s = 0; s < nz; ++s) v = fma(Hl[s * n + r], QH[s * n + c], v);
+                    for (int s = 0; s < m; ++s) {
+                        v = fma(L.Kk[s * n + r], L.PB[s * n + c], v);
+                        v = fma(L.Kk[s * n + r], L.Kt[s * n + c], v);
+                        v = fma(L.Kt[s * n + r], L.Kk[s * n + c], v);
+                    }
+                    Pm[r * ldp + c] = v;
+                }
+                for (int e = tid; e < n; e += nt) {
+                    double v = L.v2[e];
+                    for (int s = 0; s < m; ++s) {
+                        v = fma(L.Kk[s * n + e], zt[s], v);
+                        v = fma(L.Kk[s * n + e], L.u2[s], v);
+                        v = fma(L.Kt[s * n + e], L.u1[s], v);
+                    }
+                    L.v3[e] = v;
+                }
+                __syncthreads();
+                for (int e = tid; e < n; e += nt) L.v1[e] = L.v3[e];
+                __syncthreads();
             }
             if (restart) continue;
             reg_update(false);
@@ -459,7 +687,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     int failed_counter = 0, it = 0;
     bool converged = false;
     while (!converged && it <= P_.max_iter) {
-        backward();
+        if (a.mfma) backward_m(); else backward();
         const double prev_cost = cost;
         double alpha = P_.alpha0, new_cost = cost;
         bool improved = false, failed = false;
@@ -614,9 +842,25 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
     IlqrArgs a{N, n, m, nz, par, d0.as<double>(), dz.as<double>(), u_warm ? duw.as<double>() : nullptr,
                u_last ? dul.as<double>() : nullptr, dQ.as<double>(), dR.as<double>(), dQf.as<double>(), ox.as<double>(),
                ou.as<double>(), oK.as<double>(), oc.as<double>(), oi.as<int>(), work.as<double>(), iwork.as<int>(), stride,
-               hs ? lin.as<double>() : nullptr, ssm_mode, dt};
-    size_t lds = (lqr_lds_doubles(n, m) + 20 + (size_t)16 * n + 16 + NT + 16 + n) * sizeof(double);
-    if (hs) lds += sizeof(double) * (lstride + ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns));
+               hs ? lin.as<double>() : nullptr, ssm_mode, 0, 0, 0, dt};
+    const size_t tail = 20 + (size_t)16 * n + 16 + NT + 16 + n +
+                        (hs ? lstride + ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns) : 0);
+    // preferred: backward pass on f64 MFMA products over three padded (NPa x ld) panels + one 16-row panel
+    const size_t NPa = (size_t)((n + m + 15) & ~15), ldp = NPa + 1;
+    const size_t mf_off = lqr_lds_doubles(n, m, 256) + tail;
+    const size_t mf_lds = (mf_off + 3 * NPa * ldp + 16 * ldp + (size_t)16 * n + 16) * sizeof(double);
+    size_t lds;
+    if (mf_lds <= 160 * 1024 && !getenv("SRH_ILQR_NO_MFMA")) {
+        a.mfma = 1;
+        a.panel_off = mf_off;
+        a.stage_ab = hs ? 1 : 0;
+        lds = mf_lds;
+    } else {
+        lds = (lqr_lds_doubles(n, m) + tail) * sizeof(double);
+        // VALU fallback: the backward pass reads (A_t, B_t) n times per stage: stage them in LDS when they fit
+        if (hs) a.stage_ab = 1;
+        else if (lds + sizeof(double) * lstride <= 160 * 1024) { a.stage_ab = 1; lds += sizeof(double) * lstride; }
+    }
     SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
     if (ht) {
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
