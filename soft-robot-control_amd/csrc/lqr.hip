@@ -312,13 +312,21 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 zerr((clptr)L.v1, t);
                 ssm::linearize(S, a.ssm_mode, a.dt, (clptr)L.v1, (clptr)L.u1, sw, Al, n, Bl, dl);
             }
-            if (tid == 0) {
+            if (tid < 64) {          // step cost (ilqr.py:168-176): the terms of both quadratic forms over the lanes of wave 0
+                auto dui = [&](int r) {
+                    return L.u1[r] - (t == 0 ? (a.u_last ? a.u_last[p * m + r] : 0.0) : uo[(size_t)(t - 1) * m + r]);
+                };
                 double c = 0.0;
-                for (int r = 0; r < nz; ++r) for (int s = 0; s < nz; ++s) c += zt[r] * Qg[r * nz + s] * zt[s];
-                double du[16];
-                for (int r = 0; r < m; ++r) du[r] = L.u1[r] - (t == 0 ? (a.u_last ? a.u_last[p * m + r] : 0.0) : uo[(size_t)(t - 1) * m + r]);
-                for (int r = 0; r < m; ++r) for (int s = 0; s < m; ++s) c += du[r] * Rg[r * m + s] * du[s];
-                cost += 0.5 * c;
+                for (int e = tid; e < nz * nz + m * m; e += 64) {
+                    if (e < nz * nz) {
+                        c = fma(zt[e / nz] * Qg[e], zt[e % nz], c);
+                    } else {
+                        const int f = e - nz * nz;
+                        c = fma(dui(f / m) * Rg[f], dui(f % m), c);
+                    }
+                }
+                c = wg::wave_sum(c);
+                cost += 0.5 * c;     // every lane of wave 0 carries the running cost; thread 0 publishes it
             }
             if constexpr (MODEL == 0) {
                 const size_t i = (size_t)*L.flag;
@@ -341,11 +349,12 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
             __syncthreads();
         }
         zerr((clptr)L.v1, N);
-        if (tid == 0) {
+        if (tid < 64) {
             double c = 0.0;
-            for (int r = 0; r < nz; ++r) for (int s = 0; s < nz; ++s) c += zt[r] * Qfg[r * nz + s] * zt[s];
+            for (int e = tid; e < nz * nz; e += 64) c = fma(zt[e / nz] * Qfg[e], zt[e % nz], c);
+            c = wg::wave_sum(c);
             cost += 0.5 * c;
-            L.red[15] = cost;
+            if (tid == 0) L.red[15] = cost;
         }
         __syncthreads();
         cost = L.red[15];
