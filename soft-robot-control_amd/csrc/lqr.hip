@@ -588,7 +588,18 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 for (int e = tid; e < n * m; e += nt) ABm[(e / m) * ldp + n + e % m] = Bg[e];
                 for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)t * n + e];
                 __syncthreads();
-                zerr((clptr)xl, t);
+                if constexpr (MODEL == 0) {
+                    // z - z* = H x + z_ref - z*: one wave per output row, H from its LDS copy
+                    for (int r = tid >> 6; r < nz; r += nt >> 6) {
+                        double v = 0.0;
+                        for (int j = tid & 63; j < n; j += 64) v = fma(Hl[r * n + j], xl[j], v);
+                        v = wg::wave_sum(v);
+                        if ((tid & 63) == 0) zt[r] = v + zref[r] - ztar[(size_t)t * nz + r];
+                    }
+                    __syncthreads();
+                } else {
+                    zerr((clptr)xl, t);
+                }
                 if (tid >= 64 && tid < 64 + m) {
                     const int r = tid - 64;
                     double v = 0.0;
@@ -622,8 +633,16 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 }
                 // Q_x = c_x + A'p ; Q_u = c_u + B'p   (columns of the panel: odd leading dimension, conflict free)
                 for (int e = tid; e < n + m; e += nt) {
-                    double v = 0.0;
-                    for (int k = 0; k < n; ++k) v = fma(ABm[k * ldp + e], L.v1[k], v);
+                    double v0 = 0.0, v1a = 0.0, v2a = 0.0, v3a = 0.0;
+                    int k = 0;
+                    for (; k + 4 <= n; k += 4) {
+                        v0 = fma(ABm[k * ldp + e], L.v1[k], v0);
+                        v1a = fma(ABm[(k + 1) * ldp + e], L.v1[k + 1], v1a);
+                        v2a = fma(ABm[(k + 2) * ldp + e], L.v1[k + 2], v2a);
+                        v3a = fma(ABm[(k + 3) * ldp + e], L.v1[k + 3], v3a);
+                    }
+                    for (; k < n; ++k) v0 = fma(ABm[k * ldp + e], L.v1[k], v0);
+                    double v = (v0 + v1a) + (v2a + v3a);
                     if (e < n) {
                         for (int s = 0; s < nz; ++s) v = fma(Hl[s * n + e], qz[s], v);     // c_x = H^T (Q (z - z*))
                         L.v2[e] = v;
@@ -649,7 +668,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     const int r = e / n, c = e - r * n;
                     double v = 0.0;
                     for (int s = 0; s < m; ++s) v = fma(L.T[r * m + s], L.Kk[s * n + c], v);
-                    L.PB[e] = v;
+                    L.PB[e] = v + L.Kt[e];            // Quu K + Q_ux
                 }
                 if (tid < m) {
                     double v = 0.0;
@@ -663,9 +682,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     double v = Pm[r * ldp + c];
                     for (int s = 0; s < nz; ++s) v = fma(Hl[s * n + r], QH[s * n + c], v);
                     for (int s = 0; s < m; ++s) {
-                        v = fma(L.Kk[s * n + r], L.PB[s * n + c], v);
-                        v = fma(L.Kk[s * n + r], L.Kt[s * n + c], v);
-                        v = fma(L.Kt[s * n + r], L.Kk[s * n + c], v);
+                        v = fma(L.Kk[s * n + r], L.PB[s * n + c], v);        // K'(Quu K + Q_ux)
+                        v = fma(L.Kt[s * n + r], L.Kk[s * n + c], v);        // Q_ux' K
                     }
                     Pm[r * ldp + c] = v;
                 }
