@@ -790,26 +790,25 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             }
             SRH_LAP(5);
         } else {
-            // vector-only re-solve: A^T pv, B^T pv straight from the L2-resident tables
-            for (int e = tid; e < m * n; e += nt) { const int a = e / n, j = e - a * n; L.Km[a * ld + j] = w.K[(size_t)k * m * n + e]; }
+            // vector-only re-solve with the stored gains / factors: three barriers per stage.  The Cholesky factor
+            // of Quu_k is staged before the panel product (whose barriers publish it); every thread forms
+            // Qu = B^T pv + gu itself and takes its column of K_k straight from HBM (coalesced over j).
             for (int e = tid; e < m * m; e += nt) L.Lc[e] = w.Qinv[(size_t)k * m * m + e];
             ensure_panel(d, dyn, L, k);
             panel_T_vec(d, L, L.pv, L.ypv);                      // [A^T pv ; B^T pv]
-            if (tid < m) L.Qu[tid] = L.ypv[n + tid] + w.gu[(size_t)k * m + tid];
-            __syncthreads();
-            if (tid == 0) {
-                wg::chol_solve_neg(L.Lc, m, L.Qu, 1, L.kf, 1);
-                for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
-            }
             if (k >= 1) {
                 for (int j = tid; j < n; j += nt) {
                     double v = w.gx[(size_t)k * n + j] + L.ypv[j];
-                    for (int a = 0; a < m; ++a) v = fma(L.Km[a * ld + j], L.Qu[a], v);
-                    L.v1[j] = v;
+                    for (int a = 0; a < m; ++a)
+                        v = fma(w.K[((size_t)k * m + a) * n + j], L.ypv[n + a] + w.gu[(size_t)k * m + a], v);
+                    L.pv[j] = v;                                  // pv is not read again in this stage
                 }
             }
-            __syncthreads();
-            if (k >= 1) { for (int e = tid; e < n; e += nt) L.pv[e] = L.v1[e]; }
+            if (tid == nt - 1) {
+                for (int a = 0; a < m; ++a) L.Qu[a] = L.ypv[n + a] + w.gu[(size_t)k * m + a];
+                wg::chol_solve_neg(L.Lc, m, L.Qu, 1, L.kf, 1);
+                for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
+            }
             __syncthreads();
         }
     }
