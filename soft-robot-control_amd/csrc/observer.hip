@@ -29,7 +29,23 @@ struct EkfArgs {
     int *status;
 };
 
-constexpr int EKF_NT = 256;
+constexpr int EKF_NT = 512;
+
+// sum_k a[k * sa] * b[k * sb]: eight operand pairs in flight per trip (with two waves per SIMD a rolled
+// load -> fma chain pays the full LDS latency for every k)
+__device__ __forceinline__ double dotk(clptr a, int sa, clptr b, int sb, int K) {
+    double acc = 0.0;
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { av[q] = a[(k + q) * sa]; bv[q] = b[(k + q) * sb]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
+    }
+    for (; k < K; ++k) acc = fma(a[k * sa], b[k * sb], acc);
+    return acc;
+}
 
 __global__ __launch_bounds__(EKF_NT) void ekf_kernel(EkfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,16 +97,12 @@ __global__ __launch_bounds__(EKF_NT) void ekf_kernel(EkfArgs a) {
         }
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e % n;
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s = fma(Am[i * ld + k], Sg[k * ld + j], s);
-            Tm[i * ld + j] = s;
+            Tm[i * ld + j] = dotk(Am + i * ld, 1, Sg + j, ld, n);
         }
         __syncthreads();
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e % n;
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s = fma(Tm[i * ld + k], Am[j * ld + k], s);
-            Sg[i * ld + j] = s + a.W[e];
+            Sg[i * ld + j] = dotk(Tm + i * ld, 1, Am + j * ld, 1, n) + a.W[e];
         }
         for (int e = tid; e < n; e += nt) xv[e] = xn[e];
         __syncthreads();
@@ -102,15 +114,11 @@ __global__ __launch_bounds__(EKF_NT) void ekf_kernel(EkfArgs a) {
         __syncthreads();
         for (int e = tid; e < n * ny; e += nt) {       // M1 = Sigma C^T  (n x ny)
             const int i = e / ny, j = e % ny;
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s = fma(Sg[i * ld + k], Cm[j * ld + k], s);
-            Am[i * ld + j] = s;
+            Am[i * ld + j] = dotk(Sg + i * ld, 1, Cm + j * ld, 1, n);
         }
         for (int e = tid; e < ny * n; e += nt) {       // CS = C Sigma    (ny x n)
             const int i = e / n, j = e % n;
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s = fma(Cm[i * ld + k], Sg[k * ld + j], s);
-            Tm[i * ld + j] = s;
+            Tm[i * ld + j] = dotk(Cm + i * ld, 1, Sg + j, ld, n);
         }
         for (int i = tid; i < ny; i += nt) {           // innovation
             double s = 0.0;
@@ -120,45 +128,39 @@ __global__ __launch_bounds__(EKF_NT) void ekf_kernel(EkfArgs a) {
         __syncthreads();
         for (int e = tid; e < ny * ny; e += nt) {      // S = C M1 + V
             const int i = e / ny, j = e % ny;
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s = fma(Cm[i * ld + k], Am[k * ld + j], s);
-            Sm[i * ldy + j] = s + a.V[e];
+            Sm[i * ldy + j] = dotk(Cm + i * ld, 1, Am + j, ld, n) + a.V[e];
         }
         __syncthreads();
-        // Cholesky of S (symmetrised lower part), right-looking, one column per step
-        for (int j = 0; j < ny; ++j) {
-            if (tid == 0) {
+        // Cholesky of S (lower part), right-looking, by ONE wave: LDS operations of a wave execute in program
+        // order, so the ny column steps need no workgroup barrier (90 barriers at n_y = 30 otherwise)
+        if (tid < 64) {
+            for (int j = 0; j < ny; ++j) {
                 const double dj = Sm[j * ldy + j];
-                if (!(dj > 0.0)) ip[1] = 1;
-                Sm[j * ldy + j] = sqrt(dj);
+                if (!(dj > 0.0)) { if (tid == 0) ip[1] = 1; break; }       // uniform within the wave
+                const double rj = sqrt(dj);
+                for (int i = j + 1 + tid; i < ny; i += 64) Sm[i * ldy + j] = Sm[i * ldy + j] / rj;
+                if (tid == 0) Sm[j * ldy + j] = rj;
+                __builtin_amdgcn_wave_barrier();
+                const int w = ny - j - 1;
+                for (int e = tid; e < w * w; e += 64) {
+                    const int i = j + 1 + e / w, k = j + 1 + e % w;
+                    if (k <= i) Sm[i * ldy + k] = fma(-Sm[i * ldy + j], Sm[k * ldy + j], Sm[i * ldy + k]);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __syncthreads();
-            const double dj = Sm[j * ldy + j];
-            for (int i = j + 1 + tid; i < ny; i += nt) Sm[i * ldy + j] = Sm[i * ldy + j] / dj;
-            __syncthreads();
-            for (int e = tid; e < (ny - j - 1) * (ny - j - 1); e += nt) {
-                const int i = j + 1 + e / (ny - j - 1), k = j + 1 + e % (ny - j - 1);
-                if (k <= i) Sm[i * ldy + k] = fma(-Sm[i * ldy + j], Sm[k * ldy + j], Sm[i * ldy + k]);
-            }
-            __syncthreads();
         }
+        __syncthreads();
         if (ip[1] != 0) {
             if (tid == 0) *a.status = 1;
             return;
         }
-        // K row i: solve k S = M1_i  <=>  S k^T = M1_i^T  (S = L L^T), in place
+        // K row i: solve k S = M1_i  <=>  S k^T = M1_i^T  (S = L L^T), in place; the inner products run with
+        // several operand pairs in flight (dotk), only the ny substitution steps are sequential
         for (int i = tid; i < n; i += nt) {
             lptr row = Am + (size_t)i * ld;
-            for (int c = 0; c < ny; ++c) {
-                double s = row[c];
-                for (int k = 0; k < c; ++k) s = fma(-Sm[c * ldy + k], row[k], s);
-                row[c] = s / Sm[c * ldy + c];
-            }
-            for (int c = ny - 1; c >= 0; --c) {
-                double s = row[c];
-                for (int k = c + 1; k < ny; ++k) s = fma(-Sm[k * ldy + c], row[k], s);
-                row[c] = s / Sm[c * ldy + c];
-            }
+            for (int c = 0; c < ny; ++c) row[c] = (row[c] - dotk(Sm + c * ldy, 1, row, 1, c)) / Sm[c * ldy + c];
+            for (int c = ny - 1; c >= 0; --c)
+                row[c] = (row[c] - dotk(Sm + (c + 1) * ldy + c, ldy, row + c + 1, 1, ny - 1 - c)) / Sm[c * ldy + c];
         }
         __syncthreads();
         for (int i = tid; i < n; i += nt) {
@@ -168,9 +170,7 @@ __global__ __launch_bounds__(EKF_NT) void ekf_kernel(EkfArgs a) {
         }
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e % n;
-            double s = 0.0;
-            for (int k = 0; k < ny; ++k) s = fma(Am[i * ld + k], Tm[k * ld + j], s);
-            a.Sigma[e] = Sg[i * ld + j] - s;
+            a.Sigma[e] = Sg[i * ld + j] - dotk(Am + i * ld, 1, Tm + j, ld, ny);
         }
         __syncthreads();
         for (int e = tid; e < n; e += nt) a.x[e] = xn[e];

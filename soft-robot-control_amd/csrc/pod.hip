@@ -254,6 +254,25 @@ __global__ void splitk_reduce_kernel(const double *__restrict__ partial, int ksp
     out[row * ldo + (int64_t)blk * o_blk_off + j] = s;
 }
 
+// Few outputs, many partials (one full state per simulation step: 2r outputs, ~77 K-slices): one wave per output,
+// lanes over the K-slices, fixed butterfly order (deterministic).
+__global__ void splitk_reduce_wave_kernel(const double *__restrict__ partial, int ksplit, int nblk, int64_t B,
+                                          int ldp, int r, double *__restrict__ out, int64_t ldo,
+                                          int64_t o_blk_off) {
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t total = (int64_t)nblk * B * r;
+    if (idx >= total) return;
+    const int j = idx % r;
+    const int64_t row = (idx / r) % B;
+    const int blk = idx / ((int64_t)r * B);
+    double s = 0.0;
+    for (int k = lane; k < ksplit; k += 64) s += partial[(((int64_t)k * nblk + blk) * B + row) * ldp + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[row * ldo + (int64_t)blk * o_blk_off + j] = s;
+}
+
 // ------------------------------------------------------------------------------------------ lift
 struct LiftArgs {
     const double *Xr;    // (B x ldr)
@@ -546,8 +565,12 @@ int srom_project_dev(srom_t *h, int which, const double *X, int64_t B, int64_t l
     if (rc) return rc;
     if (ksplit > 1) {
         int64_t total = (int64_t)nblk * B * h->r;
-        splitk_reduce_kernel<<<(unsigned)srh::cdiv(total, 256), 256, 0, s>>>(
-            a.partial, ksplit, nblk, B, ldp, h->r, out, ldo, h->r);
+        if (total <= 4096 && ksplit >= 16)
+            splitk_reduce_wave_kernel<<<(unsigned)srh::cdiv(total, 4), 256, 0, s>>>(a.partial, ksplit, nblk, B, ldp,
+                                                                                    h->r, out, ldo, h->r);
+        else
+            splitk_reduce_kernel<<<(unsigned)srh::cdiv(total, 256), 256, 0, s>>>(
+                a.partial, ksplit, nblk, B, ldp, h->r, out, ldo, h->r);
         SRH_CHECK_HIP(hipGetLastError());
     }
     return SRH_OK;

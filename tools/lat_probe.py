@@ -29,3 +29,20 @@ def dev_nosync():
 print('srom_project_dev (enqueue)   %.1f us' % t(dev_nosync)); L.srh_sync()
 xq = np.ascontiguousarray(w['q_ref'] + 1.0); oq = np.empty(r)
 print('bare srom_project q only     %.1f us' % t(lambda: L.srom_project(rom.handle, 0, _lib.dptr(xq), C.c_int64(1), _lib.dptr(oq))))
+# EKF step
+import scipy.sparse as sp, io, contextlib
+sys.path.insert(0, 'tests')
+from bench import build_model
+tp, gm = build_model(w)
+nodes = np.arange(0, 10 * 150, 150)
+Cf = sp.lil_matrix((30, 2 * n_f))
+for i, nd in enumerate(nodes):
+    for a in range(3):
+        Cf[3 * i + a, n_f + 3 * nd + a] = 1.0
+tp.set_measurement_model(Cf.tocsr())
+from sofacontrol_amd.tpwl.observer import DiscreteEKFObserver
+ekf = DiscreteEKFObserver(tp)
+u = np.full(w['m'], 100.0); y = tp.y_ref + 0.01
+print('python ekf.update            %.1f us' % t(lambda: ekf.update(u, y, w['dt']), 200))
+up, yp, xo = _lib.dptr(u), _lib.dptr(y), np.empty(2 * r)
+print('bare sekf_step               %.1f us' % t(lambda: L.sekf_step(ekf._h, up, yp, None, None, None, _lib.dptr(xo)), 200))
