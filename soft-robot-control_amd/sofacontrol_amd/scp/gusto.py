@@ -134,6 +134,15 @@ class GuSTO:
     def compute_accuracy(self, x, u, J):
         error = 0
         approx = 0
+        if hasattr(self.model, 'get_continuous_dynamics_batch'):
+            # same sums as the loop below with the two trajectories linearised in one device call each
+            fk, Ak, Bk = self.model.get_continuous_dynamics_batch(self.x_k[:-1], self.u_k)
+            f, _, _ = self.model.get_continuous_dynamics_batch(x[:-1], u)
+            for i in range(x.shape[0] - 1):
+                f_approx = fk[i] + Ak[i] @ (x[i, :] - self.x_k[i, :]) + Bk[i] @ (u[i, :] - self.u_k[i, :])
+                error += self.dt * np.linalg.norm(np.multiply(self.f_scale, f[i] - f_approx), 2)
+                approx += self.dt * np.linalg.norm(np.multiply(self.f_scale, f_approx), 2)
+            return error / (J + approx)
         for i in range(x.shape[0] - 1):
             fk, Ak, Bk = self.model.get_continuous_dynamics(self.x_k[i, :], self.u_k[i, :])
             f, _, _ = self.model.get_continuous_dynamics(x[i, :], u[i, :])
@@ -143,6 +152,9 @@ class GuSTO:
         return error / (J + approx)
 
     def get_traj_dynamics(self, x, u):
+        if hasattr(self.model, 'get_discrete_dynamics_batch'):
+            A, B, d = self.model.get_discrete_dynamics_batch(x[:-1], u, self.dt)
+            return list(A), list(B), list(d)
         A_d, B_d, d_d = [], [], []
         for i in range(x.shape[0] - 1):
             A, B, d = self.model.get_discrete_dynamics(x[i, :], u[i, :], self.dt)
@@ -151,6 +163,9 @@ class GuSTO:
 
     def get_observer_linearizations(self, x, u):
         """gusto.py:240-251."""
+        if hasattr(self.model, 'get_observer_jacobians_batch'):
+            H, c = self.model.get_observer_jacobians_batch(x, self.dt)
+            return list(H), list(c)
         H_d, c_d = [], []
         for i in range(x.shape[0]):
             H, c = self.model.get_observer_jacobians(x[i, :], None, self.dt)

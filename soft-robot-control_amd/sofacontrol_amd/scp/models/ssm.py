@@ -29,6 +29,19 @@ class SSMGuSTO(TemplateModel):
     def get_observer_jacobians(self, x, u, dt):
         return self.dyn_sys.get_observer_jacobians(x)
 
+    # ---- batched forms used by the GuSTO host loop: one device call for the whole horizon
+    def get_discrete_dynamics_batch(self, X, U, dt):
+        return self.dyn_sys.get_jacobians(np.asarray(X), dt=dt, u=np.asarray(U))
+
+    def get_continuous_dynamics_batch(self, X, U):
+        X, U = np.asarray(X), np.asarray(U)
+        A, B, d = self.dyn_sys.get_continuous_jacobians(X, u=U)
+        f = np.einsum('kij,kj->ki', A, X) + np.einsum('kij,kj->ki', B, U) + d
+        return f, A, B
+
+    def get_observer_jacobians_batch(self, X, dt):
+        return self.dyn_sys.get_observer_jacobians(np.asarray(X))
+
     def get_characteristic_vals(self):
         return np.ones(self.n_x), np.ones(self.n_x)
 

@@ -28,6 +28,17 @@ class TPWLGuSTO(TemplateModel):
     def get_discrete_dynamics(self, x, u, dt):
         return self.dyn_sys.get_jacobians(x, dt=dt)
 
+    # ---- batched forms used by the GuSTO host loop (weighting-mode models): one device call per horizon
+    def get_discrete_dynamics_batch(self, X, U, dt):
+        A, B, d, _ = self.dyn_sys.linearize_batch(np.asarray(X), dt)
+        return A, B, d
+
+    def get_continuous_dynamics_batch(self, X, U):
+        X, U = np.asarray(X), np.asarray(U)
+        A, B, d, _ = self.dyn_sys.linearize_batch(X)
+        f = np.einsum('kij,kj->ki', A, X) + np.einsum('kij,kj->ki', B, U) + d
+        return f, A, B
+
     def pre_discretize(self, dt):
         self.dyn_sys.pre_discretize(dt)
 
