@@ -134,17 +134,17 @@ def closed_loop_latency(w, rom, tp):
 
 
 def secondary(L, _lib, rank, world, dist):
+    import workloads as wl
     """Secondary metrics of SURVEY.md section 8(d), measured outside the timed region of the headline metric:
     C3 iLQR iterations/s (SSM r=10, n_u=8, horizon 100), C4 per-GPU share of the snapshot Gramian (10 000
     snapshots x 50 000/8 DoF) in TFLOP/s plus the RCCL all-reduce of the Gramian when world > 1."""
-    from oracle import ssm as ossm          # seeded synthetic model generator only (data, not compute)
     from sofacontrol_amd.SSM.ssm import SSMDynamics
     from sofacontrol_amd.lqr.ilqr import iLQR
     from sofacontrol_amd.utils import QuadraticCost
     out = {}
     # ---- C3
     n, m, N, dt, Bn = 10, 8, 100, 0.01, 256
-    model = ossm.synthetic(n, m, 3, 2, seed=95)
+    model = wl.ssm_model(n, m, 3, 2, seed=95)
 
     def mat(v):
         a = np.empty((1, 1), dtype=object); a[0, 0] = np.asarray(v); return a

@@ -112,24 +112,7 @@ def rollout(model, x0, u, dt, method='fe', discrete=False):
 
 
 def synthetic(n, m, rom_order, ssm_order, seed=0):
-    """Seeded SSM model: damped oscillator pairs in the linear part, small random higher-order terms."""
-    from math import comb
-    rng = np.random.default_rng(seed)
-    nr, ns = comb(n + rom_order, rom_order) - 1, comb(n + ssm_order, ssm_order) - 1
-    R = np.zeros((n, nr))
-    for k in range(n // 2):
-        w, zt = 3.0 + 2.0 * k, 0.5 + 0.3 * k
-        R[2 * k:2 * k + 2, 2 * k:2 * k + 2] = [[-zt, -w], [w, -zt]]
-    if n % 2:
-        R[n - 1, n - 1] = -1.0
-    R[:, n:] = 0.2 * rng.standard_normal((n, nr - n))
-    W = np.zeros((n, ns)); W[:, :n] = np.eye(n) + 0.1 * rng.standard_normal((n, n))
-    W[:, n:] = 0.1 * rng.standard_normal((n, ns - n))
-    V = np.zeros((n, ns)); V[:, :n] = np.linalg.inv(W[:, :n])
-    V[:, n:] = 0.1 * rng.standard_normal((n, ns - n))
-    B = rng.standard_normal((n, m))
-    Rd = np.zeros((n, nr)); Rd[:, :n] = np.eye(n)
-    Rd = Rd + 0.01 * R
-    Bd = 0.01 * B
-    z_ref = rng.standard_normal(n)
-    return make_model(n, m, rom_order, ssm_order, R, B, W, V, z_ref, Rd, Bd)
+    """Seeded SSM model (the generator lives in workloads.py, shared with bench.py) as an oracle model dict."""
+    import workloads
+    d = workloads.ssm_model(n, m, rom_order, ssm_order, seed)
+    return make_model(n, m, rom_order, ssm_order, d['R'], d['B'], d['W'], d['V'], d['z_ref'], d['Rd'], d['Bd'])

@@ -111,3 +111,29 @@ def diamond_c2(r=30, N=50, dt=0.05, seed=10, P=64, n_f=4884, tip_node=1354, with
     t, z = figure8(None)
     return dict(U=U, q_ref=q_ref, v_ref=v_ref, H=H, tab=tab, Ad=Ad, Bd=Bd, dd=dd, dt=dt, N=N, Qz=Qz, R=R,
                 UA=UA, Ub=Ub, XA=XA if with_X else None, Xb=Xb if with_X else None, t=t, z=z, r=r, m=m, P=P)
+
+
+def ssm_model(n, m, rom_order, ssm_order, seed=0):
+    """Seeded SSM polynomial model (SSM/ssm.py shapes): damped oscillator pairs in the linear part, small random
+    higher-order terms.  Returns the coefficient arrays of `SSM.__init__` (r_coeff, B, w_coeff, v_coeff, rd_coeff,
+    Bd) and z_ref; monomial counts comb(dim + order, order) - 1."""
+    from math import comb
+    rng = np.random.default_rng(seed)
+    nr, ns = comb(n + rom_order, rom_order) - 1, comb(n + ssm_order, ssm_order) - 1
+    R = np.zeros((n, nr))
+    for k in range(n // 2):
+        w, zt = 3.0 + 2.0 * k, 0.5 + 0.3 * k
+        R[2 * k:2 * k + 2, 2 * k:2 * k + 2] = [[-zt, -w], [w, -zt]]
+    if n % 2:
+        R[n - 1, n - 1] = -1.0
+    R[:, n:] = 0.2 * rng.standard_normal((n, nr - n))
+    W = np.zeros((n, ns)); W[:, :n] = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+    W[:, n:] = 0.1 * rng.standard_normal((n, ns - n))
+    V = np.zeros((n, ns)); V[:, :n] = np.linalg.inv(W[:, :n])
+    V[:, n:] = 0.1 * rng.standard_normal((n, ns - n))
+    B = rng.standard_normal((n, m))
+    Rd = np.zeros((n, nr)); Rd[:, :n] = np.eye(n)
+    Rd = Rd + 0.01 * R
+    Bd = 0.01 * B
+    z_ref = rng.standard_normal(n)
+    return dict(n=n, m=m, rom_order=rom_order, ssm_order=ssm_order, R=R, B=B, W=W, V=V, Rd=Rd, Bd=Bd, z_ref=z_ref)
