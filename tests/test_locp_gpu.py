@@ -153,3 +153,30 @@ def test_locp_r36_split_panel(m, use_X):
     assert rel(x, xe) <= 2e-4 and rel(u, ue) <= 2e-4
     for k in range(case['N']):
         np.testing.assert_allclose(x[k + 1], case['Ad'][k] @ x[k] + case['Bd'][k] @ u[k] + case['dd'][k], rtol=0, atol=1e-12)
+
+
+def test_locp_terminal_set_and_input_target():
+    """Xf rows on x_N (locp.py:336-337) and an input target u_des (locp.py:226) together with U, X, Qzf."""
+    from sofacontrol_amd.scp.locp import LOCP
+    case, _ = make_case(seed=47, terminal=True, N=14, x_box=2.0)
+    XA, Xb = case['X']
+    Xf = (XA[:2], 0.5 * Xb[:2])                       # tighter box on the terminal state
+    rng = np.random.default_rng(8)
+    u_des = rng.uniform(0, 30, (case['N'], case['Bd'][0].shape[1]))
+    qp = olocp.build_qp(case['N'], case['H'], case['Qz'], case['R'], case['Ad'], case['Bd'], case['dd'], case['x0'],
+                        case['xk'], case['delta'], case['omega'], z=case['z'], u_des=u_des, Qzf=case['Qzf'],
+                        zf=case['zf'], U=case['U'], X=case['X'], Xf=Xf, x_scale=case['x_scale'])
+    w, _, info = olocp.solve_exact(qp, tol=1e-12)
+    assert info.get('status', 'optimal') == 'optimal'
+    xe, ue, se = olocp.split(qp, w)
+    Je = olocp.objective(qp, w)
+    locp = LOCP(case['N'], case['H'], case['Qz'], case['R'], Qzf=case['Qzf'], U=Poly(*case['U']), X=Poly(*case['X']),
+                Xf=Poly(*Xf), x_char=1. / case['x_scale'])
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
+                case['omega'], z=case['z'], zf=case['zf'], u=u_des)
+    J, ok, _ = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
+    assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
+    assert np.all(Xf[0] @ x[-1] <= Xf[1] + 1e-9)
