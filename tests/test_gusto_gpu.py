@@ -137,3 +137,37 @@ def test_gusto_r36_split_panel_vs_oracle():
     assert int(g.iters[0]) == len(tr)
     np.testing.assert_allclose(g.trace[0, :len(tr), 0], [t[0] for t in tr], rtol=1e-6)
     assert rel(xo, xe) <= 1e-4 and rel(uo, ue) <= 1e-4
+
+
+def test_gusto_fused_terminal_cost_set_and_input_target(golden):
+    """The fused kernel with Qzf / zf, a terminal set Xf and an input target u (gusto.py:54-56 arguments) against the
+    restated loop."""
+    from oracle import tpwl as otpwl, gusto as ogusto
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g, gm = setup(golden)
+    model, U_, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 30, q_scale=0.05)
+    tp = gm.dyn_sys
+    N, dt = 12, 0.05
+    Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    H = np.asarray(tp.H)
+    from scipy.interpolate import interp1d
+    z = interp1d(g['t'], g['zt'], axis=0)(dt * np.arange(N + 1))
+    x0 = np.zeros(8); u_init = np.zeros((N, 3))
+    x_init = otpwl.rollout(model, Ad, Bd, dd, x0, u_init)
+    rng = np.random.default_rng(12)
+    u_tgt = rng.uniform(0, 20, (N, 3))
+    Qzf = 5 * g['Qz']
+    XfA, Xfb = g["Xp_A"][:2], 50.0 * np.abs(g["Xp_b"][:2]) + 1.0      # loose terminal box: row handling, inactive
+    gu = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, u=u_tgt, Qzf=Qzf, zf=z[-1], U=Poly(g['U_A'], g['U_b']),
+               Xf=Poly(XfA, Xfb), x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, max_trace=32, max_gusto_iters=3)
+    assert gu._fused
+    # this target makes the nearest-neighbour model hop between two regions for tens of iterations: compare the
+    # first four (max_gusto_iters = 3 -> iterations 0..3, gusto.py:163-172) of a fresh solve
+    gu.solve(x0, u_init, x_init, z=z, zf=z[-1], u=u_tgt)
+    xo, uo, zo, _ = gu.get_solution()
+    xe, ue, ze, tr = ogusto.solve(model, Ad, Bd, dd, H, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, u_des=u_tgt, Qzf=Qzf,
+                                  zf=z[-1], U=(g['U_A'], g['U_b']), Xf=(XfA, Xfb), x_char=g['x_char'], f_char=g['f_char'],
+                                  convg_thresh=1e-3, max_gusto_iters=3)
+    assert int(gu.iters[0]) == len(tr) == 4
+    np.testing.assert_allclose(gu.trace[0, :len(tr), 0], [t[0] for t in tr], rtol=1e-6)
+    assert rel(xo, xe) <= 1e-4 and rel(uo, ue) <= 1e-4
