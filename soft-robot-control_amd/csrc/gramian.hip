@@ -3,6 +3,8 @@
 // np.asarray(data['q']), pod.py:149).  Compute-bound (n_s/8 flop per byte): 128 x 128 output tiles per
 // workgroup, 64 x 64 per wave (16 accumulator tiles), K streamed in 16-column chunks through a
 // double-buffered k-major LDS panel; only tiles on or above the diagonal are computed and mirrored.
+#include <algorithm>
+
 #include "common.h"
 #include "dev_la.h"
 
@@ -13,13 +15,19 @@ constexpr int TB = 128;      // tile edge
 constexpr int KC = 16;       // K chunk
 constexpr int LDT = TB + 1;  // LDS row stride of the k-major panels
 
+// Blocks [0, nfull) compute whole tiles.  The remaining `ntiles - nfull` tiles -- the partial last round of the
+// launch on a 2-workgroups-per-CU machine -- are split `ksplit` ways along K, each part written to `scratch`
+// (TB x TB per part) and summed in a fixed order by gramian_tail_kernel: the tail costs 1/ksplit of a round.
 __global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__ S, int64_t n_s, int64_t n_f, int64_t lds,
-                                                      double *__restrict__ G, int ntile) {
+                                                      double *__restrict__ G, int ntile, int nfull, int ksplit,
+                                                      double *__restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lptr Xi = (lptr)smem;                  // [2][KC][LDT]
     lptr Xj = Xi + 2 * KC * LDT;           // [2][KC][LDT]
     // linear block index -> (ti <= tj)
-    int b = blockIdx.x, ti = 0;
+    int b = blockIdx.x, ti = 0, part = -1;
+    if (b >= nfull) { part = (b - nfull) % ksplit; b = nfull + (b - nfull) / ksplit; }
+    const int tail_slot = b - nfull;
     while (b >= ntile - ti) { b -= ntile - ti; ++ti; }
     const int tj = ti + b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,11 +63,13 @@ __global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__
             Xj[(buf * KC + lc) * LDT + r4 + 16 * q] = rj[q];
         }
     };
-    const int64_t nchunk = (n_f + KC - 1) / KC;
-    gload(0);
-    lstore(0);
+    const int64_t nchunk_all = (n_f + KC - 1) / KC;
+    const int64_t cbeg = part < 0 ? 0 : nchunk_all * part / ksplit;
+    const int64_t nchunk = part < 0 ? nchunk_all : nchunk_all * (part + 1) / ksplit;
+    gload(cbeg * KC);
+    lstore(cbeg & 1);
     __syncthreads();
-    for (int64_t c = 0; c < nchunk; ++c) {
+    for (int64_t c = cbeg; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload((c + 1) * KC);
 #pragma unroll
@@ -79,6 +89,17 @@ __global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__
         __syncthreads();
     }
     // D: col = lane&15, row = (lane>>4) + 4*reg
+    if (part >= 0) {
+        double *dst = scratch + ((size_t)tail_slot * ksplit + part) * TB * TB;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst[(wr + 16 * a + kk + 4 * q) * TB + wc + 16 * cc + l16] = acc[a][cc][q];
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -93,6 +114,23 @@ __global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__
                     if (ti != tj) G[cidx * n_s + r] = v;
                 }
             }
+}
+
+// sum of the K-parts of the split tail tiles in part order, written to G and mirrored
+__global__ __launch_bounds__(256) void gramian_tail_kernel(const double *__restrict__ scratch, int64_t n_s, int ntile,
+                                                           int nfull, int ksplit, double *__restrict__ G) {
+    int b = nfull + blockIdx.x, ti = 0;
+    while (b >= ntile - ti) { b -= ntile - ti; ++ti; }
+    const int tj = ti + b;
+    const double *src = scratch + (size_t)blockIdx.x * ksplit * TB * TB;
+    for (int e = threadIdx.x; e < TB * TB; e += blockDim.x) {
+        const int64_t r = (int64_t)ti * TB + e / TB, c = (int64_t)tj * TB + e % TB;
+        if (r >= n_s || c >= n_s) continue;
+        double v = 0.0;
+        for (int p = 0; p < ksplit; ++p) v += src[(size_t)p * TB * TB + e];
+        G[r * n_s + c] = v;
+        if (ti != tj) G[c * n_s + r] = v;
+    }
 }
 
 // U (n_f x k) = S^T W, W (n_s x k), k <= 64
@@ -141,8 +179,42 @@ int srom_gramian_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds,
     const int ntile = (int)srh::cdiv(n_s, TB);
     const int64_t nblk = (int64_t)ntile * (ntile + 1) / 2;
     const size_t lbytes = sizeof(double) * 4 * KC * LDT;
-    gramian_kernel<<<(unsigned)nblk, 256, lbytes, (hipStream_t)stream>>>(S_dev, n_s, n_f, lds, G_dev, ntile);
+    // two workgroups of this kernel are resident per CU: when the last round of the launch is less than half
+    // full, its tiles are split along K so that the tail costs a fraction of a round
+    static int slots = 0;
+    static srh::DevBuf scratch;
+    static size_t scratch_bytes = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        SRH_CHECK_HIP(hipGetDevice(&dev));
+        SRH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        slots = 2 * (cus > 0 ? cus : 256);
+    }
+    const int64_t nchunk = srh::cdiv(n_f, KC);
+    const int rem = (int)(nblk % slots);
+    int ksplit = 1, ntail = 0;
+    if (nblk > slots && rem > 0 && 2 * rem <= slots && nchunk >= 64) {
+        ksplit = std::min(8, slots / rem);
+        ntail = rem;
+    }
+    const int nfull = (int)nblk - ntail;
+    if (ntail > 0) {
+        const size_t need = sizeof(double) * (size_t)ntail * ksplit * TB * TB;
+        if (need > scratch_bytes) {
+            SRH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+            int rc = scratch.alloc(need);
+            if (rc) return rc;
+            scratch_bytes = need;
+        }
+    }
+    gramian_kernel<<<(unsigned)(nfull + ntail * ksplit), 256, lbytes, (hipStream_t)stream>>>(
+        S_dev, n_s, n_f, lds, G_dev, ntile, nfull, ksplit, scratch.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
+    if (ntail > 0) {
+        gramian_tail_kernel<<<(unsigned)ntail, 256, 0, (hipStream_t)stream>>>(scratch.as<double>(), n_s, ntile, nfull, ksplit,
+                                                                             G_dev);
+        SRH_CHECK_HIP(hipGetLastError());
+    }
     return SRH_OK;
 }
 

@@ -41,7 +41,7 @@ def test_projection_ragged_shapes(n_nodes, r):
         rom.compute_RO_state()
 
 
-@pytest.mark.parametrize('n_s,n_f', [(1, 5), (3, 200), (130, 77), (257, 1000)])
+@pytest.mark.parametrize('n_s,n_f', [(1, 5), (3, 200), (130, 77), (257, 1000), (4200, 1100)])   # last: K-split tail tiles
 def test_gramian_ragged(n_s, n_f):
     from sofacontrol_amd.mor.pod import gramian
     S = np.random.default_rng(2).standard_normal((n_s, n_f))
