@@ -8,6 +8,7 @@ struct sekf {
     int n = 0, m = 0, ny = 0;
     srh::DevBuf C, y_ref, W, V, x, Sigma, scratch, ext;
     size_t lds = 0;
+    bool mfma = false;
     // pinned host mirrors of the per-step input (u, y) and output (x, status): one copy each way per step
     double *pin_in = nullptr, *pin_out = nullptr;
     ~sekf() {
@@ -43,7 +44,17 @@ __device__ __forceinline__ double dotk(clptr a, int sa, clptr b, int sb, int K) 
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
     }
-    for (; k < K; ++k) acc = fma(a[k * sa], b[k * sb], acc);
+    if (k < K) {                 // remainder as one predicated batch (a rolled tail pays the LDS latency per element)
+        double av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool in = k + q < K;
+            av[q] = in ? a[(k + q) * sa] : 0.0;
+            bv[q] = in ? b[(k + q) * sb] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
+    }
     return acc;
 }
 
@@ -181,6 +192,157 @@ __global__ __launch_bounds__(EKF_NT) void ekf_kernel(EkfArgs a) {
     if (tid == 0) *a.status = 0;
 }
 
+// ---- the same filter step on f64 MFMA products (used when the padded panels fit LDS: n_x <= 64)
+// All operands are kept k-major so that every product is C = Lm^T Rm (wg::mfma_atb):
+//   U = Sigma A^T (Lm = Sigma, symmetric; Rm = A^T from the transposed table), Sigma^- = A U (Lm = A^T, Rm = U),
+//   M1 = Sigma^- C^T (Lm = Sigma^-, Rm = C^T), CS = C Sigma^- (Lm = C^T, Rm = Sigma^-), S = C M1 (Lm = C^T, Rm = M1),
+//   Sigma = Sigma^- - K CS with K^T = S^-1 CS (Lm = K^T, Rm = CS).
+// S^-1 through the Cholesky factor and its explicit triangular inverse, both by one wave (n_y <= 64).
+struct EkfMfmaDims {
+    int n16, ny16, ld, ldy, NK, NKy;
+};
+
+__host__ __device__ inline EkfMfmaDims ekf_mfma_dims(int n, int ny) {
+    EkfMfmaDims d;
+    d.n16 = (n + 15) & ~15; d.ny16 = (ny + 15) & ~15; d.ld = d.n16 + 1; d.ldy = d.ny16 + 1;
+    d.NK = (n + 3) & ~3; d.NKy = (ny + 3) & ~3;
+    return d;
+}
+
+__host__ __device__ inline size_t ekf_mfma_doubles(int n, int ny) {
+    const EkfMfmaDims d = ekf_mfma_dims(n, ny);
+    const size_t nv = (size_t)(d.n16 > d.ny16 ? d.n16 : d.ny16);
+    return 3 * (size_t)d.n16 * d.ld + (size_t)d.ny16 * d.ld + 3 * (size_t)d.ny16 * d.ldy + 4 * nv + 8;
+}
+
+__global__ __launch_bounds__(EKF_NT) void ekf_mfma_kernel(EkfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = a.n, m = a.m, ny = a.ny;
+    const EkfMfmaDims D = ekf_mfma_dims(n, ny);
+    const int n16 = D.n16, ny16 = D.ny16, ld = D.ld, ldy = D.ldy, NK = D.NK, NKy = D.NKy;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    lptr SG = (lptr)smem;                       // Sigma, then Sigma^-                         (n16 x ld)
+    lptr AT = SG + (size_t)n16 * ld;            // A^T, then C^T, then K CS                    (n16 x ld)
+    lptr UU = AT + (size_t)n16 * ld;            // U = Sigma A^T, then M1, then Y | K^T        (n16 x ld)
+    lptr CS = UU + (size_t)n16 * ld;            // C Sigma^-                                   (ny16 x ld)
+    lptr Sm = CS + (size_t)ny16 * ld;           // S, then its Cholesky factor L (lower)       (ny16 x ldy)
+    lptr Li = Sm + (size_t)ny16 * ldy;          // L^-1 (lower)
+    lptr LiT = Li + (size_t)ny16 * ldy;         // L^-T
+    const int nv = n16 > ny16 ? n16 : ny16;
+    lptr xv = LiT + (size_t)ny16 * ldy, xn = xv + nv, iv = xn + nv, uv = iv + nv;
+    liptr ip = (liptr)(uv + nv);
+
+    for (int e = tid; e < 3 * n16 * ld + ny16 * ld + 3 * ny16 * ldy; e += nt) SG[e] = 0.0;
+    if (tid == 0) ip[1] = 0;
+    __syncthreads();
+    for (int e = tid; e < n * n; e += nt) SG[(e / n) * ld + e % n] = a.Sigma[e];
+    for (int e = tid; e < n; e += nt) xv[e] = a.x[e];
+    if (a.do_predict)
+        for (int e = tid; e < m; e += nt) uv[e] = a.u[e];
+    __syncthreads();
+
+    if (a.do_predict) {
+        const double *Bg, *dg;
+        if (a.Aext != nullptr) {
+            Bg = a.Bext; dg = a.dext;
+            for (int e = tid; e < n * n; e += nt) AT[(e % n) * ld + e / n] = a.Aext[e];
+        } else {
+            if (tid < 64) {
+                const int i = tpwl::nearest_wave(a.T, xv);
+                if (tid == 0) ip[0] = i;
+            }
+            __syncthreads();
+            const size_t i = (size_t)ip[0];
+            cgptr At = a.T.AdT + i * n * n;          // transposed table: At[k * n + r] = A[r][k]
+            Bg = (const double *)a.T.Bd + i * n * m;
+            dg = (const double *)a.T.dd + i * n;
+            for (int e = tid; e < n * n; e += nt) AT[(e / n) * ld + e % n] = At[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            double t = 0.0;
+            for (int k = 0; k < m; ++k) t = fma(Bg[i * m + k], uv[k], t);
+            xn[i] = dotk(AT + i, ld, xv, 1, n) + t + dg[i];
+        }
+        wg::mfma_atb(UU, ld, SG, AT, NK, n16 >> 4, n16 >> 4, ld, n);            // U = Sigma A^T
+        wg::mfma_atb(SG, ld, AT, UU, NK, n16 >> 4, n16 >> 4, ld, n);            // Sigma^- = A U
+        for (int e = tid; e < n * n; e += nt) SG[(e / n) * ld + e % n] += a.W[e];
+        for (int e = tid; e < n; e += nt) xv[e] = xn[e];
+        __syncthreads();
+    }
+
+    if (a.do_update) {
+        for (int e = tid; e < n16 * ld; e += nt) AT[e] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < ny * n; e += nt) AT[(e % n) * ld + e / n] = a.C[e];      // C^T
+        __syncthreads();
+        for (int i = tid; i < ny; i += nt)
+            iv[i] = a.y[i] - (a.y_ref ? a.y_ref[i] : 0.0) - dotk(AT + i, ld, xv, 1, n);
+        wg::mfma_atb(UU, ld, SG, AT, NK, n16 >> 4, ny16 >> 4, ld, n);             // M1 = Sigma^- C^T   (n x ny)
+        wg::mfma_atb(CS, ld, AT, SG, NK, ny16 >> 4, n16 >> 4, ld, ny);            // CS = C Sigma^-     (ny x n)
+        wg::mfma_atb(Sm, ldy, AT, UU, NK, ny16 >> 4, ny16 >> 4, ld, ny);          // C M1               (ny x ny)
+        for (int e = tid; e < ny * ny; e += nt) Sm[(e / ny) * ldy + e % ny] += a.V[e];
+        __syncthreads();
+        if (tid < 64) {
+            // left-looking Cholesky, lane = row: column j of L from the finished columns < j (no trailing update)
+            bool ok = true;
+            for (int j = 0; j < ny; ++j) {
+                double sj = 0.0;
+                if (lane >= j && lane < ny) sj = Sm[lane * ldy + j] - dotk(Sm + lane * ldy, 1, Sm + j * ldy, 1, j);
+                const double djj = __shfl(sj, j, 64);
+                if (!(djj > 0.0)) { ok = false; break; }                              // uniform
+                const double rj = sqrt(djj);
+                if (lane >= j && lane < ny) Sm[lane * ldy + j] = (lane == j) ? rj : sj / rj;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!ok && tid == 0) ip[1] = 1;
+            if (ok) {
+                // L^-1, lane = column c: row i from rows < i (entries above the diagonal stay zero)
+                for (int i = 0; i < ny; ++i) {
+                    if (lane <= i && lane < ny) {
+                        const double sdot = dotk(Sm + i * ldy, 1, Li + lane, ldy, i);
+                        const double v = ((lane == i) ? 1.0 : -sdot) / Sm[i * ldy + i];
+                        Li[i * ldy + lane] = v;
+                        LiT[lane * ldy + i] = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        __syncthreads();
+        if (ip[1] != 0) {
+            if (tid == 0) *a.status = 1;
+            return;
+        }
+        // Y = L^-1 CS (rows 0.. of UU), K^T = L^-T Y (rows ny16.. of UU)
+        lptr Y = UU, KT = UU + (size_t)ny16 * ld;
+        for (int e = tid; e < ny * n; e += nt) {
+            const int i = e / n, j = e % n;
+            Y[i * ld + j] = dotk(Li + i * ldy, 1, CS + j, ld, i + 1);
+        }
+        for (int e = tid; e < (ny16 - ny) * ld; e += nt) Y[ny * ld + e] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < ny16 * ld; e += nt) {
+            const int i = e / ld, j = e % ld;
+            double v = 0.0;
+            if (i < ny && j < n) v = dotk(LiT + i * ldy + i, 1, Y + (size_t)i * ld + j, ld, ny - i);
+            KT[e] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) xn[i] = xv[i] + dotk(KT + i, ld, iv, 1, ny);
+        wg::mfma_atb(AT, ld, KT, CS, NKy, n16 >> 4, n16 >> 4, ld, n);              // K CS
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            a.Sigma[e] = SG[i * ld + j] - AT[i * ld + j];
+        }
+        for (int e = tid; e < n; e += nt) a.x[e] = xn[e];
+    } else {
+        for (int e = tid; e < n * n; e += nt) a.Sigma[e] = SG[(e / n) * ld + e % n];
+        for (int e = tid; e < n; e += nt) a.x[e] = xv[e];
+    }
+    if (tid == 0) *a.status = 0;
+}
+
 size_t lds_bytes(int n, int ny) {
     const int ld = n | 1, ldy = ny | 1;
     const int nv = n > ny ? n : ny;
@@ -198,6 +360,11 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
     auto *h = new sekf();
     h->model = model; h->n = model->n; h->m = model->m; h->ny = n_y;
     h->lds = lds_bytes(h->n, n_y);
+    if (n_y <= 64 && 2 * ((n_y + 15) & ~15) <= ((h->n + 15) & ~15) && sizeof(double) * ekf_mfma_doubles(h->n, n_y) <= 160 * 1024 &&
+        !getenv("SRH_EKF_NO_MFMA")) {
+        h->mfma = true;
+        h->lds = sizeof(double) * ekf_mfma_doubles(h->n, n_y);
+    }
     if (h->lds > 160 * 1024) {
         delete h;
         srh::set_error("sekf_create: the filter step does not fit the 160 KB LDS (n_x too large)");
@@ -216,8 +383,8 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
     SRH_CHECK_HIP(hipMemset(h->x.p, 0, sizeof(double) * n));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_in, sizeof(double) * (h->m + n_y) + 64, hipHostMallocDefault));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (n + 2), hipHostMallocDefault));
-    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ekf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)h->lds));
+    SRH_CHECK_HIP(hipFuncSetAttribute(h->mfma ? (const void *)ekf_mfma_kernel : (const void *)ekf_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     *out = h;
     return SRH_OK;
 }
@@ -274,7 +441,8 @@ int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, co
     if (ext && u) { a.Aext = e; a.Bext = e + (size_t)n * n; a.dext = e + (size_t)n * n + (size_t)n * m; }
     a.do_predict = u != nullptr; a.do_update = y != nullptr;
     a.status = st;
-    ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
+    if (h->mfma) ekf_mfma_kernel<<<1, EKF_NT, h->lds>>>(a);
+    else ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out, h->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
     SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out + n, st, sizeof(int), hipMemcpyDeviceToHost, nullptr));
