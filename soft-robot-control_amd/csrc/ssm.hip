@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
 
 namespace {
 
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(SSM_NT) void ssm_dyn_kernel(SsmDev S, const double 
     for (int e = tid; e < n; e += nt) xs[e] = X[b * n + e];
     for (int e = tid; e < m; e += nt) us[e] = U[b * m + e];
     __syncthreads();
-    ssm::basis(S.er, S.nr, n, xs, w.phi, (lptr) nullptr);
+    ssm::basis(S.er, S.pr, S.vr, S.dmr, S.lvr, S.order_r, S.nr, n, xs, w.phi, (lptr) nullptr);
     cgptr Rc = discrete ? S.Rd : S.R, Bg = discrete ? S.Bd : S.Bc;
     for (int i = tid; i < n; i += nt) {
         double s = 0.0;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(SSM_NT) void ssm_reduce_kernel(SsmDev S, const doub
     lptr zs = (lptr)smem + ssm::work_doubles(n, S.m, no, S.nr, S.ns);
     for (int e = tid; e < no; e += nt) zs[e] = Z[b * no + e] - S.z_ref[e];
     __syncthreads();
-    ssm::basis(S.es, S.ns, no, zs, w.phi, (lptr) nullptr);
+    ssm::basis(S.es, S.ps, S.vs, S.dms, S.lvs, S.order_s, S.ns, no, zs, w.phi, (lptr) nullptr);
     for (int i = tid; i < n; i += nt) {
         double s = 0.0;
         for (int k = 0; k < S.ns; ++k) s = fma(S.Vc[(size_t)i * S.ns + k], w.phi[k], s);
@@ -164,10 +165,48 @@ std::vector<int> ssm_exponents(int dim, int order) {
     return out;
 }
 
+// evaluation tables of a graded monomial basis (see ssm::basis): parent, variable, derivative index, level offsets
+static int ssm_upload_tables(const std::vector<int> &E, int dim, int order, srh::DevBuf (&t)[4]) {
+    const int nm = (int)(E.size() / dim);
+    std::map<std::vector<int>, int> index;
+    for (int j = 0; j < nm; ++j) index[std::vector<int>(E.begin() + (size_t)j * dim, E.begin() + (size_t)(j + 1) * dim)] = j;
+    std::vector<int> par(nm), var(nm), dm((size_t)nm * dim), lv(order + 1, nm);
+    int prev_deg = 0;
+    for (int j = 0; j < nm; ++j) {
+        std::vector<int> e(E.begin() + (size_t)j * dim, E.begin() + (size_t)(j + 1) * dim);
+        int deg = 0, last = 0;
+        for (int i = 0; i < dim; ++i) { deg += e[i]; if (e[i] > 0) last = i; }
+        if (deg != prev_deg) { for (int d = prev_deg; d < deg; ++d) lv[d] = j; prev_deg = deg; }
+        var[j] = last;
+        if (deg == 1) {
+            par[j] = -1;
+        } else {
+            std::vector<int> p = e; p[last] -= 1;
+            par[j] = index.at(p);
+        }
+        for (int i = 0; i < dim; ++i) {
+            if (e[i] == 0) { dm[(size_t)j * dim + i] = -1; continue; }
+            if (deg == 1) { dm[(size_t)j * dim + i] = -2; continue; }
+            std::vector<int> p = e; p[i] -= 1;
+            dm[(size_t)j * dim + i] = index.at(p);
+        }
+    }
+    lv[order] = nm;
+    // lv[d] = first index of degree d + 1, d = 0 .. order - 1
+    int rc;
+    if ((rc = t[0].upload(par.data(), sizeof(int) * nm)) || (rc = t[1].upload(var.data(), sizeof(int) * nm)) ||
+        (rc = t[2].upload(dm.data(), sizeof(int) * dm.size())) || (rc = t[3].upload(lv.data(), sizeof(int) * lv.size())))
+        return rc;
+    return SRH_OK;
+}
+
 SsmDev sssm::view() const {
     SsmDev S{};
     S.n = n; S.m = m; S.no = no; S.nr = nr; S.ns = ns;
     S.er = er.as<int>(); S.es = es.as<int>();
+    S.pr = tr[0].as<int>(); S.vr = tr[1].as<int>(); S.dmr = tr[2].as<int>(); S.lvr = tr[3].as<int>();
+    S.ps = ts[0].as<int>(); S.vs = ts[1].as<int>(); S.dms = ts[2].as<int>(); S.lvs = ts[3].as<int>();
+    S.order_r = order_r; S.order_s = order_s;
     auto g = [](const srh::DevBuf &b) { return (cgptr)b.as<double>(); };
     S.R = g(R); S.Bc = g(Bc); S.Rd = g(Rd); S.Bd = g(Bd); S.Wc = g(Wc); S.Vc = g(Vc); S.z_ref = g(z_ref); S.H = g(H);
     return S;
@@ -198,7 +237,12 @@ int sssm_create(sssm_t **out, int n_x, int n_u, int n_o, int rom_order, int ssm_
     h->n = n_x; h->m = n_u; h->no = n_o;
     auto er = ssm_exponents(n_x, rom_order), es = ssm_exponents(n_o, ssm_order);
     h->nr = (int)(er.size() / n_x); h->ns = (int)(es.size() / n_o);
+    h->order_r = rom_order; h->order_s = ssm_order;
     int rc;
+    if ((rc = ssm_upload_tables(er, n_x, rom_order, h->tr)) || (rc = ssm_upload_tables(es, n_o, ssm_order, h->ts))) {
+        delete h;
+        return rc;
+    }
     std::vector<double> Hz((size_t)n_o * n_x, 0.0);
     if ((rc = h->er.upload(er.data(), sizeof(int) * er.size())) || (rc = h->es.upload(es.data(), sizeof(int) * es.size())) ||
         (rc = h->R.upload(r_coeff, sizeof(double) * n_x * h->nr)) || (rc = h->Bc.upload(B, sizeof(double) * n_x * n_u)) ||

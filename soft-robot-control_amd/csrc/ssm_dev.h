@@ -8,6 +8,11 @@ struct SsmDev {
     int n, m, no;              // reduced state, input, observed dimension
     int nr, ns;                // monomial counts: rom basis (n variables), ssm basis (no variables)
     const int *er, *es;        // exponent tables (nr x n), (ns x no)
+    // evaluation tables per basis (host-built, ssm.hip): parent monomial / multiplied variable of every monomial
+    // (phi_j = phi_parent * x_var; parent < 0: phi_j = x_var), index of the monomial e_j - 1_i for the derivatives
+    // (-1: zero, -2: the constant 1), first index of every degree (order + 1 offsets)
+    const int *pr, *vr, *dmr, *lvr, *ps, *vs, *dms, *lvs;
+    int order_r, order_s;
     cgptr R, Bc;               // r_coeff (n x nr), B (n x m)              continuous reduced dynamics
     cgptr Rd, Bd;              // rd_coeff, Bd or null                      discrete reduced dynamics
     cgptr Wc;                  // w_coeff (no x ns)  reduced -> observed (needs n == no)
@@ -22,31 +27,46 @@ enum { SSM_CONT = 0, SSM_FE = 1, SSM_BE = 2, SSM_BIL = 3, SSM_DISCRETE_MAP = 4 }
 namespace ssm {
 
 // phi_j(x) = prod_i x_i^e_ji and, if D != null, D[j][i] = d phi_j / d x_i    (all threads; ends with a sync)
-__device__ inline void basis(const int *__restrict__ ex, int nmon, int dim, clptr x, lptr phi, lptr D) {
-    for (int j = threadIdx.x; j < nmon; j += blockDim.x) {
-        const int *e = ex + (size_t)j * dim;
-        double p = 1.0;
-        for (int i = 0; i < dim; ++i) {
-            const double xi = x[i];
-            for (int k = 0; k < e[i]; ++k) p *= xi;
+// Degree by degree: phi_j = phi_parent(j) * x_var(j) (one multiply per monomial); the derivative of a monomial is
+// e_ji times the monomial with exponents e_j - 1_i, looked up in the table -- O(n_mon * dim) instead of
+// O(n_mon * dim^2 * order) for the direct products.
+__device__ inline void basis(const int *__restrict__ ex, const int *__restrict__ par, const int *__restrict__ var,
+                             const int *__restrict__ dm, const int *__restrict__ lv, int order, int nmon, int dim, clptr x,
+                             lptr phi, lptr D) {
+    for (int d = 0; d < order; ++d) {
+        const int j0 = lv[d], j1 = lv[d + 1];
+        for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+            const int pj = par[j];
+            phi[j] = (pj < 0 ? 1.0 : phi[pj]) * x[var[j]];
         }
-        phi[j] = p;
-        if (D != nullptr) {
-            for (int i = 0; i < dim; ++i) {
-                double g = 0.0;
-                if (e[i] > 0) {
-                    g = (double)e[i];
-                    for (int l = 0; l < dim; ++l) {
-                        const int pw = e[l] - (l == i ? 1 : 0);
-                        const double xl = x[l];
-                        for (int k = 0; k < pw; ++k) g *= xl;
-                    }
-                }
-                D[(size_t)j * dim + i] = g;
-            }
-        }
+        __syncthreads();
     }
-    __syncthreads();
+    if (D != nullptr) {
+        for (int e = threadIdx.x; e < nmon * dim; e += blockDim.x) {
+            const int q = dm[e];
+            D[e] = q == -1 ? 0.0 : (double)ex[e] * (q == -2 ? 1.0 : phi[q]);
+        }
+        __syncthreads();
+    }
+}
+
+// sum_k a[k * sa] * b[k * sb] with eight operand pairs in flight per trip (a rolled load -> fma chain pays the
+// L2 / LDS latency of every element); a, b in any address space
+template <typename AP, typename BP>
+__device__ __forceinline__ double dot8(AP a, int sa, BP b, int sb, int K) {
+    double acc = 0.0;
+    for (int k = 0; k < K; k += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool in = k + q < K;
+            av[q] = in ? a[(size_t)(k + q) * sa] : 0.0;
+            bv[q] = in ? b[(size_t)(k + q) * sb] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
+    }
+    return acc;
 }
 
 // In-place Gauss-Jordan inverse with partial pivoting of the n x n matrix M (LDS, leading dimension ld);
@@ -124,20 +144,16 @@ __device__ inline void linearize(const SsmDev &S, int mode, double dt, clptr x, 
     const int n = S.n, m = S.m, tid = threadIdx.x, nt = blockDim.x;
     const bool dm = mode == SSM_DISCRETE_MAP;
     cgptr Rc = dm ? S.Rd : S.R, Bg = dm ? S.Bd : S.Bc;
-    basis(S.er, S.nr, n, x, w.phi, w.D);
+    basis(S.er, S.pr, S.vr, S.dmr, S.lvr, S.order_r, S.nr, n, x, w.phi, w.D);
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e % n;
-        double s = 0.0;
-        for (int k = 0; k < S.nr; ++k) s = fma(Rc[(size_t)i * S.nr + k], w.D[(size_t)k * n + j], s);
-        A[i * lda + j] = s;
+        A[i * lda + j] = dot8(Rc + (size_t)i * S.nr, 1, w.D + j, n, S.nr);
     }
     for (int e = tid; e < n * m; e += nt) Bm[e] = Bg[e];
     for (int i = tid; i < n; i += nt) {
-        double s = 0.0;
-        for (int k = 0; k < S.nr; ++k) s = fma(Rc[(size_t)i * S.nr + k], w.phi[k], s);
         double t = 0.0;
         for (int k = 0; k < m; ++k) t = fma(Bg[i * m + k], u[k], t);
-        w.f[i] = s + t;
+        w.f[i] = dot8(Rc + (size_t)i * S.nr, 1, w.phi, 1, S.nr) + t;
     }
     __syncthreads();
     for (int i = tid; i < n; i += nt) {
@@ -209,18 +225,14 @@ __device__ inline void linearize(const SsmDev &S, int mode, double dt, clptr x, 
 // (ssm.py:220-235).  Ends with a sync.
 __device__ inline void observe(const SsmDev &S, clptr x, Work &w, lptr z, lptr Hj, lptr c) {
     const int n = S.n, no = S.no, tid = threadIdx.x, nt = blockDim.x;
-    basis(S.es, S.ns, no, x, w.phi, Hj != nullptr ? w.D : (lptr) nullptr);
+    basis(S.es, S.ps, S.vs, S.dms, S.lvs, S.order_s, S.ns, no, x, w.phi, Hj != nullptr ? w.D : (lptr) nullptr);
     for (int i = tid; i < no; i += nt) {
-        double s = 0.0;
-        for (int k = 0; k < S.ns; ++k) s = fma(S.Wc[(size_t)i * S.ns + k], w.phi[k], s);
-        z[i] = s;
+        z[i] = dot8(S.Wc + (size_t)i * S.ns, 1, w.phi, 1, S.ns);
     }
     if (Hj != nullptr) {
         for (int e = tid; e < no * n; e += nt) {
             const int i = e / n, j = e % n;
-            double s = 0.0;
-            for (int k = 0; k < S.ns; ++k) s = fma(S.Wc[(size_t)i * S.ns + k], w.D[(size_t)k * no + j], s);
-            Hj[e] = s;
+            Hj[e] = dot8(S.Wc + (size_t)i * S.ns, 1, w.D + j, no, S.ns);
         }
     }
     __syncthreads();

@@ -8,6 +8,8 @@ struct sssm {
     bool has_discrete = false;
     size_t lds = 0;
     srh::DevBuf er, es, R, Bc, Rd, Bd, Wc, Vc, z_ref, H;
+    srh::DevBuf tr[4], ts[4];          // evaluation tables of the two bases (parent, variable, derivative index, levels)
+    int order_r = 0, order_s = 0;
     SsmDev view() const;
 };
 
