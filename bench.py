@@ -216,7 +216,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--rollouts', type=int, default=2048, help='independent SCP rollouts per GPU per step')
+    ap.add_argument('--rollouts', type=int, default=4096, help='independent SCP rollouts per GPU per step')
     ap.add_argument('--proj-batch', type=int, default=65536, help='snapshots per GPU in the POD projection batch')
     ap.add_argument('--proj-launches', type=int, default=4, help='projection launches per step')
     ap.add_argument('--max-gusto-iters', type=int, default=5,
