@@ -27,15 +27,15 @@ sys.path.insert(0, os.path.join(ROOT, 'soft-robot-control_amd'))
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def build_model(w):
+def build_model(w, tip_node=1354):
     import scipy.sparse as sp
     from sofacontrol_amd.tpwl.tpwl import TPWLATV
     from sofacontrol_amd.scp.models.tpwl import TPWLGuSTO
     n_f = w['U'].shape[0]
     Hf = sp.lil_matrix((6, 2 * n_f))
     for a in range(3):
-        Hf[a, 3 * 1354 + a] = 1.0
-        Hf[3 + a, n_f + 3 * 1354 + a] = 1.0
+        Hf[a, 3 * tip_node + a] = 1.0
+        Hf[3 + a, n_f + 3 * tip_node + a] = 1.0
     data = dict(w['tab'], rom_info=dict(type='POD', U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
     tp = TPWLATV(data=data, params=dict(tpwl_method='nn', dist_weights={'q': 1.0, 'v': 0.0}), Hf=Hf.tocsr(),
                  discr_method='zoh')
@@ -135,6 +135,51 @@ def closed_loop_latency(w, rom, tp):
             'workload': 'one full state (2 x %d) -> 2r = %d; EKF n_x = %d, n_y = 30; host-pointer API' % (n_f, 2 * r, 2 * r)}
 
 
+def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
+    """BASELINE config C5: 256 parallel SCP rollouts on the Trunk shape (r = 30, n_u = 8, N = 50), STRONG scaling:
+    the 256 rollouts are split over the ranks (distributed.shard_range), no data-path collective."""
+    import workloads as wl
+    from scipy.interpolate import interp1d
+    from sofacontrol_amd.distributed import shard_range
+    from sofacontrol_amd.mor.pod import POD
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.trunk_c5()
+    N, m, r, dt = w['N'], w['m'], w['r'], w['dt']
+    lo, hi = shard_range(total, rank, world)
+    Bn = hi - lo
+    rom = POD(dict(U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
+    tp, gm = build_model(w, w['tip_node'])
+    xc, fc = gm.get_characteristic_vals()
+    X = wl.snapshots(w['q_ref'], total, seed=9)[lo:hi]
+    x0 = np.concatenate((np.zeros((Bn, r)), rom.compute_RO_state(qf=X)), axis=1)
+    u_init = np.zeros((Bn, N, m))
+    x_init, _ = tp.rollout(x0, u_init, dt)
+    zi = interp1d(w['t'], w['z'], axis=0, bounds_error=False, fill_value=(w['z'][0], w['z'][-1]))
+    z = np.stack([zi((lo + b) * (10.0 / total) + dt * np.arange(N + 1)) for b in range(Bn)])
+    g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), x_char=xc, f_char=fc,
+              convg_thresh=1e-3, batch=Bn, max_trace=0, max_gusto_iters=max_iters)
+    g.max_gusto_iters = max_iters
+    if dist is not None:
+        dist.barrier()
+    _lib.sync()
+    t0 = time.perf_counter()
+    g.solve_batch(x0, u_init, x_init, z=z)
+    el = time.perf_counter() - t0
+    its = float(g.iters.sum())
+    if dist is not None:
+        import torch
+        tt = torch.tensor([el, its], dtype=torch.float64, device='cuda')
+        tm = tt.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        el, its = float(tm[0]), float(tt[1])
+    return {'workload': 'C5: Trunk n_f=2127, r=30 (n_x=60, n_u=8), N=50, U box; %d rollouts in total, %d per rank, '
+                        'strong scaling; host buffers' % (total, Bn),
+            'iterations_per_s': its / el, 'ms': el * 1e3, 'iterations': its,
+            'not_converged_rank0': int((g.status != 0).sum())}
+
+
 def secondary(L, _lib, rank, world, dist):
     import workloads as wl
     """Secondary metrics of SURVEY.md section 8(d), measured outside the timed region of the headline metric:
@@ -199,6 +244,10 @@ def secondary(L, _lib, rank, world, dist):
     out['gramian_c4'] = {'workload': 'C4 per-GPU shard: S %d x %d f64, G = S S^T' % (n_s, n_f), 'ms': ms.value,
                          'tflops_executed': flop / (ms.value * 1e-3) / 1e12,
                          'frac_of_f64_mfma_peak': flop / (ms.value * 1e-3) / 1e12 / 78.6}
+    try:
+        out['scp_c5'] = scp_c5(_lib, rank, world, dist)
+    except Exception as exc:
+        out['scp_c5'] = {'error': repr(exc)}
     if dist is not None:
         import torch
         dist.all_reduce(G)                      # untimed: RCCL sets up its channels for this size

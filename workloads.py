@@ -90,6 +90,23 @@ def figure8(z_ref, T=10.0, M=1000, scale=1.0):
     return t, z
 
 
+def trunk_c5(r=30, N=50, dt=0.05, seed=20, P=64, n_f=2127, tip_node=51):
+    """BASELINE config C5: Trunk n_f = 2127 (3 x 709), POD r = 30 (n_x = 60), n_u = 8, SCP horizon N = 50
+    (examples/trunk/trunk.py:292-316): Qz = diag(0,0,0,100,100,0), R = 1e-5 I, U = [0,800]^8, X = None."""
+    m = 8
+    U, q_ref, v_ref = pod_basis(n_f, r, seed=3)
+    H = tip_selector_rows(U, tip_node)
+    tab = tpwl_tables(r, m, P, seed=seed, u_max=800.0)
+    Ad, Bd, dd = zoh_tables(tab, dt)
+    Qz = np.zeros((6, 6)); Qz[3, 3] = 100.0; Qz[4, 4] = 100.0
+    R = 1e-5 * np.eye(m)
+    UA = np.kron(np.eye(m), np.array([[1.0], [-1.0]]))
+    Ub = np.tile([800.0, 0.0], m)
+    t, z = figure8(None)
+    return dict(U=U, q_ref=q_ref, v_ref=v_ref, H=H, tab=tab, Ad=Ad, Bd=Bd, dd=dd, dt=dt, N=N, Qz=Qz, R=R,
+                UA=UA, Ub=Ub, XA=None, Xb=None, t=t, z=z, r=r, m=m, P=P, tip_node=tip_node)
+
+
 def diamond_c2(r=30, N=50, dt=0.05, seed=10, P=64, n_f=4884, tip_node=1354, with_X=True):
     """BASELINE config C2: Diamond n_f = 4884, POD r = 30 (n_x = 60), n_u = 4, SCP horizon N = 50,
     dt = 0.05 (examples/diamond/diamond.py:285-310): Qz = diag(0,0,0,100,100,0), R = 1e-5 I,
