@@ -41,8 +41,6 @@ class iLQR:
         """ilqr.py:27-107; batched when x0 is (B, n_x) (z_target (B, N+1, n_z), u_warmstart (B, N, n_u))."""
         from ..SSM.ssm import SSM
         is_ssm = isinstance(self.model, SSM)
-        if not is_ssm:
-            self.model._ensure_discrete(self.dt)
         N, n, m = self.planning_horizon, self.state_dim, self.input_dim
         x0a = _lib.f64(np.atleast_2d(x0))
         Bn = x0a.shape[0]
@@ -65,7 +63,7 @@ class iLQR:
                                                   _lib.iptr(iters)), 'silqr_solve_ssm')
             self.cost, self.iters = cost, iters
             return (x[0], u[0], K[0]) if single else (x, u, K)
-        _lib.check(_lib.lib().silqr_solve(self.model.handle, C.c_int(N), C.c_int64(Bn), _lib.dptr(x0a), _lib.dptr(zt),
+        _lib.check(_lib.lib().silqr_solve(self.model.handle_for(self.dt), C.c_int(N), C.c_int64(Bn), _lib.dptr(x0a), _lib.dptr(zt),
                                           _lib.dptr(uw), _lib.dptr(ul), _lib.dptr(_lib.f64(cp.Q)), _lib.dptr(_lib.f64(cp.R)),
                                           _lib.dptr(_lib.f64(cp.Qf)), C.byref(par), _lib.dptr(x), _lib.dptr(u),
                                           _lib.dptr(K), _lib.dptr(cost), _lib.iptr(iters)), 'silqr_solve')

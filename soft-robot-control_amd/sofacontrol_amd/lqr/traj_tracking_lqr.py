@@ -28,11 +28,10 @@ class TrajTrackingLQR:
         t_steps = np.arange(nbr_steps) * self.dt
         self.x_bar = x_nom_interp(t_steps)
         self.u_bar = u_nom_interp(t_steps)
-        self.model._ensure_discrete(self.dt)
         n, m = self.model.get_state_dim(), self.model.get_input_dim()
         K = np.empty((nbr_steps, m, n)); P = np.empty((nbr_steps + 1, n, n))
         xb = _lib.f64(self.x_bar)
-        _lib.check(_lib.lib().sric_tvlqr_tpwl(self.model.handle, _lib.dptr(xb), C.c_int(nbr_steps),
+        _lib.check(_lib.lib().sric_tvlqr_tpwl(self.model.handle_for(self.dt), _lib.dptr(xb), C.c_int(nbr_steps),
                                               _lib.dptr(_lib.f64(self.cost_params.Q)), _lib.dptr(_lib.f64(self.cost_params.R)),
                                               _lib.dptr(K), _lib.dptr(P)), 'sric_tvlqr_tpwl')
         return K, P

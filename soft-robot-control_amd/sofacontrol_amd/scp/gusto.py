@@ -70,11 +70,10 @@ class GuSTO:
         self.iters = None
         self.status = None
         if self._fused:
-            model.dyn_sys._ensure_discrete(dt)
             prob, self._keep = make_problem(N, model.H, Qz, R, Qzf, U, X, Xf, dU, None, True)
             par = self._params(MAX_ITERS)
             xc, fc = _lib.f64(self.x_char), _lib.f64(self.f_char)
-            _lib.check(_lib.lib().sgusto_plan_create(C.byref(self._plan), model.dyn_sys.handle, C.byref(prob),
+            _lib.check(_lib.lib().sgusto_plan_create(C.byref(self._plan), model.dyn_sys.handle_for(dt), C.byref(prob),
                                                      C.byref(par), C.c_double(dt), C.c_int64(self.batch),
                                                      _lib.dptr(xc), _lib.dptr(fc), C.c_int(self.max_trace)),
                        'sgusto_plan_create')

@@ -53,7 +53,7 @@ class TPWLGuSTO(TemplateModel):
             f = np.einsum('bij,bj->bi', A, x) + np.einsum('bij,bj->bi', B, tabs[2]) + d
             return np.abs(x).max(axis=0), np.abs(f).max(axis=0)
         xc, fc = np.empty(n), np.empty(n)
-        _lib.check(_lib.lib().stpwl_characteristic(self.dyn_sys.handle, _lib.dptr(xc), _lib.dptr(fc)),
+        _lib.check(_lib.lib().stpwl_characteristic(self.dyn_sys.handle_for(None), _lib.dptr(xc), _lib.dptr(fc)),
                    'stpwl_characteristic')
         return xc, fc
 

@@ -37,16 +37,31 @@ class DiscreteEKFObserver:
         self.C = self.dyn_sys.C
         self.state_dim = self.dyn_sys.get_state_dim()
         self.meas_dim = self.C.shape[0]
-        Sigma0 = kwargs.get('Sigma0', np.eye(self.state_dim))
+        self._Sigma0 = np.array(kwargs.get('Sigma0', np.eye(self.state_dim)), dtype=np.float64)
         self.W = kwargs.get('W', 100 * np.eye(self.state_dim))
         self.V = kwargs.get('V', np.eye(self.meas_dim))
         self._h = C.c_void_p()
+        self._filter_dt = None
+        self._make_filter(None, self._Sigma0, None)
+        self.initialize(self.dyn_sys.rom.x_ref)
+
+    def _make_filter(self, dt, Sigma, x):
+        """(Re)create the device filter on the model handle whose tables are discretised at `dt` (the planner and
+        the simulation usually run different time steps: each keeps its own tables, tpwl.handle_for)."""
+        if self._h:
+            _lib.lib().sekf_destroy(self._h)
+            self._h = C.c_void_p()
+        nn = getattr(self.dyn_sys, 'tpwl_method', 'nn') == 'nn'
+        mh = self.dyn_sys.handle_for(dt if nn else None)
         Cm, yr = _lib.f64(self.C), _lib.f64(self.dyn_sys.y_ref)
-        S0, W, V = _lib.f64(Sigma0), _lib.f64(self.W), _lib.f64(self.V)
-        _lib.check(_lib.lib().sekf_create(C.byref(self._h), self.dyn_sys.handle, _lib.dptr(Cm), _lib.dptr(yr),
+        S0, W, V = _lib.f64(Sigma), _lib.f64(self.W), _lib.f64(self.V)
+        _lib.check(_lib.lib().sekf_create(C.byref(self._h), mh, _lib.dptr(Cm), _lib.dptr(yr),
                                           C.c_int(self.meas_dim), _lib.dptr(S0), _lib.dptr(W), _lib.dptr(V)),
                    'sekf_create')
-        self.initialize(self.dyn_sys.rom.x_ref)
+        if x is not None:
+            xx = _lib.f64(x)
+            _lib.check(_lib.lib().sekf_set_state(self._h, _lib.dptr(xx), None), 'sekf_set_state')
+        self._filter_dt = dt
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -92,7 +107,8 @@ class DiscreteEKFObserver:
         A = B = d = None
         if u is not None:
             if getattr(self.dyn_sys, 'tpwl_method', 'nn') == 'nn':
-                self.dyn_sys._ensure_discrete(dt)
+                if self._filter_dt != dt:                   # first predictor step, or a new time step
+                    self._make_filter(dt, self.Sigma, self.x)
             else:
                 A, B, d = [_lib.f64(a) for a in self.dyn_sys.get_jacobians(self.x, dt)]
             u = _lib.f64(u)

@@ -51,6 +51,7 @@ class TPWL:
             raise RuntimeError("params['dist_weights'] = {'q': .., 'v': ..} is required (tpwl.py:165-166)")
 
         self._h = C.c_void_p()
+        self._dt_handles = {}          # dt -> device handle with the tables discretised at dt (never mutated)
         f = _lib.f64
         self._tabs = [f(q), f(self.tpwl_dict['v']), f(u), f(self.tpwl_dict['A_c']), f(self.tpwl_dict['B_c']),
                       f(self.tpwl_dict['d_c'])]
@@ -79,15 +80,50 @@ class TPWL:
 
     def __del__(self):
         try:
-            if self._h:
-                _lib.lib().stpwl_destroy(self._h)
-                self._h = C.c_void_p()
+            for h in list(getattr(self, '_dt_handles', {}).values()) + [self._h]:
+                if h:
+                    _lib.lib().stpwl_destroy(h)
+            self._dt_handles = {}
+            self._h = C.c_void_p()
         except Exception:
             pass
 
     @property
     def handle(self):
+        """Device handle: the one pre-discretised with `pre_discretized_dt` if there is one, else the continuous
+        one."""
+        if self.pre_discretized_dt is not None:
+            return self.handle_for(self.pre_discretized_dt)
         return self._h
+
+    def handle_for(self, dt, tables=None):
+        """Device handle whose discrete tables are discretised at `dt` (created on first use, then immutable: a
+        GuSTO plan, an observer and a rollout with different time steps each keep their own tables -- the
+        reference discretises per call in that case, tpwl.py:260-265).  dt = None: the continuous handle."""
+        if dt is None:
+            return self._h
+        key = float(dt)
+        h = self._dt_handles.get(key)
+        if h is not None:
+            return h
+        if self.tpwl_method != 'nn':
+            raise RuntimeError('tpwl method should be nn to pre-discretize')
+        if tables is None:
+            Ac, Bc, dc = self._tabs[3], self._tabs[4], self._tabs[5]
+            A_d, B_d, d_d = zip(*[self.discretize_dynamics(Ac[i], Bc[i], dc[i], dt) for i in range(self.num_points)])
+        else:
+            A_d, B_d, d_d = tables
+        Ad, Bd, dd = _lib.f64(np.stack(A_d)), _lib.f64(np.stack(B_d)), _lib.f64(np.stack(d_d))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().stpwl_create(
+            C.byref(h), C.c_int(self.num_points), C.c_int(self._tabs[0].shape[-1]), C.c_int(self.input_dim),
+            *[_lib.dptr(t) for t in self._tabs], _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd),
+            C.c_double(float(self.dist_weights['q'])), C.c_double(float(self.dist_weights['v']))), 'stpwl_create')
+        if getattr(self, 'H', None) is not None:
+            _lib.check(_lib.lib().stpwl_set_output(h, _lib.dptr(self.H), _lib.dptr(self.z_ref), C.c_int(self.output_dim)),
+                       'stpwl_set_output')
+        self._dt_handles[key] = h
+        return h
 
     def update_state(self, x, u, dt):
         raise NotImplementedError("update_state must be overriden by a child class")
@@ -106,8 +142,9 @@ class TPWL:
         self.H = np.ascontiguousarray(np.asarray(Hf @ self.rom.V), dtype=np.float64)
         self.z_ref = np.ascontiguousarray(np.asarray(Hf @ self.rom.x_ref).ravel(), dtype=np.float64)
         self.output_dim = self.H.shape[0]
-        _lib.check(_lib.lib().stpwl_set_output(self._h, _lib.dptr(self.H), _lib.dptr(self.z_ref),
-                                               C.c_int(self.output_dim)), 'stpwl_set_output')
+        for h in [self._h] + list(self._dt_handles.values()):
+            _lib.check(_lib.lib().stpwl_set_output(h, _lib.dptr(self.H), _lib.dptr(self.z_ref),
+                                                   C.c_int(self.output_dim)), 'stpwl_set_output')
 
     def zfyf_to_zy(self, zf=None, yf=None):
         if zf is not None and self.z_ref is not None:
@@ -185,7 +222,7 @@ class TPWL:
                 x[i + 1, :] = self.update_state(x[i, :], u[i, :], dt)
             z = self.x_to_zfyf(x, zf=True) if self.H is not None else None
             return x, z
-        self._ensure_discrete(dt)
+        h = self.handle_for(dt)
         x0a = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
         ua = np.ascontiguousarray(u, dtype=np.float64)
         single = ua.ndim == 2
@@ -194,7 +231,7 @@ class TPWL:
         Bn, N = ua.shape[0], ua.shape[1]
         X = np.empty((Bn, N + 1, self.state_dim))
         Z = np.empty((Bn, N + 1, self.output_dim)) if self.H is not None else None
-        _lib.check(_lib.lib().stpwl_rollout(self._h, _lib.dptr(x0a), _lib.dptr(ua), C.c_int(N), C.c_int64(Bn),
+        _lib.check(_lib.lib().stpwl_rollout(h, _lib.dptr(x0a), _lib.dptr(ua), C.c_int(N), C.c_int64(Bn),
                                             _lib.dptr(X), _lib.dptr(Z)), 'stpwl_rollout')
         if single:
             return X[0], (Z[0] if Z is not None else None)
@@ -222,13 +259,12 @@ class TPWLATV(TPWL):
         if self.tpwl_method == 'weighting':
             A, B, d, _ = self.linearize_batch(np.atleast_2d(x), dt)
             return A[0], B[0], d[0]
-        if dt is not None:
-            self._ensure_discrete(dt)
+        h = self.handle_for(dt)
         X = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
         n, m = self.state_dim, self.input_dim
         A = np.empty((1, n, n)); B = np.empty((1, n, m)); d = np.empty((1, n))
         idx = np.empty(1, dtype=np.int32)
-        _lib.check(_lib.lib().stpwl_linearize(self._h, _lib.dptr(X), C.c_int64(1), C.c_int(dt is not None),
+        _lib.check(_lib.lib().stpwl_linearize(h, _lib.dptr(X), C.c_int64(1), C.c_int(dt is not None),
                                               _lib.dptr(A), _lib.dptr(B), _lib.dptr(d), _lib.iptr(idx)),
                    'stpwl_linearize')
         self.ref_point = int(idx[0])
@@ -250,13 +286,12 @@ class TPWLATV(TPWL):
                 for b in range(Bn):
                     A[b], B[b], d[b] = self.discretize_dynamics(A[b], B[b], d[b], dt)
             return A, B, d, W
-        if dt is not None:
-            self._ensure_discrete(dt)
+        h = self.handle_for(dt)
         X = np.ascontiguousarray(X, dtype=np.float64)
         Bn, n, m = X.shape[0], self.state_dim, self.input_dim
         A = np.empty((Bn, n, n)); B = np.empty((Bn, n, m)); d = np.empty((Bn, n))
         idx = np.empty(Bn, dtype=np.int32)
-        _lib.check(_lib.lib().stpwl_linearize(self._h, _lib.dptr(X), C.c_int64(Bn), C.c_int(dt is not None),
+        _lib.check(_lib.lib().stpwl_linearize(h, _lib.dptr(X), C.c_int64(Bn), C.c_int(dt is not None),
                                               _lib.dptr(A), _lib.dptr(B), _lib.dptr(d), _lib.iptr(idx)),
                    'stpwl_linearize')
         return A, B, d, idx
@@ -292,26 +327,13 @@ class TPWLATV(TPWL):
             self.A_d.append(A_d)
             self.B_d.append(B_d)
             self.d_d.append(d_d)
-        self._install_discrete(dt)
-
-    def _install_discrete(self, dt):
-        Ad, Bd, dd = _lib.f64(np.stack(self.A_d)), _lib.f64(np.stack(self.B_d)), _lib.f64(np.stack(self.d_d))
-        _lib.check(_lib.lib().stpwl_set_discrete(self._h, _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)),
-                   'stpwl_set_discrete')
+        if float(dt) not in self._dt_handles:          # (a handle created earlier for this dt holds the same tables)
+            self.handle_for(dt, tables=(self.A_d, self.B_d, self.d_d))
         self.pre_discretized_dt = dt
-        self._device_dt = dt
 
     def _ensure_discrete(self, dt):
-        """The device keeps ONE set of discrete tables; a call with another dt re-discretises (the
-        reference discretises per call in that case, tpwl.py:260-265)."""
-        if getattr(self, '_device_dt', None) != dt:
-            import io
-            import contextlib
-            with contextlib.redirect_stdout(io.StringIO()):
-                keep = self.pre_discretized_dt
-                self.pre_discretize(dt)
-                if keep is not None:
-                    self.pre_discretized_dt = dt
+        """Make sure a device handle with the tables discretised at dt exists (see handle_for)."""
+        self.handle_for(dt)
 
     def get_characteristic_dx(self, dt):
         """tpwl.py:324-334."""

@@ -171,3 +171,26 @@ def test_gusto_fused_terminal_cost_set_and_input_target(golden):
     assert int(gu.iters[0]) == len(tr) == 4
     np.testing.assert_allclose(gu.trace[0, :len(tr), 0], [t[0] for t in tr], rtol=1e-6)
     assert rel(xo, xe) <= 1e-4 and rel(uo, ue) <= 1e-4
+
+
+def test_plan_tables_survive_other_time_steps(golden):
+    """A GuSTO plan (dt = 0.05) keeps its own discrete tables: rollouts / Jacobians / an EKF at another time step on the
+    same model object must not change its result (each dt has its own immutable device handle, tpwl.handle_for)."""
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g, gm = setup(golden)
+    tp = gm.dyn_sys
+    N, dt = 12, 0.05
+    x0 = 1e-3 * np.ones(8); u_init = np.zeros((N, 3))
+    x_init, _ = gm.rollout(x0, u_init, dt)
+    from scipy.interpolate import interp1d
+    z = interp1d(g['t'], g['zt'], axis=0)(dt * np.arange(N + 1))
+    gu = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, U=Poly(g['U_A'], g['U_b']), x_char=g['x_char'],
+               f_char=g['f_char'], convg_thresh=1e-3)
+    x1, u1 = gu.xopt.copy(), gu.uopt.copy()
+    tp.rollout(x0, np.zeros((5, 3)), 0.01)                       # another time step on the same model
+    A1, _, _ = tp.get_jacobians(x0, dt=0.01)
+    A5, _, _ = tp.get_jacobians(x0, dt=0.05)
+    assert np.abs(A1 - A5).max() > 1e-3
+    gu.solve(x0, u_init, x_init, z=z)
+    np.testing.assert_array_equal(gu.xopt, x1)
+    np.testing.assert_array_equal(gu.uopt, u1)
