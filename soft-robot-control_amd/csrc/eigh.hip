@@ -3,6 +3,7 @@
 // The dense n_s x n_s eigenproblem is a plain library call: rocSOLVER dsyevd, resolved at run time with
 // dlopen so that the rest of the library does not depend on it.
 #include "common.h"
+#include "dev_la.h"
 
 #include <dlfcn.h>
 #include <rocblas/rocblas.h>
@@ -49,12 +50,133 @@ __global__ void select_modes_kernel(const double *__restrict__ V, const double *
     Wk[j * k + i] = V[src * n + j] / sig;
 }
 
+
+// ---- small Gramians (n <= 128, e.g. a few dozen snapshots): cyclic two-sided Jacobi in one workgroup.
+// A lives in LDS (odd leading dimension), the eigenvectors as ROWS of Vt in HBM/L2 (row rotations: coalesced).
+// Round-robin ordering: n/2 disjoint rotations per step, n - 1 steps per sweep; each step = compute (c, s) of every
+// pair, rotate the rows of A and Vt, barrier, rotate the columns of A.  No library, no 200 s rocBLAS cold load.
+constexpr int JAC_NT = 512;
+constexpr int JAC_MAX = 128;
+
+__global__ __launch_bounds__(JAC_NT) void jacobi_eigh_kernel(double *__restrict__ G, int n, double *__restrict__ Vt,
+                                                             double *__restrict__ w, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ne = (n + 1) & ~1, h = ne >> 1, ld = ne | 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    lptr A = (lptr)smem;                       // ne x ld
+    lptr cs = A + (size_t)ne * ld;             // (c, s) per pair: 2 h
+    lptr red = cs + 2 * h;                     // 64
+    liptr top = (liptr)(red + 64), bot = top + h, top2 = bot + h, bot2 = top2 + h;
+    for (int e = tid; e < ne * ne; e += nt) {
+        const int i = e / ne, j = e % ne;
+        A[i * ld + j] = (i < n && j < n) ? G[(size_t)i * n + j] : 0.0;
+        Vt[e] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int i = tid; i < h; i += nt) { top[i] = 2 * i; bot[i] = 2 * i + 1; }
+    __syncthreads();
+    double diag2 = 0.0;
+    for (int i = tid; i < n; i += nt) diag2 = fma(A[i * ld + i], A[i * ld + i], diag2);
+    diag2 = wg::reduce(diag2, 0, red);
+    int sweep = 0;
+    bool done = false;
+    for (; sweep < 40 && !done; ++sweep) {
+        for (int step = 0; step < ne - 1; ++step) {
+            for (int i = tid; i < h; i += nt) {
+                const int p = top[i], q = bot[i];
+                const double apq = A[p * ld + q], app = A[p * ld + p], aqq = A[q * ld + q];
+                double c = 1.0, sn = 0.0;
+                if (fabs(apq) > 1e-300 && fabs(apq) > 1e-30 * (fabs(app) + fabs(aqq))) {
+                    const double th = (aqq - app) / (2.0 * apq);
+                    const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    sn = t * c;
+                }
+                cs[2 * i] = c; cs[2 * i + 1] = sn;
+            }
+            __syncthreads();
+            // rows of A and of Vt:  r_p' = c r_p - s r_q,  r_q' = s r_p + c r_q
+            for (int e = tid; e < h * ne; e += nt) {
+                const int i = e / ne, k = e % ne;
+                const int p = top[i], q = bot[i];
+                const double c = cs[2 * i], sn = cs[2 * i + 1];
+                const double ap = A[p * ld + k], aq = A[q * ld + k];
+                A[p * ld + k] = c * ap - sn * aq;
+                A[q * ld + k] = sn * ap + c * aq;
+                const double vp = Vt[(size_t)p * ne + k], vq = Vt[(size_t)q * ne + k];
+                Vt[(size_t)p * ne + k] = c * vp - sn * vq;
+                Vt[(size_t)q * ne + k] = sn * vp + c * vq;
+            }
+            __syncthreads();
+            // columns of A
+            for (int e = tid; e < h * ne; e += nt) {
+                const int i = e / ne, k = e % ne;
+                const int p = top[i], q = bot[i];
+                const double c = cs[2 * i], sn = cs[2 * i + 1];
+                const double ap = A[k * ld + p], aq = A[k * ld + q];
+                A[k * ld + p] = c * ap - sn * aq;
+                A[k * ld + q] = sn * ap + c * aq;
+            }
+            // next pairing (chess-tournament rotation, player top[0] fixed)
+            for (int i = tid; i < h; i += nt) {
+                top2[i] = i == 0 ? top[0] : (i == 1 ? bot[0] : top[i - 1]);
+                bot2[i] = i == h - 1 ? top[h - 1] : bot[i + 1];
+            }
+            __syncthreads();
+            for (int i = tid; i < h; i += nt) { top[i] = top2[i]; bot[i] = bot2[i]; }
+            __syncthreads();
+        }
+        double off2 = 0.0;
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            if (i != j) off2 = fma(A[i * ld + j], A[i * ld + j], off2);
+        }
+        off2 = wg::reduce(off2, 0, red);
+        done = off2 <= 1e-30 * diag2 || off2 == 0.0;
+        // the diagonal carries the norm after the first sweep
+        double d2 = 0.0;
+        for (int i = tid; i < n; i += nt) d2 = fma(A[i * ld + i], A[i * ld + i], d2);
+        diag2 = wg::reduce(d2, 0, red);
+    }
+    // ascending order: rank of eigenvalue p (ties by index); row rank_p of G <- eigenvector p (first n entries)
+    for (int p = tid; p < n; p += nt) {
+        const double lp = A[p * ld + p];
+        int rk = 0;
+        for (int q = 0; q < n; ++q) {
+            const double lq = A[q * ld + q];
+            rk += (lq < lp || (lq == lp && q < p)) ? 1 : 0;
+        }
+        w[rk] = lp;
+        // the dummy row / column of an odd n never mixes (its off-diagonals are exactly zero)
+        for (int k = 0; k < n; ++k) G[(size_t)rk * n + k] = Vt[(size_t)p * ne + k];
+    }
+    if (tid == 0) *info = done ? 0 : 1;
+}
+
 }  // namespace
 
 extern "C" {
 
 int srom_eigh_dev(double *G_dev, int64_t n, double *w_dev, void *stream) {
     SRH_REQUIRE(G_dev && w_dev && n > 0 && n < (1LL << 31), "srom_eigh_dev: bad argument");
+    if (n <= JAC_MAX && !getenv("SRH_EIGH_ROCSOLVER")) {
+        const int ne = ((int)n + 1) & ~1, ld = ne | 1;
+        const size_t lds = sizeof(double) * ((size_t)ne * ld + ne + 64) + sizeof(int) * 2 * ne + 64;
+        srh::DevBuf Vt, info;
+        int rc;
+        if ((rc = Vt.alloc(sizeof(double) * ne * ne)) || (rc = info.alloc(sizeof(int)))) return rc;
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)jacobi_eigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        jacobi_eigh_kernel<<<1, JAC_NT, lds, (hipStream_t)stream>>>(G_dev, (int)n, Vt.as<double>(), w_dev, info.as<int>());
+        SRH_CHECK_HIP(hipGetLastError());
+        SRH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        int hinfo = 0;
+        SRH_CHECK_HIP(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (hinfo != 0) {
+            srh::set_error("srom_eigh_dev: Jacobi sweeps did not converge");
+            return SRH_ENUMERIC;
+        }
+        return SRH_OK;
+    }
     Solver &s = solver();
     if (!s.ok) {
         srh::set_error("srom_eigh_dev: rocSOLVER / rocBLAS could not be loaded (%s)", dlerror() ? dlerror() : "symbol missing");

@@ -147,3 +147,18 @@ def test_errors_are_loud():
     il.set_target(np.zeros((6, 6)))
     with pytest.raises(NotImplementedError):
         il.ilqr_computation(np.zeros(6))
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 40, 127, 128, 150])
+def test_device_eigh(n):
+    """srom_eigh_dev: one-workgroup Jacobi for n <= 128, rocSOLVER dsyevd above (n = 150; the first call in a
+    process loads rocBLAS, minutes on a cold box)."""
+    from sofacontrol_amd.mor.pod import _device_eigh
+    rng = np.random.default_rng(n)
+    S = rng.standard_normal((n, n + 3)) * np.logspace(0, -3, n + 3)
+    G = S @ S.T
+    w, W = _device_eigh(G)
+    we = np.linalg.eigvalsh(G)
+    np.testing.assert_allclose(w, we, rtol=0, atol=1e-12 * max(1.0, np.abs(we).max()))
+    np.testing.assert_allclose(W.T @ W, np.eye(n), atol=1e-12)
+    np.testing.assert_allclose(G @ W, W * w, atol=1e-11 * max(1.0, np.abs(we).max()))

@@ -173,3 +173,48 @@ def test_tpwl_assembly_golden(golden):
     for k in ('A_c', 'B_c', 'd_c', 'A_d', 'B_d', 'd_d'):
         ref = g['out_' + k]
         np.testing.assert_allclose(np.asarray(data.dict[k]), ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+
+
+def test_file_round_trips(tmp_path):
+    """run_POD / load_POD (mor/pod.py:93-141) and TPWLSnapshotData.simulation_end -> TPWLATV(data=<file>)
+    (tpwl_utils.py:130-153, tpwl.py:26-29): the pickle formats of the reference, written and read back."""
+    import io, contextlib
+    from types import SimpleNamespace
+    from helpers import small_rom, assembly_points
+    from sofacontrol_amd import utils as scutils
+    from sofacontrol_amd.mor.pod import run_POD, load_POD, pod_config
+    from sofacontrol_amd.tpwl.tpwl_utils import TPWLSnapshotData
+    from sofacontrol_amd.tpwl.tpwl import TPWLATV
+    from sofacontrol_amd.utils import Point
+    rng = np.random.default_rng(3)
+    n_f, n_s = 90, 40
+    L = rng.standard_normal((n_s, 4)) * np.array([30, 10, 3, 1.0])
+    q = L @ rng.standard_normal((4, n_f)) + 1e-4 * rng.standard_normal((n_s, n_f))
+    snap, podf, tpwlf = str(tmp_path / 'snap.pkl'), str(tmp_path / 'pod.pkl'), str(tmp_path / 'tpwl.pkl')
+    scutils.save_data(snap, {'q': list(q + 5.0), 'v': list(q)})
+    cfg = pod_config(); cfg.pod_type = 'v'; cfg.pod_tolerance = 1e-6
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = run_POD(snap, podf, cfg)
+    rom = load_POD(podf)
+    assert rom.rom_dim == res['POD_info']['U'].shape[1] == 4
+    s = np.linalg.svd(q.T, compute_uv=False)
+    np.testing.assert_allclose(res['Sigma'][:4], s[:4], rtol=1e-9)
+    np.testing.assert_allclose(rom.q_ref, q[0] + 5.0)
+    # TPWL data collected with this ROM, saved, loaded back as a model
+    tcfg = SimpleNamespace(eval_type='distance', save_continuous_TPWL=True, save_discrete_TPWL=True,
+                           TPWL_weighting_factors={'q': 1.0, 'v': 0.0}, TPWL_separate_calculation=False,
+                           TPWL_threshold=1.0, TPWL_type='ATV', discr_type='zoh')
+    data = TPWLSnapshotData(rom, tcfg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for d in assembly_points(n_f, 3, rom.q_ref, 7, count=2):
+            p = Point()
+            for k, v in d.items():
+                setattr(p, k, v)
+            data.add_point(p)
+        data.simulation_end(tpwlf)
+    tp = TPWLATV(data=tpwlf, params=dict(tpwl_method='nn', dist_weights={'q': 1.0, 'v': 0.0}), discr_method='zoh')
+    assert tp.num_points == 2 and tp.get_state_dim() == 8 and tp.get_input_dim() == 3
+    saved = scutils.load_data(tpwlf)
+    A, B, d = tp.get_jacobians(np.concatenate((saved['v'][1], saved['q'][1])))
+    np.testing.assert_array_equal(A, saved['A_c'][1])
+    assert saved['info']['nbr_lin'] == '2' and saved['rom_info']['type'] == 'POD'
