@@ -520,6 +520,51 @@ def g12_assembly(out):
     np.savez_compressed(os.path.join(out, 'g12_assembly.npz'), **res)
 
 
+def g13_controllers2(out):
+    """TrajTracking and StateDLQR controllers (tpwl/controllers.py:349-437) driven by a scripted
+    (sim_time, y, x, u_prev) sequence."""
+    import sofacontrol.tpwl.controllers as ctl
+    from sofacontrol.tpwl.tpwl_utils import DynamicsTarget
+    r, m, P = 4, 3, 7
+    model, U, q_ref, v_ref, Hf = make_problem(r, m, P, 20, 40, q_scale=0.05)
+    tp = ref_tpwl(model, U, q_ref, v_ref, Hf)
+    n = 2 * r
+    rng = np.random.default_rng(130)
+    dt = 0.02
+    res = {}
+    H = np.asarray(tp.H)
+    cost = rutils.QuadraticCost()
+    cost.Q = H.T @ np.diag([0, 0, 0, 100., 100., 0]) @ H + 1e-2 * np.eye(n)
+    cost.R = 1e-3 * np.eye(m)
+    tgt = Target()
+    Nt = 12
+    tgt.t = dt * np.arange(Nt + 1)
+    tgt.u = rng.uniform(0, 300, (Nt + 1, m))
+    tgt.x, _ = tp.rollout(0.02 * rng.standard_normal(n), tgt.u[:-1], dt)
+    (c, _) = quiet(ctl.TrajTracking, tp, cost, tgt, dt=dt, delay=0.02)
+    c.set_sim_timestep(dt)
+    V = np.kron(np.eye(2), U)
+    x_ref = np.concatenate((v_ref, q_ref))
+    xs = [V @ (tgt.x[min(k, Nt)] + 1e-3 * rng.standard_normal(n)) + x_ref for k in range(13)]
+    us = [quiet(c.evaluate, k * dt, None, xs[k], np.zeros(m))[0] for k in range(13)]
+    res['tt_t'], res['tt_u_target'], res['tt_x_target'] = tgt.t, tgt.u, tgt.x
+    res['tt_x_full'], res['tt_u'] = np.stack(xs), np.stack(us)
+    res['tt_K'] = np.asarray(c.K)
+    # StateDLQR around the stored point 2
+    dtg = DynamicsTarget()
+    dtg.A, dtg.B = model['A_c'][2], model['B_c'][2]
+    dtg.x = np.concatenate((model['v'][2], model['q'][2]))
+    dtg.u = model['u'][2]
+    (c2, _) = quiet(ctl.StateDLQR, tp, cost, dtg, dt=dt, delay=0.0)
+    c2.set_sim_timestep(dt)
+    xs2 = [V @ (dtg.x + 1e-3 * rng.standard_normal(n)) + x_ref for k in range(4)]
+    res['dl_x_full'] = np.stack(xs2)
+    res['dl_u'] = np.stack([quiet(c2.evaluate, k * dt, None, xs2[k], np.zeros(m))[0] for k in range(4)])
+    res['dl_K'] = np.asarray(c2.K)
+    res['Q'], res['R'] = cost.Q, cost.R
+    np.savez_compressed(os.path.join(out, 'g13_controllers2.npz'), **res)
+
+
 class FakeGuSTOClient:
     """Deterministic stand-in for GuSTOClientNode (needs ROS): returns a smooth analytic 'solution'."""
     N, dt_g = 8, 0.05
@@ -603,5 +648,6 @@ if __name__ == '__main__':
     g10_ssm(HERE)
     g11_ilqr_ssm(HERE)
     g12_assembly(HERE)
+    g13_controllers2(HERE)
     g8_controllers(HERE)
     print('g8_controllers.npz', os.path.getsize(os.path.join(HERE, 'g8_controllers.npz')))

@@ -105,3 +105,31 @@ def test_scp_controller_with_in_process_solver_node(golden):
         assert u.shape == (3,) and np.all(np.isfinite(u))
     info = c.save_controller_info()
     assert len(info['solve_times']) >= 2 and info['t_opt'][0] == 0.0
+
+
+def test_traj_tracking_and_state_dlqr_controllers(golden):
+    """TrajTracking and StateDLQR controllers (controllers.py:349-437) against the imported reference (g13)."""
+    from sofacontrol_amd.tpwl import controllers as ctl
+    from sofacontrol_amd.tpwl.tpwl_utils import Target, DynamicsTarget
+    from sofacontrol_amd.utils import QuadraticCost
+    g = golden('g13_controllers2')
+    model, U, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 40, q_scale=0.05)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    cost = QuadraticCost(Q=g['Q'], R=g['R'])
+    dt = 0.02
+    tgt = Target()
+    tgt.t, tgt.u, tgt.x = g['tt_t'], g['tt_u_target'], g['tt_x_target']
+    c = quiet(ctl.TrajTracking, tp, cost, tgt, dt=dt, delay=0.02)
+    c.set_sim_timestep(dt)
+    np.testing.assert_allclose(np.asarray(c.K), g['tt_K'], rtol=0, atol=1e-8 * np.abs(g['tt_K']).max())
+    us = [quiet(c.evaluate, k * dt, None, g['tt_x_full'][k], np.zeros(3)) for k in range(13)]
+    np.testing.assert_allclose(np.stack(us), g['tt_u'], rtol=0, atol=1e-7 * max(1.0, np.abs(g['tt_u']).max()))
+    dtg = DynamicsTarget()
+    dtg.A, dtg.B = model['A_c'][2], model['B_c'][2]
+    dtg.x = np.concatenate((model['v'][2], model['q'][2]))
+    dtg.u = model['u'][2]
+    c2 = quiet(ctl.StateDLQR, tp, cost, dtg, dt=dt, delay=0.0)
+    c2.set_sim_timestep(dt)
+    np.testing.assert_allclose(np.asarray(c2.K), g['dl_K'], rtol=0, atol=2e-3 * np.abs(g['dl_K']).max())   # 1e-4 stopping rule
+    us2 = [quiet(c2.evaluate, k * dt, None, g['dl_x_full'][k], np.zeros(3)) for k in range(4)]
+    np.testing.assert_allclose(np.stack(us2), g['dl_u'], rtol=0, atol=1e-3 * max(1.0, np.abs(g['dl_u']).max()))
