@@ -27,8 +27,8 @@ def main():
     ap.add_argument('--ekf', action='store_true', help='DiscreteEKFObserver on 10 measured nodes instead of full state')
     args = ap.parse_args()
 
-    import scipy.sparse as sp
     import workloads as wl
+    from sofacontrol_amd.measurement_models import linearModel
     from sofacontrol_amd.tpwl.tpwl import TPWLATV
     from sofacontrol_amd.tpwl import controllers as ctl
     from sofacontrol_amd.tpwl.observer import DiscreteEKFObserver
@@ -40,21 +40,13 @@ def main():
     n_f, r = w['U'].shape
     m, N, dt_plan, dt_sim = w['m'], w['N'], w['dt'], 0.01
     tip = 1354
-    Hf = sp.lil_matrix((6, 2 * n_f))
-    for a in range(3):
-        Hf[a, 3 * tip + a] = 1.0
-        Hf[3 + a, n_f + 3 * tip + a] = 1.0
-    Cf = None
-    if args.ekf:
-        Cf = sp.lil_matrix((30, 2 * n_f))
-        for i, nd in enumerate(range(0, 1500, 150)):
-            for a in range(3):
-                Cf[3 * i + a, n_f + 3 * nd + a] = 1.0
-        Cf = Cf.tocsr()
+    num_nodes = n_f // 3
+    Hf = linearModel(nodes=[tip], num_nodes=num_nodes).C.tocsr()             # tip velocity + position (diamond.py:269)
+    Cf = linearModel(nodes=list(range(0, 1500, 150)), num_nodes=num_nodes, vel=False).C.tocsr() if args.ekf else None
     data = dict(w['tab'], rom_info=dict(type='POD', U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
     params = dict(tpwl_method='nn', dist_weights={'q': 1.0, 'v': 0.0})
-    model = TPWLATV(data=data, params=params, Hf=Hf.tocsr(), Cf=Cf, discr_method='zoh')
-    plant = TPWLATV(data=data, params=params, Hf=Hf.tocsr(), discr_method='zoh')       # its own device tables (dt_sim)
+    model = TPWLATV(data=data, params=params, Hf=Hf, Cf=Cf, discr_method='zoh')
+    plant = TPWLATV(data=data, params=params, Hf=Hf, discr_method='zoh')       # its own device tables (dt_sim)
     gm = TPWLGuSTO(model)
     quiet = contextlib.redirect_stdout(io.StringIO())
     with quiet:

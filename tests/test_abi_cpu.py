@@ -69,3 +69,19 @@ def test_host_mirror_surface_matches_reference_names():
     np.testing.assert_array_equal(hr.b, [2., 1., 3., 0.])
     assert hr.contains(np.array([0., 1.])) and not hr.contains(np.array([3., 1.]))
     np.testing.assert_allclose(hr.get_constraint_violation(np.array([3., -1.])), np.sqrt(2.0))
+
+
+def test_measurement_models_match_reference_selector(golden):
+    """linearModel (measurement_models.py:7-44) builds the same selector as the reference (golden g3 'Hf' =
+    linearModel(nodes=[10], num_nodes=20).C); pure host data format, no GPU needed."""
+    import numpy as np
+    from sofacontrol_amd.measurement_models import linearModel, MeasurementModel, buildCq, buildCv
+    g = golden('g3_tpwl')
+    m = linearModel(nodes=[10], num_nodes=20)
+    np.testing.assert_array_equal(m.C.toarray(), g['Hf'])
+    x = np.arange(120.0)
+    np.testing.assert_array_equal(m.evaluate(x), g['Hf'] @ x)
+    assert buildCq([1, 3], 5).shape == (6, 30) and buildCv([2], 5).toarray()[1, 7] == 1.0
+    mm = MeasurementModel([0, 4], 5, pos=True, vel=False)
+    assert mm.C.shape == (6, 30) and mm.mean.shape == (6,) and not mm.covariance.any()
+    np.testing.assert_array_equal(mm.evaluate(np.arange(30.0)), mm.C @ np.arange(30.0))
