@@ -167,3 +167,26 @@ def extract_AB_d(S, K, H, dt):
     A = np.block([[I - dt ** 2 * SinvK, -dt * SinvK], [dt * I - dt ** 3 * SinvK, I - dt ** 2 * SinvK]])
     B = np.block([[dt * SinvH], [dt ** 2 * SinvH]])
     return A, B
+
+
+def zoh_linear(A, B, dt):
+    """sofacontrol/utils.py:302-320: exact zero-order-hold discretisation, expm([[A, B], [0, 0]] dt).  One-off host
+    computation per stored TPWL point."""
+    from scipy.linalg import expm
+    n, m = B.shape
+    M = np.zeros((n + m, n + m))
+    M[:n, :n] = A
+    M[:n, n:] = B
+    Z = expm(M * dt)
+    return Z[:n, :n], Z[:n, n:]
+
+
+def zoh_affine(A, B, d, dt):
+    """sofacontrol/utils.py:323-335: the affine term rides along as one more input column."""
+    A_d, B_ext = zoh_linear(A, np.hstack((B, np.expand_dims(d, axis=-1))), dt)
+    return A_d, B_ext[:, :-1], B_ext[:, -1]
+
+
+def sparse_list_to_np_array(matrix_list):
+    """sofacontrol/utils.py:162-163."""
+    return np.asarray([np.asarray(matrix.todense()) for matrix in matrix_list])
