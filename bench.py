@@ -91,7 +91,15 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
         cores = max([int(i.get('num_threads', 1)) for i in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count()
-    return dict(value=iters / t_scp, unit='SCP iterations/s', cores=cores, kind='port',
+    cpu = 'unknown CPU'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                cpu = line.split(':', 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return dict(value=iters / t_scp, unit='SCP iterations/s', cores=cores, kind='port', host='%s, %d logical CPUs' % (cpu, os.cpu_count()),
                 sample='%d rollout(s) of the same workload = %d SCP iterations in %.1f s (numpy port of the kernel '
                        'algorithm inside the restated GuSTO loop); POD projection of %d snapshots: %.1f GB/s' %
                        (n_roll, iters, t_scp, proj_rows, proj_gbs),
