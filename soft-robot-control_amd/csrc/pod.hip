@@ -363,7 +363,18 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(const double *__restri
             if (o < nout) {
                 int aa = o / c, bb = o % c;
                 double s = acc[q];
-                for (int i = 0; i < nr; ++i) s += su[i * r + aa] * st[i * c + bb];
+                // eight operand pairs in flight per trip (a rolled loop pays the LDS latency per row)
+                for (int i = 0; i < nr; i += 8) {
+                    double av[8], bv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool in = i + k < nr;
+                        av[k] = in ? su[(i + k) * r + aa] : 0.0;
+                        bv[k] = in ? st[(i + k) * c + bb] : 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s = fma(av[k], bv[k], s);
+                }
                 acc[q] = s;
             }
         }
@@ -376,13 +387,17 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(const double *__restri
     }
 }
 
+// one wave per output: lanes over the row-block partials, fixed butterfly order (deterministic)
 __global__ void atb_reduce_kernel(const double *__restrict__ partial, int nblk, int nout,
                                   double *__restrict__ out, int c, int64_t ldo) {
-    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (o >= nout) return;
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * nout + o];
-    out[(int64_t)(o / c) * ldo + (o % c)] = s;
+    for (int k = lane; k < nblk; k += 64) s += partial[(int64_t)k * nout + o];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) out[(int64_t)(o / c) * ldo + (o % c)] = s;
 }
 
 }  // namespace
@@ -656,13 +671,13 @@ int srom_lift(srom_t *h, int which, const double *Xr, int64_t B, double *out) {
 // out (r x c) = U^T T for T (n_f x c), c <= 64 per pass
 static int atb_dev(srom *h, const double *T, int64_t ldt, int c, double *out, int64_t ldo,
                    double *partial, hipStream_t s) {
-    const int rows_per_wg = 256;
+    const int rows_per_wg = 64;
     const int nblk = (int)srh::cdiv(h->n_f, rows_per_wg);
     const int nout = h->r * c;
     size_t lds = sizeof(double) * 64 * (size_t)(h->r + c);
     atb_partial_kernel<<<nblk, 256, lds, s>>>(h->U.as<double>(), h->r, T, ldt, c, h->n_f, rows_per_wg, partial);
     SRH_CHECK_HIP(hipGetLastError());
-    atb_reduce_kernel<<<(unsigned)srh::cdiv(nout, 256), 256, 0, s>>>(partial, nblk, nout, out, c, ldo);
+    atb_reduce_kernel<<<(unsigned)srh::cdiv(nout, 4), 256, 0, s>>>(partial, nblk, nout, out, c, ldo);
     SRH_CHECK_HIP(hipGetLastError());
     return SRH_OK;
 }
@@ -673,7 +688,7 @@ int srom_reduce_matrix_dev(srom_t *h, const double *M, int64_t ncols, int left, 
     SRH_REQUIRE(ncols > 0, "srom_reduce_matrix_dev: ncols must be positive");
     hipStream_t s = (hipStream_t)stream;
     const bool both = (left && right) || (!left && !right);
-    const int nblk_atb = (int)srh::cdiv(h->n_f, 256);
+    const int nblk_atb = (int)srh::cdiv(h->n_f, 64);
     if (both || right) SRH_REQUIRE(ncols == h->n_f, "srom_reduce_matrix_dev: M must be n_f x n_f");
     if (right && !both) {
         // M U : rows of M projected without a reference
