@@ -63,7 +63,8 @@ class GuSTO:
         self.x_k = None
         self.u_k = None
         self.nonlinear_observer = model.nonlinear_observer
-        self._fused = (isinstance(model, TPWLGuSTO) and not self.nonlinear_observer and
+        # input-rate constraints couple the stages: they go through the generic loop around the (augmented) device QP
+        self._fused = (isinstance(model, TPWLGuSTO) and not self.nonlinear_observer and dU is None and
                        getattr(model.dyn_sys, 'tpwl_method', 'nn') == 'nn')
         self._plan = C.c_void_p()
         self.trace = None

@@ -56,8 +56,17 @@ class LOCP:
         self.n_u = R.shape[0]
         self.x_scale = np.ones(self.n_x) if x_char is None else 1. / np.abs(x_char)
         self.tr_active = kwargs.pop('is_tr_active', True)
+        self._du_aug = False
         if self.nonlinear_observer:
+            if dU is not None:
+                raise NotImplementedError('dU together with a nonlinear observer is not covered')
             self._init_augmented(N, Qz, R, Qzf, U, X, Xf, dU, kwargs)
+            return
+        if dU is not None:
+            if kwargs.pop('input_nullspace', None) is not None:
+                raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
+            self.solver_args = kwargs
+            self._init_rate_augmented(N, Qz, R, Qzf, U, X, Xf, dU)
             return
         if kwargs.pop('input_nullspace', None) is not None:
             raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
@@ -88,6 +97,54 @@ class LOCP:
         self._data = None
         self._sol = None
 
+    def _init_rate_augmented(self, N, Qz, R, Qzf, U, X, Xf, dU):
+        """Input-rate constraints dU.A (u_{k+1} - u_k) <= dU.b, k = 0..N-2 (locp.py:305-308) couple consecutive
+        stages; the stage-structured kernel takes pure state rows and pure input rows.  The previous input and the
+        input increment are carried as extra states: xa_k = [x_k; p_k; e_k], p_{k+1} = u_k, e_{k+1} = u_k - p_k
+        (e_1 = 0: u_0 has no predecessor in the reference's constraint set), and the rate rows become the state
+        rows [0 0 dU.A] xa_k <= dU.b on k = 1..N -- the same QP in (x, u, s).  Needs dU.b >= 0 (e_1 = 0 feasible)."""
+        from ..utils import Polyhedron
+        if np.any(np.asarray(dU.b) < 0):
+            raise NotImplementedError('dU with negative bounds (the zero increment infeasible) is not covered')
+        n, m, nz = self.n_x, self.n_u, self.n_z
+        na = n + 2 * m
+        Ha = np.hstack((self.H, np.zeros((nz, 2 * m))))
+        rows = [np.hstack((np.zeros((dU.A.shape[0], n + m)), np.asarray(dU.A, dtype=np.float64)))]
+        rhs = [np.asarray(dU.b, dtype=np.float64)]
+        if X is not None:
+            rows.insert(0, np.hstack((np.asarray(X.A, dtype=np.float64), np.zeros((X.A.shape[0], 2 * m)))))
+            rhs.insert(0, np.asarray(X.b, dtype=np.float64))
+        Xa = Polyhedron(np.vstack(rows), np.concatenate(rhs))
+        Xfa = None if Xf is None else Polyhedron(np.hstack((Xf.A, np.zeros((Xf.A.shape[0], 2 * m)))), Xf.b)
+        xs = np.concatenate((self.x_scale, np.zeros(2 * m)))
+        self._du_aug = True
+        self._na = na
+        self._prob, self._keep = make_problem(N, Ha, Qz, R, Qzf, U, Xa, Xfa, None, xs, self.tr_active)
+        self._data = None
+        self._sol = None
+
+    def _update_rate_augmented(self, Ad, Bd, dd, x0, xk, z, zf, u):
+        N, n, m = self.N, self.n_x, self.n_u
+        na = self._na
+        Ad = np.asarray(Ad).reshape(N, n, n); Bd = np.asarray(Bd).reshape(N, n, m); dd = np.asarray(dd).reshape(N, n)
+        Aa = np.zeros((N, na, na)); Ba = np.zeros((N, na, m)); da = np.zeros((N, na))
+        Aa[:, :n, :n] = Ad
+        Ba[:, :n] = Bd
+        da[:, :n] = dd
+        I = np.eye(m)
+        Ba[:, n:n + m] = I                       # p_{k+1} = u_k
+        Ba[1:, n + m:] = I                       # e_{k+1} = u_k - p_k   (k >= 1; e_1 = 0)
+        Aa[1:, n + m:, n:n + m] = -I
+        x0 = np.asarray(x0).reshape(n)
+        xka = np.zeros((N + 1, na))
+        if xk is not None:
+            xka[:, :n] = np.asarray(xk).reshape(N + 1, n)
+        self._data = dict(Ad=_lib.f64(Aa), Bd=_lib.f64(Ba), dd=_lib.f64(da),
+                          x0=_lib.f64(np.concatenate((x0, np.zeros(2 * m)))), xk=_lib.f64(xka),
+                          z=None if z is None else _lib.f64(np.ravel(z)),
+                          zf=None if (self.Qzf is None or zf is None) else _lib.f64(zf),
+                          u=None if u is None else _lib.f64(np.ravel(u)))
+
     def _update_augmented(self, Ad, Bd, dd, x0, xk, z, u, Hd, cd):
         N, n, m, nz = self.N, self.n_x, self.n_u, self.n_z
         Ad = np.asarray(Ad).reshape(N, n, n); Bd = np.asarray(Bd).reshape(N, n, m); dd = np.asarray(dd).reshape(N, n)
@@ -113,6 +170,8 @@ class LOCP:
         if self.nonlinear_observer and (full or self._data is None):
             self._zf_const = 0.0 if (self.Qzf is None or zf is None) else float(np.asarray(zf) @ self.Qzf @ np.asarray(zf))
             self._update_augmented(Ad, Bd, dd, x0, xk, z, u, kwargs.get('Hd'), kwargs.get('cd'))
+        elif self._du_aug and (full or self._data is None):
+            self._update_rate_augmented(Ad, Bd, dd, x0, xk, z, zf, u)
         elif full or self._data is None:
             N, n, m = self.N, self.n_x, self.n_u
             self._data = dict(
@@ -131,6 +190,8 @@ class LOCP:
         N, n, m = self.N, self.n_x, self.n_u
         if self.nonlinear_observer:
             n = n + self.n_z
+        if self._du_aug:
+            n = self._na
         x = np.empty((N + 1, n)); u = np.empty((N, m)); s = np.empty(N + 1)
         J = np.empty(1); status = np.empty(1, dtype=np.int32); iters = np.empty(1, dtype=np.int32)
         t0 = time.time()
@@ -145,6 +206,8 @@ class LOCP:
             if self.nonlinear_observer:
                 x = np.ascontiguousarray(x[:, :self.n_x])
                 J[0] += self._zf_const
+            if self._du_aug:
+                x = np.ascontiguousarray(x[:, :self.n_x])
             self._sol = (x, u, s if self.tr_active else None)
             return float(J[0]), True, _Stats(t1 - t0, int(iters[0]))
         return np.inf, False, None

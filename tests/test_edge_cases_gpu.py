@@ -138,10 +138,12 @@ def test_errors_are_loud():
     from sofacontrol_amd.lqr.ilqr import iLQR
     from sofacontrol_amd.utils import QuadraticCost, Polyhedron
     from sofacontrol_amd.scp.locp import LOCP
-    locp = LOCP(3, np.eye(2), np.eye(2), np.eye(1), dU=Polyhedron(np.eye(1), np.ones(1)))
-    locp.update([np.eye(2)] * 3, [np.ones((2, 1))] * 3, [np.zeros(2)] * 3, np.zeros(2), np.zeros((4, 2)), 1.0, 1.0)
-    with pytest.raises(RuntimeError, match='dU'):
-        locp.solve()                                   # input-rate constraints are rejected, not ignored
+    with pytest.raises(NotImplementedError, match='dU'):
+        LOCP(3, np.eye(2), np.eye(2), np.eye(1), dU=Polyhedron(np.eye(1), -np.ones(1)))   # zero increment infeasible
+    locp = LOCP(3, np.eye(2), np.eye(2), np.eye(1))
+    locp.update([np.eye(2)] * 3, [np.ones((2, 1))] * 3, [np.zeros(2)] * 3, np.zeros(2), None, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match='xk'):
+        locp.solve()                                   # trust region active without its centre
     il = iLQR(0.05, tp, QuadraticCost(Q=np.eye(6), R=np.eye(2), Qf=np.eye(6)), 5)
     il.params.do_linesearch = False
     il.set_target(np.zeros((6, 6)))

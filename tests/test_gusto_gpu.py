@@ -194,3 +194,32 @@ def test_plan_tables_survive_other_time_steps(golden):
     gu.solve(x0, u_init, x_init, z=z)
     np.testing.assert_array_equal(gu.xopt, x1)
     np.testing.assert_array_equal(gu.uopt, u1)
+
+
+def test_gusto_with_input_rate_constraints(golden):
+    """GuSTO(dU=...) (gusto.py:54-56): the rate rows couple the stages, so the solve runs the generic loop around the
+    state-augmented device QP; same iterates as the restated loop."""
+    from oracle import tpwl as otpwl, gusto as ogusto
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g, gm = setup(golden)
+    model, U_, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 30, q_scale=0.05)
+    tp = gm.dyn_sys
+    N, dt = 10, 0.05
+    Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    H = np.asarray(tp.H)
+    from scipy.interpolate import interp1d
+    z = interp1d(g['t'], g['zt'], axis=0)(dt * np.arange(N + 1))
+    x0 = np.zeros(8); u_init = np.zeros((N, 3))
+    x_init = otpwl.rollout(model, Ad, Bd, dd, x0, u_init)
+    dA = np.kron(np.eye(3), np.array([[1.], [-1.]])); db = np.full(6, 20.0)
+    gu = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, U=Poly(g['U_A'], g['U_b']), dU=Poly(dA, db),
+               x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, max_gusto_iters=3)
+    assert not gu._fused
+    gu.solve(x0, u_init, x_init, z=z)
+    xo, uo, zo, _ = gu.get_solution()
+    xe, ue, ze, tr = ogusto.solve(model, Ad, Bd, dd, H, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z,
+                                  U=(g['U_A'], g['U_b']), dU=(dA, db), x_char=g['x_char'], f_char=g['f_char'],
+                                  convg_thresh=1e-3, max_gusto_iters=3)
+    assert int(gu.iters[0]) == len(tr)
+    assert rel(xo, xe) <= 1e-4 and rel(uo, ue) <= 1e-4
+    assert np.abs(np.diff(uo, axis=0)).max() <= 20.0 * (1 + 1e-6)

@@ -180,3 +180,35 @@ def test_locp_terminal_set_and_input_target():
     assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
     assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
     assert np.all(Xf[0] @ x[-1] <= Xf[1] + 1e-9)
+
+
+@pytest.mark.parametrize('shape', ['small', 'diamond'])
+def test_locp_input_rate_constraints(shape):
+    """dU.A (u_{k+1} - u_k) <= dU.b (locp.py:305-308) through the state augmentation [x; u_prev; du] (the Diamond size
+    lands in the split-panel kernel: n_x + 2 n_u = 68)."""
+    from sofacontrol_amd.scp.locp import LOCP
+    kw = dict(seed=52, N=12) if shape == 'small' else dict(r=30, m=4, P=16, N=20, seed=53, q_scale=0.02, u_max=1500.0,
+                                                            amp=0.1, x_box=4.0)
+    case, _ = make_case(**kw)
+    m = case['Bd'][0].shape[1]
+    dA = np.kron(np.eye(m), np.array([[1.], [-1.]]))
+    db = np.full(2 * m, 8.0 if shape == 'small' else 5.0)
+    qp = olocp.build_qp(case['N'], case['H'], case['Qz'], case['R'], case['Ad'], case['Bd'], case['dd'], case['x0'],
+                        case['xk'], case['delta'], case['omega'], z=case['z'], U=case['U'], X=case['X'], dU=(dA, db),
+                        x_scale=case['x_scale'])
+    w, _, info = olocp.solve_exact(qp, tol=1e-12)
+    assert info.get('status', 'optimal') == 'optimal'
+    xe, ue, se = olocp.split(qp, w)
+    Je = olocp.objective(qp, w)
+    assert np.abs(np.diff(ue, axis=0)).max() > 0.99 * db[0]          # the rate limit is active
+    locp = LOCP(case['N'], case['H'], case['Qz'], case['R'], U=Poly(*case['U']), X=Poly(*case['X']), dU=Poly(dA, db),
+                x_char=1. / case['x_scale'])
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'],
+                case['omega'], z=case['z'])
+    J, ok, _ = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert x.shape == xe.shape
+    assert rel(x, xe) <= 2e-4 and rel(u, ue) <= 2e-4
+    assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
+    assert np.abs(np.diff(u, axis=0)).max() <= db[0] * (1 + 1e-6)
