@@ -257,7 +257,9 @@ typedef struct slocp_problem {
     int nU;  const double *UA, *Ub;    /* U.A (nU x n_u), U.b       locp.py:300-303     */
     int nX;  const double *XA, *Xb;    /* X.A (nX x n_x), X.b       locp.py:330-333     */
     int nXf; const double *XfA, *Xfb;  /* terminal set              locp.py:336-337     */
-    int ndU; const double *dUA, *dUb;  /* dU.A (ndU x n_u), dU.b    locp.py:305-308     */
+    int ndU; const double *dUA, *dUb;  /* dU.A (ndU x n_u), dU.b    locp.py:305-308: must be 0 here -- the rate rows
+                                        * couple consecutive stages; the host layer passes them as state rows of the
+                                        * augmented state [x; u_prev; du] (sofacontrol_amd/scp/locp.py) */
     int tr_active;                     /* is_tr_active              locp.py:57          */
 } slocp_problem;
 
