@@ -17,6 +17,7 @@
 //   * small B (closed-loop single vector, pod.py:51-52 via tpwl/controllers.py:96) uses split-K over
 //     workgroups with a fixed-order second-stage reduction (deterministic, no atomics).
 #include "common.h"
+#include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -29,7 +30,6 @@ constexpr int KC = 64;        // columns of X per chunk
 #endif
 constexpr int MTP = SRH_PROJ_MT;      // M-tiles (16 rows) per wave in the projection
 constexpr int ROWS_WG = 64 * MTP;     // rows of X per workgroup (4 waves x MTP M-tiles x 16)
-constexpr int LIFT_ROWS = 128;        // rows per workgroup in the lift (4 waves x 2 M-tiles x 16)
 
 struct ProjArgs {
     const double *X;      // (B x ldx)
@@ -64,19 +64,15 @@ __global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, 
     ufrag[idx] = (i < n_f && j < r) ? U[i * r + j] : 0.0;
 }
 
-__global__ void pack_ulift_kernel(const double *__restrict__ U, int64_t n_f, int r, int KS,
-                                  int64_t ntiles, double *__restrict__ ulift) {
-    // Ulift[itile][t][lane] = U[16 itile + (lane&15)][4 t + (lane>>4)]
+__global__ void pack_ut_kernel(const double *__restrict__ U, int64_t n_f, int r, int64_t ldu, int krows,
+                               double *__restrict__ ut) {
+    // Ut[k][16 + i] = U[i][k]: the basis transposed, 16 zero columns in front of and >= 16 behind every row and zero
+    // rows up to the next multiple of four, so that a shifted 16-column window of the lift never needs a guard
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = ntiles * KS * 64;
-    if (idx >= total) return;
-    int lane = idx & 63;
-    int64_t rest = idx >> 6;
-    int t = rest % KS;
-    int64_t it = rest / KS;
-    int64_t i = 16 * it + (lane & 15);
-    int j = 4 * t + (lane >> 4);
-    ulift[idx] = (i < n_f && j < r) ? U[i * r + j] : 0.0;
+    if (idx >= ldu * krows) return;
+    const int k = (int)(idx / ldu);
+    const int64_t i = idx % ldu - 16;
+    ut[idx] = (k < r && i >= 0 && i < n_f) ? U[i * r + k] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------ projection
@@ -274,66 +270,123 @@ __global__ void splitk_reduce_wave_kernel(const double *__restrict__ partial, in
 }
 
 // ------------------------------------------------------------------------------------------ lift
+// out = Xr U^T + 1 ref^T  (B x n_f, row pitch ldo): a pure write stream of 8 B n_f bytes.  What bounds it on gfx950 is
+// the shape of the stores, not their number (tools/probes/lift_probe.hip): a 16-lane segment that straddles two
+// 128-byte lines halves the rate of the memory pipe once loads share it (2.5 TB/s against 4.6 TB/s).  The pitch of
+// the full-order arrays is 8 n_f bytes (n_f = 3 x nodes: never a multiple of 128), so the rows of one MFMA tile are
+// chosen with equal alignment instead of consecutively:
+//   * rows are split in c = 16 / gcd(ldo mod 16, 16) classes, class j = rows R with R = j (mod c): all rows of a
+//     class start at the same offset a (in doubles) inside a 128-byte line;
+//   * one wave owns MT tiles of one class -- rows R0 + c (16 mt + i) -- and slides over the columns in windows
+//     [16 it - a, 16 it - a + 16): every store instruction writes four whole lines;
+//   * the B operand of window `it` is read from the transposed, zero-padded basis Ut[k][16 + i] (four 128-byte
+//     segments per load, any shift, no second packed copy); the first and last window are guarded, the interior
+//     loop has no divergent branch, and the fragment of window it+1 is requested before the stores of window it
+//     (loads and stores share the in-order vmcnt counter: a load issued after the stores would wait for their
+//     write acknowledgements).
 struct LiftArgs {
     const double *Xr;    // (B x ldr)
     int64_t ldr;
     int64_t r_blk_off;
-    const double *ulift;
-    const double *ref0, *ref1;
+    const double *ut;    // transposed padded basis, row pitch ldu
+    int64_t ldu;
+    const double *ref0, *ref1;   // null: no reference
     double *out;
     int64_t ldo;
     int64_t o_blk_off;
-    int64_t B, n_f, ntiles;
+    int64_t B, n_f;
     int r;
+    int classes;         // c
     int tiles_per_wg;
 };
 
-template <int NT, bool HAS_REF>
+template <int KS, int MT>
 __global__ __launch_bounds__(256) void lift_kernel(LiftArgs a) {
-    constexpr int KS = 4 * NT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = blockIdx.z;
     const double *Xr = a.Xr + (int64_t)blk * a.r_blk_off;
     const double *ref = blk ? a.ref1 : a.ref0;
     double *out = a.out + (int64_t)blk * a.o_blk_off;
-    const int64_t rowbase = (int64_t)blockIdx.x * LIFT_ROWS + wave * 32;
-    const int lrow = lane & 15, kgrp = lane >> 4;
+    const int c = a.classes;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t R0 = (item / c) * ((int64_t)c * 16 * MT) + item % c;       // rows R0 + c (16 mt + i)
+    if (R0 >= a.B) return;
+    const int lrow = lane & 15, kgrp = lane >> 4, col = lane & 15;
+    const int al = (int)((((uint64_t)out >> 3) + (uint64_t)R0 * (uint64_t)a.ldo) & 15);   // doubles into the line
 
-    double af[2][KS];
+    double af[MT][KS];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int64_t row = rowbase + mt * 16 + lrow;
-        if (row >= a.B) row = a.B - 1;
+    for (int mt = 0; mt < MT; ++mt) {
+        int64_t row = R0 + (int64_t)c * (16 * mt + lrow);
+        if (row >= a.B) row = a.B - 1;  // clamp: those rows are never stored
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
-            int j = 4 * t + kgrp;
+            const int j = 4 * t + kgrp;
             af[mt][t] = (j < a.r) ? Xr[row * a.ldr + j] : 0.0;
         }
     }
+    const int64_t ntl = (a.n_f + al + 15) / 16;
     const int64_t t0 = (int64_t)blockIdx.y * a.tiles_per_wg;
-    const int64_t t1 = min(t0 + (int64_t)a.tiles_per_wg, a.ntiles);
-    for (int64_t it = t0; it < t1; ++it) {
-        const double *uf = a.ulift + it * KS * 64;
-        double bf[KS];
+    const int64_t t1 = min(t0 + (int64_t)a.tiles_per_wg, ntl);
+    double bf[KS], rv = 0.0;
+    auto fetch = [&](int64_t it, double (&dst)[KS], double &rdst) {
+        const double *u = a.ut + 16 + 16 * it + col - al + (int64_t)kgrp * a.ldu;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) bf[t] = uf[t * 64 + lane];
-        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][t], bf[t], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][t], bf[t], acc1, 0, 0, 0);
+        for (int t = 0; t < KS; ++t) dst[t] = u[(int64_t)(4 * t) * a.ldu];
+        if (ref) {
+            int64_t i = 16 * it + col - al;
+            i = i < 0 ? 0 : (i >= a.n_f ? a.n_f - 1 : i);
+            rdst = ref[i];
         }
-        const int64_t i = 16 * it + (lane & 15);
-        if (i < a.n_f) {
-            const double rv = HAS_REF ? ref[i] : 0.0;
+    };
+    auto tile = [&](int64_t it, const double (&b)[KS], double r, auto guard) {
+        d4 acc[MT];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                int64_t r0 = rowbase + kgrp + 4 * reg;
-                int64_t r1 = r0 + 16;
-                if (r0 < a.B) out[r0 * a.ldo + i] = acc0[reg] + rv;
-                if (r1 < a.B) out[r1 * a.ldo + i] = acc1[reg] + rv;
-            }
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < KS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt][t], b[t], acc[mt], 0, 0, 0);
+        const int64_t i = 16 * it + col - al;
+        double *o = out + (R0 + (int64_t)c * kgrp) * a.ldo + i;
+        if (!decltype(guard)::value) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) o[(int64_t)c * (4 * reg + 16 * mt) * a.ldo] = acc[mt][reg] + r;
+        } else if (i >= 0 && i < a.n_f) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int64_t row = R0 + (int64_t)c * (kgrp + 4 * reg + 16 * mt);
+                    if (row < a.B) o[(int64_t)c * (4 * reg + 16 * mt) * a.ldo] = acc[mt][reg] + r;
+                }
         }
+    };
+    const bool rows_full = R0 + (int64_t)c * (16 * MT - 1) < a.B;                        // uniform per wave
+    const int64_t tlast = rows_full ? min(t1, (a.n_f + al) / 16) : t0;                   // windows < tlast end inside the row
+    int64_t it = t0;
+    if (it < t1 && (it == 0 && al)) {            // first window starts in front of the row
+        fetch(it, bf, rv);
+        tile(it, bf, rv, std::true_type{});
+        ++it;
+    }
+    if (it < tlast) {
+        fetch(it, bf, rv);
+        for (; it < tlast; ++it) {
+            double bn[KS], rn = 0.0;
+            fetch(it + 1 < tlast ? it + 1 : it, bn, rn);
+            tile(it, bf, rv, std::false_type{});
+#pragma unroll
+            for (int t = 0; t < KS; ++t) bf[t] = bn[t];
+            rv = rn;
+        }
+    }
+    for (; it < t1; ++it) {
+        fetch(it, bf, rv);
+        tile(it, bf, rv, std::true_type{});
     }
 }
 
@@ -407,7 +460,8 @@ struct srom {
     int64_t n_f = 0;
     int r = 0, NT = 0, nchunks = 0;
     int64_t ntiles = 0;
-    srh::DevBuf U, q_ref, v_ref, ufrag, ulift, work;
+    srh::DevBuf U, q_ref, v_ref, ufrag, ut, work;
+    int64_t ldu = 0;
     size_t work_bytes = 0;
     // per-simulation-step calls (one state in, one reduced state out) reuse these instead of paying
     // hipMalloc / hipFree and a pageable-memory copy per call: device staging + pinned host mirrors
@@ -475,10 +529,10 @@ static int launch_proj(const ProjArgs &a, bool has_ref, bool vec2, dim3 grid, hi
     return SRH_OK;
 }
 
-template <int NT>
-static int launch_lift(const LiftArgs &a, bool has_ref, dim3 grid, hipStream_t s) {
-    if (has_ref) lift_kernel<NT, true><<<grid, 256, 0, s>>>(a);
-    else lift_kernel<NT, false><<<grid, 256, 0, s>>>(a);
+template <int KS>
+static int launch_lift(const LiftArgs &a, int mt, dim3 grid, hipStream_t s) {
+    if (mt == 4) lift_kernel<KS, 4><<<grid, 256, 0, s>>>(a);
+    else lift_kernel<KS, 1><<<grid, 256, 0, s>>>(a);
     SRH_CHECK_HIP(hipGetLastError());
     return SRH_OK;
 }
@@ -503,16 +557,17 @@ int srom_create(srom_t **out, const double *U, int64_t n_f, int r, const double 
         (rc = h->q_ref.upload(q_ref ? q_ref : zeros.data(), sizeof(double) * n_f)) ||
         (rc = h->v_ref.upload(v_ref ? v_ref : zeros.data(), sizeof(double) * n_f)) ||
         (rc = h->ufrag.alloc(sizeof(double) * (size_t)h->nchunks * 16 * h->NT * 64)) ||
-        (rc = h->ulift.alloc(sizeof(double) * (size_t)h->ntiles * 4 * h->NT * 64))) {
+        (rc = h->ut.alloc(sizeof(double) * (size_t)(16 * h->ntiles + 32) * 4 * ((r + 3) / 4)))) {
         delete h;
         return rc;
     }
     int64_t tot = (int64_t)h->nchunks * 16 * h->NT * 64;
     pack_u_kernel<<<(unsigned)srh::cdiv(tot, 256), 256>>>(h->U.as<double>(), n_f, r, h->NT, h->nchunks,
                                                          h->ufrag.as<double>());
-    int64_t tot2 = h->ntiles * 4 * h->NT * 64;
-    pack_ulift_kernel<<<(unsigned)srh::cdiv(tot2, 256), 256>>>(h->U.as<double>(), n_f, r, 4 * h->NT,
-                                                              h->ntiles, h->ulift.as<double>());
+    h->ldu = 16 * h->ntiles + 32;
+    const int krows = 4 * ((r + 3) / 4);
+    pack_ut_kernel<<<(unsigned)srh::cdiv(h->ldu * krows, 256), 256>>>(h->U.as<double>(), n_f, r, h->ldu, krows,
+                                                                      h->ut.as<double>());
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         srh::set_error("srom_create: packing kernels failed: %s", hipGetErrorString(e));
@@ -623,28 +678,39 @@ int srom_lift_dev(srom_t *h, int which, const double *Xr, int64_t B, int64_t ldr
     a.Xr = Xr;
     a.ldr = ldr;
     a.r_blk_off = h->r;
-    a.ulift = h->ulift.as<double>();
+    a.ut = h->ut.as<double>();
+    a.ldu = h->ldu;
     a.out = out;
     a.ldo = ldo;
     a.o_blk_off = h->n_f;
     a.B = B;
     a.n_f = h->n_f;
-    a.ntiles = h->ntiles;
     a.r = h->r;
-    bool has_ref = which != SROM_RAW;
     if (which == SROM_Q) a.ref0 = h->q_ref.as<double>();
     if (which == SROM_V) a.ref0 = h->v_ref.as<double>();
     if (which == SROM_X) { a.ref0 = h->v_ref.as<double>(); a.ref1 = h->q_ref.as<double>(); }
-    const int64_t rowtiles = srh::cdiv(B, LIFT_ROWS);
-    int64_t ysplit = std::max<int64_t>(1, std::min<int64_t>(h->ntiles, srh::cdiv(1024, rowtiles * nblk)));
-    a.tiles_per_wg = (int)srh::cdiv(h->ntiles, ysplit);
-    ysplit = srh::cdiv(h->ntiles, a.tiles_per_wg);
-    dim3 grid((unsigned)rowtiles, (unsigned)ysplit, (unsigned)nblk);
-    switch (h->NT) {
-        case 1: return launch_lift<1>(a, has_ref, grid, s);
-        case 2: return launch_lift<2>(a, has_ref, grid, s);
-        case 3: return launch_lift<3>(a, has_ref, grid, s);
-        default: return launch_lift<4>(a, has_ref, grid, s);
+    // alignment classes of the row starts (the block offset n_f of SROM_X shifts every row alike)
+    const int m16 = (int)(ldo & 15);
+    int g = 16;
+    while (m16 % g) g >>= 1;
+    a.classes = m16 ? 16 / g : 1;
+    // four tiles per wave share one basis fragment; a handful of rows (closed loop: one state) takes one tile
+    const int mt = (B >= (int64_t)a.classes * 64) ? 4 : 1;
+    const int64_t rows_sb = (int64_t)a.classes * 16 * mt;               // rows of one super-block = `classes` items
+    const int64_t items = srh::cdiv(B, rows_sb) * a.classes;
+    const int64_t wgs = srh::cdiv(items, 4);
+    const int64_t ntl = h->ntiles + 1;                                   // windows incl. the shifted first one
+    int64_t ysplit = std::max<int64_t>(1, std::min<int64_t>(ntl, srh::cdiv(512, wgs * nblk)));
+    a.tiles_per_wg = (int)srh::cdiv(ntl, ysplit);
+    ysplit = srh::cdiv(ntl, a.tiles_per_wg);
+    dim3 grid((unsigned)wgs, (unsigned)ysplit, (unsigned)nblk);
+    switch ((h->r + 3) / 4) {
+#define SRH_LIFT_CASE(K) case K: return launch_lift<K>(a, mt, grid, s);
+        SRH_LIFT_CASE(1) SRH_LIFT_CASE(2) SRH_LIFT_CASE(3) SRH_LIFT_CASE(4) SRH_LIFT_CASE(5) SRH_LIFT_CASE(6)
+        SRH_LIFT_CASE(7) SRH_LIFT_CASE(8) SRH_LIFT_CASE(9) SRH_LIFT_CASE(10) SRH_LIFT_CASE(11) SRH_LIFT_CASE(12)
+        SRH_LIFT_CASE(13) SRH_LIFT_CASE(14) SRH_LIFT_CASE(15)
+#undef SRH_LIFT_CASE
+        default: return launch_lift<16>(a, mt, grid, s);
     }
 }
 

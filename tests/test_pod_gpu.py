@@ -71,6 +71,43 @@ def test_project_lift_vs_oracle(n_f, r, B):
     close(rom.compute_FO_state(x=pr), opod.lift_x(U, q_ref, v_ref, pr))
 
 
+@pytest.mark.parametrize('n_f,r,B,pitch_extra,base_off', [
+    (4884, 30, 300, 0, 0),      # pitch = 4 (mod 16): four alignment classes, partial last super-block
+    (4884, 30, 257, 0, 3),      # output base not line aligned
+    (2127, 9, 1100, 0, 0),      # odd pitch: sixteen classes
+    (2127, 30, 70, 5, 1),       # pitch > n_f: the gap between rows stays untouched
+    (4896, 36, 130, 0, 0),      # aligned pitch: one class
+    (333, 64, 65, 0, 7),
+    (50, 3, 1, 0, 0),
+])
+def test_lift_alignment_classes(n_f, r, B, pitch_extra, base_off):
+    """The lift picks the rows of an MFMA tile by the 128-byte alignment class of their start and shifts the column
+    window per class: every (pitch mod 16, base offset, ragged B) must still write exactly out[b, :n_f] and nothing
+    else (sentinel check around and between the rows).  Reference: sofacontrol/mor/pod.py:54-66."""
+    import ctypes as C
+    from sofacontrol_amd import _lib
+    from sofacontrol_amd.mor.pod import POD
+    U, q_ref, v_ref = make_rom(n_f, r, seed=3)
+    rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    rng = np.random.default_rng(B)
+    Xr = rng.standard_normal((B, r))
+    ldo = n_f + pitch_extra
+    guard = 64
+    total = guard + base_off + B * ldo + guard
+    sentinel = -777.25
+    dO = _lib.DeviceBuffer.from_array(np.full(total, sentinel))
+    dX = _lib.DeviceBuffer.from_array(Xr)
+    optr = C.c_void_p(dO.ptr.value + 8 * (guard + base_off))
+    L = _lib.lib()
+    _lib.check(L.srom_lift_dev(rom.handle, 0, dX.ptr, C.c_int64(B), C.c_int64(r), optr, C.c_int64(ldo), None), 'lift')
+    _lib.sync()
+    got = dO.to_array((total,))
+    body = got[guard + base_off:guard + base_off + B * ldo].reshape(B, ldo)
+    close(body[:, :n_f], opod.lift(U, q_ref, Xr))
+    assert np.all(body[:, n_f:] == sentinel)
+    assert np.all(got[:guard + base_off] == sentinel) and np.all(got[guard + base_off + B * ldo:] == sentinel)
+
+
 def test_project_transpose_detecting():
     """Asymmetric basis with identity-like snapshots: catches swapped MFMA operands / C layout."""
     from sofacontrol_amd.mor.pod import POD

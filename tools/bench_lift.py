@@ -6,7 +6,8 @@ import workloads as wl
 from sofacontrol_amd import _lib
 from sofacontrol_amd.mor.pod import POD
 L = _lib.lib()
-B, n_f = 65536, 4884
+B = 65536
+n_f = int(sys.argv[1]) if len(sys.argv) > 1 else 4884
 e0, e1 = C.c_void_p(), C.c_void_p()
 L.srh_event_create(C.byref(e0)); L.srh_event_create(C.byref(e1))
 def timed(fn, reps=8):
