@@ -10,8 +10,8 @@ B = 65536
 n_f = int(sys.argv[1]) if len(sys.argv) > 1 else 4884
 e0, e1 = C.c_void_p(), C.c_void_p()
 L.srh_event_create(C.byref(e0)); L.srh_event_create(C.byref(e1))
-def timed(fn, reps=8):
-    for _ in range(2): fn()
+def timed(fn, reps=300):     # long enough for the clocks to ramp (20 launches read 20 % low)
+    for _ in range(50): fn()
     _lib.sync(); L.srh_event_record(e0, None)
     for _ in range(reps): fn()
     L.srh_event_record(e1, None); _lib.sync()

@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 from sofacontrol_amd import _lib
 from sofacontrol_amd.mor.pod import POD
 
-n_f, r = 4884, int(sys.argv[2]) if len(sys.argv) > 2 else 30
+r = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+n_f = int(sys.argv[3]) if len(sys.argv) > 3 else 4884
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 rng = np.random.default_rng(0)
 U, _ = np.linalg.qr(rng.standard_normal((n_f, r)))
@@ -23,7 +24,7 @@ def run(n):
     for _ in range(n):
         _lib.check(L.srom_project_dev(rom.handle, 0, dX.ptr, C.c_int64(B), C.c_int64(n_f), dO.ptr, C.c_int64(r), None), 'proj')
 run(3); _lib.sync()
-iters = 20
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 L.srh_event_record(e0, None); run(iters); L.srh_event_record(e1, None)
 ms = C.c_float(); L.srh_event_elapsed_ms(e0, e1, C.byref(ms))
 t = ms.value / iters * 1e-3
