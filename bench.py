@@ -188,6 +188,50 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
             'not_converged_rank0': int((g.status != 0).sum())}
 
 
+def pod_shapes(L, _lib, B=65536):
+    """the projection at the shipped r = 36 as well, the lift (pod.py:54-66) and the full-state form
+    (both blocks, `compute_RO_state(xf=...)`); resident buffers, HIP events over 100 launches after 30 warm-up ones."""
+    import workloads as wl
+    from sofacontrol_amd.mor.pod import POD
+    n_f = 4884
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.srh_event_create(C.byref(e0)); L.srh_event_create(C.byref(e1))
+
+    def timed(fn, reps=100):
+        for _ in range(30):
+            fn()
+        _lib.sync(); L.srh_event_record(e0, None)
+        for _ in range(reps):
+            fn()
+        L.srh_event_record(e1, None); _lib.sync()
+        ms = C.c_float(); L.srh_event_elapsed_ms(e0, e1, C.byref(ms))
+        return ms.value / reps * 1e-3
+
+    out = {'workload': 'B = %d snapshots x n_f = %d, f64, resident; GB/s of the algorithmic bytes' % (B, n_f)}
+    U0, q_ref, v_ref = wl.pod_basis(n_f, 30, seed=0)
+    X = wl.snapshots(q_ref, B, seed=2)
+    dX = _lib.DeviceBuffer.from_array(X)
+    del X
+    for r in (30, 36):
+        U, q_ref, v_ref = wl.pod_basis(n_f, r, seed=0)
+        rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+        dXr = _lib.DeviceBuffer(B * r * 8)
+        byt = 8.0 * (B * n_f + n_f * r + n_f + B * r)
+        t = timed(lambda: _lib.check(L.srom_project_dev(rom.handle, 0, dX.ptr, C.c_int64(B), C.c_int64(n_f), dXr.ptr,
+                                                        C.c_int64(r), None), 'project'))
+        out['project_r%d' % r] = {'ms': t * 1e3, 'gbs': byt / t / 1e9, 'frac_of_hbm_peak': byt / t / 8e12}
+        # full-state form on the same bytes: B/2 states [v; q] of 2 n_f
+        t = timed(lambda: _lib.check(L.srom_project_dev(rom.handle, 2, dX.ptr, C.c_int64(B // 2), C.c_int64(2 * n_f), dXr.ptr,
+                                                        C.c_int64(2 * r), None), 'project_x'))
+        out['project_x_r%d' % r] = {'ms': t * 1e3, 'gbs': byt / t / 1e9, 'frac_of_hbm_peak': byt / t / 8e12}
+        t = timed(lambda: _lib.check(L.srom_lift_dev(rom.handle, 0, dXr.ptr, C.c_int64(B), C.c_int64(r), dX.ptr,
+                                                     C.c_int64(n_f), None), 'lift'))
+        out['lift_r%d' % r] = {'ms': t * 1e3, 'gbs': byt / t / 1e9, 'frac_of_hbm_peak': byt / t / 8e12}
+        dXr.free()
+    dX.free()
+    return out
+
+
 def secondary(L, _lib, rank, world, dist):
     import workloads as wl
     """Secondary metrics of SURVEY.md section 8(d), measured outside the timed region of the headline metric:
@@ -252,6 +296,10 @@ def secondary(L, _lib, rank, world, dist):
     out['gramian_c4'] = {'workload': 'C4 per-GPU shard: S %d x %d f64, G = S S^T' % (n_s, n_f), 'ms': ms.value,
                          'tflops_executed': flop / (ms.value * 1e-3) / 1e12,
                          'frac_of_f64_mfma_peak': flop / (ms.value * 1e-3) / 1e12 / 78.6}
+    try:
+        out['pod_shapes'] = pod_shapes(L, _lib)
+    except Exception as exc:
+        out['pod_shapes'] = {'error': repr(exc)}
     try:
         out['scp_c5'] = scp_c5(_lib, rank, world, dist)
     except Exception as exc:
