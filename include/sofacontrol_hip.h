@@ -93,7 +93,8 @@ int srom_reduce_matrix_dev(srom_t *h, const double *M_dev, int64_t ncols, int le
 int srom_gramian_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, double *G_dev,
                      void *stream);
 int srom_gramian(const double *S, int64_t n_s, int64_t n_f, double *G);
-/* eigh of the (symmetric) Gramian in place on the device (rocSOLVER dsyevd): on return row j of G_dev is
+/* eigh of the (symmetric) Gramian in place on the device (cyclic Jacobi kernels up to n = 2048, rocSOLVER dsyevd
+ * above): on return row j of G_dev is
  * the eigenvector of the j-th smallest eigenvalue, w_dev (n) ascending.  Replaces the SVD of pod.py:190. */
 int srom_eigh_dev(double *G_dev, int64_t n, double *w_dev, void *stream);
 /* W_k (n x k, row-major) = the k leading eigenvectors as columns, scaled by 1/sigma_i = 1/sqrt(w_i) */

@@ -204,7 +204,7 @@ def compute_POD(snapshots, tol, rom_dim=None):
     S_rows = np.ascontiguousarray(np.asarray(snapshots, dtype=np.float64).T)
     n_s, n_f = S_rows.shape
     L = _lib.lib()
-    # everything stays in HBM: Gramian (MFMA kernel) -> eigh (rocSOLVER) -> mode selection -> U = S^T W Sigma^-1;
+    # everything stays in HBM: Gramian (MFMA kernel) -> eigh (Jacobi kernels; rocSOLVER above 2048 snapshots) -> mode selection -> U = S^T W Sigma^-1;
     # only the n_s eigenvalues cross to the host for the energy truncation
     dS = _lib.DeviceBuffer.from_array(S_rows)
     dG, dw = _lib.DeviceBuffer(n_s * n_s * 8), _lib.DeviceBuffer(n_s * 8)

@@ -3,6 +3,8 @@ problems each kernel accepts, each against the oracle."""
 import io
 import contextlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -151,10 +153,10 @@ def test_errors_are_loud():
         il.ilqr_computation(np.zeros(6))
 
 
-@pytest.mark.parametrize('n', [1, 2, 5, 40, 127, 128, 150])
+@pytest.mark.parametrize('n', [1, 2, 5, 40, 127, 128, 129, 150, 257, 400])
 def test_device_eigh(n):
-    """srom_eigh_dev: one-workgroup Jacobi for n <= 128, rocSOLVER dsyevd above (n = 150; the first call in a
-    process loads rocBLAS, minutes on a cold box)."""
+    """srom_eigh_dev: one-workgroup Jacobi in LDS for n <= 128, the same Jacobi over HBM (two launches per round-robin
+    step) up to 2048 -- odd sizes pad with a dummy row that never mixes."""
     from sofacontrol_amd.mor.pod import _device_eigh
     rng = np.random.default_rng(n)
     S = rng.standard_normal((n, n + 3)) * np.logspace(0, -3, n + 3)
@@ -163,4 +165,23 @@ def test_device_eigh(n):
     we = np.linalg.eigvalsh(G)
     np.testing.assert_allclose(w, we, rtol=0, atol=1e-12 * max(1.0, np.abs(we).max()))
     np.testing.assert_allclose(W.T @ W, np.eye(n), atol=1e-12)
+    np.testing.assert_allclose(G @ W, W * w, atol=1e-11 * max(1.0, np.abs(we).max()))
+
+
+@pytest.mark.skipif(os.environ.get('SRH_TEST_ROCSOLVER') != '1',
+                    reason='the first rocSOLVER / rocBLAS load of a process takes minutes on a cold box: set SRH_TEST_ROCSOLVER=1')
+def test_device_eigh_rocsolver_path():
+    """n > 2048 goes to rocSOLVER dsyevd (dlopen at first use); SRH_EIGH_ROCSOLVER forces it for any n."""
+    from sofacontrol_amd.mor.pod import _device_eigh
+    os.environ['SRH_EIGH_ROCSOLVER'] = '1'
+    try:
+        n = 150
+        rng = np.random.default_rng(n)
+        S = rng.standard_normal((n, n + 3)) * np.logspace(0, -3, n + 3)
+        G = S @ S.T
+        w, W = _device_eigh(G)
+    finally:
+        del os.environ['SRH_EIGH_ROCSOLVER']
+    we = np.linalg.eigvalsh(G)
+    np.testing.assert_allclose(w, we, rtol=0, atol=1e-12 * max(1.0, np.abs(we).max()))
     np.testing.assert_allclose(G @ W, W * w, atol=1e-11 * max(1.0, np.abs(we).max()))
