@@ -47,20 +47,24 @@ struct ProjArgs {
     int nchunks, chunks_per_split;
 };
 
-__global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, int NT, int nchunks,
+__global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, int NTF, int NQ, int nchunks,
                               double *__restrict__ ufrag) {
-    // Ufrag[c][t][nt][lane] = U[64c + 8*(t>>1) + 2*(lane>>4) + (t&1)][16 nt + (lane&15)]
+    // Ufrag[c][t][f][lane], row i = 64c + 8*(t>>1) + 2*(lane>>4) + (t&1) of U:
+    //   f <  NTF : full 16-column tile f, column 16 f + (lane&15)            (B operand of v_mfma_f64_16x16x4)
+    //   f >= NTF : 4-column tile q = f - NTF, column 16 NTF + 4 q + (lane&3), the same 4 x 4 block for each of the
+    //              four row blocks (lane>>2)&3                                (B operand of v_mfma_f64_4x4x4, 4 blocks)
+    const int NF = NTF + NQ;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)nchunks * 16 * NT * 64;
+    int64_t total = (int64_t)nchunks * 16 * NF * 64;
     if (idx >= total) return;
     int lane = idx & 63;
     int64_t rest = idx >> 6;
-    int nt = rest % NT;
-    rest /= NT;
+    int f = rest % NF;
+    rest /= NF;
     int t = rest & 15;
     int64_t c = rest >> 4;
     int64_t i = c * KC + 8 * (t >> 1) + 2 * (lane >> 4) + (t & 1);
-    int j = 16 * nt + (lane & 15);
+    int j = f < NTF ? 16 * f + (lane & 15) : 16 * NTF + 4 * (f - NTF) + (lane & 3);
     ufrag[idx] = (i < n_f && j < r) ? U[i * r + j] : 0.0;
 }
 
@@ -76,10 +80,16 @@ __global__ void pack_ut_kernel(const double *__restrict__ U, int64_t n_f, int r,
 }
 
 // ------------------------------------------------------------------------------------ projection
-template <int NT, bool HAS_REF, bool VEC2>
+// NTF full 16-column tiles + NQ 4-column tiles (r mod 16 <= 12: the remainder runs on v_mfma_f64_4x4x4, whose four
+// 4 x 4 blocks take the SAME A operand layout -- lane = (row & 15, k-group) -- at a quarter of the issue time of a
+// padded 16-column tile: measured 7.1 ns against 26.9 ns per instruction, tools/probes/mfma4_probe.hip; r = 36 costs
+// 2.25 tiles instead of 3)
+template <int NTF, int NQ, bool HAS_REF, bool VEC2>
 __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int UCH = 16 * NT * 64;         // doubles of U fragments per chunk
+    constexpr int NF = NTF + NQ;
+    constexpr int NT = NTF > 0 ? NTF : 1, NQA = NQ > 0 ? NQ : 1;   // array extents
+    constexpr int UCH = 16 * NF * 64;         // doubles of U fragments per chunk
     constexpr int BUF = UCH + KC;             // + reference chunk
     double *lds = reinterpret_cast<double *>(smem);
 
@@ -93,10 +103,14 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     const int lrow = lane & 15, kgrp = lane >> 4;
 
     d4 acc[MTP][NT];
+    double accq[MTP][NQA];
 #pragma unroll
-    for (int mt = 0; mt < MTP; ++mt)
+    for (int mt = 0; mt < MTP; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) accq[mt][q] = 0.0;
+    }
 
     const double *xrow[MTP];
 #pragma unroll
@@ -187,11 +201,18 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                double bv = ub[(t * NT + nt) * 64 + lane];
+            for (int nt = 0; nt < NTF; ++nt) {
+                double bv = ub[(t * NF + nt) * 64 + lane];
 #pragma unroll
                 for (int mt = 0; mt < MTP; ++mt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[mt][t], bv, acc[mt][nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                double bv = ub[(t * NF + NTF + q) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt)
+                    accq[mt][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(xr[mt][t], bv, accq[mt][q], 0, 0, 0);
             }
         }
         if (more) stage_write(b ^ 1);
@@ -204,35 +225,36 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
         }
     }
 
-    // D layout of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg
+    // D layout of v_mfma_f64_16x16x4: col = lane&15, row = (lane>>4) + 4*reg; of v_mfma_f64_4x4x4 (one value per
+    // lane): col = lane&3, row = 4*((lane>>2)&3) + (lane>>4)
     const int col = lane & 15;
-    if (a.partial == nullptr) {
-        double *out = a.out + (int64_t)blk * a.o_blk_off;
+    constexpr int LDP = 16 * (NTF + (NQ ? 1 : 0));
+    const bool direct = a.partial == nullptr;
+    double *dst = direct ? a.out + (int64_t)blk * a.o_blk_off
+                         : a.partial + (((int64_t)blockIdx.y * gridDim.z + blk) * a.B) * LDP;
+    const int64_t ldd = direct ? a.ldo : LDP;
+    const int jmax = direct ? a.r : LDP;
 #pragma unroll
-        for (int mt = 0; mt < MTP; ++mt)
+    for (int mt = 0; mt < MTP; ++mt) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                int64_t row = rowbase + mt * 16 + kgrp + 4 * reg;
-                if (row < a.B) {
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t row = rowbase + mt * 16 + kgrp + 4 * reg;
+            if (row < a.B) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        int j = 16 * nt + col;
-                        if (j < a.r) out[row * a.ldo + j] = acc[mt][nt][reg];
-                    }
+                for (int nt = 0; nt < NTF; ++nt) {
+                    const int j = 16 * nt + col;
+                    if (j < jmax) dst[row * ldd + j] = acc[mt][nt][reg];
                 }
             }
-    } else {
-        double *part = a.partial + (((int64_t)blockIdx.y * gridDim.z + blk) * a.B) * (NT * 16);
+        }
+        const int64_t rowq = rowbase + mt * 16 + 4 * ((lane >> 2) & 3) + (lane >> 4);
+        if (rowq < a.B) {
 #pragma unroll
-        for (int mt = 0; mt < MTP; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                int64_t row = rowbase + mt * 16 + kgrp + 4 * reg;
-                if (row < a.B) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) part[row * (NT * 16) + 16 * nt + col] = acc[mt][nt][reg];
-                }
+            for (int q = 0; q < NQ; ++q) {
+                const int j = 16 * NTF + 4 * q + (lane & 3);
+                if (j < jmax) dst[rowq * ldd + j] = accq[mt][q];
             }
+        }
     }
 }
 
@@ -458,7 +480,7 @@ __global__ void atb_reduce_kernel(const double *__restrict__ partial, int nblk, 
 // ---------------------------------------------------------------------------------------- handle
 struct srom {
     int64_t n_f = 0;
-    int r = 0, NT = 0, nchunks = 0;
+    int r = 0, NT = 0, NTF = 0, NQ = 0, nchunks = 0;   // NT = 16-column slots (partials), NTF full + NQ 4-column MFMA tiles
     int64_t ntiles = 0;
     srh::DevBuf U, q_ref, v_ref, ufrag, ut, work;
     int64_t ldu = 0;
@@ -515,15 +537,15 @@ static int proj_ksplit(const srom *h, int64_t B, int nblk, int *chunks_per_split
     return (int)srh::cdiv(h->nchunks, *chunks_per_split);
 }
 
-template <int NT>
+template <int NTF, int NQ>
 static int launch_proj(const ProjArgs &a, bool has_ref, bool vec2, dim3 grid, hipStream_t s) {
-    size_t lds = 2 * (size_t)(16 * NT * 64 + KC) * sizeof(double);
+    size_t lds = 2 * (size_t)(16 * (NTF + NQ) * 64 + KC) * sizeof(double);
     if (has_ref) {
-        if (vec2) proj_kernel<NT, true, true><<<grid, 256, lds, s>>>(a);
-        else proj_kernel<NT, true, false><<<grid, 256, lds, s>>>(a);
+        if (vec2) proj_kernel<NTF, NQ, true, true><<<grid, 256, lds, s>>>(a);
+        else proj_kernel<NTF, NQ, true, false><<<grid, 256, lds, s>>>(a);
     } else {
-        if (vec2) proj_kernel<NT, false, true><<<grid, 256, lds, s>>>(a);
-        else proj_kernel<NT, false, false><<<grid, 256, lds, s>>>(a);
+        if (vec2) proj_kernel<NTF, NQ, false, true><<<grid, 256, lds, s>>>(a);
+        else proj_kernel<NTF, NQ, false, false><<<grid, 256, lds, s>>>(a);
     }
     SRH_CHECK_HIP(hipGetLastError());
     return SRH_OK;
@@ -548,6 +570,9 @@ int srom_create(srom_t **out, const double *U, int64_t n_f, int r, const double 
     h->n_f = n_f;
     h->r = r;
     h->NT = (r + 15) / 16;
+    h->NTF = r / 16;
+    h->NQ = (r % 16 + 3) / 4;
+    if (h->NQ == 4) { h->NTF += 1; h->NQ = 0; }
     h->nchunks = (int)srh::cdiv(n_f, KC);
     h->ntiles = srh::cdiv(n_f, 16);
     int rc;
@@ -556,13 +581,13 @@ int srom_create(srom_t **out, const double *U, int64_t n_f, int r, const double 
     if ((rc = h->U.upload(U, sizeof(double) * n_f * r)) ||
         (rc = h->q_ref.upload(q_ref ? q_ref : zeros.data(), sizeof(double) * n_f)) ||
         (rc = h->v_ref.upload(v_ref ? v_ref : zeros.data(), sizeof(double) * n_f)) ||
-        (rc = h->ufrag.alloc(sizeof(double) * (size_t)h->nchunks * 16 * h->NT * 64)) ||
+        (rc = h->ufrag.alloc(sizeof(double) * (size_t)h->nchunks * 16 * (h->NTF + h->NQ) * 64)) ||
         (rc = h->ut.alloc(sizeof(double) * (size_t)(16 * h->ntiles + 32) * 4 * ((r + 3) / 4)))) {
         delete h;
         return rc;
     }
-    int64_t tot = (int64_t)h->nchunks * 16 * h->NT * 64;
-    pack_u_kernel<<<(unsigned)srh::cdiv(tot, 256), 256>>>(h->U.as<double>(), n_f, r, h->NT, h->nchunks,
+    int64_t tot = (int64_t)h->nchunks * 16 * (h->NTF + h->NQ) * 64;
+    pack_u_kernel<<<(unsigned)srh::cdiv(tot, 256), 256>>>(h->U.as<double>(), n_f, r, h->NTF, h->NQ, h->nchunks,
                                                          h->ufrag.as<double>());
     h->ldu = 16 * h->ntiles + 32;
     const int krows = 4 * ((r + 3) / 4);
@@ -626,11 +651,17 @@ int srom_project_dev(srom_t *h, int which, const double *X, int64_t B, int64_t l
     const bool vec2 = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 2 == 0) && (h->n_f % 2 == 0);
     dim3 grid((unsigned)rowtiles, (unsigned)ksplit, (unsigned)nblk);
     int rc;
-    switch (h->NT) {
-        case 1: rc = launch_proj<1>(a, has_ref, vec2, grid, s); break;
-        case 2: rc = launch_proj<2>(a, has_ref, vec2, grid, s); break;
-        case 3: rc = launch_proj<3>(a, has_ref, vec2, grid, s); break;
-        default: rc = launch_proj<4>(a, has_ref, vec2, grid, s); break;
+    switch (4 * h->NTF + h->NQ) {
+#define SRH_PROJ_CASE(F, Q) case 4 * F + Q: rc = launch_proj<F, Q>(a, has_ref, vec2, grid, s); break;
+        SRH_PROJ_CASE(0, 1) SRH_PROJ_CASE(0, 2) SRH_PROJ_CASE(0, 3)
+        SRH_PROJ_CASE(1, 0) SRH_PROJ_CASE(1, 1) SRH_PROJ_CASE(1, 2) SRH_PROJ_CASE(1, 3)
+        SRH_PROJ_CASE(2, 0) SRH_PROJ_CASE(2, 1) SRH_PROJ_CASE(2, 2) SRH_PROJ_CASE(2, 3)
+        SRH_PROJ_CASE(3, 0) SRH_PROJ_CASE(3, 1) SRH_PROJ_CASE(3, 2) SRH_PROJ_CASE(3, 3)
+        SRH_PROJ_CASE(4, 0)
+#undef SRH_PROJ_CASE
+        default:
+            srh::set_error("srom_project_dev: no kernel for r = %d", h->r);
+            return SRH_EINVAL;
     }
     if (rc) return rc;
     if (ksplit > 1) {

@@ -53,7 +53,8 @@ def test_golden_g1(golden):
         rom.compute_RO_matrix([[1.0]])
 
 
-@pytest.mark.parametrize('n_f,r', [(4884, 30), (4884, 36), (2127, 10), (2127, 30), (50, 3), (1000, 64)])
+@pytest.mark.parametrize('n_f,r', [(4884, 30), (4884, 36), (2127, 10), (2127, 30), (50, 3), (1000, 64),
+                                   (300, 7), (300, 22), (500, 41), (500, 55)])   # every (full, 4-column) tile mix
 @pytest.mark.parametrize('B', [1, 7, 128, 1000])
 def test_project_lift_vs_oracle(n_f, r, B):
     from sofacontrol_amd.mor.pod import POD
