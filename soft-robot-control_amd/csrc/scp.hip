@@ -69,7 +69,28 @@ struct GustoBatch {
     double *trace;
     double *work;                       // per problem: [qp work | xk | uk | ints]
     size_t work_stride;
+    const int32_t *order;               // workgroup -> rollout (longest expected solve first), or null
+    int32_t *last_iters;                // SCP iterations of this solve per rollout: the next solve's dispatch key
 };
+
+// Longest-processing-time-first dispatch: the rollouts of a receding-horizon batch need 1..max SCP iterations each
+// and a workgroup owns its CU for the whole solve, so the tail of a launch is set by whichever long solves start
+// last.  The previous solve of the same rollout predicts its length; a counting sort on those iteration counts
+// (descending) gives the workgroup -> rollout map of the next launch.  Results do not depend on the order.
+__global__ __launch_bounds__(1024) void lpt_order_kernel(const int32_t *__restrict__ key, int64_t batch, int32_t *__restrict__ order) {
+    __shared__ int cnt[1024];
+    const int tid = threadIdx.x;
+    cnt[tid] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < batch; i += 1024) atomicAdd(&cnt[1023 - min(max(key[i], 0), 1023)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < 1024; ++q) { const int c = cnt[q]; cnt[q] = run; run += c; }
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < batch; i += 1024) order[atomicAdd(&cnt[1023 - min(max(key[i], 0), 1023)], 1)] = (int32_t)i;
+}
 
 template <bool SPLIT>
 __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
@@ -77,7 +98,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     QPLds L;
     qp_lds_carve(L, (lptr)smem, d, NTHREADS);
     qp_lds_init(L, d, c);
-    const size_t p = blockIdx.x;
+    const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], xk[(size_t)k * n + j], v);
         b.zopt[p * (size_t)(N + 1) * nz + e] = v;
     }
-    if (tid == 0) { b.iters[p] = itr; b.status[p] = status; }
+    if (tid == 0) { b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; }
 }
 
 // ------------------------------------------------------------------ host side: constants
@@ -401,7 +422,8 @@ struct sgusto_plan {
     QPConstHost C;
     GustoPar par{};
     int64_t batch = 0;
-    srh::DevBuf fs, work, x0, u_init, x_init, z, zf, ud, xopt, uopt, zopt, iters, status, trace;
+    srh::DevBuf fs, work, x0, u_init, x_init, z, zf, ud, xopt, uopt, zopt, iters, status, trace, order, last_iters;
+    bool have_last = false;             // a previous solve left its iteration counts
     size_t work_stride = 0;
     size_t lds = 0;
     bool has_z = false, has_zf = false, has_ud = false;
@@ -511,7 +533,8 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
         (rc = pl->zf.alloc(sizeof(double) * batch * nz)) || (rc = pl->ud.alloc(sizeof(double) * batch * N * m)) ||
         (rc = pl->xopt.alloc(sizeof(double) * batch * (N + 1) * n)) || (rc = pl->uopt.alloc(sizeof(double) * batch * N * m)) ||
         (rc = pl->zopt.alloc(sizeof(double) * batch * (N + 1) * nz)) || (rc = pl->iters.alloc(sizeof(int32_t) * batch)) ||
-        (rc = pl->status.alloc(sizeof(int32_t) * batch)) ||
+        (rc = pl->status.alloc(sizeof(int32_t) * batch)) || (rc = pl->order.alloc(sizeof(int32_t) * batch)) ||
+        (rc = pl->last_iters.alloc(sizeof(int32_t) * batch)) ||
         (rc = pl->trace.alloc(sizeof(double) * batch * (size_t)std::max(1, max_trace) * 4)) ||
         (rc = d.split ? set_lds_limit((const void *)gusto_kernel<true>, pl->lds)
                       : set_lds_limit((const void *)gusto_kernel<false>, pl->lds))) {
@@ -539,7 +562,12 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
     SRH_REQUIRE(pl && x0 && u_init && x_init && xopt && uopt && zopt && iters && status,
                 "sgusto_plan_solve_dev: null argument");
     GustoBatch b{x0, u_init, x_init, z, zf, u_des, pl->fs.as<double>(), xopt, uopt, zopt, iters, status, trace,
-                 pl->work.as<double>(), pl->work_stride};
+                 pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>()};
+    if (pl->have_last && pl->batch > 256 && !getenv("SRH_GUSTO_NO_LPT")) {      // more rollouts than CUs: order matters
+        lpt_order_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pl->last_iters.as<int32_t>(), pl->batch, pl->order.as<int32_t>());
+        b.order = pl->order.as<int32_t>();
+    }
+    pl->have_last = true;
     GustoPar par = pl->par;
     if (!trace) par.max_trace = 0;
     if (pl->C.dims.split)

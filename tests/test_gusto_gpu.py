@@ -106,6 +106,30 @@ def test_gusto_batch_equals_single(golden):
         assert int(g1.iters[0]) == int(gb.iters[b])
 
 
+def test_gusto_dispatch_order_does_not_change_results(golden):
+    """More rollouts than CUs: from the second solve of a plan on, workgroups take the rollouts longest-first (by the
+    iteration counts of the previous solve, `lpt_order_kernel`).  Same inputs -> bit-identical outputs."""
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g, gm = setup(golden)
+    N, dt, B = 12, 0.05, 300
+    rng = np.random.default_rng(5)
+    x0 = 1e-3 * rng.standard_normal((B, 8)) * rng.uniform(0.1, 30.0, (B, 1))
+    u_init = np.zeros((B, N, 3))
+    x_init, _ = gm.rollout(x0, u_init, dt)
+    from scipy.interpolate import interp1d
+    zi = interp1d(g['t'], g['zt'], axis=0)
+    z = np.stack([zi(0.003 * b + dt * np.arange(N + 1)) for b in range(B)])
+    kw = dict(x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, U=Poly(g['U_A'], g['U_b']))
+    gb = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, batch=B, **kw)    # first solve: identity order
+    first = (gb.xopt.copy(), gb.uopt.copy(), gb.iters.copy(), gb.status.copy())
+    assert len(np.unique(first[2])) > 1          # the key of the sort is not constant
+    gb.solve_batch(x0, u_init, x_init, z=z)                                                # second: sorted order
+    np.testing.assert_array_equal(gb.xopt, first[0])
+    np.testing.assert_array_equal(gb.uopt, first[1])
+    np.testing.assert_array_equal(gb.iters, first[2])
+    np.testing.assert_array_equal(gb.status, first[3])
+
+
 def test_gusto_r36_split_panel_vs_oracle():
     """The fused GuSTO kernel at n_x = 72 (r = 36, the reference's shipped Diamond basis size): split-panel QP
     path inside the persistent SCP kernel, against the restated loop around the exact QP oracle."""
