@@ -44,15 +44,23 @@ __global__ __launch_bounds__(256) void gramian_kernel(const double *__restrict__
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = g_d4{0.0, 0.0, 0.0, 0.0};
 
+    // rows beyond n_s are clamped, not zeroed: they only feed rows / columns of the tile that are never stored, and
+    // the loads of a whole chunk (k0 + KC <= n_f, uniform) then carry no per-element branch
     double ri[8], rj[8];
-    auto gload = [&](int64_t k0) {
-        const int64_t kc = k0 + lc;
-        const bool vk = kc < n_f;
+    const double *pi[8], *pj[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int64_t a = gi0 + 16 * q, b2 = gj0 + 16 * q;
-            ri[q] = (vk && a < n_s) ? S[a * lds + kc] : 0.0;
-            rj[q] = (vk && b2 < n_s) ? S[b2 * lds + kc] : 0.0;
+    for (int q = 0; q < 8; ++q) {
+        pi[q] = S + min(gi0 + 16 * q, n_s - 1) * lds + lc;
+        pj[q] = S + min(gj0 + 16 * q, n_s - 1) * lds + lc;
+    }
+    auto gload = [&](int64_t k0) {
+        if (k0 + KC <= n_f) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { ri[q] = pi[q][k0]; rj[q] = pj[q][k0]; }
+        } else {
+            const bool vk = k0 + lc < n_f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { ri[q] = vk ? pi[q][k0] : 0.0; rj[q] = vk ? pj[q][k0] : 0.0; }
         }
     };
     // k-major panel: element (row, k) at [k][row]; the 16 lanes of a store group differ in k: LDT odd -> all banks
