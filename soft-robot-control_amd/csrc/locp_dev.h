@@ -31,6 +31,21 @@ struct QPDims {
     double reg;   // dual (proximal) regularisation of the Newton systems, relative to the dual scale
 };
 
+namespace qp {
+// Kernel instantiations for a fixed n_u (MSEL) and n_x (NSEL): overwrite the runtime copies with the constants (and
+// the layout values that follow from them alone, as build_consts computes them) so that everything inlined below
+// sees compile-time extents.
+template <int MSEL, int NSEL>
+__device__ __forceinline__ void specialise(QPDims &d) {
+    if constexpr (MSEL > 0) d.m = MSEL;
+    if constexpr (NSEL > 0) {
+        d.n = NSEL;
+        d.NK = (NSEL + 3) & ~3;
+        if constexpr (MSEL > 0) { d.NPa = (NSEL + MSEL + 15) & ~15; d.ld = d.NPa + 1; }
+    }
+}
+}  // namespace qp
+
 struct QPConst {                       // shared by the whole batch (HBM/L2 resident)
     cgptr H, Qz, Qzf, R;               // (nz x n), (nz x nz), (nz x nz)|null, (m x m)
     cgptr xs;                          // (n) trust-region scaling
@@ -508,8 +523,12 @@ __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &
     return true;
 }
 
-template <bool SPLIT>
+// MSEL > 0: the kernel is an instantiation for exactly n_u = MSEL (the reference's robots: 4 and 8 cables) and carries
+// only that gain routine -- the all-sizes kernel pays for the register Cholesky of every n_u <= 8 in its allocation
+// (3.5 % on the Diamond shape); MSEL = 0: any n_u.
+template <bool SPLIT, int MSEL>
 __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L, int k, bool extras) {
+    if constexpr (MSEL > 0) return stage_gain_t<MSEL, SPLIT>(d, w, L, k, extras);
     switch (d.m) {
         case 1: return stage_gain_t<1, SPLIT>(d, w, L, k, extras);
         case 2: return stage_gain_t<2, SPLIT>(d, w, L, k, extras);
@@ -641,10 +660,10 @@ __device__ __forceinline__ void panel_vec(const QPDims &d, QPLds &L, clptr a, cl
 // give Qxx, Qux and Quu in one Gram matrix; P_k = sym(M_xx) + H_k + sym(Qux^T K) with K = -Quu^-1 Qux by
 // Cholesky solves.  P, AB, W stay in LDS for the whole horizon; A_k, B_k stream from the (L2 resident)
 // TPWL tables.
-template <bool SPLIT>
+template <bool SPLIT, int MSEL>
 __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, QPWork &w, QPLds &L,
                                      bool full, bool with_dual, double *rd_out) {
-    const int n = d.n, m = d.m, N = d.N, ld = d.ld, NK = d.NK, NPa = d.NPa, n16 = (d.n + 15) & ~15;
+    const int n = d.n, m = MSEL > 0 ? MSEL : d.m, N = d.N, ld = d.ld, NK = d.NK, NPa = d.NPa, n16 = (d.n + 15) & ~15;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int xoff = d.tr ? 2 * n + 1 : 0;
@@ -732,7 +751,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             __syncthreads();
             if (with_dual && tid < m) rd = fmax(rd, fabs(L.rdu[tid]));
             SRH_LAP(3);
-            if (!stage_gain<SPLIT>(d, w, L, k, k >= 1)) return false;
+            if (!stage_gain<SPLIT, MSEL>(d, w, L, k, k >= 1)) return false;
             SRH_LAP(4);
             if (k >= 1) {
                 // P_k = A^T W + (extra rows: -Y^T Y + X^T D X); columns n, n+1 deliver A^T pv, A^T adj
@@ -870,7 +889,7 @@ __device__ __forceinline__ double max_step(const QPDims &d, const QPWork &w, QPL
 // direction (factorisation + solve), CORR the Mehrotra corrector (re-solve with the stored factors).
 // With `prescreen` the trust-region rows are dropped first (see below) and the full QP is only solved
 // when the relaxed minimiser leaves the trust region.
-template <bool SPLIT>
+template <bool SPLIT, int MSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                      QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -954,7 +973,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             stage_prepass(d, c, q, w, mode == PRED);
             SRH_LAP(2);
             double rd = 0.0;
-            const bool ok = riccati_solve<SPLIT>(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
+            const bool ok = riccati_solve<SPLIT, MSEL>(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
             if (mode == CORR) SRH_LAP(4); else SRH_LAP(3);
             // ---------------- use the direction
             if (mode == INIT) {

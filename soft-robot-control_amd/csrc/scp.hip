@@ -25,9 +25,10 @@ struct LocpBatch {
     double *dbg;
 };
 
-template <bool SPLIT>
+template <bool SPLIT, int MSEL, int NSEL>
 __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, LocpBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    qp::specialise<MSEL, NSEL>(d);             // compile-time n_u (and n_x) for everything inlined below
     QPLds L;
     qp_lds_carve(L, (lptr)smem, d, NTHREADS);
     qp_lds_init(L, d, c);
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
              (gptr)((b.dbg && p == 0) ? b.dbg : nullptr)};
     double J;
     int it;
-    const int st = qp::solve<SPLIT>(d, c, dyn, q, wbase, L, &J, &it, true, w);
+    const int st = qp::solve<SPLIT, MSEL>(d, c, dyn, q, wbase, L, &J, &it, true, w);
     for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
     for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
     for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
@@ -92,9 +93,10 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const int32_t *__restri
     for (int64_t i = tid; i < batch; i += 1024) order[atomicAdd(&cnt[1023 - min(max(key[i], 0), 1023)], 1)] = (int32_t)i;
 }
 
-template <bool SPLIT>
+template <bool SPLIT, int MSEL, int NSEL>
 __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    qp::specialise<MSEL, NSEL>(d);             // compile-time n_u (and n_x) for everything inlined below
     QPLds L;
     qp_lds_carve(L, (lptr)smem, d, NTHREADS);
     qp_lds_init(L, d, c);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                  (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
         double J;
         int qit;
-        const int st = qp::solve<SPLIT>(d, c, dyn, q, base, L, &J, &qit, true, w);
+        const int st = qp::solve<SPLIT, MSEL>(d, c, dyn, q, base, L, &J, &qit, true, w);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
         double md = 0.0;
@@ -414,6 +416,27 @@ int set_lds_limit(const void *kernel, size_t bytes) {
     return SRH_OK;
 }
 
+// Kernel variants by (split panel, n_u, n_x): instantiations for the reference's 4- and 8-cable robots, with n_x fixed
+// as well for the benchmark's r = 30 and the shipped r = 36 Diamond model; the all-sizes kernel otherwise.
+#define SRH_QP_VARIANTS(X)                                                                  \
+    X(false, 4, 60) X(false, 8, 60) X(true, 4, 72)                                          \
+    X(false, 4, 0) X(false, 8, 0) X(false, 0, 0) X(true, 4, 0) X(true, 8, 0) X(true, 0, 0)
+inline bool variant_matches(const QPDims &d, bool sp, int msel, int nsel) {
+    return (d.split != 0) == sp && (msel == 0 || d.m == msel) && (nsel == 0 || d.n == nsel);
+}
+const void *gusto_entry(const QPDims &d) {
+#define X(SP, M, NX) if (variant_matches(d, SP, M, NX)) return (const void *)gusto_kernel<SP, M, NX>;
+    SRH_QP_VARIANTS(X)
+#undef X
+    return nullptr;
+}
+const void *locp_entry(const QPDims &d) {
+#define X(SP, M, NX) if (variant_matches(d, SP, M, NX)) return (const void *)locp_kernel<SP, M, NX>;
+    SRH_QP_VARIANTS(X)
+#undef X
+    return nullptr;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ GuSTO plan (resident solver)
@@ -479,12 +502,12 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     const bool want_dbg = getenv("SRH_LOCP_TRACE") != nullptr;
     if (want_dbg) { if ((rc = dbg.alloc(sizeof(double) * 8 * 64))) return rc; (void)hipMemset(dbg.p, 0, sizeof(double) * 8 * 64); b.dbg = dbg.as<double>(); }
     const size_t lds = qp_lds_bytes(d, NTHREADS);
-    if (d.split) {
-        if ((rc = set_lds_limit((const void *)locp_kernel<true>, lds))) return rc;
-        locp_kernel<true><<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b);
-    } else {
-        if ((rc = set_lds_limit((const void *)locp_kernel<false>, lds))) return rc;
-        locp_kernel<false><<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b);
+    if ((rc = set_lds_limit(locp_entry(d), lds))) return rc;
+    {
+        bool launched = false;
+#define X(SP, M, NX) if (!launched && variant_matches(d, SP, M, NX)) { locp_kernel<SP, M, NX><<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b); launched = true; }
+        SRH_QP_VARIANTS(X)
+#undef X
     }
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipDeviceSynchronize());
@@ -536,8 +559,7 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
         (rc = pl->status.alloc(sizeof(int32_t) * batch)) || (rc = pl->order.alloc(sizeof(int32_t) * batch)) ||
         (rc = pl->last_iters.alloc(sizeof(int32_t) * batch)) ||
         (rc = pl->trace.alloc(sizeof(double) * batch * (size_t)std::max(1, max_trace) * 4)) ||
-        (rc = d.split ? set_lds_limit((const void *)gusto_kernel<true>, pl->lds)
-                      : set_lds_limit((const void *)gusto_kernel<false>, pl->lds))) {
+        (rc = set_lds_limit(gusto_entry(d), pl->lds))) {
         delete pl;
         return rc;
     }
@@ -570,10 +592,13 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
     pl->have_last = true;
     GustoPar par = pl->par;
     if (!trace) par.max_trace = 0;
-    if (pl->C.dims.split)
-        gusto_kernel<true><<<(unsigned)pl->batch, NTHREADS, pl->lds, (hipStream_t)stream>>>(pl->C.dims, pl->C.view(), pl->model->view(), par, b);
-    else
-        gusto_kernel<false><<<(unsigned)pl->batch, NTHREADS, pl->lds, (hipStream_t)stream>>>(pl->C.dims, pl->C.view(), pl->model->view(), par, b);
+    {
+        const QPDims &d = pl->C.dims;
+        bool launched = false;
+#define X(SP, M, NX) if (!launched && variant_matches(d, SP, M, NX)) { gusto_kernel<SP, M, NX><<<(unsigned)pl->batch, NTHREADS, pl->lds, (hipStream_t)stream>>>(d, pl->C.view(), pl->model->view(), par, b); launched = true; }
+        SRH_QP_VARIANTS(X)
+#undef X
+    }
     SRH_CHECK_HIP(hipGetLastError());
     return SRH_OK;
 }
