@@ -228,10 +228,12 @@ struct IlqrArgs {
 
 // MODEL 0: prediscretised nearest-neighbour TPWL tables (T); MODEL 1: SSM polynomial model (S), linearised
 // and discretised at every step of the forward pass (ilqr.py:155: model.get_jacobians(x[t], u=u[t], dt)).
-template <int MODEL>
+// NSEL / MSEL > 0: instantiation for exactly that n_x / n_u (compile-time extents: the index arithmetic and the small
+// loops of the passes fold); 0: any size.
+template <int MODEL, int NSEL, int MSEL>
 __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = a.N, n = a.n, m = a.m, nz = a.nz;
+    const int N = a.N, n = NSEL > 0 ? NSEL : a.n, m = MSEL > 0 ? MSEL : a.m, nz = a.nz;
     LqrLds L;
     lqr_carve(L, (lptr)smem, n, m, a.mfma ? 256 : 0);
     lptr QH = L.red + 20;                     // placed after the carve: Q H (nz x n); c_xx = H^T (Q H) on the fly
@@ -889,12 +891,19 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
         else if (lds + sizeof(double) * lstride <= 160 * 1024) { a.stage_ab = 1; lds += sizeof(double) * lstride; }
     }
     SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
-    if (ht) {
-        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ilqr_kernel<0><<<(unsigned)batch, NT, lds>>>(ht->view(), SsmDev{}, a);
-    } else {
-        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ilqr_kernel<1><<<(unsigned)batch, NT, lds>>>(TpwlDev{}, hs->view(), a);
+    // variants: the reference's robots at the benchmark / shipped basis sizes (TPWL), the C3 SSM shape; else all sizes
+#define SRH_ILQR_VARIANTS(X) X(0, 60, 4) X(0, 60, 8) X(0, 72, 4) X(1, 10, 8) X(0, 0, 0) X(1, 0, 0)
+    {
+        const int model = ht ? 0 : 1;
+        bool launched = false;
+#define X(MD, NX, MU)                                                                                                           \
+    if (!launched && model == MD && (NX == 0 || n == NX) && (MU == 0 || m == MU)) {                                             \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<MD, NX, MU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        ilqr_kernel<MD, NX, MU><<<(unsigned)batch, NT, lds>>>(ht ? ht->view() : TpwlDev{}, hs ? hs->view() : SsmDev{}, a);      \
+        launched = true;                                                                                                        \
+    }
+        SRH_ILQR_VARIANTS(X)
+#undef X
     }
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipDeviceSynchronize());
