@@ -215,9 +215,10 @@ __host__ __device__ inline size_t ekf_mfma_doubles(int n, int ny) {
     return 3 * (size_t)d.n16 * d.ld + (size_t)d.ny16 * d.ld + 3 * (size_t)d.ny16 * d.ldy + 4 * nv + 8;
 }
 
+template <int NSEL>      // n_x fixed at compile time (the Diamond models at r = 30 / 36), or 0: any size
 __global__ __launch_bounds__(EKF_NT) void ekf_mfma_kernel(EkfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n = a.n, m = a.m, ny = a.ny;
+    const int n = NSEL > 0 ? NSEL : a.n, m = a.m, ny = a.ny;
     const EkfMfmaDims D = ekf_mfma_dims(n, ny);
     const int n16 = D.n16, ny16 = D.ny16, ld = D.ld, ldy = D.ldy, NK = D.NK, NKy = D.NKy;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
@@ -383,7 +384,9 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
     SRH_CHECK_HIP(hipMemset(h->x.p, 0, sizeof(double) * n));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_in, sizeof(double) * (h->m + n_y) + 64, hipHostMallocDefault));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (n + 2), hipHostMallocDefault));
-    SRH_CHECK_HIP(hipFuncSetAttribute(h->mfma ? (const void *)ekf_mfma_kernel : (const void *)ekf_kernel,
+    SRH_CHECK_HIP(hipFuncSetAttribute(h->mfma ? (n == 60 ? (const void *)ekf_mfma_kernel<60> : n == 72 ? (const void *)ekf_mfma_kernel<72>
+                                                                                             : (const void *)ekf_mfma_kernel<0>)
+                                              : (const void *)ekf_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     *out = h;
     return SRH_OK;
@@ -441,8 +444,13 @@ int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, co
     if (ext && u) { a.Aext = e; a.Bext = e + (size_t)n * n; a.dext = e + (size_t)n * n + (size_t)n * m; }
     a.do_predict = u != nullptr; a.do_update = y != nullptr;
     a.status = st;
-    if (h->mfma) ekf_mfma_kernel<<<1, EKF_NT, h->lds>>>(a);
-    else ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
+    if (h->mfma) {
+        if (n == 60) ekf_mfma_kernel<60><<<1, EKF_NT, h->lds>>>(a);
+        else if (n == 72) ekf_mfma_kernel<72><<<1, EKF_NT, h->lds>>>(a);
+        else ekf_mfma_kernel<0><<<1, EKF_NT, h->lds>>>(a);
+    } else {
+        ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
+    }
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out, h->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
     SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out + n, st, sizeof(int), hipMemcpyDeviceToHost, nullptr));
