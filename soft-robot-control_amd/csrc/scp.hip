@@ -418,7 +418,13 @@ int set_lds_limit(const void *kernel, size_t bytes) {
 
 // Kernel variants by (split panel, n_u, n_x): instantiations for the reference's 4- and 8-cable robots, with n_x fixed
 // as well for the benchmark's r = 30 and the shipped r = 36 Diamond model; the all-sizes kernel otherwise.
+// Further shapes are a build-time list:  make EXTRA='-DSRH_QP_EXTRA_VARIANTS(X)=X(false,8,44)X(true,4,80)'
+// (split panel is true for 64 < n_x <= 96).
+#ifndef SRH_QP_EXTRA_VARIANTS
+#define SRH_QP_EXTRA_VARIANTS(X)
+#endif
 #define SRH_QP_VARIANTS(X)                                                                  \
+    SRH_QP_EXTRA_VARIANTS(X)                                                                \
     X(false, 4, 60) X(false, 8, 60) X(true, 4, 72)                                          \
     X(false, 4, 0) X(false, 8, 0) X(false, 0, 0) X(true, 4, 0) X(true, 8, 0) X(true, 0, 0)
 inline bool variant_matches(const QPDims &d, bool sp, int msel, int nsel) {
