@@ -40,6 +40,26 @@ __device__ __forceinline__ double wave_min(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- sums over aligned groups of G = 4 / 8 / 16 lanes by DPP moves (no LDS crossbar: ~3 VALU instructions per step
+// instead of two ds_bpermute round trips); every lane of the group receives the sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi2, lo2);
+}
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    static_assert(G == 4 || G == 8 || G == 16, "group_sum: G must be 4, 8 or 16");
+    v += dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                       // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_mov<0x141>(v);    // row_half_mirror: lane i <- lane 7 - i of its 8
+    if constexpr (G >= 16) v += dpp_mov<0x140>(v);   // row_mirror:      lane i <- lane 15 - i of its 16
+    return v;
+}
+
 // op: 0 sum, 1 max, 2 min.  Result broadcast to every thread.  Deterministic (fixed tree).
 __device__ inline double reduce(double v, int op, lptr scratch) {
     double w = op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v));

@@ -9,6 +9,7 @@
 // owns s_k, the 2n+1 trust-region rows, the X rows and (k = N) the Xf rows.
 #pragma once
 #include "dev_la.h"
+#include <type_traits>
 
 struct QPDims {
     int N, n, m, nz, nU, nX, nXf, tr;
@@ -76,6 +77,7 @@ struct QPWork {                        // per-problem scratch in HBM/L2 (doubles
     gptr Huu, gu, gud;                                    // N x m x m, N x m, N x m
     gptr K, Qinv, kff;                                    // N x m x n, N x m x m (Cholesky factors of Quu), N x m
     gptr ez;                                              // (N+1) x nz
+    gptr dump;                                            // 64: target of the stores of lanes that own no result
     gptr tprof;                                        // optional phase timers (debug) or null
 };
 
@@ -99,6 +101,7 @@ __device__ inline void qp_carve(QPWork &w, gptr base, const QPDims &d) {
     w.Huu = take(N * m * m); w.gu = take(N * m); w.gud = take(N * m);
     w.K = take(N * m * n); w.Qinv = take(N * m * m); w.kff = take(N * m);
     w.ez = take((N + 1) * d.nz);
+    w.dump = take(64);
     w.tprof = (gptr)nullptr;
 }
 
@@ -650,6 +653,165 @@ __device__ __forceinline__ void panel_vec(const QPDims &d, QPLds &L, clptr a, cl
     __syncthreads();
 }
 
+// ---- the two vector sweeps of a Newton system (see riccati_solve): ONE barrier per stage, wave-local DPP sums, and
+// a software pipeline over the stages: everything a stage reads from HBM/L2 (gain rows, gradients) is requested one
+// stage ahead.  For that to pay, every global access inside the loops is UNCONDITIONAL (clamped indices; lanes that
+// own no result store to a dump slot): loads and stores share the in-order vmcnt counter, and behind a conditional
+// access the compiler can only wait with vmcnt(0), i.e. for the write acknowledgement of the previous stage's stores.
+//
+// backward, stage k:  Qu = B^T pv + gu  by every wave itself (GA lanes per input row);  columns col = wave + nw c of
+//   pv_k = gx + A^T pv + K^T Qu  (lane (c, g) of 8 x 8: rows g, g + 8, ..; lane g < m adds K[g][col] Qu[g]);
+//   Qu is parked in kff[k] and turned into kff = -Quu^-1 Qu for all stages at once after the sweep.
+template <int MSEL, int NSEL>
+__device__ __forceinline__ void vector_sweep_back(const QPDims &d, const QPDyn &dyn, QPWork &w, QPLds &L) {
+    const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    constexpr int NP = 2;                                   // column passes of 64: n <= 128
+    lptr pv = L.pv, pn = L.v3;
+    const int c = lane >> 3, g8 = lane & 7;
+    const int gk = g8 < m ? g8 : m - 1;                     // clamped gain row of this lane
+    auto run = [&](auto ga_tag) {
+        constexpr int GA = decltype(ga_tag)::value;
+        const int a = lane / GA, g = lane % GA;
+        const bool va = a < m;
+        const int ac = va ? a : m - 1;
+        struct Regs { double gu, kk[NP], gx[NP]; };
+        auto fetch = [&](int k, Regs &r) {
+            r.gu = w.gu[(size_t)k * m + ac];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int col = wave + nw * c + 64 * q;
+                const int cc = col < n ? col : n - 1;
+                if (64 * q < n) {                            // uniform
+                    r.kk[q] = w.K[((size_t)k * m + gk) * n + cc];
+                    r.gx[q] = w.gx[(size_t)k * n + cc];
+                }
+            }
+        };
+        auto stage = [&](int k, const Regs &cur, Regs &nxt) {
+            ensure_panel(d, dyn, L, k);
+            double p = 0.0;
+            if (va)
+                for (int i = g; i < n; i += GA) p = fma(L.AB[i * ld + n + a], pv[i], p);
+            p = wg::group_sum<GA>(p) + cur.gu;
+            if (g == 0 && va) L.Qu[a] = p;                   // every wave stores the same value
+            fetch(k >= 1 ? k - 1 : 0, nxt);
+            *(va ? w.kff + (size_t)k * m + a : w.dump + lane) = p;
+            __builtin_amdgcn_wave_barrier();                  // Qu written and read by this wave: LDS is in order
+            if (k >= 1) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (64 * q < n) {                        // uniform
+                        const int col = wave + nw * c + 64 * q;
+                        double acc = 0.0;
+                        if (col < n) {
+                            for (int i = g8; i < n; i += 8) acc = fma(L.AB[i * ld + col], pv[i], acc);
+                            if (g8 < m) acc = fma(cur.kk[q], L.Qu[g8], acc);
+                            for (int a2 = g8 + 8; a2 < m; a2 += 8) acc = fma(w.K[((size_t)k * m + a2) * n + col], L.Qu[a2], acc);
+                            if (g8 == 0) acc += cur.gx[q];
+                        }
+                        acc = wg::group_sum<8>(acc);
+                        if (g8 == 0 && col < n) pn[col] = acc;
+                    }
+                }
+            }
+            __syncthreads();
+            lptr t = pv; pv = pn; pn = t;
+        };
+        Regs ra, rb;
+        fetch(N - 1, ra);
+        int k = N - 1;
+        for (; k >= 1; k -= 2) { stage(k, ra, rb); stage(k - 1, rb, ra); }
+        if (k == 0) stage(0, ra, rb);
+    };
+    if (m <= 4) run(std::integral_constant<int, 16>{});
+    else if (m <= 8) run(std::integral_constant<int, 8>{});
+    else run(std::integral_constant<int, 4>{});
+    // kff_k = -Quu_k^-1 Qu_k, one thread per stage (the factor and Qu from HBM/L2)
+    for (int k = tid; k < N; k += nt) wg::chol_solve_neg(w.Qinv + (size_t)k * m * m, m, w.kff + (size_t)k * m, 1, w.kff + (size_t)k * m, 1);
+    __syncthreads();
+}
+
+// forward, stage k:  du = K dx + kff by every wave itself into xu = [dx_k ; du_k];  rows r = wave + nw c of
+//   dx_{k+1} = [A | B] xu  (lane (c, g) of 8 x 8: columns g, g + 8, ..).  The slack steps follow after the sweep.
+template <int MSEL, int NSEL>
+__device__ __forceinline__ void vector_sweep_fwd(const QPDims &d, const QPDyn &dyn, QPWork &w, QPLds &L) {
+    const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6, nm = n + m;
+    for (int e = tid; e < n; e += nt) { L.v1[e] = 0.0; w.dx[e] = 0.0; }
+    __syncthreads();
+    lptr xu = L.v1, xn = L.v2;
+    const int c = lane >> 3, g8 = lane & 7;
+    auto run = [&](auto ga_tag) {
+        constexpr int GA = decltype(ga_tag)::value;
+        constexpr int KQ = NSEL > 0 ? (NSEL + GA - 1) / GA : 1;      // gain entries per lane (pipelined when n is fixed)
+        const int a = lane / GA, g = lane % GA;
+        const bool va = a < m;
+        const int ac = va ? a : m - 1;
+        struct Regs { double kk[KQ], kf; };
+        auto fetch = [&](int k, Regs &r) {
+            if constexpr (NSEL > 0) {
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    const int j = g + GA * q;
+                    r.kk[q] = w.K[((size_t)k * m + ac) * n + (j < n ? j : n - 1)];
+                }
+                r.kf = w.kff[(size_t)k * m + ac];
+            }
+        };
+        auto stage = [&](int k, const Regs &cur, Regs &nxt) {
+            ensure_panel(d, dyn, L, k);
+            double p = 0.0;
+            if constexpr (NSEL > 0) {
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    const int j = g + GA * q;
+                    p = fma(cur.kk[q], j < n ? xu[j] : 0.0, p);
+                }
+                p = wg::group_sum<GA>(p) + cur.kf;
+            } else {
+                for (int j = g; j < n; j += GA) p = fma(w.K[((size_t)k * m + ac) * n + j], xu[j], p);
+                p = wg::group_sum<GA>(p) + w.kff[(size_t)k * m + ac];
+            }
+            if (g == 0 && va) xu[n + a] = p;                 // every wave stores the same value
+            fetch(k + 1 < N ? k + 1 : k, nxt);
+            *(va ? w.du + (size_t)k * m + a : w.dump + lane) = p;
+            __builtin_amdgcn_wave_barrier();                  // xu[n..] written and read by this wave: LDS is in order
+            for (int r = wave + nw * c; r < ((n + 63) & ~63); r += 64) {   // uniform trip count
+                double acc = 0.0;
+                if (r < n)
+                    for (int j = g8; j < nm; j += 8) acc = fma(L.AB[r * ld + j], xu[j], acc);
+                acc = wg::group_sum<8>(acc);
+                if (g8 == 0 && r < n) xn[r] = acc;
+                *(r < n ? w.dx + (size_t)(k + 1) * n + r : w.dump + lane) = acc;
+            }
+            __syncthreads();
+            lptr t = xu; xu = xn; xn = t;
+        };
+        Regs ra, rb;
+        fetch(0, ra);
+        int k = 0;
+        for (; k + 1 < N; k += 2) { stage(k, ra, rb); stage(k + 1, rb, ra); }
+        if (k < N) stage(k, ra, rb);
+    };
+    if (m <= 4) run(std::integral_constant<int, 16>{});
+    else if (m <= 8) run(std::integral_constant<int, 8>{});
+    else run(std::integral_constant<int, 4>{});
+    // slack steps ds_k = -(gs_k + cv_k . dx_k) / Hss_k from the stored dx (one wave per stage), or zero
+    if (tid == 0) w.ds[0] = 0.0;
+    if (d.tr) {
+        for (int k = 1 + wave; k <= N; k += nw) {
+            double v = 0.0;
+            for (int j = lane; j < n; j += 64) v = fma(w.cv[(size_t)k * n + j], w.dx[(size_t)k * n + j], v);
+            v = wg::wave_sum(v);
+            if (lane == 0) w.ds[k] = -(w.gs[k] + v) / w.Hss[k];
+        }
+    } else {
+        for (int k = 1 + tid; k <= N; k += nt) w.ds[k] = 0.0;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ Riccati solve of one Newton system
 // full = factorise (stores K_k and the Cholesky factor of Quu_k) and solve; !full = re-solve with new
 // gradients only.  Returns false on a non-positive-definite Quu.  rd_out: max |reduced dual residual|.
@@ -660,7 +822,7 @@ __device__ __forceinline__ void panel_vec(const QPDims &d, QPLds &L, clptr a, cl
 // give Qxx, Qux and Quu in one Gram matrix; P_k = sym(M_xx) + H_k + sym(Qux^T K) with K = -Quu^-1 Qux by
 // Cholesky solves.  P, AB, W stay in LDS for the whole horizon; A_k, B_k stream from the (L2 resident)
 // TPWL tables.
-template <bool SPLIT, int MSEL>
+template <bool SPLIT, int MSEL, int NSEL>
 __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, QPWork &w, QPLds &L,
                                      bool full, bool with_dual, double *rd_out) {
     const int n = d.n, m = MSEL > 0 ? MSEL : d.m, N = d.N, ld = d.ld, NK = d.NK, NPa = d.NPa, n16 = (d.n + 15) & ~15;
@@ -698,10 +860,9 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
         }
         __syncthreads();
     }
-    for (int k = N - 1; k >= 0; --k) {
-        const size_t sel = (size_t)L.idxl[k];
-        cgptr Ag = dyn.A + sel * n * n, Bg = dyn.B + sel * n * m;
-        if (full) {
+    if (!full) vector_sweep_back<MSEL, NSEL>(d, dyn, w, L);   // re-solve with the stored gains / factors
+    for (int k = N - 1; k >= 0 && full; --k) {
+        {
             ensure_panel(d, dyn, L, k);
             for (int e = tid; e < m * m; e += nt) L.Quu[e] = w.Huu[(size_t)k * m * m + e];
             if (k >= 1) {
@@ -808,27 +969,6 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                 for (int e = tid; e < n; e += nt) { L.pv[e] = L.v1[e]; L.adj[e] = L.v2[e]; }
             }
             SRH_LAP(5);
-        } else {
-            // vector-only re-solve with the stored gains / factors: three barriers per stage.  The Cholesky factor
-            // of Quu_k is staged before the panel product (whose barriers publish it); every thread forms
-            // Qu = B^T pv + gu itself and takes its column of K_k straight from HBM (coalesced over j).
-            for (int e = tid; e < m * m; e += nt) L.Lc[e] = w.Qinv[(size_t)k * m * m + e];
-            ensure_panel(d, dyn, L, k);
-            panel_T_vec(d, L, L.pv, L.ypv);                      // [A^T pv ; B^T pv]
-            if (k >= 1) {
-                for (int j = tid; j < n; j += nt) {
-                    double v = w.gx[(size_t)k * n + j] + L.ypv[j];
-                    for (int a = 0; a < m; ++a)
-                        v = fma(w.K[((size_t)k * m + a) * n + j], L.ypv[n + a] + w.gu[(size_t)k * m + a], v);
-                    L.pv[j] = v;                                  // pv is not read again in this stage
-                }
-            }
-            if (tid == nt - 1) {
-                for (int a = 0; a < m; ++a) L.Qu[a] = L.ypv[n + a] + w.gu[(size_t)k * m + a];
-                wg::chol_solve_neg(L.Lc, m, L.Qu, 1, L.kf, 1);
-                for (int a = 0; a < m; ++a) w.kff[(size_t)k * m + a] = L.kf[a];
-            }
-            __syncthreads();
         }
     }
     if (with_dual) {
@@ -838,32 +978,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
         if (rd_out) *rd_out = rd;
     }
     SRH_LAP(6);
-    // ---- forward sweep: dx_0 = 0
-    for (int e = tid; e < n; e += nt) { L.v1[e] = 0.0; w.dx[e] = 0.0; }
-    if (tid == 0) w.ds[0] = 0.0;
-    __syncthreads();
-    for (int k = 0; k < N; ++k) {
-        const size_t sel = (size_t)L.idxl[k];
-        // du = K dx + kff  (one wave per output row, lanes over the state)
-        for (int a = wave; a < m; a += nw) {
-            double v = 0.0;
-            for (int j = lane; j < n; j += 64) v = fma(w.K[((size_t)k * m + a) * n + j], L.v1[j], v);
-            v = wg::wave_sum(v);
-            if (lane == 0) { v += w.kff[(size_t)k * m + a]; L.kf[a] = v; w.du[(size_t)k * m + a] = v; }
-        }
-        __syncthreads();
-        ensure_panel(d, dyn, L, k);
-        panel_vec(d, L, L.v1, L.kf, L.v2);                       // dx_{k+1} = A dx_k + B du_k
-        for (int e = tid; e < n; e += nt) { L.v1[e] = L.v2[e]; w.dx[(size_t)(k + 1) * n + e] = L.v2[e]; }
-        if (d.tr && wave == 0) {
-            double v = 0.0;
-            for (int j = lane; j < n; j += 64) v = fma(w.cv[(size_t)(k + 1) * n + j], L.v2[j], v);
-            v = wg::wave_sum(v);
-            if (lane == 0) w.ds[k + 1] = -(w.gs[k + 1] + v) / w.Hss[k + 1];
-        }
-        __syncthreads();
-    }
-    if (!d.tr) { for (int k = tid; k <= N; k += nt) w.ds[k] = 0.0; __syncthreads(); }
+    vector_sweep_fwd<MSEL, NSEL>(d, dyn, w, L);
     SRH_LAP(7);
 #ifdef SRH_PROFILE
     if (w.tprof && tid == 0) for (int i = 0; i < 8; ++i) w.tprof[i] += (double)tp[i];
@@ -889,7 +1004,7 @@ __device__ __forceinline__ double max_step(const QPDims &d, const QPWork &w, QPL
 // direction (factorisation + solve), CORR the Mehrotra corrector (re-solve with the stored factors).
 // With `prescreen` the trust-region rows are dropped first (see below) and the full QP is only solved
 // when the relaxed minimiser leaves the trust region.
-template <bool SPLIT, int MSEL>
+template <bool SPLIT, int MSEL, int NSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                      QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -973,7 +1088,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             stage_prepass(d, c, q, w, mode == PRED);
             SRH_LAP(2);
             double rd = 0.0;
-            const bool ok = riccati_solve<SPLIT, MSEL>(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
+            const bool ok = riccati_solve<SPLIT, MSEL, NSEL>(d, c, dyn, w, L, mode != CORR, mode == PRED, &rd);
             if (mode == CORR) SRH_LAP(4); else SRH_LAP(3);
             // ---------------- use the direction
             if (mode == INIT) {

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
              (gptr)((b.dbg && p == 0) ? b.dbg : nullptr)};
     double J;
     int it;
-    const int st = qp::solve<SPLIT, MSEL>(d, c, dyn, q, wbase, L, &J, &it, true, w);
+    const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, wbase, L, &J, &it, true, w);
     for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
     for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
     for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                  (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
         double J;
         int qit;
-        const int st = qp::solve<SPLIT, MSEL>(d, c, dyn, q, base, L, &J, &qit, true, w);
+        const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
         double md = 0.0;
@@ -521,6 +521,8 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
         std::vector<double> t(8 * 64);
         dbg.download(t.data(), sizeof(double) * 8 * 64);
         fprintf(stderr, "[locp] time (shader clocks): init %.0f rows %.0f prepass %.0f ricc_full %.0f ricc_vec %.0f final %.0f\n", t[8*62], t[8*62+1], t[8*62+2], t[8*62+3], t[8*62+4], t[8*62+5]);
+        fprintf(stderr, "[locp] riccati laps (SRH_PROFILE build): load %.0f W %.0f BtW %.0f Qu %.0f gain %.0f AtW+finish %.0f vec-backward %.0f forward %.0f\n",
+                t[8*63], t[8*63+1], t[8*63+2], t[8*63+3], t[8*63+4], t[8*63+5], t[8*63+6], t[8*63+7]);
         fprintf(stderr, "[locp] riccati phases (shader clocks): load %.0f gemm1 %.0f gemm2 %.0f matvec %.0f chol+K %.0f Pnew %.0f (vec/other %.0f) fwd %.0f\n", t[8*63], t[8*63+1], t[8*63+2], t[8*63+3], t[8*63+4], t[8*63+5], t[8*63+6], t[8*63+7]);
         for (int i = 0; i < 62 && (t[8 * i + 3] != 0.0); ++i)
             fprintf(stderr, "[locp] it %2d mu %.3e rd %.3e rp %.3e (sd %.2e sp %.2e) a_aff %.3e sigma %.3e a %.3e\n", i, t[8 * i], t[8 * i + 1], t[8 * i + 2], t[8 * i + 3], t[8 * i + 4], t[8 * i + 5], t[8 * i + 6], t[8 * i + 7]);
