@@ -121,6 +121,7 @@ struct QPLds {                         // LDS carve (doubles unless noted)
     lptr red;                       // 16
     liptr flag;                         // 4 ints
     liptr idxl;                         // N ints: region of every stage (copy of dyn.idx, or 0..N-1)
+    int psel;                           // region whose [A | B] is in the panel (register copy, same in every thread)
 };
 
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
@@ -155,7 +156,7 @@ __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) 
     for (int e = tid; e < (d.split ? d.NK : ((d.n + 15) & ~15)) * d.ld; e += nt) L.P[e] = 0.0;
     for (int e = tid; e < d.RW * d.ld; e += nt) L.AB[e] = 0.0;
     for (int e = tid; e < d.WR * d.ld; e += nt) L.W[e] = 0.0;
-    if (tid == 0) L.flag[2] = -1;
+    L.psel = -1;
     for (int e = tid; e < d.nzr * n; e += nt) {
         const int r = e / n, j = e - r * n;
         L.AB[(d.RC + r) * ld + j] = c.Cq[e];
@@ -595,11 +596,13 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
 // ---- the [A | B] panel of the current TPWL region stays in LDS: consecutive stages of a horizon mostly
 // share their region, so the 30 KB table read (and its L2 latency) is paid only when the region changes;
 // the vector sweeps take A v, A^T v, B u, B^T v from the panel instead of streaming the tables again.
-__device__ __forceinline__ void ensure_panel(const QPDims &d, const QPDyn &dyn, QPLds &L, int k) {
+// Returns true when the panel was (re)written: the caller places the barrier that publishes it (the factorising pass
+// has one after its own stage loads anyway; the vector sweeps only pay it on a reload).  Which region the panel holds
+// is tracked in a per-thread copy (L.psel, identical in every thread): no LDS flag, no barrier to protect it.
+__device__ __forceinline__ bool panel_load(const QPDims &d, const QPDyn &dyn, QPLds &L, int k) {
     const int n = d.n, m = d.m, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
     const int sel = L.idxl[k];
-    const bool same = dyn.idx != nullptr && L.flag[2] == sel;
-    if (same) return;                              // uniform
+    if (dyn.idx != nullptr && L.psel == sel) return false;      // uniform
     cgptr Ag = dyn.A + (size_t)sel * n * n, Bg = dyn.B + (size_t)sel * n * m;
     const int NPa = d.NPa;
     const int jj = tid % NPa, ii0 = tid / NPa, rstep = nt / NPa;
@@ -608,9 +611,8 @@ __device__ __forceinline__ void ensure_panel(const QPDims &d, const QPDyn &dyn, 
         const int stride = jj < n ? n : m;
         for (int i = ii0; i < n; i += rstep) L.AB[i * ld + jj] = src[(size_t)i * stride];
     }
-    __syncthreads();
-    if (tid == 0) L.flag[2] = sel;
-    __syncthreads();
+    L.psel = sel;
+    return true;
 }
 
 // y[j] = sum_{i<n} AB[i][j] v[i], j < n + m      ( [A^T v ; B^T v] )
@@ -689,7 +691,7 @@ __device__ __forceinline__ void vector_sweep_back(const QPDims &d, const QPDyn &
             }
         };
         auto stage = [&](int k, const Regs &cur, Regs &nxt) {
-            ensure_panel(d, dyn, L, k);
+            if (panel_load(d, dyn, L, k)) __syncthreads();
             double p = 0.0;
             if (va)
                 for (int i = g; i < n; i += GA) p = fma(L.AB[i * ld + n + a], pv[i], p);
@@ -760,7 +762,7 @@ __device__ __forceinline__ void vector_sweep_fwd(const QPDims &d, const QPDyn &d
             }
         };
         auto stage = [&](int k, const Regs &cur, Regs &nxt) {
-            ensure_panel(d, dyn, L, k);
+            const bool reloaded = panel_load(d, dyn, L, k);  // du below does not read the panel
             double p = 0.0;
             if constexpr (NSEL > 0) {
 #pragma unroll
@@ -776,7 +778,8 @@ __device__ __forceinline__ void vector_sweep_fwd(const QPDims &d, const QPDyn &d
             if (g == 0 && va) xu[n + a] = p;                 // every wave stores the same value
             fetch(k + 1 < N ? k + 1 : k, nxt);
             *(va ? w.du + (size_t)k * m + a : w.dump + lane) = p;
-            __builtin_amdgcn_wave_barrier();                  // xu[n..] written and read by this wave: LDS is in order
+            if (reloaded) __syncthreads();                    // publish the new panel (uniform)
+            else __builtin_amdgcn_wave_barrier();             // xu[n..] written and read by this wave: LDS is in order
             for (int r = wave + nw * c; r < ((n + 63) & ~63); r += 64) {   // uniform trip count
                 double acc = 0.0;
                 if (r < n)
@@ -863,7 +866,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
     if (!full) vector_sweep_back<MSEL, NSEL>(d, dyn, w, L);   // re-solve with the stored gains / factors
     for (int k = N - 1; k >= 0 && full; --k) {
         {
-            ensure_panel(d, dyn, L, k);
+            panel_load(d, dyn, L, k);                        // published by the barrier below
             for (int e = tid; e < m * m; e += nt) L.Quu[e] = w.Huu[(size_t)k * m * m + e];
             if (k >= 1) {
                 for (int e = tid; e < n; e += nt) { L.hdv[e] = w.hd[(size_t)k * n + e]; L.cvv[e] = w.cv[(size_t)k * n + e]; }
