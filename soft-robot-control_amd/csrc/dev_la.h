@@ -25,22 +25,6 @@ __device__ __forceinline__ int tid() { return threadIdx.x; }
 __device__ __forceinline__ int nthr() { return blockDim.x; }
 
 // ---- reductions over the workgroup (scratch: >= 16 doubles of LDS) ---------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 // ---- sums over aligned groups of G = 4 / 8 / 16 lanes by DPP moves (no LDS crossbar: ~3 VALU instructions per step
 // instead of two ds_bpermute round trips); every lane of the group receives the sum.
 template <int CTRL>
@@ -60,6 +44,32 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// ---- whole-wave reductions by DPP: four steps inside the rows of 16, row_bcast15 / row_bcast31 across the rows, the
+// total of lane 63 broadcast with v_readlane (fixed tree: deterministic; every lane receives the same value)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov_rows(double v, double fill) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+    const int lo2 = __builtin_amdgcn_update_dpp(flo, lo, CTRL, ROWMASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(fhi, hi, CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi2, lo2);
+}
+template <int OP>     // 0 sum, 1 max, 2 min
+__device__ __forceinline__ double wave_reduce(double v) {
+    auto f = [](double a, double b) { return OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b)); };
+    const double id = OP == 0 ? 0.0 : (OP == 1 ? -INFINITY : INFINITY);
+    v = f(v, dpp_mov<0xB1>(v));
+    v = f(v, dpp_mov<0x4E>(v));
+    v = f(v, dpp_mov<0x141>(v));
+    v = f(v, dpp_mov<0x140>(v));
+    v = f(v, dpp_mov_rows<0x142, 0xa>(v, id));       // row_bcast15 into rows 1 and 3
+    v = f(v, dpp_mov_rows<0x143, 0xc>(v, id));       // row_bcast31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<0>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<1>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<2>(v); }
 // op: 0 sum, 1 max, 2 min.  Result broadcast to every thread.  Deterministic (fixed tree).
 __device__ inline double reduce(double v, int op, lptr scratch) {
     double w = op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v));

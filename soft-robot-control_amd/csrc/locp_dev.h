@@ -153,9 +153,15 @@ __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nt
 // one-off per kernel: constants into LDS, zero the padding of the MFMA operands
 __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) {
     const int tid = threadIdx.x, nt = blockDim.x, n = d.n, ld = d.ld;
-    for (int e = tid; e < (d.split ? d.NK : ((d.n + 15) & ~15)) * d.ld; e += nt) L.P[e] = 0.0;
-    for (int e = tid; e < d.RW * d.ld; e += nt) L.AB[e] = 0.0;
-    for (int e = tid; e < d.WR * d.ld; e += nt) L.W[e] = 0.0;
+    // the whole carve starts from zeros (the MFMA operands rely on zero padding; later rounds of a launch inherit the
+    // LDS of the previous workgroup), and the BARRIER below orders the zeroing before the constant rows written next
+    // by other threads -- without it a late zeroing thread could wipe a Cq / XA entry: an inexact Hessian the
+    // interior point corrects, visible only as a run-to-run difference of 1e-10 (tools/determinism_probe.py)
+    {
+        const size_t total = qp_lds_bytes(d, nt) / sizeof(double);
+        for (size_t e = tid; e < total; e += nt) L.P[e] = 0.0;
+        __syncthreads();
+    }
     L.psel = -1;
     for (int e = tid; e < d.nzr * n; e += nt) {
         const int r = e / n, j = e - r * n;
@@ -864,14 +870,32 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
         __syncthreads();
     }
     if (!full) vector_sweep_back<MSEL, NSEL>(d, dyn, w, L);   // re-solve with the stored gains / factors
+    // What a factorising stage reads from HBM/L2 (Huu, the trust-region terms, the X-row weights, the gradients) is
+    // requested one stage ahead: one value of each kind per thread (n <= blockDim, m^2 <= blockDim), consumed at the
+    // start of the next stage, a whole stage of MFMA work later.
+    struct StageIn { double Huu, hd, cv, Dx, g1, g2; };
+    auto stage_fetch = [&](int k, StageIn &r) {
+        if (tid < m * m) r.Huu = w.Huu[(size_t)k * m * m + tid];
+        if (k >= 1) {
+            if (tid < n) { r.hd = w.hd[(size_t)k * n + tid]; r.cv = w.cv[(size_t)k * n + tid]; }
+            if (tid < d.nX) r.Dx = w.D[(size_t)(k - 1) * d.RX + xoff + tid];
+            if (tid < 2 * n) r.g1 = tid < n ? w.gx[(size_t)k * n + tid] : w.gxd[(size_t)k * n + tid - n];
+        }
+        // thread 8 o owns output o of the Qu phase (o < m: Qu, else the dual residual): its gradient entry
+        if ((tid & 7) == 0 && (tid >> 3) < 2 * m) { const int o = tid >> 3; r.g2 = o < m ? w.gu[(size_t)k * m + o] : w.gud[(size_t)k * m + o - m]; }
+    };
+    StageIn sin{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, snx{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (full) stage_fetch(N - 1, sin);
     for (int k = N - 1; k >= 0 && full; --k) {
         {
             panel_load(d, dyn, L, k);                        // published by the barrier below
-            for (int e = tid; e < m * m; e += nt) L.Quu[e] = w.Huu[(size_t)k * m * m + e];
+            if (tid < m * m) L.Quu[tid] = sin.Huu;
             if (k >= 1) {
-                for (int e = tid; e < n; e += nt) { L.hdv[e] = w.hd[(size_t)k * n + e]; L.cvv[e] = w.cv[(size_t)k * n + e]; }
-                if (tid < d.nX) L.Dx[tid] = w.D[(size_t)(k - 1) * d.RX + xoff + tid];
+                if (tid < n) { L.hdv[tid] = sin.hd; L.cvv[tid] = sin.cv; }
+                if (tid < d.nX) L.Dx[tid] = sin.Dx;
             }
+            const double gin1 = sin.g1, gin2 = sin.g2;
+            if (k >= 1) stage_fetch(k - 1, snx);
             __syncthreads();
             SRH_LAP(0);
             // split mode (n_x > 64: P, AB and W do not fit LDS together): W = P [A|B] is produced 48 rows at a
@@ -899,16 +923,16 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                 mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16, m);        // [Qux | B^T P B] = B^T W
             }
             SRH_LAP(2);
-            // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (one wave per output), Quu += B^T P B
-            for (int o = wave; o < 2 * m; o += nw) {
-                const int a = o % m;
+            // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (8 lanes per output, DPP sums), Quu += B^T P B
+            if ((tid >> 3) < 2 * m) {                         // whole groups of 8 lanes
+                const int o = tid >> 3, g8 = tid & 7, a = o < m ? o : o - m;
                 clptr vec = o < m ? L.pv : L.adj;
                 double v = 0.0;
-                for (int i = lane; i < n; i += 64) v = fma(L.AB[i * ld + n + a], vec[i], v);
-                v = wg::wave_sum(v);
-                if (lane == 0) {
-                    if (o < m) L.Qu[a] = v + w.gu[(size_t)k * m + a];
-                    else L.rdu[a] = v + w.gud[(size_t)k * m + a];
+                for (int i = g8; i < n; i += 8) v = fma(L.AB[i * ld + n + a], vec[i], v);
+                v = wg::group_sum<8>(v);
+                if (g8 == 0) {
+                    if (o < m) L.Qu[a] = v + gin2;
+                    else L.rdu[a] = v + gin2;
                 }
             }
             for (int e = tid; e < m * m; e += nt) { const int a = e / m, b = e - a * m; L.Quu[e] += L.QUX[a * ld + n + b]; }
@@ -960,17 +984,18 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                 for (int e = tid; e < 2 * n; e += nt) {
                     const int j = e % n;
                     if (e < n) {
-                        double v = w.gx[(size_t)k * n + j] + (SPLIT ? L.ypv[j] : L.P[j * ld + n]);
+                        double v = gin1 + (SPLIT ? L.ypv[j] : L.P[j * ld + n]);
                         for (int a = 0; a < m; ++a) v = fma(L.Km[a * ld + j], L.Qu[a], v);
                         L.v1[j] = v;
                     } else {
-                        L.v2[j] = w.gxd[(size_t)k * n + j] + (SPLIT ? L.yadj[j] : L.P[j * ld + n + 1]);
+                        L.v2[j] = gin1 + (SPLIT ? L.yadj[j] : L.P[j * ld + n + 1]);
                     }
                 }
                 __syncthreads();
                 for (int e = tid; e < (NK - n) * ld; e += nt) L.P[n * ld + e] = 0.0;
                 for (int e = tid; e < n; e += nt) { L.pv[e] = L.v1[e]; L.adj[e] = L.v2[e]; }
             }
+            sin = snx;
             SRH_LAP(5);
         }
     }
