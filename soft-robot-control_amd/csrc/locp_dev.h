@@ -607,8 +607,10 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
 // is tracked in a per-thread copy (L.psel, identical in every thread): no LDS flag, no barrier to protect it.
 __device__ __forceinline__ bool panel_load(const QPDims &d, const QPDyn &dyn, QPLds &L, int k) {
     const int n = d.n, m = d.m, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
-    const int sel = L.idxl[k];
-    if (dyn.idx != nullptr && L.psel == sel) return false;      // uniform
+    // both values are the same in every lane: readfirstlane moves them to scalar registers, the branch below (and the
+    // caller's barrier on it) is then a scalar branch, not exec-mask control flow
+    const int sel = __builtin_amdgcn_readfirstlane(L.idxl[k]);
+    if (dyn.idx != nullptr && __builtin_amdgcn_readfirstlane(L.psel) == sel) return false;
     cgptr Ag = dyn.A + (size_t)sel * n * n, Bg = dyn.B + (size_t)sel * n * m;
     const int NPa = d.NPa;
     const int jj = tid % NPa, ii0 = tid / NPa, rstep = nt / NPa;
@@ -768,7 +770,7 @@ __device__ __forceinline__ void vector_sweep_fwd(const QPDims &d, const QPDyn &d
             }
         };
         auto stage = [&](int k, const Regs &cur, Regs &nxt) {
-            const bool reloaded = panel_load(d, dyn, L, k);  // du below does not read the panel
+            if (panel_load(d, dyn, L, k)) __syncthreads();
             double p = 0.0;
             if constexpr (NSEL > 0) {
 #pragma unroll
@@ -784,8 +786,7 @@ __device__ __forceinline__ void vector_sweep_fwd(const QPDims &d, const QPDyn &d
             if (g == 0 && va) xu[n + a] = p;                 // every wave stores the same value
             fetch(k + 1 < N ? k + 1 : k, nxt);
             *(va ? w.du + (size_t)k * m + a : w.dump + lane) = p;
-            if (reloaded) __syncthreads();                    // publish the new panel (uniform)
-            else __builtin_amdgcn_wave_barrier();             // xu[n..] written and read by this wave: LDS is in order
+            __builtin_amdgcn_wave_barrier();                  // xu[n..] written and read by this wave: LDS is in order
             for (int r = wave + nw * c; r < ((n + 63) & ~63); r += 64) {   // uniform trip count
                 double acc = 0.0;
                 if (r < n)
