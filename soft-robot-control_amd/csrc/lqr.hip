@@ -578,16 +578,24 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
             }
             __syncthreads();
             bool restart = false;
+            int psel = -1;                                     // TPWL region whose [A | B] is in the panel
             for (int t = N - 1; t >= 0; --t) {
                 cgptr Ag, Bg;
+                bool load_panel = true;
                 if constexpr (MODEL == 0) {
-                    const size_t i = (size_t)idx[t];
-                    Ag = T.Ad + i * n * n; Bg = T.Bd + i * n * m;
+                    // consecutive steps of a trajectory mostly share their nearest TPWL point: the 30 KB panel is
+                    // rewritten only when the region changes (uniform: every thread reads the same idx[t])
+                    const int sel = idx[t];
+                    load_panel = sel != psel;
+                    psel = sel;
+                    Ag = T.Ad + (size_t)sel * n * n; Bg = T.Bd + (size_t)sel * n * m;
                 } else {
                     Ag = (cgptr)lin + (size_t)t * lstride; Bg = Ag + (size_t)n * n;
                 }
-                for (int e = tid; e < n * n; e += nt) ABm[(e / n) * ldp + e % n] = Ag[e];
-                for (int e = tid; e < n * m; e += nt) ABm[(e / m) * ldp + n + e % m] = Bg[e];
+                if (load_panel) {
+                    for (int e = tid; e < n * n; e += nt) ABm[(e / n) * ldp + e % n] = Ag[e];
+                    for (int e = tid; e < n * m; e += nt) ABm[(e / m) * ldp + n + e % m] = Bg[e];
+                }
                 for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)t * n + e];
                 __syncthreads();
                 if constexpr (MODEL == 0) {
