@@ -46,6 +46,9 @@ int srh_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int srh_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int srh_memset(void *dptr, int value, size_t bytes);
 int srh_sync(void);
+/* The host-pointer entry points keep the device blocks they release in a small cache (<= 64 blocks / 2 GiB per
+ * process) instead of paying hipMalloc / hipFree per call; this returns them to the driver. */
+int srh_release_cached(void);
 /* average duration in milliseconds of `iters` back-to-back launches are measured by the caller with
  * these (hipEvent on the given stream): */
 int srh_event_create(void **ev);

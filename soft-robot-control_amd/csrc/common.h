@@ -31,18 +31,24 @@ void set_error(const char *fmt, ...);
         }                                     \
     } while (0)
 
+// Device allocations of the host-pointer entry points come from a small cache of released blocks (runtime.hip): a call
+// like silqr_solve makes ~15 allocations, and hipMalloc / hipFree (the latter a device-wide synchronisation) cost more
+// than the kernels of a small batch.  Blocks are only handed back after the call that used them has synchronised.
+void *pool_take(size_t bytes);               // nullptr on failure (error string set)
+void pool_give(void *p, size_t bytes);
+void pool_release();                         // hipFree everything that is cached
+
 // RAII device buffer used by the host-pointer entry points
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) pool_give(p, bytes); }
     int alloc(size_t n) {
-        if (p) { (void)hipFree(p); p = nullptr; }
+        if (p) { pool_give(p, bytes); p = nullptr; }
         bytes = n;
         if (n == 0) return SRH_OK;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); return SRH_ENOMEM; }
-        return SRH_OK;
+        p = pool_take(n);
+        return p ? SRH_OK : SRH_ENOMEM;
     }
     int upload(const void *src, size_t n) {
         int rc = alloc(n);
