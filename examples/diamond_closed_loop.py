@@ -65,7 +65,7 @@ def main():
     zi = lambda t: np.array([np.interp(t, w['t'], w['z'][:, j]) for j in range(6)])
     xr = x0.copy()
     u = np.zeros(m)
-    err, t_eval = [], []
+    err, t_eval, sat = [], [], []
     for k in range(args.steps):
         t = k * dt_sim
         x_full = V @ xr + x_ref                                   # what SOFA hands to the controller
@@ -77,11 +77,16 @@ def main():
         xr = plant.update_state(xr, u, dt_sim)                    # plant step (device gather + host affine update)
         z = H @ xr
         err.append(np.linalg.norm((z - zi(t + dt_sim))[3:5]))
+        sat.append(bool(np.any(u <= 1e-6) or np.any(u >= 1500.0 - 1e-6)))
     t_eval = np.array(t_eval) * 1e3
     replans = len(c.save_controller_info()['solve_times'])
     print('steps %d (%.2f s), observer %s, %d GuSTO replans' % (args.steps, args.steps * dt_sim, 'EKF' if args.ekf else 'full state', replans))
     print('tip tracking error (x, y): rms %.3f, max %.3f   (target amplitude %.1f)' %
           (np.sqrt(np.mean(np.square(err))), np.max(err), np.abs(w['z'][:, 3:5]).max()))
+    err_a, sat_a = np.array(err), np.array(sat)
+    per_s = int(round(1.0 / dt_sim))
+    print('per second: rms error ' + ' '.join('%.2f' % np.sqrt(np.mean(err_a[i:i + per_s] ** 2)) for i in range(0, len(err_a), per_s)))
+    print('            input at a bound on ' + ' '.join('%3.0f%%' % (100 * sat_a[i:i + per_s].mean()) for i in range(0, len(sat_a), per_s)) + ' of the steps (cables only pull: U = [0, 1500]^4)')
     print('controller.evaluate per step: median %.2f ms, max %.1f ms (replan steps include the SCP solve)' %
           (np.median(t_eval), t_eval.max()))
 
