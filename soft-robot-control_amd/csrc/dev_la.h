@@ -174,9 +174,9 @@ __device__ __forceinline__ bool chol_reg(QP Q, int ldq, double shift, double (&L
             for (int k = 0; k < j; ++k) sum -= Lr[i * M + k] * Lr[j * M + k];
             if (i == j) {
                 if (!(sum > 0.0)) ok = false;
-                const double dd = sqrt(sum);
-                Lr[i * M + i] = dd;
-                inv[i] = 1.0 / dd;
+                const double ri = rsqrt(sum);              // one reciprocal square root instead of sqrt + divide
+                inv[i] = ri;
+                Lr[i * M + i] = sum * ri;
             } else {
                 Lr[i * M + j] = sum * inv[j];
             }

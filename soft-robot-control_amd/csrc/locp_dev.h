@@ -117,6 +117,7 @@ struct QPLds {                         // LDS carve (doubles unless noted)
     lptr Qu, kf, rdu;             // 16 each
     lptr XAl;                       // (nX + nXf) x ld
     lptr Dx;                        // 32      : X-row weights of the stage
+    lptr sDx;                       // 32      : their square roots (extra Gram rows)
     lptr part;                      // blockDim
     lptr red;                       // 16
     liptr flag;                         // 4 ints
@@ -127,7 +128,7 @@ struct QPLds {                         // LDS carve (doubles unless noted)
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
     const size_t nk16 = d.split ? (size_t)d.NK : (size_t)((d.n + 15) & ~15);   // whole MFMA tiles are stored (masked in split mode)
     size_t c = nk16 * d.ld + ((size_t)d.RW + d.WR) * d.ld + (size_t)d.m * d.ld + 2 * 256 + 9 * (size_t)d.ld + 3 * 16 +
-               (size_t)(d.nX + d.nXf) * d.ld + 32 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
+               (size_t)(d.nX + d.nXf) * d.ld + 64 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
     return c * sizeof(double);
 }
 
@@ -144,6 +145,7 @@ __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nt
     L.Qu = take(16); L.kf = take(16); L.rdu = take(16);
     L.XAl = take((size_t)(d.nX + d.nXf) * d.ld);
     L.Dx = take(32);
+    L.sDx = take(32);
     L.part = take(nthreads);
     L.red = take(16);
     L.flag = (liptr)take(4);
@@ -511,7 +513,7 @@ __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &
                     L.W[(wb + a) * ld + j] = y[a];
                 }
                 for (int r = 0; r < d.nX; ++r) {
-                    const double v = sqrt(L.Dx[r]) * L.XAl[r * ld + j];
+                    const double v = L.sDx[r] * L.XAl[r * ld + j];
                     L.AB[(NK + M + r) * ld + j] = v;
                     L.W[(wb + M + r) * ld + j] = v;
                 }
@@ -581,7 +583,7 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
             }
             if (extras) {
                 for (int r = 0; r < d.nX; ++r) {
-                    const double v = sqrt(L.Dx[r]) * L.XAl[r * ld + j];
+                    const double v = L.sDx[r] * L.XAl[r * ld + j];
                     L.AB[(NK + m + r) * ld + j] = v;
                     L.W[(wb + m + r) * ld + j] = v;
                 }
@@ -893,7 +895,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             if (tid < m * m) L.Quu[tid] = sin.Huu;
             if (k >= 1) {
                 if (tid < n) { L.hdv[tid] = sin.hd; L.cvv[tid] = sin.cv; }
-                if (tid < d.nX) L.Dx[tid] = sin.Dx;
+                if (tid < d.nX) { L.Dx[tid] = sin.Dx; L.sDx[tid] = sqrt(sin.Dx); }
             }
             const double gin1 = sin.g1, gin2 = sin.g2;
             if (k >= 1) stage_fetch(k - 1, snx);
