@@ -482,6 +482,22 @@ __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &
     double shift = 1e-14 * dmax;
     for (int attempt = 0; attempt < 7 && !ok; ++attempt, shift *= 100.0) ok = wg::chol_reg<M>(L.Quu, M, shift, Lr, inv);
     if (!ok) return false;          // uniform: every thread factors the same matrix
+    // the extra rows that do not depend on the gain -- sqrt(D) X and the pv / adj columns -- are written by other
+    // threads (other waves when n_x < 128) while the first n_x + 1 threads run the column solves
+    if (extras) {
+        const int o1 = nt >= 4 * 128 ? 128 : 0, o2 = nt >= 4 * 128 ? 256 : 0;
+        for (int j = tid - o1; j >= 0 && j < n; j += nt)
+            for (int r = 0; r < d.nX; ++r) {
+                const double v = L.sDx[r] * L.XAl[r * ld + j];
+                L.AB[(NK + M + r) * ld + j] = v;
+                L.W[(wb + M + r) * ld + j] = v;
+            }
+        if (!SPLIT)
+            for (int j = tid - o2; j >= 0 && j < n; j += nt) {
+                L.W[j * ld + n] = L.pv[j];
+                L.W[j * ld + n + 1] = L.adj[j];
+            }
+    }
     for (int j = tid; j <= n; j += nt) {
         clptr b = j < n ? L.QUX + j : L.Qu;
         const int bs = j < n ? ld : 1;
@@ -511,15 +527,6 @@ __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &
                 for (int a = 0; a < M; ++a) {
                     L.AB[(NK + a) * ld + j] = -y[a];
                     L.W[(wb + a) * ld + j] = y[a];
-                }
-                for (int r = 0; r < d.nX; ++r) {
-                    const double v = L.sDx[r] * L.XAl[r * ld + j];
-                    L.AB[(NK + M + r) * ld + j] = v;
-                    L.W[(wb + M + r) * ld + j] = v;
-                }
-                if (!SPLIT) {
-                    L.W[j * ld + n] = L.pv[j];
-                    L.W[j * ld + n + 1] = L.adj[j];
                 }
             }
         } else {
