@@ -651,27 +651,6 @@ __device__ __forceinline__ void panel_T_vec(const QPDims &d, QPLds &L, clptr v, 
     __syncthreads();
 }
 
-// y[i] = sum_{j<n} AB[i][j] a[j] + sum_{j<m} AB[i][n+j] b[j], i < n      ( A a + B b )
-__device__ __forceinline__ void panel_vec(const QPDims &d, QPLds &L, clptr a, clptr b, lptr y) {
-    const int n = d.n, m = d.m, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
-    const int n16 = (n + 15) & ~15;
-    const int S = nt / n16 > 0 ? nt / n16 : 1;
-    const int row = tid % n16, sl = tid / n16;
-    if (sl < S) {
-        double acc = 0.0;
-        if (row < n)
-            for (int j = sl; j < n + m; j += S) acc = fma(L.AB[row * ld + j], j < n ? a[j] : b[j - n], acc);
-        L.part[sl * n16 + row] = acc;
-    }
-    __syncthreads();
-    if (tid < n) {
-        double r = 0.0;
-        for (int q = 0; q < S; ++q) r += L.part[q * n16 + tid];
-        y[tid] = r;
-    }
-    __syncthreads();
-}
-
 // ---- the two vector sweeps of a Newton system (see riccati_solve): ONE barrier per stage, wave-local DPP sums, and
 // a software pipeline over the stages: everything a stage reads from HBM/L2 (gain rows, gradients) is requested one
 // stage ahead.  For that to pay, every global access inside the loops is UNCONDITIONAL (clamped indices; lanes that
