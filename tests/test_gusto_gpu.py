@@ -123,11 +123,12 @@ def test_gusto_dispatch_order_does_not_change_results(golden):
     gb = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, batch=B, **kw)    # first solve: identity order
     first = (gb.xopt.copy(), gb.uopt.copy(), gb.iters.copy(), gb.status.copy())
     assert len(np.unique(first[2])) > 1          # the key of the sort is not constant
-    gb.solve_batch(x0, u_init, x_init, z=z)                                                # second: sorted order
-    np.testing.assert_array_equal(gb.xopt, first[0])
-    np.testing.assert_array_equal(gb.uopt, first[1])
-    np.testing.assert_array_equal(gb.iters, first[2])
-    np.testing.assert_array_equal(gb.status, first[3])
+    for _ in range(6):       # later solves: sorted order; repeated, since what this guards against was sporadic (a race in
+        gb.solve_batch(x0, u_init, x_init, z=z)   # the LDS set-up showed as 1e-10 differences in later rounds of a launch)
+        np.testing.assert_array_equal(gb.xopt, first[0])
+        np.testing.assert_array_equal(gb.uopt, first[1])
+        np.testing.assert_array_equal(gb.iters, first[2])
+        np.testing.assert_array_equal(gb.status, first[3])
 
 
 def test_gusto_r36_split_panel_vs_oracle():
