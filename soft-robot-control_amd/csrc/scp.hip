@@ -418,7 +418,7 @@ int set_lds_limit(const void *kernel, size_t bytes) {
 
 // Kernel variants by (split panel, n_u, n_x): instantiations for the reference's 4- and 8-cable robots, with n_x fixed
 // as well for the benchmark's r = 30 and the shipped r = 36 Diamond model; the all-sizes kernel otherwise.
-// Further shapes are a build-time list:  make EXTRA='-DSRH_QP_EXTRA_VARIANTS(X)=X(false,8,44)X(true,4,80)'
+// Further shapes are a build-time list:  make EXTRA="'-DSRH_QP_EXTRA_VARIANTS(X)=X(false,8,44)X(true,4,80)'"
 // (split panel is true for 64 < n_x <= 96).
 #ifndef SRH_QP_EXTRA_VARIANTS
 #define SRH_QP_EXTRA_VARIANTS(X)
