@@ -2,7 +2,7 @@
 
 For a TPWL model (scp/models/tpwl.py adapter) the whole `solve` -- nearest-point linearisation along the
 trajectory, the LOCP QP (Riccati interior point), trust-region / model-accuracy / convergence tests
-and re-linearisation -- runs inside ONE persistent HIP kernel (csrc/scp.hip: gusto_kernel), one
+and re-linearisation -- runs inside ONE persistent HIP kernel (csrc/gusto.hip: gusto_kernel), one
 workgroup per rollout; `batch` independent rollouts (different x0 / targets, same model) can be solved
 by one launch with `GuSTO.solve_batch`.  Any other TemplateModel falls back to the reference's host
 loop around the device QP (`LOCP`), i.e. still no CPU arithmetic for the QP."""
