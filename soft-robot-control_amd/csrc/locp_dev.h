@@ -862,6 +862,9 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
     // What a factorising stage reads from HBM/L2 (Huu, the trust-region terms, the X-row weights, the gradients) is
     // requested one stage ahead: one value of each kind per thread (n <= blockDim, m^2 <= blockDim), consumed at the
     // start of the next stage, a whole stage of MFMA work later.
+    // the Qu phase needs no result of the B^T W product: with the whole W panel it runs on the upper half of the
+    // workgroup while the first waves multiply the (four or five) tiles of that product
+    const int qbase = (!SPLIT && nt >= 512) ? 256 : 0;
     struct StageIn { double Huu, hd, cv, Dx, g1, g2; };
     auto stage_fetch = [&](int k, StageIn &r) {
         if (tid < m * m) r.Huu = w.Huu[(size_t)k * m * m + tid];
@@ -870,8 +873,8 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             if (tid < d.nX) r.Dx = w.D[(size_t)(k - 1) * d.RX + xoff + tid];
             if (tid < 2 * n) r.g1 = tid < n ? w.gx[(size_t)k * n + tid] : w.gxd[(size_t)k * n + tid - n];
         }
-        // thread 8 o owns output o of the Qu phase (o < m: Qu, else the dual residual): its gradient entry
-        if ((tid & 7) == 0 && (tid >> 3) < 2 * m) { const int o = tid >> 3; r.g2 = o < m ? w.gu[(size_t)k * m + o] : w.gud[(size_t)k * m + o - m]; }
+        // thread qbase + 8 o owns output o of the Qu phase (o < m: Qu, else the dual residual): its gradient entry
+        if ((tid & 7) == 0 && tid >= qbase && ((tid - qbase) >> 3) < 2 * m) { const int o = (tid - qbase) >> 3; r.g2 = o < m ? w.gu[(size_t)k * m + o] : w.gud[(size_t)k * m + o - m]; }
     };
     StageIn sin{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, snx{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (full) stage_fetch(N - 1, sin);
@@ -884,6 +887,20 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                 if (tid < d.nX) { L.Dx[tid] = sin.Dx; L.sDx[tid] = sqrt(sin.Dx); }
             }
             const double gin1 = sin.g1, gin2 = sin.g2;
+            // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (8 lanes per output, DPP sums)
+            auto qu_phase = [&]() {
+                if (tid >= qbase && ((tid - qbase) >> 3) < 2 * m) {          // whole groups of 8 lanes
+                    const int o = (tid - qbase) >> 3, g8 = tid & 7, a = o < m ? o : o - m;
+                    clptr vec = o < m ? L.pv : L.adj;
+                    double v = 0.0;
+                    for (int i = g8; i < n; i += 8) v = fma(L.AB[i * ld + n + a], vec[i], v);
+                    v = wg::group_sum<8>(v);
+                    if (g8 == 0) {
+                        if (o < m) L.Qu[a] = v + gin2;
+                        else L.rdu[a] = v + gin2;
+                    }
+                }
+            };
             if (k >= 1) stage_fetch(k - 1, snx);
             __syncthreads();
             SRH_LAP(0);
@@ -909,21 +926,12 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
             } else {
                 mfma_atb(L.W, ld, L.P, L.AB, NK, n16 >> 4, NPa >> 4, ld, n);          // W = P [A|B]
                 SRH_LAP(1);
+                if (qbase) qu_phase();                                                 // upper waves, beside the product below
                 mfma_atb(L.QUX, ld, L.AB + n, L.W, NK, 1, NPa >> 4, ld, 16, m);        // [Qux | B^T P B] = B^T W
             }
             SRH_LAP(2);
-            // Qu = gu + B^T pv, dual residual wrt u_k = gud + B^T adj (8 lanes per output, DPP sums), Quu += B^T P B
-            if ((tid >> 3) < 2 * m) {                         // whole groups of 8 lanes
-                const int o = tid >> 3, g8 = tid & 7, a = o < m ? o : o - m;
-                clptr vec = o < m ? L.pv : L.adj;
-                double v = 0.0;
-                for (int i = g8; i < n; i += 8) v = fma(L.AB[i * ld + n + a], vec[i], v);
-                v = wg::group_sum<8>(v);
-                if (g8 == 0) {
-                    if (o < m) L.Qu[a] = v + gin2;
-                    else L.rdu[a] = v + gin2;
-                }
-            }
+            if (qbase == 0) qu_phase();
+            // Quu += B^T P B
             for (int e = tid; e < m * m; e += nt) { const int a = e / m, b = e - a * m; L.Quu[e] += L.QUX[a * ld + n + b]; }
             __syncthreads();
             if (with_dual && tid < m) rd = fmax(rd, fabs(L.rdu[tid]));
