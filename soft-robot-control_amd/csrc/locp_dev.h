@@ -880,7 +880,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
     if (full) stage_fetch(N - 1, sin);
     for (int k = N - 1; k >= 0 && full; --k) {
         {
-            panel_load(d, dyn, L, k);                        // published by the barrier below
+            const bool reloaded = panel_load(d, dyn, L, k);  // published by the barrier below
             if (tid < m * m) L.Quu[tid] = sin.Huu;
             if (k >= 1) {
                 if (tid < n) { L.hdv[tid] = sin.hd; L.cvv[tid] = sin.cv; }
@@ -902,7 +902,10 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                 }
             };
             if (k >= 1) stage_fetch(k - 1, snx);
-            __syncthreads();
+            // what was just written (Quu, hd, cv, D) is first read behind the barrier that ends the W product; the
+            // product itself reads P (complete since the barrier of the previous stage's tail) and the panel: a barrier
+            // is needed here only for a new panel, for K-padding rows of P, and in split mode
+            if (SPLIT || reloaded || NK > n) __syncthreads();
             SRH_LAP(0);
             // split mode (n_x > 64: P, AB and W do not fit LDS together): W = P [A|B] is produced 48 rows at a
             // time; the Gram products that contract over the rows of W accumulate in MFMA registers across the
