@@ -980,20 +980,26 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                         L.P[j * ld + i] = v;
                     }
                 }
-                // pv_new = gx + A^T pv + K^T Qu ; adj_new = gxd + A^T adj
+                // pv_new = gx + A^T pv + K^T Qu ; adj_new = gxd + A^T adj.  When P needed no finishing and has no K-padding
+                // rows, nothing of this stage reads pv / adj any more and the next reader (the Qu phase) sits behind
+                // the barrier of the next W product: they are written in place and the stage ends without a barrier.
+                const bool direct = !SPLIT && !(d.tr || d.nzr == 0) && NK == n;        // uniform
+                lptr pvo = direct ? L.pv : L.v1, ado = direct ? L.adj : L.v2;
                 for (int e = tid; e < 2 * n; e += nt) {
                     const int j = e % n;
                     if (e < n) {
                         double v = gin1 + (SPLIT ? L.ypv[j] : L.P[j * ld + n]);
                         for (int a = 0; a < m; ++a) v = fma(L.Km[a * ld + j], L.Qu[a], v);
-                        L.v1[j] = v;
+                        pvo[j] = v;
                     } else {
-                        L.v2[j] = gin1 + (SPLIT ? L.yadj[j] : L.P[j * ld + n + 1]);
+                        ado[j] = gin1 + (SPLIT ? L.yadj[j] : L.P[j * ld + n + 1]);
                     }
                 }
-                __syncthreads();
-                for (int e = tid; e < (NK - n) * ld; e += nt) L.P[n * ld + e] = 0.0;
-                for (int e = tid; e < n; e += nt) { L.pv[e] = L.v1[e]; L.adj[e] = L.v2[e]; }
+                if (!direct) {
+                    __syncthreads();
+                    for (int e = tid; e < (NK - n) * ld; e += nt) L.P[n * ld + e] = 0.0;
+                    for (int e = tid; e < n; e += nt) { L.pv[e] = L.v1[e]; L.adj[e] = L.v2[e]; }
+                }
             }
             sin = snx;
             SRH_LAP(5);
