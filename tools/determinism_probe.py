@@ -25,3 +25,27 @@ for rep in range(12):
     d = np.abs(gb.xopt - first[0]).reshape(B, -1).max(1)
     bad.append((int((d > 0).sum()), np.nonzero(d > 0)[0][:4].tolist(), float(d.max()), int((gb.iters != first[1]).sum())))
 print(bad)
+
+if len(sys.argv) > 1 and sys.argv[1] == 'c2':
+    # the same check at the benchmark shape (specialised kernel, two rounds of workgroups)
+    sys.path.insert(0, '.')
+    import workloads as wl, bench
+    w = wl.diamond_c2(); N2, m2, r2, dt2 = w['N'], w['m'], w['r'], w['dt']
+    tp2, gm2 = bench.build_model(w); xc, fc = gm2.get_characteristic_vals()
+    zi2 = interp1d(w['t'], w['z'], axis=0, bounds_error=False, fill_value=(w['z'][0], w['z'][-1]))
+    R = 600
+    x02 = np.concatenate((np.zeros((R, r2)), np.random.default_rng(3).standard_normal((R, r2)) * 2.0), axis=1)
+    u02 = np.zeros((R, N2, m2)); xi2, _ = tp2.rollout(x02, u02, dt2)
+    z2 = np.stack([zi2(b * 10.0 / R + dt2 * np.arange(N2 + 1)) for b in range(R)])
+    from sofacontrol_amd.utils import Polyhedron
+    g2 = GuSTO(gm2, N2, dt2, w['Qz'], w['R'], x02, u02, xi2, z=z2, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+               x_char=xc, f_char=fc, convg_thresh=1e-3, batch=R, max_trace=0, max_gusto_iters=5)
+    g2.max_gusto_iters = 5
+    g2.solve_batch(x02, u02, xi2, z=z2)
+    ref = (g2.xopt.copy(), g2.iters.copy())
+    out = []
+    for rep in range(4):
+        g2.solve_batch(x02, u02, xi2, z=z2)
+        d = np.abs(g2.xopt - ref[0]).reshape(R, -1).max(1)
+        out.append((int((d > 0).sum()), float(d.max()), int((g2.iters != ref[1]).sum())))
+    print('c2 shape:', out)
