@@ -52,33 +52,17 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
     model = dict(w['tab'], w_q=1.0, w_v=0.0)
     N, m = w['N'], w['m']
 
-    def qp_solver(qp):
-        # stage-structured port of the kernel's algorithm (faster than the generic sparse oracle)
-        p = qp._stage_problem
-        x, u, s, J, info = ripm.solve(p)
-        return np.concatenate((x.ravel(), u.ravel(), s))
-    # oracle.gusto builds the stacked QP; hand the stage form to the port through a thin adaptor
-    orig_build = olocp.build_qp
-
-    def build_and_keep(Nn, H, Qz, R, Ad, Bd, dd, x0_, xk, delta, omega, **kw):
-        qp = orig_build(Nn, H, Qz, R, Ad, Bd, dd, x0_, xk, delta, omega, **kw)
-        qp._stage_problem = ripm.Problem(Nn, H, Qz, R, Ad, Bd, dd, x0_, xk, delta, omega, z=kw.get('z'),
-                                         u_des=kw.get('u_des'), Qzf=kw.get('Qzf'), zf=kw.get('zf'), U=kw.get('U'),
-                                         X=kw.get('X'), Xf=kw.get('Xf'), x_scale=kw.get('x_scale'))
-        return qp
-    olocp.build_qp = build_and_keep
-    try:
-        t0 = time.perf_counter()
-        iters = 0
-        for b in range(n_roll):
-            _, _, _, tr = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[b],
-                                       np.zeros((N, m)), x_init[b], z=z[b], U=(w['UA'], w['Ub']),
-                                       X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3,
-                                       qp_solver=qp_solver, max_gusto_iters=max_iters)
-            iters += len(tr)
-        t_scp = time.perf_counter() - t0
-    finally:
-        olocp.build_qp = orig_build
+    t0 = time.perf_counter()
+    iters = 0
+    sols = []
+    for b in range(n_roll):
+        xe, ue, _, tr = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[b],
+                                     np.zeros((N, m)), x_init[b], z=z[b], U=(w['UA'], w['Ub']),
+                                     X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3,
+                                     qp_solver='riccati_ipm', max_gusto_iters=max_iters)
+        iters += len(tr)
+        sols.append((xe, ue, len(tr)))
+    t_scp = time.perf_counter() - t0
     X = wl.snapshots(w['q_ref'], proj_rows, seed=2)
     t0 = time.perf_counter()
     reps = 5
@@ -103,7 +87,7 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
                 sample='%d rollout(s) of the same workload = %d SCP iterations in %.1f s (numpy port of the kernel '
                        'algorithm inside the restated GuSTO loop); POD projection of %d snapshots: %.1f GB/s' %
                        (n_roll, iters, t_scp, proj_rows, proj_gbs),
-                pod_projection_gbs=proj_gbs)
+                pod_projection_gbs=proj_gbs), sols
 
 
 def closed_loop_latency(w, rom, tp):
@@ -422,6 +406,9 @@ def main():
     elapsed = time.perf_counter() - t0
     iters = o['iters'].to_array((R_,), dtype=np.int32)
     status = o['status'].to_array((R_,), dtype=np.int32)
+    n_par = min(R_, 24)          # the rollouts the CPU port solves as well: GPU trajectories kept for `parity_sample`
+    gx = o['xopt'].to_array((R_, N + 1, n))[:n_par].copy()
+    gu = o['uopt'].to_array((R_, N, m))[:n_par].copy()
     it_per_step = int(iters.sum())
     total_iters = it_per_step * args.steps
     if dist is not None:
@@ -476,8 +463,15 @@ def main():
                      'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': alg_bytes},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=min(R_, 24), proj_rows=4096,
-                                           max_iters=args.max_gusto_iters)
+        out['cpu_baseline'], sols = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=n_par, proj_rows=4096,
+                                                 max_iters=args.max_gusto_iters)
+        rel = lambda a, b: float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+        out['parity_sample'] = {
+            'what': 'the timed GPU launch vs the CPU port (oracle.gusto around oracle.riccati_ipm) on the first %d rollouts of '
+                    'the same inputs' % n_par,
+            'kernel_variant': list(gusto.variant),
+            'max_rel_traj': max(max(rel(gx[b], sols[b][0]), rel(gu[b], sols[b][1])) for b in range(n_par)),
+            'iters_equal': bool(all(int(iters[b]) == sols[b][2] for b in range(n_par))), 'tolerance': 1e-4}
     if sec is not None:
         out['secondary'] = sec
     print(json.dumps(out))

@@ -306,6 +306,10 @@ int sgusto_plan_create(sgusto_plan_t **plan, stpwl_t *h, const slocp_problem *pr
                        double dt, int64_t batch, const double *x_char, const double *f_char, int max_trace);
 int sgusto_plan_destroy(sgusto_plan_t *plan);
 int sgusto_plan_set_max_iters(sgusto_plan_t *plan, int max_gusto_iters);   /* gusto.py:142-147 */
+/* Which kernel instantiation a solve of this plan launches: split (1: split W panel, n_x > 64), n_u_fixed / n_x_fixed
+ * = the compile-time n_u / n_x of the instantiation (0: that extent is a run-time value; 0, 0 = the all-sizes
+ * kernel).  For tests and bench records: parity is claimed per instantiation. */
+int sgusto_plan_variant(const sgusto_plan_t *plan, int *split, int *n_u_fixed, int *n_x_fixed);
 int sgusto_plan_solve(sgusto_plan_t *plan, const double *x0, const double *u_init, const double *x_init,
                       const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
                       double *zopt, int32_t *iters, int32_t *status, double *trace);

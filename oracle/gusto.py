@@ -88,6 +88,7 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
     n = x0.shape[0]
     xs = 1. / np.abs(x_char) if x_char is not None else np.ones(n)
     fs = 1. / np.abs(f_char) if f_char is not None else np.ones(n)
+    stage_qp = isinstance(qp_solver, str) and qp_solver == 'riccati_ipm'
     if qp_solver is None:
         def qp_solver(qp):
             w, _, _ = olocp.solve_exact(qp)
@@ -102,11 +103,20 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
     itr = 0
     trace = []
     while itr <= par['max_gusto_iters'] and not converged and omega <= par['omega_max']:
-        qp = olocp.build_qp(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des,
-                            Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU, x_scale=xs, Hd=H_k, cd=c_k)
-        w = qp_solver(qp)
-        J = olocp.objective(qp, w)
-        x_next, u_next, _ = olocp.split(qp, w)
+        if stage_qp:
+            # the stage-structured interior point (numpy statement of the kernel's algorithm) on the same QP data;
+            # seconds instead of minutes at the BASELINE shapes.  Checked against solve_exact in tests/test_locp_oracle.py
+            from . import riccati_ipm as ripm
+            assert dU is None and obs_lin is None
+            sp = ripm.Problem(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des, Qzf=Qzf, zf=zf,
+                              U=U, X=X, Xf=Xf, x_scale=xs)
+            x_next, u_next, _, J, _ = ripm.solve(sp)
+        else:
+            qp = olocp.build_qp(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des,
+                                Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU, x_scale=xs, Hd=H_k, cd=c_k)
+            w = qp_solver(qp)
+            J = olocp.objective(qp, w)
+            x_next, u_next, _ = olocp.split(qp, w)
         new_solution = False
         rho_k = -1.0
         e_tr, tr_ok = is_in_trust_region(x_next, xk, xs, delta, par['epsilon'])

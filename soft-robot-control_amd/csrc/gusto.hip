@@ -278,6 +278,16 @@ int sgusto_plan_set_max_iters(sgusto_plan_t *pl, int max_gusto_iters) {
     return SRH_OK;
 }
 
+int sgusto_plan_variant(const sgusto_plan_t *pl, int *split, int *n_u_fixed, int *n_x_fixed) {
+    SRH_REQUIRE(pl, "sgusto_plan_variant: null plan");
+    const QPDims &d = pl->C.dims;
+#define X(SP, M, NX) if (variant_matches(d, SP, M, NX)) { if (split) *split = SP ? 1 : 0; if (n_u_fixed) *n_u_fixed = M; if (n_x_fixed) *n_x_fixed = NX; return SRH_OK; }
+    SRH_QP_VARIANTS(X)
+#undef X
+    SRH_REQUIRE(false, "sgusto_plan_variant: no kernel variant matches");
+    return SRH_OK;
+}
+
 int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_init, const double *x_init,
                           const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
                           double *zopt, int32_t *iters, int32_t *status, double *trace, void *stream) {

@@ -109,6 +109,16 @@ class GuSTO:
     def plan(self):
         return self._plan
 
+    @property
+    def variant(self):
+        """(split panel, compile-time n_u, compile-time n_x) of the kernel instantiation this plan launches; zeros mean
+        run-time extents ((False, 0, 0) = the all-sizes kernel).  None for the host-loop models."""
+        if not self._fused:
+            return None
+        sp, mu, nx = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().sgusto_plan_variant(self._plan, C.byref(sp), C.byref(mu), C.byref(nx)), 'sgusto_plan_variant')
+        return bool(sp.value), mu.value, nx.value
+
     # ---- helper tests with the reference's names (host arrays; used by the generic loop / by users)
     def is_converged(self, x, u):
         dx = (1. / self.n_x) * np.sum(np.linalg.norm(np.multiply(self.x_scale, x - self.x_k), axis=1))

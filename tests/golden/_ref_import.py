@@ -66,11 +66,10 @@ def install():
     jax.numpy = _mod('jax.numpy', dot=np.dot, asarray=np.asarray, eye=np.eye, linalg=np.linalg, ndarray=np.ndarray,
                      array=np.array, zeros=np.zeros)
     jax.scipy = _mod('jax.scipy', special=scipy.special)
-    cp = _mod('cvxpy')
-    _mod('cvxpy.atoms')
-    _mod('cvxpy.atoms.affine')
-    _mod('cvxpy.atoms.affine.wraps', psd_wrap=lambda x: x)
-    _mod('cvxpy.atoms.affine.reshape', reshape=lambda x, s: x)
+    # cvxpy: an evaluating stand-in (expressions compute their numpy value), enough to EXECUTE scp/locp.py's objective
+    # and constraint code at given points -- see _cvxpy_eval.py
+    import _cvxpy_eval
+    _cvxpy_eval.install(sys.modules)
     try:
         import matplotlib  # noqa: F401
     except Exception:

@@ -48,3 +48,86 @@ CASES = {
     'terminal_cost': dict(seed=35, use_X=False, terminal=True),
     'warm_centre': dict(seed=36, xk_input=60.0, delta=0.05, omega=10.0),
 }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# g14: the QP *statement* pinned to the reference's own locp.py (objective 218-263, constraints 265-342), evaluated
+# through the cvxpy stand-in of tests/golden/_cvxpy_eval.py.  The inputs below are regenerated from seeds by the
+# golden generator (reference side) and by tests/test_oracle_golden.py (oracle side); only outputs are stored.
+G14_CASES = dict(CASES)
+G14_CASES.update({
+    # n_x == n_z (r = 3): the only shape for which locp.py:252 (`x[N*n_z:]`) and 330 (`x[n_z:]`) type-check
+    'qzf_r3': dict(r=3, m=2, P=5, N=9, seed=40, use_X=True, terminal=True),
+    'xf_r3': dict(r=3, m=2, P=5, N=9, seed=41, use_X=False, extra=('Xf',)),
+    'dU': dict(seed=42, use_X=False, extra=('dU',)),
+    'dU_X_Xf': dict(seed=43, extra=('dU', 'Xf')),
+    'u_des': dict(seed=44, extra=('u_des',)),
+    'nlobs_r3': dict(r=3, m=2, P=5, N=9, seed=45, use_X=True, extra=('nlobs',)),
+    'nlobs_free_r3': dict(r=3, m=2, P=5, N=9, seed=46, use_X=False, use_U=False, extra=('nlobs',)),
+    'mpc_no_tr': dict(seed=47, extra=('no_tr',)),
+    'mpc_no_tr_qzf_r3': dict(r=3, m=2, P=5, N=9, seed=48, terminal=True, extra=('no_tr', 'u_des')),
+})
+
+
+def g14_case(name):
+    """Keyword arguments of oracle.locp.build_qp for a g14 case (all variants of locp.py's optional pieces)."""
+    spec = dict(G14_CASES[name])
+    extra = spec.pop('extra', ())
+    case, info = make_case(**spec)
+    n, m = case['Bd'][0].shape
+    N = case['N']
+    rng = np.random.default_rng(900 + spec.get('seed', 30))
+    if 'Xf' in extra:
+        A = rng.standard_normal((3, n))
+        case['Xf'] = (A, np.abs(A @ case['xk'][-1]) + 0.05)
+    if 'dU' in extra:
+        case['dU'] = (np.kron(np.eye(m), np.array([[1.], [-1.]])), np.full(2 * m, 20.0))
+    if 'u_des' in extra:
+        case['u_des'] = rng.uniform(0, 50, (N, m))
+    if 'nlobs' in extra:
+        case['Hd'] = case['H'][None] + 0.1 * rng.standard_normal((N + 1,) + case['H'].shape)
+        case['cd'] = 0.01 * rng.standard_normal((N + 1, case['H'].shape[0]))
+    if 'no_tr' in extra:
+        case['tr_active'] = False
+    return case
+
+
+def g14_points(name, case, count=10):
+    """Seeded evaluation points (x, u, s): random, around the trust-region centre, with nonnegative slacks."""
+    N = case['N']
+    n, m = case['Bd'][0].shape
+    rng = np.random.default_rng(7000 + sum(map(ord, name)))
+    pts = []
+    for i in range(count):
+        sc = 10.0 ** rng.uniform(-3, 1)
+        x = case['xk'] + sc * rng.standard_normal((N + 1, n)) / case['x_scale']
+        u = rng.uniform(-100, 900, (N, m))
+        s = np.abs(rng.standard_normal(N + 1)) * sc
+        pts.append((x, u, s))
+    return pts
+
+
+def g14_oracle_values(case, w):
+    """The oracle's statement of the same quantities, in the reference's constraint order (locp.py:265-342):
+    J; dynamics (287); per-stage trust-region norm residual (295) and slack positivity (297); U (303); dU (308);
+    X (333 / 329); Xf (337); x_0 = x0 (340)."""
+    from oracle import locp as olocp
+    kw = dict(case)
+    qp = olocp.build_qp(kw.pop('N'), kw.pop('H'), kw.pop('Qz'), kw.pop('R'), kw.pop('Ad'), kw.pop('Bd'), kw.pop('dd'),
+                        kw.pop('x0'), kw.pop('xk'), kw.pop('delta'), kw.pop('omega'), **kw)
+    N, n = qp.N, qp.n
+    J = olocp.objective(qp, w)
+    eq = qp.E @ w - qp.e
+    g = qp.G @ w - qp.h
+    parts = [eq[:N * n]]
+    off = 0
+    if qp.ns:
+        tr = g[:(N + 1) * (2 * n + 1)].reshape(N + 1, 2 * n + 1)
+        parts += [tr[:, :2 * n].max(axis=1), tr[:, 2 * n]]
+        off = (N + 1) * (2 * n + 1)
+    parts += [g[off:], eq[N * n:]]
+    return J, np.concatenate(parts), qp
+
+
+def g14_pack(case, x, u, s):
+    return np.concatenate((x.ravel(), u.ravel(), s)) if case.get('tr_active', True) else np.concatenate((x.ravel(), u.ravel()))
