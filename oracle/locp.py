@@ -1,10 +1,13 @@
 """Oracle: the LOCP horizon QP (test infrastructure only).
 
-**parity unpinned** against the reference's solver: sofacontrol/scp/locp.py hands the problem to
-cvxpy (`cp.Problem(...).solve(solver=OSQP|GUROBI)`, locp.py:181,216) -- third-party, not vendored,
-versions not pinned (requirements.txt:1-5), not installable here.  What IS restated exactly is the
-problem data (locp.py:218-342): `build_qp` assembles the same stacked QP over
-w = [x_0..x_N ; u_0..u_{N-1} ; s_0..s_N] that cvxpy canonicalises.  The QP has a unique (x, u)
+Parity status.  The QP *statement* is PINNED to the reference: `build_qp` assembles the stacked QP over
+w = [x_0..x_N ; u_0..u_{N-1} ; s_0..s_N] of sofacontrol/scp/locp.py:218-342 and
+tests/test_oracle_golden.py::test_locp_statement_matches_reference_locp_py holds its objective value and every
+constraint residual to the outputs of the reference's OWN locp.py, executed in the build container through an
+evaluating cvxpy stand-in (tests/golden/_cvxpy_eval.py -> fixture g14_locp.npz: 17 cases covering trust region
+on/off, U, X, Xf, dU, u_des, Qzf/zf, nonlinear observer; ten seeded points + the optimum each, 1e-12).
+The *solver* the reference hands that QP to (cvxpy -> OSQP | GUROBI, locp.py:181,216) is third-party, not
+vendored, versions not pinned (requirements.txt:1-5) and not installable here; but the QP has a unique (x, u)
 solution (R > 0 and x is an affine function of u), so any correct solver pins the answer:
 
 * `solve_exact`   -- primal-dual interior point on the full sparse KKT system (scipy.sparse

@@ -26,46 +26,42 @@ def _val(a):
 
 
 class Expr:
+    """Operator surface shared by computed nodes (`Node`) and leaves (`Variable`, `Parameter`).  The two are SIBLING
+    classes on purpose: if one were a subclass of the other, python would try the reflected comparison of the
+    right-hand operand first and `a == b` would come out as Constraint(b, a)."""
     __array_ufunc__ = None          # numpy defers `ndarray (op) Expr` to the reflected operators below
-
-    def __init__(self, fn, *kids):
-        self._fn, self._kids = fn, kids
-
-    @property
-    def value(self):
-        return self._fn(*[_val(k) for k in self._kids])
 
     @property
     def T(self):
-        return Expr(lambda a: a.T, self)
+        return Node(lambda a: a.T, self)
 
     def __getitem__(self, key):
-        return Expr(lambda a: a[key], self)
+        return Node(lambda a: a[key], self)
 
     def __neg__(self):
-        return Expr(lambda a: -a, self)
+        return Node(lambda a: -a, self)
 
     def __add__(self, o):
-        return Expr(lambda a, b: a + b, self, o)
+        return Node(lambda a, b: a + b, self, o)
 
     __radd__ = __add__
 
     def __sub__(self, o):
-        return Expr(lambda a, b: a - b, self, o)
+        return Node(lambda a, b: a - b, self, o)
 
     def __rsub__(self, o):
-        return Expr(lambda a, b: b - a, self, o)
+        return Node(lambda a, b: b - a, self, o)
 
     def __mul__(self, o):
-        return Expr(lambda a, b: a * b, self, o)
+        return Node(lambda a, b: a * b, self, o)
 
     __rmul__ = __mul__
 
     def __matmul__(self, o):
-        return Expr(lambda a, b: a @ b, self, o)
+        return Node(lambda a, b: a @ b, self, o)
 
     def __rmatmul__(self, o):
-        return Expr(lambda a, b: b @ a, self, o)
+        return Node(lambda a, b: b @ a, self, o)
 
     def __le__(self, o):
         return Constraint('<=', self, o)
@@ -77,6 +73,15 @@ class Expr:
         return Constraint('==', self, o)
 
     __hash__ = object.__hash__
+
+
+class Node(Expr):
+    def __init__(self, fn, *kids):
+        self._fn, self._kids = fn, kids
+
+    @property
+    def value(self):
+        return self._fn(*[_val(k) for k in self._kids])
 
 
 class Leaf(Expr):
@@ -124,31 +129,31 @@ class Constraint:
 
 def quad_form(x, P):
     Pd = _val(P)
-    return Expr(lambda a: float(a @ Pd @ a), x)
+    return Node(lambda a: float(a @ Pd @ a), x)
 
 
 def sum(x):            # noqa: A001  (cvxpy's name)
-    return Expr(lambda a: float(np.sum(a)), x)
+    return Node(lambda a: float(np.sum(a)), x)
 
 
 def norm(x, p=2, axis=None):
     if p == 'inf':
-        return Expr(lambda a: np.max(np.abs(a), axis=axis), x)
+        return Node(lambda a: np.max(np.abs(a), axis=axis), x)
     if p == 2 and axis is None:
         return norm2(x)
     raise NotImplementedError('norm(%r, axis=%r)' % (p, axis))
 
 
 def norm2(x):
-    return Expr(lambda a: float(np.linalg.norm(a)), x)
+    return Node(lambda a: float(np.linalg.norm(a)), x)
 
 
 def reshape(x, shape, order='F'):
-    return Expr(lambda a: np.reshape(a, shape, order=order), x)
+    return Node(lambda a: np.reshape(a, shape, order=order), x)
 
 
 def multiply(a, b):
-    return Expr(lambda u, v: u * v, a, b)
+    return Node(lambda u, v: u * v, a, b)
 
 
 def bmat(blocks):
@@ -158,7 +163,7 @@ def bmat(blocks):
     def build(*vals):
         rows = [list(vals[i * ncol:(i + 1) * ncol]) for i in range(len(blocks))]
         return np.block(rows)
-    return Expr(build, *flat)
+    return Node(build, *flat)
 
 
 class Minimize:

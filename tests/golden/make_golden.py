@@ -328,11 +328,6 @@ def g6_gusto(out):
     np.savez_compressed(os.path.join(out, 'g6_gusto.npz'), **res)
 
 
-if __name__ == '__main__':
-    g1_pod(HERE)
-    g3_tpwl(HERE)
-    g4_riccati(HERE)
-    g6_gusto(HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))
@@ -643,11 +638,74 @@ def g8_controllers(out):
     np.savez_compressed(os.path.join(out, 'g8_controllers.npz'), **res)
 
 
+def ref_locp_values(case, pts, warm_start):
+    """Instantiate the REFERENCE `LOCP` (sofacontrol/scp/locp.py, executed through the evaluating cvxpy stand-in),
+    `update` it with the case data and evaluate its own objective (locp.py:218-263) and every constraint's residual
+    (locp.py:265-342, in the order the reference appends them) at the points.  Returns J (len(pts),) and the
+    residuals (len(pts) x rows)."""
+    from sofacontrol.scp import locp as rlocp
+    poly = lambda t: None if t is None else rutils.Polyhedron(A=np.asarray(t[0]), b=np.asarray(t[1]))
+    tr = case.get('tr_active', True)
+    nl = 'Hd' in case
+    kw = {}
+    if not tr:
+        kw['is_tr_active'] = False
+    if nl:
+        kw['nonlinear_observer'] = True
+    (lo, _) = quiet(rlocp.LOCP, case['N'], case['H'], case['Qz'], case['R'], Qzf=case.get('Qzf'), U=poly(case.get('U')),
+                    X=poly(case.get('X')), Xf=poly(case.get('Xf')), dU=poly(case.get('dU')), verbose=False,
+                    warm_start=warm_start, x_char=1.0 / case['x_scale'], **kw)
+    ukw = dict(z=case.get('z'), zf=case.get('zf'), u=case.get('u_des'))
+    if nl:
+        ukw.update(Hd=list(case['Hd']), cd=list(case['cd']))
+    quiet(lo.update, list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'] if tr else None,
+          case['delta'] if tr else 0.0, case['omega'] if tr else 0.0, **ukw)
+    Js, Rs = [], []
+    for (x, u, s) in pts:
+        lo.x.value = x.ravel()
+        lo.u.value = u.ravel()
+        if tr:
+            lo.st.value = s
+        Js.append(lo.prob.objective.value)
+        Rs.append(np.concatenate([c.residual() for c in lo.prob.constraints]))
+    return np.array(Js), np.stack(Rs)
+
+
+def g14_locp(out):
+    """The QP statement of the reference's own locp.py at seeded points and at the oracle optimum, for every entry of
+    qp_cases.G14_CASES (trust region on/off, U, X, Xf, dU, u_des, Qzf / zf, nonlinear observer), both through the
+    Parameter path (warm_start=True) and the rebuild path (warm_start=False)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import qp_cases
+    res = {}
+    for name in qp_cases.G14_CASES:
+        case = qp_cases.g14_case(name)
+        pts = qp_cases.g14_points(name, case)
+        # plus the oracle's optimum (data: stored, so that the test does not have to solve)
+        kw = dict(case)
+        qp = olocp.build_qp(kw.pop('N'), kw.pop('H'), kw.pop('Qz'), kw.pop('R'), kw.pop('Ad'), kw.pop('Bd'), kw.pop('dd'),
+                            kw.pop('x0'), kw.pop('xk'), kw.pop('delta'), kw.pop('omega'), **kw)
+        w, _, info = olocp.solve_exact(qp)
+        assert info['status'] == 'optimal', (name, info)
+        xo, uo, so = olocp.split(qp, w)
+        pts.append((xo, uo, so))
+        J1, R1 = ref_locp_values(case, pts, True)
+        if 'Hd' not in case:
+            # both paths of locp.py state the same QP.  (Not with a nonlinear observer: the rebuild path flattens the
+            # (N+1, n_z) array `cd` with cvxpy's column-major reshape, locp.py:232-233, while the Parameter path gets
+            # np.ravel(cd), locp.py:131-132 -- the default warm_start=True path is the one recorded and mirrored.)
+            J2, R2 = ref_locp_values(case, pts, False)
+            assert np.array_equal(J1, J2) and np.array_equal(R1, R2), name
+        res[name + '_J'], res[name + '_res'], res[name + '_wopt'] = J1, R1, w
+    np.savez_compressed(os.path.join(out, 'g14_locp.npz'), **res)
+
+
+GENERATORS = dict(g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
+                  g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
+                  g13_controllers2=g13_controllers2, g14_locp=g14_locp)
+
 if __name__ == '__main__':
-    g9_ekf(HERE)
-    g10_ssm(HERE)
-    g11_ilqr_ssm(HERE)
-    g12_assembly(HERE)
-    g13_controllers2(HERE)
-    g8_controllers(HERE)
-    print('g8_controllers.npz', os.path.getsize(os.path.join(HERE, 'g8_controllers.npz')))
+    # one command regenerates every fixture; `make_golden.py g6_gusto g14_locp` only the named ones
+    for name in (sys.argv[1:] or list(GENERATORS)):
+        GENERATORS[name](HERE)
+        print('%-18s %8d bytes' % (name + '.npz', os.path.getsize(os.path.join(HERE, name + '.npz'))))

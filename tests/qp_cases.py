@@ -54,7 +54,7 @@ CASES = {
 # g14: the QP *statement* pinned to the reference's own locp.py (objective 218-263, constraints 265-342), evaluated
 # through the cvxpy stand-in of tests/golden/_cvxpy_eval.py.  The inputs below are regenerated from seeds by the
 # golden generator (reference side) and by tests/test_oracle_golden.py (oracle side); only outputs are stored.
-G14_CASES = dict(CASES)
+G14_CASES = {k: v for k, v in CASES.items() if k != 'terminal_cost'}   # Qzf at n_x != n_z: locp.py:252 is ill-formed there
 G14_CASES.update({
     # n_x == n_z (r = 3): the only shape for which locp.py:252 (`x[N*n_z:]`) and 330 (`x[n_z:]`) type-check
     'qzf_r3': dict(r=3, m=2, P=5, N=9, seed=40, use_X=True, terminal=True),
@@ -62,7 +62,7 @@ G14_CASES.update({
     'dU': dict(seed=42, use_X=False, extra=('dU',)),
     'dU_X_Xf': dict(seed=43, extra=('dU', 'Xf')),
     'u_des': dict(seed=44, extra=('u_des',)),
-    'nlobs_r3': dict(r=3, m=2, P=5, N=9, seed=45, use_X=True, extra=('nlobs',)),
+    'nlobs_r3': dict(r=3, m=2, P=5, N=9, seed=45, use_X=True, x_box=5.0, extra=('nlobs',)),
     'nlobs_free_r3': dict(r=3, m=2, P=5, N=9, seed=46, use_X=False, use_U=False, extra=('nlobs',)),
     'mpc_no_tr': dict(seed=47, extra=('no_tr',)),
     'mpc_no_tr_qzf_r3': dict(r=3, m=2, P=5, N=9, seed=48, terminal=True, extra=('no_tr', 'u_des')),

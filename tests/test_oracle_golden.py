@@ -296,3 +296,32 @@ def test_ilqr_ssm_oracle(golden, tag):
     x, u, K = il.solve(g[tag + '_x0'], g[tag + '_z_target'], g[tag + '_uw'])
     assert len(il.trace) - 1 == int(g[tag + '_iters'])
     close(x, g[tag + '_x'], 1e-10); close(u, g[tag + '_u'], 1e-9); close(K, g[tag + '_K'], 1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# g14: oracle.locp.build_qp against the reference's OWN statement of the QP -- sofacontrol/scp/locp.py executed
+# through the evaluating cvxpy stand-in (tests/golden/_cvxpy_eval.py) in the build container: J(w) of
+# locp.py:218-263 and the residual of every constraint of locp.py:265-342 at ten seeded points and at the optimum.
+import qp_cases  # noqa: E402
+
+
+@pytest.mark.parametrize('name', sorted(qp_cases.G14_CASES))
+def test_locp_statement_matches_reference_locp_py(golden, name):
+    g = golden('g14_locp')
+    case = qp_cases.g14_case(name)
+    pts = qp_cases.g14_points(name, case)
+    ws = [qp_cases.g14_pack(case, *p) for p in pts] + [g[name + '_wopt']]
+    Jr, Rr = g[name + '_J'], g[name + '_res']
+    assert Jr.shape[0] == len(ws) == Rr.shape[0]
+    for i, w in enumerate(ws):
+        J, res, qp = qp_cases.g14_oracle_values(case, w)
+        assert res.shape == Rr[i].shape, (res.shape, Rr[i].shape)          # same rows in the same order
+        np.testing.assert_allclose(J, Jr[i], rtol=1e-12, atol=1e-12 * max(1.0, abs(Jr[i])))
+        np.testing.assert_allclose(res, Rr[i], rtol=0, atol=1e-12 * max(1.0, np.abs(Rr[i]).max()))
+    # the stored optimum is a KKT point of the oracle QP, and feasible in the REFERENCE's own constraint residuals
+    from oracle import locp as olocp
+    w = g[name + '_wopt']
+    n_eq_dyn = qp.N * qp.n
+    r = Rr[-1]
+    assert np.abs(r[:n_eq_dyn]).max() <= 1e-8 and np.abs(r[-qp.n:]).max() <= 1e-8      # dynamics and x_0 = x0
+    assert r[n_eq_dyn:-qp.n].max(initial=0.0) <= 1e-7                                     # every inequality
