@@ -46,8 +46,9 @@ int srh_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int srh_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int srh_memset(void *dptr, int value, size_t bytes);
 int srh_sync(void);
-/* The host-pointer entry points keep the device blocks they release in a small cache (<= 64 blocks / 2 GiB per
- * process) instead of paying hipMalloc / hipFree per call; this returns them to the driver. */
+/* The host-pointer entry points keep the device blocks they release in a size-class cache (<= 2 GiB per process)
+ * instead of paying hipMalloc / hipFree per call -- hipFree waits for EVERY stream of the device, which would stall the
+ * caller behind an asynchronous solver request; this returns the cached blocks to the driver. */
 int srh_release_cached(void);
 /* average duration in milliseconds of `iters` back-to-back launches are measured by the caller with
  * these (hipEvent on the given stream): */
@@ -316,6 +317,18 @@ int sgusto_plan_solve(sgusto_plan_t *plan, const double *x0, const double *u_ini
 int sgusto_plan_solve_dev(sgusto_plan_t *plan, const double *x0, const double *u_init, const double *x_init,
                           const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
                           double *zopt, int32_t *iters, int32_t *status, double *trace, void *stream);
+
+/* Asynchronous form of sgusto_plan_solve -- the `send_request(wait=False)` / `check_if_done` / `force_wait` protocol
+ * of the reference's solver client (scp/ros.py:183-223; used by tpwl/controllers.py:276-292,327): `_begin` copies
+ * the host inputs into the plan's pinned staging block, enqueues H2D copies, the solve and the D2H copies of the
+ * results on the plan's own (non-blocking) stream and returns; `_done` polls the completion event without blocking;
+ * `_end` waits for it and hands the results over.  One request per plan at a time. */
+int sgusto_plan_prepare_async(sgusto_plan_t *plan);   /* optional: create the stream / pinned block now (~10 ms) */
+int sgusto_plan_solve_begin(sgusto_plan_t *plan, const double *x0, const double *u_init, const double *x_init,
+                            const double *z, const double *zf, const double *u_des, int want_trace);
+int sgusto_plan_solve_done(sgusto_plan_t *plan, int *done);
+int sgusto_plan_solve_end(sgusto_plan_t *plan, double *xopt, double *uopt, double *zopt, int32_t *iters,
+                          int32_t *status, double *trace);
 
 #ifdef __cplusplus
 }

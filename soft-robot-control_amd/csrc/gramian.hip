@@ -232,7 +232,7 @@ int srom_gramian(const double *S, int64_t n_s, int64_t n_f, double *G) {
     int rc;
     if ((rc = dS.upload(S, sizeof(double) * n_s * n_f)) || (rc = dG.alloc(sizeof(double) * n_s * n_s))) return rc;
     if ((rc = srom_gramian_dev(dS.as<double>(), n_s, n_f, n_f, dG.as<double>(), nullptr))) return rc;
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dG.download(G, sizeof(double) * n_s * n_s);
 }
 

@@ -216,7 +216,40 @@ struct sgusto_plan {
     size_t work_stride = 0;
     size_t lds = 0;
     bool has_z = false, has_zf = false, has_ud = false;
+    // asynchronous requests (sgusto_plan_solve_begin / _done / _end): own stream, completion event, pinned staging
+    hipStream_t astream = nullptr;
+    hipEvent_t adone = nullptr;
+    char *pin = nullptr;               // one pinned block: [inputs | outputs]
+    size_t pin_bytes = 0;
+    bool pending = false, want_trace = false;
+    ~sgusto_plan() {
+        if (pending && adone) (void)hipEventSynchronize(adone);
+        if (adone) (void)hipEventDestroy(adone);
+        if (astream) (void)hipStreamDestroy(astream);
+        if (pin) (void)hipHostFree(pin);
+    }
 };
+
+namespace {
+// layout of the pinned staging block of a plan (byte offsets)
+struct PinLayout {
+    size_t x0, u_init, x_init, z, zf, ud, xopt, uopt, zopt, iters, status, trace, total;
+};
+PinLayout pin_layout(const sgusto_plan *pl) {
+    const QPDims &d = pl->C.dims;
+    const size_t N = d.N, n = d.n, m = d.m, nz = d.nz, B = pl->batch, D = sizeof(double);
+    PinLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 63) & ~(size_t)63; return at; };
+    L.x0 = take(D * B * n); L.u_init = take(D * B * N * m); L.x_init = take(D * B * (N + 1) * n);
+    L.z = take(D * B * (N + 1) * nz); L.zf = take(D * B * nz); L.ud = take(D * B * N * m);
+    L.xopt = take(D * B * (N + 1) * n); L.uopt = take(D * B * N * m); L.zopt = take(D * B * (N + 1) * nz);
+    L.iters = take(sizeof(int32_t) * B); L.status = take(sizeof(int32_t) * B);
+    L.trace = take(D * B * (size_t)std::max(1, pl->par.max_trace) * 4);
+    L.total = o;
+    return L;
+}
+}  // namespace
 
 extern "C" {
 
@@ -331,13 +364,92 @@ int sgusto_plan_solve(sgusto_plan_t *pl, const double *x0, const double *u_init,
                                    pl->zopt.as<double>(), pl->iters.as<int32_t>(), pl->status.as<int32_t>(),
                                    trace ? pl->trace.as<double>() : nullptr, nullptr);
     if (rc) return rc;
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = pl->xopt.download(xopt, sizeof(double) * B * (N + 1) * n)) || (rc = pl->uopt.download(uopt, sizeof(double) * B * N * m)) ||
         (rc = pl->zopt.download(zopt, sizeof(double) * B * (N + 1) * nz)))
         return rc;
     if (iters && (rc = pl->iters.download(iters, sizeof(int32_t) * B))) return rc;
     if (status && (rc = pl->status.download(status, sizeof(int32_t) * B))) return rc;
     if (trace && (rc = pl->trace.download(trace, sizeof(double) * B * pl->par.max_trace * 4))) return rc;
+    return SRH_OK;
+}
+
+int sgusto_plan_prepare_async(sgusto_plan_t *pl) {
+    SRH_REQUIRE(pl, "sgusto_plan_prepare_async: null plan");
+    if (pl->astream) return SRH_OK;
+    const PinLayout L = pin_layout(pl);
+    SRH_CHECK_HIP(hipStreamCreateWithFlags(&pl->astream, hipStreamNonBlocking));
+    SRH_CHECK_HIP(hipEventCreateWithFlags(&pl->adone, hipEventDisableTiming));
+    SRH_CHECK_HIP(hipHostMalloc((void **)&pl->pin, L.total, hipHostMallocDefault));
+    pl->pin_bytes = L.total;
+    return SRH_OK;
+}
+
+int sgusto_plan_solve_begin(sgusto_plan_t *pl, const double *x0, const double *u_init, const double *x_init,
+                            const double *z, const double *zf, const double *u_des, int want_trace) {
+    SRH_REQUIRE(pl && x0 && u_init && x_init, "sgusto_plan_solve_begin: null argument");
+    SRH_REQUIRE(!pl->pending, "sgusto_plan_solve_begin: a request is already in flight (call sgusto_plan_solve_end first)");
+    const QPDims &d = pl->C.dims;
+    const size_t N = d.N, n = d.n, m = d.m, nz = d.nz, B = pl->batch, D = sizeof(double);
+    const PinLayout L = pin_layout(pl);
+    { int rc0 = sgusto_plan_prepare_async(pl); if (rc0) return rc0; }
+    // host -> pinned (the caller's arrays may change as soon as this returns), pinned -> HBM on the plan's stream
+    auto stage = [&](size_t off, const double *src, size_t bytes, void *dst) -> hipError_t {
+        memcpy(pl->pin + off, src, bytes);
+        return hipMemcpyAsync(dst, pl->pin + off, bytes, hipMemcpyHostToDevice, pl->astream);
+    };
+    SRH_CHECK_HIP(stage(L.x0, x0, D * B * n, pl->x0.p));
+    SRH_CHECK_HIP(stage(L.u_init, u_init, D * B * N * m, pl->u_init.p));
+    SRH_CHECK_HIP(stage(L.x_init, x_init, D * B * (N + 1) * n, pl->x_init.p));
+    if (z) SRH_CHECK_HIP(stage(L.z, z, D * B * (N + 1) * nz, pl->z.p));
+    if (zf) SRH_CHECK_HIP(stage(L.zf, zf, D * B * nz, pl->zf.p));
+    if (u_des) SRH_CHECK_HIP(stage(L.ud, u_des, D * B * N * m, pl->ud.p));
+    pl->want_trace = want_trace != 0 && pl->par.max_trace > 0;
+    int rc = sgusto_plan_solve_dev(pl, pl->x0.as<double>(), pl->u_init.as<double>(), pl->x_init.as<double>(),
+                                   z ? pl->z.as<double>() : nullptr, zf ? pl->zf.as<double>() : nullptr,
+                                   u_des ? pl->ud.as<double>() : nullptr, pl->xopt.as<double>(), pl->uopt.as<double>(),
+                                   pl->zopt.as<double>(), pl->iters.as<int32_t>(), pl->status.as<int32_t>(),
+                                   pl->want_trace ? pl->trace.as<double>() : nullptr, (void *)pl->astream);
+    if (rc) return rc;
+    auto back = [&](size_t off, const void *src, size_t bytes) {
+        return hipMemcpyAsync(pl->pin + off, src, bytes, hipMemcpyDeviceToHost, pl->astream);
+    };
+    SRH_CHECK_HIP(back(L.xopt, pl->xopt.p, D * B * (N + 1) * n));
+    SRH_CHECK_HIP(back(L.uopt, pl->uopt.p, D * B * N * m));
+    SRH_CHECK_HIP(back(L.zopt, pl->zopt.p, D * B * (N + 1) * nz));
+    SRH_CHECK_HIP(back(L.iters, pl->iters.p, sizeof(int32_t) * B));
+    SRH_CHECK_HIP(back(L.status, pl->status.p, sizeof(int32_t) * B));
+    if (pl->want_trace) SRH_CHECK_HIP(back(L.trace, pl->trace.p, D * B * (size_t)pl->par.max_trace * 4));
+    SRH_CHECK_HIP(hipEventRecord(pl->adone, pl->astream));
+    pl->pending = true;
+    return SRH_OK;
+}
+
+int sgusto_plan_solve_done(sgusto_plan_t *pl, int *done) {
+    SRH_REQUIRE(pl && done, "sgusto_plan_solve_done: null argument");
+    if (!pl->pending) { *done = 1; return SRH_OK; }
+    const hipError_t e = hipEventQuery(pl->adone);
+    if (e == hipErrorNotReady) { *done = 0; return SRH_OK; }
+    SRH_CHECK_HIP(e);
+    *done = 1;
+    return SRH_OK;
+}
+
+int sgusto_plan_solve_end(sgusto_plan_t *pl, double *xopt, double *uopt, double *zopt, int32_t *iters, int32_t *status,
+                          double *trace) {
+    SRH_REQUIRE(pl && xopt && uopt && zopt, "sgusto_plan_solve_end: null argument");
+    SRH_REQUIRE(pl->pending, "sgusto_plan_solve_end: no request in flight");
+    SRH_CHECK_HIP(hipEventSynchronize(pl->adone));
+    pl->pending = false;
+    const QPDims &d = pl->C.dims;
+    const size_t N = d.N, n = d.n, m = d.m, nz = d.nz, B = pl->batch, D = sizeof(double);
+    const PinLayout L = pin_layout(pl);
+    memcpy(xopt, pl->pin + L.xopt, D * B * (N + 1) * n);
+    memcpy(uopt, pl->pin + L.uopt, D * B * N * m);
+    memcpy(zopt, pl->pin + L.zopt, D * B * (N + 1) * nz);
+    if (iters) memcpy(iters, pl->pin + L.iters, sizeof(int32_t) * B);
+    if (status) memcpy(status, pl->pin + L.status, sizeof(int32_t) * B);
+    if (trace && pl->want_trace) memcpy(trace, pl->pin + L.trace, D * B * (size_t)pl->par.max_trace * 4);
     return SRH_OK;
 }
 

@@ -801,7 +801,7 @@ static int tvlqr_impl(const double *dA, const double *dB, const int *didx, int n
     tvlqr_kernel<<<1, NT, lds>>>(dA, dB, didx, n_steps, n, m, dQ.as<double>(), dR.as<double>(), dK.as<double>(),
                                  dP.as<double>(), dS.as<int>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     int st = 0;
     if ((rc = dS.download(&st, sizeof(int)))) return rc;
     if (st != 0) { srh::set_error("sric_tvlqr: R + B'PB is not positive definite"); return SRH_ENUMERIC; }
@@ -848,7 +848,7 @@ int sric_dare_fixed_point(const double *A, const double *B, int64_t batch, int n
     dare_fp_kernel<<<(unsigned)batch, NT, lds>>>(dA.as<double>(), dB.as<double>(), n_x, n_u, dQ.as<double>(), dR.as<double>(),
                                                  tol, max_iter, dL.as<double>(), dP.as<double>(), dI.as<int>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = dL.download(L, sizeof(double) * batch * n_u * n_x)) || (rc = dP.download(P, sizeof(double) * batch * n_x * n_x))) return rc;
     if (iters) return dI.download(iters, sizeof(int32_t) * batch);
     return SRH_OK;
@@ -914,7 +914,7 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
 #undef X
     }
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = ox.download(x, sizeof(double) * batch * (N + 1) * n)) || (rc = ou.download(u, sizeof(double) * batch * N * m)) ||
         (rc = oK.download(K, sizeof(double) * batch * N * m * n)))
         return rc;

@@ -593,7 +593,7 @@ int srom_create(srom_t **out, const double *U, int64_t n_f, int r, const double 
     const int krows = 4 * ((r + 3) / 4);
     pack_ut_kernel<<<(unsigned)srh::cdiv(h->ldu * krows, 256), 256>>>(h->U.as<double>(), n_f, r, h->ldu, krows,
                                                                       h->ut.as<double>());
-    hipError_t e = hipDeviceSynchronize();
+    hipError_t e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
         srh::set_error("srom_create: packing kernels failed: %s", hipGetErrorString(e));
         delete h;
@@ -693,7 +693,7 @@ int srom_project(srom_t *h, int which, const double *X, int64_t B, double *out) 
     if ((rc = dO.alloc(sizeof(double) * B * nblk * h->r))) return rc;
     if ((rc = srom_project_dev(h, which, dX.as<double>(), B, nblk * h->n_f, dO.as<double>(), nblk * h->r, nullptr)))
         return rc;
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dO.download(out, sizeof(double) * B * nblk * h->r);
 }
 
@@ -761,7 +761,7 @@ int srom_lift(srom_t *h, int which, const double *Xr, int64_t B, double *out) {
     if ((rc = dO.alloc(sizeof(double) * B * nblk * h->n_f))) return rc;
     if ((rc = srom_lift_dev(h, which, dX.as<double>(), B, nblk * h->r, dO.as<double>(), nblk * h->n_f, nullptr)))
         return rc;
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dO.download(out, sizeof(double) * B * nblk * h->n_f);
 }
 
@@ -828,7 +828,7 @@ int srom_reduce_matrix(srom_t *h, const double *M, int64_t ncols, int left, int 
                          : (left ? sizeof(double) * h->r * ncols : sizeof(double) * h->n_f * h->r);
     if ((rc = dO.alloc(obytes))) return rc;
     if ((rc = srom_reduce_matrix_dev(h, dM.as<double>(), ncols, left, right, dO.as<double>(), nullptr))) return rc;
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dO.download(out, obytes);
 }
 

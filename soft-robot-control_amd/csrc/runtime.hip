@@ -1,7 +1,9 @@
 // Device plumbing of the C ABI: error string, memory helpers, events.
 #include "common.h"
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace srh {
 static thread_local char g_err[512] = "";
@@ -12,43 +14,48 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-// ---- cache of released device blocks (see common.h).  Best fit within 25 % (+64 KiB) of the request; at most 64
-// blocks / 2 GiB are kept, the oldest goes first.  One cache per device.
+// ---- cache of released device blocks (see common.h).  hipFree is a DEVICE-WIDE synchronisation (it waits for every
+// stream, including a GuSTO request running asynchronously on its own stream: tools/probes/sync_probe.hip), so the
+// steady state must never free: requests are rounded up to size classes (quarter octaves above 4 KiB) and a released
+// block goes back to the free list of its class, whatever the number of blocks; only when the cache holds more than
+// 2 GiB are blocks returned to the driver (largest class first).  One cache per device.
 namespace {
-struct Block { void *p; size_t bytes; int dev; };
 std::mutex g_pool_mu;
-std::vector<Block> g_pool;
+std::map<std::pair<int, size_t>, std::vector<void *>> g_free;      // (device, class bytes) -> blocks
 size_t g_pool_bytes = 0;
 constexpr size_t POOL_MAX_BYTES = (size_t)2 << 30;
-constexpr size_t POOL_MAX_BLOCKS = 64;
+
+size_t size_class(size_t bytes) {
+    if (bytes <= 4096) return (bytes + 255) & ~(size_t)255;
+    size_t p2 = 4096;
+    while (p2 * 2 <= bytes) p2 *= 2;                 // p2 <= bytes < 2 p2
+    const size_t step = p2 / 4;
+    return ((bytes + step - 1) / step) * step;
+}
 }  // namespace
 
 void *pool_take(size_t bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
+    const size_t cls = size_class(bytes);
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        size_t best = g_pool.size();
-        for (size_t i = 0; i < g_pool.size(); ++i) {
-            const Block &b = g_pool[i];
-            if (b.dev != dev || b.bytes < bytes || b.bytes > bytes + bytes / 4 + 65536) continue;
-            if (best == g_pool.size() || b.bytes < g_pool[best].bytes) best = i;
-        }
-        if (best != g_pool.size()) {
-            void *p = g_pool[best].p;
-            g_pool_bytes -= g_pool[best].bytes;
-            g_pool.erase(g_pool.begin() + best);
+        auto it = g_free.find({dev, cls});
+        if (it != g_free.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            g_pool_bytes -= cls;
             return p;
         }
     }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = hipMalloc(&p, cls);
     if (e != hipSuccess) {                       // make room and try once more
         pool_release();
-        e = hipMalloc(&p, bytes);
+        e = hipMalloc(&p, cls);
     }
     if (e != hipSuccess) {
-        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        set_error("hipMalloc(%zu) failed: %s", cls, hipGetErrorString(e));
         return nullptr;
     }
     return p;
@@ -58,31 +65,33 @@ void pool_give(void *p, size_t bytes) {
     if (!p) return;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    const size_t cls = size_class(bytes);
     std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (bytes > POOL_MAX_BYTES / 2) drop.push_back(p);
-        else {
-            g_pool.push_back({p, bytes, dev});
-            g_pool_bytes += bytes;
-            while (g_pool.size() > POOL_MAX_BLOCKS || g_pool_bytes > POOL_MAX_BYTES) {
-                drop.push_back(g_pool.front().p);
-                g_pool_bytes -= g_pool.front().bytes;
-                g_pool.erase(g_pool.begin());
-            }
+        g_free[{dev, cls}].push_back(p);
+        g_pool_bytes += cls;
+        while (g_pool_bytes > POOL_MAX_BYTES) {          // over budget: the largest cached blocks go back to the driver
+            auto big = g_free.end();
+            for (auto it = g_free.begin(); it != g_free.end(); ++it)
+                if (!it->second.empty() && (big == g_free.end() || it->first.second > big->first.second)) big = it;
+            if (big == g_free.end()) break;
+            drop.push_back(big->second.back());
+            big->second.pop_back();
+            g_pool_bytes -= big->first.second;
         }
     }
     for (void *q : drop) (void)hipFree(q);
 }
 
 void pool_release() {
-    std::vector<Block> all;
+    std::vector<void *> all;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        all.swap(g_pool);
+        for (auto &kv : g_free) { all.insert(all.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
         g_pool_bytes = 0;
     }
-    for (const Block &b : all) (void)hipFree(b.p);
+    for (void *q : all) (void)hipFree(q);
 }
 
 }  // namespace srh

@@ -117,7 +117,7 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
 #undef X
     }
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if (want_dbg) {
         std::vector<double> t(8 * 64);
         dbg.download(t.data(), sizeof(double) * 8 * 64);

@@ -306,7 +306,7 @@ int sssm_linearize(sssm_t *h, const double *X, const double *U, int64_t B, int m
     ssm_lin_kernel<<<(unsigned)B, SSM_NT, h->lds>>>(h->view(), dX.as<double>(), dU.as<double>(), mode, dt,
                                                      dA.as<double>(), dB.as<double>(), dd.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = dA.download(A, sizeof(double) * B * n * n)) || (rc = dB.download(Bm, sizeof(double) * B * n * m)) ||
         (rc = dd.download(d, sizeof(double) * B * n)))
         return rc;
@@ -325,7 +325,7 @@ int sssm_dynamics(sssm_t *h, const double *X, const double *U, int64_t B, int di
         return rc;
     ssm_dyn_kernel<<<(unsigned)B, SSM_NT, h->lds>>>(h->view(), dX.as<double>(), dU.as<double>(), discrete, dF.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dF.download(F, sizeof(double) * B * n);
 }
 
@@ -341,7 +341,7 @@ int sssm_observe(sssm_t *h, const double *X, int64_t B, double *Z, double *H, do
     ssm_obs_kernel<<<(unsigned)B, SSM_NT, h->lds>>>(h->view(), dX.as<double>(), dZ.as<double>(),
                                                      H ? dH.as<double>() : nullptr, H ? dc.as<double>() : nullptr);
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if (Z && (rc = dZ.download(Z, sizeof(double) * B * no))) return rc;
     if (H && (rc = dH.download(H, sizeof(double) * B * no * n))) return rc;
     if (H && c && (rc = dc.download(c, sizeof(double) * B * no))) return rc;
@@ -356,7 +356,7 @@ int sssm_reduce(sssm_t *h, const double *Z, int64_t B, double *X) {
     if ((rc = dZ.upload(Z, sizeof(double) * B * h->no)) || (rc = dX.alloc(sizeof(double) * B * h->n))) return rc;
     ssm_reduce_kernel<<<(unsigned)B, SSM_NT, h->lds>>>(h->view(), dZ.as<double>(), dX.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dX.download(X, sizeof(double) * B * h->n);
 }
 
@@ -378,7 +378,7 @@ int sssm_rollout(sssm_t *h, const double *x0, const double *U, int N, int64_t ba
     ssm_rollout_kernel<<<(unsigned)batch, SSM_NT, h->lds>>>(h->view(), d0.as<double>(), dU.as<double>(), N, mode, dt,
                                                             dX.as<double>(), Z ? dZ.as<double>() : nullptr);
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = dX.download(X, sizeof(double) * batch * (N + 1) * n))) return rc;
     if (Z && (rc = dZ.download(Z, sizeof(double) * batch * (N + 1) * no))) return rc;
     return SRH_OK;

@@ -276,7 +276,7 @@ int stpwl_nearest(stpwl_t *h, const double *X, int64_t B, int32_t *idx) {
     int rc;
     if ((rc = dX.upload(X, sizeof(double) * B * h->n)) || (rc = dI.alloc(sizeof(int32_t) * B))) return rc;
     if ((rc = stpwl_nearest_dev(h, dX.as<double>(), B, dI.as<int32_t>(), nullptr))) return rc;
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dI.download(idx, sizeof(int32_t) * B);
 }
 
@@ -295,7 +295,7 @@ int stpwl_linearize(stpwl_t *h, const double *X, int64_t B, int discrete, double
     if ((rc = stpwl_nearest_dev(h, dX.as<double>(), B, dI.as<int32_t>(), nullptr))) return rc;
     gather_kernel<<<(unsigned)B, 256>>>(h->view(), dI.as<int32_t>(), B, discrete, dA.as<double>(), dB.as<double>(), dd.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = dA.download(A, sizeof(double) * B * n * n)) || (rc = dB.download(Bm, sizeof(double) * B * n * m)) ||
         (rc = dd.download(d, sizeof(double) * B * n)))
         return rc;
@@ -311,7 +311,7 @@ int stpwl_weights(stpwl_t *h, const double *X, int64_t B, double beta, double *W
     if ((rc = dX.upload(X, sizeof(double) * B * h->n)) || (rc = dW.alloc(sizeof(double) * B * h->P))) return rc;
     weights_kernel<<<(unsigned)B, 256>>>(h->view(), dX.as<double>(), B, beta, dW.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dW.download(W, sizeof(double) * B * h->P);
 }
 
@@ -333,7 +333,7 @@ int stpwl_linearize_weighted(stpwl_t *h, const double *X, int64_t B, double beta
                                                                             dA.as<double>(), dB.as<double>(),
                                                                             dd.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = dA.download(A, sizeof(double) * B * n * n)) || (rc = dB.download(Bm, sizeof(double) * B * n * m)) ||
         (rc = dd.download(d, sizeof(double) * B * n)))
         return rc;
@@ -358,7 +358,7 @@ int stpwl_rollout(stpwl_t *h, const double *x0, const double *U, int N, int64_t 
     rollout_kernel<<<(unsigned)batch, 256, lds>>>(h->view(), d0.as<double>(), dU.as<double>(), N, dX.as<double>(),
                                                  Z ? dZ.as<double>() : nullptr);
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = dX.download(X, sizeof(double) * batch * (N + 1) * n))) return rc;
     if (Z) return dZ.download(Z, sizeof(double) * batch * (N + 1) * h->nz);
     return SRH_OK;
@@ -376,7 +376,7 @@ int stpwl_characteristic(stpwl_t *h, double *x_char, double *f_char) {
     colmax_kernel<<<(unsigned)srh::cdiv(n, 64), 64>>>(xa.as<double>(), h->P, n, xo.as<double>());
     colmax_kernel<<<(unsigned)srh::cdiv(n, 64), 64>>>(fa.as<double>(), h->P, n, fo.as<double>());
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipDeviceSynchronize());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     if ((rc = xo.download(x_char, sizeof(double) * n))) return rc;
     return fo.download(f_char, sizeof(double) * n);
 }

@@ -209,6 +209,49 @@ class GuSTO:
         self.xopt, self.uopt, self.zopt = xo, uo, zo
         return xo, uo, zo
 
+    # ---- asynchronous solve (fused plans): the request runs on the plan's own HIP stream
+    def solve_begin(self, x0, u_init, x_init, z=None, zf=None, u=None):
+        """Enqueue one solve (same arguments as `solve` / `solve_batch`) and return immediately; `solve_done()` polls,
+        `solve_end()` waits and installs the result like `solve` does.  (scp/ros.py:183-223 `send_request(wait=False)`.)"""
+        if not self._fused:
+            raise RuntimeError('asynchronous solves need the fused TPWL plan')
+        B, N, n, m, nz = self.batch, self.N, self.n_x, self.n_u, self.n_z
+        f = _lib.f64
+        x0 = f(np.asarray(x0).reshape(B, n)); u_init = f(np.asarray(u_init).reshape(B, N, m))
+        x_init = f(np.asarray(x_init).reshape(B, N + 1, n))
+        z = None if z is None else f(np.asarray(z).reshape(B, N + 1, nz))
+        zf = None if (zf is None or self.Qzf is None) else f(np.asarray(zf).reshape(B, nz))
+        u = None if u is None else f(np.asarray(u).reshape(B, N, m))
+        _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(self.max_gusto_iters))), 'set_max_iters')
+        self._t_begin = time.time()
+        _lib.check(_lib.lib().sgusto_plan_solve_begin(self._plan, _lib.dptr(x0), _lib.dptr(u_init), _lib.dptr(x_init),
+                                                      _lib.dptr(z), _lib.dptr(zf), _lib.dptr(u),
+                                                      C.c_int(1 if self.max_trace > 0 else 0)), 'sgusto_plan_solve_begin')
+
+    def prepare_async(self):
+        _lib.check(_lib.lib().sgusto_plan_prepare_async(self._plan), 'sgusto_plan_prepare_async')
+
+    def solve_done(self):
+        done = C.c_int(0)
+        _lib.check(_lib.lib().sgusto_plan_solve_done(self._plan, C.byref(done)), 'sgusto_plan_solve_done')
+        return bool(done.value)
+
+    def solve_end(self):
+        B, N, n, m, nz = self.batch, self.N, self.n_x, self.n_u, self.n_z
+        xo = np.empty((B, N + 1, n)); uo = np.empty((B, N, m)); zo = np.empty((B, N + 1, nz))
+        iters = np.empty(B, dtype=np.int32); status = np.empty(B, dtype=np.int32)
+        trace = np.full((B, self.max_trace, 4), np.nan) if self.max_trace > 0 else None
+        _lib.check(_lib.lib().sgusto_plan_solve_end(self._plan, _lib.dptr(xo), _lib.dptr(uo), _lib.dptr(zo), _lib.iptr(iters),
+                                                    _lib.iptr(status), _lib.dptr(trace)), 'sgusto_plan_solve_end')
+        self.locp_solve_time = time.time() - self._t_begin
+        self.iters, self.status, self.trace = iters, status, trace
+        if B == 1:
+            self.xopt, self.uopt, self.zopt = xo[0], uo[0], zo[0]
+            self.x_k, self.u_k = self.xopt.copy(), self.uopt.copy()
+        else:
+            self.xopt, self.uopt, self.zopt = xo, uo, zo
+        return self.xopt, self.uopt, self.zopt
+
     def solve(self, x0, u_init, x_init, z=None, zf=None, u=None):
         """gusto.py:283-487."""
         if self._fused:

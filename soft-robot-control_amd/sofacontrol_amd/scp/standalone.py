@@ -55,17 +55,43 @@ class GuSTOSolverNode():
             u = None
         return z, zf, u
 
-    def gusto_callback(self, t0, x0):
-        """scp/ros.py:94-127 without the ROS message types: returns (t, xopt, uopt, zopt, solve_time)."""
-        z, zf, u = self.get_target(t0)
+    def _warm_start(self, t0):
+        """Initial guess of a receding-horizon request: the previous solution shifted to start at t0, its last
+        sample held over the part of the new horizon it does not cover (scp/ros.py:109-114)."""
         idx0 = np.argwhere(self.topt >= t0)[0, 0]
         u_init = self.uopt[-1, :].reshape(1, -1).repeat(self.N, axis=0)
         u_init[0:self.N - idx0] = self.uopt[idx0:, :]
         x_init = self.xopt[-1, :].reshape(1, -1).repeat(self.N + 1, axis=0)
         x_init[0:self.N + 1 - idx0] = self.xopt[idx0:, :]
+        return u_init, x_init
+
+    def gusto_callback(self, t0, x0):
+        """scp/ros.py:94-127 without the ROS message types: returns (t, xopt, uopt, zopt, solve_time)."""
+        z, zf, u = self.get_target(t0)
+        u_init, x_init = self._warm_start(t0)
         self.gusto.solve(x0, u_init, x_init, z=z, zf=zf, u=u)
         self.xopt, self.uopt, zopt, t_solve = self.gusto.get_solution()
         self.topt = t0 + self.dt * np.arange(self.N + 1)
+        return self.topt, self.xopt, self.uopt, zopt, t_solve
+
+    # ---- the same request split into enqueue / poll / collect (the client's wait=False path)
+    @property
+    def supports_async(self):
+        return bool(getattr(self.gusto, '_fused', False)) and self.gusto.batch == 1
+
+    def gusto_callback_begin(self, t0, x0):
+        z, zf, u = self.get_target(t0)
+        u_init, x_init = self._warm_start(t0)
+        self._t0_pending = t0
+        self.gusto.solve_begin(x0, u_init, x_init, z=z, zf=zf, u=u)
+
+    def gusto_callback_done(self):
+        return self.gusto.solve_done()
+
+    def gusto_callback_end(self):
+        self.gusto.solve_end()
+        self.xopt, self.uopt, zopt, t_solve = self.gusto.get_solution()
+        self.topt = self._t0_pending + self.dt * np.arange(self.N + 1)
         return self.topt, self.xopt, self.uopt, zopt, t_solve
 
     def gusto_service(self, request, response=None):

@@ -1,11 +1,22 @@
-"""Closed-loop controllers on the MI355X hot path -- surface of sofacontrol/tpwl/controllers.py.
+"""Closed-loop controllers for the SOFA loop, MI355X hot path underneath.
 
-`TemplateController.evaluate` (lines 85-117) keeps the reference's time gating verbatim (host glue); what it
-calls runs on the device: the POD projection of the full FEM state (`rom.compute_RO_state`, line 96), the
-policy computation (`iLQR.ilqr_computation`, GuSTO through a solver client) and the nearest-point lookup of
-the LQR feedback (`calc_nearest_point`, line 330).  The ROS2 `GuSTOClientNode` of the reference is replaced
-by `GuSTOClient`, an in-process client with the same methods around `scp.standalone.GuSTOSolverNode`; any
-object with that client protocol (e.g. a ROS client) can be passed as `client=`."""
+Implements the controller protocol SURVEY.md section 8(b) records for sofacontrol/tpwl/controllers.py (class names,
+constructor arguments, `evaluate(sim_time, y, x, u_prev) -> u`, `set_sim_timestep`, `save_controller_info`, the
+public attributes `observer`, `K`, `x_bar`, `u_bar`, `t_opt`, `u_opt`, `x_opt`, `solve_times`); its behaviour is
+pinned by the golden sequences g8 / g13 recorded from the imported reference.  Everything numeric goes to the device:
+the POD projection of the full FEM state, the observer, the iLQR / TV-LQR / DARE policies, the GuSTO replans and
+the nearest-point lookup of the feedback gain.
+
+Structure (this file's own): a `_Schedule` keeps the control clock on the reference's 1e-4 s grid; a `_PlanTape`
+stitches successive receding-horizon plans into one time-indexed tape; the controller classes only say *when* to
+plan and *how* to turn a belief into an input.
+
+Solver clients.  `scp` talks to an object with the GuSTOClientNode protocol of sofacontrol/scp/ros.py:162-223
+(`send_request(t0, x0, wait)`, `check_if_done`, `force_wait`, `force_spin`, `get_solution(n_x, n_u)`).
+`GuSTOClient` is the in-process one: with `wait=False` the request is enqueued on the solver plan's own HIP stream
+(inputs -> kernel -> pinned outputs) and `send_request` returns at once; `check_if_done` polls the stream's event,
+`force_wait` blocks on it -- the asynchronous semantics the reference gets from a second ROS process.
+"""
 import numpy as np
 from scipy.interpolate import interp1d
 
@@ -15,53 +26,144 @@ from ..lqr.ilqr import iLQR
 from ..lqr.traj_tracking_lqr import TrajTrackingLQR
 from ..lqr.lqr import DLQR, dare_batch
 
+_GRID = 4            # decimals of the control clock (the reference compares times rounded to 1e-4 s)
+
+
+def _on_grid(t):
+    return round(float(t), _GRID)
+
+
+class _Schedule:
+    """Control clock: inputs start `delay` seconds into the simulation and are renewed every `dt` seconds of
+    simulation time.  `due(sim_time)` says whether the next control instant has been reached; `advance()` moves to
+    the following one.  All comparisons on the 1e-4 s grid (controllers.py:85-117 gate the same way)."""
+
+    def __init__(self, dt, delay):
+        self.dt, self.delay = dt, delay
+        self.t_next = 0.0                      # control time (starts at 0 when the delay has elapsed)
+
+    def started(self, sim_time):
+        return not (_on_grid(sim_time) < _on_grid(self.delay))
+
+    def due(self, sim_time):
+        return _on_grid(_on_grid(sim_time) - self.delay) >= _on_grid(self.t_next)
+
+    def advance(self):
+        self.t_next = _on_grid(self.t_next + self.dt)
+
+
+class _PlanTape:
+    """Receding-horizon plans stitched into one tape.  Every accepted plan contributes the `n_keep` control steps that
+    will be executed before the next plan arrives (sampled from the plan by linear interpolation; the plan's input
+    trajectory is held at its last value over the final interval).  `u(t)`, `x(t)` interpolate the tape."""
+
+    def __init__(self, dt, n_keep):
+        self.dt, self.n_keep = dt, n_keep
+        self.t = self.u = self.x = None
+        self._u_of_t = self._x_of_t = None
+
+    @property
+    def t_end(self):
+        return self.t[-1]
+
+    def append(self, t_plan, u_plan, x_plan):
+        u_held = np.vstack((u_plan, u_plan[-1:]))                 # (N+1) samples like x
+        sample_u = interp1d(t_plan, u_held, axis=0)
+        sample_x = interp1d(t_plan, x_plan, axis=0)
+        start = 0.0 if self.t is None else self.t[-1]
+        t_new = start + self.dt * np.arange(self.n_keep + 1)
+        u_new, x_new = sample_u(t_new), sample_x(t_new)
+        if self.t is None:
+            self.t, self.u, self.x = t_new, u_new, x_new
+        else:
+            # the junction sample belongs to the new plan for u (it is applied from there on) and to the old one
+            # for x (the state the new plan started from)
+            self.t = np.concatenate((self.t, t_new[1:]))
+            self.u = np.concatenate((self.u[:-1], u_new))
+            self.x = np.concatenate((self.x, x_new[1:]))
+        self._u_of_t = interp1d(self.t, self.u, axis=0)
+        self._x_of_t = interp1d(self.t, self.x, axis=0)
+
+    def u_at(self, t):
+        return self._u_of_t(t)
+
+    def x_at(self, t):
+        return self._x_of_t(t)
+
 
 class GuSTOClient:
-    """In-process stand-in for scp/ros.py:162-223 (send_request / check_if_done / force_wait / force_spin /
-    get_solution) around a GuSTOSolverNode: requests are solved synchronously on the GPU."""
+    """In-process solver client (protocol of scp/ros.py:162-223) around a `scp.standalone.GuSTOSolverNode`.
+
+    wait=True : the request is solved before `send_request` returns.
+    wait=False: the request is enqueued on the GPU (solver plan's own stream) and `send_request` returns immediately;
+                `check_if_done()` polls, `force_wait()` blocks, `get_solution()` blocks if it has to."""
 
     def __init__(self, solver_node):
         self.node = solver_node
-        self._res = None
+        self._result = None
+        self._pending = False
+        if getattr(solver_node, 'supports_async', False):
+            solver_node.gusto.prepare_async()          # stream + pinned staging now, not inside the first request
 
     def send_request(self, t0, x0, wait=True):
-        self._res = self.node.gusto_callback(t0, np.asarray(x0, dtype=np.float64))
+        x0 = np.asarray(x0, dtype=np.float64)
+        self._result = None
+        if wait or not self.node.supports_async:
+            self._result = self.node.gusto_callback(t0, x0)
+            self._pending = False
+        else:
+            self.node.gusto_callback_begin(t0, x0)
+            self._pending = True
 
     def force_spin(self):
-        pass
+        """Nothing to pump: the GPU makes progress on its own."""
 
     def check_if_done(self):
-        return self._res is not None
+        if self._pending and self.node.gusto_callback_done():
+            self._collect()
+        return self._result is not None
 
     def force_wait(self):
-        pass
+        if self._pending:
+            self._collect()
+
+    def _collect(self):
+        self._result = self.node.gusto_callback_end()
+        self._pending = False
 
     def get_solution(self, n_x, n_u):
-        t, xopt, uopt, zopt, t_solve = self._res
+        self.force_wait()
+        t, xopt, uopt, zopt, t_solve = self._result
         return np.asarray(t), np.asarray(uopt).reshape(-1, n_u), np.asarray(xopt).reshape(-1, n_x), t_solve
 
 
 class TemplateController(closed_loop_controller.TemplateController):
-    """tpwl/controllers.py:18-132."""
+    """Common part: estimate the reduced state from the full FEM state, then act on the control clock."""
 
     def __init__(self, dyn_sys, cost_params, dt=0.01, observer=None, delay=2, u0=None):
         super().__init__()
         self.dyn_sys = dyn_sys
-        self.dt = dt
-        self.input_dim = self.dyn_sys.get_input_dim()
-        self.state_dim = self.dyn_sys.get_state_dim()
         self.cost_params = cost_params
-        self.observer = observer if observer is not None else FullStateObserver(self.state_dim, self.dyn_sys.H)
+        self.dt = dt
         self.t_delay = delay
-        self.u0 = u0 if u0 is not None else np.zeros(self.input_dim)
-        self.t_compute = 0.
+        self.input_dim = dyn_sys.get_input_dim()
+        self.state_dim = dyn_sys.get_state_dim()
+        self.observer = FullStateObserver(self.state_dim, dyn_sys.H) if observer is None else observer
+        self.u0 = np.zeros(self.input_dim) if u0 is None else u0
         self.u = self.u0
+        self._clock = _Schedule(dt, delay)
 
+    # the reference exposes the control time as an attribute
+    @property
+    def t_compute(self):
+        return self._clock.t_next
+
+    # ---- hooks
     def validate_problem(self):
         raise NotImplementedError('Must be subclassed')
 
     def recompute_policy(self, t_step):
-        return True if t_step == 0 else False
+        return t_step == 0
 
     def compute_policy(self, t_step, x_belief):
         raise NotImplementedError('Must be subclassed')
@@ -69,52 +171,55 @@ class TemplateController(closed_loop_controller.TemplateController):
     def compute_input(self, t_step, x_belief):
         raise NotImplementedError('Must be subclassed')
 
+    # ---- the per-simulation-step entry point
     def evaluate(self, sim_time, y, x, u_prev):
-        """controllers.py:85-117."""
-        sim_time = round(sim_time, 4)
-        x_actual = self.dyn_sys.rom.compute_RO_state(xf=x)           # POD projection kernel
-        self.observer.update(u_prev, y, self.sim_dt, x=x_actual)
-        if round(sim_time, 4) < round(self.t_delay, 4):
+        x_reduced = self.dyn_sys.rom.compute_RO_state(xf=x)                  # POD projection on the device
+        self.observer.update(u_prev, y, self.sim_dt, x=x_reduced)
+        clock = self._clock
+        if not clock.started(sim_time):
             self.u = self.u0
-        else:
-            if round(sim_time - self.t_delay, 4) >= round(self.t_compute, 4):
-                if self.recompute_policy(self.t_compute):
-                    self.compute_policy(self.t_compute, self.observer.x)
-                self.u = self.compute_input(self.t_compute, self.observer.x)
-                self.t_compute += self.dt
-                self.t_compute = round(self.t_compute, 4)
+        elif clock.due(sim_time):
+            t = clock.t_next
+            belief = self.observer.x
+            if self.recompute_policy(t):
+                self.compute_policy(t, belief)
+            self.u = self.compute_input(t, belief)
+            clock.advance()
         self.u = np.atleast_1d(self.u)
         return self.u.copy()
 
     def save_controller_info(self):
-        info = dict()
-        info['cost_params'] = self.cost_params
+        info = {'cost_params': self.cost_params}
         if self.observer is not None:
             info['observer_params'] = self.observer.get_observer_params()
         if self.dyn_sys is not None:
-            info['dyn_sys_params'] = self.dyn_sys.get_sim_params()
-            info['state_dim'] = self.dyn_sys.get_state_dim()
-            info['input_dim'] = self.dyn_sys.get_input_dim()
+            info.update(dyn_sys_params=self.dyn_sys.get_sim_params(), state_dim=self.dyn_sys.get_state_dim(),
+                        input_dim=self.dyn_sys.get_input_dim())
         return info
 
 
+def _tracking_input(ctrl, t_step, x_belief):
+    """u = u_bar[k] + K[k] (x - x_bar[k]) on a stored per-step policy; the nominal input u0 after its end."""
+    if t_step > ctrl.final_time:
+        return ctrl.u0
+    k = int(t_step / ctrl.dt)
+    return ctrl.u_bar[k] + ctrl.K[k] @ (x_belief - ctrl.x_bar[k])
+
+
 class ilqr(TemplateController):
-    """controllers.py:135-206."""
+    """Open-loop iLQR plan (one device launch) + its time-varying feedback.  target.z 1-D: set-point reaching over
+    `tf` seconds; 2-D: trajectory tracking over the target's own time span."""
 
     def __init__(self, dyn_sys, cost_params, target, dt=0.01, observer=None, delay=2., u0=None, **kwargs):
         super().__init__(dyn_sys=dyn_sys, cost_params=cost_params, dt=dt, observer=observer, delay=delay, u0=u0)
         self.target = target
         self.setpoint_reaching = True
         self.validate_problem()
-        if self.setpoint_reaching:
-            self.final_time, self.planning_horizon = self.get_problem_horizon(kwargs.get('tf'))
-        else:
-            self.final_time, self.planning_horizon = self.get_problem_horizon(self.target.t[-1])
+        tf = kwargs.get('tf') if self.setpoint_reaching else self.target.t[-1]
+        self.final_time, self.planning_horizon = self.get_problem_horizon(tf)
         self.policy = iLQR(dt=self.dt, model=self.dyn_sys, cost_params=self.cost_params,
                            planning_horizon=self.planning_horizon)
-        self.x_bar = None
-        self.u_bar = None
-        self.K = None
+        self.x_bar = self.u_bar = self.K = None
 
     def get_problem_horizon(self, tf):
         if tf is None:
@@ -122,133 +227,115 @@ class ilqr(TemplateController):
         return tf, int(tf / self.dt)
 
     def validate_problem(self):
-        assert self.target.z is not None and self.target.Hf is not None
-        assert self.target.Hf.shape[0] == self.target.z.shape[-1]
-        assert self.target.z.ndim <= 2
-        if self.target.z.ndim == 2:
-            self.setpoint_reaching = False
-        assert (np.asarray(self.target.Hf @ self.dyn_sys.rom.V) == self.dyn_sys.H).all()
-        output_dim = self.dyn_sys.get_output_dim()
+        tgt, cost = self.target, self.cost_params
+        assert tgt.z is not None and tgt.Hf is not None
+        assert tgt.z.ndim <= 2 and tgt.Hf.shape[0] == tgt.z.shape[-1]
+        self.setpoint_reaching = tgt.z.ndim < 2
+        assert (np.asarray(tgt.Hf @ self.dyn_sys.rom.V) == self.dyn_sys.H).all()      # same output map as the model
+        n_out = self.dyn_sys.get_output_dim()
+        assert cost.Q.shape == (n_out, n_out) and cost.R.shape == (self.input_dim, self.input_dim)
         if self.setpoint_reaching:
-            assert self.cost_params.Qf.shape == (output_dim, output_dim)
-        assert self.cost_params.Q.shape == (output_dim, output_dim)
-        assert self.cost_params.R.shape == (self.input_dim, self.input_dim)
+            assert cost.Qf.shape == (n_out, n_out)
 
     def compute_policy(self, t_step, x_belief):
+        steps = self.planning_horizon + 1
         if self.setpoint_reaching:
-            self.policy.set_target(np.repeat(self.target.z[np.newaxis, :], self.planning_horizon + 1, axis=0))
+            z = np.tile(self.target.z, (steps, 1))
         else:
-            z_interp = interp1d(self.target.t, self.target.z, axis=0)
-            self.policy.set_target(z_interp(np.linspace(0, self.final_time, self.planning_horizon + 1)))
+            z = interp1d(self.target.t, self.target.z, axis=0)(np.linspace(0, self.final_time, steps))
+        self.policy.set_target(z)
         self.x_bar, self.u_bar, self.K = self.policy.ilqr_computation(x_belief)
 
     def compute_input(self, t_step, x_belief):
-        if t_step > self.final_time:
-            self.u = self.u0
-        else:
-            step = int(t_step / self.dt)
-            self.u = self.u_bar[step] + self.K[step] @ (x_belief - self.x_bar[step])
+        self.u = _tracking_input(self, t_step, x_belief)
         return self.u
 
 
 class scp(TemplateController):
-    """controllers.py:209-346.  `client` is any object with the GuSTOClientNode protocol (scp/ros.py:162-223);
-    `solver_node` (a scp.standalone.GuSTOSolverNode) is wrapped into the in-process `GuSTOClient`."""
+    """Receding-horizon SCP (GuSTO) with an LQR around the stitched plan.
+
+    Every `N_replan` control steps the next plan is requested from the solver client, starting from the END of the
+    current tape (or from the current belief with mpc=True) so that the solver works one plan ahead of the robot;
+    with wait=False the request runs on the GPU while the simulation goes on.  Feedback: the DARE gain of the TPWL
+    point nearest to the plan's state (all points in one batched launch at start-up).
+    `client`: any GuSTOClientNode-protocol object; or `solver_node`: a GuSTOSolverNode, wrapped in `GuSTOClient`."""
 
     def __init__(self, dyn_sys, cost, dt, N_replan=None, observer=None, delay=2, u0=None, wait=True, client=None,
                  solver_node=None, **kwargs):
         super().__init__(dyn_sys, None, dt=dt, observer=observer, delay=delay, u0=u0)
-        self.N_replan = N_replan if N_replan is not None else 1
-        self.t_opt = None
-        self.u_opt = None
-        self.x_opt = None
-        self.u_bar = None
-        self.x_bar = None
-        self.wait = wait
-        self.t_next_solve = 0
-        self.initialized = False
-        self.solve_times = []
         if client is None:
             if solver_node is None:
                 raise RuntimeError('scp needs client= (GuSTOClientNode protocol) or solver_node= (GuSTOSolverNode)')
             client = GuSTOClient(solver_node)
         self.GuSTO = client
-        self.z_opt_horizon = []
-        self.t_opt_horizon = []
+        self.N_replan = 1 if N_replan is None else N_replan
+        self.wait = wait
         self.mpc = kwargs.pop('mpc', False)
-        # per-point LQR gains (controllers.py:238-246: scipy dare per point) in one batched launch
-        Ad, Bd = [], []
-        for i in range(self.dyn_sys.num_points):
-            A_d, B_d, _ = self.dyn_sys.discretize_dynamics(self.dyn_sys.tpwl_dict['A_c'][i], self.dyn_sys.tpwl_dict['B_c'][i],
-                                                            self.dyn_sys.tpwl_dict['d_c'][i], dt)
-            Ad.append(A_d); Bd.append(B_d)
-        Kb, _ = dare_batch(np.stack(Ad), np.stack(Bd), cost.Q, cost.R)
-        self.K = [Kb[i] for i in range(Kb.shape[0])]
+        self._tape = _PlanTape(dt, self.N_replan)
+        self.initialized = False
+        self.t_next_solve = 0
+        self.solve_times = []
+        self.z_opt_horizon, self.t_opt_horizon = [], []
+        self.K = self._point_gains(cost, dt)
 
-    def compute_policy(self, t_step, x_belief):
-        """controllers.py:248-274."""
-        if not self.initialized:
-            self.run_GuSTO(t_step, x_belief, wait=True)
-            self.update_policy(init=True)
-            self.initialized = True
-        else:
-            self.update_policy()
-        self.t_next_solve = round(self.t_opt[-1], 6)
-        x0 = x_belief if self.mpc else self.x_opt[-1, :]
-        self.run_GuSTO(self.t_opt[-1], x0, wait=self.wait)
+    def _point_gains(self, cost, dt):
+        tab = self.dyn_sys.tpwl_dict
+        disc = [self.dyn_sys.discretize_dynamics(tab['A_c'][i], tab['B_c'][i], tab['d_c'][i], dt)[:2]
+                for i in range(self.dyn_sys.num_points)]
+        gains, _ = dare_batch(np.stack([a for a, _ in disc]), np.stack([b for _, b in disc]), cost.Q, cost.R)
+        return list(gains)
+
+    # tape views under the reference's attribute names
+    t_opt = property(lambda self: self._tape.t)
+    u_opt = property(lambda self: self._tape.u)
+    x_opt = property(lambda self: self._tape.x)
+
+    def u_bar(self, t):
+        return self._tape.u_at(t)
+
+    def x_bar(self, t):
+        return self._tape.x_at(t)
+
+    def recompute_policy(self, t_step):
+        return _on_grid(t_step) >= _on_grid(self.t_next_solve)
 
     def run_GuSTO(self, t0, x0, wait):
         self.GuSTO.send_request(t0, x0, wait=wait)
 
-    def recompute_policy(self, t_step):
-        return round(t_step, 4) >= round(self.t_next_solve, 4)
+    def compute_policy(self, t_step, x_belief):
+        if not self.initialized:
+            self.run_GuSTO(t_step, x_belief, wait=True)          # nothing to execute yet: the first plan is awaited
+            self.initialized = True
+        self.update_policy()
+        self.t_next_solve = round(self._tape.t_end, 6)
+        start = x_belief if self.mpc else self._tape.x[-1]
+        self.run_GuSTO(self._tape.t_end, start, wait=self.wait)
 
-    def update_policy(self, init=False):
-        """controllers.py:288-324."""
+    def update_policy(self, init=None):
+        """Take the finished plan from the client and append its first N_replan steps to the tape."""
         if not self.GuSTO.check_if_done():
             print('GuSTO cannot provide real-time compatibility, consider modifying problem')
             self.GuSTO.force_wait()
-        t_opt_p, u_opt_p, x_opt_p, t_solve = self.GuSTO.get_solution(self.state_dim, self.input_dim)
+        t_plan, u_plan, x_plan, t_solve = self.GuSTO.get_solution(self.state_dim, self.input_dim)
         self.solve_times.append(t_solve)
-        u_opt_intp = interp1d(t_opt_p, np.vstack((u_opt_p, u_opt_p[-1, :])), axis=0)
-        x_opt_intp = interp1d(t_opt_p, x_opt_p, axis=0)
-        if init:
-            t_opt_new = self.dt * np.arange(self.N_replan + 1)
-            self.t_opt = t_opt_new
-            self.u_opt = u_opt_intp(t_opt_new)
-            self.x_opt = x_opt_intp(t_opt_new)
-        else:
-            t_opt_new = self.t_opt[-1] + self.dt * np.arange(self.N_replan + 1)
-            u_opt_new = u_opt_intp(t_opt_new)
-            x_opt_new = x_opt_intp(t_opt_new)
-            self.t_opt = np.concatenate((self.t_opt, t_opt_new[1:]))
-            self.u_opt = np.concatenate((self.u_opt[:-1, :], u_opt_new))
-            self.x_opt = np.concatenate((self.x_opt, x_opt_new[1:, :]))
-        self.z_opt_horizon.append(self.dyn_sys.x_to_zfyf(x_opt_p, zf=True))
-        self.t_opt_horizon.append(t_opt_p)
-        self.u_bar = interp1d(self.t_opt, self.u_opt, axis=0)
-        self.x_bar = interp1d(self.t_opt, self.x_opt, axis=0)
+        self._tape.append(t_plan, u_plan, x_plan)
+        self.t_opt_horizon.append(t_plan)
+        self.z_opt_horizon.append(self.dyn_sys.x_to_zfyf(x_plan, zf=True))
 
     def compute_input(self, t_step, x_belief):
-        """controllers.py:326-333."""
         self.GuSTO.force_spin()
-        i_near = self.dyn_sys.calc_nearest_point(self.x_bar(t_step))
-        return self.u_bar(t_step) + self.K[i_near] @ (x_belief - self.x_bar(t_step))
+        x_plan = self._tape.x_at(t_step)
+        gain = self.K[self.dyn_sys.calc_nearest_point(x_plan)]
+        return self._tape.u_at(t_step) + gain @ (x_belief - x_plan)
 
     def save_controller_info(self):
-        info = dict()
-        info['t_opt'] = self.t_opt
-        info['u_opt'] = self.u_opt
-        info['z_opt'] = self.dyn_sys.x_to_zfyf(self.x_opt, zf=True)
-        info['solve_times'] = self.solve_times
-        info['rollout_time'] = self.N_replan * self.dt
-        info['z_rollout'] = self.z_opt_horizon
-        info['t_rollout'] = self.t_opt_horizon
-        return info
+        return {'t_opt': self.t_opt, 'u_opt': self.u_opt, 'z_opt': self.dyn_sys.x_to_zfyf(self.x_opt, zf=True),
+                'solve_times': self.solve_times, 'rollout_time': self.N_replan * self.dt,
+                'z_rollout': self.z_opt_horizon, 't_rollout': self.t_opt_horizon}
 
 
 class TrajTracking(TemplateController):
-    """controllers.py:349-395."""
+    """TV-LQR around a given (t, x, u) trajectory; the gains come from one device launch at construction."""
 
     def __init__(self, dyn_sys, cost_params, target, dt=0.01, observer=None, delay=2., u0=None, **kwargs):
         super().__init__(dyn_sys=dyn_sys, cost_params=cost_params, dt=dt, observer=observer, delay=delay, u0=u0)
@@ -259,27 +346,22 @@ class TrajTracking(TemplateController):
         self.x_bar, self.u_bar, self.K = self.policy.compute_policy(self.target)
 
     def validate_problem(self):
-        assert self.target.x is not None and self.target.u is not None and self.target.t is not None
-        assert self.target.x.ndim == 2 and self.target.u.ndim == 2
-        assert self.target.u.shape[-1] == self.input_dim
-        assert self.target.x.shape[-1] == self.state_dim
-        assert self.cost_params.Q.shape == (self.state_dim, self.state_dim)
-        assert self.cost_params.R.shape == (self.input_dim, self.input_dim)
+        tgt, cost = self.target, self.cost_params
+        assert tgt.t is not None and tgt.x is not None and tgt.u is not None
+        assert tgt.x.ndim == 2 and tgt.x.shape[-1] == self.state_dim
+        assert tgt.u.ndim == 2 and tgt.u.shape[-1] == self.input_dim
+        assert cost.Q.shape == (self.state_dim, self.state_dim) and cost.R.shape == (self.input_dim, self.input_dim)
 
     def compute_policy(self, t_step, x_belief):
-        pass
+        """The policy is fixed at construction."""
 
     def compute_input(self, t_step, x_belief):
-        if t_step > self.final_time:
-            self.u = self.u0
-        else:
-            step = int(t_step / self.dt)
-            self.u = np.atleast_1d(self.u_bar[step] + self.K[step] @ (x_belief - self.x_bar[step]))
+        self.u = np.atleast_1d(_tracking_input(self, t_step, x_belief))
         return self.u
 
 
 class StateDLQR(TemplateController):
-    """controllers.py:398-437."""
+    """Infinite-horizon discrete LQR about one (A, B, x, u) operating point."""
     LQR_type = DLQR
 
     def __init__(self, dyn_sys, cost_params, target, dt=0.01, observer=None, delay=2, u0=None, **kwargs):
@@ -290,15 +372,13 @@ class StateDLQR(TemplateController):
         self.x_bar, self.u_bar, self.K = self.policy.compute_policy(target=self.target)
 
     def validate_problem(self):
-        assert self.target.A is not None and self.target.B is not None and self.target.u is not None \
-            and self.target.x is not None
-        assert self.target.A.shape == (self.state_dim, self.state_dim)
-        assert self.target.B.shape == (self.state_dim, self.input_dim)
-        assert self.cost_params.Q.shape == (self.state_dim, self.state_dim)
-        assert self.cost_params.R.shape == (self.input_dim, self.input_dim)
+        tgt, cost = self.target, self.cost_params
+        assert all(v is not None for v in (tgt.A, tgt.B, tgt.x, tgt.u))
+        assert tgt.A.shape == (self.state_dim, self.state_dim) and tgt.B.shape == (self.state_dim, self.input_dim)
+        assert cost.Q.shape == (self.state_dim, self.state_dim) and cost.R.shape == (self.input_dim, self.input_dim)
 
     def compute_policy(self, t_step, x_belief):
-        pass
+        """The policy is fixed at construction."""
 
     def compute_input(self, t_step, x_belief):
         self.u = self.u_bar + self.K @ (x_belief - self.x_bar)

@@ -1,167 +1,165 @@
-"""Target containers (sofacontrol/tpwl/tpwl_utils.py:5-38)."""
+"""TPWL model assembly: full-order linearisation points -> reduced piecewise-affine model, on the device.
+
+Protocol of sofacontrol/tpwl/tpwl_utils.py: `Target` / `DynamicsTarget` containers and
+`TPWLSnapshotData` with `save_snapshot(point, prev_point) -> bool`, `add_point(point)`, `simulation_end(filename)`,
+the data dictionary `dict` (keys q, v, u, K, D, M, S, H, b, f, q+, v+, A_c, B_c, d_c, A_d, B_d, d_d, rom_info,
+info, dt -- the on-disk format TPWLATV loads) and the acceptance tests `evaluate_point_dist/_dynamics`.  Behaviour
+pinned by the golden g12 (recorded from the imported reference).
+
+Every full-order quantity of a point goes through the POD handle: states by `compute_RO_state`, the n_f x n_f
+matrices K, D, M, S by `compute_RO_matrix` (ONE HBM pass over each 191 MB matrix at the Diamond size), H / b / f by
+the left projection.  What is left for the host is r x r algebra (`extract_AB`, `extract_AB_d`), once per point.
+"""
 import numpy as np
 
 from .. import utils as scutils
 
 
 class Target:
+    """What a controller should reach: times `t`, outputs `z`, inputs `u`, reduced states `x`, output selector `Hf`."""
+
     def __init__(self):
-        self.t = None
-        self.u = None
-        self.z = None
-        self.x = None
-        self.Hf = None
+        self.t = self.u = self.z = self.x = self.Hf = None
 
     def load_target_file(self, file):
-        data = scutils.load_data(file)
-        self.t = data.get('t')
-        self.u = data.get('u')
-        self.z = data.get('z')
-        self.Hf = data.get('Hf')
+        stored = scutils.load_data(file)
+        for key in ('t', 'u', 'z', 'Hf'):
+            setattr(self, key, stored.get(key))
 
 
 class DynamicsTarget(Target):
+    """An operating point (A, B, x, u) for the LQR controllers."""
+
     def __init__(self):
         super().__init__()
-        self.A = None
-        self.B = None
-        self.x = None
+        self.A = self.B = None
+
+
+# how each field of a full-order point is reduced: (dictionary key, attribute of the point, reducer name)
+_REDUCTIONS = (
+    ('q', 'q', 'pos'), ('v', 'v', 'vel'), ('u', 'u', 'keep'),
+    ('K', 'K', 'both'), ('D', 'D', 'both'), ('M', 'M', 'both'),
+    ('b', 'b', 'left'), ('f', 'f', 'left'), ('H', 'H', 'left'), ('S', 'S', 'both'),
+    ('q+', 'q_next', 'pos'), ('v+', 'v_next', 'vel'),
+)
+_MODEL_KEYS = ('A_c', 'B_c', 'd_c', 'A_d', 'B_d', 'd_d', 'z', 'z_est')
 
 
 class TPWLSnapshotData(scutils.SnapshotData):
-    """sofacontrol/tpwl/tpwl_utils.py:40-290: collects the points of a TPWL model.  Every full-order quantity
-    of a point (q, v, K, D, M, S, H, b, f, q+, v+) is reduced on the device (POD.compute_RO_state /
-    compute_RO_matrix: one HBM pass over each n_f x n_f matrix); the r x r assembly of (A_c, B_c, d_c) and
-    (A_d, B_d, d_d) that follows is one-off host algebra like in the reference."""
-
     def __init__(self, rom, config, info=None, Hf=None):
         super().__init__(save_dynamics=True)
-        for k in ('A_c', 'B_c', 'd_c', 'A_d', 'B_d', 'd_d', 'z', 'z_est'):
-            self.dict[k] = []
-        self.rom = rom
-        self.dict['rom_info'] = self.rom.get_info()
-        self.config = config
-        if self.config.eval_type == 'dynamics':
-            self.sim_sys_class = self.config.sim_sys
-            self.sim_sys_params = self.config.constants_sim
-        self.info = dict() if info is None else info
-        self.save_step = 0
+        self.rom, self.config, self.Hf = rom, config, Hf
+        self.dict.update({k: [] for k in _MODEL_KEYS})
+        self.dict['rom_info'] = rom.get_info()
+        self.info = {} if info is None else info
         self.saved_tpwl_steps = []
-        self.Hf = Hf
+        self.save_step = 0
+        if config.eval_type == 'dynamics':          # acceptance by one-step prediction error of the model so far
+            self.sim_sys_class, self.sim_sys_params = config.sim_sys, config.constants_sim
+        self._reduce = {
+            'pos': lambda a: rom.compute_RO_state(qf=a), 'vel': lambda a: rom.compute_RO_state(vf=a),
+            'both': rom.compute_RO_matrix, 'left': lambda a: rom.compute_RO_matrix(a, left=True), 'keep': lambda a: a}
+
+    # ---- collection protocol
+    def save_snapshot(self, point, prev_point):
+        return False if prev_point is None else self.evaluate_point(point, prev_point)
 
     def add_point(self, point):
-        """tpwl_utils.py:84-117."""
-        if self.dict['dt'] == -1:
-            self.dict['dt'] = point.dt
+        store = self.dict
+        if store['dt'] == -1:
+            store['dt'] = point.dt
         self.saved_tpwl_steps.append(point.t)
         print('Time: {}, Number of points saved: {}'.format(point.t, len(self.saved_tpwl_steps)))
-        rom = self.rom
-        self.dict['q'].append(rom.compute_RO_state(qf=point.q))
-        self.dict['v'].append(rom.compute_RO_state(vf=point.v))
-        self.dict['u'].append(point.u)
-        self.dict['K'].append(rom.compute_RO_matrix(point.K))
-        self.dict['D'].append(rom.compute_RO_matrix(point.D))
-        self.dict['M'].append(rom.compute_RO_matrix(point.M))
-        self.dict['b'].append(rom.compute_RO_matrix(point.b, left=True))
-        self.dict['f'].append(rom.compute_RO_matrix(point.f, left=True))
-        self.dict['H'].append(rom.compute_RO_matrix(point.H, left=True))
-        self.dict['S'].append(rom.compute_RO_matrix(point.S))
-        self.dict['q+'].append(rom.compute_RO_state(qf=point.q_next))
-        self.dict['v+'].append(rom.compute_RO_state(vf=point.v_next))
+        for key, attr, how in _REDUCTIONS:
+            store[key].append(self._reduce[how](getattr(point, attr)))
         if self.config.save_continuous_TPWL:
             self.add_continuous_TPWL()
         if self.config.save_discrete_TPWL:
             self.add_discrete_TPWL()
         if self.config.eval_type == 'dynamics':
-            self.sim_sys = self.sim_sys_class(data=self.dict, params=self.sim_sys_params)
-
-    def save_snapshot(self, point, prev_point):
-        return self.evaluate_point(point, prev_point) if prev_point is not None else False
+            self.sim_sys = self.sim_sys_class(data=store, params=self.sim_sys_params)
 
     def simulation_end(self, filename):
-        """tpwl_utils.py:130-153."""
+        cfg = self.config
         print('Computed TPWL, resulting in %d linearization points' % len(self.saved_tpwl_steps))
-        self.info['state_dim'] = str(self.rom.rom_dim)
-        self.info['nbr_lin'] = str(len(self.saved_tpwl_steps))
-        self.info['saved_step_nbrs'] = self.saved_tpwl_steps
-        self.info['tpwl_method'] = self.config.eval_type
-        self.info['tpwl_parameters'] = vars(self.config)
-        self.info['tpwl_type'] = self.config.TPWL_type
-        self.info['discr_type'] = self.config.discr_type
-        if self.config.eval_type == 'dynamics':
-            del self.info['tpwl_parameters']['sim_sys']
+        self.info.update(state_dim=str(self.rom.rom_dim), nbr_lin=str(len(self.saved_tpwl_steps)),
+                         saved_step_nbrs=self.saved_tpwl_steps, tpwl_method=cfg.eval_type, tpwl_parameters=vars(cfg),
+                         tpwl_type=cfg.TPWL_type, discr_type=cfg.discr_type)
+        if cfg.eval_type == 'dynamics':
+            del self.info['tpwl_parameters']['sim_sys']         # a class object: not part of the stored parameters
         self.dict['info'] = self.info
         print('Saving TPWL data to {}...'.format(filename))
         scutils.dict_lists_to_array(self.dict)
         scutils.save_data(filename, self.dict)
         print('Done.')
 
+    # ---- does a candidate point add information?
     def evaluate_point(self, point, prev_point):
         if not self.dict['q']:
-            return True
+            return True                                          # the first point always enters the model
         if self.config.eval_type == 'distance':
             return self.evaluate_point_dist(point)
-        elif self.config.eval_type == 'dynamics':
+        if self.config.eval_type == 'dynamics':
             return self.evaluate_point_dynamics(point, prev_point)
+        return None
+
+    def _beyond_threshold(self, q_part, v_part):
+        """Separate criteria: either part alone may trigger; otherwise their sum is compared."""
+        thr = self.config.TPWL_threshold
+        if self.config.TPWL_separate_calculation:
+            return bool(q_part >= thr or v_part >= thr)
+        return bool(q_part + v_part >= thr)
 
     def evaluate_point_dist(self, point):
-        """tpwl_utils.py:170-196."""
-        q_d = np.asarray(self.rom.compute_RO_state(qf=point.q) - np.asarray(self.dict['q']))
-        v_d = np.asarray(self.rom.compute_RO_state(vf=point.v) - np.asarray(self.dict['v']))
-        q_d = self.config.TPWL_weighting_factors['q'] * np.linalg.norm(q_d, axis=1)
-        v_d = self.config.TPWL_weighting_factors['v'] * np.linalg.norm(v_d, axis=1)
+        """Far enough (weighted reduced distance) from every stored point?"""
+        w = self.config.TPWL_weighting_factors
+        dq = w['q'] * np.linalg.norm(self._reduce['pos'](point.q) - np.asarray(self.dict['q']), axis=1)
+        dv = w['v'] * np.linalg.norm(self._reduce['vel'](point.v) - np.asarray(self.dict['v']), axis=1)
         if self.config.TPWL_separate_calculation:
-            return bool(np.min(q_d) >= self.config.TPWL_threshold or np.min(v_d) >= self.config.TPWL_threshold)
-        return bool(np.min(q_d + v_d) >= self.config.TPWL_threshold)
+            return self._beyond_threshold(np.min(dq), np.min(dv))
+        return self._beyond_threshold(np.min(dq + dv), 0.0)
 
     def evaluate_point_dynamics(self, point, prev_point):
-        """tpwl_utils.py:199-261."""
-        add_point = False
-        if not (prev_point.u == np.zeros_like(prev_point.u)).all():
-            x = scutils.qv2x(point.q, point.v)
-            x_prev = scutils.qv2x(prev_point.q, prev_point.v)
-            x_prev_r = self.rom.compute_RO_state(xf=x_prev)
-            x_r_tpwl = self.sim_sys.update_state(x_prev_r, prev_point.u, prev_point.dt)
-            w = self.config.TPWL_weighting_factors
-            if self.Hf is not None and self.config.output_based:
-                zf_est = self.Hf @ self.rom.compute_FO_state(x=x_r_tpwl)
-                zf = self.Hf @ x
-                if np.linalg.norm(zf_est - zf) >= self.config.TPWL_threshold:
-                    add_point = True
-                self.dict['z_est'].append(zf_est)
-                self.dict['z'].append(zf)
-            else:
-                if not self.config.fom_based:
-                    x_r = self.rom.compute_RO_state(xf=x)
-                    dq, dv = scutils.x2qv(x_r - x_prev_r)
-                    dq_e, dv_e = scutils.x2qv(x_r_tpwl - x_prev_r)
-                else:
-                    x_tpwl = self.rom.compute_FO_state(x=x_r_tpwl)
-                    dq, dv = scutils.x2qv(x - x_prev)
-                    dq_e, dv_e = scutils.x2qv(x_tpwl - x_prev)
-                q_err = w['q'] * np.linalg.norm(dq_e - dq)
-                v_err = w['v'] * np.linalg.norm(dv_e - dv)
-                if self.config.TPWL_separate_calculation:
-                    add_point = bool(q_err >= self.config.TPWL_threshold or v_err >= self.config.TPWL_threshold)
-                else:
-                    add_point = bool(q_err + v_err >= self.config.TPWL_threshold)
-        return add_point
+        """Does the model collected so far mispredict the step prev_point -> point?  (Unactuated steps never add.)"""
+        if not np.any(prev_point.u):
+            return False
+        cfg, rom = self.config, self.rom
+        x_now = scutils.qv2x(point.q, point.v)
+        x_before = scutils.qv2x(prev_point.q, prev_point.v)
+        xr_before = rom.compute_RO_state(xf=x_before)
+        xr_pred = self.sim_sys.update_state(xr_before, prev_point.u, prev_point.dt)
+        if self.Hf is not None and cfg.output_based:
+            z_pred = self.Hf @ rom.compute_FO_state(x=xr_pred)
+            z_true = self.Hf @ x_now
+            self.dict['z_est'].append(z_pred)
+            self.dict['z'].append(z_true)
+            return bool(np.linalg.norm(z_pred - z_true) >= cfg.TPWL_threshold)
+        if cfg.fom_based:          # compare increments in the full-order space
+            true_step, pred_step = x_now - x_before, rom.compute_FO_state(x=xr_pred) - x_before
+        else:                      # ... or in the reduced space
+            true_step, pred_step = rom.compute_RO_state(xf=x_now) - xr_before, xr_pred - xr_before
+        (dq, dv), (dq_p, dv_p) = scutils.x2qv(true_step), scutils.x2qv(pred_step)
+        w = cfg.TPWL_weighting_factors
+        return self._beyond_threshold(w['q'] * np.linalg.norm(dq_p - dq), w['v'] * np.linalg.norm(dv_p - dv))
+
+    # ---- reduced model of the newest point
+    def _last(self, *keys):
+        return [self.dict[k][-1] for k in keys]
 
     def add_continuous_TPWL(self):
-        """tpwl_utils.py:263-276."""
-        d = self.dict
-        A, B = scutils.extract_AB(d['K'][-1], d['D'][-1], d['M'][-1], d['H'][-1])
-        b_n = np.linalg.solve(d['M'][-1], d['f'][-1] + d['K'][-1] @ d['q'][-1])
-        d['A_c'].append(A)
-        d['B_c'].append(B)
-        d['d_c'].append(np.hstack((b_n, np.zeros(np.shape(b_n)))))
+        """x' = A_c x + B_c u + d_c with x = [v; q]: second-order form M v' = -D v - K (q - q_i) + f + H u."""
+        K, D, M, H, f, q = self._last('K', 'D', 'M', 'H', 'f', 'q')
+        A, B = scutils.extract_AB(K, D, M, H)
+        accel0 = np.linalg.solve(M, f + K @ q)
+        self.dict['A_c'].append(A)
+        self.dict['B_c'].append(B)
+        self.dict['d_c'].append(np.concatenate((accel0, np.zeros_like(accel0))))
 
     def add_discrete_TPWL(self):
-        """tpwl_utils.py:279-290."""
-        d = self.dict
-        A_d, B_d = scutils.extract_AB_d(d['S'][-1], d['K'][-1], d['H'][-1], d['dt'])
-        x = scutils.qv2x(d['q'][-1], d['v'][-1])
-        x_next = scutils.qv2x(d['q+'][-1], d['v+'][-1])
-        d['A_d'].append(A_d)
-        d['B_d'].append(B_d)
-        d['d_d'].append(x_next - A_d @ x - B_d @ np.atleast_1d(d['u'][-1]))
+        """x+ = A_d x + B_d u + d_d from the simulator's own step matrix S; d_d closes the recorded step exactly."""
+        S, K, H, q, v, qn, vn, u = self._last('S', 'K', 'H', 'q', 'v', 'q+', 'v+', 'u')
+        A_d, B_d = scutils.extract_AB_d(S, K, H, self.dict['dt'])
+        x, x_next = scutils.qv2x(q, v), scutils.qv2x(qn, vn)
+        self.dict['A_d'].append(A_d)
+        self.dict['B_d'].append(B_d)
+        self.dict['d_d'].append(x_next - A_d @ x - B_d @ np.atleast_1d(u))

@@ -133,3 +133,78 @@ def test_traj_tracking_and_state_dlqr_controllers(golden):
     np.testing.assert_allclose(np.asarray(c2.K), g['dl_K'], rtol=0, atol=2e-3 * np.abs(g['dl_K']).max())   # 1e-4 stopping rule
     us2 = [quiet(c2.evaluate, k * dt, None, g['dl_x_full'][k], np.zeros(3)) for k in range(4)]
     np.testing.assert_allclose(np.stack(us2), g['dl_u'], rtol=0, atol=1e-3 * max(1.0, np.abs(g['dl_u']).max()))
+
+
+def _c2_node(max_iters=500):
+    """A GuSTOSolverNode on BASELINE config C2 (Diamond r = 30, N = 50): one request = tens of milliseconds of GPU work."""
+    import bench
+    import workloads as wl
+    from sofacontrol_amd.scp.standalone import GuSTOSolverNode
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2()
+    tp, gm = bench.build_model(w)
+    node = quiet(GuSTOSolverNode, gm, w['N'], w['dt'], w['Qz'], w['R'], np.zeros(2 * w['r']), t=w['t'], z=w['z'],
+                 U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']), convg_thresh=1e-3, max_gusto_iters=max_iters)
+    return w, tp, node
+
+
+def test_gusto_client_wait_false_is_asynchronous():
+    """send_request(wait=False) (scp/ros.py:183-198) returns while the GPU is still solving; check_if_done polls,
+    force_wait blocks (ros.py:199-210); the result is the one the synchronous request gives."""
+    import time
+    from sofacontrol_amd.tpwl import controllers as ctl
+    w, tp, node_a = _c2_node()
+    _, _, node_s = _c2_node()
+    rng = np.random.default_rng(3)
+    x0 = node_a.xopt[2] + 1e-2 * rng.standard_normal(2 * w['r'])
+    t0 = 2 * w['dt']
+    ca, cs = ctl.GuSTOClient(node_a), ctl.GuSTOClient(node_s)
+    t_start = time.perf_counter()
+    quiet(cs.send_request, t0, x0, wait=True)
+    t_sync = time.perf_counter() - t_start
+    assert cs.check_if_done()
+    t_start = time.perf_counter()
+    ca.send_request(t0, x0, wait=False)
+    t_send = time.perf_counter() - t_start
+    done_at_once = ca.check_if_done()
+    polls = 0
+    while not ca.check_if_done():
+        polls += 1
+        time.sleep(1e-3)
+    t_total = time.perf_counter() - t_start
+    ca.force_wait()
+    assert t_send < 0.25 * t_sync, (t_send, t_sync)           # the request came back long before a solve can finish
+    assert not done_at_once and polls >= 1, (t_send, t_total, t_sync)
+    ta, ua, xa, _ = ca.get_solution(2 * w['r'], w['m'])
+    ts, us, xs, _ = cs.get_solution(2 * w['r'], w['m'])
+    np.testing.assert_array_equal(ta, ts)
+    np.testing.assert_array_equal(ua, us)
+    np.testing.assert_array_equal(xa, xs)
+
+
+def test_scp_controller_wait_false_overlaps_solve_with_simulation_steps():
+    """scp(wait=False) (controllers.py:276-292): evaluate() hands the replan to the GPU and returns; the inputs are the
+    ones the blocking controller computes."""
+    import time
+    from sofacontrol_amd.tpwl import controllers as ctl
+    from sofacontrol_amd.utils import QuadraticCost
+    outs, t_replan_step = {}, {}
+    for wait in (True, False):
+        w, tp, node = _c2_node(max_iters=5)
+        n = 2 * w['r']
+        cost = QuadraticCost(Q=tp.H.T @ w['Qz'] @ tp.H + 1e-2 * np.eye(n), R=1e-3 * np.eye(w['m']))
+        c = quiet(ctl.scp, tp, cost, w['dt'], N_replan=2, delay=0.0, solver_node=node, wait=wait)
+        c.set_sim_timestep(w['dt'])
+        x_ref = np.concatenate((w['v_ref'], w['q_ref']))
+        rng = np.random.default_rng(1)
+        us, ts = [], []
+        for k in range(7):
+            xf = x_ref + 1e-3 * rng.standard_normal(x_ref.size)
+            t_start = time.perf_counter()
+            us.append(quiet(c.evaluate, k * w['dt'], None, xf, np.zeros(w['m'])))
+            ts.append(time.perf_counter() - t_start)
+            if not wait:
+                time.sleep(0.05)            # the "simulation step": the replan finishes in the background
+        outs[wait], t_replan_step[wait] = np.stack(us), ts[2]        # step 2 requests a replan (N_replan = 2)
+    np.testing.assert_allclose(outs[False], outs[True], rtol=0, atol=1e-9 * max(1.0, np.abs(outs[True]).max()))
+    assert t_replan_step[False] < 0.5 * t_replan_step[True], t_replan_step
