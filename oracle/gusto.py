@@ -89,6 +89,7 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
     xs = 1. / np.abs(x_char) if x_char is not None else np.ones(n)
     fs = 1. / np.abs(f_char) if f_char is not None else np.ones(n)
     stage_qp = isinstance(qp_solver, str) and qp_solver == 'riccati_ipm'
+    cond_qp = isinstance(qp_solver, str) and qp_solver == 'condensed_ipm'
     if qp_solver is None:
         def qp_solver(qp):
             w, _, _ = olocp.solve_exact(qp)
@@ -111,6 +112,18 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
             sp = ripm.Problem(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des, Qzf=Qzf, zf=zf,
                               U=U, X=X, Xf=Xf, x_scale=xs)
             x_next, u_next, _, J, _ = ripm.solve(sp)
+        elif cond_qp:
+            # the condensed interior point (numpy statement of csrc/locp_cond.h) with the kernel's control flow: the QP
+            # without its trust-region rows first; the full stage-structured solve only if that minimiser leaves the
+            # trust region
+            from . import riccati_ipm as ripm, condensed_ipm as cipm
+            assert dU is None and obs_lin is None
+            sp = ripm.Problem(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des, Qzf=Qzf, zf=zf,
+                              U=U, X=X, Xf=Xf, x_scale=xs)
+            x_next, u_next, J, info = cipm.solve(sp)
+            J += omega * max(0.0, np.max(np.abs(xs * (x0 - xk[0]))) - delta)       # s_0 (closed form)
+            if not (info['status'] == 'optimal' and info['inside']):
+                x_next, u_next, _, J, _ = ripm.solve(sp)
         else:
             qp = olocp.build_qp(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des,
                                 Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU, x_scale=xs, Hd=H_k, cd=c_k)

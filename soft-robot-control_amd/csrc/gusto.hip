@@ -46,8 +46,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     extern __shared__ __attribute__((aligned(16))) char smem[];
     qp::specialise<MSEL, NSEL>(d);             // compile-time n_u (and n_x) for everything inlined below
     QPLds L;
-    qp_lds_carve(L, (lptr)smem, d, NTHREADS);
-    qp_lds_init(L, d, c);
+    qp_lds_carve(L, (lptr)smem, d, NTHREADS);          // qp::solve fills the constants of the layout it uses
     const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -276,13 +275,16 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
     if (x_char) p2.x_scale = xs.data();
     int rc = build_consts(&p2, pl->C);
     if (rc) { delete pl; return rc; }
-    const QPDims &d = pl->C.dims;
+    QPDims &d = pl->C.dims;
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
                        par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace};
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
     size_t doubles = qp_work_doubles(d) + (N + 1) * n + N * m + 2 * N + (2 * N + 1) / 2 + 8;
+    doubles = (doubles + 3) & ~(size_t)3;
+    d.qc_off = (long long)doubles;                 // the condensed path's block sits behind the SCP loop's own arrays
+    doubles += qc_work_doubles(d);
     pl->work_stride = (doubles + 3) & ~(size_t)3;
-    pl->lds = qp_lds_bytes(d, NTHREADS);
+    pl->lds = qp_kernel_lds_bytes(d);
     if ((rc = pl->fs.upload(fs.data(), sizeof(double) * n)) || (rc = pl->work.alloc(sizeof(double) * pl->work_stride * batch)) ||
         (rc = pl->x0.alloc(sizeof(double) * batch * n)) || (rc = pl->u_init.alloc(sizeof(double) * batch * N * m)) ||
         (rc = pl->x_init.alloc(sizeof(double) * batch * (N + 1) * n)) || (rc = pl->z.alloc(sizeof(double) * batch * (N + 1) * nz)) ||

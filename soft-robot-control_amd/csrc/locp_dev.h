@@ -30,6 +30,10 @@ struct QPDims {
     int max_iter;
     double tol;
     double reg;   // dual (proximal) regularisation of the Newton systems, relative to the dual scale
+    int cond;  // 1: the condensed (output-space) interior point of locp_cond.h serves the QP without trust-region rows
+    int po;    // output directions spanning Cq, X.A, Xf.A (rows of C_o)
+    int KT;    // 16 x 16 tiles along N * po
+    long long qc_off;   // offset (doubles) of the condensed path's HBM block (QCWork) from the problem's work base
 };
 
 namespace qp {
@@ -55,6 +59,11 @@ struct QPConst {                       // shared by the whole batch (HBM/L2 resi
     cgptr HtQz2, HtQzf2;               // 2 H^T Qz, 2 H^T Qzf               (n x nz)
     cgptr R2;                          // 2 R
     cgptr Cq;                          // (nzr x n) with 2 H^T Qz H = Cq^T Cq, or null
+    // condensed path (locp_cond.h): output basis C_o (po x n, orthonormal rows) and everything expressed in it
+    cgptr Co;                          // (po x n)
+    cgptr Sc, ScN;                     // (po x po): 2 H^T Qz H = C_o^T Sc C_o (+ the terminal 2 H^T Qzf H for ScN)
+    cgptr Tx, Txf;                     // (nX x po), (nXf x po): X.A = Tx C_o, Xf.A = Txf C_o
+    cgptr Cz2, Czf2;                   // (po x nz): C_o H^T 2 Qz, C_o H^T 2 Qzf
 };
 
 struct QPDyn {                         // stage dynamics: matrix k at base + idx[k]*size (idx null: k)
@@ -123,6 +132,8 @@ struct QPLds {                         // LDS carve (doubles unless noted)
     liptr flag;                         // 4 ints
     liptr idxl;                         // N ints: region of every stage (copy of dyn.idx, or 0..N-1)
     int psel;                           // region whose [A | B] is in the panel (register copy, same in every thread)
+    lptr base;                          // start of the workgroup's dynamic LDS (the condensed path carves it its own way)
+    bool ready;                         // the Riccati layout holds its constants (qp_lds_init ran and nothing clobbered it)
 };
 
 __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
@@ -134,6 +145,9 @@ __host__ __device__ inline size_t qp_lds_bytes(const QPDims &d, int nthreads) {
 
 __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nthreads) {
     lptr p = base;
+    L.base = base;
+    L.ready = false;
+    L.psel = -1;
     auto take = [&](size_t c) { lptr q = p; p += c; return q; };
     const size_t nk16 = d.split ? (size_t)d.NK : (size_t)((d.n + 15) & ~15);
     L.P = take(nk16 * d.ld); L.AB = take((size_t)d.RW * d.ld); L.W = take((size_t)d.WR * d.ld);
@@ -165,6 +179,7 @@ __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) 
         __syncthreads();
     }
     L.psel = -1;
+    L.ready = true;
     for (int e = tid; e < d.nzr * n; e += nt) {
         const int r = e / n, j = e - r * n;
         L.AB[(d.RC + r) * ld + j] = c.Cq[e];
@@ -1031,6 +1046,10 @@ __device__ __forceinline__ double max_step(const QPDims &d, const QPWork &w, QPL
     return wg::reduce(a, 2, L.red);
 }
 
+}  // namespace qp
+#include "locp_cond.h"
+namespace qp {
+
 // Solve one QP.  Results in w.x, w.u, w.s.  Returns status: 0 optimal, 1 max iterations, 2 numerical failure.
 //
 // One loop drives every Newton system through a single (inlined) copy of the pre-pass and the Riccati
@@ -1045,7 +1064,44 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
     int status = 1, it = 0;
     double J = 0.0;
     const int npass = (prescreen && dfull.tr) ? 2 : 1;
-    for (int pass = 0; pass < npass; ++pass) {
+    int first_pass = 0;
+    // ---- fast path: the QP without its trust-region rows by the condensed interior point (locp_cond.h).  Accepted when
+    // it converges and (trust region present) its minimiser lies inside the trust region -- the same argument as the
+    // prescreen below; otherwise the stage-wise Riccati solve of the full QP follows.
+    if (dfull.cond && (npass == 2 || !dfull.tr)) {
+        const int st = qpc::solve<MSEL, NSEL>(dfull, c, dyn, q, work_base, L.base, L, &it, wout);
+        qp_lds_carve(L, L.base, dfull, nt);            // back to the Riccati layout (its constants are gone: ready = false)
+        if (q.dbg && tid == 0) { q.dbg[8 * 61] = 1.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; }
+        if (st == 0) {
+            QPDims d0 = dfull;
+            d0.tr = 0;
+            QPWork w = wout;
+            const int N = d0.N, n = d0.n;
+            const double s0 = slack0(dfull, c, q, L);
+            for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+            for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
+            __syncthreads();
+            rollout(d0, dyn, q, w.u, w.x, L);
+            J = objective(d0, c, q, w.x, w.u, w.s, L);
+            bool inside = true;
+            if (dfull.tr) {
+                double md = 0.0;
+                for (int e = tid + n; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (w.x[e] - q.xk[e])));
+                md = wg::reduce(md, 1, L.red);
+                inside = md <= q.delta;
+                J += q.omega * s0;
+            }
+            if (q.dbg && tid == 0) q.dbg[8 * 61 + 3] = inside ? 1.0 : 0.0;
+            if (inside) {
+                if (J_out) *J_out = J;
+                if (iters_out) *iters_out = it;
+                return 0;
+            }
+            first_pass = npass - 1;                      // outside the trust region: straight to the full QP
+        }
+    }
+    if (!L.ready) qp_lds_init(L, dfull, c);
+    for (int pass = first_pass; pass < npass; ++pass) {
         // Trust-region prescreen.  The 2n+1 trust-region rows per stage are 90 % of the inequality rows, yet
         // with GuSTO's delta (1e4 initially) they are almost never active.  Pass 0 solves the QP WITHOUT
         // them: if its minimiser satisfies ||xs (x_k - xbar_k)||_inf <= delta for every k then

@@ -22,8 +22,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
     extern __shared__ __attribute__((aligned(16))) char smem[];
     qp::specialise<MSEL, NSEL>(d);             // compile-time n_u (and n_x) for everything inlined below
     QPLds L;
-    qp_lds_carve(L, (lptr)smem, d, NTHREADS);
-    qp_lds_init(L, d, c);
+    qp_lds_carve(L, (lptr)smem, d, NTHREADS);          // qp::solve fills the constants of the layout it uses
     const size_t p = blockIdx.x;
     const size_t N = d.N, n = d.n, m = d.m;
     QPWork w;
@@ -79,7 +78,7 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     QPConstHost C;
     int rc = build_consts(prob, C);
     if (rc) return rc;
-    const QPDims &d = C.dims;
+    QPDims &d = C.dims;
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
     srh::DevBuf dA, dAT, dB, dBT, dD, dx0, dxk, ddel, dom, dz, dzf, dud, ox, ou, os, oJ, ost, oit, work;
     std::vector<double> xk0;
@@ -96,7 +95,8 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     if (z && (rc = dz.upload(z, sizeof(double) * batch * (N + 1) * nz))) return rc;
     if (zf && (rc = dzf.upload(zf, sizeof(double) * batch * nz))) return rc;
     if (u_des && (rc = dud.upload(u_des, sizeof(double) * batch * N * m))) return rc;
-    const size_t stride = (qp_work_doubles(d) + 3) & ~(size_t)3;
+    d.qc_off = (long long)((qp_work_doubles(d) + 3) & ~(size_t)3);
+    const size_t stride = ((size_t)d.qc_off + qc_work_doubles(d) + 3) & ~(size_t)3;
     if ((rc = work.alloc(sizeof(double) * stride * batch))) return rc;
     transpose_batch_kernel<<<(unsigned)(batch * N), 256>>>(dA.as<double>(), batch * N, (int)n, (int)n, dAT.as<double>());
     transpose_batch_kernel<<<(unsigned)(batch * N), 256>>>(dB.as<double>(), batch * N, (int)n, (int)m, dBT.as<double>());
@@ -108,7 +108,7 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     srh::DevBuf dbg;
     const bool want_dbg = getenv("SRH_LOCP_TRACE") != nullptr;
     if (want_dbg) { if ((rc = dbg.alloc(sizeof(double) * 8 * 64))) return rc; (void)hipMemset(dbg.p, 0, sizeof(double) * 8 * 64); b.dbg = dbg.as<double>(); }
-    const size_t lds = qp_lds_bytes(d, NTHREADS);
+    const size_t lds = qp_kernel_lds_bytes(d);
     if ((rc = set_lds_limit(locp_entry(d), lds))) return rc;
     {
         bool launched = false;
@@ -121,6 +121,9 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     if (want_dbg) {
         std::vector<double> t(8 * 64);
         dbg.download(t.data(), sizeof(double) * 8 * 64);
+        fprintf(stderr, "[locp] cond %d po %d KT %d lds %zu; condensed path ran %.0f status %.0f iters %.0f inside %.0f\n", d.cond, d.po, d.KT, lds, t[8*61], t[8*61+1], t[8*61+2], t[8*61+3]);
+        fprintf(stderr, "[locp] condensed laps (SRH_PROFILE build): condense %.0f rows %.0f dual-res %.0f stage-factors %.0f gram %.0f cholesky %.0f grad+newton %.0f steps %.0f\n",
+                t[8*60], t[8*60+1], t[8*60+2], t[8*60+3], t[8*60+4], t[8*60+5], t[8*60+6], t[8*60+7]);
         fprintf(stderr, "[locp] time (shader clocks): init %.0f rows %.0f prepass %.0f ricc_full %.0f ricc_vec %.0f final %.0f\n", t[8*62], t[8*62+1], t[8*62+2], t[8*62+3], t[8*62+4], t[8*62+5]);
         fprintf(stderr, "[locp] riccati laps (SRH_PROFILE build): load %.0f W %.0f BtW %.0f Qu %.0f gain %.0f AtW+finish %.0f vec-backward %.0f forward %.0f\n",
                 t[8*63], t[8*63+1], t[8*63+2], t[8*63+3], t[8*63+4], t[8*63+5], t[8*63+6], t[8*63+7]);

@@ -3,14 +3,19 @@
 #pragma once
 #include "tpwl_host.h"
 #include "locp_dev.h"
+#include <algorithm>
 #include <cstdlib>
+
+#ifndef SRH_QC_MAX_M
+#define SRH_QC_MAX_M 16
+#endif
 
 namespace {
 
 constexpr int NTHREADS = 512;
 
 struct QPConstHost {
-    srh::DevBuf H, Qz, Qzf, R, xs, UA, Ub, XA, Xb, XfA, Xfb, Qx, QxN, HtQz2, HtQzf2, R2, Cq;
+    srh::DevBuf H, Qz, Qzf, R, xs, UA, Ub, XA, Xb, XfA, Xfb, Qx, QxN, HtQz2, HtQzf2, R2, Cq, Co, Sc, ScN, Tx, Txf, Cz2, Czf2;
     QPDims dims{};
     QPConst view() const {
         QPConst c{};
@@ -21,6 +26,7 @@ struct QPConstHost {
         c.QxN = g(QxN); c.HtQz2 = g(HtQz2); c.HtQzf2 = g(HtQzf2);
         c.R2 = g(R2);
         c.Cq = g(Cq);
+        c.Co = g(Co); c.Sc = g(Sc); c.ScN = g(ScN); c.Tx = g(Tx); c.Txf = g(Txf); c.Cz2 = g(Cz2); c.Czf2 = g(Czf2);
         return c;
     }
 };
@@ -128,6 +134,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.max_iter = 60;
     d.tol = 1e-12;
     d.reg = 1e-8;
+    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0;
     std::vector<double> Qx(n * n), QxN(n * n), Ht2(n * nz), Htf2(n * nz, 0.0), R2(m * m), xs(n, 1.0);
     std::vector<double> QzH(nz * n), QzfH(nz * n, 0.0);
     for (int a = 0; a < nz; ++a)
@@ -168,7 +175,126 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
         (rc = up(C.R2, R2.data(), (size_t)m * m)) || (rc = up(C.Cq, Cq.data(), Cq.size())))
         return rc;
     if (pr->Qzf && (rc = up(C.Qzf, pr->Qzf, (size_t)nz * nz))) return rc;
+    // ---- condensed path (locp_cond.h): an orthonormal basis C_o of the row space of [Cq; Cqf; X.A; Xf.A] and the
+    // cost / constraint rows expressed in it.  Enabled when the space is small (po <= 4, N po <= 128) and the LDS
+    // carve fits; SRH_QP_NO_COND=1 switches it off (A/B runs, tests of the Riccati path).
+    {
+        std::vector<double> Cqf;
+        if (pr->Qzf) {
+            std::vector<double> Qs((size_t)nz * nz), wv, V;
+            for (int a = 0; a < nz; ++a) for (int b = 0; b < nz; ++b) Qs[a * nz + b] = 0.5 * (pr->Qzf[a * nz + b] + pr->Qzf[b * nz + a]);
+            jacobi_eig(Qs, nz, wv, V);
+            double wmax = 0.0;
+            for (double x : wv) wmax = std::max(wmax, fabs(x));
+            for (int e = 0; e < nz; ++e) {
+                if (wv[e] <= 1e-13 * wmax) continue;
+                const double sc = sqrt(2.0 * wv[e]);
+                for (int j = 0; j < n; ++j) {
+                    double v = 0.0;
+                    for (int a = 0; a < nz; ++a) v += V[a * nz + e] * pr->H[a * n + j];
+                    Cqf.push_back(sc * v);
+                }
+            }
+        }
+        const int ncq = (int)(Cq.size() / n), ncqf = (int)(Cqf.size() / n);
+        const int rows = ncq + ncqf + pr->nX + pr->nXf;
+        std::vector<double> M((size_t)rows * n);
+        auto rowp = [&](int r) -> const double * {
+            if (r < ncq) return Cq.data() + (size_t)r * n;
+            r -= ncq;
+            if (r < ncqf) return Cqf.data() + (size_t)r * n;
+            r -= ncqf;
+            if (r < pr->nX) return pr->XA + (size_t)r * n;
+            return pr->XfA + (size_t)(r - pr->nX) * n;
+        };
+        for (int r = 0; r < rows; ++r) std::copy(rowp(r), rowp(r) + n, M.begin() + (size_t)r * n);
+        // Gram matrix of the normalised rows; its eigenvectors with non-negligible eigenvalue span the row space
+        std::vector<double> Gm((size_t)n * n, 0.0), wv, V;
+        for (int r = 0; r < rows; ++r) {
+            double nr2 = 0.0;
+            for (int j = 0; j < n; ++j) nr2 += M[(size_t)r * n + j] * M[(size_t)r * n + j];
+            if (nr2 <= 0.0) continue;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) Gm[(size_t)i * n + j] += M[(size_t)r * n + i] * M[(size_t)r * n + j] / nr2;
+        }
+        int po = 0;
+        std::vector<double> Co;
+        if (rows > 0) {
+            jacobi_eig(Gm, n, wv, V);
+            std::vector<int> ord(n);
+            for (int i = 0; i < n; ++i) ord[i] = i;
+            std::sort(ord.begin(), ord.end(), [&](int a, int b) { return wv[a] > wv[b]; });
+            const double wmax = wv[ord[0]];
+            // (eigenvalues of a Gram matrix carry an absolute error ~1e-16 wmax: a direction whose relative singular value is
+            // below 1e-6 counts as dependent -- the reconstruction check below disables the path if that loses a row)
+            while (po < n && wv[ord[po]] > 1e-12 * wmax && wv[ord[po]] > 0.0) ++po;
+            Co.resize((size_t)po * n);
+            for (int a = 0; a < po; ++a)
+                for (int j = 0; j < n; ++j) Co[(size_t)a * n + j] = V[(size_t)j * n + ord[a]];
+        }
+        auto project = [&](const double *rowsrc, int nr, std::vector<double> &T) {      // T = rows Co^T  (nr x po)
+            T.assign((size_t)std::max(1, nr * po), 0.0);
+            for (int r = 0; r < nr; ++r)
+                for (int a = 0; a < po; ++a) {
+                    double v = 0.0;
+                    for (int j = 0; j < n; ++j) v += rowsrc[(size_t)r * n + j] * Co[(size_t)a * n + j];
+                    T[(size_t)r * po + a] = v;
+                }
+        };
+        bool ok = po >= 1 && po <= 4 && N * po <= 128 && m <= SRH_QC_MAX_M && !getenv("SRH_QP_NO_COND");
+        std::vector<double> Tc, Tcf, Tx, Txf, Sc, ScN, Cz2, Czf2;
+        if (ok) {
+            project(Cq.data(), ncq, Tc); project(Cqf.data(), ncqf, Tcf);
+            project(pr->XA, pr->nX, Tx); project(pr->XfA, pr->nXf, Txf);
+            // the basis must reproduce every row (it does by construction; guards the rank threshold)
+            double err = 0.0, scale = 0.0;
+            auto check = [&](const double *rowsrc, int nr, const std::vector<double> &T) {
+                for (int r = 0; r < nr; ++r)
+                    for (int j = 0; j < n; ++j) {
+                        double v = 0.0;
+                        for (int a = 0; a < po; ++a) v += T[(size_t)r * po + a] * Co[(size_t)a * n + j];
+                        err = std::max(err, fabs(v - rowsrc[(size_t)r * n + j]));
+                        scale = std::max(scale, fabs(rowsrc[(size_t)r * n + j]));
+                    }
+            };
+            check(Cq.data(), ncq, Tc); check(Cqf.data(), ncqf, Tcf); check(pr->XA, pr->nX, Tx); check(pr->XfA, pr->nXf, Txf);
+            ok = err <= 1e-10 * std::max(scale, 1e-300);
+        }
+        if (ok) {
+            Sc.assign((size_t)po * po, 0.0); ScN.assign((size_t)po * po, 0.0);
+            for (int a = 0; a < po; ++a)
+                for (int b = 0; b < po; ++b) {
+                    double v = 0.0, vf = 0.0;
+                    for (int r = 0; r < ncq; ++r) v += Tc[(size_t)r * po + a] * Tc[(size_t)r * po + b];
+                    for (int r = 0; r < ncqf; ++r) vf += Tcf[(size_t)r * po + a] * Tcf[(size_t)r * po + b];
+                    Sc[a * po + b] = v; ScN[a * po + b] = v + vf;
+                }
+            Cz2.assign((size_t)po * nz, 0.0); Czf2.assign((size_t)po * nz, 0.0);
+            for (int a = 0; a < po; ++a)
+                for (int b = 0; b < nz; ++b) {
+                    double v = 0.0, vf = 0.0;
+                    for (int i = 0; i < n; ++i) { v += Co[(size_t)a * n + i] * Ht2[(size_t)i * nz + b]; vf += Co[(size_t)a * n + i] * Htf2[(size_t)i * nz + b]; }
+                    Cz2[a * nz + b] = v; Czf2[a * nz + b] = vf;
+                }
+            d.po = po;
+            d.KT = (N * po + 15) / 16;
+            d.cond = 1;
+            if (qpc::lds_doubles(d, NTHREADS) * sizeof(double) > (size_t)160 * 1024) { d.cond = 0; d.po = 0; d.KT = 0; }
+        }
+        if (d.cond) {
+            if ((rc = up(C.Co, Co.data(), Co.size())) || (rc = up(C.Sc, Sc.data(), Sc.size())) || (rc = up(C.ScN, ScN.data(), ScN.size())) ||
+                (rc = up(C.Tx, Tx.data(), (size_t)pr->nX * po)) || (rc = up(C.Txf, Txf.data(), (size_t)pr->nXf * po)) ||
+                (rc = up(C.Cz2, Cz2.data(), Cz2.size())) || (rc = up(C.Czf2, Czf2.data(), Czf2.size())))
+                return rc;
+        }
+    }
     return SRH_OK;
+}
+
+// dynamic LDS of a QP / GuSTO kernel: the larger of the two layouts
+inline size_t qp_kernel_lds_bytes(const QPDims &d) {
+    const size_t a = qp_lds_bytes(d, NTHREADS), b = d.cond ? qpc::lds_doubles(d, NTHREADS) * sizeof(double) : 0;
+    return std::max(a, b);
 }
 
 int set_lds_limit(const void *kernel, size_t bytes) {
