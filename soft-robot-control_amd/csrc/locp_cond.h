@@ -5,16 +5,22 @@
 // drivers: the tip x / y rows, po = 2).  Eliminating the states with the dynamics,
 //     y_k = C_o x_k = yfree_k + sum_{j<k} G[k][j] u_j ,   G[k][j] = C_o A_{k-1} ... A_{j+1} B_j   (po x m),
 // leaves a QP in u alone (N m variables) whose interior-point Newton systems are
-//     M du = rhs ,  M = blkdiag(2R + U.A^T D_u U.A) + G^T blkdiag(S_k) G ,  S_k = Tc^T Tc + Tx^T D_x,k Tx  (po x po).
+//     M du = -g ,  M = blkdiag(D_j) + G^T blkdiag(S_k) G ,  D_j = 2R + U.A^T D_u U.A ,  S_k = Tc^T Tc + Tx^T D_x,k Tx .
 // They are solved in OUTPUT space (Woodbury): with D_j = Ld_j Ld_j^T, S_k = Ls_k Ls_k^T, Gd = Ls^T G Ld^-T,
-//     K = I + Gd Gd^T   (N po x N po: 100 x 100 for both robots at N = 50),   K v = Ls^T G D^-1 rhs ,
-//     du = D^-1 (rhs - G^T Ls v) .
-// Per interior-point iteration: one Gram product (f64 MFMA, accumulated in registers over slabs of the scaled G staged
-// through LDS), one tile Cholesky of K in LDS (diagonal 16 x 16 tiles factored and inverted in registers with
-// v_readlane broadcasts, panel / trailing updates on MFMA), and a handful of mat-vecs with G -- ~2.5 MFLOP instead of
-// the ~50 MFLOP of a backward Riccati factorisation with n_x = 60 states.  Once per QP: G by the adjoint recursion
+//     K = I + Gd Gd^T = R^T R    (N po x N po: 100 x 100 for both robots at N = 50),
+//     t = -D^-1 (gu + G^T gy) ,   K v = Ls^T G t ,   du = t - D^-1 G^T Ls v ,   dy = G du
+// (gu / gy: input / output part of the gradient; the total gradient is formed in u-space BEFORE D^-1 amplifies it --
+// short-cuts through (K - I) lose that cancellation): two products with G and two with G^T per Newton system, G
+// streaming from L2 (180 - 360 KB, ~20 B/clock per CU: tools/probes/mv_probe.hip), everything else in LDS.
+// Per interior-point iteration: one Gram product (f64 MFMA, accumulated in registers over 32-row slabs of the scaled
+// G^T staged through LDS), one tile Cholesky of K in LDS (diagonal 16 x 16 tiles factored and inverted in registers with
+// v_readlane broadcasts, panel / trailing updates on MFMA) -- ~2.5 MFLOP instead of the ~50 MFLOP of a backward
+// Riccati factorisation with n_x = 60 states.  Once per QP: G by the adjoint recursion
 //     Theta_{j-1} = [C_o ; Theta_j A_j] ,  G[:, j] = Theta_j B_j
 // as one MFMA product per stage with the same LDS panel [A_j | B_j] the Riccati path uses.
+// The slack / multiplier / residual of every inequality row live in the REGISTERS of the thread that owns the row
+// (<= 2 rows per thread); only the weights D, the gradient shifts rho and the multipliers go through L2 for the
+// per-stage sums.
 //
 // The iteration (Mehrotra predictor-corrector, starting point, regularised weights, stopping rule) is the one of
 // qp::solve / oracle/riccati_ipm.py; the numpy statement of THIS file is oracle/condensed_ipm.py (newton='output').
@@ -23,108 +29,121 @@
 #pragma once
 
 struct QCWork {                        // per-problem scratch in HBM/L2 (doubles), behind the QPWork block
-    gptr GT;                           // (N m) x ldG : GT[(j,b)][(k-1) po + a] = G[k][a][j][b]; zero where k <= j
-    gptr yf, y, dy;                    // (N+1) x po : free response, current outputs, output step (index k po + a)
+    // (N m) x ldG : GT[(j,b)][(k-1) po + a] = G[k][a][j][b]; zero where k <= j.  Streams from L2 at ~20 B/clock per CU
+    // (tools/probes/mv_probe.hip).  A packed triangular store was tried: its index arithmetic cost more than the bytes.
+    gptr GT;
 };
 
 __host__ __device__ inline int qc_ldg(const QPDims &d) { return 16 * d.KT; }
 __host__ __device__ inline size_t qc_work_doubles(const QPDims &d) {
     if (!d.cond) return 0;
-    return (size_t)d.N * d.m * qc_ldg(d) + 3 * (size_t)(d.N + 1) * d.po + 8;
+    return (size_t)d.N * d.m * qc_ldg(d) + 8;
 }
-__device__ inline void qc_carve(QCWork &w, gptr base, const QPDims &d) {
-    gptr p = base;
-    auto take = [&](size_t c) { gptr q = p; p += c; return q; };
-    w.GT = take((size_t)d.N * d.m * qc_ldg(d));
-    w.yf = take((size_t)(d.N + 1) * d.po); w.y = take((size_t)(d.N + 1) * d.po); w.dy = take((size_t)(d.N + 1) * d.po);
-}
+__device__ inline void qc_carve(QCWork &w, gptr base, const QPDims &d) { w.GT = base; }
 
 namespace qpc {
 
 constexpr int TS = 17;                 // row stride of a 16 x 16 LDS tile (odd: row and column accesses conflict free)
 constexpr int TSZ = 16 * TS;
 constexpr int SR = 32;                 // rows (contraction length) of a Gram slab
+constexpr int QR = 2;                  // inequality rows per thread (register resident)
 
 struct Lds {
-    lptr A;        // [A | B] panel (n16 x ld) while condensing; Gram slab (SR x ldG) afterwards
-    lptr B;        // Theta^T (n16 x ldT) while condensing; upper tiles of K / its Cholesky factor afterwards
+    lptr A;        // [A | B] panel (NK x ld) while condensing; Gram slab (SR x ldG); u-space temporaries otherwise
+    lptr B;        // Theta^T (NK x ldT) while condensing; upper tiles of K / its Cholesky factor afterwards
     lptr Rinv;     // KT tiles: inverses of the diagonal tiles of the factor
-    lptr Ldi;      // N x m x m : Ld_j^-1 (lower)
+    lptr Ldi;      // diagD: N x m, 1 / sqrt(D_j[b][b]);  else N x m x m : Ld_j^-1 (lower)
     lptr Ls;       // N x po x po : Ls_k (lower), index k - 1
-    lptr ua, ub, uc;           // u-space vectors (N m)
-    lptr ya, yb, yc, yd;       // y-space vectors (ldG; index (k-1) po + a)
-    lptr v1, v2, Qu, part, red;
+    lptr u, du;                        // N m
+    lptr y, dy, yf;                    // ldG, index (k-1) po + a, k = 1..N
+    lptr ya, yb, yc, yd, yg;           // y-space temporaries (ldG)
+    lptr UA, Tx;                       // (nU x m), ((nX + nXf) x po): row coefficients
+    lptr v1, v2, Qu, red;
     liptr flag, idxl;
+    liptr goff;                        // N ints: start of the rows (j, .) in the packed G^T
+    lptr ta, tb, tc, part;             // aliases inside region A: u-space temporaries (N m), reduction scratch
 };
 
-__host__ __device__ inline size_t lds_doubles(const QPDims &d, int nthreads) {
+struct Sizes { size_t regA, regB, rinv, ldi, ls, nm4, ldG, ua, tx, ld, idx; };
+__host__ __device__ inline Sizes sizes(const QPDims &d, int nthreads) {
+    Sizes s;
     // the panel and Theta^T need rows up to the contraction extent roundup4(n) only (NK; zero padded)
-    const size_t n16 = (size_t)d.NK, ldG = qc_ldg(d), ldT = ldG + 1, nm = (size_t)d.N * d.m;
-    const size_t regA = n16 * d.ld > (size_t)SR * ldG ? n16 * d.ld : (size_t)SR * ldG;
+    const size_t nk = (size_t)d.NK, nm = (size_t)d.N * d.m;
+    s.ldG = qc_ldg(d);
+    s.nm4 = (nm + 3) & ~(size_t)3;
+    s.regA = nk * d.ld > (size_t)SR * s.ldG ? nk * d.ld : (size_t)SR * s.ldG;
+    const size_t tmp = 3 * s.nm4 + (size_t)nthreads;
+    if (s.regA < tmp) s.regA = tmp;
     const size_t tiles = (size_t)d.KT * (d.KT + 1) / 2 * TSZ;
-    const size_t regB = n16 * ldT > tiles ? n16 * ldT : tiles;
-    return regA + regB + (size_t)d.KT * TSZ + nm * d.m + (size_t)d.N * d.po * d.po + 3 * ((nm + 3) & ~(size_t)3) + 4 * ldG +
-           2 * (size_t)d.ld + 16 + nthreads + 16 + 4 + (size_t)(d.N / 2 + 2);
+    s.regB = nk * (s.ldG + 1) > tiles ? nk * (s.ldG + 1) : tiles;
+    s.rinv = (size_t)d.KT * TSZ;
+    s.ldi = d.diagD ? s.nm4 : nm * d.m;
+    s.ls = (size_t)d.N * d.po * d.po;
+    s.ua = ((size_t)d.nU * d.m + 3) & ~(size_t)3;
+    s.tx = ((size_t)(d.nX + d.nXf) * d.po + 3) & ~(size_t)3;
+    s.ld = ((size_t)d.ld + 3) & ~(size_t)3;
+    s.idx = ((size_t)(d.N / 2 + 2) + 3) & ~(size_t)3;
+    return s;
 }
-
+__host__ __device__ inline size_t lds_doubles(const QPDims &d, int nthreads) {
+    const Sizes s = sizes(d, nthreads);
+    return s.regA + s.regB + s.rinv + s.ldi + s.ls + 2 * s.nm4 + 8 * s.ldG + s.ua + s.tx + 2 * s.ld + 16 + 16 + 4 + 2 * s.idx;
+}
 __device__ inline void lds_carve(Lds &L, lptr base, const QPDims &d, int nthreads) {
+    const Sizes s = sizes(d, nthreads);
     lptr p = base;
     auto take = [&](size_t c) { lptr q = p; p += c; return q; };
-    const size_t n16 = (size_t)d.NK, ldG = qc_ldg(d), ldT = ldG + 1, nm = (size_t)d.N * d.m, nm4 = (nm + 3) & ~(size_t)3;
-    const size_t regA = n16 * d.ld > (size_t)SR * ldG ? n16 * d.ld : (size_t)SR * ldG;
-    const size_t tiles = (size_t)d.KT * (d.KT + 1) / 2 * TSZ;
-    const size_t regB = n16 * ldT > tiles ? n16 * ldT : tiles;
-    L.A = take(regA); L.B = take(regB); L.Rinv = take((size_t)d.KT * TSZ);
-    L.Ldi = take(nm * d.m); L.Ls = take((size_t)d.N * d.po * d.po);
-    L.ua = take(nm4); L.ub = take(nm4); L.uc = take(nm4);
-    L.ya = take(ldG); L.yb = take(ldG); L.yc = take(ldG); L.yd = take(ldG);
-    L.v1 = take(d.ld); L.v2 = take(d.ld); L.Qu = take(16); L.part = take(nthreads); L.red = take(16);
+    L.A = take(s.regA); L.B = take(s.regB); L.Rinv = take(s.rinv); L.Ldi = take(s.ldi); L.Ls = take(s.ls);
+    L.u = take(s.nm4); L.du = take(s.nm4);
+    L.y = take(s.ldG); L.dy = take(s.ldG); L.yf = take(s.ldG);
+    L.ya = take(s.ldG); L.yb = take(s.ldG); L.yc = take(s.ldG); L.yd = take(s.ldG); L.yg = take(s.ldG);
+    L.UA = take(s.ua); L.Tx = take(s.tx);
+    L.v1 = take(s.ld); L.v2 = take(s.ld); L.Qu = take(16); L.red = take(16);
     L.flag = (liptr)take(4);
-    L.idxl = (liptr)take((size_t)(d.N / 2 + 2));
+    L.idxl = (liptr)take(s.idx);
+    L.goff = (liptr)take(s.idx);
+    L.ta = L.A; L.tb = L.A + s.nm4; L.tc = L.A + 2 * s.nm4; L.part = L.A + 3 * s.nm4;
 }
+
+#ifdef SRH_PROFILE
+struct Prof { long long t[24]; long long last; };
+#define QC_SUB(P, x) do { const long long now_ = clock64(); (P).t[x] += now_ - (P).last; (P).last = now_; } while (0)
+#else
+struct Prof { };
+#define QC_SUB(P, x) ((void)0)
+#endif
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int g_c0(const QPDims &d, int j) { return ((j * d.po) >> 4) << 4; }
 __device__ __forceinline__ int tile_index(int I, int J, int KT) { return I * KT - I * (I - 1) / 2 + (J - I); }   // I <= J
 
-// row coefficients of x-stage k, row r, in output coordinates
-__device__ __forceinline__ cgptr xrow_T(const QPDims &d, const QPConst &c, int r) {
-    return r < d.nX ? c.Tx + (size_t)r * d.po : c.Txf + (size_t)(r - d.nX) * d.po;
-}
-
-// out[row] = a_row . (vy, vu)     (d.tr == 0 in this mode: the x rows are the X / Xf rows)
-__device__ __forceinline__ void rows_apply(const QPDims &d, const QPConst &c, cgptr vy, cgptr vu, gptr out) {
-    const int po = d.po, m = d.m;
-    qp::for_rows(d, [&](int row, bool isU, int k, int r) {
-        double acc = 0.0;
-        if (!isU) {
-            cgptr t = xrow_T(d, c, r);
-            for (int a = 0; a < po; ++a) acc = fma(t[a], vy[(size_t)k * po + a], acc);
-        } else {
-            cgptr ua = c.UA + (size_t)r * m, uk = vu + (size_t)k * m;
-            for (int j = 0; j < m; ++j) acc = fma(ua[j], uk[j], acc);
-        }
-        out[row] = acc;
-    });
-}
-
-// ------------------------------------------------------------------ mat-vecs with G (HBM/L2 resident)
-// yv[i] (+)= sum_rows GT[row][i] uv[row]   (uv in LDS, yv in LDS; row (j,b) only reaches columns i >= j po)
+// ------------------------------------------------------------------ products with G (streams from HBM/L2)
+// yv[i] = sum_{rows (j,b), j <= i / po} GT[row][i] uv[row]   (uv, yv in LDS).  512 threads = 4 row groups x 128 columns;
+// every thread issues its loads in blocks of CH independent requests (the latency of L2, not its bandwidth, is what a
+// one-load-per-trip loop would pay).
 __device__ __forceinline__ void g_times(const QPDims &d, const QCWork &w, Lds &L, clptr uv, lptr yv) {
+    constexpr int CH = 16, CW = 128;
     const int ldG = qc_ldg(d), m = d.m, po = d.po, nm = d.N * m, tid = threadIdx.x, nt = blockDim.x;
-    const int CW = 128, G = nt / CW;                       // column lanes per group, row groups
-    const int col = tid % CW, grp = tid / CW;
+    const int G = nt / CW, col = tid % CW, grp = tid / CW;
+    const int cc = col < ldG ? col : ldG - 1;
+    int rmax = (cc / po + 1) * m;                          // rows (j,b) with j <= col / po reach this column
+    if (rmax > nm) rmax = nm;
+    const int cmax = min(ldG - 1, (col | 63));             // wave-uniform bound: the largest column of this wave
+    int rwave = (cmax / po + 1) * m;
+    if (rwave > nm) rwave = nm;
     double acc = 0.0;
-    if (col < ldG && grp < G) {
-        int rmax = (col / po + 1) * m;                     // rows (j,b) with j <= col / po
-        if (rmax > nm) rmax = nm;
-        cgptr g = w.GT + col;
-#pragma unroll 4
-        for (int r = grp; r < rmax; r += G) acc = fma(g[(size_t)r * ldG], uv[r], acc);
+    cgptr g = w.GT + cc;
+    for (int r0 = grp; r0 < rwave; r0 += G * CH) {
+        double gv[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { const int r = r0 + G * t; gv[t] = g[(size_t)(r < nm ? r : nm - 1) * ldG]; }
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { const int r = r0 + G * t; const double uu = uv[r < nm ? r : nm - 1]; acc = fma(gv[t], r < rmax ? uu : 0.0, acc); }
     }
-    if (grp < G) L.part[grp * CW + col] = acc;
+    L.part[grp * CW + col] = acc;
     __syncthreads();
     if (tid < ldG) {
         double s = 0.0;
@@ -134,20 +153,24 @@ __device__ __forceinline__ void g_times(const QPDims &d, const QCWork &w, Lds &L
     __syncthreads();
 }
 
-// out1[row] = sum_i GT[row][i] y1[i]  (and out2 with y2 when y2 != null): 8 lanes per row
-__device__ __forceinline__ void gT_times(const QPDims &d, const QCWork &w, clptr y1, clptr y2, lptr out1, lptr out2) {
+// out1[row] = sum_i GT[row][i] y1[i]  (and out2 with y2 when y2 != null): 8 lanes per row, 16 independent loads each
+__device__ __forceinline__ void gT_times(const QPDims &d, const QCWork &w, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2) {
     const int ldG = qc_ldg(d), m = d.m, po = d.po, nm = d.N * m, tid = threadIdx.x, nt = blockDim.x;
     const int g8 = tid & 7;
     for (int r0 = 0; r0 < nm; r0 += nt / 8) {              // uniform trip count
-        const int r = r0 + (tid >> 3);
+        const int r = r0 + (tid >> 3), rc = r < nm ? r : nm - 1;
+        const int q0 = ((rc / m) * po) >> 3;               // first 8-column group the row reaches
+        cgptr g = w.GT + (size_t)rc * ldG + g8;
+        double gv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int qq = 8 * q < ldG ? q : 0; gv[q] = g[8 * (qq >= q0 ? qq : q0)]; }
         double a1 = 0.0, a2 = 0.0;
-        if (r < nm) {
-            const int i0 = (r / m) * po;                   // first column the row reaches
-            cgptr g = w.GT + (size_t)r * ldG;
-            for (int i = (i0 & ~7) + g8; i < ldG; i += 8) {
-                const double gv = g[i];
-                a1 = fma(gv, y1[i], a1);
-                if (y2) a2 = fma(gv, y2[i], a2);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (8 * q < ldG) {                              // uniform
+                const double gq = q >= q0 ? gv[q] : 0.0;
+                a1 = fma(gq, y1[8 * q + g8], a1);
+                if (y2) a2 = fma(gq, y2[8 * q + g8], a2);
             }
         }
         a1 = wg::group_sum<8>(a1);
@@ -159,21 +182,23 @@ __device__ __forceinline__ void gT_times(const QPDims &d, const QCWork &w, clptr
 
 // ------------------------------------------------------------------ condensation (once per QP)
 // Free response: x (N+1 x n) must hold the zero-input rollout; yf = C_o x.
-// G by the adjoint recursion; Theta^T lives in L.B (n16 x ldT, column i = (k-1) po + a), the stage panel in L.A.
+// G by the adjoint recursion; Theta^T lives in L.B (NK x ldT, column i = (k-1) po + a), the stage panel in L.A.
 template <int MSEL, int NSEL>
 __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, const QPDyn &dyn, cgptr x, QCWork &w, Lds &L) {
     const int N = d.N, n = d.n, m = d.m, po = d.po, ld = d.ld, KT = d.KT, ldG = qc_ldg(d), ldT = ldG + 1;
-    const int n16 = d.NK, NPa = d.NPa;              // rows of the panel / of Theta^T: the contraction extent
+    const int nk = d.NK, NPa = d.NPa;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
-    for (int e = tid; e < (N + 1) * po; e += nt) {
-        const int k = e / po, a = e - k * po;
+    for (int e = tid; e < ldG; e += nt) {
         double v = 0.0;
-        for (int j = 0; j < n; ++j) v = fma(c.Co[(size_t)a * n + j], x[(size_t)k * n + j], v);
-        w.yf[e] = v;
+        if (e < N * po) {
+            const int k = e / po + 1, a = e - (k - 1) * po;
+            for (int j = 0; j < n; ++j) v = fma(c.Co[(size_t)a * n + j], x[(size_t)k * n + j], v);
+        }
+        L.yf[e] = v;
     }
-    for (int e = tid; e < n16 * ldT; e += nt) L.B[e] = 0.0;
-    for (int e = tid; e < n16 * ld; e += nt) L.A[e] = 0.0;
+    for (int e = tid; e < nk * ldT; e += nt) L.B[e] = 0.0;
+    for (int e = tid; e < nk * ld; e += nt) L.A[e] = 0.0;
     __syncthreads();
     // a QPLds view for panel_load: panel in region A
     QPLds P{};
@@ -199,8 +224,8 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
             }
             __builtin_amdgcn_wave_barrier();
             // this wave owns columns 16 ti .. 16 ti + 15 of Theta^T: operands to registers, products, write back in place
-            double bop[(NSEL > 0 ? (NSEL + 3) / 4 : 32)];
             constexpr int KSMAX = NSEL > 0 ? (NSEL + 3) / 4 : 32;
+            double bop[KSMAX];
 #pragma unroll
             for (int s = 0; s < KSMAX; ++s) bop[s] = s < KS ? L.B[(4 * s + kk) * ldT + 16 * ti + l16] : 0.0;
             for (int ci = 0; ci < MT; ++ci) {
@@ -221,21 +246,20 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
 }
 
 // ------------------------------------------------------------------ per-stage pieces of a Newton system
-// gu (N m) -> L.ua, gy (ldG) -> L.ya from the weights `wx` / `wu` = rho (right-hand side) or lam (dual residual)
-__device__ __forceinline__ void gradients(const QPDims &d, const QPConst &c, const QPData &q, const QPWork &w, const QCWork &qw,
-                                          cgptr wrow, lptr gu, lptr gy) {
+// gu (N m), gy (ldG) from the row weights `wrow` = rho (right-hand side) or lam (dual residual), read from L2
+__device__ __forceinline__ void gradients(const QPDims &d, const QPConst &c, const QPData &q, Lds &L, cgptr wrow, lptr gu, lptr gy) {
     const int N = d.N, m = d.m, po = d.po, nz = d.nz, ldG = qc_ldg(d), tid = threadIdx.x, nt = blockDim.x;
     for (int e = tid; e < ldG; e += nt) {
         double g = 0.0;
         if (e < N * po) {
             const int k = e / po + 1, a = e - (k - 1) * po;
             cgptr S = (k == N) ? c.ScN : c.Sc;
-            for (int b = 0; b < po; ++b) g = fma(S[a * po + b], qw.y[(size_t)k * po + b], g);
+            for (int b = 0; b < po; ++b) g = fma(S[a * po + b], L.y[(k - 1) * po + b], g);
             if (q.z) for (int b = 0; b < nz; ++b) g = fma(-c.Cz2[a * nz + b], q.z[(size_t)k * nz + b], g);
             if (k == N && c.Qzf && q.zf) for (int b = 0; b < nz; ++b) g = fma(-c.Czf2[a * nz + b], q.zf[b], g);
             const int nr = qp::xrows_of(d, k);
             cgptr wr = wrow + (size_t)(k - 1) * d.RX;
-            for (int r = 0; r < nr; ++r) g = fma(xrow_T(d, c, r)[a], wr[r], g);
+            for (int r = 0; r < nr; ++r) g = fma(L.Tx[r * po + a], wr[r], g);
         }
         gy[e] = g;
     }
@@ -243,8 +267,8 @@ __device__ __forceinline__ void gradients(const QPDims &d, const QPConst &c, con
     for (int e = tid; e < N * m; e += nt) {
         const int k = e / m, a = e - k * m;
         double g = 0.0;
-        for (int b = 0; b < m; ++b) g = fma(c.R2[a * m + b], w.u[(size_t)k * m + b] - (q.ud ? q.ud[(size_t)k * m + b] : 0.0), g);
-        for (int r = 0; r < d.nU; ++r) g = fma(c.UA[r * m + a], wu[(size_t)k * d.nU + r], g);
+        for (int b = 0; b < m; ++b) g = fma(c.R2[a * m + b], L.u[k * m + b] - (q.ud ? q.ud[(size_t)k * m + b] : 0.0), g);
+        for (int r = 0; r < d.nU; ++r) g = fma(L.UA[r * m + a], wu[(size_t)k * d.nU + r], g);
         gu[e] = g;
     }
     __syncthreads();
@@ -285,49 +309,67 @@ __device__ __forceinline__ void tri_inverse(lptr A, int m) {
     }
 }
 
-// D_j = 2R + U.A^T D_u U.A -> Ld_j^-1 ;  S_k = S*_k + T^T D_x T -> Ls_k.  Returns false when one of them is not PD.
-__device__ __forceinline__ bool stage_factors(const QPDims &d, const QPConst &c, const QPWork &w, Lds &L) {
+// D_j = 2R + U.A^T D_u U.A -> Ld_j^-1 (diagD: the reciprocal square roots of its diagonal);  S_k = S*_k + T^T D_x T -> Ls_k.
+// Returns false when one of them is not positive definite.  Dw = the weights D (L2).
+__device__ __forceinline__ bool stage_factors(const QPDims &d, const QPConst &c, cgptr Dw, Lds &L) {
     const int N = d.N, m = d.m, po = d.po, tid = threadIdx.x, nt = blockDim.x;
-    cgptr Du = w.D + (size_t)N * d.RX;
-    for (int e = tid; e < N * m * m; e += nt) {
-        const int k = e / (m * m), ab = e - k * m * m, a = ab / m, b = ab - a * m;
-        double v = c.R2[ab];
-        for (int r = 0; r < d.nU; ++r) v = fma(c.UA[r * m + a] * Du[(size_t)k * d.nU + r], c.UA[r * m + b], v);
-        L.Ldi[e] = v;
+    cgptr Du = Dw + (size_t)N * d.RX;
+    if (tid == 0) L.flag[0] = 1;
+    __syncthreads();
+    bool ok = true;
+    if (d.diagD) {
+        for (int e = tid; e < N * m; e += nt) {
+            const int k = e / m, b = e - k * m;
+            double v = c.R2[b * m + b];
+            for (int r = 0; r < d.nU; ++r) { const double a = L.UA[r * m + b]; v = fma(a * Du[(size_t)k * d.nU + r], a, v); }
+            ok = ok && (v > 0.0);
+            L.Ldi[e] = 1.0 / sqrt(v);
+        }
+    } else {
+        for (int e = tid; e < N * m * m; e += nt) {
+            const int k = e / (m * m), ab = e - k * m * m, a = ab / m, b = ab - a * m;
+            double v = c.R2[ab];
+            for (int r = 0; r < d.nU; ++r) v = fma(L.UA[r * m + a] * Du[(size_t)k * d.nU + r], L.UA[r * m + b], v);
+            L.Ldi[e] = v;
+        }
     }
     for (int e = tid; e < N * po * po; e += nt) {
         const int k = e / (po * po) + 1, ab = e - (k - 1) * po * po, a = ab / po, b = ab - a * po;
         double v = (k == N ? c.ScN : c.Sc)[ab];
         const int nr = qp::xrows_of(d, k);
-        cgptr Dk = w.D + (size_t)(k - 1) * d.RX;
-        for (int r = 0; r < nr; ++r) { cgptr t = xrow_T(d, c, r); v = fma(t[a] * Dk[r], t[b], v); }
+        cgptr Dk = Dw + (size_t)(k - 1) * d.RX;
+        for (int r = 0; r < nr; ++r) v = fma(L.Tx[r * po + a] * Dk[r], L.Tx[r * po + b], v);
         L.Ls[e] = v;
     }
-    if (tid == 0) L.flag[0] = 1;
     __syncthreads();
-    bool ok = true;
-    // one thread per stage; the input blocks on the first waves, the output blocks from thread 256 on (other SIMDs)
-    if (tid < N) {
+    // one thread per stage; the output blocks from thread 256 on (other SIMDs than the input blocks)
+    if (!d.diagD && tid < N) {
         lptr A = L.Ldi + (size_t)tid * m * m;
         ok = small_chol(A, m);
         if (ok) tri_inverse(A, m);
     }
     const int t2 = tid - (nt >= 512 ? 256 : 64);
-    if (t2 >= 0 && t2 < N) ok = small_chol(L.Ls + (size_t)t2 * po * po, po);
+    if (t2 >= 0 && t2 < N) ok = ok && small_chol(L.Ls + (size_t)t2 * po * po, po);
     if (!ok) L.flag[0] = 0;
     __syncthreads();
     return L.flag[0] != 0;
 }
 
 // ------------------------------------------------------------------ Gram matrix K = I + Gd Gd^T -> upper tiles in L.B
+// Slab = rows (j, b) of Gd^T for the stages j0 .. j0 + cj - 1.  One thread per (stage, column i): it applies Ld_j^-1 to
+// its column of the G^T block and -- po == 2 -- mixes the two columns of an output stage by Ls_k with one DPP swap
+// (otherwise a second pass over the slab does).  With a compile-time n_u the loads of slab s + 1 are issued before the
+// MFMAs of slab s.
 template <int MSEL>
 __device__ __forceinline__ void gram(const QPDims &d, const QCWork &w, Lds &L) {
-    constexpr int MB = MSEL > 0 ? MSEL : 16;       // bound of the register block (rows of a G^T block)
-    const int N = d.N, m = d.m, po = d.po, KT = d.KT, ldG = qc_ldg(d);
+    constexpr bool PIPE = MSEL > 0;
+    constexpr int MB = PIPE ? MSEL : 16;                                   // bound of the register block
+    constexpr int IT = PIPE ? (SR / MB * 128 + 511) / 512 : 1;             // (stage, column) items per thread and slab
+    const int N = d.N, m = d.m, po = d.po, KT = d.KT, ldG = qc_ldg(d), NP = N * po;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int cj = SR / m > 0 ? SR / m : 1;        // stages per slab
-    const int rows_used = cj * m;
+    const int rows_used = (cj * m + 3) & ~3;
     const int ntiles = KT * (KT + 1) / 2;
     wg::qp_d4 acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     // tile t = wave + nw * slot -> (I, J), I <= J (row-major over the upper triangle)
@@ -339,44 +381,92 @@ __device__ __forceinline__ void gram(const QPDims &d, const QCWork &w, Lds &L) {
         while (t >= KT - I) { t -= KT - I; ++I; }
         tI[sl] = I; tJ[sl] = I + t;
     }
-    for (int e = tid; e < SR * ldG; e += nt) L.A[e] = 0.0;      // K padding columns / unused rows stay zero
+    for (int e = tid; e < SR * ldG; e += nt) L.A[e] = 0.0;      // rows beyond cj m stay zero
+    // one item: column i of the G^T block of stage j (m values), zero where the block is structurally zero
+    auto fetch_item = [&](int e, int j0, double (&g)[MB]) {
+        const int jj = e / ldG, i = e - jj * ldG, j = j0 + jj;
+        const bool live = jj < cj && j < N && i < NP && i >= j * po;            // k = i / po + 1 > j
+        const int jc = j < N ? j : N - 1, ic = jj < cj ? i : 0;
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            const double v = w.GT[((size_t)jc * m + (b < m ? b : 0)) * ldG + ic];
+            g[b] = (live && b < m) ? v : 0.0;
+        }
+    };
+    auto store_item = [&](int e, int j0, const double (&g)[MB]) {
+        const int jj = e / ldG, i = e - jj * ldG, j = j0 + jj;
+        const int jc = j < N ? j : N - 1;
+        double t[MB];
+        if (d.diagD) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b) t[b] = b < m ? g[b] * L.Ldi[jc * m + b] : 0.0;
+        } else {
+            clptr Li = L.Ldi + (size_t)jc * m * m;
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                double s = 0.0;
+                if (b < m) {
+#pragma unroll
+                    for (int b2 = 0; b2 < MB; ++b2) if (b2 <= b) s = fma(Li[b * m + b2], g[b2], s);
+                }
+                t[b] = s;
+            }
+        }
+        if (po == 2) {
+            // columns (k, 0) and (k, 1) sit in adjacent lanes: out_0 = t_0 L00 + t_1 L10, out_1 = t_1 L11
+            const int kq = (i < NP ? i : 0) >> 1, a = i & 1;
+            clptr Lk = L.Ls + (size_t)kq * 4;
+            const double l_own = a == 0 ? Lk[0] : Lk[3], l_oth = a == 0 ? Lk[2] : 0.0;
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                const double tp = wg::dpp_mov<0xB1>(t[b]);             // quad_perm [1,0,3,2]: the partner lane
+                if (b < m && jj < cj) L.A[(size_t)(jj * m + b) * ldG + i] = fma(tp, l_oth, t[b] * l_own);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < MB; ++b) if (b < m && jj < cj) L.A[(size_t)(jj * m + b) * ldG + i] = t[b];
+        }
+    };
+    double g[IT][MB];
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) fetch_item(tid + nt * it, 0, g[it]);
+    }
     __syncthreads();
     for (int j0 = 0; j0 < N; j0 += cj) {
-        // ---- fill: block (j, k) of G^T (m x po) -> Ld_j^-1 . blk . Ls_k
-        for (int e = tid; e < cj * N; e += nt) {
-            const int jj = e / N, k = e - jj * N + 1, j = j0 + jj;
-            lptr dst = L.A + (size_t)(jj * m) * ldG + (k - 1) * po;
-            if (j >= N || k <= j) {
-                for (int b = 0; b < m; ++b)
-                    for (int a = 0; a < po; ++a) dst[b * ldG + a] = 0.0;
-                continue;
+        // ---- scale and store the slab
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) store_item(tid + nt * it, j0, g[it]);
+            if (j0 + cj < N) {                             // in flight while this slab is multiplied
+#pragma unroll
+                for (int it = 0; it < IT; ++it) fetch_item(tid + nt * it, j0 + cj, g[it]);
             }
-            clptr Li = L.Ldi + (size_t)j * m * m, Lk = L.Ls + (size_t)(k - 1) * po * po;
-            for (int a = 0; a < po; ++a) {               // one column of the block at a time: t = Ld^-1 g
-                double g[MB];
-#pragma unroll
-                for (int b = 0; b < MB; ++b) g[b] = b < m ? w.GT[((size_t)j * m + b) * ldG + (k - 1) * po + a] : 0.0;
-#pragma unroll
-                for (int b = MB - 1; b >= 0; --b) {      // lower-triangular product, bottom row first (in place)
-                    if (b < m) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int b2 = 0; b2 < MB; ++b2) if (b2 <= b) s = fma(Li[b * m + b2], g[b2], s);
-                        g[b] = s;
-                    }
-                }
-                // times Ls_k (lower): out[:, a2] += t * Ls[a][a2] for a2 <= a
-#pragma unroll
-                for (int b = 0; b < MB; ++b)
-                    if (b < m)
-                        for (int a2 = 0; a2 <= a; ++a2) {
-                            const double add = g[b] * Lk[a * po + a2];
-                            dst[b * ldG + a2] = (a == a2 ? 0.0 : dst[b * ldG + a2]) + add;   // first touch of column a2 is a == a2
-                        }
+        } else {
+            for (int e0 = 0; e0 < cj * ldG; e0 += nt) {    // uniform trip count (the DPP swap needs whole waves)
+                fetch_item(e0 + tid, j0, g[0]);
+                store_item(e0 + tid, j0, g[0]);
             }
         }
         __syncthreads();
-        // ---- accumulate the upper tiles
+        if (po != 2) {
+            // mix the po columns of every output stage by Ls_k (lower): out_a = sum_{a' >= a} t_a' Ls[a'][a]
+            for (int e = tid; e < cj * m * N; e += nt) {
+                const int row = e / N, kq = e - row * N;
+                lptr p = L.A + (size_t)row * ldG + kq * po;
+                clptr Lk = L.Ls + (size_t)kq * po * po;
+                double v[4];
+                for (int a = 0; a < po; ++a) v[a] = p[a];
+                for (int a = 0; a < po; ++a) {
+                    double s = 0.0;
+                    for (int a2 = a; a2 < po; ++a2) s = fma(v[a2], Lk[a2 * po + a], s);
+                    p[a] = s;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- accumulate the upper tiles.  (Advancing the four tiles of a wave together, one k-step at a time with the
+        // operands preloaded, measured slower inside the fused kernels: they sit at the 256-VGPR limit.)
         const int first = (j0 * po) >> 4;              // column tiles below hold only zeros in this slab
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
@@ -415,8 +505,7 @@ __device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
         const double piv = readlane_d(a[s], s);
         ok = ok && (piv > 0.0);
         const double di = rsqrt(piv);
-        // one Newton step on the reciprocal square root: full double accuracy
-        const double di2 = di * (1.5 - 0.5 * piv * di * di);
+        const double di2 = di * (1.5 - 0.5 * piv * di * di);       // one Newton step: full double accuracy
         dinv[s] = di2;
         a[s] *= di2;
 #pragma unroll
@@ -439,15 +528,29 @@ __device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
     return ok;
 }
 
+// T <- T - Ra^T Rb (one 16 x 16 x 16 product)
+__device__ __forceinline__ void tile_update(lptr T, clptr Ra, clptr Rb, int l16, int kk) {
+    wg::qp_d4 acc;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) acc[qd] = T[(kk + 4 * qd) * TS + l16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ra[(4 * s + kk) * TS + l16], Rb[(4 * s + kk) * TS + l16], acc, 0, 0, 0);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) T[(kk + 4 * qd) * TS + l16] = acc[qd];
+}
+
+// Right-looking over tile rows.  Wave 0 owns the critical path: it updates the next diagonal tile first and factors it
+// while the other waves finish the trailing update of the step.
 __device__ __forceinline__ bool tile_cholesky(const QPDims &d, Lds &L) {
     const int KT = d.KT, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
+    if (wave == 0) {
+        const bool ok = chol16(L.B, L.Rinv);
+        if (lane == 0) L.flag[1] = ok ? 1 : 0;
+    }
+    __syncthreads();
     for (int J = 0; J < KT; ++J) {
-        if (wave == 0) {
-            const bool ok = chol16(L.B + (size_t)tile_index(J, J, KT) * TSZ, L.Rinv + (size_t)J * TSZ);
-            if (lane == 0) L.flag[1] = ok ? 1 : 0;
-        }
-        __syncthreads();
         if (L.flag[1] == 0) return false;
         // panel: R_JJ' = Rinv^T K_JJ'   (J' > J), one tile per wave
         clptr Ri = L.Rinv + (size_t)J * TSZ;
@@ -463,26 +566,64 @@ __device__ __forceinline__ bool tile_cholesky(const QPDims &d, Lds &L) {
             for (int qd = 0; qd < 4; ++qd) T[(kk + 4 * qd) * TS + l16] = acc[qd];
         }
         __syncthreads();
-        // trailing update: K_IK -= R_JI^T R_JK  for J < I <= K
+        if (J + 1 >= KT) break;
+        // trailing update: K_IK -= R_JI^T R_JK  for J < I <= K.  Tile (J+1, J+1) by wave 0, which then factors it at once
         const int rem = KT - J - 1, ntr = rem * (rem + 1) / 2;
-        for (int t = wave; t < ntr; t += nw) {
-            int tt = t, Ir = 0;
-            while (tt >= rem - Ir) { tt -= rem - Ir; ++Ir; }
-            const int I = J + 1 + Ir, Kc = I + tt;
-            clptr Ra = L.B + (size_t)tile_index(J, I, KT) * TSZ, Rb = L.B + (size_t)tile_index(J, Kc, KT) * TSZ;
-            lptr T = L.B + (size_t)tile_index(I, Kc, KT) * TSZ;
-            wg::qp_d4 acc;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) acc[qd] = T[(kk + 4 * qd) * TS + l16];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ra[(4 * s + kk) * TS + l16], Rb[(4 * s + kk) * TS + l16], acc, 0, 0, 0);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) T[(kk + 4 * qd) * TS + l16] = acc[qd];
+        if (wave == 0) {
+            clptr Ra = L.B + (size_t)tile_index(J, J + 1, KT) * TSZ;
+            lptr T = L.B + (size_t)tile_index(J + 1, J + 1, KT) * TSZ;
+            tile_update(T, Ra, Ra, l16, kk);
+            __builtin_amdgcn_wave_barrier();
+            const bool ok = chol16(T, L.Rinv + (size_t)(J + 1) * TSZ);
+            if (lane == 0) L.flag[1] = ok ? 1 : 0;
+        } else {
+            for (int t = wave; t < ntr; t += nw - 1) {          // tiles 1 .. ntr-1 over waves 1 .. nw-1 (tile 0 is wave 0's)
+                int tt = t, Ir = 0;
+                while (tt >= rem - Ir) { tt -= rem - Ir; ++Ir; }
+                const int I = J + 1 + Ir, Kc = I + tt;
+                tile_update(L.B + (size_t)tile_index(I, Kc, KT) * TSZ, L.B + (size_t)tile_index(J, I, KT) * TSZ,
+                            L.B + (size_t)tile_index(J, Kc, KT) * TSZ, l16, kk);
+            }
         }
         __syncthreads();
     }
-    return true;
+    return L.flag[1] != 0;
+}
+
+// ---- products with the factor (tile rows / columns over the waves; vectors of 16 KT entries in LDS)
+// out = R x   (R upper: tile row J needs tiles (J, J') for J' >= J)
+__device__ __forceinline__ void r_times(const QPDims &d, Lds &L, clptr x, lptr out) {
+    const int KT = d.KT, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int c = lane & 15, part = lane >> 4;
+    for (int J = wave; J < KT; J += nw) {
+        double acc = 0.0;
+        for (int Jp = J; Jp < KT; ++Jp) {
+            clptr T = L.B + (size_t)tile_index(J, Jp, KT) * TSZ;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) { const int k = 4 * part + kq; acc = fma(T[c * TS + k], x[16 * Jp + k], acc); }
+        }
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (part == 0) out[16 * J + c] = acc;
+    }
+    __syncthreads();
+}
+// out = R^T x   (tile column J needs tiles (I, J) for I <= J)
+__device__ __forceinline__ void rT_times(const QPDims &d, Lds &L, clptr x, lptr out) {
+    const int KT = d.KT, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int c = lane & 15, part = lane >> 4;
+    for (int J = wave; J < KT; J += nw) {
+        double acc = 0.0;
+        for (int I = 0; I <= J; ++I) {
+            clptr T = L.B + (size_t)tile_index(I, J, KT) * TSZ;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) { const int k = 4 * part + kq; acc = fma(T[k * TS + c], x[16 * I + k], acc); }
+        }
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (part == 0) out[16 * J + c] = acc;
+    }
+    __syncthreads();
 }
 
 // v <- K^-1 v (in place, LDS vector of 16 KT entries) by wave 0; ends with a barrier
@@ -542,10 +683,12 @@ __device__ __forceinline__ void k_solve(const QPDims &d, Lds &L, lptr v) {
     __syncthreads();
 }
 
-// t_j <- D_j^-1 r_j = Ld^-T (Ld^-1 r_j)   (in place on an LDS u-space vector; one thread per stage)
+// r_j <- D_j^-1 r_j   (in place on an LDS u-space vector)
 __device__ __forceinline__ void dinv_apply(const QPDims &d, Lds &L, lptr r) {
-    const int m = d.m, tid = threadIdx.x;
-    if (tid < d.N) {
+    const int m = d.m, tid = threadIdx.x, nt = blockDim.x;
+    if (d.diagD) {
+        for (int e = tid; e < d.N * m; e += nt) { const double s = L.Ldi[e]; r[e] *= s * s; }
+    } else if (tid < d.N) {
         clptr Li = L.Ldi + (size_t)tid * m * m;
         lptr v = r + (size_t)tid * m;
         for (int i = m - 1; i >= 0; --i) {               // y = Li v, bottom row first (in place)
@@ -562,49 +705,85 @@ __device__ __forceinline__ void dinv_apply(const QPDims &d, Lds &L, lptr r) {
     __syncthreads();
 }
 
-// Newton direction for the right-hand side -(gu + G^T gy) held as gu in L.ua, gy in L.ya:
-//   du -> w.du (global) and L.uc, dy -> qw.dy.  The factors (stage_factors, gram, tile_cholesky) must be current.
-__device__ __forceinline__ void newton_solve(const QPDims &d, QPWork &w, QCWork &qw, Lds &L) {
-    const int N = d.N, m = d.m, po = d.po, nm = N * m, ldG = qc_ldg(d), tid = threadIdx.x, nt = blockDim.x;
-    gT_times(d, qw, L.ya, (clptr) nullptr, L.ub, (lptr) nullptr);              // ub = G^T gy
-    for (int e = tid; e < nm; e += nt) L.ub[e] = -(L.ua[e] + L.ub[e]);          // rhs
-    __syncthreads();
-    for (int e = tid; e < nm; e += nt) L.uc[e] = L.ub[e];
-    __syncthreads();
-    dinv_apply(d, L, L.uc);                                                     // t = D^-1 rhs
-    g_times(d, qw, L, L.uc, L.yb);                                              // yb = G t
-    if (tid < N) {                                                              // yc_k = Ls_k^T yb_k
+// per output stage: out_k = Ls_k in_k (FWD), Ls_k^T in_k (TR), Ls_k^-1 in_k (INV), Ls_k^-T in_k (INVT); padding zeroed
+enum { LS_FWD = 0, LS_TR = 1, LS_INV = 2, LS_INVT = 3 };
+template <int OP>
+__device__ __forceinline__ void ls_apply(const QPDims &d, Lds &L, clptr in, lptr out) {
+    const int N = d.N, po = d.po, ldG = qc_ldg(d), tid = threadIdx.x, nt = blockDim.x;
+    if (tid < N) {
         clptr Lk = L.Ls + (size_t)tid * po * po;
-        for (int a = 0; a < po; ++a) {
-            double s = 0.0;
-            for (int b = a; b < po; ++b) s = fma(Lk[b * po + a], L.yb[tid * po + b], s);
-            L.yc[tid * po + a] = s;
+        double v[4] = {0.0, 0.0, 0.0, 0.0}, o[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) if (a < po) v[a] = in[tid * po + a];
+        if (OP == LS_FWD) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) if (a < po) { double s = 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (b <= a) s = fma(Lk[a * po + b], v[b], s);
+                o[a] = s; }
+        } else if (OP == LS_TR) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) if (a < po) { double s = 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (b >= a && b < po) s = fma(Lk[b * po + a], v[b], s);
+                o[a] = s; }
+        } else if (OP == LS_INV) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) if (a < po) { double s = v[a];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (b < a) s = fma(-Lk[a * po + b], o[b], s);
+                o[a] = s / Lk[a * po + a]; }
+        } else {
+#pragma unroll
+            for (int a = 3; a >= 0; --a) if (a < po) { double s = v[a];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (b > a && b < po) s = fma(-Lk[b * po + a], o[b], s);
+                o[a] = s / Lk[a * po + a]; }
         }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) if (a < po) out[tid * po + a] = o[a];
     }
-    for (int e = N * po + tid; e < ldG; e += nt) L.yc[e] = 0.0;
-    __syncthreads();
-    k_solve(d, L, L.yc);                                                        // v
-    if (tid < N) {                                                              // yb_k = Ls_k v_k
-        clptr Lk = L.Ls + (size_t)tid * po * po;
-        for (int a = 0; a < po; ++a) {
-            double s = 0.0;
-            for (int b = 0; b <= a; ++b) s = fma(Lk[a * po + b], L.yc[tid * po + b], s);
-            L.yb[tid * po + a] = s;
-        }
-    }
-    for (int e = N * po + tid; e < ldG; e += nt) L.yb[e] = 0.0;
-    __syncthreads();
-    gT_times(d, qw, L.yb, (clptr) nullptr, L.ub, (lptr) nullptr);              // ub = G^T Ls v
-    dinv_apply(d, L, L.ub);
-    for (int e = tid; e < nm; e += nt) { const double v = L.uc[e] - L.ub[e]; L.uc[e] = v; w.du[e] = v; }
-    __syncthreads();
-    g_times(d, qw, L, L.uc, L.yd);                                              // dy = G du
-    for (int e = tid; e < (N + 1) * po; e += nt) qw.dy[e] = e < po ? 0.0 : L.yd[e - po];
+    for (int e = N * po + tid; e < ldG; e += nt) out[e] = 0.0;
     __syncthreads();
 }
 
+// Newton direction.  In: gu in L.ta, gy in L.ya.  Out: du in L.du, dy = G du in L.dy.  If gyd != null the reduced dual
+// residual max |gud + G^T gyd| (gud in L.tb) is returned through *rd -- its G^T pass rides along with the first one.
+// Order of operations: the total gradient g = gu + G^T gy is formed in u-space FIRST (it is small near the solution; the
+// two parts are not), and only then amplified by D^-1 -- algebraically equivalent short-cuts through (K - I) lose the
+// cancellation and leave the dual residual at 1e-7.
+__device__ __forceinline__ void newton_solve(const QPDims &d, QCWork &qw, Lds &L, clptr gyd, double *rd, Prof &pf) {
+    const int nm = d.N * d.m, ldG = qc_ldg(d), tid = threadIdx.x, nt = blockDim.x;
+    QC_SUB(pf, 8);
+    gT_times(d, qw, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr);            // du (scratch) = G^T gy; tc = G^T gyd
+    QC_SUB(pf, 9);
+    if (gyd) {
+        double r = 0.0;
+        for (int e = tid; e < nm; e += nt) r = fmax(r, fabs(L.tb[e] + L.tc[e]));
+        *rd = wg::reduce(r, 1, L.red);
+    }
+    for (int e = tid; e < nm; e += nt) L.ta[e] = -(L.ta[e] + L.du[e]);        // rhs = -g
+    __syncthreads();
+    dinv_apply(d, L, L.ta);                                                   // t = D^-1 rhs
+    QC_SUB(pf, 10);
+    g_times(d, qw, L, L.ta, L.yb);                                            // G t
+    QC_SUB(pf, 11);
+    ls_apply<LS_TR>(d, L, L.yb, L.yc);                                        // Ls^T G t
+    k_solve(d, L, L.yc);                                                      // v
+    QC_SUB(pf, 12);
+    ls_apply<LS_FWD>(d, L, L.yc, L.yd);                                       // Ls v
+    gT_times(d, qw, L, L.yd, (clptr) nullptr, L.du, (lptr) nullptr);             // G^T Ls v
+    QC_SUB(pf, 13);
+    dinv_apply(d, L, L.du);
+    for (int e = tid; e < nm; e += nt) L.du[e] = L.ta[e] - L.du[e];
+    __syncthreads();
+    QC_SUB(pf, 14);
+    g_times(d, qw, L, L.du, L.dy);                                            // dy = G du
+    QC_SUB(pf, 15);
+}
+
 // ------------------------------------------------------------------ the solve
-// Results: w.u (and w.x by the caller's final rollout).  Returns 0 optimal, 1 max iterations, 2 numerical failure.
+// Results: w.u (the caller rolls the states out).  Returns 0 optimal, 1 max iterations, 2 numerical failure.
 template <int MSEL, int NSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                      lptr smem, QPLds &Lq, int *iters_out, QPWork &wout) {
@@ -622,80 +801,97 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
     qc_carve(qw, work_base + dfull.qc_off, dfull);
     Lds L;
     lds_carve(L, smem, d, nt);
-    const int N = d.N, m = d.m, po = d.po, nm = N * m;
+    const int N = d.N, m = d.m, po = d.po, nm = N * m, ldG = qc_ldg(d);
     // a QPLds view on this carve for the shared helpers (rollout, reductions)
     Lq.v1 = L.v1; Lq.v2 = L.v2; Lq.Qu = L.Qu; Lq.part = L.part; Lq.red = L.red; Lq.idxl = L.idxl; Lq.flag = L.flag;
-    for (int e = tid; e < nm; e += nt) w.u[e] = 0.0;
-    for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
-    for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
-    __syncthreads();
-    qp::rollout(d, dyn, q, w.u, w.x, Lq);
-    condense<MSEL, NSEL>(d, c, dyn, w.x, qw, L);
-    for (int e = tid; e < (N + 1) * po; e += nt) { qw.y[e] = qw.yf[e]; qw.dy[e] = 0.0; }
-    __syncthreads();
-    int status = 1, it = 0;
-    enum { INIT = 0, PRED = 1, CORR = 2 };
-    int mode = INIT;
-    double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
-    bool near_opt = false;
+    Prof pf;
 #ifdef SRH_PROFILE
     long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 24; ++i) pf.t[i] = 0;
     long long tq_last = clock64();
     auto qlap = [&](int slot) { const long long now = clock64(); tq[slot] += now - tq_last; tq_last = now; };
 #define QC_LAP(x) qlap(x)
 #else
 #define QC_LAP(x) ((void)0)
 #endif
-    QC_LAP(0);                                      // rollout + condensation
+    for (int e = tid; e < nm; e += nt) { w.u[e] = 0.0; L.u[e] = 0.0; }
+    for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
+    for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+    for (int e = tid; e < d.nU * m; e += nt) L.UA[e] = c.UA[e];
+    for (int e = tid; e < (d.nX + d.nXf) * po; e += nt) L.Tx[e] = e < d.nX * po ? c.Tx[e] : c.Txf[e - d.nX * po];
+    __syncthreads();
+    qp::rollout(d, dyn, q, w.u, w.x, Lq);
+    QC_LAP(0);                                      // set-up + zero-input rollout
+    condense<MSEL, NSEL>(d, c, dyn, w.x, qw, L);
+    for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yf[e]; L.dy[e] = 0.0; }
+    __syncthreads();
+    QC_LAP(2);                                      // condensation
+    // ---- the rows of this thread: slot e = tid + nt q;  x rows (k-1) RX + r, then u rows N RX + k nU + r
+    bool rv[QR], ru[QR];
+    int rk[QR], rr[QR];
+    double rh[QR], rt[QR], rlam[QR], rrg[QR], rrc[QR], rdt[QR], rdl[QR];
+#pragma unroll
+    for (int qi = 0; qi < QR; ++qi) {
+        const int e = tid + nt * qi, nxs = N * d.RX;
+        rt[qi] = rlam[qi] = rrg[qi] = rrc[qi] = rdt[qi] = rdl[qi] = 0.0;
+        if (e < nxs) {
+            rk[qi] = e / d.RX + 1; rr[qi] = e - (rk[qi] - 1) * d.RX; ru[qi] = false;
+            rv[qi] = rr[qi] < qp::xrows_of(d, rk[qi]);
+        } else {
+            const int e2 = e - nxs;
+            ru[qi] = true; rv[qi] = e2 < N * d.nU;
+            rk[qi] = rv[qi] ? e2 / d.nU : 0; rr[qi] = rv[qi] ? e2 - rk[qi] * d.nU : 0;
+        }
+        rh[qi] = rv[qi] ? qp::row_h(d, c, q, ru[qi], rk[qi], rr[qi]) : 0.0;
+    }
+    auto row_val = [&](int qi, clptr vy, clptr vu) {              // a_row . (vy, vu)
+        double acc = 0.0;
+        if (!ru[qi]) { for (int a = 0; a < po; ++a) acc = fma(L.Tx[rr[qi] * po + a], vy[(rk[qi] - 1) * po + a], acc); }
+        else { for (int j = 0; j < m; ++j) acc = fma(L.UA[rr[qi] * m + j], vu[rk[qi] * m + j], acc); }
+        return acc;
+    };
+    int status = 1, it = 0;
+    enum { INIT = 0, PRED = 1, CORR = 2 };
+    int mode = INIT;
+    double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
+    bool near_opt = false;
     while (true) {
         QC_LAP(7);
-        if (mode != CORR) {
-            rows_apply(d, c, qw.y, w.u, w.rg);
-            __syncthreads();
-        }
-        if (mode == INIT) {
-            qp::for_rows(d, [&](int row, bool isU, int k, int r) {
-                const double g = w.rg[row] - qp::row_h(d, c, q, isU, k, r);
-                w.D[row] = d.ng ? 1.0 : 0.0; w.rho[row] = g; w.lam[row] = 0.0;
-            });
-        } else if (mode == PRED) {
-            double musum = 0.0, rpm = 0.0;
-            qp::for_rows(d, [&](int row, bool isU, int k, int r) {
-                const double g = w.rg[row] - qp::row_h(d, c, q, isU, k, r);
-                const double t = w.t[row], lam = w.lam[row];
-                const double rg = g + t;
-                w.rg[row] = rg;
+        // ---------------- rows: weights D and gradient shifts rho of this Newton system -> L2 for the stage sums
+        double musum = 0.0, rpm = 0.0;
+#pragma unroll
+        for (int qi = 0; qi < QR; ++qi) {
+            if (!rv[qi]) continue;
+            const int e = tid + nt * qi;
+            if (mode == INIT) {
+                const double g = row_val(qi, L.y, L.u) - rh[qi];
+                w.D[e] = 1.0; w.rho[e] = g; rlam[qi] = 0.0;
+            } else if (mode == PRED) {
+                const double g = row_val(qi, L.y, L.u) - rh[qi];
+                const double t = rt[qi], lam = rlam[qi], rg = g + t;
+                rrg[qi] = rg;
                 const double D = lam / (t + dreg * lam);
-                w.D[row] = D;
-                w.rho[row] = D * (rg + dreg * lam);
+                w.D[e] = D; w.rho[e] = D * (rg + dreg * lam); w.lam[e] = lam;
                 musum += lam * t;
                 rpm = fmax(rpm, fabs(rg));
-            });
+            } else {
+                const double t = rt[qi], lam = rlam[qi];
+                const double rc = lam * t + rdt[qi] * rdl[qi] - sig * mu;
+                rrc[qi] = rc;
+                w.rho[e] = lam + (lam * rrg[qi] - rc) / (t + dreg * lam);
+            }
+        }
+        if (mode == PRED) {
             mu = wg::reduce(musum, 0, L.red) / d.ng;
             rp = wg::reduce(rpm, 1, L.red);
-        } else {
-            qp::for_rows(d, [&](int row, bool, int, int) {
-                const double t = w.t[row], lam = w.lam[row];
-                const double rc = lam * t + w.dt[row] * w.dlam[row] - sig * mu;
-                w.rc[row] = rc;
-                w.rho[row] = lam + (lam * w.rg[row] - rc) / (t + dreg * lam);
-            });
         }
         __syncthreads();
-        QC_LAP(1);                                  // rows
+        QC_LAP(1);
         // ---------------- Newton system
         double rd = 0.0;
         bool ok = true;
-        if (mode == PRED) {
-            // reduced dual residual: gradient of the Lagrangian wrt u with the true multipliers
-            gradients(d, c, q, w, qw, w.lam, L.ua, L.ya);
-            gT_times(d, qw, L.ya, (clptr) nullptr, L.ub, (lptr) nullptr);
-            for (int e = tid; e < nm; e += nt) rd = fmax(rd, fabs(L.ua[e] + L.ub[e]));
-            rd = wg::reduce(rd, 1, L.red);
-        }
-        QC_LAP(2);                                  // dual residual
         if (mode != CORR) {
-            ok = stage_factors(d, c, w, L);
+            ok = stage_factors(d, c, w.D, L);
             QC_LAP(3);
             if (ok) {
                 gram<MSEL>(d, qw, L);
@@ -704,34 +900,35 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
                 QC_LAP(5);
             }
         }
+#ifdef SRH_PROFILE
+        pf.last = clock64();
+#endif
         if (ok) {
-            gradients(d, c, q, w, qw, w.rho, L.ua, L.ya);
-            newton_solve(d, w, qw, L);
+            if (mode == PRED) gradients(d, c, q, L, w.lam, L.tb, L.yg);          // multipliers: the dual residual
+            gradients(d, c, q, L, w.rho, L.ta, L.ya);
+            newton_solve(d, qw, L, mode == PRED ? (clptr)L.yg : (clptr) nullptr, &rd, pf);
         }
-        QC_LAP(6);                                  // gradients + Newton solve
+        QC_LAP(6);
         // ---------------- use the direction
         if (mode == INIT) {
             if (!ok) { status = 2; break; }
-            for (int e = tid; e < nm; e += nt) w.u[e] += w.du[e];
-            for (int e = tid; e < (N + 1) * po; e += nt) qw.y[e] += qw.dy[e];
+            for (int e = tid; e < nm; e += nt) L.u[e] += L.du[e];
+            for (int e = tid; e < ldG; e += nt) L.y[e] += L.dy[e];
             __syncthreads();
             if (d.ng == 0) { status = 0; break; }
-            rows_apply(d, c, qw.y, w.u, w.rg);
-            __syncthreads();
             double zmin = INFINITY, zmax = -INFINITY;
-            qp::for_rows(d, [&](int row, bool isU, int k, int r) {
-                const double g = w.rg[row] - qp::row_h(d, c, q, isU, k, r);
-                w.rg[row] = g;
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi) {
+                if (!rv[qi]) continue;
+                const double g = row_val(qi, L.y, L.u) - rh[qi];
+                rrg[qi] = g;
                 zmin = fmin(zmin, g); zmax = fmax(zmax, g);
-            });
+            }
             zmin = wg::reduce(zmin, 2, L.red);
             zmax = wg::reduce(zmax, 1, L.red);
             const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
-            qp::for_rows(d, [&](int row, bool, int, int) {
-                const double g = w.rg[row];
-                w.t[row] = -g + sh_t; w.lam[row] = g + sh_l;
-            });
-            __syncthreads();
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi) { rt[qi] = -rrg[qi] + sh_t; rlam[qi] = rrg[qi] + sh_l; }
             for (int e = tid; e < d.n; e += nt) {
                 double g = 0.0;
                 if (q.z) for (int a = 0; a < d.nz; ++a) g = fma(c.HtQz2[e * d.nz + a], -q.z[d.nz + a], g);
@@ -744,6 +941,21 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             mode = PRED;
             continue;
         }
+        // row directions  dt, dlam  and the largest step that keeps t, lam positive
+        double amax = 1e300;
+        if (ok) {
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi) {
+                if (!rv[qi]) continue;
+                const double t = rt[qi], lam = rlam[qi], rga = rrg[qi] + row_val(qi, L.dy, L.du);
+                const double dl = ((mode == PRED ? -lam * t : -rrc[qi]) + lam * rga) / (t + dreg * lam);
+                const double dtv = -rga + dreg * dl;
+                rdl[qi] = dl; rdt[qi] = dtv;
+                if (dtv < 0.0) amax = fmin(amax, -t / dtv);
+                if (dl < 0.0) amax = fmin(amax, -lam / dl);
+            }
+        }
+        amax = wg::reduce(amax, 2, L.red);
         if (mode == PRED) {
             if (!ok) { status = near_opt ? 0 : 2; break; }
             if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
@@ -753,20 +965,11 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
             near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
             if (it >= d.max_iter) { status = 1; break; }
-            rows_apply(d, c, qw.dy, w.du, w.dt);
-            __syncthreads();
-            qp::for_rows(d, [&](int row, bool, int, int) {
-                const double t = w.t[row], lam = w.lam[row], rga = w.rg[row] + w.dt[row];
-                const double dl = (-lam * t + lam * rga) / (t + dreg * lam);
-                w.dlam[row] = dl;
-                w.dt[row] = -rga + dreg * dl;
-            });
-            __syncthreads();
-            const double a_aff = fmin(1.0, qp::max_step(d, w, Lq));
+            const double a_aff = fmin(1.0, amax);
             double ma = 0.0;
-            qp::for_rows(d, [&](int row, bool, int, int) {
-                ma += (w.lam[row] + a_aff * w.dlam[row]) * (w.t[row] + a_aff * w.dt[row]);
-            });
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi)
+                if (rv[qi]) ma += (rlam[qi] + a_aff * rdl[qi]) * (rt[qi] + a_aff * rdt[qi]);
             const double mu_aff = wg::reduce(ma, 0, L.red) / d.ng;
             sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
             if (q.dbg && tid == 0) { gptr g = q.dbg + 8 * it; g[5] = a_aff; g[6] = sig; }
@@ -774,30 +977,22 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             continue;
         }
         // mode == CORR: step
-        rows_apply(d, c, qw.dy, w.du, w.dt);
-        __syncthreads();
-        qp::for_rows(d, [&](int row, bool, int, int) {
-            const double t = w.t[row], lam = w.lam[row], rga = w.rg[row] + w.dt[row];
-            const double dl = (-w.rc[row] + lam * rga) / (t + dreg * lam);
-            w.dlam[row] = dl;
-            w.dt[row] = -rga + dreg * dl;
-        });
-        __syncthreads();
-        const double a = fmin(1.0, 0.99 * qp::max_step(d, w, Lq));
+        if (!ok) { status = 2; break; }
+        const double a = fmin(1.0, 0.99 * amax);
         if (q.dbg && tid == 0) { gptr g = q.dbg + 8 * it; g[7] = a; }
-        for (int e = tid; e < nm; e += nt) w.u[e] += a * w.du[e];
-        for (int e = tid; e < (N + 1) * po; e += nt) qw.y[e] += a * qw.dy[e];
-        qp::for_rows(d, [&](int row, bool, int, int) {
-            w.t[row] += a * w.dt[row];
-            w.lam[row] += a * w.dlam[row];
-        });
+        for (int e = tid; e < nm; e += nt) L.u[e] += a * L.du[e];
+        for (int e = tid; e < ldG; e += nt) L.y[e] += a * L.dy[e];
+#pragma unroll
+        for (int qi = 0; qi < QR; ++qi) { rt[qi] += a * rdt[qi]; rlam[qi] += a * rdl[qi]; }
         __syncthreads();
         ++it;
         mode = PRED;
     }
-    QC_LAP(7);                                      // steps (row directions, step lengths, updates)
+    __syncthreads();
+    for (int e = tid; e < nm; e += nt) w.u[e] = L.u[e];
+    __syncthreads();
 #ifdef SRH_PROFILE
-    if (q.dbg && tid == 0) for (int i = 0; i < 8; ++i) q.dbg[8 * 60 + i] = (double)tq[i];
+    if (q.dbg && tid == 0) for (int i = 0; i < 8; ++i) { q.dbg[8 * 60 + i] = (double)tq[i]; q.dbg[8 * 59 + i] = (double)pf.t[8 + i]; }
 #endif
     if (iters_out) *iters_out = it;
     return status;

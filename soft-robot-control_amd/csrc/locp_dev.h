@@ -34,6 +34,7 @@ struct QPDims {
     int po;    // output directions spanning Cq, X.A, Xf.A (rows of C_o)
     int KT;    // 16 x 16 tiles along N * po
     long long qc_off;   // offset (doubles) of the condensed path's HBM block (QCWork) from the problem's work base
+    int diagD;          // 1: 2R + U.A^T D U.A is diagonal for every weight vector D (R diagonal, one entry per U.A row)
 };
 
 namespace qp {

@@ -121,9 +121,11 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     if (want_dbg) {
         std::vector<double> t(8 * 64);
         dbg.download(t.data(), sizeof(double) * 8 * 64);
-        fprintf(stderr, "[locp] cond %d po %d KT %d lds %zu; condensed path ran %.0f status %.0f iters %.0f inside %.0f\n", d.cond, d.po, d.KT, lds, t[8*61], t[8*61+1], t[8*61+2], t[8*61+3]);
-        fprintf(stderr, "[locp] condensed laps (SRH_PROFILE build): condense %.0f rows %.0f dual-res %.0f stage-factors %.0f gram %.0f cholesky %.0f grad+newton %.0f steps %.0f\n",
+        fprintf(stderr, "[locp] cond %d diagD %d po %d KT %d lds %zu; condensed path ran %.0f status %.0f iters %.0f inside %.0f\n", d.cond, d.diagD, d.po, d.KT, lds, t[8*61], t[8*61+1], t[8*61+2], t[8*61+3]);
+        fprintf(stderr, "[locp] condensed laps (SRH_PROFILE build): setup+rollout %.0f rows %.0f condense %.0f stage-factors %.0f gram %.0f cholesky %.0f grad+newton %.0f steps %.0f\n",
                 t[8*60], t[8*60+1], t[8*60+2], t[8*60+3], t[8*60+4], t[8*60+5], t[8*60+6], t[8*60+7]);
+        fprintf(stderr, "[locp] newton laps: gradients %.0f gT_times(1) %.0f rhs+dinv %.0f g_times(1) %.0f k_solve %.0f gT_times(2) %.0f du %.0f g_times(2) %.0f\n",
+                t[8*59], t[8*59+1], t[8*59+2], t[8*59+3], t[8*59+4], t[8*59+5], t[8*59+6], t[8*59+7]);
         fprintf(stderr, "[locp] time (shader clocks): init %.0f rows %.0f prepass %.0f ricc_full %.0f ricc_vec %.0f final %.0f\n", t[8*62], t[8*62+1], t[8*62+2], t[8*62+3], t[8*62+4], t[8*62+5]);
         fprintf(stderr, "[locp] riccati laps (SRH_PROFILE build): load %.0f W %.0f BtW %.0f Qu %.0f gain %.0f AtW+finish %.0f vec-backward %.0f forward %.0f\n",
                 t[8*63], t[8*63+1], t[8*63+2], t[8*63+3], t[8*63+4], t[8*63+5], t[8*63+6], t[8*63+7]);

@@ -134,7 +134,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.max_iter = 60;
     d.tol = 1e-12;
     d.reg = 1e-8;
-    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0;
+    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0; d.diagD = 0;
     std::vector<double> Qx(n * n), QxN(n * n), Ht2(n * nz), Htf2(n * nz, 0.0), R2(m * m), xs(n, 1.0);
     std::vector<double> QzH(nz * n), QzfH(nz * n, 0.0);
     for (int a = 0; a < nz; ++a)
@@ -241,7 +241,19 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
                     T[(size_t)r * po + a] = v;
                 }
         };
-        bool ok = po >= 1 && po <= 4 && N * po <= 128 && m <= SRH_QC_MAX_M && !getenv("SRH_QP_NO_COND");
+        // the inequality rows live in registers, qpc::QR per thread
+        bool ok = po >= 1 && po <= 4 && N * po <= 128 && m <= SRH_QC_MAX_M && !getenv("SRH_QP_NO_COND") &&
+                  N * (pr->nX + pr->nXf) + N * pr->nU <= qpc::QR * NTHREADS;
+        {   // box-type input rows and a diagonal R make every D_j diagonal: scalar scalings instead of m x m factors
+            bool diag = true;
+            for (int a = 0; a < m && diag; ++a) for (int b = 0; b < m; ++b) if (a != b && pr->R[a * m + b] != 0.0) { diag = false; break; }
+            for (int r = 0; r < pr->nU && diag; ++r) {
+                int nnz = 0;
+                for (int b = 0; b < m; ++b) nnz += pr->UA[r * m + b] != 0.0;
+                if (nnz > 1) diag = false;
+            }
+            d.diagD = diag && !getenv("SRH_QP_NO_DIAGD") ? 1 : 0;
+        }
         std::vector<double> Tc, Tcf, Tx, Txf, Sc, ScN, Cz2, Czf2;
         if (ok) {
             project(Cq.data(), ncq, Tc); project(Cqf.data(), ncqf, Tcf);
