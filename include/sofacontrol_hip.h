@@ -279,6 +279,11 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
                 const double *omega, const double *z, const double *zf, const double *u_des,
                 double *x, double *u, double *s, double *J, int32_t *status, int32_t *iters);
 
+/* Whether QPs of this shape take the condensed (output-space) interior point for their trust-region-free pass
+ * (csrc/locp_cond.h): enabled, the number of output directions found (rows of C_o spanning Cq, X.A, Xf.A) and whether
+ * the input Hessian blocks 2R + U.A^T D U.A are diagonal for every D.  For tests and records. */
+int slocp_condensed_info(const slocp_problem *prob, int *enabled, int *n_outputs, int *diag_input_hessian);
+
 typedef struct sgusto_params {
     double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh; /* gusto.py:12-22 */
     int    max_gusto_iters;

@@ -16,8 +16,10 @@ G (N p x N m).  A Newton system of the interior point is then
   M du = -g ,   M = blkdiag(2R + U.A^T D_u U.A) + G^T blkdiag(S_k) G ,   S_k = Tc^T Tc + Tx^T D_x,k Tx   (p x p)
 
 `newton='primal'` factors M (N m x N m) by Cholesky; `newton='output'` solves the equivalent output-space system
-(I + Gs Dinv Gs^T) v = ... of size N p (Gs = rows of G scaled by chol(S_k)), with iterative refinement on the
-primal residual.  Both give the Newton direction of riccati_ipm up to rounding, hence the same iterates.
+(I + Gs Dinv Gs^T) v = ... of size N p (Gs = rows of G scaled by chol(S_k)) -- what the kernel does (`refine` > 0 adds
+steps of iterative refinement on the primal residual, which the kernel does not: its reduced dual residual passes
+through ~1e-5 relative mid-way and reaches the 1e-9 stopping level with the last iterations, sometimes one or two
+iterations after the refined variant).  All variants give the Newton direction of riccati_ipm up to rounding.
 
 One-off per QP: G by the adjoint recursion  Psi_j = [C_o ; Psi_{j+1}] A_j,  G[:, j] = Psi_j B_j  (N^2/2 products of a
 p-row block with A_j instead of N factorisations of n x n matrices per interior-point iteration).
@@ -52,6 +54,23 @@ def output_basis(p, tol=1e-10):
     return Co, Cq @ Co.T, Cqf @ Co.T, XA @ Co.T, XfA @ Co.T
 
 
+def chol_psd(S):
+    """Lower Cholesky factor of a symmetric positive SEMI-definite matrix (S = L L^T): a pivot that has cancelled to
+    (numerically) nothing gets a zero column.  The output blocks S_k = Tc^T Tc + Tx^T D Tx lose rank in floating point
+    when an output direction is weighted only by state rows whose weights D -> 0 (inactive rows late in the iteration)."""
+    n = S.shape[0]
+    L = np.zeros_like(S)
+    dmax = max(np.abs(np.diag(S)).max(), 1e-300)
+    for i in range(n):
+        for j in range(i + 1):
+            v = S[i, j] - L[i, :j] @ L[j, :j]
+            if i == j:
+                L[i, i] = np.sqrt(v) if v > 1e-14 * dmax else 0.0
+            else:
+                L[i, j] = v / L[j, j] if L[j, j] > 0.0 else 0.0
+    return L
+
+
 def condense(p, Co):
     """xfree (N+1, n), yfree (N+1, p_o) and G as a dense (N+1, p_o, N, m) array (G[k, :, j, :] = 0 for j >= k)."""
     N, n, m = p.N, p.n, p.m
@@ -68,7 +87,7 @@ def condense(p, Co):
     return xf, xf @ Co.T, G
 
 
-def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='primal', refine=2, verbose=False):
+def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbose=False):
     """The QP of `p` (riccati_ipm.Problem) WITHOUT its trust-region rows.  Returns x, u, J (objective without the
     omega * s term), info (iters, status, and `inside`: whether the minimiser satisfies the trust region of p)."""
     N, n, m = p.N, p.n, p.m
@@ -122,11 +141,13 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='primal', refine=2, verbos
             L = np.linalg.cholesky(M)
             return np.linalg.solve(L.T, np.linalg.solve(L, rhs))
         # output space: M = D + Gs^T Gs with Gs = blkdiag(Ls_k^T) G, S_k = Ls_k Ls_k^T
-        Ls = [None] + [np.linalg.cholesky(Sk[k] + 1e-300 * np.eye(po)) for k in range(1, N + 1)]
+        Ls = [None] + [chol_psd(Sk[k]) for k in range(1, N + 1)]
         Gs = np.vstack([Ls[k].T @ Gm[k * po:(k + 1) * po] for k in range(1, N + 1)])          # (N p x N m)
         Ld = [np.linalg.cholesky(Dblk[k]) for k in range(N)]
         Gd = np.hstack([np.linalg.solve(Ld[k], Gs[:, k * m:(k + 1) * m].T).T for k in range(N)])   # Gs Ld^-T
-        Kc = np.linalg.cholesky(np.eye(N * po) + Gd @ Gd.T)
+        K = np.eye(N * po) + Gd @ Gd.T
+        ks = 1.0 / np.sqrt(np.diag(K))              # factored under a symmetric scaling to unit diagonal (as the kernel)
+        Kc = np.linalg.cholesky(ks[:, None] * K * ks[None, :])
 
         def Dinv(v):
             out = np.empty_like(v)
@@ -142,7 +163,7 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='primal', refine=2, verbos
 
         def woodbury(r):
             t = Dinv(r)
-            v = np.linalg.solve(Kc.T, np.linalg.solve(Kc, Gs @ t))
+            v = ks * np.linalg.solve(Kc.T, np.linalg.solve(Kc, ks * (Gs @ t)))
             return t - Dinv(Gs.T @ v)
         du = woodbury(rhs)
         for _ in range(refine):

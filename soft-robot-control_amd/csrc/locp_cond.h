@@ -57,6 +57,7 @@ struct Lds {
     lptr u, du;                        // N m
     lptr y, dy, yf;                    // ldG, index (k-1) po + a, k = 1..N
     lptr ya, yb, yc, yd, yg;           // y-space temporaries (ldG)
+    lptr ks;                           // 1 / sqrt(diag K): the symmetric scaling under which K is factored
     lptr UA, Tx;                       // (nU x m), ((nX + nXf) x po): row coefficients
     lptr v1, v2, Qu, red;
     liptr flag, idxl;
@@ -87,7 +88,7 @@ __host__ __device__ inline Sizes sizes(const QPDims &d, int nthreads) {
 }
 __host__ __device__ inline size_t lds_doubles(const QPDims &d, int nthreads) {
     const Sizes s = sizes(d, nthreads);
-    return s.regA + s.regB + s.rinv + s.ldi + s.ls + 2 * s.nm4 + 8 * s.ldG + s.ua + s.tx + 2 * s.ld + 16 + 16 + 4 + 2 * s.idx;
+    return s.regA + s.regB + s.rinv + s.ldi + s.ls + 2 * s.nm4 + 9 * s.ldG + s.ua + s.tx + 2 * s.ld + 16 + 16 + 4 + 2 * s.idx;
 }
 __device__ inline void lds_carve(Lds &L, lptr base, const QPDims &d, int nthreads) {
     const Sizes s = sizes(d, nthreads);
@@ -96,7 +97,7 @@ __device__ inline void lds_carve(Lds &L, lptr base, const QPDims &d, int nthread
     L.A = take(s.regA); L.B = take(s.regB); L.Rinv = take(s.rinv); L.Ldi = take(s.ldi); L.Ls = take(s.ls);
     L.u = take(s.nm4); L.du = take(s.nm4);
     L.y = take(s.ldG); L.dy = take(s.ldG); L.yf = take(s.ldG);
-    L.ya = take(s.ldG); L.yb = take(s.ldG); L.yc = take(s.ldG); L.yd = take(s.ldG); L.yg = take(s.ldG);
+    L.ya = take(s.ldG); L.yb = take(s.ldG); L.yc = take(s.ldG); L.yd = take(s.ldG); L.yg = take(s.ldG); L.ks = take(s.ldG);
     L.UA = take(s.ua); L.Tx = take(s.tx);
     L.v1 = take(s.ld); L.v2 = take(s.ld); L.Qu = take(16); L.red = take(16);
     L.flag = (liptr)take(4);
@@ -275,8 +276,10 @@ __device__ __forceinline__ void gradients(const QPDims &d, const QPConst &c, con
 }
 
 // in-place Cholesky factor (lower, row-major m x m; the strict upper part is zeroed) of a tiny SPD matrix in LDS, by one
-// thread.  false: not positive definite.
-__device__ __forceinline__ bool small_chol(lptr A, int m) {
+// thread.  false: not positive definite.  semidef: a pivot that cancelled to (numerically) nothing gets a zero column
+// instead (oracle/condensed_ipm.py: chol_psd) -- the output blocks S_k lose rank in floating point when an output
+// direction is weighted only by state rows whose weights go to zero.
+__device__ __forceinline__ bool small_chol(lptr A, int m, bool semidef = false) {
     double dmax = 0.0;
     for (int i = 0; i < m; ++i) dmax = fmax(dmax, fabs(A[i * m + i]));
     for (int i = 0; i < m; ++i)
@@ -284,10 +287,12 @@ __device__ __forceinline__ bool small_chol(lptr A, int m) {
             double sum = A[i * m + j];
             for (int k = 0; k < j; ++k) sum = fma(-A[i * m + k], A[j * m + k], sum);
             if (i == j) {
+                if (semidef) { A[i * m + i] = sum > 1e-14 * dmax ? sqrt(sum) : 0.0; continue; }
                 if (!(sum > 1e-300 * dmax)) return false;
                 A[i * m + i] = sqrt(sum);
             } else {
-                A[i * m + j] = sum / A[j * m + j];
+                const double piv = A[j * m + j];
+                A[i * m + j] = piv > 0.0 ? sum / piv : 0.0;
             }
         }
     for (int i = 0; i < m; ++i)
@@ -349,7 +354,7 @@ __device__ __forceinline__ bool stage_factors(const QPDims &d, const QPConst &c,
         if (ok) tri_inverse(A, m);
     }
     const int t2 = tid - (nt >= 512 ? 256 : 64);
-    if (t2 >= 0 && t2 < N) ok = ok && small_chol(L.Ls + (size_t)t2 * po * po, po);
+    if (t2 >= 0 && t2 < N) ok = ok && small_chol(L.Ls + (size_t)t2 * po * po, po, true);
     if (!ok) L.flag[0] = 0;
     __syncthreads();
     return L.flag[0] != 0;
@@ -478,15 +483,28 @@ __device__ __forceinline__ void gram(const QPDims &d, const QCWork &w, Lds &L) {
         }
         __syncthreads();
     }
-    // ---- K = I + acc into the tile store (region B: Theta^T is no longer needed)
+    // ---- K = I + acc, scaled symmetrically to a unit diagonal, into the tile store (region B: Theta^T is no longer
+    // needed).  The scaling matters: active state rows put weights up to 1e12 into single stages of Ls, and the tile
+    // factorisation below multiplies by explicit inverses of its diagonal tiles -- accurate only as far as those tiles
+    // are reasonably conditioned (without it the reduced dual residual stalls at 1e-5 relative on the C2 QPs).
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        if (tI[sl] < 0 || tI[sl] != tJ[sl]) continue;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+            if (kk + 4 * qd == l16) L.ks[16 * tI[sl] + l16] = 1.0 / sqrt(acc[sl][qd] + 1.0);
+    }
+    __syncthreads();
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
         if (tI[sl] < 0) continue;
         lptr T = L.B + (size_t)tile_index(tI[sl], tJ[sl], KT) * TSZ;
+        const double sc = L.ks[16 * tJ[sl] + l16];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int r = kk + 4 * qd;
-            T[r * TS + l16] = acc[sl][qd] + ((tI[sl] == tJ[sl] && r == l16) ? 1.0 : 0.0);
+            const double v = acc[sl][qd] + ((tI[sl] == tJ[sl] && r == l16) ? 1.0 : 0.0);
+            T[r * TS + l16] = v * L.ks[16 * tI[sl] + r] * sc;
         }
     }
     __syncthreads();
@@ -769,7 +787,11 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, QCWork &qw, Lds &L
     g_times(d, qw, L, L.ta, L.yb);                                            // G t
     QC_SUB(pf, 11);
     ls_apply<LS_TR>(d, L, L.yb, L.yc);                                        // Ls^T G t
+    for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];                   // K^-1 = ks (ks K ks)^-1 ks
+    __syncthreads();
     k_solve(d, L, L.yc);                                                      // v
+    for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
+    __syncthreads();
     QC_SUB(pf, 12);
     ls_apply<LS_FWD>(d, L, L.yc, L.yd);                                       // Ls v
     gT_times(d, qw, L, L.yd, (clptr) nullptr, L.du, (lptr) nullptr);             // G^T Ls v

@@ -66,6 +66,17 @@ const void *locp_entry(const QPDims &d) {
 
 extern "C" {
 
+int slocp_condensed_info(const slocp_problem *prob, int *enabled, int *n_outputs, int *diag_input_hessian) {
+    SRH_REQUIRE(prob, "slocp_condensed_info: null problem");
+    QPConstHost C;
+    int rc = build_consts(prob, C);
+    if (rc) return rc;
+    if (enabled) *enabled = C.dims.cond;
+    if (n_outputs) *n_outputs = C.dims.po;
+    if (diag_input_hessian) *diag_input_hessian = C.dims.diagD;
+    return SRH_OK;
+}
+
 int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, const double *Bd, const double *dd,
                 const double *x0, const double *xk, const double *delta, const double *omega, const double *z,
                 const double *zf, const double *u_des, double *x, double *u, double *s, double *J,

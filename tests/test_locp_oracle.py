@@ -95,3 +95,35 @@ def test_osqp_restatement_reaches_reference_accuracy():
     xo, uo, _ = olocp.split(qp, wo)
     assert rel(xo, xe) <= 5e-2 and rel(uo, ue) <= 5e-2
     assert abs(olocp.objective(qp, wo) - Je) <= 1e-5 * abs(Je)
+
+
+# ---------------------------------------------------------------- condensed (output-space) interior point
+@pytest.mark.parametrize('name', ['box_X', 'free', 'box_only_tr_loose', 'terminal_cost'])
+@pytest.mark.parametrize('newton', ['primal', 'output'])
+def test_condensed_ipm_matches_exact_solver(name, newton):
+    """oracle.condensed_ipm (numpy statement of csrc/locp_cond.h: states eliminated, Newton systems in input / output
+    space) against the generic sparse solver on the same QP, for the cases whose trust region is inactive."""
+    from oracle import condensed_ipm as cipm
+    from qp_cases import make_case, CASES
+    case, _ = make_case(**CASES[name])
+    kw = dict(case)
+    args = [kw.pop(k) for k in ('N', 'H', 'Qz', 'R', 'Ad', 'Bd', 'dd', 'x0', 'xk', 'delta', 'omega')]
+    qp = olocp.build_qp(*args, **kw)
+    w, _, _ = olocp.solve_exact(qp)
+    xe, ue, se = olocp.split(qp, w)
+    sp = ripm.Problem(*args, **kw)
+    x, u, J, info = cipm.solve(sp, newton=newton)
+    assert info['status'] == 'optimal' and info['inside']
+    assert np.abs(x - xe).max() <= 1e-6 * max(1e-12, np.abs(xe).max())
+    assert np.abs(u - ue).max() <= 1e-6 * max(1e-12, np.abs(ue).max())
+    assert abs(J + case['omega'] * se[0] - olocp.objective(qp, w)) <= 1e-8 * abs(olocp.objective(qp, w))
+
+
+def test_condensed_ipm_reports_a_minimiser_outside_the_trust_region():
+    from oracle import condensed_ipm as cipm
+    from qp_cases import make_case, CASES
+    case, _ = make_case(**CASES['tr_active_small_delta'])
+    kw = dict(case)
+    args = [kw.pop(k) for k in ('N', 'H', 'Qz', 'R', 'Ad', 'Bd', 'dd', 'x0', 'xk', 'delta', 'omega')]
+    x, u, J, info = cipm.solve(ripm.Problem(*args, **kw))
+    assert info['status'] == 'optimal' and not info['inside']      # -> the full stage-wise solve takes over
