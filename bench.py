@@ -45,36 +45,79 @@ def build_model(w, tip_node=1354):
     return tp, gm
 
 
+def usable_cpus():
+    """CPUs this process can actually keep busy: the affinity mask, capped by the cgroup CPU quota (on the GPU box
+    os.cpu_count() says 256 while cpu.max grants 16 CPUs' worth of time -- more threads than that only add switching)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(np.ceil(float(quota) / float(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
-    """The CPU port (oracle/: numpy restatement, reference op sequence) on a bounded sample."""
-    from oracle import gusto as ogusto, riccati_ipm as ripm, pod as opod, locp as olocp
+    """The CPU side of the same workload on a bounded sample, on this box's host cores (oracle/ only: never the product):
+      * native twin (oracle/csrc/sofacontrol_cpu.cpp: stage-structured Riccati interior point with the kernel's
+        trust-region prescreen, nearest-point TPWL, the GuSTO loop) on ONE thread and on ALL cores, one rollout per thread;
+      * the numpy port (oracle.gusto around oracle.riccati_ipm) on a few rollouts;
+      * the reference's solver class -- OSQP at cvxpy's default tolerances -- as restated in oracle.locp.solve_osqp, on
+        the first QP of the first rollout: what it costs in ADMM iterations and what accuracy it delivers.
+    `value` is the all-cores native number (the strongest CPU figure); `cores` = threads actually used."""
+    from oracle import gusto as ogusto, pod as opod, locp as olocp, tpwl as otpwl, cpu_twin
     import workloads as wl
     model = dict(w['tab'], w_q=1.0, w_v=0.0)
     N, m = w['N'], w['m']
+    kw = dict(z=None, U=(w['UA'], w['Ub']), X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, max_gusto_iters=max_iters)
+    u0 = np.zeros((n_roll, N, m))
 
+    def twin(nr, threads):
+        t0 = time.perf_counter()
+        xo, uo, it, _ = cpu_twin.gusto_solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[:nr], u0[:nr],
+                                             x_init[:nr], **dict(kw, z=z[:nr]), threads=threads)
+        return time.perf_counter() - t0, xo, uo, it
+    cpu_twin.lib()
+    ncpu = usable_cpus()
+    t1, xo1, uo1, it1 = twin(min(6, n_roll), 1)
+    nall = min(n_roll, 4 * ncpu)
+    tall, xoa, uoa, ita = twin(nall, ncpu)
+    sols = [(xoa[b], uoa[b], int(ita[b])) for b in range(nall)]
+    # numpy port, a few rollouts
+    nnp = min(3, n_roll)
     t0 = time.perf_counter()
-    iters = 0
-    sols = []
-    for b in range(n_roll):
-        xe, ue, _, tr = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[b],
-                                     np.zeros((N, m)), x_init[b], z=z[b], U=(w['UA'], w['Ub']),
-                                     X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3,
-                                     qp_solver='riccati_ipm', max_gusto_iters=max_iters)
-        iters += len(tr)
-        sols.append((xe, ue, len(tr)))
-    t_scp = time.perf_counter() - t0
+    np_iters = 0
+    np_sols = []
+    for b in range(nnp):
+        xe, ue, _, tr = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[b], np.zeros((N, m)),
+                                     x_init[b], **dict(kw, z=z[b]), qp_solver='riccati_ipm')
+        np_iters += len(tr)
+        np_sols.append((xe, ue, len(tr)))
+    t_np = time.perf_counter() - t0
+    # the reference's solver class on the first QP
+    A_k, B_k, d_k, _ = ogusto.traj_dynamics(model, w['Ad'], w['Bd'], w['dd'], x_init[0])
+    qp = olocp.build_qp(N, w['H'], w['Qz'], w['R'], A_k, B_k, d_k, x0[0], x_init[0], 1e4, 1.0, z=z[0], U=(w['UA'], w['Ub']),
+                        X=(w['XA'], w['Xb']), x_scale=1.0 / np.abs(xc))
+    t0 = time.perf_counter()
+    wo, _, io = olocp.solve_osqp(qp)
+    t_osqp = time.perf_counter() - t0
+    xq, uq, _, Jq, _ = cpu_twin.locp_solve(N, w['H'], w['Qz'], w['R'], A_k, B_k, d_k, x0[0], x_init[0], 1e4, 1.0, z=z[0], U=(w['UA'], w['Ub']),
+                                           X=(w['XA'], w['Xb']), x_scale=1.0 / np.abs(xc))
+    xo_, uo_, _ = olocp.split(qp, wo)
+    # projection
     X = wl.snapshots(w['q_ref'], proj_rows, seed=2)
+    byt = X.nbytes + w['U'].nbytes + w['q_ref'].nbytes + proj_rows * w['r'] * 8
+    proj = {}
+    for name, thr in (('single_thread', 1), ('all_cores', ncpu)):
+        cpu_twin.project(w['U'], w['q_ref'], X[:64], threads=thr)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cpu_twin.project(w['U'], w['q_ref'], X, threads=thr)
+        proj[name] = byt / ((time.perf_counter() - t0) / 3) / 1e9
     t0 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        opod.project(w['U'], w['q_ref'], X)
-    t_proj = (time.perf_counter() - t0) / reps
-    proj_gbs = (X.nbytes + w['U'].nbytes + w['q_ref'].nbytes + proj_rows * w['r'] * 8) / t_proj / 1e9
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([int(i.get('num_threads', 1)) for i in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count()
+    opod.project(w['U'], w['q_ref'], X)
+    proj['numpy'] = byt / (time.perf_counter() - t0) / 1e9
     cpu = 'unknown CPU'
     try:
         for line in open('/proc/cpuinfo'):
@@ -83,11 +126,23 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
                 break
     except Exception:
         pass
-    return dict(value=iters / t_scp, unit='SCP iterations/s', cores=cores, kind='port', host='%s, %d logical CPUs' % (cpu, os.cpu_count()),
-                sample='%d rollout(s) of the same workload = %d SCP iterations in %.1f s (numpy port of the kernel '
-                       'algorithm inside the restated GuSTO loop); POD projection of %d snapshots: %.1f GB/s' %
-                       (n_roll, iters, t_scp, proj_rows, proj_gbs),
-                pod_projection_gbs=proj_gbs), sols
+    out = dict(value=float(ita.sum()) / tall, unit='SCP iterations/s', cores=ncpu, kind='port',
+               host='%s, %d logical CPUs, %d usable by this process (affinity / cgroup quota)' % (cpu, os.cpu_count() or 1, ncpu),
+               sample='native CPU twin (oracle/csrc), one rollout per thread: %d rollouts = %d SCP iterations in %.2f s on %d threads; '
+                      'single thread: %d rollouts = %d SCP iterations in %.2f s' % (nall, int(ita.sum()), tall, ncpu, len(it1), int(it1.sum()), t1),
+               single_thread=dict(scp_iterations_per_s=float(it1.sum()) / t1, ms_per_scp_iteration=t1 / float(it1.sum()) * 1e3,
+                                  ms_per_solve=t1 / len(it1) * 1e3, rollouts=len(it1)),
+               all_cores=dict(scp_iterations_per_s=float(ita.sum()) / tall, threads=ncpu, rollouts=nall, seconds=tall),
+               numpy_port=dict(scp_iterations_per_s=np_iters / t_np, rollouts=nnp, seconds=t_np,
+                               what='oracle.gusto around oracle.riccati_ipm (numpy + BLAS threads)'),
+               osqp_restated_eps1e_5=dict(what='oracle.locp.solve_osqp (published OSQP algorithm, cvxpy defaults eps_abs = eps_rel = 1e-5, no polish) '
+                                               'on the first QP of rollout 0; python + scipy SuperLU, so the seconds are not those of the C library',
+                                          admm_iterations=int(io['iters']), status=io['status'], seconds=t_osqp,
+                                          rel_traj_error_vs_exact=float(max(np.abs(xo_ - xq).max() / np.abs(xq).max(),
+                                                                            np.abs(uo_ - uq).max() / np.abs(uq).max())),
+                                          rel_cost_error_vs_exact=float(abs(olocp.objective(qp, wo) - Jq) / abs(Jq))),
+               pod_projection_gbs=proj)
+    return out, sols, np_sols
 
 
 def closed_loop_latency(w, rom, tp):
@@ -170,6 +225,31 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
                         'strong scaling; host buffers' % (total, Bn),
             'iterations_per_s': its / el, 'ms': el * 1e3, 'iterations': its,
             'not_converged_rank0': int((g.status != 0).sum())}
+
+
+def scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, max_iters):
+    """The reference's actual use: ONE receding-horizon solve at a time (scp/ros.py:94-127), C2 shape.  Wall time of
+    GuSTO.solve through the host-pointer API (PCIe copies inside), per SCP iteration and per solve, against the replan
+    budget of the Diamond driver (N_replan = 10 steps of 0.01 s: examples/diamond/diamond.py:230,249)."""
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    N, m = w['N'], w['m']
+    out = {'workload': 'C2, one rollout at a time (batch = 1 plan), host buffers; median over rollouts', 'replan_budget_ms': 100.0}
+    for cap, key in ((max_iters, 'capped'), (500, 'reference_default_500')):
+        g = GuSTO(gm, N, w['dt'], w['Qz'], w['R'], x0[0], np.zeros((N, m)), x_init[0], z=z[0], U=Polyhedron(w['UA'], w['Ub']),
+                  X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, max_trace=0, max_gusto_iters=cap)
+        ts, its = [], []
+        for b in range(8):
+            t0 = time.perf_counter()
+            g.solve(x0[b], np.zeros((N, m)), x_init[b], z=z[b])
+            ts.append(time.perf_counter() - t0)
+            its.append(int(g.iters[0]))
+        per_it = sorted(t / i for t, i in zip(ts, its))
+        out[key] = {'max_gusto_iters': cap, 'ms_per_solve_median': sorted(ts)[len(ts) // 2] * 1e3, 'ms_per_solve_max': max(ts) * 1e3,
+                    'scp_iterations': its, 'ms_per_scp_iteration_median': per_it[len(per_it) // 2] * 1e3}
+    out['ms_per_scp_iteration'] = out['capped']['ms_per_scp_iteration_median']
+    out['within_replan_budget'] = bool(out['capped']['ms_per_solve_max'] <= 100.0)
+    return out
 
 
 def pod_shapes(L, _lib, B=65536):
@@ -290,6 +370,8 @@ def secondary(L, _lib, rank, world, dist):
         out['pod_shapes'] = {'error': repr(exc)}
     try:
         out['scp_c5'] = scp_c5(_lib, rank, world, dist)
+        if world == 1:       # what one GPU of an 8-GPU node gets of the 256 rollouts
+            out['scp_c5_32_rollouts'] = scp_c5(_lib, 0, 1, None, total=32)
     except Exception as exc:
         out['scp_c5'] = {'error': repr(exc)}
     if dist is not None:
@@ -406,7 +488,7 @@ def main():
     elapsed = time.perf_counter() - t0
     iters = o['iters'].to_array((R_,), dtype=np.int32)
     status = o['status'].to_array((R_,), dtype=np.int32)
-    n_par = min(R_, 24)          # the rollouts the CPU port solves as well: GPU trajectories kept for `parity_sample`
+    n_par = min(R_, 512)         # the rollouts the CPU side may solve as well: GPU trajectories kept for `parity_sample`
     gx = o['xopt'].to_array((R_, N + 1, n))[:n_par].copy()
     gu = o['uopt'].to_array((R_, N, m))[:n_par].copy()
     it_per_step = int(iters.sum())
@@ -421,15 +503,21 @@ def main():
         total_iters = float(t[1])
     sec = None
     if not args.no_secondary:
+        try:
+            # per-step latencies BEFORE anything large is freed: after a hipFree of GB-sized buffers the HIP runtime
+            # serves small synchronous calls ~100 us slower for the rest of the process (observed, ROCm 7.2)
+            cl = closed_loop_latency(w, rom, tp) if rank == 0 else None
+            single = scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, args.max_gusto_iters) if rank == 0 else None
+        except Exception as exc:
+            cl, single = {'error': repr(exc)}, None
         for b in list(d.values()) + list(o.values()) + [dX, dXr]:
             b.free()
         try:
-            # per-step latencies first: after the large buffers of the other secondary measurements are freed the HIP
-            # runtime serves small synchronous calls ~100 us slower for the rest of the process (observed, ROCm 7.2)
-            cl = closed_loop_latency(w, rom, tp) if rank == 0 else None
             sec = secondary(L, _lib, rank, world, dist)
             if cl is not None:
                 sec['closed_loop_step'] = cl
+            if single is not None:
+                sec['scp_single_rollout'] = single
         except Exception as exc:      # never lose the headline line to a secondary measurement
             sec = {'error': repr(exc)}
     if rank != 0:
@@ -463,15 +551,27 @@ def main():
                      'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': alg_bytes},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'], sols = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=n_par, proj_rows=4096,
-                                                 max_iters=args.max_gusto_iters)
+        out['cpu_baseline'], sols, np_sols = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=R_, proj_rows=4096,
+                                                          max_iters=args.max_gusto_iters)
         rel = lambda a, b: float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+        n_par = min(n_par, len(sols))
         out['parity_sample'] = {
-            'what': 'the timed GPU launch vs the CPU port (oracle.gusto around oracle.riccati_ipm) on the first %d rollouts of '
-                    'the same inputs' % n_par,
+            'what': 'trajectories and SCP iteration counts of the timed GPU launch vs the numpy oracle (oracle.gusto around '
+                    'oracle.riccati_ipm; first %d rollouts) and vs the native CPU twin (first %d rollouts) on the same inputs' %
+                    (len(np_sols), n_par),
             'kernel_variant': list(gusto.variant),
-            'max_rel_traj': max(max(rel(gx[b], sols[b][0]), rel(gu[b], sols[b][1])) for b in range(n_par)),
-            'iters_equal': bool(all(int(iters[b]) == sols[b][2] for b in range(n_par))), 'tolerance': 1e-4}
+            'max_rel_traj': max(max(rel(gx[b], np_sols[b][0]), rel(gu[b], np_sols[b][1])) for b in range(len(np_sols))),
+            'iters_equal': bool(all(int(iters[b]) == np_sols[b][2] for b in range(len(np_sols)))),
+            'max_rel_traj_vs_cpu_twin': max(max(rel(gx[b], sols[b][0]), rel(gu[b], sols[b][1])) for b in range(n_par)),
+            'iters_equal_vs_cpu_twin': bool(all(int(iters[b]) == sols[b][2] for b in range(n_par))), 'tolerance': 1e-4}
+        cb = out['cpu_baseline']
+        if sec is not None and 'scp_single_rollout' in sec:
+            g1 = sec['scp_single_rollout']
+            cb['gpu_vs_cpu'] = {'throughput_vs_all_cores': out['value'] / cb['value'],
+                                'throughput_vs_single_thread': out['value'] / cb['single_thread']['scp_iterations_per_s'],
+                                'single_rollout_ms_per_scp_iteration': {'gpu': g1['ms_per_scp_iteration'],
+                                                                        'cpu_single_thread': cb['single_thread']['ms_per_scp_iteration'],
+                                                                        'ratio': cb['single_thread']['ms_per_scp_iteration'] / g1['ms_per_scp_iteration']}}
     if sec is not None:
         out['secondary'] = sec
     print(json.dumps(out))

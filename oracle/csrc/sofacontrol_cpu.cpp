@@ -1,0 +1,742 @@
+// CPU twin of the hot path -- TEST / BASELINE INFRASTRUCTURE ONLY (part of oracle/: never loaded by the product package;
+// only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py use it).
+//
+// Native (C++17, no BLAS, IEEE: no -ffast-math) restatement of
+//   * the POD projection            out = (X - ref) U                       sofacontrol/mor/pod.py:39-54
+//   * the nearest-point TPWL model  argmin_i w_q |q_i - q| + w_v |v_i - v|  sofacontrol/tpwl/tpwl.py:160-168, 236-270
+//   * the LOCP horizon QP           sofacontrol/scp/locp.py:218-342, solved like oracle/riccati_ipm.py: Mehrotra
+//     predictor-corrector interior point, Newton systems by a backward Riccati recursion over the horizon, with the
+//     trust-region prescreen of the device kernel (the QP without its 2n+1 trust-region rows per stage first; the full
+//     QP only when that minimiser leaves the trust region)
+//   * the GuSTO outer loop          sofacontrol/scp/gusto.py:283-487 (oracle/gusto.py)
+// so that bench.py can put an honest native number next to the GPU one: single thread, and all cores with one rollout
+// per thread (`threads` = the number actually used).  tests/test_cpu_twin.py holds it to the numpy oracle.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+using vec = std::vector<double>;
+constexpr double INF = std::numeric_limits<double>::infinity();
+
+// ---- small dense helpers (row-major)
+inline void matvec(const double *A, int r, int c, const double *x, double *y) {          // y = A x
+    for (int i = 0; i < r; ++i) {
+        double s = 0.0;
+        const double *a = A + (size_t)i * c;
+        for (int j = 0; j < c; ++j) s += a[j] * x[j];
+        y[i] = s;
+    }
+}
+inline void matTvec_add(const double *A, int r, int c, const double *x, double *y) {     // y += A^T x
+    for (int i = 0; i < r; ++i) {
+        const double xi = x[i];
+        const double *a = A + (size_t)i * c;
+        for (int j = 0; j < c; ++j) y[j] += a[j] * xi;
+    }
+}
+// C (r x c) = A (r x k) B (k x c)
+inline void matmul(const double *A, const double *B, int r, int k, int c, double *C) {
+    std::fill(C, C + (size_t)r * c, 0.0);
+    for (int i = 0; i < r; ++i)
+        for (int p = 0; p < k; ++p) {
+            const double a = A[(size_t)i * k + p];
+            const double *b = B + (size_t)p * c;
+            double *cr = C + (size_t)i * c;
+            for (int j = 0; j < c; ++j) cr[j] += a * b[j];
+        }
+}
+// C (c1 x c2) = A^T B with A (r x c1), B (r x c2)
+inline void matTmul(const double *A, const double *B, int r, int c1, int c2, double *C) {
+    std::fill(C, C + (size_t)c1 * c2, 0.0);
+    for (int p = 0; p < r; ++p) {
+        const double *a = A + (size_t)p * c1, *b = B + (size_t)p * c2;
+        for (int i = 0; i < c1; ++i) {
+            const double ai = a[i];
+            double *cr = C + (size_t)i * c2;
+            for (int j = 0; j < c2; ++j) cr[j] += ai * b[j];
+        }
+    }
+}
+// in-place lower Cholesky of an m x m SPD matrix; false if not positive definite
+inline bool cholesky(double *A, int m) {
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * m + j];
+            for (int k = 0; k < j; ++k) s -= A[i * m + k] * A[j * m + k];
+            if (i == j) {
+                if (!(s > 0.0)) return false;
+                A[i * m + i] = std::sqrt(s);
+            } else {
+                A[i * m + j] = s / A[j * m + j];
+            }
+        }
+    return true;
+}
+// X (m x c) <- -(L L^T)^-1 B  column by column
+inline void chol_solve_neg(const double *L, int m, const double *B, int c, double *X) {
+    vec y(m);
+    for (int col = 0; col < c; ++col) {
+        for (int i = 0; i < m; ++i) {
+            double s = B[(size_t)i * c + col];
+            for (int k = 0; k < i; ++k) s -= L[i * m + k] * y[k];
+            y[i] = s / L[i * m + i];
+        }
+        for (int i = m - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int k = i + 1; k < m; ++k) s -= L[k * m + i] * y[k];
+            y[i] = s / L[i * m + i];
+        }
+        for (int i = 0; i < m; ++i) X[(size_t)i * c + col] = -y[i];
+    }
+}
+
+struct Model {          // nearest-point TPWL tables (oracle/tpwl.py dict)
+    int P, r, n, m;
+    double w_q, w_v;
+    const double *q, *v;            // (P x r)
+    const double *Ac, *Bc, *dc;     // continuous (P x n x n), (P x n x m), (P x n)
+    const double *Ad, *Bd, *dd;     // discrete tables
+};
+
+int nearest(const Model &M, const double *x) {
+    int best = 0;
+    double bd = INF;
+    for (int i = 0; i < M.P; ++i) {
+        double sq = 0.0, sv = 0.0;
+        for (int j = 0; j < M.r; ++j) { const double e = M.q[(size_t)i * M.r + j] - x[M.r + j]; sq += e * e; }
+        for (int j = 0; j < M.r; ++j) { const double e = M.v[(size_t)i * M.r + j] - x[j]; sv += e * e; }
+        const double d = M.w_q * std::sqrt(sq) + M.w_v * std::sqrt(sv);
+        if (d < bd) { bd = d; best = i; }
+    }
+    return best;
+}
+
+struct Problem {        // the QP data (oracle/riccati_ipm.py: Problem)
+    int N, n, m, nz, nU, nX, nXf;
+    const double *H, *Qz, *R, *Qzf;                 // Qzf may be null
+    const double *UA, *Ub, *XA, *Xb, *XfA, *Xfb;
+    const double *xs;                               // (n) trust-region scaling
+    vec Qx, QxN, Ru;                                // 2 H^T Qz H (+ terminal), 2 R
+    std::vector<const double *> A, B, d;            // stage dynamics (N pointers)
+    const double *x0, *xk;                          // xk (N+1 x n)
+    const double *z, *zf, *ud;                      // z (N+1 x nz) or null, zf (nz) or null, ud (N x m) or null
+    double delta, omega;
+    bool tr;
+};
+
+void problem_consts(Problem &p) {
+    const int n = p.n, nz = p.nz, m = p.m;
+    vec QH((size_t)nz * n), QfH((size_t)nz * n, 0.0);
+    matmul(p.Qz, p.H, nz, nz, n, QH.data());
+    p.Qx.assign((size_t)n * n, 0.0); p.QxN.assign((size_t)n * n, 0.0);
+    matTmul(p.H, QH.data(), nz, n, n, p.Qx.data());
+    for (auto &e : p.Qx) e *= 2.0;
+    p.QxN = p.Qx;
+    if (p.Qzf) {
+        matmul(p.Qzf, p.H, nz, nz, n, QfH.data());
+        vec t((size_t)n * n);
+        matTmul(p.H, QfH.data(), nz, n, n, t.data());
+        for (size_t e = 0; e < t.size(); ++e) p.QxN[e] += 2.0 * t[e];
+    }
+    p.Ru.assign(p.R, p.R + (size_t)m * m);
+    for (auto &e : p.Ru) e *= 2.0;
+}
+
+void grad_x(const Problem &p, int k, const double *x, double *g) {          // riccati_ipm.Problem.grad_x
+    const int n = p.n, nz = p.nz;
+    matvec(p.Qx.data(), n, n, x, g);
+    vec t(nz, 0.0), t2(nz);
+    if (p.z) {
+        matvec(p.Qz, nz, nz, p.z + (size_t)k * nz, t.data());
+        for (int i = 0; i < n; ++i) { double s = 0.0; for (int a = 0; a < nz; ++a) s += p.H[(size_t)a * n + i] * t[a]; g[i] -= 2.0 * s; }
+    }
+    if (k == p.N && p.Qzf) {
+        vec e(nz);
+        matvec(p.H, nz, n, x, e.data());
+        for (int a = 0; a < nz; ++a) e[a] -= p.zf ? p.zf[a] : 0.0;
+        matvec(p.Qzf, nz, nz, e.data(), t2.data());
+        for (int i = 0; i < n; ++i) { double s = 0.0; for (int a = 0; a < nz; ++a) s += p.H[(size_t)a * n + i] * t2[a]; g[i] += 2.0 * s; }
+    }
+}
+
+double objective(const Problem &p, const vec &x, const vec &u, const vec &s) {
+    const int N = p.N, n = p.n, m = p.m, nz = p.nz;
+    double J = 0.0;
+    vec e(nz), t(nz);
+    for (int k = 0; k <= N; ++k) {
+        matvec(p.H, nz, n, &x[(size_t)k * n], e.data());
+        if (p.z) for (int a = 0; a < nz; ++a) e[a] -= p.z[(size_t)k * nz + a];
+        matvec(p.Qz, nz, nz, e.data(), t.data());
+        for (int a = 0; a < nz; ++a) J += e[a] * t[a];
+    }
+    if (p.Qzf) {
+        matvec(p.H, nz, n, &x[(size_t)N * n], e.data());
+        for (int a = 0; a < nz; ++a) e[a] -= p.zf ? p.zf[a] : 0.0;
+        matvec(p.Qzf, nz, nz, e.data(), t.data());
+        for (int a = 0; a < nz; ++a) J += e[a] * t[a];
+    }
+    vec ue(m), tu(m);
+    for (int k = 0; k < N; ++k) {
+        for (int a = 0; a < m; ++a) ue[a] = u[(size_t)k * m + a] - (p.ud ? p.ud[(size_t)k * m + a] : 0.0);
+        matvec(p.R, m, m, ue.data(), tu.data());
+        for (int a = 0; a < m; ++a) J += ue[a] * tu[a];
+    }
+    if (p.tr) for (int k = 0; k <= N; ++k) J += p.omega * s[k];
+    return J;
+}
+
+// inequality rows owned by x_k (k >= 1): Ax x + as s <= h   (riccati_ipm._rows_x)
+struct XRows { int nr; vec Ax, as, h; };
+XRows rows_x(const Problem &p, int k) {
+    const int n = p.n;
+    XRows r;
+    r.nr = (p.tr ? 2 * n + 1 : 0) + p.nX + (k == p.N ? p.nXf : 0);
+    r.Ax.assign((size_t)r.nr * n, 0.0); r.as.assign(r.nr, 0.0); r.h.assign(r.nr, 0.0);
+    int o = 0;
+    if (p.tr) {
+        for (int i = 0; i < n; ++i) { r.Ax[(size_t)(o + i) * n + i] = p.xs[i]; r.as[o + i] = -1.0; r.h[o + i] = p.delta + p.xs[i] * p.xk[(size_t)k * n + i]; }
+        o += n;
+        for (int i = 0; i < n; ++i) { r.Ax[(size_t)(o + i) * n + i] = -p.xs[i]; r.as[o + i] = -1.0; r.h[o + i] = p.delta - p.xs[i] * p.xk[(size_t)k * n + i]; }
+        o += n;
+        r.as[o] = -1.0; o += 1;
+    }
+    for (int i = 0; i < p.nX; ++i) { std::copy(p.XA + (size_t)i * n, p.XA + (size_t)(i + 1) * n, &r.Ax[(size_t)(o + i) * n]); r.h[o + i] = p.Xb[i]; }
+    o += p.nX;
+    if (k == p.N) for (int i = 0; i < p.nXf; ++i) { std::copy(p.XfA + (size_t)i * n, p.XfA + (size_t)(i + 1) * n, &r.Ax[(size_t)(o + i) * n]); r.h[o + i] = p.Xfb[i]; }
+    return r;
+}
+
+struct Info { int iters; int status; double mu; };      // status 0 optimal, 1 max_iter, 2 failed
+
+// oracle/riccati_ipm.py: solve().  x (N+1 x n), u (N x m), s (N+1).
+Info ipm_solve(const Problem &p, vec &x, vec &u, vec &s, double *J_out, double tol = 1e-12, int max_iter = 60, double reg = 1e-8) {
+    const int N = p.N, n = p.n, m = p.m, nU = p.nU;
+    std::vector<XRows> rows(N + 1);
+    for (int k = 1; k <= N; ++k) rows[k] = rows_x(p, k);
+    int ng = N * nU;
+    for (int k = 1; k <= N; ++k) ng += rows[k].nr;
+    auto rollout = [&](const vec &uu, vec &xx) {
+        std::copy(p.x0, p.x0 + n, xx.begin());
+        vec t(n);
+        for (int k = 0; k < N; ++k) {
+            matvec(p.A[k], n, n, &xx[(size_t)k * n], t.data());
+            for (int i = 0; i < n; ++i) {
+                double sB = 0.0;
+                for (int a = 0; a < m; ++a) sB += p.B[k][(size_t)i * m + a] * uu[(size_t)k * m + a];
+                xx[(size_t)(k + 1) * n + i] = t[i] + sB + p.d[k][i];
+            }
+        }
+    };
+    // per-row state: x rows per stage, u rows per stage
+    std::vector<vec> tx(N + 1), lx(N + 1), Dx(N + 1), rhox(N + 1), rgx(N + 1), dtx(N + 1), dlx(N + 1), rcx(N + 1), ex(N + 1);
+    std::vector<vec> tu(N), lu(N), Du(N), rhou(N), rgu(N), dtu(N), dlu(N), rcu(N), eu(N);
+    for (int k = 1; k <= N; ++k) for (auto *v : {&tx[k], &lx[k], &Dx[k], &rhox[k], &rgx[k], &dtx[k], &dlx[k], &rcx[k], &ex[k]}) v->assign(rows[k].nr, 0.0);
+    for (int k = 0; k < N; ++k) for (auto *v : {&tu[k], &lu[k], &Du[k], &rhou[k], &rgu[k], &dtu[k], &dlu[k], &rcu[k], &eu[k]}) v->assign(nU, 0.0);
+    // storage of the factorisation
+    vec K((size_t)N * m * n), kff((size_t)N * m), Lq((size_t)N * m * m), dx((size_t)(N + 1) * n), du((size_t)N * m), ds(N + 1);
+    std::vector<vec> celim_c(N + 1);
+    vec celim_H(N + 1, 1.0), celim_g(N + 1, 0.0);
+
+    // Newton system by a backward Riccati recursion.  use_lam: also the reduced dual residual with the multipliers.
+    auto newton = [&](bool factor, bool use_lam, double *rd_out) -> bool {
+        vec P((size_t)n * n), pv(n), adj(n), Hxx((size_t)n * n), gx(n), gxd(n), W((size_t)n * n), G((size_t)n * m), Quu((size_t)m * m),
+            Qux((size_t)m * n), Qu(m), gu(m), gud(m), t1(n), Pn((size_t)n * n), t2(std::max(n, m));
+        double rd = 0.0;
+        for (int k = N; k >= 0; --k) {
+            if (k >= 1) {
+                const XRows &r = rows[k];
+                grad_x(p, k, &x[(size_t)k * n], gx.data());
+                gxd = gx;
+                matTvec_add(r.Ax.data(), r.nr, n, rhox[k].data(), gx.data());
+                if (use_lam) {
+                    matTvec_add(r.Ax.data(), r.nr, n, lx[k].data(), gxd.data());
+                    if (p.tr) { double sl = p.omega; for (int i = 0; i < r.nr; ++i) sl += r.as[i] * lx[k][i]; rd = std::max(rd, std::fabs(sl)); }
+                } else {
+                    gxd = gx;
+                }
+                if (factor) {
+                    Hxx = (k == N) ? p.QxN : p.Qx;
+                    for (int i = 0; i < r.nr; ++i) {           // Ax^T D Ax (rows are sparse for the trust region: skip zeros)
+                        const double dw = Dx[k][i];
+                        const double *a = &r.Ax[(size_t)i * n];
+                        for (int c1 = 0; c1 < n; ++c1) {
+                            if (a[c1] == 0.0) continue;
+                            const double f = dw * a[c1];
+                            for (int c2 = 0; c2 < n; ++c2) Hxx[(size_t)c1 * n + c2] += f * a[c2];
+                        }
+                    }
+                }
+                if (p.tr) {
+                    double gs = p.omega, Hss = 0.0;
+                    vec c(n, 0.0);
+                    for (int i = 0; i < r.nr; ++i) {
+                        gs += r.as[i] * rhox[k][i];
+                        Hss += r.as[i] * Dx[k][i] * r.as[i];
+                        const double f = Dx[k][i] * r.as[i];
+                        if (f != 0.0) for (int c1 = 0; c1 < n; ++c1) c[c1] += r.Ax[(size_t)i * n + c1] * f;
+                    }
+                    celim_c[k] = c; celim_H[k] = Hss; celim_g[k] = gs;
+                    if (factor) {
+                        // eliminate s_k; the diagonal of diag(hd) - c c^T / Hss without cancellation (see the port)
+                        for (int i = 0; i < n; ++i)
+                            for (int j = 0; j < n; ++j) if (i != j) Hxx[(size_t)i * n + j] -= c[i] * c[j] / Hss;
+                        for (int i = 0; i < n; ++i) {
+                            const double Dp = Dx[k][i], Dm = Dx[k][n + i];
+                            const double naive = p.xs[i] * p.xs[i] * (Dp + Dm);
+                            const double stable = p.xs[i] * p.xs[i] * ((Dp + Dm) * (Hss - (Dp + Dm)) + 4.0 * Dp * Dm) / Hss;
+                            Hxx[(size_t)i * n + i] += stable - naive;
+                        }
+                    }
+                    for (int i = 0; i < n; ++i) gx[i] -= c[i] * gs / Hss;
+                }
+            }
+            if (k == N) {
+                if (factor) P = Hxx;
+                pv = gx; adj = gxd;
+                continue;
+            }
+            // input stage k
+            for (int a = 0; a < m; ++a) {
+                double s1 = 0.0;
+                for (int b = 0; b < m; ++b) s1 += p.Ru[(size_t)a * m + b] * (u[(size_t)k * m + b] - (p.ud ? p.ud[(size_t)k * m + b] : 0.0));
+                gu[a] = s1; gud[a] = s1;
+            }
+            for (int r = 0; r < nU; ++r)
+                for (int a = 0; a < m; ++a) {
+                    gu[a] += p.UA[(size_t)r * m + a] * rhou[k][r];
+                    if (use_lam) gud[a] += p.UA[(size_t)r * m + a] * lu[k][r];
+                }
+            if (!use_lam) gud = gu;
+            const double *A = p.A[k], *B = p.B[k];
+            // Qu = gu + B^T pv ; reduced gradient wrt u_k with the multipliers
+            for (int a = 0; a < m; ++a) {
+                double s1 = gu[a], s2 = gud[a];
+                for (int i = 0; i < n; ++i) { s1 += B[(size_t)i * m + a] * pv[i]; s2 += B[(size_t)i * m + a] * adj[i]; }
+                Qu[a] = s1;
+                rd = std::max(rd, std::fabs(s2));
+            }
+            double *Kk = &K[(size_t)k * m * n], *Lk = &Lq[(size_t)k * m * m];
+            if (factor) {
+                matmul(P.data(), A, n, n, n, W.data());
+                matmul(P.data(), B, n, n, m, G.data());
+                matTmul(B, G.data(), n, m, m, Quu.data());
+                for (int e = 0; e < m * m; ++e) Quu[e] += p.Ru[e];
+                for (int r = 0; r < nU; ++r) {
+                    const double dw = Du[k][r];
+                    for (int a = 0; a < m; ++a) for (int b = 0; b < m; ++b) Quu[(size_t)a * m + b] += p.UA[(size_t)r * m + a] * dw * p.UA[(size_t)r * m + b];
+                }
+                matTmul(B, W.data(), n, m, n, Qux.data());
+                std::copy(Quu.begin(), Quu.end(), Lk);
+                if (!cholesky(Lk, m)) return false;
+                chol_solve_neg(Lk, m, Qux.data(), n, Kk);
+            }
+            chol_solve_neg(Lk, m, Qu.data(), 1, &kff[(size_t)k * m]);
+            if (k >= 1) {
+                if (factor) {
+                    // P = Hxx + A^T W + Qux^T K, symmetrised
+                    matTmul(A, W.data(), n, n, n, Pn.data());
+                    for (int i = 0; i < n; ++i)
+                        for (int j = 0; j < n; ++j) {
+                            double s1 = Hxx[(size_t)i * n + j] + Pn[(size_t)i * n + j];
+                            for (int a = 0; a < m; ++a) s1 += Qux[(size_t)a * n + i] * Kk[(size_t)a * n + j];
+                            P[(size_t)i * n + j] = s1;
+                        }
+                    for (int i = 0; i < n; ++i)
+                        for (int j = i + 1; j < n; ++j) { const double v = 0.5 * (P[(size_t)i * n + j] + P[(size_t)j * n + i]); P[(size_t)i * n + j] = P[(size_t)j * n + i] = v; }
+                }
+                // pv = gx + A^T pv + K^T Qu ; adj = gxd + A^T adj
+                std::fill(t1.begin(), t1.end(), 0.0);
+                matTvec_add(A, n, n, pv.data(), t1.data());
+                for (int j = 0; j < n; ++j) { double s1 = gx[j] + t1[j]; for (int a = 0; a < m; ++a) s1 += Kk[(size_t)a * n + j] * Qu[a]; t1[j] = s1; }
+                std::fill(t2.begin(), t2.end(), 0.0);
+                matTvec_add(A, n, n, adj.data(), t2.data());
+                for (int j = 0; j < n; ++j) adj[j] = gxd[j] + t2[j];
+                pv = t1;
+            }
+        }
+        // forward
+        std::fill(dx.begin(), dx.end(), 0.0);
+        ds.assign(N + 1, 0.0);
+        vec t(n);
+        for (int k = 0; k < N; ++k) {
+            const double *Kk = &K[(size_t)k * m * n];
+            for (int a = 0; a < m; ++a) {
+                double s1 = kff[(size_t)k * m + a];
+                for (int j = 0; j < n; ++j) s1 += Kk[(size_t)a * n + j] * dx[(size_t)k * n + j];
+                du[(size_t)k * m + a] = s1;
+            }
+            matvec(p.A[k], n, n, &dx[(size_t)k * n], t.data());
+            for (int i = 0; i < n; ++i) {
+                double sB = 0.0;
+                for (int a = 0; a < m; ++a) sB += p.B[k][(size_t)i * m + a] * du[(size_t)k * m + a];
+                dx[(size_t)(k + 1) * n + i] = t[i] + sB;
+            }
+            if (p.tr) {
+                double cd = 0.0;
+                for (int i = 0; i < n; ++i) cd += celim_c[k + 1][i] * dx[(size_t)(k + 1) * n + i];
+                ds[k + 1] = -(celim_g[k + 1] + cd) / celim_H[k + 1];
+            }
+        }
+        if (rd_out) *rd_out = rd;
+        return true;
+    };
+    auto row_vals = [&](const vec &xx, const vec &uu, const vec &ss, std::vector<vec> &gxo, std::vector<vec> &guo) {
+        for (int k = 1; k <= N; ++k) {
+            const XRows &r = rows[k];
+            for (int i = 0; i < r.nr; ++i) {
+                double s1 = r.as[i] * ss[k] - r.h[i];
+                const double *a = &r.Ax[(size_t)i * n];
+                for (int j = 0; j < n; ++j) s1 += a[j] * xx[(size_t)k * n + j];
+                gxo[k][i] = s1;
+            }
+        }
+        for (int k = 0; k < N; ++k)
+            for (int r = 0; r < nU; ++r) {
+                double s1 = -p.Ub[r];
+                for (int a = 0; a < m; ++a) s1 += p.UA[(size_t)r * m + a] * uu[(size_t)k * m + a];
+                guo[k][r] = s1;
+            }
+    };
+    auto row_dirs = [&](std::vector<vec> &axo, std::vector<vec> &auo) {
+        for (int k = 1; k <= N; ++k) {
+            const XRows &r = rows[k];
+            for (int i = 0; i < r.nr; ++i) {
+                double s1 = r.as[i] * ds[k];
+                const double *a = &r.Ax[(size_t)i * n];
+                for (int j = 0; j < n; ++j) s1 += a[j] * dx[(size_t)k * n + j];
+                axo[k][i] = s1;
+            }
+        }
+        for (int k = 0; k < N; ++k)
+            for (int r = 0; r < nU; ++r) {
+                double s1 = 0.0;
+                for (int a = 0; a < m; ++a) s1 += p.UA[(size_t)r * m + a] * du[(size_t)k * m + a];
+                auo[k][r] = s1;
+            }
+    };
+    auto s0 = [&]() {
+        if (!p.tr) return 0.0;
+        double v = 0.0;
+        for (int i = 0; i < n; ++i) v = std::max(v, std::fabs(p.xs[i] * (p.x0[i] - p.xk[i])));
+        return std::max(0.0, v - p.delta);
+    };
+    x.assign((size_t)(N + 1) * n, 0.0); u.assign((size_t)N * m, 0.0); s.assign(N + 1, 0.0);
+    s[0] = s0();
+    rollout(u, x);
+    Info info{0, 1, 0.0};
+    std::vector<vec> gx(N + 1), gu(N), ax(N + 1), au(N);
+    for (int k = 1; k <= N; ++k) { gx[k].assign(rows[k].nr, 0.0); ax[k].assign(rows[k].nr, 0.0); }
+    for (int k = 0; k < N; ++k) { gu[k].assign(nU, 0.0); au[k].assign(nU, 0.0); }
+    if (ng == 0) {
+        if (!newton(true, false, nullptr)) { info.status = 2; return info; }
+        for (size_t e = 0; e < u.size(); ++e) u[e] += du[e];
+        rollout(u, x);
+        if (J_out) *J_out = objective(p, x, u, s);
+        info.status = 0;
+        return info;
+    }
+    // starting point: unit weights, gradient shifts = row values, then shift into the positive orthant
+    row_vals(x, u, s, gx, gu);
+    for (int k = 1; k <= N; ++k) { std::fill(Dx[k].begin(), Dx[k].end(), 1.0); rhox[k] = gx[k]; }
+    for (int k = 0; k < N; ++k) { std::fill(Du[k].begin(), Du[k].end(), 1.0); rhou[k] = gu[k]; }
+    if (!newton(true, false, nullptr)) { info.status = 2; return info; }
+    for (size_t e = 0; e < x.size(); ++e) x[e] += dx[e];
+    for (size_t e = 0; e < u.size(); ++e) u[e] += du[e];
+    for (int k = 0; k <= N; ++k) s[k] += ds[k];
+    s[0] = s0();
+    row_vals(x, u, s, gx, gu);
+    double zmin = INF, zmax = -INF;
+    for (int k = 1; k <= N; ++k) for (double g : gx[k]) { zmin = std::min(zmin, g); zmax = std::max(zmax, g); }
+    for (int k = 0; k < N; ++k) for (double g : gu[k]) { zmin = std::min(zmin, g); zmax = std::max(zmax, g); }
+    const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
+    for (int k = 1; k <= N; ++k) for (int i = 0; i < rows[k].nr; ++i) { tx[k][i] = -gx[k][i] + sh_t; lx[k][i] = gx[k][i] + sh_l; }
+    for (int k = 0; k < N; ++k) for (int i = 0; i < nU; ++i) { tu[k][i] = -gu[k][i] + sh_t; lu[k][i] = gu[k][i] + sh_l; }
+    vec g1(n), zero(n, 0.0);
+    grad_x(p, 1, zero.data(), g1.data());
+    double scale_d = std::max(1.0, p.omega), scale_p = std::max(1.0, std::fabs(p.delta));
+    for (double g : g1) scale_d = std::max(scale_d, std::fabs(g));
+    for (int r = 0; r < nU; ++r) scale_p = std::max(scale_p, std::fabs(p.Ub[r]));
+    const double dreg = reg / scale_d;
+    auto each_row = [&](auto f) {            // f(t, lam, rg, D, rho, rc, dt, dlam, e, a) over every row
+        for (int k = 1; k <= N; ++k) for (int i = 0; i < rows[k].nr; ++i) f(tx[k][i], lx[k][i], rgx[k][i], Dx[k][i], rhox[k][i], rcx[k][i], dtx[k][i], dlx[k][i], ex[k][i], ax[k][i], gx[k][i]);
+        for (int k = 0; k < N; ++k) for (int i = 0; i < nU; ++i) f(tu[k][i], lu[k][i], rgu[k][i], Du[k][i], rhou[k][i], rcu[k][i], dtu[k][i], dlu[k][i], eu[k][i], au[k][i], gu[k][i]);
+    };
+    double mu = 0.0;
+    int it = 0;
+    for (it = 0; it < max_iter; ++it) {
+        row_vals(x, u, s, gx, gu);
+        double musum = 0.0, rp = 0.0;
+        each_row([&](double &t, double &lam, double &rg, double &D, double &rho, double &, double &, double &, double &e, double &, double &g) {
+            rg = g + t;
+            musum += lam * t;
+            e = t + dreg * lam;
+            D = lam / e;
+            rho = lam + (lam * rg - lam * t) / e;
+            rp = std::max(rp, std::fabs(rg));
+        });
+        mu = musum / ng;
+        double rd = 0.0;
+        if (!newton(true, true, &rd)) { info.status = 2; break; }
+        if (rd <= std::max(tol, 1e-9) * scale_d && rp <= std::max(tol, 1e-9) * scale_p && mu <= tol) { info.status = 0; break; }
+        row_dirs(ax, au);
+        double a_aff = 1.0;
+        each_row([&](double &t, double &lam, double &rg, double &, double &, double &, double &dt, double &dl, double &e, double &a, double &) {
+            dl = (-lam * t + lam * (rg + a)) / e;
+            dt = -rg - a + dreg * dl;
+            if (dt < 0.0) a_aff = std::min(a_aff, -t / dt);
+            if (dl < 0.0) a_aff = std::min(a_aff, -lam / dl);
+        });
+        double ma = 0.0;
+        each_row([&](double &t, double &lam, double &, double &, double &, double &, double &dt, double &dl, double &, double &, double &) { ma += (lam + a_aff * dl) * (t + a_aff * dt); });
+        const double mu_aff = ma / ng;
+        const double sigma = mu > 0.0 ? std::pow(mu_aff / mu, 3.0) : 0.0;
+        each_row([&](double &t, double &lam, double &rg, double &, double &rho, double &rc, double &dt, double &dl, double &e, double &, double &) {
+            rc = lam * t + dt * dl - sigma * mu;
+            rho = lam + (lam * rg - rc) / e;
+        });
+        if (!newton(false, false, nullptr)) { info.status = 2; break; }
+        row_dirs(ax, au);
+        double amax = INF;
+        each_row([&](double &t, double &lam, double &rg, double &, double &, double &rc, double &dt, double &dl, double &e, double &a, double &) {
+            dl = (-rc + lam * (rg + a)) / e;
+            dt = -rg - a + dreg * dl;
+            if (dt < 0.0) amax = std::min(amax, -t / dt);
+            if (dl < 0.0) amax = std::min(amax, -lam / dl);
+        });
+        const double a = std::min(1.0, 0.99 * amax);
+        for (size_t e = 0; e < x.size(); ++e) x[e] += a * dx[e];
+        for (size_t e = 0; e < u.size(); ++e) u[e] += a * du[e];
+        for (int k = 0; k <= N; ++k) s[k] += a * ds[k];
+        s[0] = s0();
+        each_row([&](double &t, double &lam, double &, double &, double &, double &, double &dt, double &dl, double &, double &, double &) { t += a * dt; lam += a * dl; });
+        if (!std::isfinite(mu)) { info.status = 2; break; }
+    }
+    rollout(u, x);
+    if (J_out) *J_out = objective(p, x, u, s);
+    info.iters = it; info.mu = mu;
+    return info;
+}
+
+// The QP with the device kernel's control flow: without the trust-region rows first; the full QP only if that
+// minimiser leaves the trust region (dropping satisfied constraints cannot change an optimum).
+Info qp_solve(Problem &p, vec &x, vec &u, vec &s, double *J) {
+    if (p.tr) {
+        Problem q = p;
+        q.tr = false;
+        Info a = ipm_solve(q, x, u, s, J);
+        if (a.status == 0) {
+            double md = 0.0;
+            for (int k = 1; k <= p.N; ++k)
+                for (int i = 0; i < p.n; ++i) md = std::max(md, std::fabs(p.xs[i] * (x[(size_t)k * p.n + i] - p.xk[(size_t)k * p.n + i])));
+            if (md <= p.delta) {
+                double v = 0.0;
+                for (int i = 0; i < p.n; ++i) v = std::max(v, std::fabs(p.xs[i] * (p.x0[i] - p.xk[i])));
+                s.assign(p.N + 1, 0.0);
+                s[0] = std::max(0.0, v - p.delta);
+                if (J) *J += p.omega * s[0];
+                return a;
+            }
+        }
+    }
+    return ipm_solve(p, x, u, s, J);
+}
+
+struct GustoPar { double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh; int max_iters; };
+
+// one rollout: oracle/gusto.py _loop with the nearest-point TPWL model.  Returns the number of SCP iterations.
+int gusto_one(const Model &M, Problem base, const GustoPar &par, double dt, const double *fs, const double *x0, const double *u_init,
+              const double *x_init, double *xopt, double *uopt, double *trace, int max_trace) {
+    const int N = base.N, n = base.n, m = base.m;
+    vec xk(x_init, x_init + (size_t)(N + 1) * n), uk(u_init, u_init + (size_t)N * m);
+    std::vector<int> idx(N), idx2(N);
+    auto linearise = [&](const vec &xx, std::vector<int> &id) { for (int k = 0; k < N; ++k) id[k] = nearest(M, &xx[(size_t)k * n]); };
+    linearise(xk, idx);
+    double delta = par.delta0, omega = par.omega0, J_prev = INF, d_prev = INF, o_prev = INF;
+    bool converged = false;
+    int itr = 0;
+    vec x, u, s;
+    while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
+        Problem p = base;
+        p.x0 = x0; p.xk = xk.data(); p.delta = delta; p.omega = omega;
+        p.A.resize(N); p.B.resize(N); p.d.resize(N);
+        for (int k = 0; k < N; ++k) { p.A[k] = M.Ad + (size_t)idx[k] * n * n; p.B[k] = M.Bd + (size_t)idx[k] * n * m; p.d[k] = M.dd + (size_t)idx[k] * n; }
+        double J = 0.0;
+        const Info inf = qp_solve(p, x, u, s, &J);
+        if (inf.status != 0) break;
+        double md = 0.0;
+        for (int k = 0; k <= N; ++k) for (int i = 0; i < n; ++i) md = std::max(md, std::fabs(p.xs[i] * (x[(size_t)k * n + i] - xk[(size_t)k * n + i])));
+        const bool tr_ok = !(md - delta > par.epsilon);
+        bool new_solution = false;
+        double rho_k = -1.0;
+        const double d_cur = delta, o_cur = omega;
+        if (tr_ok) {
+            linearise(x, idx2);
+            double err = 0.0, app = 0.0;
+            for (int k = 0; k < N; ++k) {
+                const double *Ak = M.Ac + (size_t)idx[k] * n * n, *Bk = M.Bc + (size_t)idx[k] * n * m, *dk = M.dc + (size_t)idx[k] * n;
+                const double *An = M.Ac + (size_t)idx2[k] * n * n, *Bn = M.Bc + (size_t)idx2[k] * n * m, *dn = M.dc + (size_t)idx2[k] * n;
+                double e2 = 0.0, a2 = 0.0;
+                for (int r = 0; r < n; ++r) {
+                    double fk = dk[r], fl = 0.0, f = dn[r];
+                    for (int c = 0; c < n; ++c) {
+                        const double xo = xk[(size_t)k * n + c], xn = x[(size_t)k * n + c];
+                        fk += Ak[(size_t)r * n + c] * xo; fl += Ak[(size_t)r * n + c] * (xn - xo); f += An[(size_t)r * n + c] * xn;
+                    }
+                    for (int c = 0; c < m; ++c) {
+                        const double uo = uk[(size_t)k * m + c], un = u[(size_t)k * m + c];
+                        fk += Bk[(size_t)r * m + c] * uo; fl += Bk[(size_t)r * m + c] * (un - uo); f += Bn[(size_t)r * m + c] * un;
+                    }
+                    const double fa = fk + fl, de = fs[r] * (f - fa), da = fs[r] * fa;
+                    e2 += de * de; a2 += da * da;
+                }
+                err += dt * std::sqrt(e2); app += dt * std::sqrt(a2);
+            }
+            rho_k = err / (J + app);
+            if (rho_k > par.rho && itr != 1) {
+                delta = par.beta_fail * delta;
+            } else {
+                if (d_prev == delta && o_prev == omega && J_prev <= J) delta = par.beta_fail * delta;
+                d_prev = delta; J_prev = J; o_prev = omega;
+                double viol = 0.0;
+                for (int k = 0; k <= N && base.nX > 0; ++k) {
+                    double v2 = 0.0;
+                    for (int r = 0; r < base.nX; ++r) {
+                        double v = -base.Xb[r];
+                        for (int j = 0; j < n; ++j) v += base.XA[(size_t)r * n + j] * x[(size_t)k * n + j];
+                        v = std::max(v, 0.0); v2 += v * v;
+                    }
+                    viol = std::max(viol, std::sqrt(v2));
+                }
+                const bool X_ok = !(viol > par.epsilon);
+                if (!X_ok) omega = par.gamma_fail * omega;
+                double dsum = 0.0;
+                for (int k = 0; k <= N; ++k) {
+                    double v2 = 0.0;
+                    for (int j = 0; j < n; ++j) { const double e = p.xs[j] * (x[(size_t)k * n + j] - xk[(size_t)k * n + j]); v2 += e * e; }
+                    dsum += std::sqrt(v2);
+                }
+                converged = ((1.0 / N) * ((1.0 / n) * dsum) <= par.convg_thresh) && X_ok;
+                new_solution = true;
+            }
+        } else {
+            omega = par.gamma_fail * omega;
+        }
+        if (trace && itr < max_trace) { double *t = trace + (size_t)itr * 4; t[0] = J; t[1] = d_cur; t[2] = o_cur; t[3] = rho_k; }
+        ++itr;
+        if (new_solution) {
+            xk = x; uk = u;
+            if (par.max_iters >= 1) linearise(xk, idx);
+        }
+    }
+    std::copy(xk.begin(), xk.end(), xopt);
+    std::copy(uk.begin(), uk.end(), uopt);
+    return itr;
+}
+
+template <typename F>
+void parallel_for(int64_t count, int threads, F f) {
+    threads = std::max(1, std::min<int>(threads, (int)count));
+    if (threads == 1) { for (int64_t i = 0; i < count; ++i) f(i); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([=]() { for (int64_t i = t; i < count; i += threads) f(i); });
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+struct scpu_problem {       // mirrors slocp_problem (include/sofacontrol_hip.h)
+    int N, n_x, n_u, n_z;
+    const double *H, *Qz, *R, *Qzf, *x_scale;
+    int nU; const double *UA, *Ub;
+    int nX; const double *XA, *Xb;
+    int nXf; const double *XfA, *Xfb;
+    int tr_active;
+};
+struct scpu_model { int P, r, m; double w_q, w_v; const double *q, *v, *Ac, *Bc, *dc, *Ad, *Bd, *dd; };
+struct scpu_gusto_params { double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh; int max_gusto_iters; };
+
+int scpu_version(void) { return 1; }
+
+// out (B x r) = (X (B x n_f) - ref) U (n_f x r), rows split over `threads`
+int scpu_project(const double *U, int64_t n_f, int r, const double *ref, const double *X, int64_t B, double *out, int threads) {
+    parallel_for(B, threads, [&](int64_t b) {
+        const double *x = X + (size_t)b * n_f;
+        double acc[64];
+        for (int j = 0; j < r; ++j) acc[j] = 0.0;
+        for (int64_t i = 0; i < n_f; ++i) {
+            const double e = x[i] - ref[i];
+            const double *urow = U + (size_t)i * r;
+            for (int j = 0; j < r; ++j) acc[j] += e * urow[j];
+        }
+        for (int j = 0; j < r; ++j) out[(size_t)b * r + j] = acc[j];
+    });
+    return 0;
+}
+
+static Problem make_problem(const scpu_problem *pr, const vec &ones) {
+    Problem p{};
+    p.N = pr->N; p.n = pr->n_x; p.m = pr->n_u; p.nz = pr->n_z; p.nU = pr->nU; p.nX = pr->nX; p.nXf = pr->nXf;
+    p.H = pr->H; p.Qz = pr->Qz; p.R = pr->R; p.Qzf = pr->Qzf;
+    p.UA = pr->UA; p.Ub = pr->Ub; p.XA = pr->XA; p.Xb = pr->Xb; p.XfA = pr->XfA; p.Xfb = pr->Xfb;
+    p.xs = pr->x_scale ? pr->x_scale : ones.data();
+    p.tr = pr->tr_active != 0;
+    problem_consts(p);
+    return p;
+}
+
+// one QP (LOCP.update + solve): per-stage Ad (N x n x n), Bd, dd given explicitly.  status 0 = optimal.
+int scpu_locp_solve(const scpu_problem *pr, const double *Ad, const double *Bd, const double *dd, const double *x0, const double *xk,
+                    double delta, double omega, const double *z, const double *zf, const double *u_des, double *x, double *u,
+                    double *s, double *J, int *iters) {
+    vec ones(pr->n_x, 1.0);
+    Problem p = make_problem(pr, ones);
+    const int N = p.N, n = p.n, m = p.m;
+    p.A.resize(N); p.B.resize(N); p.d.resize(N);
+    for (int k = 0; k < N; ++k) { p.A[k] = Ad + (size_t)k * n * n; p.B[k] = Bd + (size_t)k * n * m; p.d[k] = dd + (size_t)k * n; }
+    p.x0 = x0; p.xk = xk; p.z = z; p.zf = zf; p.ud = u_des; p.delta = delta; p.omega = omega;
+    vec xv, uv, sv;
+    double Jv = 0.0;
+    const Info inf = qp_solve(p, xv, uv, sv, &Jv);
+    std::copy(xv.begin(), xv.end(), x); std::copy(uv.begin(), uv.end(), u);
+    if (s) std::copy(sv.begin(), sv.end(), s);
+    if (J) *J = Jv;
+    if (iters) *iters = inf.iters;
+    return inf.status;
+}
+
+// GuSTO.solve for `batch` independent rollouts, one per thread at a time.  iters (batch): SCP iterations per rollout.
+int scpu_gusto_solve(const scpu_model *mo, const scpu_problem *pr, const scpu_gusto_params *gp, double dt, int64_t batch,
+                     const double *x0, const double *u_init, const double *x_init, const double *z, const double *zf,
+                     const double *u_des, const double *x_char, const double *f_char, double *xopt, double *uopt, int32_t *iters,
+                     double *trace, int max_trace, int threads) {
+    const int n = pr->n_x, m = pr->n_u, N = pr->N, nz = pr->n_z;
+    vec xs(n, 1.0), fs(n, 1.0);
+    if (x_char) for (int i = 0; i < n; ++i) xs[i] = 1.0 / std::fabs(x_char[i]);
+    if (f_char) for (int i = 0; i < n; ++i) fs[i] = 1.0 / std::fabs(f_char[i]);
+    scpu_problem p2 = *pr;
+    p2.x_scale = xs.data();
+    vec ones(n, 1.0);
+    const Problem base = make_problem(&p2, ones);
+    Model M{mo->P, mo->r, 2 * mo->r, mo->m, mo->w_q, mo->w_v, mo->q, mo->v, mo->Ac, mo->Bc, mo->dc, mo->Ad, mo->Bd, mo->dd};
+    GustoPar par{gp->delta0, gp->omega0, gp->rho, gp->beta_fail, gp->gamma_fail, gp->epsilon, gp->omega_max, gp->convg_thresh, gp->max_gusto_iters};
+    parallel_for(batch, threads, [&](int64_t b) {
+        Problem pb = base;
+        pb.z = z ? z + (size_t)b * (N + 1) * nz : nullptr;
+        pb.zf = zf ? zf + (size_t)b * nz : nullptr;
+        pb.ud = u_des ? u_des + (size_t)b * N * m : nullptr;
+        iters[b] = gusto_one(M, pb, par, dt, fs.data(), x0 + (size_t)b * n, u_init + (size_t)b * N * m, x_init + (size_t)b * (N + 1) * n,
+                             xopt + (size_t)b * (N + 1) * n, uopt + (size_t)b * N * m, trace ? trace + (size_t)b * max_trace * 4 : nullptr, max_trace);
+    });
+    return 0;
+}
+
+}  // extern "C"

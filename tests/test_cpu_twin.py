@@ -1,0 +1,61 @@
+"""CPU: the native CPU twin (oracle/csrc/sofacontrol_cpu.cpp -- the cpu_baseline of bench.py) against the numpy oracle:
+projection, the stage-structured interior point on the seeded QPs, the GuSTO loop on a small TPWL model."""
+import numpy as np
+import pytest
+
+from oracle import cpu_twin, gusto as ogusto, locp as olocp, pod as opod, riccati_ipm as ripm, tpwl as otpwl
+from qp_cases import CASES, make_case
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def test_projection_matches_numpy():
+    rng = np.random.default_rng(0)
+    U, _ = np.linalg.qr(rng.standard_normal((300, 8)))
+    ref = rng.uniform(-100, 100, 300)
+    X = ref + rng.standard_normal((37, 300))
+    for threads in (1, 3):
+        np.testing.assert_allclose(cpu_twin.project(U, ref, X, threads=threads), opod.project(U, ref, X), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_locp_matches_exact_solver(name):
+    case, _ = make_case(**CASES[name])
+    kw = dict(case)
+    args = [kw.pop(k) for k in ('N', 'H', 'Qz', 'R', 'Ad', 'Bd', 'dd', 'x0', 'xk', 'delta', 'omega')]
+    qp = olocp.build_qp(*args, **kw)
+    w, _, _ = olocp.solve_exact(qp)
+    xe, ue, se = olocp.split(qp, w)
+    x, u, s, J, info = cpu_twin.locp_solve(*args, **kw)
+    assert info['status'] == 0
+    assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
+    assert abs(J - olocp.objective(qp, w)) <= 1e-7 * max(1.0, abs(olocp.objective(qp, w)))
+
+
+def test_gusto_loop_matches_numpy_loop():
+    model = otpwl.synthetic_model(4, 3, 7, seed=30)
+    model['q'] = model['q'] * 0.05
+    dt, N = 0.05, 12
+    Ad, Bd, dd = otpwl.pre_discretize(model, dt, 'zoh')
+    H = otpwl.synthetic_output_matrix(4, 6, 31)
+    Qz = np.diag([0, 0, 0, 100., 100., 0]); R = 1e-5 * np.eye(3)
+    th = np.linspace(0, 1.5, N + 1)
+    z = np.zeros((N + 1, 6)); z[:, 3] = -0.15 * np.sin(th); z[:, 4] = 0.075 * np.sin(2 * th)
+    UA = np.kron(np.eye(3), np.array([[1.], [-1.]])); Ub = np.tile([800., 0.], 3)
+    xc, fc = otpwl.characteristic_vals(model)
+    rng = np.random.default_rng(2)
+    B = 3
+    x0 = 1e-3 * rng.standard_normal((B, 8))
+    u_init = np.zeros((B, N, 3))
+    x_init = np.stack([otpwl.rollout(model, Ad, Bd, dd, x0[b], u_init[b]) for b in range(B)])
+    zb = np.stack([z * (1 + 0.2 * b) for b in range(B)])
+    xo, uo, iters, trace = cpu_twin.gusto_solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=zb, U=(UA, Ub), x_char=xc,
+                                                f_char=fc, convg_thresh=1e-3, max_gusto_iters=8, threads=2, max_trace=16)
+    for b in range(B):
+        xe, ue, ze, tr = ogusto.solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0[b], u_init[b], x_init[b], z=zb[b], U=(UA, Ub), x_char=xc,
+                                      f_char=fc, convg_thresh=1e-3, max_gusto_iters=8, qp_solver='riccati_ipm')
+        assert int(iters[b]) == len(tr)
+        np.testing.assert_allclose(trace[b, :len(tr), :3], np.array([t[:3] for t in tr]), rtol=1e-6)
+        assert rel(xo[b], xe) <= 1e-4 and rel(uo[b], ue) <= 1e-4
