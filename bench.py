@@ -338,24 +338,24 @@ def secondary(L, _lib, rank, world, dist):
                                   '(PCIe copies inside the time); best of 3 calls' % Bn,
                       'iterations_per_s': float(il.iters.sum()) / t, 'ms': t * 1e3, 'ms_all_calls': [x * 1e3 for x in ts],
                       'iterations': int(il.iters.sum())}
-    # ---- C4 (per-GPU column shard)
+    # ---- C4 (per-GPU column shard): the local Gramian alone, then the whole sharded POD build of the product
+    # (distributed.pod_from_column_shards: Gramian -> reduce-scatter + all-gather over RCCL when world > 1 -> replicated
+    # eigen-decomposition -> local mode rows), everything resident in HBM, phases timed separately
+    import torch
+    from sofacontrol_amd.distributed import pod_from_column_shards
     n_s, n_f = 10000, 50000 // 8
-    S = np.random.default_rng(7 + rank).standard_normal((n_s, n_f))
-    dS = _lib.DeviceBuffer.from_array(S)
-    del S
-    if dist is not None:
-        import torch
-        G = torch.empty((n_s, n_s), dtype=torch.float64, device='cuda')
-        gptr = C.c_void_p(G.data_ptr())
-    else:
-        dG = _lib.DeviceBuffer(n_s * n_s * 8)
-        gptr = dG.ptr
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(7 + rank)
+    S_t = torch.randn((n_s, n_f), dtype=torch.float64, device='cuda', generator=gen)
+    G_t = torch.empty((n_s, n_s), dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    sptr, gptr = C.c_void_p(S_t.data_ptr()), C.c_void_p(G_t.data_ptr())
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.srh_event_create(C.byref(e0)); L.srh_event_create(C.byref(e1))
-    _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), gptr, None), 'gramian')
+    _lib.check(L.srom_gramian_dev(sptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), gptr, None), 'gramian')
     _lib.sync()
     L.srh_event_record(e0, None)
-    _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), gptr, None), 'gramian')
+    _lib.check(L.srom_gramian_dev(sptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), gptr, None), 'gramian')
     L.srh_event_record(e1, None)
     _lib.sync()
     ms = C.c_float()
@@ -364,6 +364,21 @@ def secondary(L, _lib, rank, world, dist):
     out['gramian_c4'] = {'workload': 'C4 per-GPU shard: S %d x %d f64, G = S S^T' % (n_s, n_f), 'ms': ms.value,
                          'tflops_executed': flop / (ms.value * 1e-3) / 1e12,
                          'frac_of_f64_mfma_peak': flop / (ms.value * 1e-3) / 1e12 / 78.6}
+    del G_t
+    try:
+        tm = {}
+        pod_from_column_shards(S_t, 1e-4, rom_dim=64, timings=tm, keep_on_device=True, force_torch=True)      # first call: loads rocSOLVER
+        tm = {}
+        U_loc, k, Sig = pod_from_column_shards(S_t, 1e-4, rom_dim=64, timings=tm, keep_on_device=True, force_torch=True)
+        out['pod_build_c4'] = {'workload': 'C4: 10000 snapshots x %d DoF columns per GPU (50000 over 8), %d GPU(s); k = 64 modes kept; '
+                                           'S resident in HBM' % (n_f, world), 'world': world,
+                               'phases_ms': {kk: (v * 1e3 if isinstance(v, float) else v) for kk, v in tm.items()},
+                               'allreduce_payload_bytes': n_s * n_s * 8}
+        del U_loc
+    except Exception as exc:
+        out['pod_build_c4'] = {'error': repr(exc)}
+    del S_t
+    torch.cuda.empty_cache()
     try:
         out['pod_shapes'] = pod_shapes(L, _lib)
     except Exception as exc:
@@ -374,15 +389,6 @@ def secondary(L, _lib, rank, world, dist):
             out['scp_c5_32_rollouts'] = scp_c5(_lib, 0, 1, None, total=32)
     except Exception as exc:
         out['scp_c5'] = {'error': repr(exc)}
-    if dist is not None:
-        import torch
-        dist.all_reduce(G)                      # untimed: RCCL sets up its channels for this size
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        dist.all_reduce(G)
-        torch.cuda.synchronize()
-        out['gramian_c4']['allreduce_ms'] = (time.perf_counter() - t0) * 1e3
-        out['gramian_c4']['allreduce_bytes'] = n_s * n_s * 8
     return out
 
 
@@ -404,10 +410,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    # torch (device memory for the RCCL collective, C4 secondary) brings its own HIP runtime: it has to initialise
+    # before the first call into libsofacontrol_hip
+    import torch
+    torch.cuda.set_device(local_rank)
+    torch.cuda.init()
     if world > 1 or os.environ.get('SRH_FORCE_DIST') == '1':
-        import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     import workloads as wl

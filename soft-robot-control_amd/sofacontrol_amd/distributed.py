@@ -18,41 +18,174 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _hip_local_gramian(S_shard):
-    from .mor.pod import gramian
-    return gramian(S_shard)
+class _HostSteps:
+    """numpy stand-ins for the four device steps -- the CPU (gloo) tests inject these to run the sharding and exchange
+    logic of `pod_from_column_shards` without a GPU (no product path uses it)."""
+
+    def __init__(self, gramian, eigh, modes):
+        self._gramian, self._eigh, self._modes = gramian, eigh, modes
+
+    def upload(self, S):
+        return np.ascontiguousarray(S, dtype=np.float64)
+
+    def gramian(self, S):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(self._gramian(S)))          # reduced in place by torch.distributed
+
+    def eigenvalues_descending(self, G):
+        w, W = self._eigh(G.numpy())
+        self._W = W[:, ::-1]
+        return np.maximum(w[::-1], 0.0)
+
+    def modes(self, S, G, k, sigma):
+        return self._modes(S, np.ascontiguousarray(self._W[:, :k] / sigma[:k]))
+
+    def sync(self):
+        pass
+
+
+class _DeviceSteps:
+    """The same four steps on the GPU with everything resident in HBM: the snapshot shard is uploaded once, the
+    eigen-decomposition overwrites the Gramian, and only the n_s eigenvalues (for the energy truncation) and the local
+    mode rows come back to the host.  With a process group the buffers are torch CUDA tensors, so that RCCL reduces the
+    Gramian in place; a single rank uses the library's own allocations and needs no torch at all.  (Torch brings its own
+    HIP runtime: a process that uses both must initialise torch.cuda BEFORE the first call into libsofacontrol_hip --
+    bench.py and tests/conftest.py do.)"""
+
+    def __init__(self, use_torch):
+        from . import _lib
+        self._lib, self.L, self.use_torch = _lib, _lib.lib(), use_torch
+        if use_torch:
+            import torch
+            self.torch = torch
+
+    def _alloc(self, shape):
+        if self.use_torch:
+            return self.torch.empty(shape, dtype=self.torch.float64, device='cuda')
+        return self._lib.DeviceBuffer(int(np.prod(shape)) * 8)
+
+    def _ptr(self, a):
+        import ctypes as C
+        return C.c_void_p(a.data_ptr()) if self.use_torch else a.ptr
+
+    def upload(self, S):
+        self.shape = tuple(S.shape)
+        if self.use_torch:
+            if self.torch.is_tensor(S):
+                assert S.is_cuda and S.dtype == self.torch.float64 and S.is_contiguous()
+                return S
+            return self.torch.from_numpy(np.ascontiguousarray(S, dtype=np.float64)).cuda()
+        if not isinstance(S, np.ndarray):           # a resident torch tensor on a single rank: use its memory as it is
+            self.use_torch, self.torch = True, __import__('torch')
+            return self.upload(S)
+        return self._lib.DeviceBuffer.from_array(np.ascontiguousarray(S, dtype=np.float64))
+
+    def gramian(self, S):
+        import ctypes as C
+        n_s, n_f = self.shape
+        G = self._alloc((n_s, n_s))
+        self.sync()
+        self._lib.check(self.L.srom_gramian_dev(self._ptr(S), C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), self._ptr(G), None),
+                        'srom_gramian_dev')
+        self._lib.sync()
+        return G
+
+    def eigenvalues_descending(self, G):
+        import ctypes as C
+        n_s = self.shape[0]
+        self._w = self._alloc((n_s,))
+        self.sync()
+        self._lib.check(self.L.srom_eigh_dev(self._ptr(G), C.c_int64(n_s), self._ptr(self._w), None), 'srom_eigh_dev')
+        self._lib.sync()                                                 # rows of G are now the eigenvectors (ascending)
+        w = self._w.cpu().numpy() if self.use_torch else self._w.to_array((n_s,))
+        return np.maximum(w[::-1], 0.0)
+
+    def modes(self, S, G, k, sigma):
+        import ctypes as C
+        n_s, n_f = self.shape
+        Wk, U = self._alloc((n_s, k)), self._alloc((n_f, k))
+        self.sync()
+        self._lib.check(self.L.srom_select_modes_dev(self._ptr(G), self._ptr(self._w), C.c_int64(n_s), C.c_int(k), self._ptr(Wk), None),
+                        'srom_select_modes_dev')
+        self._lib.check(self.L.srom_modes_dev(self._ptr(S), C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), self._ptr(Wk), C.c_int(k),
+                                              self._ptr(U), None), 'srom_modes_dev')
+        self._lib.sync()
+        self._k = k
+        return U
+
+    def to_host(self, U):
+        return U.cpu().numpy() if self.use_torch else U.to_array((self.shape[1], self._k))
+
+    def sync(self):
+        if self.use_torch:
+            self.torch.cuda.synchronize()
+        else:
+            self._lib.sync()
+
+
+def reduce_gramian(G, group=None, collective='auto'):
+    """The one exchange step of the path: sum the partial Gramians over the ranks, in place on the tensor G (HBM with
+    the nccl = RCCL backend, host memory with gloo).  'rs_ag' = reduce-scatter of row blocks + all-gather (keeps all
+    xGMI links of a node busy; needs n_s divisible by the world size and a backend that has reduce_scatter), 'all_reduce'
+    = the plain collective; 'auto' picks rs_ag when it applies."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 'none'
+    world = dist.get_world_size(group)
+    can_rs = dist.get_backend(group) == 'nccl' and G.shape[0] % world == 0
+    if collective == 'rs_ag' and not can_rs:
+        raise RuntimeError('rs_ag needs the nccl backend and n_s divisible by the world size')
+    if collective == 'rs_ag' or (collective == 'auto' and can_rs):
+        rows = G.shape[0] // world
+        mine = G.new_empty((rows, G.shape[1]))
+        dist.reduce_scatter_tensor(mine, G, op=dist.ReduceOp.SUM, group=group)
+        dist.all_gather_into_tensor(G, mine, group=group)
+        return 'rs_ag'
+    dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+    return 'all_reduce'
 
 
 def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian=None, local_modes=None,
-                           local_eigh=None):
-    """Distributed method-of-snapshots POD.
+                           local_eigh=None, collective='auto', timings=None, keep_on_device=False, force_torch=False):
+    """Distributed method-of-snapshots POD (sofacontrol/mor/pod.py:181-200 for a snapshot matrix sharded by DoF columns).
 
-    S_shard: this rank's (n_s x n_f_local) block of snapshot columns (numpy).  Returns
-    (U_local (n_f_local x k), k, Sigma).  `local_gramian` / `local_eigh` / `local_modes` default to the device; the
-    CPU (gloo) tests inject numpy stand-ins to exercise the sharding / reduction logic without a GPU."""
-    import torch
-    import torch.distributed as dist
+    S_shard: this rank's (n_s x n_f_local) block of snapshot columns -- a numpy array (uploaded once) or a CUDA float64
+    torch tensor (used in place).  Steps: local Gramian (f64 MFMA kernel) -> `reduce_gramian` (the only collective) ->
+    replicated eigen-decomposition on the device -> this rank's rows of U = S^T W Sigma^-1.  The Gramian never visits the
+    host.  Returns (U_local (n_f_local x k), k, Sigma); U_local is a numpy array unless keep_on_device.
+    `local_gramian` / `local_eigh` / `local_modes`: numpy stand-ins for the device steps (CPU tests of the exchange
+    logic).  `timings`: optional dict that receives the seconds of each phase.  keep_on_device: return the device
+    array (a torch tensor with a process group or force_torch, else a _lib.DeviceBuffer)."""
+    import time
     from .mor import pod as _pod
-    lg = local_gramian or _hip_local_gramian
-    G = np.ascontiguousarray(lg(np.ascontiguousarray(S_shard, dtype=np.float64)))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        use_cuda = dist.get_backend(group) == 'nccl'
-        t = torch.from_numpy(G)
-        if use_cuda:
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)      # the one exchange step of the path
-        G = t.cpu().numpy()
-    Wk, k, Sigma = _pod.modes_from_gramian(None, G, tol, rom_dim, eigh=local_eigh)
-    if local_modes is not None:
-        U_local = local_modes(S_shard, Wk)
+    host = local_gramian is not None or local_modes is not None or local_eigh is not None
+    if host:
+        steps = _HostSteps(local_gramian or (lambda A: A @ A.T), local_eigh or np.linalg.eigh, local_modes or (lambda A, W: A.T @ W))
     else:
-        import ctypes as C
-        from . import _lib
-        n_s, n_fl = S_shard.shape
-        dS, dW = _lib.DeviceBuffer.from_array(np.ascontiguousarray(S_shard)), _lib.DeviceBuffer.from_array(Wk)
-        dU = _lib.DeviceBuffer(n_fl * k * 8)
-        _lib.check(_lib.lib().srom_modes_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_fl), C.c_int64(n_fl), dW.ptr, C.c_int(k),
-                                             dU.ptr, None), 'srom_modes_dev')
-        _lib.sync()
-        U_local = dU.to_array((n_fl, k))
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        steps = _DeviceSteps(use_torch=multi or force_torch)
+
+    def lap(name, t0):
+        steps.sync()
+        if timings is not None:
+            timings[name] = time.perf_counter() - t0
+        return time.perf_counter()
+    t0 = time.perf_counter()
+    S = steps.upload(S_shard)
+    t0 = lap('upload_s', t0)
+    G = steps.gramian(S)
+    t0 = lap('gramian_s', t0)
+    how = reduce_gramian(G, group, collective)
+    t0 = lap('collective_s', t0)
+    if timings is not None:
+        timings['collective'] = how
+    w = steps.eigenvalues_descending(G)
+    t0 = lap('eigh_s', t0)
+    Sigma = np.sqrt(w)
+    k = _pod.energy_truncation(Sigma, tol) if rom_dim is None else int(rom_dim)
+    U_local = steps.modes(S, G, k, Sigma)
+    lap('modes_s', t0)
+    if not host and not keep_on_device:
+        U_local = steps.to_host(U_local)
     return U_local, k, Sigma

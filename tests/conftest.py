@@ -14,6 +14,15 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # torch ships its own HIP runtime; where a test uses torch CUDA tensors next to libsofacontrol_hip (the sharded POD
+    # build), torch has to come up first -- once the library's runtime owns the device, torch finds "no HIP GPUs"
+    if 'gpu' in (config.getoption('-m') or '') and 'not gpu' not in (config.getoption('-m') or ''):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope='session')

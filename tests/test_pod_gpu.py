@@ -256,3 +256,49 @@ def test_file_round_trips(tmp_path):
     A, B, d = tp.get_jacobians(np.concatenate((saved['v'][1], saved['q'][1])))
     np.testing.assert_array_equal(A, saved['A_c'][1])
     assert saved['info']['nbr_lin'] == '2' and saved['rom_info']['type'] == 'POD'
+
+
+def test_sharded_pod_build_device_resident_single_rank():
+    """distributed.pod_from_column_shards on the device (world = 1: no collective): Gramian in a torch-owned HBM tensor ->
+    eigh in place -> mode selection -> local rows of U; against the reference SVD route (oracle.pod.compute_pod)."""
+    import torch
+    from oracle import pod as opod
+    from sofacontrol_amd.distributed import pod_from_column_shards
+    rng = np.random.default_rng(4)
+    n_s, n_f = 60, 501
+    Lm = rng.standard_normal((n_s, 6)) * np.array([50, 20, 8, 3, 1, 0.3])
+    S = Lm @ rng.standard_normal((6, n_f)) + 1e-3 * rng.standard_normal((n_s, n_f))
+    tm = {}
+    U, k, Sig = pod_from_column_shards(S, 1e-4, timings=tm)
+    _, U_ref, k_ref, S_ref = opod.compute_pod(S.T, 1e-4)
+    assert k == k_ref and tm['collective'] == 'none' and set(tm) >= {'gramian_s', 'eigh_s', 'modes_s'}
+    np.testing.assert_allclose(Sig[:6], S_ref[:6], rtol=1e-9)
+    np.testing.assert_allclose(np.abs(U), np.abs(U_ref), rtol=0, atol=1e-8)
+    # the same with torch-owned buffers (what a process group uses so that RCCL reduces the Gramian in place), from a shard
+    # that is already resident, result kept on the device
+    Ud, k2, _ = pod_from_column_shards(torch.from_numpy(S).cuda(), 1e-4, keep_on_device=True, force_torch=True)
+    assert Ud.is_cuda and k2 == k
+    np.testing.assert_allclose(np.abs(Ud.cpu().numpy()), np.abs(U_ref), rtol=0, atol=1e-8)
+
+
+def test_gramian_full_size_c4_shard_properties():
+    """BASELINE config C4 at its per-GPU size (10 000 snapshots x 6250 DoF columns): size-independent properties of
+    G = S S^T -- symmetry, trace(G) = |S|_F^2, G v = S (S^T v) for random v."""
+    import ctypes as C
+    import torch
+    from sofacontrol_amd import _lib
+    n_s, n_f = 10000, 6250
+    gen = torch.Generator(device='cuda'); gen.manual_seed(11)
+    S = torch.randn((n_s, n_f), dtype=torch.float64, device='cuda', generator=gen)
+    G = torch.empty((n_s, n_s), dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().srom_gramian_dev(C.c_void_p(S.data_ptr()), C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f),
+                                           C.c_void_p(G.data_ptr()), None), 'srom_gramian_dev')
+    _lib.sync()
+    assert torch.equal(G, G.T)                                            # mirrored, not recomputed: exactly symmetric
+    fro2 = float((S * S).sum())
+    assert abs(float(torch.diagonal(G).sum()) - fro2) <= 1e-11 * fro2
+    v = torch.randn((n_s, 3), dtype=torch.float64, device='cuda', generator=gen)
+    ref = S @ (S.T @ v)
+    got = G @ v
+    assert float((got - ref).abs().max()) <= 1e-10 * float(ref.abs().max())
