@@ -243,7 +243,12 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     ssm::Work sw;
     lptr zs = part + NT, xl = zs + 16;        // observed output, a state vector (both models)
     lptr Al = xl + n, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m;      // MODEL 1 only (not allocated for MODEL 0)
-    if constexpr (MODEL == 1) ssm::carve(sw, dl + n, S);
+    SsmLds ST;
+    if constexpr (MODEL == 1) {
+        ssm::carve(sw, dl + n, S);
+        // coefficient rows and exponent tables of the polynomial model into LDS, once per kernel
+        ssm::stage(ST, dl + n + ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns), S, a.ssm_mode == SSM_DISCRETE_MAP);
+    }
     // MFMA backward pass: padded panels P / G, [A|B], W = P [A|B] (NPa x ld each) and B^T [A|B] (16 x ld)
     const int NPa = (n + m + 15) & ~15, ldp = NPa + 1, NK4 = (n + 3) & ~3, n16 = (n + 15) & ~15;
     lptr Pm = (lptr)smem + a.panel_off, ABm = Pm + (size_t)NPa * ldp, Wm = ABm + (size_t)NPa * ldp, RBm = Wm + (size_t)NPa * ldp;
@@ -275,19 +280,29 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
             }
             __syncthreads();
         } else {
-            ssm::observe(S, xq, sw, zs, (lptr) nullptr, (lptr) nullptr);
+            ssm::observe_l(S, ST, xq, sw, zs);
             if (tid < nz) zt[tid] = zs[tid] + zref[tid] - ztar[(size_t)t * nz + tid];
             __syncthreads();
         }
     };
 
     // forward pass (ilqr.py:117-162): from (xp, up) with gains (Kg, kg, alpha) into (xo, uo, io); returns cost
+#ifdef SRH_PROFILE
+    long long fp[6] = {0, 0, 0, 0, 0, 0};
+    long long fpl = 0;
+#define FP_T0() fpl = clock64()
+#define FP_LAP(i) do { const long long now_ = clock64(); fp[i] += now_ - fpl; fpl = now_; } while (0)
+#else
+#define FP_T0() ((void)0)
+#define FP_LAP(i) ((void)0)
+#endif
     auto forward = [&](cgptr xp, cgptr up, double alpha, cgptr Kg, cgptr kg, gptr xo, gptr uo, giptr io,
                        gptr lo) -> double {
         double cost = 0.0;
         for (int e = tid; e < n; e += nt) { L.v1[e] = x0[e]; xo[e] = x0[e]; }
         __syncthreads();
         for (int t = 0; t < N; ++t) {
+            FP_T0();
             // u_t = u_prev + alpha k + K (x - x_prev)
             if (tid < m) {
                 double v = up[(size_t)t * m + tid];
@@ -311,8 +326,13 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 __syncthreads();
             } else {
                 __syncthreads();
+                FP_LAP(0);
                 zerr((clptr)L.v1, t);
-                ssm::linearize(S, a.ssm_mode, a.dt, (clptr)L.v1, (clptr)L.u1, sw, Al, n, Bl, dl);
+                FP_LAP(1);
+                ssm::jacobians_l(S, ST, a.ssm_mode == SSM_DISCRETE_MAP, (clptr)L.v1, (clptr)L.u1, sw, Al, n, Bl, dl);
+                FP_LAP(2);
+                ssm::discretize(S, a.ssm_mode, a.dt, sw, Al, n, Bl, dl);
+                FP_LAP(3);
             }
             if (tid < 64) {          // step cost (ilqr.py:168-176): the terms of both quadratic forms over the lanes of wave 0
                 auto dui = [&](int r) {
@@ -349,6 +369,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
             }
             for (int e = tid; e < n; e += nt) { L.v1[e] = L.v2[e]; xo[(size_t)(t + 1) * n + e] = L.v2[e]; }
             __syncthreads();
+            FP_LAP(4);
         }
         zerr((clptr)L.v1, N);
         if (tid < 64) {
@@ -720,17 +741,33 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     for (int e = tid; e < (N + 1) * n; e += nt) X2[e] = (e < n) ? x0[e] : 0.0;
     for (int e = tid; e < N * m; e += nt) U2[e] = a.u_warm ? a.u_warm[p * (size_t)N * m + e] : 0.0;
     __syncthreads();
+#ifdef SRH_PROFILE
+    long long tf = 0, tb = 0, tc0 = clock64();
+    int nf = 0;
+#define IL_T0() tc0 = clock64()
+#define IL_ACC(v) v += clock64() - tc0
+#else
+#define IL_T0() ((void)0)
+#define IL_ACC(v) ((void)0)
+#endif
     double cost = forward((cgptr)X2, (cgptr)U2, 1.0, (cgptr)nullptr, (cgptr)nullptr, X, U, idx, lin);
     int failed_counter = 0, it = 0;
     bool converged = false;
     while (!converged && it <= P_.max_iter) {
+        IL_T0();
         if (a.mfma) backward_m(); else backward();
+        IL_ACC(tb);
         const double prev_cost = cost;
         double alpha = P_.alpha0, new_cost = cost;
         bool improved = false, failed = false;
         while (!improved && !failed) {
             improved = true;
+            IL_T0();
             new_cost = forward((cgptr)X, (cgptr)U, alpha, (cgptr)Kout, (cgptr)kff, X2, U2, idx2, lin2);
+            IL_ACC(tf);
+#ifdef SRH_PROFILE
+            ++nf;
+#endif
             double dc = 0.0;
             for (int t = tid; t < N; t += nt) {
                 double s1 = 0.0, s2 = 0.0;
@@ -774,6 +811,12 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
         ++it;
     }
     if (tid == 0) { a.cost[p] = cost; a.iters[p] = it; }
+#ifdef SRH_PROFILE
+    if (tid == 0 && p == 0) printf("[ilqr] forward laps per step: control %.0f zerr %.0f jacobians %.0f discretize %.0f cost+store+update %.0f\n",
+                                   (double)fp[0] / (nf + 1) / N, (double)fp[1] / (nf + 1) / N, (double)fp[2] / (nf + 1) / N, (double)fp[3] / (nf + 1) / N, (double)fp[4] / (nf + 1) / N);
+    if (tid == 0 && p == 0) printf("[ilqr] problem 0: %d iterations, %d forward passes %lld clocks (%.0f per step), backward %lld clocks (%.0f per stage); mfma %d\n",
+                                   it, nf, tf, (double)tf / (nf > 0 ? nf : 1) / N, tb, (double)tb / (it > 0 ? it : 1) / N, a.mfma);
+#endif
 }
 
 }  // namespace
@@ -881,7 +924,7 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
                ou.as<double>(), oK.as<double>(), oc.as<double>(), oi.as<int>(), work.as<double>(), iwork.as<int>(), stride,
                hs ? lin.as<double>() : nullptr, ssm_mode, 0, 0, 0, dt};
     const size_t tail = 20 + (size_t)16 * n + 16 + NT + 16 + n +
-                        (hs ? lstride + ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns) : 0);
+                        (hs ? lstride + ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns) + ssm::lds_tab_doubles(hs->n, hs->no, hs->nr, hs->ns) : 0);
     // preferred: backward pass on f64 MFMA products over three padded (NPa x ld) panels + one 16-row panel
     const size_t NPa = (size_t)((n + m + 15) & ~15), ldp = NPa + 1;
     const size_t mf_off = lqr_lds_doubles(n, m, 256) + tail;

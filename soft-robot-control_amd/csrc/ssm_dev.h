@@ -137,6 +137,8 @@ __device__ inline void carve(Work &w, lptr base, const SsmDev &S) {
     w.piv = (liptr)(w.f + S.n + 2);
 }
 
+__device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w, lptr A, int lda, lptr Bm, lptr d);
+
 // (A, B, d) of ssm.py:198-218 at (x, u) [LDS]: continuous Jacobians of f = R phi(x) + B u, affine remainder
 // d = f - A x - B u, then discretised per `mode`.  A (n x lda), Bm (n x m), d (n) in LDS.  Ends with a sync.
 __device__ inline void linearize(const SsmDev &S, int mode, double dt, clptr x, clptr u, Work &w, lptr A, int lda,
@@ -163,7 +165,13 @@ __device__ inline void linearize(const SsmDev &S, int mode, double dt, clptr x, 
         d[i] = w.f[i] - ax - bu;
     }
     __syncthreads();
-    if (mode == SSM_CONT || dm) return;
+    discretize(S, mode, dt, w, A, lda, Bm, d);
+}
+
+// (A, B, d) continuous -> discrete per `mode` (ssm.py:279-301), in place.  Ends with a sync.
+__device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w, lptr A, int lda, lptr Bm, lptr d) {
+    const int n = S.n, m = S.m, tid = threadIdx.x, nt = blockDim.x;
+    if (mode == SSM_CONT || mode == SSM_DISCRETE_MAP) return;
     if (mode == SSM_FE) {                                       // I + dt A, dt B, dt d
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e % n;
@@ -244,6 +252,143 @@ __device__ inline void observe(const SsmDev &S, clptr x, Work &w, lptr z, lptr H
         }
         __syncthreads();
     }
+}
+
+}  // namespace ssm
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-resident form for kernels that evaluate the model at every step of a loop (iLQR forward pass on an SSM model:
+// N steps per pass).  Measured on the C3 shape (n = 10, 285 monomials): with the coefficient rows and exponent tables
+// read from L2 inside 100 latency-bound dot products the linearisation took ~80 k clocks per step; staged once per
+// kernel in LDS and spread over all threads it is a few thousand.
+struct SsmLds {
+    lptr R;                    // (n x nr) coefficients of the map in use (r_coeff, or rd_coeff for the discrete map)
+    lptr W;                    // (no x ns) w_coeff
+    lptr Bg;                   // (n x m) input matrix of the map in use
+    liptr er, dmr, pr, vr;     // rom basis tables: exponents (nr x n), derivative monomial (nr x n), parent, variable (nr)
+    liptr es, dms, ps, vs;     // ssm basis tables
+    int lvr[8], lvs[8];        // first monomial of every degree (order <= 6)
+};
+
+namespace ssm {
+
+__host__ __device__ inline size_t lds_tab_doubles(int n, int no, int nr, int ns) {
+    const size_t ints = 2 * (size_t)nr * n + 2 * (size_t)nr + 2 * (size_t)ns * no + 2 * (size_t)ns;
+    return (size_t)n * nr + (size_t)no * ns + (size_t)n * 16 + (ints + 1) / 2 + 8;       // m <= 16
+}
+
+// copy the tables (all threads; ends with a sync)
+__device__ inline void stage(SsmLds &T, lptr base, const SsmDev &S, bool discrete_map) {
+    const int n = S.n, no = S.no, nr = S.nr, ns = S.ns, tid = threadIdx.x, nt = blockDim.x;
+    T.R = base; T.W = T.R + (size_t)n * nr; T.Bg = T.W + (size_t)no * ns;
+    liptr ip = (liptr)(T.Bg + (size_t)n * 16);
+    T.er = ip; T.dmr = T.er + nr * n; T.pr = T.dmr + nr * n; T.vr = T.pr + nr;
+    T.es = T.vr + nr; T.dms = T.es + ns * no; T.ps = T.dms + ns * no; T.vs = T.ps + ns;
+    cgptr Rc = discrete_map ? S.Rd : S.R;
+    for (int e = tid; e < n * nr; e += nt) T.R[e] = Rc[e];
+    for (int e = tid; e < no * ns; e += nt) T.W[e] = S.Wc[e];
+    for (int e = tid; e < n * S.m; e += nt) T.Bg[e] = (discrete_map ? S.Bd : S.Bc)[e];
+    for (int e = tid; e < nr * n; e += nt) { T.er[e] = S.er[e]; T.dmr[e] = S.dmr[e]; }
+    for (int e = tid; e < nr; e += nt) { T.pr[e] = S.pr[e]; T.vr[e] = S.vr[e]; }
+    for (int e = tid; e < ns * no; e += nt) { T.es[e] = S.es[e]; T.dms[e] = S.dms[e]; }
+    for (int e = tid; e < ns; e += nt) { T.ps[e] = S.ps[e]; T.vs[e] = S.vs[e]; }
+    for (int q = 0; q < 8; ++q) { T.lvr[q] = q <= S.order_r ? S.lvr[q] : 0; T.lvs[q] = q <= S.order_s ? S.lvs[q] : 0; }
+    __syncthreads();
+}
+
+// monomials (and derivative table D) from LDS tables; as `basis`
+__device__ inline void basis_l(const liptr ex, const liptr par, const liptr var, const liptr dm, const int *lv, int order, int nmon,
+                               int dim, clptr x, lptr phi, lptr D) {
+    for (int d = 0; d < order; ++d) {
+        const int j0 = lv[d], j1 = lv[d + 1];
+        for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+            const int pj = par[j];
+            phi[j] = (pj < 0 ? 1.0 : phi[pj]) * x[var[j]];
+        }
+        __syncthreads();
+    }
+    if (D != nullptr) {
+        const int tot = nmon * dim, nt = blockDim.x;
+        for (int e0 = threadIdx.x; e0 < tot; e0 += 4 * nt) {          // four entries per trip: their table look-ups overlap
+            int q[4], ee[4];
+            double pv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int e = e0 + c * nt; const bool in = e < tot; q[c] = in ? dm[e] : -1; ee[c] = in ? ex[e] : 0; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pv[c] = q[c] >= 0 ? phi[q[c]] : 1.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int e = e0 + c * nt; if (e < tot) D[e] = q[c] == -1 ? 0.0 : (double)ee[c] * pv[c]; }
+        }
+        __syncthreads();
+    }
+}
+
+// continuous Jacobians + affine remainder from the LDS tables (the front part of `linearize`); ends with a sync
+__device__ inline void jacobians_l(const SsmDev &S, const SsmLds &T, bool dm, clptr x, clptr u, Work &w, lptr A, int lda, lptr Bm,
+                                   lptr d) {
+    const int n = S.n, m = S.m, nr = S.nr, tid = threadIdx.x, nt = blockDim.x;
+    clptr Bg = T.Bg;
+    basis_l(T.er, T.pr, T.vr, T.dmr, T.lvr, S.order_r, nr, n, x, w.phi, w.D);
+    // A[i][j] = sum_k R[i][k] D[k][j] and f[i] = sum_k R[i][k] phi[k]: n (n + 1) dot products of length nr, four lanes
+    // each (the k range split four ways, DPP sum)
+    const int g4 = tid & 3;
+    for (int o0 = 0; o0 < n * (n + 1); o0 += nt / 4) {           // uniform trip count
+        const int o = o0 + (tid >> 2);
+        const bool live = o < n * (n + 1);
+        const int i = live ? o / (n + 1) : 0, j = live ? o - i * (n + 1) : 0;
+        double acc = 0.0;
+        if (live) {
+            // eight operand pairs in flight per trip (a rolled load -> fma chain pays the LDS latency of every element)
+            clptr r = T.R + (size_t)i * nr;
+            clptr b = j < n ? w.D + j : w.phi;
+            const int bs = j < n ? n : 1;
+            for (int k0 = g4; k0 < nr; k0 += 32) {
+                double av[8], bv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int k = k0 + 4 * q; const bool in = k < nr; av[q] = in ? r[k] : 0.0; bv[q] = in ? b[(size_t)k * bs] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
+            }
+        }
+        acc = wg::group_sum<4>(acc);
+        if (g4 == 0 && live) { if (j < n) A[i * lda + j] = acc; else w.f[i] = acc; }
+    }
+    for (int e = tid; e < n * m; e += nt) Bm[e] = Bg[e];
+    __syncthreads();
+    {   // f = R phi + B u ;  d = f - A x - B u : eight lanes per row
+        const int g8 = tid & 7;
+        for (int i0 = 0; i0 < n; i0 += nt / 8) {
+            const int i = i0 + (tid >> 3);
+            double ax = 0.0, bu = 0.0;
+            if (i < n) {
+                for (int k = g8; k < n; k += 8) ax = fma(A[i * lda + k], x[k], ax);
+                for (int k = g8; k < m; k += 8) bu = fma(Bg[i * m + k], u[k], bu);
+            }
+            ax = wg::group_sum<8>(ax);
+            bu = wg::group_sum<8>(bu);
+            if (g8 == 0 && i < n) {
+                const double f = w.f[i] + bu;
+                d[i] = f - ax - bu;
+                w.f[i] = f;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// z = W phi_s(x) from the LDS tables (no Jacobian); ends with a sync
+__device__ inline void observe_l(const SsmDev &S, const SsmLds &T, clptr x, Work &w, lptr z) {
+    const int no = S.no, ns = S.ns, tid = threadIdx.x, nt = blockDim.x;
+    basis_l(T.es, T.ps, T.vs, T.dms, T.lvs, S.order_s, ns, no, x, w.phi, (lptr) nullptr);
+    const int g8 = tid & 7;
+    for (int o0 = 0; o0 < no; o0 += nt / 8) {
+        const int o = o0 + (tid >> 3);
+        double acc = 0.0;
+        if (o < no) for (int k = g8; k < ns; k += 8) acc = fma(T.W[(size_t)o * ns + k], w.phi[k], acc);
+        acc = wg::group_sum<8>(acc);
+        if (g8 == 0 && o < no) z[o] = acc;
+    }
+    __syncthreads();
 }
 
 }  // namespace ssm
