@@ -176,8 +176,23 @@ def closed_loop_latency(w, rom, tp):
     u = np.full(w['m'], 100.0)
     y = tp.y_ref + 0.01 * rng.standard_normal(30)
     ekf_med, ekf_p99 = median_us(lambda: ekf.update(u, y, w['dt']), 200, 10)
+    fused_med, fused_p99 = median_us(lambda: ekf.update_projected(rom, x, u, y, w['dt']), 300, 20)
+    # the same call straight through the C ABI (what a compiled host pays: no numpy/ctypes marshalling)
+    import ctypes as C
+    from sofacontrol_amd import _lib as _lm
+    lib = _lm.lib()
+    xr, xh = np.empty(2 * r), np.empty(2 * r)
+    px, pu, py, pxr, pxh = [a.ctypes.data_as(C.c_void_p) for a in (x, u, y, xr, xh)]
+    fn = lib.sekf_step_projected
+    fn.argtypes = [C.c_void_p] * 7
+    hk, hr = ekf._h, rom.handle
+    abi_med, abi_p99 = median_us(lambda: fn(hk, hr, px, pu, py, pxr, pxh), 300, 20)
+    fn.argtypes = None
     return {'project_one_state_us': proj_med, 'project_one_state_p99_us': proj_p99, 'ekf_step_us': ekf_med,
-            'ekf_step_p99_us': ekf_p99, 'statistic': 'median (and 99th percentile) of per-call wall times',
+            'ekf_step_p99_us': ekf_p99, 'fused_step_us': fused_med, 'fused_step_p99_us': fused_p99,
+            'fused_step_c_abi_us': abi_med, 'fused_step_c_abi_p99_us': abi_p99,
+            'fused_step': 'sekf_step_projected: projection (side stream) + EKF predict/update in one call',
+            'statistic': 'median (and 99th percentile) of per-call wall times',
 
             'workload': 'one full state (2 x %d) -> 2r = %d; EKF n_x = %d, n_y = 30; host-pointer API' % (n_f, 2 * r, 2 * r)}
 

@@ -167,6 +167,13 @@ int sekf_get_state(sekf_t *h, double *x, double *Sigma);
  * Returns SRH_ENUMERIC when the innovation covariance is not positive definite. */
 int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, const double *B_d,
               const double *d_d, double *x_out);
+/* One call for the per-simulation-step path of a closed-loop controller (closed_loop_controller.py:205-233,
+ * tpwl/controllers.py:128-157: compute_RO_state(xf=x) followed by observer.update(u_prev, y, dt)): the full-order
+ * state x_full = [v_f; q_f] (2 n_f) is projected to x_reduced_out (2 r) on a side stream while the filter step
+ * (sekf_step with the model's own discrete tables) runs on stream 0; both go through their pinned mirrors and the
+ * host waits once for each.  x_hat_out (n_x) optional.  Errors as sekf_step / srom_project. */
+int sekf_step_projected(sekf_t *h, srom_t *rom, const double *x_full, const double *u, const double *y,
+                        double *x_reduced_out, double *x_hat_out);
 
 /* =====================================================================================================
  * SSM polynomial reduced model.                                  reference: sofacontrol/SSM/ssm.py

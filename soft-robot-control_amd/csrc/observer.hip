@@ -3,6 +3,10 @@
 // update_state 108-126.  One workgroup per filter step; every matrix of the step lives in LDS.
 #include "tpwl_host.h"
 
+// pod.hip: two-phase staged projection (enqueue on a stream; read the pinned mirror once that stream has drained)
+int srom_stage_project(srom *h, int which, const double *X, int64_t B, hipStream_t stream);
+int srom_stage_collect(srom *h, double *out, int64_t B, int which);
+
 struct sekf {
     stpwl *model = nullptr;
     int n = 0, m = 0, ny = 0;
@@ -11,7 +15,9 @@ struct sekf {
     bool mfma = false;
     // pinned host mirrors of the per-step input (u, y) and output (x, status): one copy each way per step
     double *pin_in = nullptr, *pin_out = nullptr;
+    hipStream_t side = nullptr;          // sekf_step_projected: the projection runs beside the filter kernel
     ~sekf() {
+        if (side) (void)hipStreamDestroy(side);
         if (pin_in) (void)hipHostFree(pin_in);
         if (pin_out) (void)hipHostFree(pin_out);
     }
@@ -215,6 +221,106 @@ __host__ __device__ inline size_t ekf_mfma_doubles(int n, int ny) {
     return 3 * (size_t)d.n16 * d.ld + (size_t)d.ny16 * d.ld + 3 * (size_t)d.ny16 * d.ldy + 4 * nv + 8;
 }
 
+__device__ __forceinline__ double ekf_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1 / p to working precision without the ~30-instruction IEEE division sequence (it sits on the critical path of
+// every elimination step): v_rcp_f64 and two Newton steps.  p is a pivot of a positive definite matrix: normal range.
+__device__ __forceinline__ double ekf_rcp(double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    r = fma(fma(-p, r, 1.0), r, r);
+    r = fma(fma(-p, r, 1.0), r, r);
+    return r;
+}
+
+// K^T = S^-1 CS by Gauss-Jordan elimination of the tableau [S | CS] -> [I | S^-1 CS] on the whole workgroup.
+// Wave w owns rows w, w + nw, ... (RW of them), lane = column (NC chunks of 64), every entry in a register with a
+// compile-time index; the row index of an entry is wave-uniform, so "is this the pivot row" is a scalar branch and
+// the multiplier one broadcast read.  Per pivot step the pivot row and the pivot column travel through LDS (double
+// buffered: one barrier per step); their owners publish the row / column of the NEXT step right after updating them.
+// No pivoting: S is symmetric positive definite, its elimination pivots are the squared diagonal of the Cholesky
+// factor, so "pivot <= 0" reports exactly what a failed factorisation would.
+// Measured alternatives at n_y = 30, n = 60 (tools/probes/ekf_prof.py): one wave, Cholesky + triangular inverse with
+// LDS operands 80 k clocks (+ 12 k for the two triangular products); one wave, factor in registers with v_readlane
+// operands 45 k; the same with broadcast LDS reads 42 k; this elimination with one thread per entry 60 k (the index
+// arithmetic and the IEEE division dominate).
+// buf: 2 x (n_y + n + RW nw) doubles inside a cleared panel of 128 doubles more; *bad cleared by the caller.
+// Returns false when S is not positive definite (uniform over the workgroup).
+template <int RW, int NC>
+__device__ __forceinline__ bool ekf_gain_gj(clptr Sm, int ldy, int ny, clptr CS, int ld, int n, lptr KT, lptr buf, liptr bad) {
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = ny + n, stride = W + RW * nw;
+    double av[RW][NC];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int i = wave + r * nw;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            const int c = lane + 64 * ch;
+            av[r][ch] = (i < ny && c < W) ? (c < ny ? Sm[i * ldy + c] : CS[i * ld + c - ny]) : 0.0;
+        }
+    }
+    // The owner of row jn divides it by its pivot BEFORE publishing it (so only one wave pays the reciprocal and the
+    // others eliminate with a -= a[i][jn] * row'); every wave publishes its entries of column jn, with a zero in
+    // place of the pivot row's own entry (that row is final: its multiplier is zero).  Rows >= n_y of a wave write
+    // into the padding behind the column (stride counts RW * nw rows) -- zeros, since their entries stay zero.
+    auto publish = [&](int jn, lptr nr, lptr nc) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            if (wave + r * nw == jn) {                                       // wave-uniform
+                const double piv = ekf_readlane(av[r][0], jn);               // column jn < n_y <= 64: chunk 0
+                if (!(piv > 0.0) && lane == 0) *bad = 1;
+                const double rp = ekf_rcp(piv);
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) {
+                    av[r][ch] *= rp;
+                    if (lane + 64 * ch < W) nr[lane + 64 * ch] = av[r][ch];
+                }
+            }
+        }
+        if (lane == jn) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) nc[wave + r * nw] = (wave + r * nw == jn) ? 0.0 : av[r][0];
+        }
+    };
+    publish(0, buf, buf + W);
+    __syncthreads();
+    for (int j = 0; j < ny; ++j) {
+        clptr pr = buf + (j & 1) * stride, pc = pr + W;
+        lptr nr = buf + ((j + 1) & 1) * stride;
+        double prc[NC], mv[RW];
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) prc[ch] = pr[lane + 64 * ch];        // entries past W: never stored
+#pragma unroll
+        for (int r = 0; r < RW; ++r) mv[r] = pc[wave + r * nw];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) av[r][ch] = fma(-mv[r], prc[ch], av[r][ch]);
+        if (j + 1 < ny) publish(j + 1, nr, nr + W);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int i = wave + r * nw;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            const int c = lane + 64 * ch;
+            if (i < ny && c >= ny && c < W) KT[i * ld + c - ny] = av[r][ch];
+        }
+    }
+    return *bad == 0;
+}
+
+#ifdef SRH_PROFILE
+#define EKF_LAP(i) do { __syncthreads(); const long long now_ = clock64(); ekp[i] += now_ - ekl; ekl = now_; } while (0)
+#else
+#define EKF_LAP(i) ((void)0)
+#endif
+
 template <int NSEL>      // n_x fixed at compile time (the Diamond models at r = 30 / 36), or 0: any size
 __global__ __launch_bounds__(EKF_NT) void ekf_mfma_kernel(EkfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,105 +339,170 @@ __global__ __launch_bounds__(EKF_NT) void ekf_mfma_kernel(EkfArgs a) {
     lptr xv = LiT + (size_t)ny16 * ldy, xn = xv + nv, iv = xn + nv, uv = iv + nv;
     liptr ip = (liptr)(uv + nv);
 
-    for (int e = tid; e < 3 * n16 * ld + ny16 * ld + 3 * ny16 * ldy; e += nt) SG[e] = 0.0;
-    if (tid == 0) ip[1] = 0;
+#ifdef SRH_PROFILE
+    long long ekp[16] = {0}, ekl = clock64();
+#endif
+    // Every global operand that does not depend on the nearest-point index is requested now, into registers, so that
+    // the HBM / L2 latency (~2-4 k clocks each when exposed) is paid once: W, C, V, y - y_ref.  n <= 64, nt = 512:
+    // at most 8 entries per thread each.
+    constexpr int PQ = 8;
+    double wreg[PQ], creg[PQ], vreg[PQ], yreg = 0.0;
+    if (a.do_predict) {
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) wreg[k] = tid + k * nt < n * n ? a.W[tid + k * nt] : 0.0;
+    }
+    if (a.do_update) {
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) creg[k] = tid + k * nt < ny * n ? a.C[tid + k * nt] : 0.0;
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) vreg[k] = tid + k * nt < ny * ny ? a.V[tid + k * nt] : 0.0;
+        if (tid < ny) yreg = a.y[tid] - (a.y_ref ? a.y_ref[tid] : 0.0);
+    }
+    // wave 0: state, input and the nearest-point search; the other waves: Sigma into its zero-padded panel and the
+    // clearing of every other panel (the two never touch the same LDS words, so one barrier ends both)
+    const bool table = a.do_predict && a.Aext == nullptr;
+    if (tid < 64) {
+        for (int e = tid; e < n; e += 64) xv[e] = a.x[e];
+        if (a.do_predict)
+            for (int e = tid; e < m; e += 64) uv[e] = a.u[e];
+        if (tid == 0) ip[1] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (table) {
+            const int i = tpwl::nearest_wave(a.T, xv);
+            if (tid == 0) ip[0] = i;
+        }
+    } else {
+        const int t2 = tid - 64, nt2 = nt - 64;
+        for (int e = t2; e < n16 * ld; e += nt2) {
+            const int i = e / ld, j = e - i * ld;
+            SG[e] = (i < n && j < n) ? a.Sigma[i * n + j] : 0.0;
+        }
+        for (int e = t2; e < 2 * n16 * ld + ny16 * ld + 3 * ny16 * ldy; e += nt2) AT[e] = 0.0;
+    }
     __syncthreads();
-    for (int e = tid; e < n * n; e += nt) SG[(e / n) * ld + e % n] = a.Sigma[e];
-    for (int e = tid; e < n; e += nt) xv[e] = a.x[e];
-    if (a.do_predict)
-        for (int e = tid; e < m; e += nt) uv[e] = a.u[e];
-    __syncthreads();
+    EKF_LAP(0);
 
     if (a.do_predict) {
-        const double *Bg, *dg;
+        double tb = 0.0, dgv = 0.0;                 // row tid of B u and of d (n <= nt: one row per thread)
         if (a.Aext != nullptr) {
-            Bg = a.Bext; dg = a.dext;
+            if (tid < n) {
+                for (int k = 0; k < m; ++k) tb = fma(a.Bext[tid * m + k], uv[k], tb);
+                dgv = a.dext[tid];
+            }
             for (int e = tid; e < n * n; e += nt) AT[(e % n) * ld + e / n] = a.Aext[e];
         } else {
-            if (tid < 64) {
-                const int i = tpwl::nearest_wave(a.T, xv);
-                if (tid == 0) ip[0] = i;
-            }
-            __syncthreads();
             const size_t i = (size_t)ip[0];
             cgptr At = a.T.AdT + i * n * n;          // transposed table: At[k * n + r] = A[r][k]
-            Bg = (const double *)a.T.Bd + i * n * m;
-            dg = (const double *)a.T.dd + i * n;
+            const double *Bg = (const double *)a.T.Bd + i * n * m;
+            if (tid < n) {
+                for (int k = 0; k < m; ++k) tb = fma(Bg[tid * m + k], uv[k], tb);
+                dgv = ((const double *)a.T.dd + i * n)[tid];
+            }
             for (int e = tid; e < n * n; e += nt) AT[(e / n) * ld + e % n] = At[e];
         }
         __syncthreads();
-        for (int i = tid; i < n; i += nt) {
-            double t = 0.0;
-            for (int k = 0; k < m; ++k) t = fma(Bg[i * m + k], uv[k], t);
-            xn[i] = dotk(AT + i, ld, xv, 1, n) + t + dg[i];
-        }
+        EKF_LAP(2);
+        if (tid < n) xn[tid] = dotk(AT + tid, ld, xv, 1, n) + tb + dgv;
+        EKF_LAP(3);
         wg::mfma_atb(UU, ld, SG, AT, NK, n16 >> 4, n16 >> 4, ld, n);            // U = Sigma A^T
         wg::mfma_atb(SG, ld, AT, UU, NK, n16 >> 4, n16 >> 4, ld, n);            // Sigma^- = A U
-        for (int e = tid; e < n * n; e += nt) SG[(e / n) * ld + e % n] += a.W[e];
+        EKF_LAP(4);
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) {
+            const int e = tid + k * nt;
+            if (e < n * n) SG[(e / n) * ld + e % n] += wreg[k];
+        }
         for (int e = tid; e < n; e += nt) xv[e] = xn[e];
         __syncthreads();
     }
 
+    EKF_LAP(5);
     if (a.do_update) {
         for (int e = tid; e < n16 * ld; e += nt) AT[e] = 0.0;
         __syncthreads();
-        for (int e = tid; e < ny * n; e += nt) AT[(e % n) * ld + e / n] = a.C[e];      // C^T
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) {
+            const int e = tid + k * nt;
+            if (e < ny * n) AT[(e % n) * ld + e / n] = creg[k];                          // C^T
+        }
         __syncthreads();
-        for (int i = tid; i < ny; i += nt)
-            iv[i] = a.y[i] - (a.y_ref ? a.y_ref[i] : 0.0) - dotk(AT + i, ld, xv, 1, n);
+        if (tid < ny) iv[tid] = yreg - dotk(AT + tid, ld, xv, 1, n);
+        EKF_LAP(6);
         wg::mfma_atb(UU, ld, SG, AT, NK, n16 >> 4, ny16 >> 4, ld, n);             // M1 = Sigma^- C^T   (n x ny)
-        wg::mfma_atb(CS, ld, AT, SG, NK, ny16 >> 4, n16 >> 4, ld, ny);            // CS = C Sigma^-     (ny x n)
         wg::mfma_atb(Sm, ldy, AT, UU, NK, ny16 >> 4, ny16 >> 4, ld, ny);          // C M1               (ny x ny)
-        for (int e = tid; e < ny * ny; e += nt) Sm[(e / ny) * ldy + e % ny] += a.V[e];
+        // CS = C Sigma^- = M1^T: Sigma^- = A (Sigma A^T) + W is symmetric up to the rounding of the two products
+        for (int e = tid; e < ny * n; e += nt) CS[(e / n) * ld + e % n] = UU[(e % n) * ld + e / n];
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) {
+            const int e = tid + k * nt;
+            if (e < ny * ny) Sm[(e / ny) * ldy + e % ny] += vreg[k];
+        }
         __syncthreads();
-        if (tid < 64) {
-            // left-looking Cholesky, lane = row: column j of L from the finished columns < j (no trailing update)
-            bool ok = true;
-            for (int j = 0; j < ny; ++j) {
-                double sj = 0.0;
-                if (lane >= j && lane < ny) sj = Sm[lane * ldy + j] - dotk(Sm + lane * ldy, 1, Sm + j * ldy, 1, j);
-                const double djj = __shfl(sj, j, 64);
-                if (!(djj > 0.0)) { ok = false; break; }                              // uniform
-                const double rj = sqrt(djj);
-                if (lane >= j && lane < ny) Sm[lane * ldy + j] = (lane == j) ? rj : sj / rj;
-                __builtin_amdgcn_wave_barrier();
+        EKF_LAP(7);
+        lptr Y = UU, KT = UU + (size_t)ny16 * ld;
+        if (ny <= 4 * (nt >> 6) && ny <= 64 && ny + n <= 128 && 2 * (ny + n + 4 * (nt >> 6)) + 128 <= 2 * ny16 * ldy) {
+            for (int e = tid; e < ny16 * ld; e += nt) KT[e] = 0.0;          // M1 is dead: S and CS are built
+            __syncthreads();
+            (void)ekf_gain_gj<4, 2>(Sm, ldy, ny, CS, ld, n, KT, Li, ip + 1);     // Li, LiT: one cleared 2-panel buffer
+            __syncthreads();
+            EKF_LAP(8);
+            if (ip[1] != 0) {
+                if (tid == 0) *a.status = 1;
+                return;
             }
-            if (!ok && tid == 0) ip[1] = 1;
-            if (ok) {
-                // L^-1, lane = column c: row i from rows < i (entries above the diagonal stay zero)
-                for (int i = 0; i < ny; ++i) {
-                    if (lane <= i && lane < ny) {
-                        const double sdot = dotk(Sm + i * ldy, 1, Li + lane, ldy, i);
-                        const double v = ((lane == i) ? 1.0 : -sdot) / Sm[i * ldy + i];
-                        Li[i * ldy + lane] = v;
-                        LiT[lane * ldy + i] = v;
-                    }
+        } else {
+            if (tid < 64) {
+                // left-looking Cholesky, lane = row: column j of L from the finished columns < j (no trailing update)
+                bool ok = true;
+                for (int j = 0; j < ny; ++j) {
+                    double sj = 0.0;
+                    if (lane >= j && lane < ny) sj = Sm[lane * ldy + j] - dotk(Sm + lane * ldy, 1, Sm + j * ldy, 1, j);
+                    const double djj = __shfl(sj, j, 64);
+                    if (!(djj > 0.0)) { ok = false; break; }                              // uniform
+                    const double rj = sqrt(djj);
+                    if (lane >= j && lane < ny) Sm[lane * ldy + j] = (lane == j) ? rj : sj / rj;
                     __builtin_amdgcn_wave_barrier();
                 }
+                if (!ok && tid == 0) ip[1] = 1;
+                if (ok) {
+                    // L^-1, lane = column c: row i from rows < i (entries above the diagonal stay zero)
+                    for (int i = 0; i < ny; ++i) {
+                        if (lane <= i && lane < ny) {
+                            const double sdot = dotk(Sm + i * ldy, 1, Li + lane, ldy, i);
+                            const double v = ((lane == i) ? 1.0 : -sdot) / Sm[i * ldy + i];
+                            Li[i * ldy + lane] = v;
+                            LiT[lane * ldy + i] = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
             }
+            __syncthreads();
+            EKF_LAP(8);
+            if (ip[1] != 0) {
+                if (tid == 0) *a.status = 1;
+                return;
+            }
+            // Y = L^-1 CS (rows 0.. of UU), K^T = L^-T Y (rows ny16.. of UU)
+            for (int e = tid; e < ny * n; e += nt) {
+                const int i = e / n, j = e % n;
+                Y[i * ld + j] = dotk(Li + i * ldy, 1, CS + j, ld, i + 1);
+            }
+            for (int e = tid; e < (ny16 - ny) * ld; e += nt) Y[ny * ld + e] = 0.0;
+            __syncthreads();
+            for (int e = tid; e < ny16 * ld; e += nt) {
+                const int i = e / ld, j = e % ld;
+                double v = 0.0;
+                if (i < ny && j < n) v = dotk(LiT + i * ldy + i, 1, Y + (size_t)i * ld + j, ld, ny - i);
+                KT[e] = v;
+            }
+            __syncthreads();
+            EKF_LAP(9);
         }
-        __syncthreads();
-        if (ip[1] != 0) {
-            if (tid == 0) *a.status = 1;
-            return;
-        }
-        // Y = L^-1 CS (rows 0.. of UU), K^T = L^-T Y (rows ny16.. of UU)
-        lptr Y = UU, KT = UU + (size_t)ny16 * ld;
-        for (int e = tid; e < ny * n; e += nt) {
-            const int i = e / n, j = e % n;
-            Y[i * ld + j] = dotk(Li + i * ldy, 1, CS + j, ld, i + 1);
-        }
-        for (int e = tid; e < (ny16 - ny) * ld; e += nt) Y[ny * ld + e] = 0.0;
-        __syncthreads();
-        for (int e = tid; e < ny16 * ld; e += nt) {
-            const int i = e / ld, j = e % ld;
-            double v = 0.0;
-            if (i < ny && j < n) v = dotk(LiT + i * ldy + i, 1, Y + (size_t)i * ld + j, ld, ny - i);
-            KT[e] = v;
-        }
-        __syncthreads();
         for (int i = tid; i < n; i += nt) xn[i] = xv[i] + dotk(KT + i, ld, iv, 1, ny);
         wg::mfma_atb(AT, ld, KT, CS, NKy, n16 >> 4, n16 >> 4, ld, n);              // K CS
+        EKF_LAP(10);
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e % n;
             a.Sigma[e] = SG[i * ld + j] - AT[i * ld + j];
@@ -342,6 +513,12 @@ __global__ __launch_bounds__(EKF_NT) void ekf_mfma_kernel(EkfArgs a) {
         for (int e = tid; e < n; e += nt) a.x[e] = xv[e];
     }
     if (tid == 0) *a.status = 0;
+#ifdef SRH_PROFILE
+    EKF_LAP(11);
+    if (tid == 0)
+        printf("ekf clocks: load %lld nearest %lld Aload %lld xn %lld pred-mfma %lld W %lld Cload+innov %lld upd-mfma %lld chol+inv %lld Y+KT %lld KCS %lld store %lld\n",
+               ekp[0], ekp[1], ekp[2], ekp[3], ekp[4], ekp[5], ekp[6], ekp[7], ekp[8], ekp[9], ekp[10], ekp[11]);
+#endif
 }
 
 size_t lds_bytes(int n, int ny) {
@@ -375,13 +552,13 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
     int rc;
     if ((rc = h->C.upload(C, sizeof(double) * n_y * n)) || (rc = h->W.upload(W, sizeof(double) * n * n)) ||
         (rc = h->V.upload(V, sizeof(double) * n_y * n_y)) || (rc = h->Sigma.upload(Sigma0, sizeof(double) * n * n)) ||
-        (rc = h->x.alloc(sizeof(double) * n)) || (rc = h->scratch.alloc(sizeof(double) * (h->m + n_y) + 64)) ||
+        (rc = h->x.alloc(sizeof(double) * (n + 1))) || (rc = h->scratch.alloc(sizeof(double) * (h->m + n_y) + 64)) ||
         (rc = h->ext.alloc(sizeof(double) * (n * n + n * h->m + n)))) {
         delete h;
         return rc;
     }
     if (y_ref && (rc = h->y_ref.upload(y_ref, sizeof(double) * n_y))) { delete h; return rc; }
-    SRH_CHECK_HIP(hipMemset(h->x.p, 0, sizeof(double) * n));
+    SRH_CHECK_HIP(hipMemset(h->x.p, 0, sizeof(double) * (n + 1)));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_in, sizeof(double) * (h->m + n_y) + 64, hipHostMallocDefault));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (n + 2), hipHostMallocDefault));
     SRH_CHECK_HIP(hipFuncSetAttribute(h->mfma ? (n == 60 ? (const void *)ekf_mfma_kernel<60> : n == 72 ? (const void *)ekf_mfma_kernel<72>
@@ -413,18 +590,15 @@ int sekf_get_state(sekf_t *h, double *x, double *Sigma) {
     return SRH_OK;
 }
 
-int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, const double *B_d, const double *d_d,
-              double *x_out) {
-    SRH_REQUIRE(h, "sekf_step: null argument");
-    SRH_REQUIRE(u || y, "sekf_step: need an input (predict) and/or a measurement (update)");
+// enqueue one predictor/update on stream 0 (inputs through the pinned mirror, state and status copied back to it)
+static int ekf_enqueue(sekf *h, const double *u, const double *y, const double *A_d, const double *B_d,
+                       const double *d_d) {
     const bool ext = A_d != nullptr;
-    SRH_REQUIRE(!ext || (B_d && d_d), "sekf_step: A_d given without B_d, d_d");
-    SRH_REQUIRE(!u || ext || h->model->has_discrete, "sekf_step: model has not been pre-discretised");
     const int n = h->n, m = h->m, ny = h->ny;
-    // scratch layout (device): [u (m) | y (ny) | status (int, 8 bytes) ]; x lives in h->x
+    // scratch layout (device): [u (m) | y (ny)]; h->x holds x (n) and, behind it, the status word: one copy back
     double *su = h->scratch.as<double>();
     double *sy = su + m;
-    int *st = (int *)(sy + ny);
+    int *st = (int *)(h->x.as<double>() + n);
     if (u) memcpy(h->pin_in, u, sizeof(double) * m);
     if (y) memcpy(h->pin_in + m, y, sizeof(double) * ny);
     SRH_CHECK_HIP(hipMemcpyAsync(su, h->pin_in, sizeof(double) * (m + ny), hipMemcpyHostToDevice, nullptr));
@@ -452,17 +626,49 @@ int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, co
         ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
     }
     SRH_CHECK_HIP(hipGetLastError());
-    SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out, h->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
-    SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out + n, st, sizeof(int), hipMemcpyDeviceToHost, nullptr));
-    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    SRH_CHECK_HIP(hipMemcpyAsync(h->pin_out, h->x.p, sizeof(double) * (n + 1), hipMemcpyDeviceToHost, nullptr));
+    return SRH_OK;
+}
+
+// after stream 0 has drained: status check and the state estimate out of the pinned mirror
+static int ekf_collect(sekf *h, double *x_out, const char *who) {
     int status = 0;
-    memcpy(&status, h->pin_out + n, sizeof(int));
+    memcpy(&status, h->pin_out + h->n, sizeof(int));
     if (status != 0) {
-        srh::set_error("sekf_step: innovation covariance S is not positive definite");
+        srh::set_error("%s: innovation covariance S is not positive definite", who);
         return SRH_ENUMERIC;
     }
-    if (x_out) memcpy(x_out, h->pin_out, sizeof(double) * n);
+    if (x_out) memcpy(x_out, h->pin_out, sizeof(double) * h->n);
     return SRH_OK;
+}
+
+int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, const double *B_d, const double *d_d,
+              double *x_out) {
+    SRH_REQUIRE(h, "sekf_step: null argument");
+    SRH_REQUIRE(u || y, "sekf_step: need an input (predict) and/or a measurement (update)");
+    SRH_REQUIRE(!A_d || (B_d && d_d), "sekf_step: A_d given without B_d, d_d");
+    SRH_REQUIRE(!u || A_d || h->model->has_discrete, "sekf_step: model has not been pre-discretised");
+    int rc = ekf_enqueue(h, u, y, A_d, B_d, d_d);
+    if (rc) return rc;
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    return ekf_collect(h, x_out, "sekf_step");
+}
+
+int sekf_step_projected(sekf_t *h, srom_t *rom, const double *x_full, const double *u, const double *y,
+                        double *x_reduced_out, double *x_hat_out) {
+    SRH_REQUIRE(h && rom && x_full && x_reduced_out, "sekf_step_projected: null argument");
+    SRH_REQUIRE(u || y, "sekf_step_projected: need an input (predict) and/or a measurement (update)");
+    SRH_REQUIRE(!u || h->model->has_discrete, "sekf_step_projected: model has not been pre-discretised");
+    int rc;
+    if (!h->side) SRH_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    // the two halves are independent (the filter never reads the projected state): filter on stream 0 -- enqueued
+    // first, its one-workgroup kernel is the long pole -- projection on the side stream, one wait for each
+    if ((rc = ekf_enqueue(h, u, y, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = srom_stage_project(rom, SROM_X, x_full, 1, h->side))) return rc;
+    SRH_CHECK_HIP(hipStreamSynchronize(h->side));
+    if ((rc = srom_stage_collect(rom, x_reduced_out, 1, SROM_X))) return rc;
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    return ekf_collect(h, x_hat_out, "sekf_step_projected");
 }
 
 }  // extern "C"

@@ -520,6 +520,29 @@ static int staged_call(srom *h, const double *in, size_t in_bytes, double *out, 
     return SRH_OK;
 }
 
+// Two-phase form of the staged projection for callers that overlap it with other work (sekf_step_projected):
+// enqueue on `stream` (copy in, kernels, copy out), and after that stream has drained read the pinned mirror.
+int srom_stage_project(srom *h, int which, const double *X, int64_t B, hipStream_t stream) {
+    const int nblk = (which == SROM_X) ? 2 : 1;
+    const size_t inb = sizeof(double) * B * nblk * h->n_f, outb = sizeof(double) * B * nblk * h->r;
+    SRH_REQUIRE(inb <= srom::STAGE_BYTES && outb <= srom::STAGE_BYTES, "srom_stage_project: batch exceeds the staging buffer");
+    int rc = ensure_staging(h);
+    if (rc) return rc;
+    memcpy(h->st_host_in, X, inb);
+    SRH_CHECK_HIP(hipMemcpyAsync(h->st_dev_in, h->st_host_in, inb, hipMemcpyHostToDevice, stream));
+    if ((rc = srom_project_dev(h, which, (const double *)h->st_dev_in, B, nblk * h->n_f, (double *)h->st_dev_out,
+                               nblk * h->r, stream)))
+        return rc;
+    SRH_CHECK_HIP(hipMemcpyAsync(h->st_host_out, h->st_dev_out, outb, hipMemcpyDeviceToHost, stream));
+    return SRH_OK;
+}
+
+int srom_stage_collect(srom *h, double *out, int64_t B, int which) {
+    const int nblk = (which == SROM_X) ? 2 : 1;
+    memcpy(out, h->st_host_out, sizeof(double) * B * nblk * h->r);
+    return SRH_OK;
+}
+
 static int ensure_work(srom *h, size_t bytes) {
     if (bytes <= h->work_bytes) return SRH_OK;
     int rc = h->work.alloc(bytes);

@@ -173,8 +173,12 @@ class TemplateController(closed_loop_controller.TemplateController):
 
     # ---- the per-simulation-step entry point
     def evaluate(self, sim_time, y, x, u_prev):
-        x_reduced = self.dyn_sys.rom.compute_RO_state(xf=x)                  # POD projection on the device
-        self.observer.update(u_prev, y, self.sim_dt, x=x_reduced)
+        fused = getattr(self.observer, 'update_projected', None)
+        if fused is not None:                        # projection + filter step in one library call
+            fused(self.dyn_sys.rom, x, u_prev, y, self.sim_dt)
+        else:
+            x_reduced = self.dyn_sys.rom.compute_RO_state(xf=x)              # POD projection on the device
+            self.observer.update(u_prev, y, self.sim_dt, x=x_reduced)
         clock = self._clock
         if not clock.started(sim_time):
             self.u = self.u0

@@ -42,6 +42,8 @@ class DiscreteEKFObserver:
         self.V = kwargs.get('V', np.eye(self.meas_dim))
         self._h = C.c_void_p()
         self._filter_dt = None
+        self.x = None
+        self._z = None
         self._make_filter(None, self._Sigma0, None)
         self.initialize(self.dyn_sys.rom.x_ref)
 
@@ -90,11 +92,23 @@ class DiscreteEKFObserver:
         S = _lib.f64(S)
         _lib.check(_lib.lib().sekf_set_state(self._h, None, _lib.dptr(S)), 'sekf_set_state')
 
+    # z follows x (observer.py:92-95, 123-126); it is evaluated when read, so a control loop that only uses the
+    # estimate does not pay a sparse product per simulation step
+    @property
+    def z(self):
+        if self._z is None and self.x is not None:
+            if self.dyn_sys.H is not None:
+                self._z = self.dyn_sys.x_to_zfyf(self.x, zf=True)
+            else:
+                self._z = self.dyn_sys.x_to_zfyf(self.x, yf=True)
+        return self._z
+
+    @z.setter
+    def z(self, value):
+        self._z = value
+
     def _set_z(self):
-        if self.dyn_sys.H is not None:
-            self.z = self.dyn_sys.x_to_zfyf(self.x, zf=True)
-        else:
-            self.z = self.dyn_sys.x_to_zfyf(self.x, yf=True)
+        self._z = None
 
     def initialize(self, xf):
         """observer.py:76-86."""
@@ -118,6 +132,28 @@ class DiscreteEKFObserver:
         _lib.check(_lib.lib().sekf_step(self._h, _lib.dptr(u), _lib.dptr(y), _lib.dptr(A), _lib.dptr(B),
                                         _lib.dptr(d), _lib.dptr(x)), 'sekf_step')
         self.x = x
+
+    def update_projected(self, rom, xf, u, y, dt):
+        """The per-simulation-step pair rom.compute_RO_state(xf=xf); update(u, y, dt) in one library call
+        (`sekf_step_projected`: the projection runs on a side stream beside the filter kernel).  Returns the projected
+        state.  Models that hand the filter external Jacobians (weighting modes) take the two separate calls."""
+        if u is None or getattr(self.dyn_sys, 'tpwl_method', 'nn') != 'nn' or getattr(rom, 'handle', None) is None:
+            x_reduced = rom.compute_RO_state(xf=xf)
+            self.update(u, y, dt)
+            return x_reduced
+        if self._filter_dt != dt:
+            self._make_filter(dt, self.Sigma, self.x)
+        xf, u, y = _lib.f64(xf), _lib.f64(u), _lib.f64(y)
+        n_f, r = rom.U.shape
+        if xf.shape != (2 * n_f,):
+            raise RuntimeError('sekf_step_projected: expected a full-order state of %d entries, got %s'
+                               % (2 * n_f, xf.shape))
+        x_reduced, x = np.empty(2 * r), np.empty(self.state_dim)
+        _lib.check(_lib.lib().sekf_step_projected(self._h, rom.handle, _lib.dptr(xf), _lib.dptr(u), _lib.dptr(y),
+                                                  _lib.dptr(x_reduced), _lib.dptr(x)), 'sekf_step_projected')
+        self.x = x
+        self._set_z()
+        return x_reduced
 
     def update(self, u, y, dt, **kwargs):
         """observer.py:88-95: predictor + filter update in one kernel."""

@@ -126,3 +126,53 @@ def test_ekf_diamond_size_weighting_and_partial_steps():
             x, S = oobs.update(Cm, y_ref, x, S, y, V)
             ekf.update(u, y, dt)
         close(ekf.x, x); close(ekf.Sigma, S)
+
+
+def test_ekf_step_projected_golden(golden):
+    """sekf_step_projected (projection on a side stream beside the filter kernel): the filter half reproduces the g9
+    vectors of the imported reference, the projection half equals compute_RO_state bit for bit and the oracle."""
+    from sofacontrol_amd.tpwl.observer import DiscreteEKFObserver
+    from oracle import pod as opod
+    g = golden('g9_ekf')
+    model, tp, (U, q_ref, v_ref) = _model()
+    dt = 0.02
+    with contextlib.redirect_stdout(io.StringIO()):
+        tp.pre_discretize(dt)
+    ekf = DiscreteEKFObserver(tp, Sigma0=g['Sigma0'].copy(), W=g['W'], V=g['V'])
+    rng = np.random.default_rng(11)
+    n_f = U.shape[0]
+    for k in range(g['u'].shape[0]):
+        xf = np.concatenate([v_ref, q_ref]) + rng.standard_normal(2 * n_f)
+        xr = ekf.update_projected(tp.rom, xf, g['u'][k], g['y'][k], dt)
+        np.testing.assert_array_equal(xr, tp.rom.compute_RO_state(xf=xf))
+        want = np.concatenate([opod.project(U, v_ref, xf[None, :n_f])[0], opod.project(U, q_ref, xf[None, n_f:])[0]])
+        close(xr, want, 1e-12)
+        close(ekf.x, g['x'][k]); close(ekf.Sigma, g['Sigma'][k]); close(ekf.z, g['z'][k])
+    with pytest.raises(RuntimeError):
+        ekf.update_projected(tp.rom, np.zeros(3), g['u'][0], g['y'][0], dt)
+
+
+def test_ekf_step_projected_diamond_size():
+    """Full Diamond shape (n_f = 4884, r = 30, n_y = 30): fused call against the two separate calls on a twin filter."""
+    from sofacontrol_amd.tpwl.observer import DiscreteEKFObserver
+    r, m, P, nodes = 30, 4, 16, 1628
+    model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, nodes, 72, q_scale=0.3)
+    Cf = meas_selector(list(range(2, 22, 2)), nodes)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf, Cf=Cf)
+    dt = 0.01
+    with contextlib.redirect_stdout(io.StringIO()):
+        tp.pre_discretize(dt)
+    n, ny = 2 * r, 30
+    a = DiscreteEKFObserver(tp, W=100 * np.eye(n), V=np.eye(ny))
+    b = DiscreteEKFObserver(tp, W=100 * np.eye(n), V=np.eye(ny))
+    rng = np.random.default_rng(8)
+    for k in range(4):
+        u = rng.uniform(0, 300, m)
+        y = tp.y_ref + 0.05 * rng.standard_normal(ny)
+        xf = tp.rom.x_ref + rng.standard_normal(2 * U.shape[0])
+        xr = a.update_projected(tp.rom, xf, u, y, dt)
+        want = tp.rom.compute_RO_state(xf=xf)
+        b.update(u, y, dt)
+        np.testing.assert_array_equal(xr, want)
+        np.testing.assert_array_equal(a.x, b.x)
+        np.testing.assert_array_equal(a.Sigma, b.Sigma)
