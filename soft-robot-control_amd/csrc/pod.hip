@@ -45,6 +45,7 @@ struct ProjArgs {
     int64_t n_f;
     int r;
     int nchunks, chunks_per_split;
+    const double *Urows;  // UTMU only: the basis, row-major (n_f x r)
 };
 
 __global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, int NTF, int NQ, int nchunks,
@@ -84,7 +85,11 @@ __global__ void pack_ut_kernel(const double *__restrict__ U, int64_t n_f, int r,
 // 4 x 4 blocks take the SAME A operand layout -- lane = (row & 15, k-group) -- at a quarter of the issue time of a
 // padded 16-column tile: measured 7.1 ns against 26.9 ns per instruction, tools/probes/mfma4_probe.hip; r = 36 costs
 // 2.25 tiles instead of 3)
-template <int NTF, int NQ, bool HAS_REF, bool VEC2>
+// UTMU: X is a square matrix M (B = n_f rows); instead of storing its tile of T = M U the workgroup multiplies it by
+// the matching rows of the basis, P = U[rows]^T T (r x r), and stores that: U^T M U in ONE pass over M, the n_f x r
+// intermediate never reaches HBM (mor/pod.py:62-64).  The r x r partials of all workgroups are summed by
+// utmu_reduce_kernel in a fixed order.
+template <int NTF, int NQ, bool HAS_REF, bool VEC2, bool UTMU = false>
 __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NF = NTF + NQ;
@@ -174,6 +179,21 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
         if (HAS_REF && tid < KC) lds[b * BUF + UCH + tid] = refreg;
     };
 
+    // UTMU: A operand of the epilogue product P = U[rows]^T T for this wave's first output tile, U[row0 + k][16 ti + i]
+    // with lane = (i, k mod 4); all ROWS_WG / 4 loads are requested right after the main loop, before the T tile goes
+    // to LDS (requesting them during the last chunk costs registers the streaming loop needs for two waves per SIMD)
+    constexpr int LDPU = 16 * (NTF + (NQ ? 1 : 0)), NTTU = LDPU / 16;
+    double ua[UTMU ? ROWS_WG / 4 : 1];
+    auto load_ua = [&](int t) {
+        const int ucol = 16 * (t / NTTU) + lrow;
+        const int64_t row0 = (int64_t)blockIdx.x * ROWS_WG + kgrp;
+#pragma unroll
+        for (int q = 0; q < ROWS_WG / 4; ++q) {
+            const int64_t row = row0 + 4 * q;
+            ua[UTMU ? q : 0] = (row < a.B && ucol < a.r) ? a.Urows[row * a.r + ucol] : 0.0;
+        }
+    };
+
     if (c0 < c1) {
         stage_load(c0);
         load_x(c0, xr);
@@ -229,6 +249,44 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     // lane): col = lane&3, row = 4*((lane>>2)&3) + (lane>>4)
     const int col = lane & 15;
     constexpr int LDP = 16 * (NTF + (NQ ? 1 : 0));
+    if (UTMU) {
+        // T tile (ROWS_WG x LDP) into LDS -- the staging buffers are free after the last barrier of the loop -- with a
+        // row pitch = 16 (mod 32) doubles: the four k-groups of a B-operand read then fall on disjoint banks
+        constexpr int LDT = (LDP % 32 == 0) ? LDP + 16 : LDP;
+        constexpr int NTT = LDP / 16;
+        load_ua(wave);
+#pragma unroll
+        for (int mt = 0; mt < MTP; ++mt) {
+            const int lr = wave * (16 * MTP) + mt * 16;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int nt = 0; nt < NTF; ++nt) lds[(lr + kgrp + 4 * reg) * LDT + 16 * nt + col] = acc[mt][nt][reg];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                lds[(lr + 4 * ((lane >> 2) & 3) + (lane >> 4)) * LDT + 16 * NTF + 4 * q + (lane & 3)] = accq[mt][q];
+            if (NQ > 0 && NQ < 4) {              // columns of the last 16-wide tile that no 4-column tile covers
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (col >= 4 * NQ) lds[(lr + kgrp + 4 * reg) * LDT + 16 * NTF + col] = 0.0;
+            }
+        }
+        __syncthreads();
+        double *P = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (LDP * LDP);
+        for (int t = wave; t < NTT * NTT; t += 4) {
+            const int ti = t / NTT, tj = t - ti * NTT;
+            d4 pa = d4{0.0, 0.0, 0.0, 0.0};
+            if (t != wave) load_ua(t);
+#pragma unroll
+            for (int q = 0; q < ROWS_WG / 4; ++q) {
+                const double bv = lds[(4 * q + kgrp) * LDT + 16 * tj + lrow];                     // T[row][16 tj + j]
+                pa = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[q], bv, pa, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) P[(16 * ti + kgrp + 4 * reg) * LDP + 16 * tj + col] = pa[reg];
+        }
+        return;
+    }
     const bool direct = a.partial == nullptr;
     double *dst = direct ? a.out + (int64_t)blk * a.o_blk_off
                          : a.partial + (((int64_t)blockIdx.y * gridDim.z + blk) * a.B) * LDP;
@@ -289,6 +347,26 @@ __global__ void splitk_reduce_wave_kernel(const double *__restrict__ partial, in
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) out[row * ldo + (int64_t)blk * o_blk_off + j] = s;
+}
+
+// U^T M U: out (r x r) = sum over the nwg workgroup partials (ldp x ldp each); one wave per output entry, lanes over
+// the partials, fixed butterfly order (deterministic).
+__global__ void utmu_reduce_kernel(const double *__restrict__ partial, int nwg, int ldp, int r, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (idx >= r * r) return;
+    const int i = idx / r, j = idx - i * r;
+    double s = 0.0;
+    for (int k0 = lane; k0 < nwg; k0 += 512) {          // eight loads in flight per lane (a rolled loop pays the latency per load)
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = k0 + 64 * q < nwg ? partial[((int64_t)(k0 + 64 * q) * ldp + i) * ldp + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[i * r + j] = s;
 }
 
 // ------------------------------------------------------------------------------------------ lift
@@ -561,6 +639,16 @@ static int proj_ksplit(const srom *h, int64_t B, int nblk, int *chunks_per_split
 }
 
 template <int NTF, int NQ>
+static int launch_utmu(const ProjArgs &a, bool vec2, dim3 grid, hipStream_t s) {
+    constexpr int LDP = 16 * (NTF + (NQ ? 1 : 0)), LDT = (LDP % 32 == 0) ? LDP + 16 : LDP;
+    size_t lds = std::max<size_t>(2 * (size_t)(16 * (NTF + NQ) * 64 + KC), (size_t)ROWS_WG * LDT) * sizeof(double);
+    if (vec2) proj_kernel<NTF, NQ, false, true, true><<<grid, 256, lds, s>>>(a);
+    else proj_kernel<NTF, NQ, false, false, true><<<grid, 256, lds, s>>>(a);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
+template <int NTF, int NQ>
 static int launch_proj(const ProjArgs &a, bool has_ref, bool vec2, dim3 grid, hipStream_t s) {
     size_t lds = 2 * (size_t)(16 * (NTF + NQ) * 64 + KC) * sizeof(double);
     if (has_ref) {
@@ -663,6 +751,7 @@ int srom_project_dev(srom_t *h, int which, const double *X, int64_t B, int64_t l
     if (which == SROM_Q) a.ref0 = h->q_ref.as<double>();
     if (which == SROM_V) a.ref0 = h->v_ref.as<double>();
     if (which == SROM_X) { a.ref0 = h->v_ref.as<double>(); a.ref1 = h->q_ref.as<double>(); }
+    const bool vec2 = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 2 == 0) && (h->n_f % 2 == 0);
     const int64_t rowtiles = srh::cdiv(B, ROWS_WG);
     int ksplit = proj_ksplit(h, B, nblk, &a.chunks_per_split);
     const int ldp = h->NT * 16;
@@ -671,7 +760,6 @@ int srom_project_dev(srom_t *h, int which, const double *X, int64_t B, int64_t l
         if (rc) return rc;
         a.partial = h->work.as<double>();
     }
-    const bool vec2 = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 2 == 0) && (h->n_f % 2 == 0);
     dim3 grid((unsigned)rowtiles, (unsigned)ksplit, (unsigned)nblk);
     int rc;
     switch (4 * h->NTF + h->NQ) {
@@ -815,7 +903,39 @@ int srom_reduce_matrix_dev(srom_t *h, const double *M, int64_t ncols, int left, 
         return srom_project_dev(h, SROM_RAW, M, h->n_f, ncols, out, h->r, stream);
     }
     if (both) {
-        // T = M U (n_f x r) streamed once from HBM, then U^T T (r x r)
+        // one pass over M: every workgroup turns its tile of T = M U into an r x r partial U[rows]^T T; then one small
+        // reduction over the partials (SRH_UTMU_TWO_PASS: the older T-through-HBM path, kept for A/B timing)
+        if (!getenv("SRH_UTMU_TWO_PASS")) {
+            ProjArgs a{};
+            a.X = M; a.ldx = ncols; a.ufrag = h->ufrag.as<double>(); a.B = h->n_f; a.n_f = h->n_f; a.r = h->r;
+            a.nchunks = h->nchunks; a.Urows = h->U.as<double>();
+            const int64_t rowtiles = srh::cdiv(h->n_f, ROWS_WG);
+            const int ksplit = proj_ksplit(h, h->n_f, 1, &a.chunks_per_split);
+            const int ldp = 16 * (h->NTF + (h->NQ ? 1 : 0));
+            const int nwg = (int)(rowtiles * ksplit);
+            int rc = ensure_work(h, sizeof(double) * (size_t)nwg * ldp * ldp);
+            if (rc) return rc;
+            a.partial = h->work.as<double>();
+            const bool vec2 = ((reinterpret_cast<uintptr_t>(M) & 15) == 0) && (ncols % 2 == 0);
+            dim3 grid((unsigned)rowtiles, (unsigned)ksplit, 1);
+            switch (4 * h->NTF + h->NQ) {
+#define SRH_UTMU_CASE(F, Q) case 4 * F + Q: rc = launch_utmu<F, Q>(a, vec2, grid, s); break;
+                SRH_UTMU_CASE(0, 1) SRH_UTMU_CASE(0, 2) SRH_UTMU_CASE(0, 3)
+                SRH_UTMU_CASE(1, 0) SRH_UTMU_CASE(1, 1) SRH_UTMU_CASE(1, 2) SRH_UTMU_CASE(1, 3)
+                SRH_UTMU_CASE(2, 0) SRH_UTMU_CASE(2, 1) SRH_UTMU_CASE(2, 2) SRH_UTMU_CASE(2, 3)
+                SRH_UTMU_CASE(3, 0) SRH_UTMU_CASE(3, 1) SRH_UTMU_CASE(3, 2) SRH_UTMU_CASE(3, 3)
+                SRH_UTMU_CASE(4, 0)
+#undef SRH_UTMU_CASE
+                default:
+                    srh::set_error("srom_reduce_matrix_dev: no kernel for r = %d", h->r);
+                    return SRH_EINVAL;
+            }
+            if (rc) return rc;
+            utmu_reduce_kernel<<<(unsigned)srh::cdiv(h->r * h->r, 4), 256, 0, s>>>(a.partial, nwg, ldp, h->r, out);
+            SRH_CHECK_HIP(hipGetLastError());
+            return SRH_OK;
+        }
+        // T = M U (n_f x r) streamed once from HBM and stored, then U^T T (r x r)
         size_t tbytes = sizeof(double) * (size_t)h->n_f * h->r;
         size_t pbytes = sizeof(double) * (size_t)nblk_atb * h->r * h->r;
         // workspace: [split-K partials of the projection | T | atb partials]

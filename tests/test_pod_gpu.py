@@ -134,6 +134,21 @@ def test_reduce_matrix_diamond_size():
     close(rom.compute_RO_matrix(b, left=True), U.T @ b)
 
 
+@pytest.mark.parametrize('n_f,r', [(131, 5), (300, 16), (777, 22), (1000, 30), (1539, 36), (640, 48), (515, 64)])
+def test_reduce_matrix_one_pass_shapes(n_f, r, monkeypatch):
+    """U^T M U in one pass over M (the r x r partial of every workgroup, then one reduction): every accumulator
+    layout of the projection kernel (full 16-column tiles, 4-column tiles, both), ragged last row tile and last
+    column chunk; against the oracle and against the older two-pass path (T = M U through HBM)."""
+    from sofacontrol_amd.mor.pod import POD
+    U, q_ref, v_ref = make_rom(n_f, r)
+    rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    M = np.random.default_rng(n_f + r).standard_normal((n_f, n_f))
+    got = rom.compute_RO_matrix(M)
+    close(got, opod.reduce_matrix(U, M), rtol=1e-12)
+    monkeypatch.setenv('SRH_UTMU_TWO_PASS', '1')
+    close(got, rom.compute_RO_matrix(M), rtol=1e-12)
+
+
 def test_projection_round_trip_full_size():
     """BASELINE size property test: lifting then projecting is the identity on the reduced space
     (U orthonormal), and projection is linear -- independent of any CPU result."""

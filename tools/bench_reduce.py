@@ -1,7 +1,8 @@
 """U^T M U on a resident dense M (n_f x n_f): GB/s of the one HBM pass over M (191 MB at n_f = 4884)."""
-import ctypes as C, sys, time
+import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, 'soft-robot-control_amd'); sys.path.insert(0, '.')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'soft-robot-control_amd')); sys.path.insert(0, ROOT)
 import workloads as wl
 from sofacontrol_amd import _lib
 from sofacontrol_amd.mor.pod import POD
