@@ -553,7 +553,7 @@ def main():
     # corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01i_proj_pmc.json')))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_proj_pmc.json')))
         if pmc.get('algorithmic_bytes_per_launch') == alg_bytes:
             traffic = pmc['traffic_bytes_per_launch']
     except Exception:

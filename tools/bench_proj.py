@@ -1,6 +1,6 @@
 """POD projection of a resident batch (B x n_f, Diamond shape): GB/s of the one HBM pass over X, per call, with HIP
-events around `reps` back-to-back launches.  SRH_PROJ_NO_STREAM=1 times the register-direct kernel instead of the
-LDS-streaming one.  Usage (GPU box): python tools/bench_proj.py [B]"""
+events around back-to-back launches.  300 launches by default: a 20-launch run reads ~15-20 % low while the clocks ramp.
+Usage (GPU box): python tools/bench_proj.py [B [launches]]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ for which, name in ((SROM_Q, 'q (reference subtracted)'), (SROM_RAW, 'raw')):
     for _ in range(3):
         call()
     _lib.sync()
-    reps = 20
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     L.srh_event_record(e0, None)
     for _ in range(reps):
         call()
