@@ -126,15 +126,15 @@ class _DeviceSteps:
 def reduce_gramian(G, group=None, collective='auto'):
     """The one exchange step of the path: sum the partial Gramians over the ranks, in place on the tensor G (HBM with
     the nccl = RCCL backend, host memory with gloo).  'rs_ag' = reduce-scatter of row blocks + all-gather (keeps all
-    xGMI links of a node busy; needs n_s divisible by the world size and a backend that has reduce_scatter), 'all_reduce'
-    = the plain collective; 'auto' picks rs_ag when it applies."""
+    xGMI links of a node busy; needs n_s divisible by the world size), 'all_reduce' = the plain collective; 'auto' picks
+    rs_ag when it applies."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 'none'
     world = dist.get_world_size(group)
-    can_rs = dist.get_backend(group) == 'nccl' and G.shape[0] % world == 0
+    can_rs = G.shape[0] % world == 0
     if collective == 'rs_ag' and not can_rs:
-        raise RuntimeError('rs_ag needs the nccl backend and n_s divisible by the world size')
+        raise RuntimeError('rs_ag needs n_s divisible by the world size')
     if collective == 'rs_ag' or (collective == 'auto' and can_rs):
         rows = G.shape[0] // world
         mine = G.new_empty((rows, G.shape[1]))

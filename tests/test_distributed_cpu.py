@@ -19,33 +19,40 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, S, tol, out):
+def _worker(rank, world, port, S, tol, out, collective='auto'):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from sofacontrol_amd.distributed import pod_from_column_shards, shard_range
     lo, hi = shard_range(S.shape[1], rank, world)
+    tm = {}
     U_loc, k, Sig = pod_from_column_shards(S[:, lo:hi], tol, local_gramian=lambda A: A @ A.T,
-                                           local_modes=lambda A, W: A.T @ W, local_eigh=np.linalg.eigh)
-    out[rank] = (lo, hi, U_loc, k, Sig)
+                                           local_modes=lambda A, W: A.T @ W, local_eigh=np.linalg.eigh,
+                                           collective=collective, timings=tm)
+    out[rank] = (lo, hi, U_loc, k, Sig, tm.get('collective'))
     dist.destroy_process_group()
 
 
-def test_pod_column_shards_two_ranks():
+@pytest.mark.parametrize('collective,n_s,used', [('auto', 40, 'rs_ag'), ('rs_ag', 40, 'rs_ag'),
+                                                  ('all_reduce', 40, 'all_reduce'), ('auto', 41, 'all_reduce')])
+def test_pod_column_shards_two_ranks(collective, n_s, used):
+    """Both forms of the one exchange step (reduce-scatter of row blocks + all-gather; plain all-reduce), and the
+    fall-back of 'auto' when n_s does not divide by the world size."""
     rng = np.random.default_rng(0)
-    n_s, n_f = 40, 301
+    n_f = 301
     L = rng.standard_normal((n_s, 6)) * np.array([50, 20, 8, 3, 1, 0.3])
     S = L @ rng.standard_normal((6, n_f)) + 1e-3 * rng.standard_normal((n_s, n_f))
     tol = 1e-4
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, S, tol, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, S, tol, out, collective), nprocs=2, join=True)
     U = np.zeros((n_f, out[0][3]))
     for r in range(2):
-        lo, hi, U_loc, k, Sig = out[r]
+        lo, hi, U_loc, k, Sig, coll = out[r]
         U[lo:hi] = U_loc
+        assert coll == used
     _, U_ref, k_ref, S_ref = opod.compute_pod(S.T, tol)
     assert out[0][3] == out[1][3] == k_ref
     np.testing.assert_allclose(out[0][4][:6], S_ref[:6], rtol=1e-9)
