@@ -227,6 +227,13 @@ int sric_tvlqr_tpwl(stpwl_t *h, const double *xbar, int n_steps, const double *Q
 int sric_dare_fixed_point(const double *A, const double *B, int64_t batch, int n_x, int n_u,
                           const double *Q, const double *R, double tol, int max_iter, double *L,
                           double *P, int32_t *iters);
+/* dare (lqr.py:24-31, scipy.linalg.solve_discrete_are in the reference; per TPWL point at the start-up of the scp
+ * controller, tpwl/controllers.py:238-246): the stabilising solution by the structure-preserving doubling algorithm,
+ * quadratic convergence (about a dozen steps).  Stops when max|H_k+1 - H_k| <= tol max|H_k+1|.  Same shapes as above;
+ * iters = doubling steps.  SRH_ENUMERIC when R or R + B^T P B is not positive definite, I + G H is singular, or
+ * max_iter steps do not converge. */
+int sric_dare(const double *A, const double *B, int64_t batch, int n_x, int n_u, const double *Q, const double *R,
+              double tol, int max_iter, double *L, double *P, int32_t *iters);
 
 /* =====================================================================================================
  * iLQR.                           reference: sofacontrol/lqr/ilqr.py, sofacontrol/lqr/config.py

@@ -172,6 +172,162 @@ __global__ __launch_bounds__(NT) void dare_fp_kernel(const double *A, const doub
     if (threadIdx.x == 0 && iters) iters[p] = it;
 }
 
+// ------------------------------------------------------------------ DARE by structure-preserving doubling
+// lqr.py:24-31 (`dare`: scipy.linalg.solve_discrete_are in the reference; the scp controller calls it for every TPWL
+// point at start-up, tpwl/controllers.py:238-246).  A fixed-point Riccati iteration converges like rho(A_cl)^2k and
+// crawls on lightly damped points; the doubling algorithm (SDA) squares the closed-loop transition per step:
+//   G = B R^-1 B^T, H = Q;   W = I + G H,  [V1 V2] = W^-1 [A G]
+//   A <- A V1,   G <- G + A V2 A^T,   H <- H + A^T (H V1)            ->   H converges quadratically to P
+// (11-12 steps at the Diamond size where the fixed point needs ~900).  One workgroup per (A, B) pair; five n x n
+// slots (W / scratch, A -> V1, G -> V2, H, A_next) in LDS when they fit (n <= 62), else in the per-problem HBM
+// workspace next to the copies of A_k, G_k that the products read through L2; W^-1 by Gauss-Jordan elimination with
+// partial pivoting (physical row swaps) on the tableau [W | A | G]; all products on the VALU (mm), generic pointers.
+struct SdaTail {
+    lptr Rq, Lc, Bt, Yn;     // R (m x m), its Cholesky factor, B^T (m x n), -R^-1 B^T (m x n)
+    lptr fcol, prow, jrow;   // Gauss-Jordan: multipliers (n), pivot row (3n), old row j (3n)
+    lptr red;
+    liptr flag, ipiv;
+};
+
+__host__ __device__ inline size_t sda_tail_doubles(int n, int m) { return 512 + 2 * (size_t)m * n + 7 * (size_t)n + 16 + 8; }
+
+__global__ __launch_bounds__(NT) void dare_sda_kernel(const double *A, const double *B, int n, int m, const double *Q,
+                                                      const double *R, double tol, int max_iter, double *work,
+                                                      int lds_slots, double *Lout, double *Pout, int *iters,
+                                                      int *status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t p = blockIdx.x;
+    const int ld = n | 1, tid = threadIdx.x, nt = blockDim.x;
+    const size_t nn = (size_t)n * ld;
+    double *wk = work + p * (7 * nn);
+    double *gA = wk, *gG = wk + nn;
+    double *sm = (double *)smem;
+    double *S1, *S2, *S3, *S4, *S5;
+    lptr tail;
+    if (lds_slots) {
+        S1 = sm; S2 = sm + nn; S3 = sm + 2 * nn; S4 = sm + 3 * nn; S5 = sm + 4 * nn;
+        tail = (lptr)smem + 5 * nn;
+    } else {
+        S1 = wk + 2 * nn; S2 = wk + 3 * nn; S3 = wk + 4 * nn; S4 = wk + 5 * nn; S5 = wk + 6 * nn;
+        tail = (lptr)smem;
+    }
+    SdaTail T;
+    {
+        lptr q = tail;
+        auto take = [&](size_t c) { lptr r0 = q; q += c; return r0; };
+        T.Rq = take(256); T.Lc = take(256); T.Bt = take((size_t)m * n); T.Yn = take((size_t)m * n);
+        T.fcol = take(n); T.prow = take(3 * (size_t)n); T.jrow = take(3 * (size_t)n); T.red = take(16);
+        T.flag = (liptr)take(4); T.ipiv = (liptr)take(4);
+    }
+    cgptr Ag = (cgptr)A + p * n * n, Bg = (cgptr)B + p * n * m, Qg = (cgptr)Q, Rg = (cgptr)R;
+    int st = 0, it = 0;
+
+    // ---- G0 = B R^-1 B^T, H0 = Q, A0 = A
+    for (int e = tid; e < m * m; e += nt) T.Rq[e] = Rg[e];
+    for (int e = tid; e < m * n; e += nt) T.Bt[e] = Bg[(e % n) * m + e / n];
+    __syncthreads();
+    if (!wg::chol_factor(T.Rq, T.Lc, m, T.flag, false)) st = 2;
+    if (st == 0) {
+        for (int j = tid; j < n; j += nt) wg::chol_solve_neg(T.Lc, m, T.Bt + j, n, T.Yn + j, n);
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) {
+            const int r = e / n, c = e - r * n;
+            double g = 0.0;
+            for (int a = 0; a < m; ++a) g = fma(-T.Bt[a * n + r], T.Yn[a * n + c], g);
+            S3[r * ld + c] = g; gG[r * ld + c] = g;
+            const double av = Ag[e];
+            S2[r * ld + c] = av; gA[r * ld + c] = av;
+            S4[r * ld + c] = Qg[e];
+        }
+        __syncthreads();
+    }
+    while (st == 0 && it < max_iter) {
+        // W = I + G H
+        mm<false, false>(S1, ld, S3, ld, S4, ld, n, n, n);
+        for (int e = tid; e < n; e += nt) S1[e * ld + e] += 1.0;
+        __syncthreads();
+        // [V1 V2] = W^-1 [A G]: Gauss-Jordan with partial pivoting on [S1 | S2 | S3]
+        for (int j = 0; j < n && st == 0; ++j) {
+            if (tid < 64) {
+                double best = -1.0;
+                int bi = j;
+                for (int i = j + tid; i < n; i += 64) {
+                    const double v = fabs(S1[i * ld + j]);
+                    if (v > best) { best = v; bi = i; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ob = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (tid == 0) { T.ipiv[0] = bi; T.ipiv[1] = (best > 1e-300 && best < 1e300) ? 1 : 0; }
+            }
+            __syncthreads();
+            const int pv = T.ipiv[0];
+            if (T.ipiv[1] == 0) { st = 3; break; }
+            // snapshot: pivot row (old row pv), old row j, multipliers of every row as they will sit after the swap
+            for (int c = tid; c < 3 * n; c += nt) {
+                double *blk = c < n ? S1 : (c < 2 * n ? S2 : S3);
+                const int cc = c < n ? c : (c < 2 * n ? c - n : c - 2 * n);
+                T.prow[c] = blk[pv * ld + cc];
+                T.jrow[c] = blk[j * ld + cc];
+            }
+            for (int i = tid; i < n; i += nt) T.fcol[i] = S1[(i == pv ? j : i) * ld + j];
+            __syncthreads();
+            const double rp = 1.0 / T.prow[j];
+            for (int e = tid; e < 3 * n * n; e += nt) {
+                const int i = e / (3 * n), c = e - i * 3 * n;
+                double *blk = c < n ? S1 : (c < 2 * n ? S2 : S3);
+                const int cc = c < n ? c : (c < 2 * n ? c - n : c - 2 * n);
+                const double pr = T.prow[c] * rp;
+                double v;
+                if (i == j) v = pr;
+                else {
+                    const double src = (i == pv) ? T.jrow[c] : blk[i * ld + cc];
+                    v = fma(-T.fcol[i], pr, src);
+                }
+                blk[i * ld + cc] = v;
+            }
+            __syncthreads();
+        }
+        if (st != 0) break;
+        mm<false, false>(S5, ld, gA, ld, S2, ld, n, n, n);            // A_next = A V1
+        mm<false, false>(S1, ld, gA, ld, S3, ld, n, n, n);            // T2 = A V2
+        mm<false, true>(S3, ld, S1, ld, gA, ld, n, n, n);             // T2 A^T  (V2 is dead)
+        for (int e = tid; e < n * n; e += nt) { const int r = e / n, c = e - r * n; S3[r * ld + c] += gG[r * ld + c]; }
+        mm<false, false>(S1, ld, S4, ld, S2, ld, n, n, n);            // T3 = H V1
+        mm<true, false>(S2, ld, gA, ld, S1, ld, n, n, n);             // A^T T3  (V1 is dead)
+        double dmax = 0.0, hmax = 0.0;
+        for (int e = tid; e < n * n; e += nt) {
+            const int r = e / n, c = e - r * n;
+            const double d = S2[r * ld + c], h = S4[r * ld + c] + d;
+            S4[r * ld + c] = h;
+            dmax = fmax(dmax, fabs(d)); hmax = fmax(hmax, fabs(h));
+            const double an = S5[r * ld + c];
+            S2[r * ld + c] = an; gA[r * ld + c] = an;
+            gG[r * ld + c] = S3[r * ld + c];
+        }
+        dmax = wg::reduce(dmax, 1, T.red);
+        hmax = wg::reduce(hmax, 1, T.red);
+        __syncthreads();
+        ++it;
+        if (!(dmax == dmax) || !(hmax < 1e300)) { st = 3; break; }
+        if (dmax <= tol * hmax) break;
+    }
+    if (st == 0 && it >= max_iter) st = 1;
+    for (int e = tid; e < n * n; e += nt) { const int r = e / n, c = e - r * n; Pout[p * n * n + e] = S4[r * ld + c]; }
+    __syncthreads();
+    // gain K = -(R + B^T P B)^-1 B^T P A from the converged P (the fixed-point kernel's routine, its own LDS carve)
+    LqrLds L;
+    lqr_carve(L, (lptr)smem, n, m);
+    for (int e = tid; e < n * n; e += nt) L.P[e] = Pout[p * n * n + e];
+    __syncthreads();
+    if (!lqr_gain(L, Ag, Bg, Rg, n, m)) { if (st == 0) st = 2; }
+    for (int e = tid; e < m * n; e += nt) Lout[p * m * n + e] = L.Kk[e];
+    if (tid == 0) { if (iters) iters[p] = it; status[p] = st; }
+}
+
 // K = -Q~uu^-1 Q~ux (columns of L.BK -> L.Kk), k = -Q~uu^-1 Q_u (L.u2 -> L.u1) with the Cholesky factor of the
 // tiny Q~uu recomputed in registers by every thread (no serial thread-0 phase, no barrier before the solves).
 // Returns false (uniformly) if Q~uu is not positive definite.
@@ -892,6 +1048,45 @@ int sric_dare_fixed_point(const double *A, const double *B, int64_t batch, int n
                                                  tol, max_iter, dL.as<double>(), dP.as<double>(), dI.as<int>());
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    if ((rc = dL.download(L, sizeof(double) * batch * n_u * n_x)) || (rc = dP.download(P, sizeof(double) * batch * n_x * n_x))) return rc;
+    if (iters) return dI.download(iters, sizeof(int32_t) * batch);
+    return SRH_OK;
+}
+
+int sric_dare(const double *A, const double *B, int64_t batch, int n_x, int n_u, const double *Q, const double *R,
+              double tol, int max_iter, double *L, double *P, int32_t *iters) {
+    SRH_REQUIRE(A && B && Q && R && L && P, "sric_dare: null argument");
+    SRH_REQUIRE(batch > 0 && n_x > 0 && n_u > 0 && n_u <= 16, "sric_dare: bad dimensions");
+    const int ld = n_x | 1;
+    const size_t nn = (size_t)n_x * ld;
+    srh::DevBuf dA, dB, dQ, dR, dL, dP, dI, dS, dW;
+    int rc;
+    if ((rc = dA.upload(A, sizeof(double) * batch * n_x * n_x)) || (rc = dB.upload(B, sizeof(double) * batch * n_x * n_u)) ||
+        (rc = dQ.upload(Q, sizeof(double) * n_x * n_x)) || (rc = dR.upload(R, sizeof(double) * n_u * n_u)) ||
+        (rc = dL.alloc(sizeof(double) * batch * n_u * n_x)) || (rc = dP.alloc(sizeof(double) * batch * n_x * n_x)) ||
+        (rc = dI.alloc(sizeof(int32_t) * batch)) || (rc = dS.alloc(sizeof(int32_t) * batch)) ||
+        (rc = dW.alloc(sizeof(double) * batch * 7 * nn)))
+        return rc;
+    const size_t gain_lds = lqr_lds_doubles(n_x, n_u) * sizeof(double);
+    const size_t tail = sda_tail_doubles(n_x, n_u) * sizeof(double);
+    SRH_REQUIRE(gain_lds <= 160 * 1024 && tail <= 160 * 1024, "sric_dare: state dimension too large for LDS");
+    const int lds_slots = (5 * nn * sizeof(double) + tail <= 160 * 1024 && !getenv("SRH_DARE_HBM_SLOTS")) ? 1 : 0;
+    const size_t lds = std::max(gain_lds, (lds_slots ? 5 * nn * sizeof(double) : 0) + tail);
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)dare_sda_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dare_sda_kernel<<<(unsigned)batch, NT, lds>>>(dA.as<double>(), dB.as<double>(), n_x, n_u, dQ.as<double>(), dR.as<double>(),
+                                                  tol, max_iter, dW.as<double>(), lds_slots, dL.as<double>(), dP.as<double>(),
+                                                  dI.as<int>(), dS.as<int>());
+    SRH_CHECK_HIP(hipGetLastError());
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    std::vector<int32_t> st((size_t)batch);
+    if ((rc = dS.download(st.data(), sizeof(int32_t) * batch))) return rc;
+    for (int64_t i = 0; i < batch; ++i)
+        if (st[i] != 0) {
+            srh::set_error("sric_dare: problem %lld: %s", (long long)i,
+                           st[i] == 1 ? "no convergence within max_iter doubling steps"
+                                      : (st[i] == 2 ? "R or R + B^T P B is not positive definite" : "singular I + G H (not stabilisable / detectable?)"));
+            return SRH_ENUMERIC;
+        }
     if ((rc = dL.download(L, sizeof(double) * batch * n_u * n_x)) || (rc = dP.download(P, sizeof(double) * batch * n_x * n_x))) return rc;
     if (iters) return dI.download(iters, sizeof(int32_t) * batch);
     return SRH_OK;

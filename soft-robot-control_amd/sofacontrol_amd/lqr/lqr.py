@@ -24,17 +24,28 @@ def solve_riccati(A, B, Q, R):
     return L[0], P[0]
 
 
+def _doubling(A, B, Q, R, tol, max_iter):
+    A = _lib.f64(np.atleast_3d(A).reshape(-1, A.shape[-2], A.shape[-1]))
+    B = _lib.f64(np.atleast_3d(B).reshape(-1, B.shape[-2], B.shape[-1]))
+    batch, n, m = B.shape
+    L = np.empty((batch, m, n)); P = np.empty((batch, n, n)); it = np.empty(batch, dtype=np.int32)
+    _lib.check(_lib.lib().sric_dare(_lib.dptr(A), _lib.dptr(B), C.c_int64(batch), C.c_int(n), C.c_int(m),
+                                    _lib.dptr(_lib.f64(Q)), _lib.dptr(_lib.f64(R)), C.c_double(tol), C.c_int(max_iter),
+                                    _lib.dptr(L), _lib.dptr(P), _lib.iptr(it)), 'sric_dare')
+    return L, P, it
+
+
 def dare(Ad, Bd, Q, R):
-    """lqr.py:24-31 (scipy.linalg.solve_discrete_are in the reference): the stabilising DARE solution,
-    here the same fixed point iterated to 1e-13 relative change of the gain."""
-    L, P, _ = _fixed_point(Ad, Bd, Q, R, 1e-13, 1000000)
+    """lqr.py:24-31 (scipy.linalg.solve_discrete_are in the reference): the stabilising DARE solution and its gain
+    K = -(R + B'PB)^-1 B'PA, by the structure-preserving doubling algorithm on the device (`sric_dare`)."""
+    L, P, _ = _doubling(Ad, Bd, Q, R, 1e-14, 100)
     return L[0], P[0]
 
 
-def dare_batch(Ad, Bd, Q, R, tol=1e-13):
+def dare_batch(Ad, Bd, Q, R, tol=1e-14):
     """Gains for a stack of (A_d, B_d) pairs in one launch (the per-point gains of the scp controller,
     tpwl/controllers.py:238-246)."""
-    L, P, _ = _fixed_point(Ad, Bd, Q, R, tol, 1000000)
+    L, P, _ = _doubling(Ad, Bd, Q, R, tol, 100)
     return L, P
 
 

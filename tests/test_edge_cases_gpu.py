@@ -168,10 +168,9 @@ def test_device_eigh(n):
     np.testing.assert_allclose(G @ W, W * w, atol=1e-11 * max(1.0, np.abs(we).max()))
 
 
-@pytest.mark.skipif(os.environ.get('SRH_TEST_ROCSOLVER') != '1',
-                    reason='the first rocSOLVER / rocBLAS load of a process takes minutes on a cold box: set SRH_TEST_ROCSOLVER=1')
 def test_device_eigh_rocsolver_path():
-    """n > 2048 goes to rocSOLVER dsyevd (dlopen at first use); SRH_EIGH_ROCSOLVER forces it for any n."""
+    """n > 2048 goes to rocSOLVER dsyevd (dlopen at first use); SRH_EIGH_ROCSOLVER forces it for any n.  (The first
+    rocSOLVER / rocBLAS load of a process pages the libraries in: seconds on a warm box, up to minutes on a cold one.)"""
     from sofacontrol_amd.mor.pod import _device_eigh
     os.environ['SRH_EIGH_ROCSOLVER'] = '1'
     try:
@@ -185,3 +184,16 @@ def test_device_eigh_rocsolver_path():
     we = np.linalg.eigvalsh(G)
     np.testing.assert_allclose(w, we, rtol=0, atol=1e-12 * max(1.0, np.abs(we).max()))
     np.testing.assert_allclose(G @ W, W * w, atol=1e-11 * max(1.0, np.abs(we).max()))
+
+
+def test_device_eigh_above_jacobi_limit():
+    """n = 2100 > 2048: the size-based dispatch itself picks rocSOLVER (no environment override)."""
+    from sofacontrol_amd.mor.pod import _device_eigh
+    n = 2100
+    rng = np.random.default_rng(n)
+    S = rng.standard_normal((n, 64)) * np.logspace(0, -2, 64)
+    G = S @ S.T + 1e-6 * np.eye(n)
+    w, W = _device_eigh(G)
+    we = np.linalg.eigvalsh(G)
+    np.testing.assert_allclose(w, we, rtol=0, atol=1e-11 * np.abs(we).max())
+    np.testing.assert_allclose(G @ W[:, -8:], W[:, -8:] * w[-8:], atol=1e-10 * np.abs(we).max())

@@ -94,3 +94,45 @@ def test_ilqr_diamond_sizes_vs_oracle(r, m):
     xo, uo, Ko = o.solve(x0, zt)
     assert int(il.iters[0]) == len(o.trace) - 1
     close(x, xo, 1e-6); close(u, uo, 1e-6); close(K, Ko, 1e-5)
+
+
+def _dare_case(n, m, rho, rank_q, seed):
+    rng = np.random.default_rng(seed)
+    V = rng.standard_normal((n, n))
+    lam = rho * rng.uniform(0.3, 1.0, n)
+    lam[0] = rho                                     # the slowest mode sits at |lambda| = rho
+    A = np.real(V @ np.diag(lam) @ np.linalg.inv(V))
+    B = rng.standard_normal((n, m))
+    Cq = rng.standard_normal((rank_q, n))
+    return A, B, Cq.T @ Cq, np.diag(rng.uniform(0.5, 2.0, m)) * 1e-2
+
+
+@pytest.mark.parametrize('n,m,rho,rank_q', [(8, 2, 0.9, 8), (20, 3, 0.9999, 20), (60, 4, 0.999, 2), (60, 8, 1.02, 6),
+                                             (72, 4, 0.99, 3), (33, 16, 0.95, 33)])
+def test_dare_doubling_vs_scipy(n, m, rho, rank_q, monkeypatch):
+    """sric_dare (structure-preserving doubling) against scipy.linalg.solve_discrete_are: lightly damped and unstable
+    open loops, rank-deficient state cost, n_x = 72 (slots in HBM instead of LDS), n_u = 16; also the batched call and
+    the forced HBM-slot path at a size that would fit LDS."""
+    import scipy.linalg as sl
+    from sofacontrol_amd.lqr.lqr import dare, dare_batch
+    A, B, Q, R = _dare_case(n, m, rho, rank_q, 100 * n + m)
+    K, P = dare(A, B, Q, R)
+    Ps = sl.solve_discrete_are(A, B, Q, R)
+    Ks = -np.linalg.solve(R + B.T @ Ps @ B, B.T @ Ps @ A)
+    close(P, Ps, 1e-9); close(K, Ks, 1e-8)
+    assert np.abs(np.linalg.eigvals(A + B @ K)).max() < 1.0
+    A2, B2, _, _ = _dare_case(n, m, min(rho, 0.97), rank_q, 7 * n + m)
+    Kb, Pb = dare_batch(np.stack([A, A2]), np.stack([B, B2]), Q, R)
+    np.testing.assert_array_equal(Pb[0], P)
+    close(Pb[1], sl.solve_discrete_are(A2, B2, Q, R), 1e-9)
+    if n <= 60:
+        monkeypatch.setenv('SRH_DARE_HBM_SLOTS', '1')
+        K3, P3 = dare(A, B, Q, R)
+        close(P3, Ps, 1e-9)
+
+
+def test_dare_reports_failure():
+    from sofacontrol_amd.lqr.lqr import dare
+    A = np.diag([1.5, 0.5]); B = np.array([[0.0], [1.0]])        # the unstable mode is not controllable
+    with pytest.raises(Exception):
+        dare(A, B, np.eye(2), np.eye(1))
