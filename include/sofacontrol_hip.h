@@ -175,6 +175,12 @@ int sekf_step(sekf_t *h, const double *u, const double *y, const double *A_d, co
 int sekf_step_projected(sekf_t *h, srom_t *rom, const double *x_full, const double *u, const double *y,
                         double *x_reduced_out, double *x_hat_out);
 
+/* Polyhedron(with_reproject=True).project_to_polyhedron (utils.py:364-407; the measurement re-projection of
+ * SSM/controllers.py:96-97): Euclidean projection of `batch` points X (batch x n) onto {p : A p <= b}, A (n_rows x n)
+ * row-major, n <= 16, n_rows <= 64; exact (interior point to a 1e-13 gap; the reference hands the same QP to OSQP).
+ * Points already inside are returned unchanged.  SRH_ENUMERIC when the iteration does not converge (empty set). */
+int spoly_project(const double *A, const double *b, int n_rows, int n, const double *X, int64_t batch, double *out);
+
 /* =====================================================================================================
  * SSM polynomial reduced model.                                  reference: sofacontrol/SSM/ssm.py
  * f(x,u) = r_coeff phi_rom(x) + B u;  z = w_coeff phi_ssm(x) + z_ref;  x = v_coeff phi_ssm(z - z_ref),

@@ -97,6 +97,11 @@ class SSM:
     def x_to_zy(self, x):
         return self.C_map(x)
 
+    def get_sim_params(self):
+        """ssm.py:121-123 (the reference's dict names two attributes an SSM model does not have; the discretisation is
+        what identifies the run)."""
+        return {'discr_method': self.discr_method, 'discrete': self.discrete}
+
     def get_state_dim(self):
         return self.state_dim
 

@@ -57,8 +57,9 @@ class _PlanTape:
     will be executed before the next plan arrives (sampled from the plan by linear interpolation; the plan's input
     trajectory is held at its last value over the final interval).  `u(t)`, `x(t)` interpolate the tape."""
 
-    def __init__(self, dt, n_keep):
+    def __init__(self, dt, n_keep, grid_samples=False):
         self.dt, self.n_keep = dt, n_keep
+        self.grid_samples = grid_samples       # sample later plans at times rounded to the 1e-4 s grid (SSM controllers)
         self.t = self.u = self.x = None
         self._u_of_t = self._x_of_t = None
 
@@ -72,7 +73,8 @@ class _PlanTape:
         sample_x = interp1d(t_plan, x_plan, axis=0)
         start = 0.0 if self.t is None else self.t[-1]
         t_new = start + self.dt * np.arange(self.n_keep + 1)
-        u_new, x_new = sample_u(t_new), sample_x(t_new)
+        t_at = np.round(t_new, _GRID) if (self.grid_samples and self.t is not None) else t_new
+        u_new, x_new = sample_u(t_at), sample_x(t_at)
         if self.t is None:
             self.t, self.u, self.x = t_new, u_new, x_new
         else:

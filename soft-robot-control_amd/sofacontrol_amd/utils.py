@@ -50,21 +50,35 @@ def load_data(filename):
 
 
 class Polyhedron:
-    """{x : A x <= b} (sofacontrol/utils.py:364-398; the OSQP re-projection option is not part of the
-    hot path and is not provided)."""
+    """{x : A x <= b} (sofacontrol/utils.py:364-407).  with_reproject=True enables `project_to_polyhedron`: the
+    Euclidean projection min 1/2 |p - x|^2 s.t. A p <= b -- the QP the reference hands to OSQP -- solved exactly on
+    the device (`spoly_project`, csrc/poly.hip)."""
 
     def __init__(self, A, b, with_reproject=False):
-        if with_reproject:
-            raise NotImplementedError('with_reproject needs osqp and is outside the hot path')
         self.A = np.asarray(A, dtype=np.float64)
         self.b = np.asarray(b, dtype=np.float64)
-        self.with_reproject = False
+        self.with_reproject = with_reproject
 
     def contains(self, x):
         return not (np.max(self.A @ x - self.b) > 0)
 
     def get_constraint_violation(self, x):
         return np.linalg.norm(np.maximum(self.A @ x - self.b, 0))
+
+    def project_to_polyhedron(self, x):
+        if not self.with_reproject:
+            raise RuntimeError('Reproject not specified for class instance, set with_reproject=True to enable'
+                               'reprojection to the Polyhedron through a QP')
+        import ctypes as C
+        from . import _lib
+        X = _lib.f64(np.atleast_2d(x))
+        A, b = _lib.f64(self.A), _lib.f64(self.b)
+        if X.shape[1] != A.shape[1]:
+            raise RuntimeError('project_to_polyhedron: expected points of dimension %d, got %s' % (A.shape[1], np.shape(x)))
+        out = np.empty_like(X)
+        _lib.check(_lib.lib().spoly_project(_lib.dptr(A), _lib.dptr(b), C.c_int(A.shape[0]), C.c_int(A.shape[1]),
+                                            _lib.dptr(X), C.c_int64(X.shape[0]), _lib.dptr(out)), 'spoly_project')
+        return out[0] if np.ndim(x) == 1 else out
 
 
 class HyperRectangle(Polyhedron):

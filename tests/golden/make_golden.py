@@ -638,6 +638,45 @@ def g8_controllers(out):
     np.savez_compressed(os.path.join(out, 'g8_controllers.npz'), **res)
 
 
+def g15_ssm_controllers(out):
+    """SSM closed-loop controller (SSM/controllers.py:16-252: TemplateController.evaluate time gating, SSMObserver
+    302-310, scp policy stitching 140-252) driven by a scripted measurement sequence, the solver client replaced by the
+    deterministic stand-in above (the real one needs ROS).  Y = None: the re-projection of measurements
+    (controllers.py:96-97) goes through OSQP, absent here -- the product's projection is tested against the exact
+    projection instead (tests/test_edge_cases_gpu.py)."""
+    import sofacontrol.SSM.controllers as sctl
+    from oracle import ssm as ossm
+    sctl.GuSTOClientNode = FakeGuSTOClient
+    n, m = 6, 4
+    model = ossm.synthetic(n, m, 3, 3, seed=150)
+    s = ref_ssm(model)
+    rng = np.random.default_rng(151)
+    dt = 0.01
+    res = {}
+    for tag, (N_replan, delay, steps) in dict(a=(3, 0.02, 14), b=(1, 0.0, 6)).items():
+        (c, _) = quiet(sctl.scp, s, None, dt, N_replan=N_replan, delay=delay)
+        c.set_sim_timestep(dt)
+        ys, us, xs = [], [], []
+
+        def run():
+            for k in range(steps):
+                y = rutils.vq2qv(model['z_ref'] + 0.05 * rng.standard_normal(n))      # swaps the halves: its own inverse
+                ys.append(y)
+                us.append(c.evaluate(k * dt, y, None, np.zeros(m)))
+                xs.append(np.asarray(c.observer.x).copy())
+        quiet(run)
+        info = c.save_controller_info()
+        res[tag + '_y'], res[tag + '_u'], res[tag + '_x_obs'] = np.stack(ys), np.stack(us), np.stack(xs)
+        res[tag + '_z_obs'] = np.asarray(c.observer.z)
+        res[tag + '_t_opt'], res[tag + '_u_opt'], res[tag + '_z_opt'] = info['t_opt'], info['u_opt'], info['z_opt']
+        res[tag + '_rollout_time'] = info['rollout_time']
+        res[tag + '_n_solves'] = len(info['solve_times'])
+        res[tag + '_z_rollout0'] = np.asarray(info['z_rollout'][0])
+        res[tag + '_t_rollout0'] = np.asarray(info['t_rollout'][0])
+        res[tag + '_params'] = np.array([N_replan, delay, steps, dt])
+    np.savez_compressed(os.path.join(out, 'g15_ssm_controllers.npz'), **res)
+
+
 def ref_locp_values(case, pts, warm_start):
     """Instantiate the REFERENCE `LOCP` (sofacontrol/scp/locp.py, executed through the evaluating cvxpy stand-in),
     `update` it with the case data and evaluate its own objective (locp.py:218-263) and every constraint's residual
@@ -702,7 +741,7 @@ def g14_locp(out):
 
 GENERATORS = dict(g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
                   g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
-                  g13_controllers2=g13_controllers2, g14_locp=g14_locp)
+                  g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers)
 
 if __name__ == '__main__':
     # one command regenerates every fixture; `make_golden.py g6_gusto g14_locp` only the named ones

@@ -48,7 +48,11 @@ def test_host_mirror_surface_matches_reference_names():
     import sofacontrol_amd.lqr.lqr as lqr
     import sofacontrol_amd.lqr.traj_tracking_lqr as tt
     import sofacontrol_amd.utils as utils
-    for mod, names in [(pod, ['POD', 'pod_config', 'load_POD', 'run_POD', 'get_snapshots', 'process_snapshots', 'compute_POD']),
+    import sofacontrol_amd.SSM.controllers as sctl
+    import sofacontrol_amd.tpwl.controllers as tctl
+    for mod, names in [(sctl, ['TemplateController', 'scp', 'SSMObserver']),
+                       (tctl, ['TemplateController', 'scp', 'ilqr', 'TrajTracking', 'StateDLQR', 'GuSTOClient']),
+                       (pod, ['POD', 'pod_config', 'load_POD', 'run_POD', 'get_snapshots', 'process_snapshots', 'compute_POD']),
                        (tpwl, ['TPWL', 'TPWLATV']), (gusto, ['GuSTO']), (locp, ['LOCP']),
                        (sa, ['runGuSTOSolverStandAlone', 'GuSTOSolverNode']), (mt, ['TPWLGuSTO']),
                        (ilqr, ['iLQR']), (lqr, ['solve_riccati', 'dare', 'DLQR']), (tt, ['TrajTrackingLQR']),
