@@ -306,6 +306,14 @@ def pod_shapes(L, _lib, B=65536):
         t = timed(lambda: _lib.check(L.srom_lift_dev(rom.handle, 0, dXr.ptr, C.c_int64(B), C.c_int64(r), dX.ptr,
                                                      C.c_int64(n_f), None), 'lift'))
         out['lift_r%d' % r] = {'ms': t * 1e3, 'gbs': byt / t / 1e9, 'frac_of_hbm_peak': byt / t / 8e12}
+        # U^T M U of a dense n_f x n_f matrix (mor/pod.py:56-72) in one pass over M: the first 191 MB of the batch buffer
+        # serve as M (the values do not matter for the time)
+        dP = _lib.DeviceBuffer(r * r * 8)
+        t = timed(lambda: _lib.check(L.srom_reduce_matrix_dev(rom.handle, dX.ptr, C.c_int64(n_f), 1, 1, dP.ptr, None), 'reduce'),
+                  reps=300)
+        out['utmu_r%d' % r] = {'us': t * 1e6, 'gbs': 8.0 * n_f * n_f / t / 1e9, 'frac_of_hbm_peak': 8.0 * n_f * n_f / t / 8e12,
+                               'what': 'U^T M U, M 4884 x 4884 f64 resident, one pass + one reduction launch'}
+        dP.free()
         dXr.free()
     dX.free()
     return out
