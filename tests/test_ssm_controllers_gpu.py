@@ -111,3 +111,43 @@ def test_ssm_controller_reprojects_measurements(golden):
     y = zr + np.array([0.05, -0.01, 0.0, -0.07, 0.015, 0.3])
     quiet(c.evaluate, 0.0, y, None, np.zeros(4))
     np.testing.assert_allclose(vq2qv(c.observer.z), np.clip(y, zr - lim, zr + lim), rtol=0, atol=1e-9)
+
+
+def test_ssm_closed_loop_with_solver_node():
+    """End to end without stand-ins: SSM plant -> measurement -> SSMObserver (W_map on the device) -> `scp` controller ->
+    in-process GuSTOClient -> GuSTOSolverNode over SSMGuSTO (device QP with the per-stage observer linearisation) ->
+    input back into the plant.  The tracked outputs must approach the target and the inputs respect their box."""
+    import sofacontrol_amd.SSM.controllers as sctl
+    from sofacontrol_amd.scp.models.ssm import SSMGuSTO
+    from sofacontrol_amd.scp.standalone import GuSTOSolverNode
+    from sofacontrol_amd.utils import HyperRectangle, vq2qv
+    n, m, N, dt = 4, 2, 8, 0.02
+    model = ossm.synthetic(n, m, 3, 2, seed=81)
+    # a consistent pair of maps (the synthetic coefficients are independent random polynomials): z = x + z_ref and back
+    model['W'][:] = 0.0; model['W'][:, :n] = np.eye(n)
+    model['V'][:] = 0.0; model['V'][:, :n] = np.eye(n)
+    s = product_ssm(model, discr='fe')
+    gm = SSMGuSTO(s)
+    x = np.zeros(n)
+    zf = lambda xx: ossm.observe(model, xx) + model['z_ref']          # oracle C_map is without z_ref
+    z_goal = zf(x) + np.array([0.08, -0.04, 0.0, 0.0])
+    Qz = np.diag([10., 10., 0.1, 0.1]); R = 1e-2 * np.eye(m)
+    U = HyperRectangle([2.0] * m, [-2.0] * m)
+    # the solver's cost compares C_map(x) (no z_ref) with its target (locp.py:231-245 with the SSM observer map)
+    node = quiet(GuSTOSolverNode, gm, N, dt, Qz, R, x, z=z_goal - model['z_ref'], U=U, verbose=0, max_gusto_iters=4,
+                 convg_thresh=1e-4)
+    c = sctl.scp(s, None, dt, N_replan=2, delay=0.0, solver_node=node, wait=False)
+    c.set_sim_timestep(dt)
+    err0 = np.linalg.norm((zf(x) - z_goal)[:2])
+    u = np.zeros(m)
+    for k in range(24):
+        y = vq2qv(zf(x))                                      # the simulator hands over [v; q]
+        u = quiet(c.evaluate, k * dt, y, None, u)
+        assert np.all(np.abs(u) <= 2.0 + 1e-9)
+        np.testing.assert_allclose(c.observer.x, x, rtol=0, atol=1e-9)      # W_map inverts the observation on the manifold
+        A, B, d = ossm.jacobians(model, x, u, dt, 'fe')
+        x = A @ x + B @ u + d
+    err1 = np.linalg.norm((zf(x) - z_goal)[:2])
+    assert err1 < 0.5 * err0, (err0, err1)
+    info = c.save_controller_info()
+    assert len(info['solve_times']) == 12 and info['t_opt'][-1] == pytest.approx(24 * dt)
