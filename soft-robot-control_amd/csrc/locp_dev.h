@@ -15,7 +15,6 @@ struct QPDims {
     int N, n, m, nz, nU, nX, nXf, tr;
     int ld;    // leading dimension of the LDS matrices = NPa + 1 (odd: row AND column accesses conflict-free)
     int NPa;   // roundup16(n + m): extent of the stage Gram matrix
-    int mp;    // unused (kept for layout stability)
     int split; // 1: the W panel holds half of the rows at a time (n_x > 64, see riccati_solve); 0: whole W in LDS
     int WR;    // rows of the W panel (RW, or 48 in split mode)
     int NK;    // roundup4(n): K extent of the MFMA products (zero padded rows)

@@ -79,7 +79,6 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.tr = pr->tr_active ? 1 : 0;
     d.NPa = (n + m + 15) & ~15;
     d.ld = d.NPa + 1;
-    d.mp = (m + 3) & ~3;
     d.NK = (n + 3) & ~3;
     d.NE4 = (m + pr->nX + 3) & ~3;
     d.split = 0; d.WR = 0; d.nzr = 0; d.RC = 0; d.RW = 0;
