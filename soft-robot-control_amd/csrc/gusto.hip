@@ -41,9 +41,18 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const int32_t *__restri
     for (int64_t i = tid; i < batch; i += 1024) order[atomicAdd(&cnt[1023 - min(max(key[i], 0), 1023)], 1)] = (int32_t)i;
 }
 
+#ifdef SRH_PROFILE
+#define GU_LAP(i) do { __syncthreads(); const long long now_ = clock64(); gup[i] += now_ - gul; gul = now_; } while (0)
+#else
+#define GU_LAP(i) ((void)0)
+#endif
+
 template <bool SPLIT, int MSEL, int NSEL>
 __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef SRH_PROFILE
+    long long gup[8] = {0}, gul = clock64();
+#endif
     qp::specialise<MSEL, NSEL>(d);             // compile-time n_u (and n_x) for everything inlined below
     QPLds L;
     qp_lds_carve(L, (lptr)smem, d, NTHREADS);          // qp::solve fills the constants of the layout it uses
@@ -65,6 +74,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
     __syncthreads();
     tpwl::nearest_many(T, xk, n, N, idx);
+    GU_LAP(0);
 
     QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     double delta = par.delta0, omega = par.omega0;
@@ -76,7 +86,9 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                  (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
         double J;
         int qit;
+        GU_LAP(1);
         const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w);
+        GU_LAP(2);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
         double md = 0.0;
@@ -88,27 +100,51 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         const double d_cur = delta, o_cur = omega;
         if (tr_ok) {
             // model accuracy (gusto.py:203-223) with continuous nearest-point dynamics
+            GU_LAP(3);
             tpwl::nearest_many(T, w.x, n, N, idx2);
+            GU_LAP(4);
             for (int i = wave; i < N; i += nw) {
                 const size_t ia = idx[i], ib = idx2[i];
                 double e2 = 0.0, a2 = 0.0;
                 for (int r = lane; r < n; r += 64) {
                     double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
+                    // columns in order, eight at a time: the 32 loads of a batch are in flight before its FMAs (the
+                    // rolled form paid the L2 latency per column: ~0.15 ms of an SCP iteration); same sums, same order
                     cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
-                    for (int cidx = 0; cidx < n; ++cidx) {
-                        const double xo = xk[(size_t)i * n + cidx], xn = w.x[(size_t)i * n + cidx];
-                        const double a = Ak[(size_t)cidx * n + r];
-                        fk = fma(a, xo, fk);
-                        fl = fma(a, xn - xo, fl);
-                        f = fma(An[(size_t)cidx * n + r], xn, f);
+                    for (int c0 = 0; c0 < n; c0 += 8) {
+                        double av[8], anv[8], xo[8], xn[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int cc = c0 + q < n ? c0 + q : n - 1;
+                            av[q] = Ak[(size_t)cc * n + r]; anv[q] = An[(size_t)cc * n + r];
+                            xo[q] = xk[(size_t)i * n + cc]; xn[q] = w.x[(size_t)i * n + cc];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            if (c0 + q < n) {
+                                fk = fma(av[q], xo[q], fk);
+                                fl = fma(av[q], xn[q] - xo[q], fl);
+                                f = fma(anv[q], xn[q], f);
+                            }
+                        }
                     }
                     cgptr Bk = T.BcT + ia * m * n, Bn = T.BcT + ib * m * n;
-                    for (int cidx = 0; cidx < m; ++cidx) {
-                        const double uo = uk[(size_t)i * m + cidx], un = w.u[(size_t)i * m + cidx];
-                        const double bb = Bk[(size_t)cidx * n + r];
-                        fk = fma(bb, uo, fk);
-                        fl = fma(bb, un - uo, fl);
-                        f = fma(Bn[(size_t)cidx * n + r], un, f);
+                    for (int c0 = 0; c0 < m; c0 += 8) {
+                        double bv[8], bnv[8], uo[8], un[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int cc = c0 + q < m ? c0 + q : m - 1;
+                            bv[q] = Bk[(size_t)cc * n + r]; bnv[q] = Bn[(size_t)cc * n + r];
+                            uo[q] = uk[(size_t)i * m + cc]; un[q] = w.u[(size_t)i * m + cc];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            if (c0 + q < m) {
+                                fk = fma(bv[q], uo[q], fk);
+                                fl = fma(bv[q], un[q] - uo[q], fl);
+                                f = fma(bnv[q], un[q], f);
+                            }
+                        }
                     }
                     const double fa = fk + fl;
                     const double fsr = b.fs[r];
@@ -121,6 +157,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
                 if (lane == 0) { accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2); }
             }
             __syncthreads();
+            GU_LAP(5);
             double err = 0.0, app = 0.0;      // sequential sums in stage order, as the reference loop
             for (int i = 0; i < N; ++i) { err += accb[2 * i]; app += accb[2 * i + 1]; }
             rho_k = err / (J + app);
@@ -170,6 +207,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
             tr[0] = J; tr[1] = d_cur; tr[2] = o_cur; tr[3] = rho_k;
         }
         ++itr;
+        GU_LAP(6);
         if (new_solution) {
             __syncthreads();
             for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = w.x[e];
@@ -177,7 +215,13 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
             __syncthreads();
             if (par.max_iters >= 1) tpwl::nearest_many(T, xk, n, N, idx);
         }
+        GU_LAP(7);
     }
+#ifdef SRH_PROFILE
+    if (tid == 0 && blockIdx.x == 0)
+        printf("gusto clocks (%d iterations): init+nearest %lld loop-top %lld qp %lld tr-test %lld nearest(new) %lld accuracy %lld tests %lld accept+nearest %lld\n",
+               itr, gup[0], gup[1], gup[2], gup[3], gup[4], gup[5], gup[6], gup[7]);
+#endif
     if (status == 0) {
         if (omega > par.omega_max) status = 2;
         else if (itr - 1 > par.max_iters) status = 3;

@@ -26,24 +26,31 @@ __device__ inline int nearest_wave(const TpwlDev &T, XP x) {
     const int lane = threadIdx.x & 63;
     double best = INFINITY;
     int besti = 0x7fffffff;
+    // sum_j (tab[j][i] - x[xoff + j])^2 in the order j = 0, 1, ...: eight table / state loads are requested before the
+    // first FMA (a rolled load -> FMA loop pays the L2 latency r times per point; same sums, same order)
+    auto sqdist = [&](cgptr tab, int xoff, int i) {
+        double sq = 0.0;
+        for (int j0 = 0; j0 < T.r; j0 += 8) {
+            double tv[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = j0 + q < T.r ? j0 + q : T.r - 1;
+                tv[q] = tab[j * T.P + i];
+                xv[q] = x[xoff + j];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (j0 + q < T.r) { const double e = tv[q] - xv[q]; sq = fma(e, e, sq); }
+            }
+        }
+        return sq;
+    };
     for (int i0 = 0; i0 < T.P; i0 += 64) {
         const int i = i0 + lane;
         double d = INFINITY;
         if (i < T.P) {
-            double sq = 0.0;
-            for (int j = 0; j < T.r; ++j) {
-                const double e = T.qT[j * T.P + i] - x[T.r + j];
-                sq = fma(e, e, sq);
-            }
-            d = T.w_q * sqrt(sq);
-            if (T.w_v != 0.0) {
-                double sv = 0.0;
-                for (int j = 0; j < T.r; ++j) {
-                    const double e = T.vT[j * T.P + i] - x[j];
-                    sv = fma(e, e, sv);
-                }
-                d += T.w_v * sqrt(sv);
-            }
+            d = T.w_q * sqrt(sqdist(T.qT, T.r, i));
+            if (T.w_v != 0.0) d += T.w_v * sqrt(sqdist(T.vT, 0, i));
         }
         if (d < best) { best = d; besti = i; }
     }
