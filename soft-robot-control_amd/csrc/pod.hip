@@ -352,7 +352,9 @@ __global__ void splitk_reduce_wave_kernel(const double *__restrict__ partial, in
 // U^T M U: out (r x r) = sum over the nwg workgroup partials (ldp x ldp each); one wave per output entry, lanes over
 // the partials, fixed butterfly order (deterministic).  5.2 us for the 4 MB of 507 partials.  A coalesced two-level form in
 // one launch (blocks over entry chunks x partial groups, the last-arriving block of a chunk adds the group sums) was
-// measured at 14 us: the device-scope release / acquire around the arrival counter write back and invalidate L2.
+// measured at 14 us: the device-scope release / acquire around the arrival counter write back and invalidate L2; a
+// sector-wise form (one wave per eight consecutive entries, whole 64-byte sectors per lane) measured the same 5.2 us:
+// the time is the kernel boundary itself (write-back of the partials, launch, first misses), not the access pattern.
 __global__ void utmu_reduce_kernel(const double *__restrict__ partial, int nwg, int ldp, int r, double *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
