@@ -285,6 +285,7 @@ class GuSTO:
         Jstar_prev = delta_prev = omega_prev = np.inf
         converged = False
         delta, omega = self.delta0, self.omega0
+        log = []
         while self.is_valid_iteration(itr) and not converged and omega <= self.omega_max:
             self.locp.update(A_d, B_d, d_d, x0, self.x_k, delta, omega, z=z, zf=zf, u=u, full=new_solution,
                              Hd=H_d, cd=c_d)
@@ -302,8 +303,11 @@ class GuSTO:
             t_locp += stats.solve_time
             x_next, u_next, _ = self.locp.get_solution()
             e_tr, tr_satisfied = self.is_in_trust_region(x_next, delta)
+            rho_k = -1.0
+            log.append([Jstar, delta, omega, rho_k])          # (J, delta, omega, rho) per QP, like the fused kernel's trace
             if tr_satisfied:
                 rho_k = self.compute_accuracy(x_next, u_next, Jstar)
+                log[-1][3] = rho_k
                 if rho_k > self.rho and itr != 1:
                     delta = self.beta_fail * delta
                 else:
@@ -336,6 +340,9 @@ class GuSTO:
         self.zopt = np.transpose(self.model.H @ self.xopt.T)
         self.locp_solve_time = t_locp
         self.iters = np.array([itr], dtype=np.int32)
+        if self.max_trace > 0:
+            self.trace = np.full((1, max(self.max_trace, len(log)), 4), np.nan)
+            self.trace[0, :len(log)] = np.asarray(log, dtype=np.float64).reshape(-1, 4)
 
     def get_solution(self):
         return self.xopt, self.uopt, self.zopt, self.locp_solve_time

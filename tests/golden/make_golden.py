@@ -677,6 +677,42 @@ def g15_ssm_controllers(out):
     np.savez_compressed(os.path.join(out, 'g15_ssm_controllers.npz'), **res)
 
 
+def g16_dubins(out):
+    """The reference's own runnable GuSTO demonstration (sofacontrol/scp/example.py:1-35): DubinsCar, N = 50, dt = 0.1,
+    terminal cost only, input-rate polytope dU, x_char, warm_start=False -- run with the imported reference GuSTO class and
+    model, the QP solved by the exact oracle in place of cvxpy; plus a second case with the U and X boxes that
+    example.py defines but does not pass (its terminal box Xf is infeasible for the first linearisation: y is not
+    reachable from a straight, standing start)."""
+    from sofacontrol.scp.models.dubins_car import DubinsCar
+    rgusto.LOCP = InjectedLOCP
+    model = DubinsCar()
+    model.nonlinear_observer = False     # gusto.py:133 reads it; the reference's DubinsCar never sets it (example.py fails there)
+    N, dt = 50, 0.1
+    U = rutils.HyperRectangle(np.array([1., 1.]), np.array([0., -1.]))
+    xmax = np.array([6., 6., np.pi])
+    X = rutils.HyperRectangle(xmax, -xmax)
+    x_target = np.array([5., 5., 0.])
+    Xf = rutils.HyperRectangle(x_target + 2, x_target - 2)
+    dU = rutils.HyperRectangle(np.array([0.1, 0.1]), np.array([-0.1, -0.1]))
+    Qz = np.zeros((3, 3)); R = np.eye(2); Qzf = 100 * np.eye(3)
+    zf_des = np.array([4., 5., 0.])
+    x0 = np.zeros(3)
+    u_init = np.zeros((N, 2))
+    x_init = model.rollout(x0, u_init, dt)
+    x_char = np.array([1., 1., np.pi])
+    res = dict(N=N, dt=dt, Qz=Qz, R=R, Qzf=Qzf, zf=zf_des, x0=x0, u_init=u_init, x_init=x_init, x_char=x_char)
+    for tag, cons in dict(example=dict(U=None, dU=dU), boxes=dict(U=U, X=X, dU=dU)).items():
+        InjectedLOCP.log = []
+        g, _ = quiet(rgusto.GuSTO, model, N, dt, Qz, R, x0, u_init, x_init, u=u_init, zf=zf_des, Qzf=Qzf,
+                     verbose=0, visual=[], warm_start=False, x_char=x_char, jit=False, **cons)
+        x, u, z, _ = g.get_solution()
+        res[tag + '_x'], res[tag + '_u'], res[tag + '_z'] = x, u, z
+        res[tag + '_trace'] = np.array(InjectedLOCP.log)
+    for nm, poly in dict(U=U, X=X, Xf=Xf, dU=dU).items():
+        res[nm + '_A'], res[nm + '_b'] = poly.A, poly.b
+    np.savez_compressed(os.path.join(out, 'g16_dubins.npz'), **res)
+
+
 def ref_locp_values(case, pts, warm_start):
     """Instantiate the REFERENCE `LOCP` (sofacontrol/scp/locp.py, executed through the evaluating cvxpy stand-in),
     `update` it with the case data and evaluate its own objective (locp.py:218-263) and every constraint's residual
@@ -741,7 +777,8 @@ def g14_locp(out):
 
 GENERATORS = dict(g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
                   g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
-                  g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers)
+                  g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers,
+                  g16_dubins=g16_dubins)
 
 if __name__ == '__main__':
     # one command regenerates every fixture; `make_golden.py g6_gusto g14_locp` only the named ones

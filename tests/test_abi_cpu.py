@@ -49,6 +49,8 @@ def test_host_mirror_surface_matches_reference_names():
     import sofacontrol_amd.lqr.traj_tracking_lqr as tt
     import sofacontrol_amd.utils as utils
     import sofacontrol_amd.SSM.controllers as sctl
+    import sofacontrol_amd.scp.models.dubins_car as dub
+    assert hasattr(dub, 'DubinsCar')
     import sofacontrol_amd.tpwl.controllers as tctl
     for mod, names in [(sctl, ['TemplateController', 'scp', 'SSMObserver']),
                        (tctl, ['TemplateController', 'scp', 'ilqr', 'TrajTracking', 'StateDLQR', 'GuSTOClient']),
