@@ -713,6 +713,46 @@ def g16_dubins(out):
     np.savez_compressed(os.path.join(out, 'g16_dubins.npz'), **res)
 
 
+def g17_ssm_hardware(out):
+    """The reference's own SSM module test (examples/hardware/diamond_SSM.py:21-80, `module_test_continuous` and its
+    continuous twin): the SHIPPED Diamond SSM model (examples/hardware/SSMmodels/SSM_model.mat: n_x = 6, n_u = 4, cubic,
+    83 monomials) rolled out open loop on the recorded inputs (checkModel/u_big.csv, 1002 x 4) and compared with the
+    recorded tip trajectory (checkModel/z_big.csv, [v; q] rows).  The fixture holds the reference's data files (model
+    coefficients, inputs, measured outputs) and the trajectories / mean squared errors the imported reference computes
+    (numpy standing in for jax.numpy).  rest_qv.pkl (the equilibrium) is not shipped: the first measured sample serves."""
+    from scipy.io import loadmat
+    from scipy.interpolate import interp1d
+    from sofacontrol.SSM import ssm as rssm
+    from _ref_import import REF
+    base = os.path.join(REF, 'examples', 'hardware')
+    data = loadmat(os.path.join(base, 'SSMmodels', 'SSM_model.mat'))['py_data'][0, 0]
+    raw_model, raw_params = data['model'], data['params']
+    u_true = np.genfromtxt(os.path.join(base, 'checkModel', 'u_big.csv'), delimiter=',')
+    z_true = np.genfromtxt(os.path.join(base, 'checkModel', 'z_big.csv'), delimiter=',')
+    zq_true, zv_true = rutils.x2qv(z_true)
+    z_eq = np.hstack((zq_true[0], np.zeros(3)))
+    dt, T = 0.01, 10.01
+    N = int(T / dt)
+    t_original = np.linspace(0, T, int(T / 0.01) + 1)
+    t_interp = np.linspace(0, T, N + 1)
+    u_interp = interp1d(t_original, u_true, axis=0)(t_interp)
+    z_true_qv = interp1d(t_original, np.hstack((zq_true, zv_true)), axis=0)(t_interp)
+    res = dict(u_big=u_true, z_big=z_true, z_eq=z_eq, dt=dt, u_interp=u_interp, z_true_qv=z_true_qv)
+    for k in raw_model.dtype.names:
+        res['model_' + k] = np.asarray(raw_model[k][0, 0])
+    for k in raw_params.dtype.names:
+        res['params_' + k] = np.asarray(raw_params[k][0, 0])
+    n = int(raw_model['B'][0, 0].shape[0])
+    for tag, kw in dict(discrete=dict(discrete=True, discr_method='be'), be=dict(discrete=False, discr_method='be'),
+                        fe=dict(discrete=False, discr_method='fe')).items():
+        model = rssm.SSMDynamics(z_eq, model=raw_model, params=raw_params, **kw)
+        p_traj, z_traj = model.rollout(np.zeros(n), u_interp, dt)
+        err = z_true_qv - np.asarray(z_traj)[:-1]
+        res[tag + '_p'], res[tag + '_z'] = np.asarray(p_traj), np.asarray(z_traj)
+        res[tag + '_mse'] = np.linalg.norm(np.linalg.norm(err, axis=1)) ** 2 / err.shape[0]
+    np.savez_compressed(os.path.join(out, 'g17_ssm_hardware.npz'), **res)
+
+
 def ref_locp_values(case, pts, warm_start):
     """Instantiate the REFERENCE `LOCP` (sofacontrol/scp/locp.py, executed through the evaluating cvxpy stand-in),
     `update` it with the case data and evaluate its own objective (locp.py:218-263) and every constraint's residual
@@ -778,7 +818,7 @@ def g14_locp(out):
 GENERATORS = dict(g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
                   g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
                   g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers,
-                  g16_dubins=g16_dubins)
+                  g16_dubins=g16_dubins, g17_ssm_hardware=g17_ssm_hardware)
 
 if __name__ == '__main__':
     # one command regenerates every fixture; `make_golden.py g6_gusto g14_locp` only the named ones

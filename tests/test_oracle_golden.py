@@ -325,3 +325,20 @@ def test_locp_statement_matches_reference_locp_py(golden, name):
     r = Rr[-1]
     assert np.abs(r[:n_eq_dyn]).max() <= 1e-8 and np.abs(r[-qp.n:]).max() <= 1e-8      # dynamics and x_0 = x0
     assert r[n_eq_dyn:-qp.n].max(initial=0.0) <= 1e-7                                     # every inequality
+
+
+@pytest.mark.parametrize('tag', ['discrete', 'be', 'fe'])
+def test_ssm_oracle_on_the_shipped_model(golden, tag):
+    """oracle.ssm on the reference's shipped Diamond SSM model and recorded inputs (golden g17: the reference's own
+    module test, examples/hardware/diamond_SSM.py:21-80): 1002-step open-loop rollout and its MSE against the
+    measured tip trajectory."""
+    from oracle import ssm as ossm
+    g = golden('g17_ssm_hardware')
+    model = ossm.make_model(6, 4, int(g['params_ROM_order'].item()), int(g['params_SSM_order'].item()), g['model_r_coeff'], g['model_B'],
+                            g['model_w_coeff'], g['model_v_coeff'], g['z_eq'], rd_coeff=g['model_rd_coeff'], Bd=g['model_Bd'])
+    kw = dict(discrete=dict(method='be', discrete=True), be=dict(method='be'), fe=dict(method='fe'))[tag]
+    p, z = ossm.rollout(model, np.zeros(6), g['u_interp'], float(g['dt']), **kw)
+    close(p, g[tag + '_p'], 1e-9)
+    close(z, g[tag + '_z'], 1e-9)
+    err = g['z_true_qv'] - g[tag + '_z'][:-1]
+    assert np.linalg.norm(np.linalg.norm(err, axis=1)) ** 2 / err.shape[0] == pytest.approx(float(g[tag + '_mse']), rel=1e-12)

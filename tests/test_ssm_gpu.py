@@ -175,3 +175,23 @@ def test_ilqr_ssm_c3_shape_batched():
         xo, uo, Ko = o.solve(x0[b], zt[b])
         assert int(il.iters[b]) == len(o.trace) - 1
         close(x[b], xo, 1e-8); close(u[b], uo, 1e-7)
+
+
+@pytest.mark.parametrize('tag', ['discrete', 'be', 'fe'])
+def test_shipped_ssm_model_open_loop_rollout(golden, tag):
+    """The reference's own SSM module test (examples/hardware/diamond_SSM.py:21-80) on its shipped Diamond model
+    (SSM_model.mat: n_x = 6, n_u = 4, cubic) and recorded inputs / outputs (checkModel/u_big.csv, z_big.csv; golden g17
+    holds the data files and what the imported reference computes): 1002-step open-loop rollout on the device, the
+    trajectories and the mean squared error against the measured tip trajectory."""
+    from sofacontrol_amd.SSM.ssm import SSMDynamics
+    g = golden('g17_ssm_hardware')
+    mdl = {k[len('model_'):]: _mat(g[k]) for k in g.files if k.startswith('model_')}
+    prm = {k[len('params_'):]: _mat(g[k]) for k in g.files if k.startswith('params_')}
+    kw = dict(discrete=dict(discrete=True, discr_method='be'), be=dict(discrete=False, discr_method='be'),
+              fe=dict(discrete=False, discr_method='fe'))[tag]
+    s = SSMDynamics(g['z_eq'].copy(), model=mdl, params=prm, **kw)
+    p, z = s.rollout(np.zeros(6), g['u_interp'], float(g['dt']))
+    close(p, g[tag + '_p'], 1e-8); close(z, g[tag + '_z'], 1e-8)
+    err = g['z_true_qv'] - z[:-1]
+    mse = np.linalg.norm(np.linalg.norm(err, axis=1)) ** 2 / err.shape[0]
+    assert mse == pytest.approx(float(g[tag + '_mse']), rel=1e-8)
