@@ -719,7 +719,7 @@ def g17_ssm_hardware(out):
     83 monomials) rolled out open loop on the recorded inputs (checkModel/u_big.csv, 1002 x 4) and compared with the
     recorded tip trajectory (checkModel/z_big.csv, [v; q] rows).  The fixture holds the reference's data files (model
     coefficients, inputs, measured outputs) and the trajectories / mean squared errors the imported reference computes
-    (numpy standing in for jax.numpy).  rest_qv.pkl (the equilibrium) is not shipped: the first measured sample serves."""
+    (numpy standing in for jax.numpy)."""
     from scipy.io import loadmat
     from scipy.interpolate import interp1d
     from sofacontrol.SSM import ssm as rssm
@@ -730,7 +730,10 @@ def g17_ssm_hardware(out):
     u_true = np.genfromtxt(os.path.join(base, 'checkModel', 'u_big.csv'), delimiter=',')
     z_true = np.genfromtxt(os.path.join(base, 'checkModel', 'z_big.csv'), delimiter=',')
     zq_true, zv_true = rutils.x2qv(z_true)
-    z_eq = np.hstack((zq_true[0], np.zeros(3)))
+    # equilibrium of the tip exactly as the module test takes it (diamond_SSM.py:29-36): rest_qv.pkl -> x_eq -> tip node 1354
+    rest = rutils.load_data(os.path.join(base, 'rest_qv.pkl'))['rest']
+    x_eq = rutils.qv2x(q=np.asarray(rest[0]), v=np.asarray(rest[1]))
+    z_eq = linearModel([1354], 1628).evaluate(x_eq, qv=True)
     dt, T = 0.01, 10.01
     N = int(T / dt)
     t_original = np.linspace(0, T, int(T / 0.01) + 1)
@@ -751,6 +754,34 @@ def g17_ssm_hardware(out):
         res[tag + '_p'], res[tag + '_z'] = np.asarray(p_traj), np.asarray(z_traj)
         res[tag + '_mse'] = np.linalg.norm(np.linalg.norm(err, axis=1)) ** 2 / err.shape[0]
     np.savez_compressed(os.path.join(out, 'g17_ssm_hardware.npz'), **res)
+
+
+def g18_pod_shipped(out):
+    """The reference's SHIPPED Diamond POD model (examples/diamond/pod_model.pkl: U 4884 x 36 at tolerance 5e-5, q_ref,
+    v_ref) and rest state (examples/diamond/rest.pkl) through the imported reference POD class: projections, lifts and
+    model reductions of seeded full-order data (the tests regenerate the inputs from the seeds; the fixture holds the
+    reference's data files and the reference's results)."""
+    from _ref_import import REF
+    shipped = rutils.load_data(os.path.join(REF, 'examples/diamond/pod_model.pkl'))
+    rest = rutils.load_data(os.path.join(REF, 'examples/diamond/rest.pkl'))
+    info = shipped['POD_info']
+    U, q_ref, v_ref = np.asarray(info['U']), np.asarray(info['q_ref']), np.asarray(info['v_ref'])
+    rom = rpod.POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    n_f, r = U.shape
+    rng = np.random.default_rng(180)
+    Xq = q_ref + 5 * rng.standard_normal((5, n_f))
+    Xv = rng.standard_normal((5, n_f))
+    res = dict(U=U, q_ref=q_ref, v_ref=v_ref, rest=np.asarray(rest['rest']), seed=180)
+    res['proj_rest'] = rom.compute_RO_state(qf=res['rest'])
+    res['proj_q'] = np.stack([rom.compute_RO_state(qf=x) for x in Xq])
+    res['proj_x'] = np.stack([rom.compute_RO_state(xf=x) for x in rutils.qv2x(Xq, Xv)])
+    res['lift_x'] = np.stack([rom.compute_FO_state(x=p) for p in res['proj_x']])
+    M = np.random.default_rng(181).standard_normal((n_f, n_f))
+    res['UMU'] = rom.compute_RO_matrix(M)
+    res['MU_rows'] = rom.compute_RO_matrix(M, right=True)[:64]
+    Hm = np.random.default_rng(182).standard_normal((n_f, 4))
+    res['UH'] = rom.compute_RO_matrix(Hm, left=True)
+    np.savez_compressed(os.path.join(out, 'g18_pod_shipped.npz'), **res)
 
 
 def ref_locp_values(case, pts, warm_start):
@@ -818,7 +849,7 @@ def g14_locp(out):
 GENERATORS = dict(g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
                   g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
                   g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers,
-                  g16_dubins=g16_dubins, g17_ssm_hardware=g17_ssm_hardware)
+                  g16_dubins=g16_dubins, g17_ssm_hardware=g17_ssm_hardware, g18_pod_shipped=g18_pod_shipped)
 
 if __name__ == '__main__':
     # one command regenerates every fixture; `make_golden.py g6_gusto g14_locp` only the named ones

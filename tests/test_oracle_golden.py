@@ -342,3 +342,21 @@ def test_ssm_oracle_on_the_shipped_model(golden, tag):
     close(z, g[tag + '_z'], 1e-9)
     err = g['z_true_qv'] - g[tag + '_z'][:-1]
     assert np.linalg.norm(np.linalg.norm(err, axis=1)) ** 2 / err.shape[0] == pytest.approx(float(g[tag + '_mse']), rel=1e-12)
+
+
+def test_pod_oracle_on_the_shipped_model(golden):
+    """oracle.pod on the reference's shipped Diamond basis and rest state (golden g18)."""
+    from oracle import pod as opod
+    g = golden('g18_pod_shipped')
+    U, q_ref, v_ref = g['U'], g['q_ref'], g['v_ref']
+    n_f, r = U.shape
+    rng = np.random.default_rng(int(g['seed']))
+    Xq = q_ref + 5 * rng.standard_normal((5, n_f))
+    Xv = rng.standard_normal((5, n_f))
+    close(opod.project(U, q_ref, g['rest'][None])[0], g['proj_rest'], 1e-12)
+    close(opod.project(U, q_ref, Xq), g['proj_q'], 1e-12)
+    want = np.concatenate((opod.project(U, v_ref, Xv), opod.project(U, q_ref, Xq)), axis=1)
+    close(want, g['proj_x'], 1e-12)
+    M = np.random.default_rng(int(g['seed']) + 1).standard_normal((n_f, n_f))
+    close(opod.reduce_matrix(U, M), g['UMU'], 1e-11)
+    assert np.abs(U.T @ U - np.eye(r)).max() < 1e-13

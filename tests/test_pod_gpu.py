@@ -317,3 +317,27 @@ def test_gramian_full_size_c4_shard_properties():
     ref = S @ (S.T @ v)
     got = G @ v
     assert float((got - ref).abs().max()) <= 1e-10 * float(ref.abs().max())
+
+
+def test_shipped_pod_model(golden):
+    """The reference's shipped Diamond POD model (examples/diamond/pod_model.pkl: U 4884 x 36 -- two 16-column MFMA tiles
+    + one 4-column tile -- q_ref, v_ref) and rest state through the device kernels, against what the imported reference
+    POD class computes on the same files (golden g18; seeded inputs are regenerated here)."""
+    from sofacontrol_amd.mor.pod import POD
+    from sofacontrol_amd.utils import qv2x
+    g = golden('g18_pod_shipped')
+    U, q_ref, v_ref = g['U'], g['q_ref'], g['v_ref']
+    rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    n_f, r = U.shape
+    rng = np.random.default_rng(int(g['seed']))
+    Xq = q_ref + 5 * rng.standard_normal((5, n_f))
+    Xv = rng.standard_normal((5, n_f))
+    close(rom.compute_RO_state(qf=g['rest']), g['proj_rest'], 1e-12)
+    close(rom.compute_RO_state(qf=Xq), g['proj_q'], 1e-12)
+    close(rom.compute_RO_state(xf=qv2x(Xq, Xv)), g['proj_x'], 1e-12)
+    close(rom.compute_FO_state(x=g['proj_x']), g['lift_x'], 1e-12)
+    M = np.random.default_rng(int(g['seed']) + 1).standard_normal((n_f, n_f))
+    close(rom.compute_RO_matrix(M), g['UMU'], 1e-11)
+    close(rom.compute_RO_matrix(M, right=True)[:64], g['MU_rows'], 1e-12)
+    Hm = np.random.default_rng(int(g['seed']) + 2).standard_normal((n_f, 4))
+    close(rom.compute_RO_matrix(Hm, left=True), g['UH'], 1e-12)
