@@ -12,7 +12,7 @@ struct sekf {
     int n = 0, m = 0, ny = 0;
     srh::DevBuf C, y_ref, W, V, x, Sigma, scratch, ext;
     size_t lds = 0;
-    bool mfma = false;
+    bool mfma = false, wide = false;      // wide: ekf_wide_kernel (64 < n_x <= 80)
     // pinned host mirrors of the per-step input (u, y) and output (x, status): one copy each way per step
     double *pin_in = nullptr, *pin_out = nullptr;
     hipStream_t side = nullptr;          // sekf_step_projected: the projection runs beside the filter kernel
@@ -521,6 +521,204 @@ __global__ __launch_bounds__(EKF_NT) void ekf_mfma_kernel(EkfArgs a) {
 #endif
 }
 
+// ---- the MFMA filter step for 64 < n_x <= 80 (the shipped Diamond basis: r = 36, n_x = 72), where three padded
+// n16 x ld panels no longer fit LDS.  Two things make room: panels that only ever serve as k-major operands or receive
+// n valid rows are allocated with NK = n rows instead of n16, and A^T is never staged -- both products that need it
+// read it as an MFMA operand straight from the (L2-resident) transposed table.  K C Sigma^- is subtracted from Sigma^-
+// on its way to HBM instead of going through a panel.  LDS at n = 72, n_y = 30: 161 KB.
+//   C[i][j] = sum_k Lm[k][i] Rm[k][j], i < 16 MT, j < 16 NTl; Lm / Rm k-major with their own pitches, either one in LDS
+//   or global (LG / RG), columns >= nl / nr of a global operand read as zero; rows >= crows of C are not stored,
+//   columns >= ccols are stored as zeros; `epi(i, j, acc)` replaces the store when given.
+template <bool LG, bool RG, typename LP, typename RP, typename EPI>
+__device__ __forceinline__ void ekf_mm(lptr C, int ldc, int crows, int ccols, LP Lm, int ldl, int nl, RP Rm, int ldr, int nr,
+                                       int K, int MT, int NTl, EPI epi, bool use_epi) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    for (int t = wave; t < MT * NTl; t += nw) {
+        const int ti = t / NTl, tj = t - ti * NTl;
+        const int ci = 16 * ti + l16, cj = 16 * tj + l16;
+        const bool li = !LG || ci < nl, rj = !RG || cj < nr;
+        wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < K; k0 += 24) {              // six k-steps of operands in flight
+            double av[6], bv[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int k = k0 + 4 * q + kk;
+                const bool in = k0 + 4 * q < K;
+                av[q] = (in && li) ? Lm[(size_t)(in ? k : 0) * ldl + (li ? ci : 0)] : 0.0;
+                bv[q] = (in && rj) ? Rm[(size_t)(in ? k : 0) * ldr + (rj ? cj : 0)] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (k0 + 4 * q < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * ti + kk + 4 * q;
+            if (use_epi) epi(i, cj, acc[q]);
+            else if (i < crows) C[(size_t)i * ldc + cj] = cj < ccols ? acc[q] : 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+__host__ __device__ inline size_t ekf_wide_doubles(int n, int ny) {
+    const int n16 = (n + 15) & ~15, ny16 = (ny + 15) & ~15, NK = (n + 3) & ~3, ld = n16 + 1, ldy = ny16 + 1;
+    return 2 * (size_t)NK * ld + (size_t)ny16 * ld + (size_t)NK * ldy + 3 * (size_t)ny16 * ldy + 4 * (size_t)n16 + 8;
+}
+
+__global__ __launch_bounds__(EKF_NT) void ekf_wide_kernel(EkfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = a.n, m = a.m, ny = a.ny;
+    const int n16 = (n + 15) & ~15, ny16 = (ny + 15) & ~15, NK = (n + 3) & ~3, NKy = (ny + 3) & ~3, ld = n16 + 1, ldy = ny16 + 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    lptr SG = (lptr)smem;                       // Sigma, then Sigma^-                   (NK x ld)
+    lptr UU = SG + (size_t)NK * ld;             // U = Sigma A^T, then M1, then K^T      (NK x ld)
+    lptr CS = UU + (size_t)NK * ld;             // C Sigma^-                             (ny16 x ld)
+    lptr CT = CS + (size_t)ny16 * ld;           // C^T                                   (NK x ldy)
+    lptr Sm = CT + (size_t)NK * ldy;            // S                                     (ny16 x ldy)
+    lptr GB = Sm + (size_t)ny16 * ldy;          // elimination buffer                    (2 ny16 x ldy)
+    lptr xv = GB + 2 * (size_t)ny16 * ldy, xn = xv + n16, iv = xn + n16, uv = iv + n16;
+    liptr ip = (liptr)(uv + n16);
+    auto none = [](int, int, double) {};
+
+    constexpr int PQ = 16;                      // n <= 80: at most 13 entries of an n x n matrix per thread
+    double wreg[PQ], creg[PQ / 2], vreg[2], yreg = 0.0;
+    if (a.do_predict) {
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) wreg[k] = tid + k * nt < n * n ? a.W[tid + k * nt] : 0.0;
+    }
+    if (a.do_update) {
+#pragma unroll
+        for (int k = 0; k < PQ / 2; ++k) creg[k] = tid + k * nt < ny * n ? a.C[tid + k * nt] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) vreg[k] = tid + k * nt < ny * ny ? a.V[tid + k * nt] : 0.0;
+        if (tid < ny) yreg = a.y[tid] - (a.y_ref ? a.y_ref[tid] : 0.0);
+    }
+    const bool table = a.do_predict && a.Aext == nullptr;
+    if (tid < 64) {
+        for (int e = tid; e < n; e += 64) xv[e] = a.x[e];
+        if (a.do_predict)
+            for (int e = tid; e < m; e += 64) uv[e] = a.u[e];
+        if (tid == 0) ip[1] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (table) {
+            const int i = tpwl::nearest_wave(a.T, xv);
+            if (tid == 0) ip[0] = i;
+        }
+    } else {
+        const int t2 = tid - 64, nt2 = nt - 64;
+        for (int e = t2; e < NK * ld; e += nt2) {
+            const int i = e / ld, j = e - i * ld;
+            SG[e] = (i < n && j < n) ? a.Sigma[i * n + j] : 0.0;
+        }
+        for (int e = t2; e < NK * ld + ny16 * ld + NK * ldy + 3 * ny16 * ldy; e += nt2) UU[e] = 0.0;
+    }
+    __syncthreads();
+
+    if (a.do_predict) {
+        // A^T as an operand: the transposed table of the nearest point, or the caller's A transposed on the fly
+        const double *Bg, *dg;
+        cgptr At;
+        int ats, att;                                          // At[k * ats + i * att] = A[i][k]
+        if (a.Aext != nullptr) { Bg = a.Bext; dg = a.dext; At = (cgptr)a.Aext; ats = 1; att = n; }
+        else {
+            const size_t i = (size_t)ip[0];
+            At = a.T.AdT + i * n * n; ats = n; att = 1;
+            Bg = (const double *)a.T.Bd + i * n * m; dg = (const double *)a.T.dd + i * n;
+        }
+        if (tid < n) {
+            double t = 0.0;
+            for (int k = 0; k < m; ++k) t = fma(Bg[tid * m + k], uv[k], t);
+            double acc = 0.0;
+            for (int k0 = 0; k0 < n; k0 += 8) {                 // eight table entries in flight, sums in order
+                double av[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) av[q] = At[(size_t)(k0 + q < n ? k0 + q : n - 1) * ats + (size_t)tid * att];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k0 + q < n) acc = fma(av[q], xv[k0 + q], acc);
+            }
+            xn[tid] = acc + t + dg[tid];
+        }
+        if (att == 1) {
+            ekf_mm<false, true>(UU, ld, NK, n, SG, ld, n, At, n, n, NK, n16 >> 4, n16 >> 4, none, false);     // U = Sigma A^T
+            ekf_mm<true, false>(SG, ld, NK, n, At, n, n, UU, ld, n, NK, n16 >> 4, n16 >> 4, none, false);     // Sigma^- = A U
+        } else {
+            // explicit (A_d, B_d, d_d) (weighting-mode models): stage A^T through the free C Sigma^- / C^T panels? they
+            // are too small -- transpose into UU's rows is impossible while U is being formed; use the VALU products
+            for (int e = tid; e < n * n; e += nt) {
+                const int i = e / n, j = e - i * n;            // U[i][j] = sum_k Sigma[i][k] A[j][k]
+                double acc = 0.0;
+                for (int k = 0; k < n; ++k) acc = fma(SG[i * ld + k], a.Aext[(size_t)j * n + k], acc);
+                UU[i * ld + j] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < n * n; e += nt) {
+                const int i = e / n, j = e - i * n;            // Sigma^-[i][j] = sum_k A[i][k] U[k][j]
+                double acc = 0.0;
+                for (int k = 0; k < n; ++k) acc = fma(a.Aext[(size_t)i * n + k], UU[k * ld + j], acc);
+                SG[i * ld + j] = acc;                          // rows of SG are read above only: safe after the barrier
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < PQ; ++k) {
+            const int e = tid + k * nt;
+            if (e < n * n) SG[(e / n) * ld + e % n] += wreg[k];
+        }
+        if (tid < n) xv[tid] = xn[tid];
+        __syncthreads();
+    }
+
+    if (a.do_update) {
+#pragma unroll
+        for (int k = 0; k < PQ / 2; ++k) {
+            const int e = tid + k * nt;
+            if (e < ny * n) CT[(e % n) * ldy + e / n] = creg[k];                                  // C^T (n x ny)
+        }
+        for (int e = tid; e < NK * ld; e += nt) UU[e] = 0.0;
+        __syncthreads();
+        if (tid < ny) {
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc = fma(CT[k * ldy + tid], xv[k], acc);
+            iv[tid] = yreg - acc;
+        }
+        ekf_mm<false, false>(UU, ld, NK, ny, SG, ld, n, CT, ldy, ny, NK, n16 >> 4, ny16 >> 4, none, false);   // M1 = Sigma^- C^T
+        ekf_mm<false, false>(Sm, ldy, ny16, ny, CT, ldy, ny, UU, ld, ny, NK, ny16 >> 4, ny16 >> 4, none, false);   // C M1
+        for (int e = tid; e < ny * n; e += nt) CS[(e / n) * ld + e % n] = UU[(e % n) * ld + e / n];             // C Sigma^- = M1^T
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * nt;
+            if (e < ny * ny) Sm[(e / ny) * ldy + e % ny] += vreg[k];
+        }
+        __syncthreads();
+        lptr KT = UU;                                                                              // K^T (ny16 x ld), M1 is dead
+        for (int e = tid; e < ny16 * ld; e += nt) KT[e] = 0.0;
+        __syncthreads();
+        (void)ekf_gain_gj<4, 2>(Sm, ldy, ny, CS, ld, n, KT, GB, ip + 1);
+        __syncthreads();
+        if (ip[1] != 0) {
+            if (tid == 0) *a.status = 1;
+            return;
+        }
+        if (tid < n) {
+            double acc = 0.0;
+            for (int k = 0; k < ny; ++k) acc = fma(KT[k * ld + tid], iv[k], acc);
+            xn[tid] = xv[tid] + acc;
+        }
+        double *Sout = a.Sigma;
+        auto sub = [&](int i, int j, double v) { if (i < n && j < n) Sout[(size_t)i * n + j] = SG[i * ld + j] - v; };
+        ekf_mm<false, false>(SG, ld, 0, 0, KT, ld, n, CS, ld, n, NKy, n16 >> 4, n16 >> 4, sub, true);            // Sigma^- - K C Sigma^-
+        if (tid < n) a.x[tid] = xn[tid];
+    } else {
+        for (int e = tid; e < n * n; e += nt) a.Sigma[e] = SG[(e / n) * ld + e % n];
+        if (tid < n) a.x[tid] = xv[tid];
+    }
+    if (tid == 0) *a.status = 0;
+}
+
 size_t lds_bytes(int n, int ny) {
     const int ld = n | 1, ldy = ny | 1;
     const int nv = n > ny ? n : ny;
@@ -543,6 +741,11 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
         h->mfma = true;
         h->lds = sizeof(double) * ekf_mfma_doubles(h->n, n_y);
     }
+    if (!h->mfma && h->n > 64 && h->n <= 80 && n_y <= 32 && sizeof(double) * ekf_wide_doubles(h->n, n_y) <= 160 * 1024 &&
+        !getenv("SRH_EKF_NO_MFMA")) {
+        h->wide = true;
+        h->lds = sizeof(double) * ekf_wide_doubles(h->n, n_y);
+    }
     if (h->lds > 160 * 1024) {
         delete h;
         srh::set_error("sekf_create: the filter step does not fit the 160 KB LDS (n_x too large)");
@@ -561,9 +764,8 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
     SRH_CHECK_HIP(hipMemset(h->x.p, 0, sizeof(double) * (n + 1)));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_in, sizeof(double) * (h->m + n_y) + 64, hipHostMallocDefault));
     SRH_CHECK_HIP(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (n + 2), hipHostMallocDefault));
-    SRH_CHECK_HIP(hipFuncSetAttribute(h->mfma ? (n == 60 ? (const void *)ekf_mfma_kernel<60> : n == 72 ? (const void *)ekf_mfma_kernel<72>
-                                                                                             : (const void *)ekf_mfma_kernel<0>)
-                                              : (const void *)ekf_kernel,
+    SRH_CHECK_HIP(hipFuncSetAttribute(h->mfma ? (n == 60 ? (const void *)ekf_mfma_kernel<60> : (const void *)ekf_mfma_kernel<0>)
+                                              : (h->wide ? (const void *)ekf_wide_kernel : (const void *)ekf_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     *out = h;
     return SRH_OK;
@@ -620,8 +822,9 @@ static int ekf_enqueue(sekf *h, const double *u, const double *y, const double *
     a.status = st;
     if (h->mfma) {
         if (n == 60) ekf_mfma_kernel<60><<<1, EKF_NT, h->lds>>>(a);
-        else if (n == 72) ekf_mfma_kernel<72><<<1, EKF_NT, h->lds>>>(a);
         else ekf_mfma_kernel<0><<<1, EKF_NT, h->lds>>>(a);
+    } else if (h->wide) {
+        ekf_wide_kernel<<<1, EKF_NT, h->lds>>>(a);
     } else {
         ekf_kernel<<<1, EKF_NT, h->lds>>>(a);
     }

@@ -176,3 +176,44 @@ def test_ekf_step_projected_diamond_size():
         np.testing.assert_array_equal(xr, want)
         np.testing.assert_array_equal(a.x, b.x)
         np.testing.assert_array_equal(a.Sigma, b.Sigma)
+
+
+@pytest.mark.parametrize('r,method', [(36, 'nn'), (36, 'weighting'), (33, 'nn'), (35, 'nn')])
+def test_ekf_wide_kernel_vs_oracle(r, method):
+    """64 < n_x <= 80 (the shipped Diamond basis r = 36 -> n_x = 72, and sizes that are not multiples of 4 / 16): the
+    MFMA kernel that reads A^T from the table instead of staging it; against the oracle, incl. predict-only and
+    update-only calls and the explicit-Jacobian (weighting) form."""
+    from sofacontrol_amd.tpwl.observer import DiscreteEKFObserver
+    from sofacontrol_amd import _lib
+    m, P, nodes = 4, 8, 44
+    model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, nodes, 73 + r, q_scale=0.3)
+    Cf = meas_selector(list(range(2, 22, 2)), nodes)
+    kw = dict(method='weighting', beta=2.0, discr='fe') if method == 'weighting' else {}
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf, Cf=Cf, **kw)
+    dt = 0.01
+    if method == 'nn':
+        with contextlib.redirect_stdout(io.StringIO()):
+            tp.pre_discretize(dt)
+        Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    rng = np.random.default_rng(r)
+    n, ny = 2 * r, 30
+    W = 100 * np.eye(n) + 0.1 * np.diag(rng.uniform(0, 1, n)); V = np.eye(ny) + 0.05 * np.diag(rng.uniform(0, 1, ny))
+    ekf = DiscreteEKFObserver(tp, W=W, V=V)
+    x, S = np.zeros(n), np.eye(n)
+    Cm, y_ref = np.asarray(tp.C), tp.y_ref
+    for k in range(5):
+        u = rng.uniform(0, 300, m)
+        y = y_ref + 0.05 * rng.standard_normal(ny)
+        if method == 'nn':
+            xp, Sp = oobs.predict(model, Ad, Bd, dd, x, S, u, W)
+        else:
+            A, B, d = otpwl.weighted_jacobians(model, x, 2.0, dt, 'fe')
+            xp, Sp = A @ x + B @ u + d, A @ S @ A.T + W
+        if k == 2:                                            # predict only, then update only
+            ekf.predict_state(u, dt)
+            close(ekf.x, xp); close(ekf.Sigma, Sp)
+            ekf.update_state(y)
+        else:
+            ekf.update(u, y, dt)
+        x, S = oobs.update(Cm, y_ref, xp, Sp, y, V)
+        close(ekf.x, x); close(ekf.Sigma, S)
