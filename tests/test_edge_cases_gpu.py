@@ -197,3 +197,29 @@ def test_device_eigh_above_jacobi_limit():
     we = np.linalg.eigvalsh(G)
     np.testing.assert_allclose(w, we, rtol=0, atol=1e-11 * np.abs(we).max())
     np.testing.assert_allclose(G @ W[:, -8:], W[:, -8:] * w[-8:], atol=1e-10 * np.abs(we).max())
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Round-2 entry points: argument checks raise (never a silent fallback), empty batches are no-ops."""
+    import ctypes as C
+    from sofacontrol_amd import _lib
+    from sofacontrol_amd.utils import Polyhedron
+    from sofacontrol_amd.lqr.lqr import dare
+    L = _lib.lib()
+    A, b = np.vstack((np.eye(2), -np.eye(2))), np.array([1.0, 1.0, -2.0, 1.0])      # x_0 <= 1 and x_0 >= 2: empty set
+    with pytest.raises(Exception, match='spoly_project'):
+        Polyhedron(A, b, with_reproject=True).project_to_polyhedron(np.array([5.0, 0.0]))
+    P = Polyhedron(np.vstack((np.eye(2), -np.eye(2))), np.ones(4), with_reproject=True)
+    assert P.project_to_polyhedron(np.zeros((0, 2))).shape == (0, 2)
+    with pytest.raises(RuntimeError):
+        P.project_to_polyhedron(np.zeros(3))
+    big = Polyhedron(np.vstack((np.eye(17), -np.eye(17))), np.ones(34), with_reproject=True)
+    with pytest.raises(RuntimeError):
+        big.project_to_polyhedron(2 * np.ones(17))                                  # n <= 16
+    with pytest.raises(RuntimeError):
+        dare(np.eye(3), np.ones((3, 17)), np.eye(3), np.eye(17))                       # n_u <= 16
+    with pytest.raises(Exception):
+        dare(np.eye(2), np.ones((2, 1)), np.eye(2), -np.eye(1))                        # R not positive definite
+    x = np.zeros(4)
+    rc = L.sekf_step_projected(None, None, _lib.dptr(x), None, None, _lib.dptr(x), None)
+    assert rc != 0 and b'sekf_step_projected' in L.srh_last_error()

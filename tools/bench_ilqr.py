@@ -2,12 +2,15 @@
 the numpy oracle port of the reference loop."""
 import io, contextlib, sys, time
 import numpy as np
-sys.path.insert(0, 'soft-robot-control_amd'); sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'soft-robot-control_amd'), ROOT, os.path.join(ROOT, 'tests')]
 from oracle import lqr as olqr
 from helpers import golden_problem, product_tpwl
 from sofacontrol_amd.lqr.ilqr import iLQR
 from sofacontrol_amd.utils import QuadraticCost
-r, m, P, N, dt = 30, 4, 32, 50, 0.05
+r = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+m, P, N, dt = 4, 32, 50, 0.05
 model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, 40, 55, q_scale=0.2)
 tp = product_tpwl(model, U, q_ref, v_ref, Hf)
 with contextlib.redirect_stdout(io.StringIO()):
