@@ -1072,6 +1072,9 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         const int st = qpc::solve<MSEL, NSEL>(dfull, c, dyn, q, work_base, L.base, L, &it, wout);
         qp_lds_carve(L, L.base, dfull, nt);            // back to the Riccati layout (its constants are gone: ready = false)
         if (q.dbg && tid == 0) { q.dbg[8 * 61] = 1.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; }
+#ifdef SRH_PROFILE
+        if (st != 0 && tid == 0) printf("[qp] block %d: condensed path status %d after %d iterations -> Riccati path\n", (int)blockIdx.x, st, it);
+#endif
         if (st == 0) {
             QPDims d0 = dfull;
             d0.tr = 0;
@@ -1097,6 +1100,9 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
                 if (iters_out) *iters_out = it;
                 return 0;
             }
+#ifdef SRH_PROFILE
+            if (tid == 0) printf("[qp] block %d: condensed minimiser outside the trust region -> full QP on the Riccati path\n", (int)blockIdx.x);
+#endif
             first_pass = npass - 1;                      // outside the trust region: straight to the full QP
         }
     }
