@@ -382,6 +382,52 @@ struct IlqrArgs {
     double dt;
 };
 
+// MFMA product for the backward pass when the [A_t | B_t] panel does not fit LDS (64 < n_x: the shipped Diamond basis,
+// n_x = 72): C[i][j] = sum_k L(k, i) R(k, j) like wg::mfma_atb, but an operand is either an LDS panel or the pair
+// (A_t, B_t) read in place from the L2-resident tables -- AB(k, c) = A[k][c] for c < n, B[k][c - n] for c < n + m, else 0,
+// rows k >= n zero; `coff` shifts the columns (coff = n: the B block).  Rows >= vrows of C are stored as zeros, rows
+// >= srows not at all.  Six k-steps of operands are requested before their MFMAs.
+struct IlqrOp {
+    clptr p; int ld;                 // LDS panel (p != null)
+    cgptr A, B; int n, m, coff;      // or the stage's Jacobians in HBM / L2
+    __device__ __forceinline__ double get(int k, int c) const {
+        if (p) return p[(size_t)k * ld + c];
+        const int cc = c + coff;
+        if (k >= n) return 0.0;
+        return cc < n ? A[(size_t)k * n + cc] : (cc < n + m ? B[(size_t)k * m + cc - n] : 0.0);
+    }
+};
+
+__device__ __forceinline__ void ilqr_mm(lptr C, int ldc, const IlqrOp &Lo, const IlqrOp &Ro, int K, int MT, int NTl, int vrows,
+                                        int srows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    for (int t = wave; t < MT * NTl; t += nw) {
+        const int ti = t / NTl, tj = t - ti * NTl;
+        const int ci = 16 * ti + l16, cj = 16 * tj + l16;
+        wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < K; k0 += 24) {
+            double av[6], bv[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const bool in = k0 + 4 * q < K;
+                const int k = in ? k0 + 4 * q + kk : 0;
+                av[q] = in ? Lo.get(k, ci) : 0.0;
+                bv[q] = in ? Ro.get(k, cj) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (k0 + 4 * q < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * ti + kk + 4 * q;
+            if (i < srows) C[(size_t)i * ldc + cj] = i < vrows ? acc[q] : 0.0;
+        }
+    }
+    __syncthreads();
+}
+
 // MODEL 0: prediscretised nearest-neighbour TPWL tables (T); MODEL 1: SSM polynomial model (S), linearised
 // and discretised at every step of the forward pass (ilqr.py:155: model.get_jacobians(x[t], u=u[t], dt)).
 // NSEL / MSEL > 0: instantiation for exactly that n_x / n_u (compile-time extents: the index arithmetic and the small
@@ -407,7 +453,12 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     }
     // MFMA backward pass: padded panels P / G, [A|B], W = P [A|B] (NPa x ld each) and B^T [A|B] (16 x ld)
     const int NPa = (n + m + 15) & ~15, ldp = NPa + 1, NK4 = (n + 3) & ~3, n16 = (n + 15) & ~15;
-    lptr Pm = (lptr)smem + a.panel_off, ABm = Pm + (size_t)NPa * ldp, Wm = ABm + (size_t)NPa * ldp, RBm = Wm + (size_t)NPa * ldp;
+    // mfma == 1: P / G, [A|B], W panels of NPa rows.  mfma == 2 (they do not fit: n_x > 64): P / G with n + m rows, W with
+    // NK4 rows, no [A|B] panel -- the products read the stage's Jacobians in place (ilqr_mm)
+    const bool abg = a.mfma == 2;
+    const int prow = abg ? n + m : NPa;
+    lptr Pm = (lptr)smem + a.panel_off, ABm = Pm + (size_t)prow * ldp, Wm = abg ? ABm : ABm + (size_t)NPa * ldp,
+         RBm = Wm + (size_t)(abg ? NK4 : NPa) * ldp;
     lptr Hl = RBm + (size_t)16 * ldp, qz = Hl + (size_t)16 * n;      // H (nz x n) and Q (z - z*) in LDS (MFMA path)
     cgptr Hm = MODEL == 0 ? T.H : S.H;
     cgptr zref = MODEL == 0 ? T.z_ref : S.z_ref;
@@ -728,7 +779,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     auto backward_m = [&]() {
         while (true) {
             for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)N * n + e];
-            for (int e = tid; e < NPa * ldp; e += nt) { Pm[e] = 0.0; ABm[e] = 0.0; }
+            for (int e = tid; e < prow * ldp; e += nt) Pm[e] = 0.0;
+            if (!abg) for (int e = tid; e < NPa * ldp; e += nt) ABm[e] = 0.0;
             __syncthreads();
             zerr((clptr)xl, N);
             for (int e = tid; e < n * n; e += nt) {
@@ -769,7 +821,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 } else {
                     Ag = (cgptr)lin + (size_t)t * lstride; Bg = Ag + (size_t)n * n;
                 }
-                if (load_panel) {
+                if (load_panel && !abg) {
                     for (int e = tid; e < n * n; e += nt) ABm[(e / n) * ldp + e % n] = Ag[e];
                     for (int e = tid; e < n * m; e += nt) ABm[(e / m) * ldp + n + e % m] = Bg[e];
                 }
@@ -801,9 +853,17 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     for (int s2 = 0; s2 < nz; ++s2) q1 = fma(Qg[tid * nz + s2], zt[s2], q1);
                     qz[tid] = q1;
                 }
-                wg::mfma_atb(Wm, ldp, Pm, ABm, NK4, n16 >> 4, NPa >> 4, ldp, n);              // W = P [A|B]
-                wg::mfma_atb(Pm, ldp, ABm, Wm, NK4, NPa >> 4, NPa >> 4, ldp, NPa);           // G = [A|B]^T W  (over P)
-                wg::mfma_atb(RBm, ldp, ABm + n, ABm, NK4, 1, NPa >> 4, ldp, 16, m);           // [B'A | B'B]
+                if (!abg) {
+                    wg::mfma_atb(Wm, ldp, Pm, ABm, NK4, n16 >> 4, NPa >> 4, ldp, n);              // W = P [A|B]
+                    wg::mfma_atb(Pm, ldp, ABm, Wm, NK4, NPa >> 4, NPa >> 4, ldp, NPa);           // G = [A|B]^T W  (over P)
+                    wg::mfma_atb(RBm, ldp, ABm + n, ABm, NK4, 1, NPa >> 4, ldp, 16, m);           // [B'A | B'B]
+                } else {
+                    const IlqrOp ab{nullptr, 0, Ag, Bg, n, m, 0}, bb{nullptr, 0, Ag, Bg, n, m, n};
+                    const IlqrOp pp{Pm, ldp, nullptr, nullptr, 0, 0, 0}, ww{Wm, ldp, nullptr, nullptr, 0, 0, 0};
+                    ilqr_mm(Wm, ldp, pp, ab, NK4, n16 >> 4, NPa >> 4, n, NK4);
+                    ilqr_mm(Pm, ldp, ab, ww, NK4, NPa >> 4, NPa >> 4, NPa, n + m);
+                    ilqr_mm(RBm, ldp, bb, ab, NK4, 1, NPa >> 4, 16, m);
+                }
                 // Q_uu = R + B'PB ; Q~_uu = Q_uu + rho B'B ; Q_ux = B'PA ; Q~_ux = Q_ux + rho B'A
                 for (int e = tid; e < m * m; e += nt) {
                     const int r = e / m, c = e - r * m;
@@ -822,13 +882,33 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 for (int e = tid; e < n + m; e += nt) {
                     double v0 = 0.0, v1a = 0.0, v2a = 0.0, v3a = 0.0;
                     int k = 0;
-                    for (; k + 4 <= n; k += 4) {
-                        v0 = fma(ABm[k * ldp + e], L.v1[k], v0);
-                        v1a = fma(ABm[(k + 1) * ldp + e], L.v1[k + 1], v1a);
-                        v2a = fma(ABm[(k + 2) * ldp + e], L.v1[k + 2], v2a);
-                        v3a = fma(ABm[(k + 3) * ldp + e], L.v1[k + 3], v3a);
+                    if (!abg) {
+                        for (; k + 4 <= n; k += 4) {
+                            v0 = fma(ABm[k * ldp + e], L.v1[k], v0);
+                            v1a = fma(ABm[(k + 1) * ldp + e], L.v1[k + 1], v1a);
+                            v2a = fma(ABm[(k + 2) * ldp + e], L.v1[k + 2], v2a);
+                            v3a = fma(ABm[(k + 3) * ldp + e], L.v1[k + 3], v3a);
+                        }
+                        for (; k < n; ++k) v0 = fma(ABm[k * ldp + e], L.v1[k], v0);
+                    } else {
+                        // column e of [A | B] from the tables: the same four partial sums, eight entries in flight
+                        cgptr col = e < n ? Ag + e : Bg + (e - n);
+                        const int cs = e < n ? n : m;
+                        for (; k + 8 <= n; k += 8) {
+                            double c8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) c8[q] = col[(size_t)(k + q) * cs];
+                            v0 = fma(c8[0], L.v1[k], v0); v1a = fma(c8[1], L.v1[k + 1], v1a);
+                            v2a = fma(c8[2], L.v1[k + 2], v2a); v3a = fma(c8[3], L.v1[k + 3], v3a);
+                            v0 = fma(c8[4], L.v1[k + 4], v0); v1a = fma(c8[5], L.v1[k + 5], v1a);
+                            v2a = fma(c8[6], L.v1[k + 6], v2a); v3a = fma(c8[7], L.v1[k + 7], v3a);
+                        }
+                        for (; k + 4 <= n; k += 4) {
+                            v0 = fma(col[(size_t)k * cs], L.v1[k], v0); v1a = fma(col[(size_t)(k + 1) * cs], L.v1[k + 1], v1a);
+                            v2a = fma(col[(size_t)(k + 2) * cs], L.v1[k + 2], v2a); v3a = fma(col[(size_t)(k + 3) * cs], L.v1[k + 3], v3a);
+                        }
+                        for (; k < n; ++k) v0 = fma(col[(size_t)k * cs], L.v1[k], v0);
                     }
-                    for (; k < n; ++k) v0 = fma(ABm[k * ldp + e], L.v1[k], v0);
                     double v = (v0 + v1a) + (v2a + v3a);
                     if (e < n) {
                         for (int s = 0; s < nz; ++s) v = fma(Hl[s * n + e], qz[s], v);     // c_x = H^T (Q (z - z*))
@@ -841,7 +921,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 }
                 __syncthreads();
                 // the Q_ux rows of G are consumed: rows n.. of P must be zero again (K padding of the next product)
-                for (int e = tid; e < (NPa - n) * ldp; e += nt) Pm[n * ldp + e] = 0.0;
+                for (int e = tid; e < (prow - n) * ldp; e += nt) Pm[n * ldp + e] = 0.0;
                 if (!ilqr_gain(L, n, m)) {                        // not PD: raise rho, restart (ilqr.py:276-287)
                     __syncthreads();
                     reg_update(true);
@@ -1125,11 +1205,19 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
     const size_t mf_off = lqr_lds_doubles(n, m, 256) + tail;
     const size_t mf_lds = (mf_off + 3 * NPa * ldp + 16 * ldp + (size_t)16 * n + 16) * sizeof(double);
     size_t lds;
+    // when those do not fit (n_x > 64): P / G with n + m rows, W with NK4 rows, [A|B] read in place (ilqr_mm)
+    const size_t NK4h = (size_t)((n + 3) & ~3);
+    const size_t mf2_lds = (mf_off + ((size_t)n + m + NK4h + 16) * ldp + (size_t)16 * n + 16) * sizeof(double);
     if (mf_lds <= 160 * 1024 && !getenv("SRH_ILQR_NO_MFMA")) {
         a.mfma = 1;
         a.panel_off = mf_off;
         a.stage_ab = hs ? 1 : 0;
         lds = mf_lds;
+    } else if (mf2_lds <= 160 * 1024 && !getenv("SRH_ILQR_NO_MFMA")) {
+        a.mfma = 2;
+        a.panel_off = mf_off;
+        a.stage_ab = hs ? 1 : 0;
+        lds = mf2_lds;
     } else {
         lds = (lqr_lds_doubles(n, m) + tail) * sizeof(double);
         // VALU fallback: the backward pass reads (A_t, B_t) n times per stage: stage them in LDS when they fit
