@@ -96,6 +96,51 @@ def test_ilqr_diamond_sizes_vs_oracle(r, m):
     close(x, xo, 1e-6); close(u, uo, 1e-6); close(K, Ko, 1e-5)
 
 
+def test_baseline_config_c1_r5_horizon10():
+    """BASELINE.json configs[0] -- Diamond TPWL ROM r = 5 (n_x = 10), LQR horizon 10: iLQR plan and the TV-LQR tracking
+    gains around it, against the oracle (the numpy restatement of the reference's CPU path)."""
+    import io, contextlib
+    from oracle import lqr as olqr
+    from helpers import golden_problem, product_tpwl
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.lqr.traj_tracking_lqr import TrajTrackingLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    r, m, P, N, dt = 5, 4, 12, 10, 0.05
+    model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, 40, 5, q_scale=0.2)
+    tp = product_tpwl(model, U, q_ref, v_ref, Hf)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tp.pre_discretize(dt)
+    Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    H, z_ref = np.asarray(tp.H), np.asarray(tp.z_ref)
+    Qz = np.diag([0., 0., 0., 100., 100., 10.]); R = 1e-3 * np.eye(m)
+    th = np.linspace(0, 1.0, N + 1)
+    zt = np.zeros((N + 1, 6)); zt[:, 3] = -0.02 * np.sin(th); zt[:, 4] = 0.01 * np.sin(2 * th)
+    zt = zt + z_ref
+    x0 = 1e-3 * np.random.default_rng(5).standard_normal(2 * r)
+    il = iLQR(dt, tp, QuadraticCost(Q=Qz, R=R, Qf=10 * Qz), N)
+    il.set_target(zt)
+    x, u, K = il.ilqr_computation(x0)
+    o = olqr.ILQR(model, Ad, Bd, dd, H, z_ref, Qz, R, 10 * Qz, N)
+    xo, uo, Ko = o.solve(x0, zt)
+    assert int(il.iters[0]) == len(o.trace) - 1
+    close(x, xo, 1e-8); close(u, uo, 1e-8); close(K, Ko, 1e-7)
+    # TV-LQR around the plan (traj_tracking_lqr.py:18-48)
+    Q = H.T @ Qz @ H + 1e-3 * np.eye(2 * r)
+
+    class Target:
+        t, x, u = dt * np.arange(N + 1), xo, np.vstack((uo, uo[-1:]))
+    tt = TrajTrackingLQR(dt, tp, QuadraticCost(Q=Q, R=R))
+    Kt, Pt = tt.perform_dlqr_recursion(Target)
+    idx = [int(np.argmin(np.linalg.norm(model['q'] - xi[r:], axis=1))) for xi in np.asarray(Target.x)]
+    Po = Q.copy()
+    for k in range(len(Kt) - 1, -1, -1):
+        A, B = Ad[idx[k]], Bd[idx[k]]
+        Kk = -np.linalg.solve(R + B.T @ Po @ B, B.T @ Po @ A)
+        close(Kt[k], Kk, 1e-8)
+        Acl = A + B @ Kk
+        Po = Q + Kk.T @ R @ Kk + Acl.T @ Po @ Acl
+
+
 def _dare_case(n, m, rho, rank_q, seed):
     rng = np.random.default_rng(seed)
     V = rng.standard_normal((n, n))
