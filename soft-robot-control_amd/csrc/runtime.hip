@@ -104,7 +104,7 @@ int srh_release_cached(void) {
 }
 
 const char *srh_last_error(void) { return srh::g_err; }
-int srh_version(void) { return 100; }
+int srh_version(void) { return 200; }      // major * 100 + minor: 2.0 = the round-2 ABI (async plan solves, sekf_step_projected, sric_dare, spoly_project)
 
 int srh_device_count(int *count) {
     SRH_REQUIRE(count, "srh_device_count: null argument");
