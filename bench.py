@@ -415,6 +415,57 @@ def secondary(L, _lib, rank, world, dist):
     return out
 
 
+def rank_environments(n, port=None):
+    """The environment of each of the n rank processes (one per GPU of this node, rendezvous on 127.0.0.1)."""
+    if port is None:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+    envs = []
+    for rk in range(n):
+        envs.append({'RANK': str(rk), 'LOCAL_RANK': str(rk), 'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n),
+                     'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    return envs
+
+
+def launch_ranks(n, argv, dry, cmd=None):
+    """Start n child processes of this file, one rank per GPU, and wait for them.  The parent never initialises a GPU
+    (a process that has must not exec / fork GPU work); rank 0's stdout (the ONE JSON line) is passed through."""
+    import subprocess
+    if n < 1:
+        print('bench.py: --gpus must be >= 1', file=sys.stderr)
+        return 2
+    envs = rank_environments(n)
+    if cmd is None:
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    if dry:
+        print(json.dumps({'dry_launch': True, 'n_ranks': n, 'cmd': cmd, 'env': envs}))
+        return 0
+    procs = []
+    for e in envs:
+        procs.append(subprocess.Popen(cmd, env=dict(os.environ, **e), stdout=None if e['RANK'] == '0' else subprocess.DEVNULL))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            r = p.poll()
+            if r is None:
+                continue
+            procs.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+                deadline = time.time() + 30.0      # a rank died: the others would wait in a collective for ever
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()                           # exact PIDs of our own children
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -427,7 +478,18 @@ def main():
                     help='GuSTO iteration cap per solve (the reference default is 500; its real-time drivers use 0-5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary metrics (iLQR C3, Gramian C4)')
+    ap.add_argument('--dry-launch', action='store_true',
+                    help='with --gpus N > 1 and no WORLD_SIZE: print the per-rank environments / command lines and exit (no GPU call)')
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` on its own (no torch.distributed.run around it): this process is only a launcher.  It
+    # starts N fresh rank processes of this file BEFORE anything touches a GPU (no torch.cuda.*, no _lib.lib()), waits,
+    # and exits non-zero if any rank failed.  Under torch.distributed.run (WORLD_SIZE set) it is a rank already.
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.dry_launch):
+        raise SystemExit(launch_ranks(args.gpus, [a for a in sys.argv[1:] if a != '--dry-launch'], args.dry_launch))
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != args.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%s: the launcher\'s world size is used' % (args.gpus, os.environ['WORLD_SIZE']),
+              file=sys.stderr)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -38,3 +38,37 @@ def test_bench_defaults_are_single_gpu_and_short():
     assert "'--gpus', type=int, default=1" in src
     m = re.search(r"'--steps', type=int, default=(\d+)", src)
     assert m and int(m.group(1)) <= 10
+
+
+def test_gpus_flag_starts_one_rank_per_gpu_dry_launch():
+    """`python bench.py --gpus 2` without torch.distributed.run around it must start 2 ranks:
+    --dry-launch prints what would be started, without touching a GPU."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--dry-launch'],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d['n_ranks'] == 2 and len(d['env']) == 2
+    assert [e['RANK'] for e in d['env']] == ['0', '1'] and [e['LOCAL_RANK'] for e in d['env']] == ['0', '1']
+    assert all(e['WORLD_SIZE'] == '2' and e['MASTER_ADDR'] == '127.0.0.1' for e in d['env'])
+    assert len({e['MASTER_PORT'] for e in d['env']}) == 1
+    assert d['cmd'][1].endswith('bench.py') and '--dry-launch' not in d['cmd'] and d['cmd'][-4:] == ['--gpus', '2', '--steps', '3']
+
+
+def test_launcher_runs_children_and_propagates_failure():
+    """launch_ranks with a stand-in child command: every rank gets its own environment, rank 0's stdout passes through,
+    a failing rank makes the launcher's exit code non-zero."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "rc = bench.launch_ranks(3, [], False, cmd=[sys.executable, '-c', "
+            "'import os, sys; print(\"rank\", os.environ[\"RANK\"], os.environ[\"WORLD_SIZE\"]); "
+            "sys.exit(FAIL if os.environ[\"RANK\"] == \"2\" else 0)']); print('rc', rc)" % ROOT)
+    for fail, want in ((0, 0), (7, 7)):
+        out = subprocess.run([sys.executable, '-c', code.replace('FAIL', str(fail))], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.strip().splitlines()
+        assert 'rank 0 3' in lines and not any(l.startswith('rank 1') or l.startswith('rank 2') for l in lines)
+        assert lines[-1] == 'rc %d' % want
