@@ -44,6 +44,9 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             build()
         _lib = C.CDLL(LIB_PATH)
+        if _lib.scpu_version() < 2:          # a stale build from an earlier round
+            build()
+            _lib = C.CDLL(LIB_PATH)
     return _lib
 
 
@@ -77,21 +80,27 @@ def project(U, ref, X, threads=1):
     return out
 
 
+ALGO = {'riccati': 0, 'condensed': 1}
+
+
 def locp_solve(N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega, z=None, zf=None, u_des=None, Qzf=None, U=None, X=None, Xf=None,
-               x_scale=None, tr_active=True):
+               x_scale=None, tr_active=True, algo='riccati'):
+    """algo 'riccati': stage-wise Riccati interior point (oracle/riccati_ipm.py) with the trust-region prescreen;
+    'condensed': the device kernel's control flow -- condensed interior point (oracle/condensed_ipm.py) for the QP without
+    its trust-region rows, the Riccati interior point of the full QP when that minimiser leaves the trust region."""
     pr, keep = _problem(N, H, Qz, R, Qzf, U, X, Xf, x_scale, tr_active)
     Ad, Bd, dd, x0, xk, z, zf, u_des = map(_a, (Ad, Bd, dd, x0, xk, z, zf, u_des))
     n, m = Bd.shape[1], Bd.shape[2]
     x = np.empty((N + 1, n)); u = np.empty((N, m)); s = np.empty(N + 1)
     J = C.c_double(); it = C.c_int()
-    st = lib().scpu_locp_solve(C.byref(pr), _p(Ad), _p(Bd), _p(dd), _p(x0), _p(xk), C.c_double(delta), C.c_double(omega), _p(z), _p(zf),
-                               _p(u_des), _p(x), _p(u), _p(s), C.byref(J), C.byref(it))
+    st = lib().scpu_locp_solve_algo(C.byref(pr), _p(Ad), _p(Bd), _p(dd), _p(x0), _p(xk), C.c_double(delta), C.c_double(omega), _p(z),
+                                    _p(zf), _p(u_des), _p(x), _p(u), _p(s), C.byref(J), C.byref(it), C.c_int(ALGO[algo]))
     return x, u, s, J.value, dict(status=st, iters=it.value)
 
 
 def gusto_solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=None, zf=None, u_des=None, Qzf=None, U=None, X=None,
-                Xf=None, x_char=None, f_char=None, threads=1, max_trace=0, **kw):
-    """oracle.gusto.solve for a batch (leading axis) of rollouts; returns xopt, uopt, iters, trace."""
+                Xf=None, x_char=None, f_char=None, threads=1, max_trace=0, algo='riccati', **kw):
+    """oracle.gusto.solve for a batch (leading axis) of rollouts; returns xopt, uopt, iters, trace.  `algo` as locp_solve."""
     from .gusto import DEFAULTS
     par = dict(DEFAULTS); par.update(kw)
     pr, keep = _problem(N, H, Qz, R, Qzf, U, X, Xf, None, True)
@@ -109,7 +118,7 @@ def gusto_solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=None, 
     m = u_init.shape[2]
     xo = np.empty((B, N + 1, n)); uo = np.empty((B, N, m)); iters = np.empty(B, dtype=np.int32)
     trace = np.full((B, max(1, max_trace), 4), np.nan)
-    lib().scpu_gusto_solve(C.byref(mo), C.byref(pr), C.byref(gp), C.c_double(dt), C.c_int64(B), _p(x0), _p(u_init), _p(x_init), _p(z),
-                           _p(zf), _p(u_des), _p(x_char), _p(f_char), _p(xo), _p(uo), iters.ctypes.data_as(C.POINTER(C.c_int32)),
-                           _p(trace) if max_trace > 0 else None, C.c_int(max_trace), C.c_int(threads))
+    lib().scpu_gusto_solve_algo(C.byref(mo), C.byref(pr), C.byref(gp), C.c_double(dt), C.c_int64(B), _p(x0), _p(u_init), _p(x_init), _p(z),
+                                _p(zf), _p(u_des), _p(x_char), _p(f_char), _p(xo), _p(uo), iters.ctypes.data_as(C.POINTER(C.c_int32)),
+                                _p(trace) if max_trace > 0 else None, C.c_int(max_trace), C.c_int(threads), C.c_int(ALGO[algo]))
     return xo, uo, iters, trace

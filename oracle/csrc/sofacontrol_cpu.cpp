@@ -523,9 +523,480 @@ Info ipm_solve(const Problem &p, vec &x, vec &u, vec &s, double *J_out, double t
     return info;
 }
 
+
+// ------------------------------------------------------------------ condensed (output-space) interior point
+// oracle/condensed_ipm.py (newton = 'output'), i.e. the algorithm of the device kernel csrc/locp_cond.h / gusto_cond.hip:
+// the QP WITHOUT its trust-region rows with the states eliminated, Newton systems through the Woodbury form
+// K = I + Gd Gd^T (N p_o square).  Plain loops over the causal (block lower-triangular) structure of G, no BLAS.
+
+// eigen-decomposition of a small symmetric matrix (cyclic Jacobi): A = V diag(w) V^T, eigenvectors in the columns of V
+void jacobi_eig(vec A, int n, vec &w, vec &V) {
+    V.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) off += A[(size_t)a * n + b] * A[(size_t)a * n + b];
+        if (off < 1e-300) break;
+        for (int a = 0; a < n; ++a)
+            for (int b = a + 1; b < n; ++b) {
+                if (std::fabs(A[(size_t)a * n + b]) < 1e-300) continue;
+                const double th = (A[(size_t)b * n + b] - A[(size_t)a * n + a]) / (2.0 * A[(size_t)a * n + b]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; ++k) {
+                    const double ka = A[(size_t)k * n + a], kb = A[(size_t)k * n + b];
+                    A[(size_t)k * n + a] = cs * ka - sn * kb; A[(size_t)k * n + b] = sn * ka + cs * kb;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double ak = A[(size_t)a * n + k], bk = A[(size_t)b * n + k];
+                    A[(size_t)a * n + k] = cs * ak - sn * bk; A[(size_t)b * n + k] = sn * ak + cs * bk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double ka = V[(size_t)k * n + a], kb = V[(size_t)k * n + b];
+                    V[(size_t)k * n + a] = cs * ka - sn * kb; V[(size_t)k * n + b] = sn * ka + cs * kb;
+                }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = A[(size_t)i * n + i];
+}
+
+struct CondBasis {          // condensed_ipm.output_basis: rows of C_o and everything expressed in them
+    int po = 0;
+    bool ok = false;
+    vec Co, Sc, ScN, Tx, Txf;          // (po x n), (po x po), (po x po), (nX x po), (nXf x po)
+};
+
+CondBasis cond_basis(const Problem &p) {
+    const int n = p.n, nz = p.nz;
+    CondBasis cb;
+    auto sqrt_rows = [&](const double *Q) {
+        vec out;
+        if (!Q) return out;
+        vec Qs((size_t)nz * nz), w, V;
+        for (int a = 0; a < nz; ++a) for (int b = 0; b < nz; ++b) Qs[(size_t)a * nz + b] = 0.5 * (Q[(size_t)a * nz + b] + Q[(size_t)b * nz + a]);
+        jacobi_eig(Qs, nz, w, V);
+        double wmax = 0.0;
+        for (double v : w) wmax = std::max(wmax, std::fabs(v));
+        for (int e = 0; e < nz; ++e) {
+            if (!(w[e] > 1e-13 * std::max(1e-300, wmax))) continue;
+            const double sc = std::sqrt(2.0 * w[e]);
+            for (int j = 0; j < n; ++j) {
+                double v = 0.0;
+                for (int a = 0; a < nz; ++a) v += V[(size_t)a * nz + e] * p.H[(size_t)a * n + j];
+                out.push_back(sc * v);
+            }
+        }
+        return out;
+    };
+    const vec Cq = sqrt_rows(p.Qz), Cqf = sqrt_rows(p.Qzf);
+    const int ncq = (int)(Cq.size() / n), ncqf = (int)(Cqf.size() / n), rows = ncq + ncqf + p.nX + p.nXf;
+    if (rows == 0) return cb;
+    auto rowp = [&](int r) -> const double * {
+        if (r < ncq) return &Cq[(size_t)r * n];
+        r -= ncq;
+        if (r < ncqf) return &Cqf[(size_t)r * n];
+        r -= ncqf;
+        if (r < p.nX) return p.XA + (size_t)r * n;
+        return p.XfA + (size_t)(r - p.nX) * n;
+    };
+    vec Gm((size_t)n * n, 0.0), w, V;
+    for (int r = 0; r < rows; ++r) {
+        const double *row = rowp(r);
+        double nr2 = 0.0;
+        for (int j = 0; j < n; ++j) nr2 += row[j] * row[j];
+        if (nr2 <= 0.0) continue;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Gm[(size_t)i * n + j] += row[i] * row[j] / nr2;
+    }
+    jacobi_eig(Gm, n, w, V);
+    std::vector<int> ord(n);
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return w[a] > w[b]; });
+    int po = 0;
+    while (po < n && w[ord[po]] > 1e-12 * w[ord[0]] && w[ord[po]] > 0.0) ++po;
+    cb.po = po;
+    cb.Co.resize((size_t)po * n);
+    for (int a = 0; a < po; ++a) for (int j = 0; j < n; ++j) cb.Co[(size_t)a * n + j] = V[(size_t)j * n + ord[a]];
+    auto project = [&](const double *src, int nr) {
+        vec T((size_t)nr * po, 0.0);
+        for (int r = 0; r < nr; ++r)
+            for (int a = 0; a < po; ++a) {
+                double v = 0.0;
+                for (int j = 0; j < n; ++j) v += src[(size_t)r * n + j] * cb.Co[(size_t)a * n + j];
+                T[(size_t)r * po + a] = v;
+            }
+        return T;
+    };
+    const vec Tc = project(Cq.data(), ncq), Tcf = project(Cqf.data(), ncqf);
+    cb.Tx = project(p.XA, p.nX); cb.Txf = project(p.XfA, p.nXf);
+    cb.Sc.assign((size_t)po * po, 0.0); cb.ScN.assign((size_t)po * po, 0.0);
+    for (int a = 0; a < po; ++a)
+        for (int b = 0; b < po; ++b) {
+            double v = 0.0, vf = 0.0;
+            for (int r = 0; r < ncq; ++r) v += Tc[(size_t)r * po + a] * Tc[(size_t)r * po + b];
+            for (int r = 0; r < ncqf; ++r) vf += Tcf[(size_t)r * po + a] * Tcf[(size_t)r * po + b];
+            cb.Sc[(size_t)a * po + b] = v; cb.ScN[(size_t)a * po + b] = v + vf;
+        }
+    cb.ok = po >= 1 && po <= 8;
+    return cb;
+}
+
+// lower Cholesky factor of a positive SEMI-definite matrix (condensed_ipm.chol_psd): cancelled pivots get a zero column
+inline void chol_psd(double *S, int n) {
+    double dmax = 1e-300;
+    for (int i = 0; i < n; ++i) dmax = std::max(dmax, std::fabs(S[(size_t)i * n + i]));
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double v = S[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) v -= S[(size_t)i * n + k] * S[(size_t)j * n + k];
+            if (i == j) S[(size_t)i * n + i] = v > 1e-14 * dmax ? std::sqrt(v) : 0.0;
+            else S[(size_t)i * n + j] = S[(size_t)j * n + j] > 0.0 ? v / S[(size_t)j * n + j] : 0.0;
+        }
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) S[(size_t)i * n + j] = 0.0;
+}
+
+// The QP of p without its trust-region rows.  x, u, s as ipm_solve; *inside: the minimiser satisfies p's trust region.
+Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, double *J_out, bool *inside_out,
+                double tol = 1e-12, int max_iter = 60, double reg = 1e-8) {
+    const int N = p.N, n = p.n, m = p.m, nz = p.nz, nU = p.nU, nX = p.nX, nXf = p.nXf, po = cb.po;
+    const int NP = N * po, NM = N * m, ng = N * nU + N * nX + nXf;
+    auto nrx = [&](int k) { return nX + (k == N ? nXf : 0); };                  // state rows of stage k = 1..N
+    auto Trow = [&](int k, int r) { return r < nX ? &cb.Tx[(size_t)r * po] : &cb.Txf[(size_t)(r - nX) * po]; };
+    auto brow = [&](int k, int r) { return r < nX ? p.Xb[r] : p.Xfb[r - nX]; };
+    const int RX = nX + nXf;                                                     // row stride per x stage
+    // ---- condensation: free response, G (NP x NM; row (k-1) po + a, column j m + b; zero for j >= k)
+    vec xf((size_t)(N + 1) * n), yf(NP), G((size_t)NP * NM, 0.0);
+    std::copy(p.x0, p.x0 + n, xf.begin());
+    for (int k = 0; k < N; ++k) {
+        matvec(p.A[k], n, n, &xf[(size_t)k * n], &xf[(size_t)(k + 1) * n]);
+        for (int i = 0; i < n; ++i) xf[(size_t)(k + 1) * n + i] += p.d[k][i];
+    }
+    for (int k = 1; k <= N; ++k) matvec(cb.Co.data(), po, n, &xf[(size_t)k * n], &yf[(size_t)(k - 1) * po]);
+    {
+        vec Psi((size_t)NP * n, 0.0), t(n);                  // rows C_o Phi(k, j+1) of stage k at (k-1) po
+        for (int j = N - 1; j >= 0; --j) {
+            for (int i = (j + 1) * po; i < NP; ++i) {         // stages k >= j+2: times A_{j+1}
+                std::fill(t.begin(), t.end(), 0.0);
+                matTvec_add(p.A[j + 1], n, n, &Psi[(size_t)i * n], t.data());
+                std::copy(t.begin(), t.end(), &Psi[(size_t)i * n]);
+            }
+            std::copy(cb.Co.begin(), cb.Co.end(), &Psi[(size_t)j * po * n]);
+            for (int i = j * po; i < NP; ++i) {
+                const double *ps = &Psi[(size_t)i * n];
+                double *g = &G[(size_t)i * NM + (size_t)j * m];
+                for (int c = 0; c < n; ++c) { const double pc = ps[c]; const double *b = p.B[j] + (size_t)c * m; for (int a = 0; a < m; ++a) g[a] += pc * b[a]; }
+            }
+        }
+    }
+    // linear cost term in output space
+    vec lin(NP, 0.0);
+    {
+        vec t(nz), g0(n);
+        for (int k = 1; k <= N; ++k) {
+            std::fill(g0.begin(), g0.end(), 0.0);
+            if (p.z) { matvec(p.Qz, nz, nz, p.z + (size_t)k * nz, t.data()); for (int i = 0; i < n; ++i) for (int a = 0; a < nz; ++a) g0[i] -= 2.0 * p.H[(size_t)a * n + i] * t[a]; }
+            if (k == N && p.Qzf && p.zf) { matvec(p.Qzf, nz, nz, p.zf, t.data()); for (int i = 0; i < n; ++i) for (int a = 0; a < nz; ++a) g0[i] -= 2.0 * p.H[(size_t)a * n + i] * t[a]; }
+            matvec(cb.Co.data(), po, n, g0.data(), &lin[(size_t)(k - 1) * po]);
+        }
+    }
+    auto jmax_of_row = [&](int i) { return i / po + 1; };       // row i = (k-1) po + a reaches the stages j < k
+    auto G_times = [&](const vec &uu, vec &yy) {                 // yy = G uu
+        for (int i = 0; i < NP; ++i) {
+            const double *g = &G[(size_t)i * NM];
+            const int ce = jmax_of_row(i) * m;
+            double sacc = 0.0;
+            for (int c = 0; c < ce; ++c) sacc += g[c] * uu[c];
+            yy[i] = sacc;
+        }
+    };
+    auto GT_add = [&](const vec &yy, vec &uu) {                  // uu += G^T yy
+        for (int i = 0; i < NP; ++i) {
+            const double *g = &G[(size_t)i * NM];
+            const int ce = jmax_of_row(i) * m;
+            const double yi = yy[i];
+            for (int c = 0; c < ce; ++c) uu[c] += g[c] * yi;
+        }
+    };
+    // ---- rows: x rows (k-1) RX + r (k = 1..N), then u rows N RX + k nU + r
+    const int NR = N * RX + N * nU;
+    vec tt(NR, 0.0), lam(NR, 0.0), rg(NR, 0.0), D(NR, 0.0), rho(NR, 0.0), rc(NR, 0.0), dtv(NR, 0.0), dl(NR, 0.0), ev(NR, 1.0), gval(NR, 0.0), aval(NR, 0.0);
+    std::vector<char> live(NR, 0);
+    for (int k = 1; k <= N; ++k) for (int r = 0; r < nrx(k); ++r) live[(size_t)(k - 1) * RX + r] = 1;
+    for (int e = N * RX; e < NR; ++e) live[e] = 1;
+    auto row_apply = [&](const vec &yy, const vec &uu, vec &out, bool with_h) {
+        for (int k = 1; k <= N; ++k)
+            for (int r = 0; r < nrx(k); ++r) {
+                const double *T = Trow(k, r);
+                double v = with_h ? -brow(k, r) : 0.0;
+                for (int a = 0; a < po; ++a) v += T[a] * yy[(size_t)(k - 1) * po + a];
+                out[(size_t)(k - 1) * RX + r] = v;
+            }
+        for (int k = 0; k < N; ++k)
+            for (int r = 0; r < nU; ++r) {
+                double v = with_h ? -p.Ub[r] : 0.0;
+                for (int a = 0; a < m; ++a) v += p.UA[(size_t)r * m + a] * uu[(size_t)k * m + a];
+                out[(size_t)N * RX + (size_t)k * nU + r] = v;
+            }
+    };
+    // total gradient wrt u of cost + rows^T w
+    vec gy(NP), gtot(NM);
+    auto grad = [&](const vec &uu, const vec &yy, const vec &w, vec &out) {
+        for (int k = 1; k <= N; ++k) {
+            const vec &S = (k == N) ? cb.ScN : cb.Sc;
+            for (int a = 0; a < po; ++a) {
+                double v = lin[(size_t)(k - 1) * po + a];
+                for (int b = 0; b < po; ++b) v += S[(size_t)a * po + b] * yy[(size_t)(k - 1) * po + b];
+                for (int r = 0; r < nrx(k); ++r) v += Trow(k, r)[a] * w[(size_t)(k - 1) * RX + r];
+                gy[(size_t)(k - 1) * po + a] = v;
+            }
+        }
+        for (int k = 0; k < N; ++k)
+            for (int a = 0; a < m; ++a) {
+                double v = 0.0;
+                for (int b = 0; b < m; ++b) v += p.Ru[(size_t)a * m + b] * (uu[(size_t)k * m + b] - (p.ud ? p.ud[(size_t)k * m + b] : 0.0));
+                for (int r = 0; r < nU; ++r) v += p.UA[(size_t)r * m + a] * w[(size_t)N * RX + (size_t)k * nU + r];
+                out[(size_t)k * m + a] = v;
+            }
+        GT_add(gy, out);
+    };
+    // ---- Newton systems  (blkdiag(Dblk) + G^T blkdiag(S) G) du = rhs  in output space
+    vec Ld((size_t)N * m * m), Ls((size_t)N * po * po), Gd((size_t)NP * NM), K((size_t)NP * NP), ks(NP), tv(NM), yv(NP), wv(NP), t2(NM);
+    auto factor = [&]() -> bool {
+        for (int k = 0; k < N; ++k) {
+            double *L = &Ld[(size_t)k * m * m];
+            for (int a = 0; a < m; ++a)
+                for (int b = 0; b < m; ++b) {
+                    double v = p.Ru[(size_t)a * m + b];
+                    for (int r = 0; r < nU; ++r) v += p.UA[(size_t)r * m + a] * D[(size_t)N * RX + (size_t)k * nU + r] * p.UA[(size_t)r * m + b];
+                    L[(size_t)a * m + b] = v;
+                }
+            if (!cholesky(L, m)) return false;
+        }
+        for (int k = 1; k <= N; ++k) {
+            double *L = &Ls[(size_t)(k - 1) * po * po];
+            const vec &S = (k == N) ? cb.ScN : cb.Sc;
+            for (int a = 0; a < po; ++a)
+                for (int b = 0; b < po; ++b) {
+                    double v = S[(size_t)a * po + b];
+                    for (int r = 0; r < nrx(k); ++r) v += Trow(k, r)[a] * D[(size_t)(k - 1) * RX + r] * Trow(k, r)[b];
+                    L[(size_t)a * po + b] = v;
+                }
+            chol_psd(L, po);
+        }
+        // Gd = blkdiag(Ls^T) G blkdiag(Ld^-T): row mixing per output stage, forward substitution per input block
+        vec tmp(m);
+        for (int k = 1; k <= N; ++k) {
+            const double *L = &Ls[(size_t)(k - 1) * po * po];
+            const int ce = k * m;
+            for (int a = 0; a < po; ++a) {
+                double *out = &Gd[((size_t)(k - 1) * po + a) * NM];
+                std::fill(out, out + NM, 0.0);
+                for (int a2 = a; a2 < po; ++a2) {            // (Ls^T)[a][a2] = Ls[a2][a]
+                    const double l = L[(size_t)a2 * po + a];
+                    if (l == 0.0) continue;
+                    const double *g = &G[((size_t)(k - 1) * po + a2) * NM];
+                    for (int c = 0; c < ce; ++c) out[c] += l * g[c];
+                }
+                for (int j = 0; j < k; ++j) {                // row block j: solve Ld_j y = block^T
+                    const double *Lj = &Ld[(size_t)j * m * m];
+                    double *blk = out + (size_t)j * m;
+                    for (int i = 0; i < m; ++i) {
+                        double v = blk[i];
+                        for (int q = 0; q < i; ++q) v -= Lj[(size_t)i * m + q] * tmp[q];
+                        tmp[i] = v / Lj[(size_t)i * m + i];
+                    }
+                    for (int i = 0; i < m; ++i) blk[i] = tmp[i];
+                }
+            }
+        }
+        for (int i = 0; i < NP; ++i) {
+            const double *gi = &Gd[(size_t)i * NM];
+            for (int j = 0; j <= i; ++j) {
+                const double *gj = &Gd[(size_t)j * NM];
+                const int ce = jmax_of_row(j) * m;           // the shorter of the two rows (j <= i)
+                double v = (i == j) ? 1.0 : 0.0;
+                for (int c = 0; c < ce; ++c) v += gi[c] * gj[c];
+                K[(size_t)i * NP + j] = v;
+            }
+        }
+        for (int i = 0; i < NP; ++i) ks[i] = 1.0 / std::sqrt(K[(size_t)i * NP + i]);
+        for (int i = 0; i < NP; ++i) for (int j = 0; j <= i; ++j) K[(size_t)i * NP + j] *= ks[i] * ks[j];
+        return cholesky(K.data(), NP);
+    };
+    auto Dinv = [&](vec &v) {
+        for (int k = 0; k < N; ++k) {
+            const double *L = &Ld[(size_t)k * m * m];
+            double *b = &v[(size_t)k * m];
+            for (int i = 0; i < m; ++i) { double s1 = b[i]; for (int q = 0; q < i; ++q) s1 -= L[(size_t)i * m + q] * b[q]; b[i] = s1 / L[(size_t)i * m + i]; }
+            for (int i = m - 1; i >= 0; --i) { double s1 = b[i]; for (int q = i + 1; q < m; ++q) s1 -= L[(size_t)q * m + i] * b[q]; b[i] = s1 / L[(size_t)i * m + i]; }
+        }
+    };
+    auto Ls_apply = [&](vec &v, bool transpose) {            // per stage: v_k <- Ls_k v_k or Ls_k^T v_k
+        vec o(po);
+        for (int k = 0; k < N; ++k) {
+            const double *L = &Ls[(size_t)k * po * po];
+            double *b = &v[(size_t)k * po];
+            for (int a = 0; a < po; ++a) {
+                double s1 = 0.0;
+                if (transpose) { for (int c = a; c < po; ++c) s1 += L[(size_t)c * po + a] * b[c]; }
+                else { for (int c = 0; c <= a; ++c) s1 += L[(size_t)a * po + c] * b[c]; }
+                o[a] = s1;
+            }
+            for (int a = 0; a < po; ++a) b[a] = o[a];
+        }
+    };
+    // du = M^-1 rhs:  t = D^-1 rhs;  K v = Ls^T G t;  du = t - D^-1 G^T Ls v
+    auto newton_solve = [&](const vec &rhs, vec &duo) {
+        tv = rhs;
+        Dinv(tv);
+        G_times(tv, yv);
+        Ls_apply(yv, true);
+        for (int i = 0; i < NP; ++i) yv[i] *= ks[i];
+        for (int i = 0; i < NP; ++i) { double s1 = yv[i]; for (int q = 0; q < i; ++q) s1 -= K[(size_t)i * NP + q] * yv[q]; yv[i] = s1 / K[(size_t)i * NP + i]; }
+        for (int i = NP - 1; i >= 0; --i) { double s1 = yv[i]; for (int q = i + 1; q < NP; ++q) s1 -= K[(size_t)q * NP + i] * yv[q]; yv[i] = s1 / K[(size_t)i * NP + i]; }
+        for (int i = 0; i < NP; ++i) yv[i] *= ks[i];
+        Ls_apply(yv, false);
+        std::fill(t2.begin(), t2.end(), 0.0);
+        GT_add(yv, t2);
+        Dinv(t2);
+        for (int e = 0; e < NM; ++e) duo[e] = tv[e] - t2[e];
+    };
+    auto finish = [&](int it, int status, double mu) {
+        x.assign((size_t)(N + 1) * n, 0.0);
+        std::copy(p.x0, p.x0 + n, x.begin());
+        vec t(n);
+        for (int k = 0; k < N; ++k) {
+            matvec(p.A[k], n, n, &x[(size_t)k * n], t.data());
+            for (int i = 0; i < n; ++i) {
+                double sB = 0.0;
+                for (int a = 0; a < m; ++a) sB += p.B[k][(size_t)i * m + a] * u[(size_t)k * m + a];
+                x[(size_t)(k + 1) * n + i] = t[i] + sB + p.d[k][i];
+            }
+        }
+        s.assign(N + 1, 0.0);
+        Problem q = p;
+        q.tr = false;
+        if (J_out) *J_out = objective(q, x, u, s);
+        bool inside = true;
+        if (p.tr) {
+            double md = 0.0;
+            for (int k = 1; k <= N; ++k) for (int i = 0; i < n; ++i) md = std::max(md, std::fabs(p.xs[i] * (x[(size_t)k * n + i] - p.xk[(size_t)k * n + i])));
+            inside = md <= p.delta;
+        }
+        if (inside_out) *inside_out = inside;
+        return Info{it, status, mu};
+    };
+    u.assign(NM, 0.0);
+    vec y = yf, du(NM), dy(NP), rhs(NM);
+    auto neg_grad = [&](const vec &w) { grad(u, y, w, gtot); for (int e = 0; e < NM; ++e) rhs[e] = -gtot[e]; };
+    if (ng == 0) {
+        if (!factor()) return finish(0, 2, 0.0);
+        neg_grad(rho);
+        newton_solve(rhs, du);
+        for (int e = 0; e < NM; ++e) u[e] += du[e];
+        return finish(0, 0, 0.0);
+    }
+    // starting point: unit weights, gradient shifts = row values
+    row_apply(y, u, gval, true);
+    for (int e = 0; e < NR; ++e) { D[e] = live[e] ? 1.0 : 0.0; rho[e] = live[e] ? gval[e] : 0.0; }
+    if (!factor()) return finish(0, 2, 0.0);
+    neg_grad(rho);
+    newton_solve(rhs, du);
+    for (int e = 0; e < NM; ++e) u[e] += du[e];
+    G_times(u, y);
+    for (int i = 0; i < NP; ++i) y[i] += yf[i];
+    row_apply(y, u, gval, true);
+    double zmin = INF, zmax = -INF;
+    for (int e = 0; e < NR; ++e) if (live[e]) { zmin = std::min(zmin, gval[e]); zmax = std::max(zmax, gval[e]); }
+    const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
+    for (int e = 0; e < NR; ++e) if (live[e]) { tt[e] = -gval[e] + sh_t; lam[e] = gval[e] + sh_l; }
+    vec g1(n), zero(n, 0.0);
+    grad_x(p, 1, zero.data(), g1.data());
+    double scale_d = std::max(1.0, p.omega), scale_p = std::max(1.0, std::fabs(p.delta));
+    for (double g : g1) scale_d = std::max(scale_d, std::fabs(g));
+    for (int r = 0; r < nU; ++r) scale_p = std::max(scale_p, std::fabs(p.Ub[r]));
+    const double dreg = reg / scale_d;
+    int status = 1, it = 0;
+    double mu = 0.0;
+    auto maxstep = [&]() {
+        double a = INF;
+        for (int e = 0; e < NR; ++e) if (live[e]) {
+            if (dtv[e] < 0.0) a = std::min(a, -tt[e] / dtv[e]);
+            if (dl[e] < 0.0) a = std::min(a, -lam[e] / dl[e]);
+        }
+        return a;
+    };
+    for (it = 0; it < max_iter; ++it) {
+        row_apply(y, u, gval, true);
+        double musum = 0.0, rp = 0.0;
+        for (int e = 0; e < NR; ++e) if (live[e]) {
+            rg[e] = gval[e] + tt[e];
+            musum += lam[e] * tt[e];
+            ev[e] = tt[e] + dreg * lam[e];
+            D[e] = lam[e] / ev[e];
+            rho[e] = lam[e] + (lam[e] * rg[e] - lam[e] * tt[e]) / ev[e];
+            rp = std::max(rp, std::fabs(rg[e]));
+        }
+        mu = musum / ng;
+        grad(u, y, lam, gtot);
+        double rd = 0.0;
+        for (int e = 0; e < NM; ++e) rd = std::max(rd, std::fabs(gtot[e]));
+        if (rd <= std::max(tol, 1e-9) * scale_d && rp <= std::max(tol, 1e-9) * scale_p && mu <= tol) { status = 0; break; }
+        if (!factor()) { status = 2; break; }
+        neg_grad(rho);
+        newton_solve(rhs, du);
+        G_times(du, dy);
+        row_apply(dy, du, aval, false);
+        for (int e = 0; e < NR; ++e) if (live[e]) {
+            dl[e] = (-lam[e] * tt[e] + lam[e] * (rg[e] + aval[e])) / ev[e];
+            dtv[e] = -rg[e] - aval[e] + dreg * dl[e];
+        }
+        const double a_aff = std::min(1.0, maxstep());
+        double ma = 0.0;
+        for (int e = 0; e < NR; ++e) if (live[e]) ma += (lam[e] + a_aff * dl[e]) * (tt[e] + a_aff * dtv[e]);
+        const double mu_aff = ma / ng;
+        const double sigma = mu > 0.0 ? std::pow(mu_aff / mu, 3.0) : 0.0;
+        for (int e = 0; e < NR; ++e) if (live[e]) {
+            rc[e] = lam[e] * tt[e] + dtv[e] * dl[e] - sigma * mu;
+            rho[e] = lam[e] + (lam[e] * rg[e] - rc[e]) / ev[e];
+        }
+        neg_grad(rho);
+        newton_solve(rhs, du);
+        G_times(du, dy);
+        row_apply(dy, du, aval, false);
+        for (int e = 0; e < NR; ++e) if (live[e]) {
+            dl[e] = (-rc[e] + lam[e] * (rg[e] + aval[e])) / ev[e];
+            dtv[e] = -rg[e] - aval[e] + dreg * dl[e];
+        }
+        const double a = std::min(1.0, 0.99 * maxstep());
+        for (int e = 0; e < NM; ++e) u[e] += a * du[e];
+        for (int i = 0; i < NP; ++i) y[i] += a * dy[i];
+        for (int e = 0; e < NR; ++e) if (live[e]) { tt[e] += a * dtv[e]; lam[e] += a * dl[e]; }
+        if (!std::isfinite(mu)) { status = 2; break; }
+    }
+    return finish(it, status, mu);
+}
+
 // The QP with the device kernel's control flow: without the trust-region rows first; the full QP only if that
 // minimiser leaves the trust region (dropping satisfied constraints cannot change an optimum).
-Info qp_solve(Problem &p, vec &x, vec &u, vec &s, double *J) {
+// algo 0: stage-wise Riccati interior point throughout.  algo 1: what the device kernel does -- the condensed interior point
+// for the QP without its trust-region rows (accepted when it converges inside the trust region), the Riccati interior point
+// of the full QP otherwise.
+Info qp_solve(Problem &p, vec &x, vec &u, vec &s, double *J, int algo = 0, const CondBasis *cb = nullptr) {
+    auto s0 = [&]() {
+        double v = 0.0;
+        for (int i = 0; i < p.n; ++i) v = std::max(v, std::fabs(p.xs[i] * (p.x0[i] - p.xk[i])));
+        return std::max(0.0, v - p.delta);
+    };
+    if (algo == 1 && cb && cb->ok) {
+        bool inside = true;
+        Info a = cond_solve(p, *cb, x, u, s, J, &inside);
+        if (a.status == 0 && inside) {
+            if (p.tr) { s[0] = s0(); if (J) *J += p.omega * s[0]; }
+            return a;
+        }
+        return ipm_solve(p, x, u, s, J);
+    }
     if (p.tr) {
         Problem q = p;
         q.tr = false;
@@ -535,10 +1006,8 @@ Info qp_solve(Problem &p, vec &x, vec &u, vec &s, double *J) {
             for (int k = 1; k <= p.N; ++k)
                 for (int i = 0; i < p.n; ++i) md = std::max(md, std::fabs(p.xs[i] * (x[(size_t)k * p.n + i] - p.xk[(size_t)k * p.n + i])));
             if (md <= p.delta) {
-                double v = 0.0;
-                for (int i = 0; i < p.n; ++i) v = std::max(v, std::fabs(p.xs[i] * (p.x0[i] - p.xk[i])));
                 s.assign(p.N + 1, 0.0);
-                s[0] = std::max(0.0, v - p.delta);
+                s[0] = s0();
                 if (J) *J += p.omega * s[0];
                 return a;
             }
@@ -551,7 +1020,7 @@ struct GustoPar { double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, om
 
 // one rollout: oracle/gusto.py _loop with the nearest-point TPWL model.  Returns the number of SCP iterations.
 int gusto_one(const Model &M, Problem base, const GustoPar &par, double dt, const double *fs, const double *x0, const double *u_init,
-              const double *x_init, double *xopt, double *uopt, double *trace, int max_trace) {
+              const double *x_init, double *xopt, double *uopt, double *trace, int max_trace, int algo = 0, const CondBasis *cb = nullptr) {
     const int N = base.N, n = base.n, m = base.m;
     vec xk(x_init, x_init + (size_t)(N + 1) * n), uk(u_init, u_init + (size_t)N * m);
     std::vector<int> idx(N), idx2(N);
@@ -567,7 +1036,7 @@ int gusto_one(const Model &M, Problem base, const GustoPar &par, double dt, cons
         p.A.resize(N); p.B.resize(N); p.d.resize(N);
         for (int k = 0; k < N; ++k) { p.A[k] = M.Ad + (size_t)idx[k] * n * n; p.B[k] = M.Bd + (size_t)idx[k] * n * m; p.d[k] = M.dd + (size_t)idx[k] * n; }
         double J = 0.0;
-        const Info inf = qp_solve(p, x, u, s, &J);
+        const Info inf = qp_solve(p, x, u, s, &J, algo, cb);
         if (inf.status != 0) break;
         double md = 0.0;
         for (int k = 0; k <= N; ++k) for (int i = 0; i < n; ++i) md = std::max(md, std::fabs(p.xs[i] * (x[(size_t)k * n + i] - xk[(size_t)k * n + i])));
@@ -664,7 +1133,7 @@ struct scpu_problem {       // mirrors slocp_problem (include/sofacontrol_hip.h)
 struct scpu_model { int P, r, m; double w_q, w_v; const double *q, *v, *Ac, *Bc, *dc, *Ad, *Bd, *dd; };
 struct scpu_gusto_params { double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh; int max_gusto_iters; };
 
-int scpu_version(void) { return 1; }
+int scpu_version(void) { return 2; }
 
 // out (B x r) = (X (B x n_f) - ref) U (n_f x r), rows split over `threads`
 int scpu_project(const double *U, int64_t n_f, int r, const double *ref, const double *X, int64_t B, double *out, int threads) {
@@ -694,9 +1163,10 @@ static Problem make_problem(const scpu_problem *pr, const vec &ones) {
 }
 
 // one QP (LOCP.update + solve): per-stage Ad (N x n x n), Bd, dd given explicitly.  status 0 = optimal.
-int scpu_locp_solve(const scpu_problem *pr, const double *Ad, const double *Bd, const double *dd, const double *x0, const double *xk,
-                    double delta, double omega, const double *z, const double *zf, const double *u_des, double *x, double *u,
-                    double *s, double *J, int *iters) {
+// algo: 0 Riccati interior point (with the trust-region prescreen), 1 condensed interior point first (as the device kernel).
+int scpu_locp_solve_algo(const scpu_problem *pr, const double *Ad, const double *Bd, const double *dd, const double *x0, const double *xk,
+                         double delta, double omega, const double *z, const double *zf, const double *u_des, double *x, double *u,
+                         double *s, double *J, int *iters, int algo) {
     vec ones(pr->n_x, 1.0);
     Problem p = make_problem(pr, ones);
     const int N = p.N, n = p.n, m = p.m;
@@ -705,19 +1175,26 @@ int scpu_locp_solve(const scpu_problem *pr, const double *Ad, const double *Bd, 
     p.x0 = x0; p.xk = xk; p.z = z; p.zf = zf; p.ud = u_des; p.delta = delta; p.omega = omega;
     vec xv, uv, sv;
     double Jv = 0.0;
-    const Info inf = qp_solve(p, xv, uv, sv, &Jv);
+    CondBasis cb;
+    if (algo == 1) cb = cond_basis(p);
+    const Info inf = qp_solve(p, xv, uv, sv, &Jv, algo, &cb);
     std::copy(xv.begin(), xv.end(), x); std::copy(uv.begin(), uv.end(), u);
     if (s) std::copy(sv.begin(), sv.end(), s);
     if (J) *J = Jv;
     if (iters) *iters = inf.iters;
     return inf.status;
 }
+int scpu_locp_solve(const scpu_problem *pr, const double *Ad, const double *Bd, const double *dd, const double *x0, const double *xk,
+                    double delta, double omega, const double *z, const double *zf, const double *u_des, double *x, double *u,
+                    double *s, double *J, int *iters) {
+    return scpu_locp_solve_algo(pr, Ad, Bd, dd, x0, xk, delta, omega, z, zf, u_des, x, u, s, J, iters, 0);
+}
 
 // GuSTO.solve for `batch` independent rollouts, one per thread at a time.  iters (batch): SCP iterations per rollout.
-int scpu_gusto_solve(const scpu_model *mo, const scpu_problem *pr, const scpu_gusto_params *gp, double dt, int64_t batch,
-                     const double *x0, const double *u_init, const double *x_init, const double *z, const double *zf,
-                     const double *u_des, const double *x_char, const double *f_char, double *xopt, double *uopt, int32_t *iters,
-                     double *trace, int max_trace, int threads) {
+int scpu_gusto_solve_algo(const scpu_model *mo, const scpu_problem *pr, const scpu_gusto_params *gp, double dt, int64_t batch,
+                          const double *x0, const double *u_init, const double *x_init, const double *z, const double *zf,
+                          const double *u_des, const double *x_char, const double *f_char, double *xopt, double *uopt, int32_t *iters,
+                          double *trace, int max_trace, int threads, int algo) {
     const int n = pr->n_x, m = pr->n_u, N = pr->N, nz = pr->n_z;
     vec xs(n, 1.0), fs(n, 1.0);
     if (x_char) for (int i = 0; i < n; ++i) xs[i] = 1.0 / std::fabs(x_char[i]);
@@ -728,15 +1205,24 @@ int scpu_gusto_solve(const scpu_model *mo, const scpu_problem *pr, const scpu_gu
     const Problem base = make_problem(&p2, ones);
     Model M{mo->P, mo->r, 2 * mo->r, mo->m, mo->w_q, mo->w_v, mo->q, mo->v, mo->Ac, mo->Bc, mo->dc, mo->Ad, mo->Bd, mo->dd};
     GustoPar par{gp->delta0, gp->omega0, gp->rho, gp->beta_fail, gp->gamma_fail, gp->epsilon, gp->omega_max, gp->convg_thresh, gp->max_gusto_iters};
+    CondBasis cb;
+    if (algo == 1) cb = cond_basis(base);
     parallel_for(batch, threads, [&](int64_t b) {
         Problem pb = base;
         pb.z = z ? z + (size_t)b * (N + 1) * nz : nullptr;
         pb.zf = zf ? zf + (size_t)b * nz : nullptr;
         pb.ud = u_des ? u_des + (size_t)b * N * m : nullptr;
         iters[b] = gusto_one(M, pb, par, dt, fs.data(), x0 + (size_t)b * n, u_init + (size_t)b * N * m, x_init + (size_t)b * (N + 1) * n,
-                             xopt + (size_t)b * (N + 1) * n, uopt + (size_t)b * N * m, trace ? trace + (size_t)b * max_trace * 4 : nullptr, max_trace);
+                             xopt + (size_t)b * (N + 1) * n, uopt + (size_t)b * N * m, trace ? trace + (size_t)b * max_trace * 4 : nullptr, max_trace, algo, &cb);
     });
     return 0;
+}
+int scpu_gusto_solve(const scpu_model *mo, const scpu_problem *pr, const scpu_gusto_params *gp, double dt, int64_t batch,
+                     const double *x0, const double *u_init, const double *x_init, const double *z, const double *zf,
+                     const double *u_des, const double *x_char, const double *f_char, double *xopt, double *uopt, int32_t *iters,
+                     double *trace, int max_trace, int threads) {
+    return scpu_gusto_solve_algo(mo, pr, gp, dt, batch, x0, u_init, x_init, z, zf, u_des, x_char, f_char, xopt, uopt, iters, trace,
+                                 max_trace, threads, 0);
 }
 
 }  // extern "C"

@@ -3,7 +3,7 @@ projection, the stage-structured interior point on the seeded QPs, the GuSTO loo
 import numpy as np
 import pytest
 
-from oracle import cpu_twin, gusto as ogusto, locp as olocp, pod as opod, riccati_ipm as ripm, tpwl as otpwl
+from oracle import condensed_ipm as cipm, cpu_twin, gusto as ogusto, locp as olocp, pod as opod, riccati_ipm as ripm, tpwl as otpwl
 from qp_cases import CASES, make_case
 
 
@@ -32,6 +32,57 @@ def test_locp_matches_exact_solver(name):
     assert info['status'] == 0
     assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
     assert abs(J - olocp.objective(qp, w)) <= 1e-7 * max(1.0, abs(olocp.objective(qp, w)))
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_condensed_twin_matches_numpy_statement(name):
+    """algo='condensed' (the device kernel's control flow: condensed interior point of the QP without its trust-region rows,
+    Riccati interior point of the full QP when that minimiser leaves the trust region) against the numpy statements of the
+    same two algorithms: same interior-point iteration count, iterates to 1e-7."""
+    case, _ = make_case(**CASES[name])
+    kw = dict(case)
+    args = [kw.pop(k) for k in ('N', 'H', 'Qz', 'R', 'Ad', 'Bd', 'dd', 'x0', 'xk', 'delta', 'omega')]
+    x, u, s, J, info = cpu_twin.locp_solve(*args, **kw, algo='condensed')
+    assert info['status'] == 0
+    N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega = args
+    p = ripm.Problem(N, H, Qz, R, Ad, Bd, dd, x0, xk, delta, omega, z=kw.get('z'), zf=kw.get('zf'), u_des=kw.get('u_des'),
+                     Qzf=kw.get('Qzf'), U=kw.get('U'), X=kw.get('X'), Xf=kw.get('Xf'), x_scale=kw.get('x_scale'),
+                     tr_active=kw.get('tr_active', True))
+    xe, ue, Je, inf = cipm.solve(p)
+    if inf['status'] == 'optimal' and inf['inside']:
+        assert info['iters'] == inf['iters']
+    else:                                   # trust region active: the full QP on the Riccati path
+        xe, ue, se, Je, inf = ripm.solve(p)
+        assert info['iters'] == inf['iters']
+    assert rel(x, xe) <= 1e-7 and rel(u, ue) <= 1e-7
+
+
+def test_gusto_loop_condensed_twin_matches_riccati_twin():
+    """The two native algorithms drive the same GuSTO loop to the same iterates (what bench.py's cpu_baseline relies on)."""
+    model = otpwl.synthetic_model(4, 3, 7, seed=30)
+    model['q'] = model['q'] * 0.05
+    dt, N = 0.05, 12
+    Ad, Bd, dd = otpwl.pre_discretize(model, dt, 'zoh')
+    H = otpwl.synthetic_output_matrix(4, 6, 31)
+    Qz = np.diag([0, 0, 0, 100., 100., 0]); R = 1e-5 * np.eye(3)
+    th = np.linspace(0, 1.5, N + 1)
+    z = np.zeros((N + 1, 6)); z[:, 3] = -0.15 * np.sin(th); z[:, 4] = 0.075 * np.sin(2 * th)
+    UA = np.kron(np.eye(3), np.array([[1.], [-1.]])); Ub = np.tile([800., 0.], 3)
+    xc, fc = otpwl.characteristic_vals(model)
+    rng = np.random.default_rng(2)
+    B = 3
+    x0 = 1e-3 * rng.standard_normal((B, 8))
+    u_init = np.zeros((B, N, 3))
+    x_init = np.stack([otpwl.rollout(model, Ad, Bd, dd, x0[b], u_init[b]) for b in range(B)])
+    zb = np.stack([z * (1 + 0.2 * b) for b in range(B)])
+    out = {}
+    for algo in ('riccati', 'condensed'):
+        out[algo] = cpu_twin.gusto_solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=zb, U=(UA, Ub), x_char=xc, f_char=fc,
+                                         convg_thresh=1e-3, max_gusto_iters=8, threads=2, max_trace=16, algo=algo)
+    assert (out['riccati'][2] == out['condensed'][2]).all()
+    assert rel(out['condensed'][0], out['riccati'][0]) <= 1e-7 and rel(out['condensed'][1], out['riccati'][1]) <= 1e-7
+    k = int(out['riccati'][2].max())
+    np.testing.assert_allclose(out['condensed'][3][:, :k, :3], out['riccati'][3][:, :k, :3], rtol=1e-7)
 
 
 def test_gusto_loop_matches_numpy_loop():
