@@ -69,4 +69,12 @@ struct DevBuf {
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Dynamic LDS of a launch, as it should be REQUESTED: whole 2560-byte units (capped at the 160 KB of a CU).  The 160 KB LDS of
+// gfx950 is allocated in 1280-byte granules; a 161 568-byte request (not a multiple) was observed to end at 161 280 bytes --
+// the last ints of the kernel's carve read back as zeros and their stores were dropped (round 3, lean SCP kernels).
+inline size_t lds_request(size_t bytes) {
+    const size_t r = (bytes + 2559) / 2560 * 2560;
+    return r < (size_t)160 * 1024 ? r : (bytes > (size_t)160 * 1024 ? bytes : (size_t)160 * 1024);
+}
+
 }  // namespace srh

@@ -313,7 +313,7 @@ int srom_eigh_dev(double *G_dev, int64_t n, double *w_dev, void *stream) {
     SRH_REQUIRE(G_dev && w_dev && n > 0 && n < (1LL << 31), "srom_eigh_dev: bad argument");
     if (n <= JAC_MAX && !getenv("SRH_EIGH_ROCSOLVER")) {
         const int ne = ((int)n + 1) & ~1, ld = ne | 1;
-        const size_t lds = sizeof(double) * ((size_t)ne * ld + ne + 64) + sizeof(int) * 2 * ne + 64;
+        const size_t lds = srh::lds_request(sizeof(double) * ((size_t)ne * ld + ne + 64) + sizeof(int) * 2 * ne + 64);
         srh::DevBuf Vt, info;
         int rc;
         if ((rc = Vt.alloc(sizeof(double) * ne * ne)) || (rc = info.alloc(sizeof(int)))) return rc;

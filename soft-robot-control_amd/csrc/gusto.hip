@@ -1,26 +1,8 @@
 // GuSTO (SCP outer loop, sofacontrol/scp/gusto.py:283-487) on the device: one workgroup per rollout runs the whole
 // solve, each SCP iteration's QP through the device interior point of locp_dev.h; the resident plan API.
-#include "scp_host.h"
+#include "scp_types.h"
 
 namespace {
-
-struct GustoPar {
-    double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh, dt;
-    int max_iters, max_trace;
-};
-
-
-struct GustoBatch {
-    const double *x0, *u_init, *x_init, *z, *zf, *ud;
-    const double *fs;                   // 1/|f_char| (n)
-    double *xopt, *uopt, *zopt;
-    int32_t *iters, *status;
-    double *trace;
-    double *work;                       // per problem: [qp work | xk | uk | ints]
-    size_t work_stride;
-    const int32_t *order;               // workgroup -> rollout (longest expected solve first), or null
-    int32_t *last_iters;                // SCP iterations of this solve per rollout: the next solve's dispatch key
-};
 
 // Longest-processing-time-first dispatch: the rollouts of a receding-horizon batch need 1..max SCP iterations each
 // and a workgroup owns its CU for the whole solve, so the tail of a launch is set by whichever long solves start
@@ -63,24 +45,33 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     gptr base = (gptr)(b.work + p * b.work_stride);
     QPWork w;
     qp_carve(w, base, d);
-    gptr xk = base + qp_work_doubles(d);
-    gptr uk = xk + (size_t)(N + 1) * n;
-    gptr accb = uk + (size_t)N * m;                    // 2*N doubles: per-stage error / approx
-    giptr idx = (giptr)(accb + 2 * (size_t)N);
+    const GustoWork gw = gusto_work(d);
+    gptr xk = base + gw.xk, uk = base + gw.uk;
+    gptr accb = base + gw.acc;                         // 2*N doubles: per-stage error / approx
+    gptr rec = base + gw.rec;                          // resume record of a rollout handed over by the lean kernel
+    giptr idx = (giptr)(base + gw.idx);
     giptr idx2 = idx + N;
 
     cgptr x0 = (cgptr)(b.x0 + p * n);
-    for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = b.x_init[p * (size_t)(N + 1) * n + e];
-    for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
-    __syncthreads();
-    tpwl::nearest_many(T, xk, n, N, idx);
-    GU_LAP(0);
-
-    QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
     bool converged = false;
     int itr = 0, status = 0;
+    if (b.mode == 2) {
+        // only the rollouts a lean launch (lean.hip) could not finish: xk, uk, idx are where it left them
+        if (rec[0] != 1.0) return;
+        delta = rec[1]; omega = rec[2]; J_prev = rec[3]; d_prev = rec[4]; o_prev = rec[5]; itr = (int)rec[6];
+        __syncthreads();
+        if (tid == 0) rec[0] = 0.0;
+    } else {
+        for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = b.x_init[p * (size_t)(N + 1) * n + e];
+        for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
+        __syncthreads();
+        tpwl::nearest_many(T, xk, n, N, idx);
+    }
+    GU_LAP(0);
+
+    QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
         QPData q{x0, xk, (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr), (cgptr)(b.zf ? b.zf + p * nz : nullptr),
                  (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
@@ -257,7 +248,8 @@ struct sgusto_plan {
     srh::DevBuf fs, work, x0, u_init, x_init, z, zf, ud, xopt, uopt, zopt, iters, status, trace, order, last_iters;
     bool have_last = false;             // a previous solve left its iteration counts
     size_t work_stride = 0;
-    size_t lds = 0;
+    size_t lds = 0, lean_lds = 0;
+    bool lean = false;                  // the lean condensed kernel runs first, the fused kernel takes what it hands over
     bool has_z = false, has_zf = false, has_ud = false;
     // asynchronous requests (sgusto_plan_solve_begin / _done / _end): own stream, completion event, pinned staging
     hipStream_t astream = nullptr;
@@ -323,7 +315,7 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
                        par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace};
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
-    size_t doubles = qp_work_doubles(d) + (N + 1) * n + N * m + 2 * N + (2 * N + 1) / 2 + 8;
+    size_t doubles = gusto_work(d).end;
     doubles = (doubles + 3) & ~(size_t)3;
     d.qc_off = (long long)doubles;                 // the condensed path's block sits behind the SCP loop's own arrays
     doubles += qc_work_doubles(d);
@@ -341,6 +333,11 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
         (rc = set_lds_limit(gusto_entry(d), pl->lds))) {
         delete pl;
         return rc;
+    }
+    if (d.lean && !getenv("SRH_GUSTO_NO_LEAN")) {
+        pl->lean_lds = lean_kernel_lds_bytes(d);
+        if ((rc = lean_prepare(d, pl->lean_lds))) { delete pl; return rc; }
+        pl->lean = true;
     }
     *out = pl;
     return SRH_OK;
@@ -373,7 +370,7 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
     SRH_REQUIRE(pl && x0 && u_init && x_init && xopt && uopt && zopt && iters && status,
                 "sgusto_plan_solve_dev: null argument");
     GustoBatch b{x0, u_init, x_init, z, zf, u_des, pl->fs.as<double>(), xopt, uopt, zopt, iters, status, trace,
-                 pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>()};
+                 pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>(), 0};
     if (pl->have_last && pl->batch > 256 && !getenv("SRH_GUSTO_NO_LPT")) {      // more rollouts than CUs: order matters
         lpt_order_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pl->last_iters.as<int32_t>(), pl->batch, pl->order.as<int32_t>());
         b.order = pl->order.as<int32_t>();
@@ -381,6 +378,14 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
     pl->have_last = true;
     GustoPar par = pl->par;
     if (!trace) par.max_trace = 0;
+    if (pl->lean) {
+        // lean condensed kernel over every rollout; the fused kernel then continues the handed-over ones (its other
+        // workgroups leave at once)
+        int rc = lean_launch_gusto(pl->C.dims, pl->C.view(), pl->model->view(), par, b, (unsigned)pl->batch, pl->lean_lds, (hipStream_t)stream);
+        if (rc) return rc;
+        b.mode = 2;
+        b.order = nullptr;
+    }
     {
         const QPDims &d = pl->C.dims;
         bool launched = false;

@@ -1,0 +1,306 @@
+// The lean condensed kernels (locp_lean.h): one LOCP QP per workgroup, and the whole GuSTO loop (sofacontrol/scp/gusto.py:
+// 283-487) per workgroup around it.  A QP this path cannot finish -- interior point not converged, or its minimiser
+// outside the trust region (the full QP with its 2 n_x + 1 trust-region rows per stage is needed) -- is handed over: the
+// rollout's SCP state is written to a resume record in its work block and the fused kernel (gusto.hip, mode 2) continues it.
+#include "scp_types.h"
+
+namespace {
+
+#ifdef SRH_PROFILE
+#define GU_LAP(i) do { __syncthreads(); const long long now_ = clock64(); gup[i] += now_ - gul; gul = now_; } while (0)
+#else
+#define GU_LAP(i) ((void)0)
+#endif
+
+template <int MSEL, int NSEL>
+__global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long prof[24] = {0};
+#ifdef SRH_PROFILE
+    long long gup[8] = {0}, gul = clock64();
+#endif
+    qp::specialise<MSEL, NSEL>(d);
+    ql::Lds L;
+    ql::lds_carve(L, (lptr)smem, d, NTHREADS);
+    const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
+    const int N = d.N, n = d.n, m = d.m, nz = d.nz;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    gptr base = (gptr)(b.work + p * b.work_stride);
+    QPWork w;
+    qp_carve(w, base, d);
+    const GustoWork gw = gusto_work(d);
+    gptr xk = base + gw.xk, uk = base + gw.uk, accb = base + gw.acc, rec = base + gw.rec;
+    giptr idx = (giptr)(base + gw.idx);
+    giptr idx2 = idx + N;
+
+    cgptr x0 = (cgptr)(b.x0 + p * n);
+    for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = b.x_init[p * (size_t)(N + 1) * n + e];
+    for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
+    __syncthreads();
+    tpwl::nearest_many(T, xk, n, N, idx);
+    GU_LAP(0);
+
+    QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
+    double delta = par.delta0, omega = par.omega0;
+    double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
+    bool converged = false, handed_over = false;
+    int itr = 0, status = 0;
+    while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
+        QPData q{x0, xk, (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr), (cgptr)(b.zf ? b.zf + p * nz : nullptr),
+                 (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
+        double J;
+        int qit;
+        GU_LAP(1);
+        const int st = ql::solve_qp<MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, w, prof);
+        GU_LAP(2);
+        if (st != 0) {                               // the fused kernel takes this rollout from here
+            if (tid == 0) {
+                rec[0] = 1.0; rec[1] = delta; rec[2] = omega; rec[3] = J_prev; rec[4] = d_prev; rec[5] = o_prev; rec[6] = (double)itr;
+            }
+            handed_over = true;
+            break;
+        }
+        // trust region test (gusto.py:174-183)
+        double md = 0.0;
+        for (int e = tid; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (w.x[e] - xk[e])));
+        md = wg::reduce(md, 1, L.red);
+        const bool tr_ok = !(md - delta > par.epsilon);
+        bool new_solution = false;
+        double rho_k = -1.0;
+        const double d_cur = delta, o_cur = omega;
+        if (tr_ok) {
+            // model accuracy (gusto.py:203-223) with continuous nearest-point dynamics
+            GU_LAP(3);
+            tpwl::nearest_many(T, w.x, n, N, idx2);
+            GU_LAP(4);
+            for (int i = wave; i < N; i += nw) {
+                const size_t ia = idx[i], ib = idx2[i];
+                double e2 = 0.0, a2 = 0.0;
+                for (int r = lane; r < n; r += 64) {
+                    double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
+                    cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
+                    for (int c0 = 0; c0 < n; c0 += 8) {
+                        double av[8], anv[8], xo[8], xn[8];
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            const int cc = c0 + qq < n ? c0 + qq : n - 1;
+                            av[qq] = Ak[(size_t)cc * n + r]; anv[qq] = An[(size_t)cc * n + r];
+                            xo[qq] = xk[(size_t)i * n + cc]; xn[qq] = w.x[(size_t)i * n + cc];
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            if (c0 + qq < n) {
+                                fk = fma(av[qq], xo[qq], fk);
+                                fl = fma(av[qq], xn[qq] - xo[qq], fl);
+                                f = fma(anv[qq], xn[qq], f);
+                            }
+                        }
+                    }
+                    cgptr Bk = T.BcT + ia * m * n, Bn = T.BcT + ib * m * n;
+                    for (int c0 = 0; c0 < m; c0 += 8) {
+                        double bv[8], bnv[8], uo[8], un[8];
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            const int cc = c0 + qq < m ? c0 + qq : m - 1;
+                            bv[qq] = Bk[(size_t)cc * n + r]; bnv[qq] = Bn[(size_t)cc * n + r];
+                            uo[qq] = uk[(size_t)i * m + cc]; un[qq] = w.u[(size_t)i * m + cc];
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            if (c0 + qq < m) {
+                                fk = fma(bv[qq], uo[qq], fk);
+                                fl = fma(bv[qq], un[qq] - uo[qq], fl);
+                                f = fma(bnv[qq], un[qq], f);
+                            }
+                        }
+                    }
+                    const double fa = fk + fl;
+                    const double fsr = b.fs[r];
+                    const double de = fsr * (f - fa), da = fsr * fa;
+                    e2 = fma(de, de, e2);
+                    a2 = fma(da, da, a2);
+                }
+                e2 = wg::wave_sum(e2);
+                a2 = wg::wave_sum(a2);
+                if (lane == 0) { accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2); }
+            }
+            __syncthreads();
+            GU_LAP(5);
+            double err = 0.0, app = 0.0;      // sequential sums in stage order, as the reference loop
+            for (int i = 0; i < N; ++i) { err += accb[2 * i]; app += accb[2 * i + 1]; }
+            rho_k = err / (J + app);
+            if (rho_k > par.rho && itr != 1) {
+                delta = par.beta_fail * delta;
+            } else {
+                if (d_prev == delta && o_prev == omega && J_prev <= J) delta = par.beta_fail * delta;
+                d_prev = delta; J_prev = J; o_prev = omega;
+                // state-constraint violation (gusto.py:185-201): all k = 0..N
+                double viol = 0.0;
+                if (d.nX > 0) {
+                    for (int k = tid; k <= N; k += nt) {
+                        double v2 = 0.0;
+                        for (int r = 0; r < d.nX; ++r) {
+                            double v = -c.Xb[r];
+                            for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], w.x[(size_t)k * n + j], v);
+                            v = fmax(v, 0.0);
+                            v2 = fma(v, v, v2);
+                        }
+                        viol = fmax(viol, sqrt(v2));
+                    }
+                    viol = wg::reduce(viol, 1, L.red);
+                }
+                const bool X_ok = !(viol > par.epsilon);
+                if (!X_ok) omega = par.gamma_fail * omega;
+                // convergence (gusto.py:150-161)
+                double ds = 0.0;
+                for (int k = wave; k <= N; k += nw) {
+                    double v2 = 0.0;
+                    for (int j = lane; j < n; j += 64) {
+                        const double e = c.xs[j] * (w.x[(size_t)k * n + j] - xk[(size_t)k * n + j]);
+                        v2 = fma(e, e, v2);
+                    }
+                    v2 = wg::wave_sum(v2);
+                    if (lane == 0) ds += sqrt(v2);
+                }
+                ds = wg::reduce(ds, 0, L.red);
+                const double dsol = (1.0 / N) * ((1.0 / n) * ds);
+                converged = (dsol <= par.convg_thresh) && X_ok;
+                new_solution = true;
+            }
+        } else {
+            omega = par.gamma_fail * omega;
+        }
+        if (b.trace && itr < par.max_trace && tid == 0) {
+            double *tr = b.trace + (p * par.max_trace + itr) * 4;
+            tr[0] = J; tr[1] = d_cur; tr[2] = o_cur; tr[3] = rho_k;
+        }
+        ++itr;
+        GU_LAP(6);
+        if (new_solution) {
+            __syncthreads();
+            for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = w.x[e];
+            for (int e = tid; e < N * m; e += nt) uk[e] = w.u[e];
+            __syncthreads();
+            if (par.max_iters >= 1) tpwl::nearest_many(T, xk, n, N, idx);
+        }
+        GU_LAP(7);
+    }
+#ifdef SRH_PROFILE
+    if (tid == 0 && blockIdx.x == 0) {
+        printf("lean gusto clocks (%d iterations): init+nearest %lld loop-top %lld qp %lld tr-test %lld nearest(new) %lld accuracy %lld tests %lld accept+nearest %lld\n",
+               itr, gup[0], gup[1], gup[2], gup[3], gup[4], gup[5], gup[6], gup[7]);
+        printf("lean qp laps: setup+rollout %lld rows %lld condense %lld stage-factors %lld gram %lld cholesky %lld grad+newton %lld steps %lld\n",
+               prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6], prof[7]);
+        printf("lean newton laps: gradients %lld gT(1) %lld rhs+dinv %lld g(1) %lld k_solve %lld gT(2) %lld du %lld g(2) %lld\n",
+               prof[8], prof[9], prof[10], prof[11], prof[12], prof[13], prof[14], prof[15]);
+    }
+#endif
+    if (handed_over) {
+        if (tid == 0) { b.iters[p] = itr; b.status[p] = LEAN_PENDING; }
+        return;
+    }
+    if (status == 0) {
+        if (omega > par.omega_max) status = 2;
+        else if (itr - 1 > par.max_iters) status = 3;
+    }
+    __syncthreads();
+    for (int e = tid; e < (N + 1) * n; e += nt) b.xopt[p * (size_t)(N + 1) * n + e] = xk[e];
+    for (int e = tid; e < N * m; e += nt) b.uopt[p * (size_t)N * m + e] = uk[e];
+    for (int e = tid; e < (N + 1) * nz; e += nt) {
+        const int k = e / nz, a = e - k * nz;
+        double v = 0.0;
+        for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], xk[(size_t)k * n + j], v);
+        b.zopt[p * (size_t)(N + 1) * nz + e] = v;
+    }
+    if (tid == 0) { rec[0] = 0.0; b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; }
+}
+
+template <int MSEL, int NSEL>
+__global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c, LocpBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long prof[24] = {0};
+    qp::specialise<MSEL, NSEL>(d);
+    ql::Lds L;
+    ql::lds_carve(L, (lptr)smem, d, NTHREADS);
+#ifdef QL_POISON
+    {   // debug build: every LDS word starts as a NaN, the problem's work block as NaNs too
+        const size_t total = ql::lds_doubles(d, NTHREADS, d.lean_j0);
+#if QL_POISON == 1
+        const double fill = __longlong_as_double(0x7ff8dead00000000LL);
+#elif QL_POISON == 2
+        const double fill = 1e30;
+#else
+        const double fill = 0.0;
+#endif
+#if QL_POISON != 4
+        for (size_t e = threadIdx.x; e < total; e += blockDim.x) ((lptr)smem)[e] = fill;
+#endif
+#if QL_POISON == 1 || QL_POISON == 2
+        for (size_t e = threadIdx.x; e < b.work_stride; e += blockDim.x) b.work[blockIdx.x * b.work_stride + e] = fill;
+#endif
+        __syncthreads();
+    }
+#endif
+    const size_t p = blockIdx.x;
+    const size_t N = d.N, n = d.n, m = d.m;
+    QPWork w;
+    gptr wbase = (gptr)(b.work + p * b.work_stride);
+    QPDyn dyn{(cgptr)(b.Ad + p * N * n * n), (cgptr)(b.AdT + p * N * n * n), (cgptr)(b.Bd + p * N * n * m),
+              (cgptr)(b.BdT + p * N * n * m), (cgptr)(b.dd + p * N * n), (cgiptr)nullptr};
+    QPData q{(cgptr)(b.x0 + p * n), (cgptr)(b.xk + p * (N + 1) * n), (cgptr)(b.z ? b.z + p * (N + 1) * d.nz : nullptr),
+             (cgptr)(b.zf ? b.zf + p * d.nz : nullptr), (cgptr)(b.ud ? b.ud + p * N * m : nullptr), b.delta[p], b.omega[p],
+             (gptr)((b.dbg && p == 0) ? b.dbg : nullptr)};
+    double J = 0.0;
+    int it = 0;
+    const int st = ql::solve_qp<MSEL, NSEL>(d, c, dyn, q, wbase, L, &J, &it, w, prof);
+    if (q.dbg && threadIdx.x == 0) {
+        q.dbg[8 * 61] = 2.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; q.dbg[8 * 61 + 3] = st == 100 ? 0.0 : 1.0;
+#ifdef SRH_PROFILE
+        for (int i = 0; i < 8; ++i) { q.dbg[8 * 60 + i] = (double)prof[i]; q.dbg[8 * 59 + i] = (double)prof[8 + i]; }
+#endif
+    }
+    if (st != 0) {
+        if (threadIdx.x == 0) { b.status[p] = LEAN_PENDING; b.iters[p] = it; }
+        return;
+    }
+    for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
+    for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
+    for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
+    if (threadIdx.x == 0) { b.J[p] = J; b.status[p] = 0; b.iters[p] = it; }
+}
+
+// instantiated shapes: the reference's 4- and 8-cable robots, n_x fixed for the benchmark's r = 30 next to any n_x <= 64
+#define SRH_LEAN_VARIANTS(X) X(4, 60) X(8, 60) X(4, 0) X(8, 0)
+inline bool lean_matches(const QPDims &d, int msel, int nsel) { return d.m == msel && (nsel == 0 || d.n == nsel); }
+
+}  // namespace
+
+int lean_prepare(const QPDims &d, size_t lds) {
+    SRH_REQUIRE(lds <= 160 * 1024, "lean kernels: %zu bytes of LDS needed, 160 KiB available", lds);
+#define X(M, NX) if (lean_matches(d, M, NX)) { \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_lean_kernel<M, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)locp_lean_kernel<M, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        return SRH_OK; }
+    SRH_LEAN_VARIANTS(X)
+#undef X
+    SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
+    return SRH_OK;
+}
+
+int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
+                      size_t lds, hipStream_t stream) {
+#define X(M, NX) if (lean_matches(d, M, NX)) { gusto_lean_kernel<M, NX><<<grid, NTHREADS, lds, stream>>>(d, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+    SRH_LEAN_VARIANTS(X)
+#undef X
+    SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
+    return SRH_OK;
+}
+
+int lean_launch_locp(const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream) {
+#define X(M, NX) if (lean_matches(d, M, NX)) { locp_lean_kernel<M, NX><<<grid, NTHREADS, lds, stream>>>(d, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+    SRH_LEAN_VARIANTS(X)
+#undef X
+    SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
+    return SRH_OK;
+}

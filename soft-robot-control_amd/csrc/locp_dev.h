@@ -34,6 +34,8 @@ struct QPDims {
     int KT;    // 16 x 16 tiles along N * po
     long long qc_off;   // offset (doubles) of the condensed path's HBM block (QCWork) from the problem's work base
     int diagD;          // 1: 2R + U.A^T D U.A is diagonal for every weight vector D (R diagonal, one entry per U.A row)
+    int lean;           // 1: the lean condensed kernels (locp_lean.h: packed G resident in LDS) serve this problem
+    int lean_j0;        // first stage whose packed G^T rows live in LDS (the stages before it stay in the L2 block)
 };
 
 namespace qp {
@@ -64,6 +66,7 @@ struct QPConst {                       // shared by the whole batch (HBM/L2 resi
     cgptr Sc, ScN;                     // (po x po): 2 H^T Qz H = C_o^T Sc C_o (+ the terminal 2 H^T Qzf H for ScN)
     cgptr Tx, Txf;                     // (nX x po), (nXf x po): X.A = Tx C_o, Xf.A = Txf C_o
     cgptr Cz2, Czf2;                   // (po x nz): C_o H^T 2 Qz, C_o H^T 2 Qzf
+    cgiptr gram_sched;                 // lean kernels: tile tasks of the Gram product, 8 waves x 4 tasks x {I, J0, nJ, 0}
 };
 
 struct QPDyn {                         // stage dynamics: matrix k at base + idx[k]*size (idx null: k)

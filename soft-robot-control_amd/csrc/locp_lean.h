@@ -1,0 +1,861 @@
+// Lean condensed interior point for the LOCP QP (sofacontrol/scp/locp.py:218-342) -- the kernel the SCP loop spends its
+// time in, as its own code path: no stage-wise Riccati solver inlined next to it (the fused kernel of locp_dev.h +
+// locp_cond.h sits at 256 VGPRs with ~1.5 KB of scratch per lane for that reason), and the block lower-triangular
+//     G[k][j] = C_o Phi(k, j+1) B_j          (N p_o x N m; locp_cond.h has the mathematics)
+// RESIDENT IN LDS in packed form instead of streaming from L2 four to six times per Newton system.
+//
+// Packed G^T: row (j, b) (input b of stage j) holds only its structurally non-zero columns i = p_o j .. N p_o - 1, rows in
+// the order (j, b); p_o = 2:  off(j) = m (j NP - j (j - 1)) doubles, element (j, b, i) at off(j) + b (NP - 2 j) + i - 2 j.
+// The rows of the stages j >= j0 live in LDS (`Gt`), the first j0 stages -- the longest rows -- in the problem's L2 block
+// (`gh`); j0 is the smallest value for which the carve fits into the 160 KB of a CU (7 at the Diamond shape: 61 of 82 KB
+// in LDS; the Trunk's eight inputs leave room for the last 27 of 50 stages).
+//
+// What changes against locp_cond.h, phase by phase (same iteration, same iterates up to rounding):
+//   condensation   writes G packed (LDS / L2 head) -- no zero fill of the structurally empty part
+//   Gram matrix    K = I + Ls^T (G D^-1 G^T) Ls: MFMA operands straight from the packed rows (weights applied to the B
+//                  operand in registers), causal k-ranges (a tile row stops at the last stage that reaches it), tiles
+//                  distributed by a host-built schedule; Ls and the Jacobi scaling applied to the accumulators
+//   G / G^T        products from LDS (+ the L2 head)
+// Requirements (checked on the host: QPDims::lean): the condensed path applies, p_o = 2, diagonal input Hessians
+// (diagD), n_u a multiple of 4.  Everything else stays on the fused kernel.
+#pragma once
+#include "locp_dev.h"
+
+namespace ql {
+
+using qpc::TS;
+using qpc::TSZ;
+using qpc::QR;
+using qpc::Prof;
+
+struct Lds : qpc::Lds {
+    lptr Gt;           // packed G^T rows of the stages j >= j0
+    lptr panel;        // [A | B] panel while condensing (aliases Rinv / the u-space temporaries)
+};
+
+__host__ __device__ inline int goff(int j, int m, int NP) { return m * (j * NP - j * (j - 1)); }     // p_o = 2
+constexpr int YPAD = 48;               // zeros behind the y-space vectors that feed gT_times (see there)
+
+struct Sizes { size_t regX, thetaT, tiles, rinv, nm4, gt, ldi, ls, ldG, ua, tx, ld, idx; };
+__host__ __device__ inline Sizes sizes(const QPDims &d, int nthreads, int j0) {
+    Sizes s;
+    const size_t nk = (size_t)d.NK, nm = (size_t)d.N * d.m;
+    s.ldG = 16 * (size_t)d.KT;
+    s.nm4 = (nm + 3) & ~(size_t)3;
+    s.thetaT = nk * (s.ldG + 1);
+    s.tiles = (size_t)d.KT * (d.KT + 1) / 2 * TSZ;
+    s.rinv = (size_t)d.KT * TSZ;
+    const size_t a = s.thetaT + nk * d.ld, b = s.tiles + s.rinv + 3 * s.nm4 + (size_t)nthreads;
+    s.regX = ((a > b ? a : b) + 3) & ~(size_t)3;
+    const int NP = d.N * d.po;
+    s.gt = ((size_t)(goff(d.N, d.m, NP) - goff(j0, d.m, NP)) + 3) & ~(size_t)3;
+    s.ldi = s.nm4;
+    s.ls = (size_t)d.N * d.po * d.po;
+    s.ua = ((size_t)d.nU * d.m + 3) & ~(size_t)3;
+    s.tx = ((size_t)(d.nX + d.nXf) * d.po + 3) & ~(size_t)3;
+    s.ld = ((size_t)d.ld + 3) & ~(size_t)3;
+    s.idx = ((size_t)(d.N / 2 + 2) + 3) & ~(size_t)3;
+    return s;
+}
+__host__ __device__ inline size_t lds_doubles(const QPDims &d, int nthreads, int j0) {
+    const Sizes s = sizes(d, nthreads, j0);
+    return s.regX + s.gt + s.ldi + s.ls + 2 * s.nm4 + 9 * s.ldG + 3 * 48 + s.ua + s.tx + 2 * s.ld + 16 + 16 + 4 + 2 * s.idx;
+}
+__device__ inline void lds_carve(Lds &L, lptr base, const QPDims &d, int nthreads) {
+    const Sizes s = sizes(d, nthreads, d.lean_j0);
+    lptr p = base;
+    auto take = [&](size_t c) { lptr q = p; p += c; return q; };
+    lptr X = take(s.regX);
+    // interior-point view: K tiles | inverses of the diagonal tiles | u-space temporaries | reduction scratch
+    L.B = X; L.Rinv = X + s.tiles;
+    L.ta = L.Rinv + s.rinv; L.tb = L.ta + s.nm4; L.tc = L.tb + s.nm4; L.part = L.tc + s.nm4;
+    // condensation view: Theta^T (in L.B) | [A | B] panel
+    L.panel = X + s.thetaT;
+    L.A = L.panel;
+    L.Gt = take(s.gt);
+    L.Ldi = take(s.ldi); L.Ls = take(s.ls);
+    L.u = take(s.nm4); L.du = take(s.nm4);
+    L.y = take(s.ldG); L.dy = take(s.ldG); L.yf = take(s.ldG);
+    // ya, yd, yg feed gT_times: YPAD zeros behind each (written once by ipm, never touched again)
+    L.ya = take(s.ldG + 48); L.yd = take(s.ldG + 48); L.yg = take(s.ldG + 48);
+    L.yb = take(s.ldG); L.yc = take(s.ldG); L.ks = take(s.ldG);
+    L.UA = take(s.ua); L.Tx = take(s.tx);
+    L.v1 = take(s.ld); L.v2 = take(s.ld); L.Qu = take(16); L.red = take(16);
+    L.flag = (liptr)take(4);
+    L.idxl = (liptr)take(s.idx);
+    L.goff = (liptr)take(s.idx);
+}
+
+// packed G^T: head rows in the problem's L2 block, the rest in LDS
+struct GPack {
+    cgptr gh;          // rows of the stages j < j0
+    clptr gt;          // rows of the stages j >= j0, offset so that gt[goff(j) + ...] addresses stage j
+    int j0, m, NP;
+};
+
+// ------------------------------------------------------------------ rollout x_{k+1} = A_k x_k + B_k u_k + d_k  (u null: zero inputs)
+// One dot product of length n + m per state row through the [A | B] panel in LDS (reloaded only when the TPWL region
+// changes: ~12 % of the stages), ONE barrier per stage: 8 lanes per row, lane (il, s) of a 16-lane DPP row takes the columns
+// 2 s + h + 16 q of row 2 r + il (bank = (row + column) mod 16: conflict free), three DPP additions finish the row.
+// The stage vector [x_k ; u_k ; 0] is double buffered in v1 / v2.  (qp::rollout: two L2-fed products and four barriers
+// per stage, 7.6 k clocks per stage against ~0.8 k.)
+template <int MSEL, int NSEL>
+__device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr x0, cgptr u, gptr x, Lds &L) {
+    const int N = d.N, n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, nk = d.NK;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
+    const int l = lane & 15, il = l >> 3, sl = l & 7;
+    const int i = 8 * wave + 2 * (lane >> 4) + il, ic = i < n ? i : n - 1;
+    const int vlen = (int)(((size_t)ld + 3) & ~(size_t)3);
+    lptr va = L.v1, vb = L.v2;
+    for (int e = tid; e < nk * ld; e += nt) L.panel[e] = 0.0;
+    for (int e = tid; e < vlen; e += nt) {
+        const double v = e < n ? x0[e] : (e < n + m && u ? u[e - n] : 0.0);
+        va[e] = v; vb[e] = 0.0;
+        if (e < n) x[e] = v;
+    }
+    __syncthreads();
+    QPLds P{};
+    P.AB = L.panel; P.idxl = L.idxl; P.psel = -1;
+    if (qp::panel_load(d, dyn, P, 0)) __syncthreads();
+    const int nq = NPa >> 4;
+    for (int k = 0; k < N; ++k) {
+        const int sel = __builtin_amdgcn_readfirstlane(L.idxl[k]);
+        const double dk = dyn.d[(size_t)sel * n + ic];
+        const double un = (tid < m && u && k + 1 < N) ? u[(size_t)(k + 1) * m + tid] : 0.0;
+        clptr row = L.panel + ic * ld + 2 * sl;
+        double acc = 0.0;
+        for (int q = 0; q < nq; ++q) {
+            acc = fma(row[16 * q], va[2 * sl + 16 * q], acc);
+            acc = fma(row[16 * q + 1], va[2 * sl + 16 * q + 1], acc);
+        }
+        acc = wg::group_sum<8>(acc) + dk;
+        if (sl == 0 && i < n) { vb[i] = acc; x[(size_t)(k + 1) * n + i] = acc; }
+        if (tid < m) vb[n + tid] = un;
+        __syncthreads();
+        if (k + 1 < N) {
+            const int nsel = __builtin_amdgcn_readfirstlane(L.idxl[k + 1]);
+            if (dyn.idx == nullptr || nsel != sel) { if (qp::panel_load(d, dyn, P, k + 1)) __syncthreads(); }
+        }
+        lptr t = va; va = vb; vb = t;
+    }
+}
+
+// ------------------------------------------------------------------ condensation (once per QP)
+// As qpc::condense (adjoint recursion Theta_{j-1} = [C_o ; Theta_j A_j], G[:, j] = Theta_j B_j, one MFMA product per
+// stage with the [A_j | B_j] panel in LDS); G goes to the packed store.
+template <int MSEL, int NSEL>
+__device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, const QPDyn &dyn, cgptr x, gptr gh, Lds &L) {
+    const int N = d.N, n = d.n, m = d.m, po = d.po, ld = d.ld, KT = d.KT, ldG = 16 * d.KT, ldT = ldG + 1;
+    const int nk = d.NK, NPa = d.NPa, NP = N * po, j0 = d.lean_j0;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    for (int e = tid; e < ldG; e += nt) {
+        double v = 0.0;
+        if (e < NP) {
+            const int k = e / po + 1, a = e - (k - 1) * po;
+            for (int j = 0; j < n; ++j) v = fma(c.Co[(size_t)a * n + j], x[(size_t)k * n + j], v);
+        }
+        L.yf[e] = v;
+    }
+    for (int e = tid; e < nk * ldT; e += nt) L.B[e] = 0.0;
+    for (int e = tid; e < nk * ld; e += nt) L.panel[e] = 0.0;
+    // gT_times runs its lanes past the end of a row (times zeros of y): finite values behind the last L2-resident row
+    for (int e = tid; e < YPAD; e += nt) gh[goff(j0, m, NP) + e] = 0.0;
+    __syncthreads();
+    QPLds P{};
+    P.AB = L.panel; P.idxl = L.idxl; P.psel = -1;
+    const int MT = NPa >> 4;
+    const int KS = (n + 3) >> 2;
+    const int goff0 = goff(j0, m, NP);
+    for (int j = N - 1; j >= 0; --j) {
+        const int sel = __builtin_amdgcn_readfirstlane(L.idxl[j]);
+        const bool reload = dyn.idx == nullptr || __builtin_amdgcn_readfirstlane(P.psel) != sel;
+        if (reload) __syncthreads();
+        if (qp::panel_load(d, dyn, P, j)) __syncthreads();
+        const int t_first = (j * po) >> 4;
+        const int len = NP - po * j, gj = goff(j, m, NP);
+        for (int ti = wave; ti < KT; ti += nw) {
+            if (ti < t_first) continue;
+            for (int e = lane; e < po * n; e += 64) {
+                const int a = e / n, r = e - a * n, i = j * po + a;
+                if ((i >> 4) == ti) L.B[r * ldT + i] = c.Co[(size_t)a * n + r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            constexpr int KSMAX = NSEL > 0 ? (NSEL + 3) / 4 : 32;
+            double bop[KSMAX];
+#pragma unroll
+            for (int s = 0; s < KSMAX; ++s) bop[s] = s < KS ? L.B[(4 * s + kk) * ldT + 16 * ti + l16] : 0.0;
+            for (int ci = 0; ci < MT; ++ci) {
+                wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < KSMAX; ++s)
+                    if (s < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L.panel[(4 * s + kk) * ld + 16 * ci + l16], bop[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 16 * ci + kk + 4 * q, i = 16 * ti + l16;
+                    if (row < n) {
+                        L.B[row * ldT + i] = acc[q];
+                    } else if (row < n + m && i >= po * j && i < NP) {
+                        const int at = gj + (row - n) * len + (i - po * j);
+                        if (j < j0) gh[at] = acc[q]; else L.Gt[at - goff0] = acc[q];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ products with G
+// Row (j, b) of the packed G^T starts at goff(j) + b (NP - 2 j); with R(j, b) = that start - 2 j, element i sits at R + i and
+//     R(j + 1, b) = R(j, b) + m (NP - 2 j) - 2 b - 2
+// -- the loops below walk the stages with two integer additions instead of re-deriving the offsets.
+
+// yv[i] = sum_{rows (j,b), 2 j <= i} G^T[(j,b)][i] uv[(j,b)]: thread = (column, input class b mod 4).  Stages j <= jlo (the
+// last stage that reaches EVERY column of the wave) need no mask; lanes read past "their" rows only inside LDS / the L2
+// block (the select discards what they get).  8 loads of G and of u per trip before the FMAs.
+template <int MSEL>
+__device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L, clptr uv, lptr yv) {
+    constexpr int M = MSEL, CH = 8, CW = 128;
+    const int ldG = 16 * d.KT, NP = g.NP, N = d.N, tid = threadIdx.x, nt = blockDim.x;
+    const int GR = nt / CW, col = tid % CW, grp = tid / CW;          // GR = 4
+    const int cc = col < NP ? col : NP - 1;
+    const int jcnt = col < NP ? min(N, cc / 2 + 1) : 0;              // stages that reach this column
+    // wave-uniform: stages that reach every column of the wave / any column of the wave
+    const int c_lo = col & ~63, c_hi = min(NP - 1, col | 63);
+    const int jall = __builtin_amdgcn_readfirstlane((col | 63) < NP ? min(N, c_lo / 2 + 1) : 0);
+    const int jany = __builtin_amdgcn_readfirstlane(c_lo < NP ? min(N, c_hi / 2 + 1) : 0);
+    const int goff0 = goff(g.j0, M, NP);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};            // four independent chains (a dependent f64 FMA issues every ~13 clocks)
+    for (int b = grp; b < M; b += GR) {
+        // stages [jb, je) of input b; MASK: lanes past their last stage contribute zero
+        auto pass = [&](auto src, int jb, int je, auto MASK) {
+            constexpr bool masked = decltype(MASK)::value;
+            int R = goff(jb, M, NP) + b * (NP - 2 * jb) - 2 * jb + cc, dl = M * (NP - 2 * jb) - 2 * b - 2;
+            for (int j0 = jb; j0 < je; j0 += CH) {
+                double gv[CH], uu[CH];
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    gv[t] = src[R];
+                    uu[t] = uv[min(j0 + t, N - 1) * M + b];
+                    R += dl; dl -= 2 * M;
+                }
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int j = j0 + t;
+                    bool ok = j < je;                                 // uniform: the tail of the last trip
+                    if constexpr (masked) ok = ok && j < jcnt;
+                    acc[t & 3] = fma(ok ? gv[t] : 0.0, uu[t], acc[t & 3]);     // (what masked lanes read may be anything)
+                }
+            }
+        };
+        auto span = [&](auto src, int lo, int hi) {                   // stages [lo, hi) of one store
+            const int mid = max(lo, min(hi, jall));
+            if (mid > lo) pass(src, lo, mid, std::false_type{});
+            if (hi > mid) pass(src, mid, hi, std::true_type{});
+        };
+        span(g.gh, 0, min(g.j0, jany));
+        span(g.gt - goff0, g.j0, jany);
+    }
+    L.part[grp * CW + col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (tid < ldG) {
+        double s = 0.0;
+        if (tid < NP) for (int q = 0; q < GR; ++q) s += L.part[q * CW + tid];
+        yv[tid] = s;
+    }
+    __syncthreads();
+}
+
+// out1[row] = sum_{i >= 2 j} G^T[row][i] y1[i]  (and out2 with y2 when y2 != null): 8 lanes per row, 64 rows per pass; the
+// L2-resident rows (stages < j0) in passes of their own.  No masks: y1 / y2 must be zero from index NP up to NP + YPAD - 1
+// (the lanes run to the length of the longest row of the pass; what they read of G past the end of a row is the next
+// rows' data -- finite -- times those zeros).
+template <int MSEL>
+__device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2) {
+    constexpr int M = MSEL;
+    const int NP = g.NP, nm = d.N * M, tid = threadIdx.x, nt = blockDim.x;
+    const int g8 = tid & 7, rpp = nt / 8;
+    const int goff0 = goff(g.j0, M, NP);
+    auto rows = [&](auto src, int rb, int re, auto TWO) {           // rows [rb, re) from `src` (indexed by the global offset)
+        constexpr bool two = decltype(TWO)::value;
+        for (int r0 = rb; r0 < re; r0 += rpp) {
+            const int r = r0 + (tid >> 3), rc = r < re ? r : re - 1;
+            const int j = rc / M, b = rc - j * M, len = NP - 2 * j;
+            const int at = goff(j, M, NP) + b * len + g8;
+            clptr p1 = y1 + 2 * j + g8, p2 = (two ? y2 : y1) + 2 * j + g8;
+            const int nq = (NP - 2 * (r0 / M) + 7) >> 3;             // trips of the longest row of this pass (uniform)
+            double a1 = 0.0, a2 = 0.0, c1 = 0.0, c2 = 0.0;         // two chains per output
+            int q = 0;
+            for (; q + 4 <= nq; q += 4) {
+                double gv[4], ya[4], yb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { gv[t] = src[at + 8 * (q + t)]; ya[t] = p1[8 * (q + t)]; if (two) yb[t] = p2[8 * (q + t)]; }
+                a1 = fma(gv[0], ya[0], a1); c1 = fma(gv[1], ya[1], c1); a1 = fma(gv[2], ya[2], a1); c1 = fma(gv[3], ya[3], c1);
+                if (two) { a2 = fma(gv[0], yb[0], a2); c2 = fma(gv[1], yb[1], c2); a2 = fma(gv[2], yb[2], a2); c2 = fma(gv[3], yb[3], c2); }
+            }
+            for (; q < nq; ++q) {
+                const double gq = src[at + 8 * q];
+                a1 = fma(gq, p1[8 * q], a1);
+                if (two) a2 = fma(gq, p2[8 * q], a2);
+            }
+            a1 += c1; a2 += c2;
+            a1 = wg::group_sum<8>(a1);
+            if (two) a2 = wg::group_sum<8>(a2);
+            if (g8 == 0 && r < re) { out1[r] = a1; if (two) out2[r] = a2; }
+        }
+    };
+    const int rh = min(nm, g.j0 * M);
+    if (y2) {
+        if (rh > 0) rows(g.gh, 0, rh, std::true_type{});
+        if (nm > rh) rows(g.gt - goff0, rh, nm, std::true_type{});
+    } else {
+        if (rh > 0) rows(g.gh, 0, rh, std::false_type{});
+        if (nm > rh) rows(g.gt - goff0, rh, nm, std::false_type{});
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ Gram matrix K = I + Ls^T (G D^-1 G^T) Ls -> upper tiles
+// One task = up to 4 tiles (I, J0 .. J0 + nJ - 1) of one tile row: the A operand (columns 16 I .. of the packed rows) is
+// shared by the tiles of the task; k-steps = 4 packed rows = the inputs 4 sub .. 4 sub + 3 of one stage, and a tile row only
+// runs over the stages that reach it: 2 j < 16 (I + 1).  Stages with 2 j <= 16 I reach every lane of the tile row (no
+// masks); the last seven are triangular.  sched: per wave 4 tasks x {I, J0, nJ, 0} (host-built, longest first onto the
+// least loaded SIMD; nJ = 0: no more tasks).
+template <int MSEL>
+__device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GPack &g, Lds &L) {
+    static_assert(MSEL == 4 || MSEL == 8, "lean Gram: n_u = 4 or 8");
+    constexpr int M = MSEL, SPS = M / 4;                       // k-steps per stage
+    const int N = d.N, KT = d.KT, NP = g.NP;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int goff0 = goff(g.j0, M, NP);
+    lptr w2 = L.tc;                                            // 1 / D per packed row
+    for (int e = tid; e < N * M; e += nt) { const double s = L.Ldi[e]; w2[e] = s * s; }
+    __syncthreads();
+    // this wave's tasks: all descriptors requested at once (one L2 latency instead of one per task)
+    int tI[4], tJ0[4], tnJ[4];
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) {
+        cgiptr task = c.gram_sched + (wave * 4 + slot) * 4;
+        tI[slot] = task[0]; tJ0[slot] = task[1]; tnJ[slot] = task[2];
+    }
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) {
+        tI[slot] = __builtin_amdgcn_readfirstlane(tI[slot]); tJ0[slot] = __builtin_amdgcn_readfirstlane(tJ0[slot]);
+        tnJ[slot] = __builtin_amdgcn_readfirstlane(tnJ[slot]);
+    }
+    for (int slot = 0; slot < 4; ++slot) {
+        const int I = tI[slot], J0 = tJ0[slot], nJ = tnJ[slot];
+        if (nJ == 0) break;
+        wg::qp_d4 acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        const int jend = min(N, 8 * (I + 1));                  // stages with 2 j < 16 (I + 1)
+        const int jfull = min(jend, 8 * I + 1);                // stages with 2 j <= 16 I: every lane of the row is live
+        const int ia = 16 * I + l16;
+        const bool diag0 = J0 == I;                            // tile 0 of the task is the diagonal tile
+        const int dJ = 16 * (J0 - I);                          // B operand of tile t: 16 (dJ / 16 + t) doubles behind A's
+        // stages [jb, je) from `src` (indexed by the global packed offset); MASK: triangular part of the tile row; NJ tiles.
+        // No masks for the padding columns i >= NP of the last tile row / column: what they read (finite or not) only
+        // reaches the padding rows / columns of K, which are overwritten below.  1 / D goes onto the shared A operand.
+        auto run = [&](auto src, int jb, int je, auto MASK, auto NJ) {
+            constexpr bool masked = decltype(MASK)::value;
+            constexpr int nj = decltype(NJ)::value;
+            int R = goff(jb, M, NP) + kk * (NP - 2 * jb) - 2 * jb + ia;           // R(jb, b = kk) + column of the A operand
+            int dl = M * (NP - 2 * jb) - 2 * kk - 2;
+            constexpr int UN = 4 / SPS;                                      // stages per full trip: 4 k-steps
+            auto trip = [&](int j0, auto UNS) {                              // UNS stages = UNS * SPS k-steps
+                constexpr int uns = decltype(UNS)::value, KS = uns * SPS;
+                double av[KS], bv[KS][nj];
+#pragma unroll
+                for (int us = 0; us < uns; ++us) {
+                    const int j = j0 + us;
+#pragma unroll
+                    for (int sub = 0; sub < SPS; ++sub) {
+                        const int u = us * SPS + sub;
+                        const int base = R + 4 * sub * (NP - 2 * j);
+                        av[u] = src[base] * w2[j * M + 4 * sub + kk];
+#pragma unroll
+                        for (int t = 0; t < nj; ++t) bv[u][t] = src[base + dJ + 16 * t];
+                        if constexpr (masked) {
+                            const bool va = ia >= 2 * j;
+                            av[u] = va ? av[u] : 0.0;
+                            if (diag0) bv[u][0] = va ? bv[u][0] : 0.0;
+                        }
+                    }
+                    R += dl; dl -= 2 * M;
+                }
+#pragma unroll
+                for (int u = 0; u < KS; ++u)
+#pragma unroll
+                    for (int t = 0; t < nj; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
+            };
+            int j0 = jb;
+            for (; j0 + UN <= je; j0 += UN) trip(j0, std::integral_constant<int, UN>{});
+            for (; j0 < je; ++j0) trip(j0, std::integral_constant<int, 1>{});
+        };
+        // four ranges: {L2 head, LDS} x {full, triangular}
+        auto task_body = [&](auto NJ) {
+            const int hf = min(jfull, g.j0), he = min(jend, g.j0);
+            if (hf > 0) run(g.gh, 0, hf, std::false_type{}, NJ);
+            if (he > hf) run(g.gh, hf, he, std::true_type{}, NJ);
+            if (jfull > g.j0) run(g.gt - goff0, g.j0, jfull, std::false_type{}, NJ);
+            if (jend > max(jfull, g.j0)) run(g.gt - goff0, max(jfull, g.j0), jend, std::true_type{}, NJ);
+        };
+        if (nJ == 4) task_body(std::integral_constant<int, 4>{});
+        else if (nJ == 3) task_body(std::integral_constant<int, 3>{});
+        else if (nJ == 2) task_body(std::integral_constant<int, 2>{});
+        else task_body(std::integral_constant<int, 1>{});
+        // ---- Ls on both sides, + I, raw tile to the store; the diagonal feeds the Jacobi scaling
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= nJ) continue;
+            const int J = J0 + t;
+            const int gjc = 16 * J + l16, kb = min(gjc >> 1, N - 1), bc = gjc & 1;
+            clptr Lb = L.Ls + (size_t)kb * 4;
+            const double cb_own = bc == 0 ? Lb[0] : Lb[3], cb_oth = bc == 0 ? Lb[2] : 0.0;
+            lptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = kk + 4 * q, gi = 16 * I + r, ka = min(gi >> 1, N - 1), ar = gi & 1;
+                clptr La = L.Ls + (size_t)ka * 4;
+                double v = (gi < NP && gjc < NP) ? acc[t][q] : 0.0;      // padding rows / columns: exactly the identity
+                const double vp = wg::dpp_mov<0xB1>(v);                 // the other column of the output stage
+                v = fma(vp, cb_oth, v * cb_own);                        // (Ky Ls)
+                const double vr = __shfl_xor(v, 16, 64);                // the other row of the output stage (kk ^ 1)
+                v = ar == 0 ? fma(La[2], vr, La[0] * v) : La[3] * v;    // Ls^T (Ky Ls)
+                const bool dg = I == J && r == l16;
+                v += dg ? 1.0 : 0.0;
+                const double ri = rsqrt(dg ? v : 1.0);
+                if (dg) L.ks[gi] = ri * (1.5 - 0.5 * v * ri * ri);       // one Newton step: full double accuracy
+                T[r * TS + l16] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- symmetric scaling to a unit diagonal (see qpc::gram for why it matters): every wave scales the tiles it wrote
+    for (int slot = 0; slot < 4; ++slot) {
+        const int I = tI[slot], J0 = tJ0[slot], nJ = tnJ[slot];
+        if (nJ == 0) break;
+        for (int t = 0; t < nJ; ++t) {
+            lptr T = L.B + (size_t)qpc::tile_index(I, J0 + t, KT) * TSZ;
+            const double sc = L.ks[16 * (J0 + t) + l16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int r = kk + 4 * q; T[r * TS + l16] *= L.ks[16 * I + r] * sc; }
+        }
+    }
+    __syncthreads();
+}
+
+// Newton direction (qpc::newton_solve with the products from the packed store)
+template <int MSEL>
+__device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
+    const int nm = d.N * d.m, ldG = 16 * d.KT, tid = threadIdx.x, nt = blockDim.x;
+    QC_SUB(pf, 8);
+    gT_times<MSEL>(d, g, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr);
+    QC_SUB(pf, 9);
+    if (gyd) {
+        double r = 0.0;
+        for (int e = tid; e < nm; e += nt) r = fmax(r, fabs(L.tb[e] + L.tc[e]));
+        *rd = wg::reduce(r, 1, L.red);
+    }
+    for (int e = tid; e < nm; e += nt) L.ta[e] = -(L.ta[e] + L.du[e]);
+    __syncthreads();
+    qpc::dinv_apply(d, L, L.ta);
+    QC_SUB(pf, 10);
+    g_times<MSEL>(d, g, L, L.ta, L.yb);
+    QC_SUB(pf, 11);
+    qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc);
+    for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
+    __syncthreads();
+    qpc::k_solve(d, L, L.yc);
+    for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
+    __syncthreads();
+    QC_SUB(pf, 12);
+    qpc::ls_apply<qpc::LS_FWD>(d, L, L.yc, L.yd);
+    gT_times<MSEL>(d, g, L, L.yd, (clptr) nullptr, L.du, (lptr) nullptr);
+    QC_SUB(pf, 13);
+    qpc::dinv_apply(d, L, L.du);
+    for (int e = tid; e < nm; e += nt) L.du[e] = L.ta[e] - L.du[e];
+    __syncthreads();
+    QC_SUB(pf, 14);
+    g_times<MSEL>(d, g, L, L.du, L.dy);
+    QC_SUB(pf, 15);
+}
+
+#ifdef QL_SELFCHECK
+// Debug build only: the products and the Gram matrix of the CURRENT data against naive loops over the packed store.
+template <int MSEL>
+__device__ __noinline__ void selfcheck(const QPDims &d, const QPConst &c, const GPack &g, Lds &L, gptr chk, int where) {
+    const int tid = threadIdx.x, nt = blockDim.x, N = d.N, m = d.m, NP = g.NP, nm = N * m;
+    auto Gat = [&](int j, int b, int i) -> double {
+        if (i < 2 * j || i >= NP) return 0.0;
+        const int at = goff(j, m, NP) + b * (NP - 2 * j) + (i - 2 * j);
+        return j < g.j0 ? (double)g.gh[at] : (double)L.Gt[at - goff(g.j0, m, NP)];
+    };
+    __syncthreads();
+    for (int e = tid; e < nm; e += nt) L.ta[e] = 0.37 + 0.001 * e;
+    __syncthreads();
+    g_times<MSEL>(d, g, L, L.ta, L.yb);
+    double e0 = 0.0;
+    for (int i = tid; i < NP; i += nt) {
+        double sref = 0.0;
+        for (int j = 0; j < N; ++j) for (int b = 0; b < m; ++b) sref += Gat(j, b, i) * L.ta[j * m + b];
+        e0 = fmax(e0, fabs(sref - L.yb[i]) / (1e-30 + fabs(sref)));
+    }
+    e0 = wg::reduce(e0, 1, L.red);
+    for (int e = tid; e < 16 * d.KT + YPAD; e += nt) { L.ya[e] = e < NP ? 0.2 + 0.01 * e : 0.0; L.yg[e] = e < NP ? 1.0 - 0.003 * e : 0.0; }
+    __syncthreads();
+    gT_times<MSEL>(d, g, L, L.ya, L.yg, L.du, L.tb);
+    double e1 = 0.0;
+    for (int r = tid; r < nm; r += nt) {
+        const int j = r / m, b = r % m;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < NP; ++i) { s1 += Gat(j, b, i) * L.ya[i]; s2 += Gat(j, b, i) * L.yg[i]; }
+        e1 = fmax(e1, fmax(fabs(s1 - L.du[r]) / (1e-30 + fabs(s1)), fabs(s2 - L.tb[r]) / (1e-30 + fabs(s2))));
+    }
+    e1 = wg::reduce(e1, 1, L.red);
+    gT_times<MSEL>(d, g, L, L.ya, (clptr) nullptr, L.du, (lptr) nullptr);
+    double e1b = 0.0;
+    for (int r = tid; r < nm; r += nt) {
+        const int j = r / m, b = r % m;
+        double s1 = 0.0;
+        for (int i = 0; i < NP; ++i) s1 += Gat(j, b, i) * L.ya[i];
+        e1b = fmax(e1b, fabs(s1 - L.du[r]) / (1e-30 + fabs(s1)));
+    }
+    e1b = wg::reduce(e1b, 1, L.red);
+    if (tid == 0 && blockIdx.x == 0) printf("[selfcheck %d] gT_times single %.2e\n", where, e1b);
+    double e2 = 0.0;
+    for (int e = tid; e < NP * NP; e += nt) {
+        const int i1 = e / NP, i2 = e % NP;
+        if (i1 > i2) continue;
+        const int k1 = i1 >> 1, k2 = i2 >> 1;
+        double v = 0.0;
+        for (int a1 = 0; a1 < 2; ++a1) for (int a2 = 0; a2 < 2; ++a2) {
+            const double l1 = L.Ls[k1 * 4 + a1 * 2 + (i1 & 1)], l2 = L.Ls[k2 * 4 + a2 * 2 + (i2 & 1)];
+            if (l1 == 0.0 || l2 == 0.0) continue;
+            double ky = 0.0;
+            for (int j = 0; j < N; ++j) for (int b = 0; b < m; ++b) { const double sd = L.Ldi[j * m + b]; ky += Gat(j, b, 2 * k1 + a1) * Gat(j, b, 2 * k2 + a2) * sd * sd; }
+            v += l1 * ky * l2;
+        }
+        if (i1 == i2) v += 1.0;
+        chk[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NP * NP; e += nt) {
+        const int i1 = e / NP, i2 = e % NP;
+        if (i1 > i2) continue;
+        const double ref = chk[e] / sqrt(chk[i1 * NP + i1] * chk[i2 * NP + i2]);
+        const double got = L.B[(size_t)qpc::tile_index(i1 >> 4, i2 >> 4, d.KT) * TSZ + (i1 & 15) * TS + (i2 & 15)];
+        e2 = fmax(e2, fabs(ref - got));
+    }
+    e2 = wg::reduce(e2, 1, L.red);
+    if (tid == 0 && blockIdx.x == 0) printf("[selfcheck %d] g_times %.2e gT_times %.2e gram %.2e\n", where, e0, e1, e2);
+    __syncthreads();
+}
+#endif
+
+// ------------------------------------------------------------------ the QP without its trust-region rows
+// Results: w.u, and -- after the final rollout of solve_qp below -- w.x.  Returns 0 optimal, 1 max iterations, 2 numerical failure.
+template <int MSEL, int NSEL>
+__device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
+                                   Lds &L, QPLds &Lq, int *iters_out, QPWork &wout, long long *prof) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    QPDims d = dfull;
+    d.tr = 0;
+    d.nrx = d.nX;
+    d.RX = d.nrx + d.nXf;
+    d.NR = d.N * d.RX + d.N * d.nU;
+    d.ng = d.N * d.nrx + d.nXf + d.N * d.nU;
+    QPWork w;
+    qp_carve(w, work_base, d);
+    wout = w;
+    gptr gh = work_base + dfull.qc_off;
+    const int N = d.N, m = d.m, po = d.po, nm = N * m, ldG = 16 * d.KT, NP = N * po;
+    GPack g{(cgptr)gh, (clptr)(L.Gt), d.lean_j0, m, NP};
+#ifdef QL_SELFCHECK
+    QCWork qwd; qwd.GT = work_base + dfull.qc_off + 80000;
+#endif
+    Prof pf;
+#ifdef SRH_PROFILE
+    for (int i = 0; i < 24; ++i) pf.t[i] = 0;
+    long long tq_last = clock64();
+    auto qlap = [&](int slot) { const long long now = clock64(); prof[slot] += now - tq_last; tq_last = now; };
+#define QL_LAP(x) qlap(x)
+#else
+#define QL_LAP(x) ((void)0)
+#endif
+    for (int e = tid; e < nm; e += nt) { w.u[e] = 0.0; L.u[e] = 0.0; }
+    static_assert(YPAD == 48, "the carve reserves 48 doubles behind ya, yd, yg");
+    for (int e = tid; e < YPAD; e += nt) { L.ya[ldG + e] = 0.0; L.yd[ldG + e] = 0.0; L.yg[ldG + e] = 0.0; }
+    for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
+    for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+    for (int e = tid; e < d.nU * m; e += nt) L.UA[e] = c.UA[e];
+    for (int e = tid; e < (d.nX + d.nXf) * po; e += nt) L.Tx[e] = e < d.nX * po ? c.Tx[e] : c.Txf[e - d.nX * po];
+    __syncthreads();
+    rollout<MSEL, NSEL>(d, dyn, q.x0, (cgptr) nullptr, w.x, L);
+    QL_LAP(0);
+    condense<MSEL, NSEL>(d, c, dyn, w.x, gh, L);
+#ifdef QL_SELFCHECK
+    {   // the packed G against qpc::condense (dense, L2), the free response against qp::rollout
+        gptr dense = work_base + dfull.qc_off + 80000, xref = dense + (size_t)nm * ldG + 64;
+        qpc::Lds Lc = L;
+        Lc.A = L.panel;
+        QCWork qw; qw.GT = dense;
+        for (int e = tid; e < ldG; e += nt) L.ya[e] = L.yf[e];
+        __syncthreads();
+        qpc::condense<MSEL, NSEL>(d, c, dyn, w.x, qw, Lc);
+        double e4 = 0.0, e5 = 0.0, e6 = 0.0;
+        for (int e = tid; e < nm * NP; e += nt) {
+            const int r = e / NP, i = e % NP, j = r / m, b = r % m;
+            const double ref = dense[(size_t)r * ldG + i];
+            double got = 0.0;
+            if (i >= 2 * j) { const int at = goff(j, m, NP) + b * (NP - 2 * j) + (i - 2 * j); got = j < g.j0 ? (double)gh[at] : (double)L.Gt[at - goff(g.j0, m, NP)]; }
+            e4 = fmax(e4, fabs(ref - got));
+            e5 = fmax(e5, fabs(ref));
+        }
+        for (int e = tid; e < ldG; e += nt) e6 = fmax(e6, fabs(L.ya[e] - L.yf[e]));
+        e4 = wg::reduce(e4, 1, L.red); e5 = wg::reduce(e5, 1, L.red); e6 = wg::reduce(e6, 1, L.red);
+        qp::rollout(d, dyn, q, w.u, xref, Lq);
+        double e7 = 0.0;
+        for (int e = tid; e < (N + 1) * d.n; e += nt) e7 = fmax(e7, fabs(xref[e] - w.x[e]));
+        e7 = wg::reduce(e7, 1, L.red);
+        if (tid == 0 && blockIdx.x == 0) printf("[selfcheck] condense max |dG| %.3e (max |G| %.3e) yf %.3e free rollout %.3e\n", e4, e5, e6, e7);
+        __syncthreads();
+    }
+#endif
+    for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yf[e]; L.dy[e] = 0.0; }
+    __syncthreads();
+    QL_LAP(2);
+    bool rv[QR], ru[QR];
+    int rk[QR], rr[QR];
+    double rh[QR], rt[QR], rlam[QR], rrg[QR], rrc[QR], rdt[QR], rdl[QR];
+#pragma unroll
+    for (int qi = 0; qi < QR; ++qi) {
+        const int e = tid + nt * qi, nxs = N * d.RX;
+        rt[qi] = rlam[qi] = rrg[qi] = rrc[qi] = rdt[qi] = rdl[qi] = 0.0;
+        if (e < nxs) {
+            rk[qi] = e / d.RX + 1; rr[qi] = e - (rk[qi] - 1) * d.RX; ru[qi] = false;
+            rv[qi] = rr[qi] < qp::xrows_of(d, rk[qi]);
+        } else {
+            const int e2 = e - nxs;
+            ru[qi] = true; rv[qi] = e2 < N * d.nU;
+            rk[qi] = rv[qi] ? e2 / d.nU : 0; rr[qi] = rv[qi] ? e2 - rk[qi] * d.nU : 0;
+        }
+        rh[qi] = rv[qi] ? qp::row_h(d, c, q, ru[qi], rk[qi], rr[qi]) : 0.0;
+    }
+    auto row_val = [&](int qi, clptr vy, clptr vu) {
+        double acc = 0.0;
+        if (!ru[qi]) { for (int a = 0; a < po; ++a) acc = fma(L.Tx[rr[qi] * po + a], vy[(rk[qi] - 1) * po + a], acc); }
+        else { for (int j = 0; j < m; ++j) acc = fma(L.UA[rr[qi] * m + j], vu[rk[qi] * m + j], acc); }
+        return acc;
+    };
+    int status = 1, it = 0;
+    enum { INIT = 0, PRED = 1, CORR = 2 };
+    int mode = INIT;
+    double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
+    bool near_opt = false;
+    while (true) {
+        QL_LAP(7);
+        double musum = 0.0, rpm = 0.0;
+#pragma unroll
+        for (int qi = 0; qi < QR; ++qi) {
+            if (!rv[qi]) continue;
+            const int e = tid + nt * qi;
+            if (mode == INIT) {
+                const double gq = row_val(qi, L.y, L.u) - rh[qi];
+                w.D[e] = 1.0; w.rho[e] = gq; rlam[qi] = 0.0;
+            } else if (mode == PRED) {
+                const double gq = row_val(qi, L.y, L.u) - rh[qi];
+                const double t = rt[qi], lam = rlam[qi], rg = gq + t;
+                rrg[qi] = rg;
+                const double D = lam / (t + dreg * lam);
+                w.D[e] = D; w.rho[e] = D * (rg + dreg * lam); w.lam[e] = lam;
+                musum += lam * t;
+                rpm = fmax(rpm, fabs(rg));
+            } else {
+                const double t = rt[qi], lam = rlam[qi];
+                const double rc = lam * t + rdt[qi] * rdl[qi] - sig * mu;
+                rrc[qi] = rc;
+                w.rho[e] = lam + (lam * rrg[qi] - rc) / (t + dreg * lam);
+            }
+        }
+        if (mode == PRED) {
+            mu = wg::reduce(musum, 0, L.red) / d.ng;
+            rp = wg::reduce(rpm, 1, L.red);
+        }
+        __syncthreads();
+        QL_LAP(1);
+        double rd = 0.0;
+        bool ok = true;
+        if (mode != CORR) {
+            ok = qpc::stage_factors(d, c, w.D, L);
+            QL_LAP(3);
+            if (ok) {
+#ifdef QL_OLD_GRAM
+                { qpc::Lds Lc = L; Lc.A = L.panel; qpc::gram<MSEL>(d, qwd, Lc); }
+#else
+                gram<MSEL>(d, c, g, L);
+#endif
+#ifdef QL_SELFCHECK
+                if (mode == INIT || it == 3) selfcheck<MSEL>(d, c, g, L, work_base + dfull.qc_off + 60000, it);
+#endif
+                QL_LAP(4);
+                ok = qpc::tile_cholesky(d, L);
+                QL_LAP(5);
+            }
+        }
+#ifdef SRH_PROFILE
+        pf.last = clock64();
+#endif
+        if (ok) {
+            if (mode == PRED) qpc::gradients(d, c, q, L, w.lam, L.tb, L.yg);
+            qpc::gradients(d, c, q, L, w.rho, L.ta, L.ya);
+#ifdef QL_OLD_NEWTON
+            { qpc::Lds Lc = L; Lc.A = L.ta; qpc::newton_solve(d, qwd, L, mode == PRED ? (clptr)L.yg : (clptr) nullptr, &rd, pf); }
+#else
+            newton_solve<MSEL>(d, g, L, mode == PRED ? (clptr)L.yg : (clptr) nullptr, &rd, pf);
+#endif
+        }
+        QL_LAP(6);
+        if (mode == INIT) {
+            if (!ok) { status = 2; break; }
+            for (int e = tid; e < nm; e += nt) L.u[e] += L.du[e];
+            for (int e = tid; e < ldG; e += nt) L.y[e] += L.dy[e];
+            __syncthreads();
+            if (d.ng == 0) { status = 0; break; }
+            double zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi) {
+                if (!rv[qi]) continue;
+                const double gq = row_val(qi, L.y, L.u) - rh[qi];
+                rrg[qi] = gq;
+                zmin = fmin(zmin, gq); zmax = fmax(zmax, gq);
+            }
+            zmin = wg::reduce(zmin, 2, L.red);
+            zmax = wg::reduce(zmax, 1, L.red);
+            const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi) { rt[qi] = -rrg[qi] + sh_t; rlam[qi] = rrg[qi] + sh_l; }
+            for (int e = tid; e < d.n; e += nt) {
+                double gq = 0.0;
+                if (q.z) for (int a = 0; a < d.nz; ++a) gq = fma(c.HtQz2[e * d.nz + a], -q.z[d.nz + a], gq);
+                sd = fmax(sd, fabs(gq));
+            }
+            for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
+            sd = fmax(wg::reduce(sd, 1, L.red), q.omega);
+            sp = fmax(wg::reduce(sp, 1, L.red), fabs(q.delta));
+            dreg = d.reg / sd;
+            mode = PRED;
+            continue;
+        }
+        double amax = 1e300;
+        if (ok) {
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi) {
+                if (!rv[qi]) continue;
+                const double t = rt[qi], lam = rlam[qi], rga = rrg[qi] + row_val(qi, L.dy, L.du);
+                const double dl = ((mode == PRED ? -lam * t : -rrc[qi]) + lam * rga) / (t + dreg * lam);
+                const double dtv = -rga + dreg * dl;
+                rdl[qi] = dl; rdt[qi] = dtv;
+                if (dtv < 0.0) amax = fmin(amax, -t / dtv);
+                if (dl < 0.0) amax = fmin(amax, -lam / dl);
+            }
+        }
+        amax = wg::reduce(amax, 2, L.red);
+        if (mode == PRED) {
+            if (!ok) { status = near_opt ? 0 : 2; break; }
+            if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
+            if (!(rd == rd)) { status = near_opt ? 0 : 6; break; }
+            if (q.dbg && tid == 0) { gptr gd = q.dbg + 8 * it; gd[0] = mu; gd[1] = rd; gd[2] = rp; gd[3] = sd; gd[4] = sp; }
+            const double ltol = fmax(d.tol, 1e-9);
+            if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
+            near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
+            if (it >= d.max_iter) { status = 1; break; }
+            const double a_aff = fmin(1.0, amax);
+            double ma = 0.0;
+#pragma unroll
+            for (int qi = 0; qi < QR; ++qi)
+                if (rv[qi]) ma += (rlam[qi] + a_aff * rdl[qi]) * (rt[qi] + a_aff * rdt[qi]);
+            const double mu_aff = wg::reduce(ma, 0, L.red) / d.ng;
+            sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+            if (q.dbg && tid == 0) { gptr gd = q.dbg + 8 * it; gd[5] = a_aff; gd[6] = sig; }
+            mode = CORR;
+            continue;
+        }
+        if (!ok) { status = 2; break; }
+        const double a = fmin(1.0, 0.99 * amax);
+        if (q.dbg && tid == 0) { gptr gd = q.dbg + 8 * it; gd[7] = a; }
+        for (int e = tid; e < nm; e += nt) L.u[e] += a * L.du[e];
+        for (int e = tid; e < ldG; e += nt) L.y[e] += a * L.dy[e];
+#pragma unroll
+        for (int qi = 0; qi < QR; ++qi) { rt[qi] += a * rdt[qi]; rlam[qi] += a * rdl[qi]; }
+        __syncthreads();
+        ++it;
+        mode = PRED;
+    }
+    __syncthreads();
+    for (int e = tid; e < nm; e += nt) w.u[e] = L.u[e];
+    __syncthreads();
+#ifdef SRH_PROFILE
+    for (int i = 0; i < 8; ++i) prof[8 + i] += pf.t[8 + i];
+#endif
+    if (iters_out) *iters_out = it;
+    return status;
+}
+
+// The QP as the SCP loop needs it: condensed interior point, states by a rollout of the minimiser, objective, trust-region
+// test.  Returns 0 when the result IS the minimiser of the full QP (converged, inside the trust region); anything else
+// means "hand this QP to the fused kernel" (status of the interior point, or 100 = minimiser outside the trust region).
+template <int MSEL, int NSEL>
+__device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
+                                        Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    QPLds Lq{};
+    Lq.v1 = L.v1; Lq.v2 = L.v2; Lq.Qu = L.Qu; Lq.part = L.part; Lq.red = L.red; Lq.idxl = L.idxl; Lq.flag = L.flag;
+    int it = 0;
+    const int st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
+    if (iters_out) *iters_out = it;
+    if (st != 0) return st;
+    QPDims d0 = dfull;
+    d0.tr = 0;
+    QPWork w = wout;
+    const int N = d0.N, n = d0.n;
+    const double s0 = qp::slack0(dfull, c, q, Lq);
+    for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+    for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
+    __syncthreads();
+    rollout<MSEL, NSEL>(d0, dyn, q.x0, (cgptr)w.u, w.x, L);
+    __syncthreads();
+#ifdef QL_CHECK_ROLLOUT
+    {
+        gptr xref = work_base + dfull.qc_off + 100000;
+        qp::rollout(d0, dyn, q, w.u, xref, Lq);
+        double e7 = 0.0;
+        int worst = 0;
+        for (int e = tid; e < (N + 1) * n; e += nt) { const double dv = fabs(xref[e] - w.x[e]); if (dv > e7) { e7 = dv; worst = e; } }
+        const double emax = wg::reduce(e7, 1, L.red);
+        if (e7 == emax && emax > 0.0) printf("[check] final rollout max err %.3e at stage %d component %d (block %d)\n", emax, worst / n, worst % n, (int)blockIdx.x);
+        if (tid == 0) {
+            printf("[check] idxl[36..49]: %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", L.idxl[36], L.idxl[37], L.idxl[38], L.idxl[39], L.idxl[40], L.idxl[41], L.idxl[42],
+                   L.idxl[43], L.idxl[44], L.idxl[45], L.idxl[46], L.idxl[47], L.idxl[48], L.idxl[49]);
+            printf("[check] u[40][0..3] = %.6f %.6f %.6f %.6f  x[41][0..1] = %.6f %.6f  x[40][0..1] %.6f %.6f\n", (double)w.u[40 * dfull.m], (double)w.u[40 * dfull.m + 1],
+                   (double)w.u[40 * dfull.m + 2], (double)w.u[40 * dfull.m + 3], (double)w.x[41 * n], (double)w.x[41 * n + 1], (double)w.x[40 * n], (double)w.x[40 * n + 1]);
+        }
+        __syncthreads();
+    }
+#endif
+    double J = qp::objective(d0, c, q, w.x, w.u, w.s, Lq);
+    bool inside = true;
+    if (dfull.tr) {
+        double md = 0.0;
+        for (int e = tid + n; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (w.x[e] - q.xk[e])));
+        md = wg::reduce(md, 1, L.red);
+        inside = md <= q.delta;
+        J += q.omega * s0;
+    }
+    if (J_out) *J_out = J;
+    return inside ? 0 : 100;
+}
+
+}  // namespace ql

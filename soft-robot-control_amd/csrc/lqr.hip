@@ -1074,7 +1074,7 @@ static int tvlqr_impl(const double *dA, const double *dB, const int *didx, int n
         (rc = dK.alloc(sizeof(double) * (size_t)n_steps * m * n)) || (rc = dP.alloc(sizeof(double) * (size_t)(n_steps + 1) * n * n)) ||
         (rc = dS.alloc(sizeof(int))))
         return rc;
-    const size_t lds = lqr_lds_doubles(n, m) * sizeof(double);
+    const size_t lds = srh::lds_request(lqr_lds_doubles(n, m) * sizeof(double));
     SRH_REQUIRE(lds <= 160 * 1024, "sric_tvlqr: state dimension too large for LDS");
     SRH_CHECK_HIP(hipFuncSetAttribute((const void *)tvlqr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     tvlqr_kernel<<<1, NT, lds>>>(dA, dB, didx, n_steps, n, m, dQ.as<double>(), dR.as<double>(), dK.as<double>(),
@@ -1121,7 +1121,7 @@ int sric_dare_fixed_point(const double *A, const double *B, int64_t batch, int n
         (rc = dL.alloc(sizeof(double) * batch * n_u * n_x)) || (rc = dP.alloc(sizeof(double) * batch * n_x * n_x)) ||
         (rc = dI.alloc(sizeof(int32_t) * batch)))
         return rc;
-    const size_t lds = lqr_lds_doubles(n_x, n_u) * sizeof(double);
+    const size_t lds = srh::lds_request(lqr_lds_doubles(n_x, n_u) * sizeof(double));
     SRH_REQUIRE(lds <= 160 * 1024, "sric_dare_fixed_point: state dimension too large for LDS");
     SRH_CHECK_HIP(hipFuncSetAttribute((const void *)dare_fp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dare_fp_kernel<<<(unsigned)batch, NT, lds>>>(dA.as<double>(), dB.as<double>(), n_x, n_u, dQ.as<double>(), dR.as<double>(),
@@ -1151,7 +1151,7 @@ int sric_dare(const double *A, const double *B, int64_t batch, int n_x, int n_u,
     const size_t tail = sda_tail_doubles(n_x, n_u) * sizeof(double);
     SRH_REQUIRE(gain_lds <= 160 * 1024 && tail <= 160 * 1024, "sric_dare: state dimension too large for LDS");
     const int lds_slots = (5 * nn * sizeof(double) + tail <= 160 * 1024 && !getenv("SRH_DARE_HBM_SLOTS")) ? 1 : 0;
-    const size_t lds = std::max(gain_lds, (lds_slots ? 5 * nn * sizeof(double) : 0) + tail);
+    const size_t lds = srh::lds_request(std::max(gain_lds, (lds_slots ? 5 * nn * sizeof(double) : 0) + tail));
     SRH_CHECK_HIP(hipFuncSetAttribute((const void *)dare_sda_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dare_sda_kernel<<<(unsigned)batch, NT, lds>>>(dA.as<double>(), dB.as<double>(), n_x, n_u, dQ.as<double>(), dR.as<double>(),
                                                   tol, max_iter, dW.as<double>(), lds_slots, dL.as<double>(), dP.as<double>(),
@@ -1225,6 +1225,7 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
         else if (lds + sizeof(double) * lstride <= 160 * 1024) { a.stage_ab = 1; lds += sizeof(double) * lstride; }
     }
     SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
+    lds = srh::lds_request(lds);
     // variants: the reference's robots at the benchmark / shipped basis sizes (TPWL), the C3 SSM shape; else all sizes
 #define SRH_ILQR_VARIANTS(X) X(0, 60, 4) X(0, 60, 8) X(0, 72, 4) X(1, 10, 8) X(0, 0, 0) X(1, 0, 0)
     {

@@ -746,6 +746,7 @@ int sekf_create(sekf_t **out, stpwl_t *model, const double *C, const double *y_r
         h->wide = true;
         h->lds = sizeof(double) * ekf_wide_doubles(h->n, n_y);
     }
+    h->lds = srh::lds_request(h->lds);
     if (h->lds > 160 * 1024) {
         delete h;
         srh::set_error("sekf_create: the filter step does not fit the 160 KB LDS (n_x too large)");

@@ -3,19 +3,9 @@
 // sofacontrol/scp/models/tpwl.py:32-58 (model adapter).
 // This unit: the batched QP entry point (slocp_solve); the GuSTO kernel and plan live in gusto.hip (two units: the
 // kernel variants of each compile in parallel).
-#include "scp_host.h"
+#include "scp_types.h"
 
 namespace {
-
-struct LocpBatch {
-    const double *Ad, *AdT, *Bd, *BdT, *dd;     // (batch x N x ...)
-    const double *x0, *xk, *delta, *omega, *z, *zf, *ud;
-    double *x, *u, *s, *J;
-    int32_t *status, *iters;
-    double *work;
-    size_t work_stride;
-    double *dbg;
-};
 
 template <bool SPLIT, int MSEL, int NSEL>
 __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, LocpBatch b) {
@@ -24,6 +14,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
     QPLds L;
     qp_lds_carve(L, (lptr)smem, d, NTHREADS);          // qp::solve fills the constants of the layout it uses
     const size_t p = blockIdx.x;
+    if (b.only_pending && b.status[p] != LEAN_PENDING) return;      // the lean kernel finished this one
     const size_t N = d.N, n = d.n, m = d.m;
     QPWork w;
     gptr wbase = (gptr)(b.work + p * b.work_stride);
@@ -115,12 +106,32 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
     LocpBatch b{dA.as<double>(), dAT.as<double>(), dB.as<double>(), dBT.as<double>(), dD.as<double>(), dx0.as<double>(),
                 dxk.as<double>(), ddel.as<double>(), dom.as<double>(), z ? dz.as<double>() : nullptr,
                 zf ? dzf.as<double>() : nullptr, u_des ? dud.as<double>() : nullptr, ox.as<double>(), ou.as<double>(),
-                os.as<double>(), oJ.as<double>(), ost.as<int32_t>(), oit.as<int32_t>(), work.as<double>(), stride, nullptr};
+                os.as<double>(), oJ.as<double>(), ost.as<int32_t>(), oit.as<int32_t>(), work.as<double>(), stride, nullptr, 0};
     srh::DevBuf dbg;
     const bool want_dbg = getenv("SRH_LOCP_TRACE") != nullptr;
     if (want_dbg) { if ((rc = dbg.alloc(sizeof(double) * 8 * 64))) return rc; (void)hipMemset(dbg.p, 0, sizeof(double) * 8 * 64); b.dbg = dbg.as<double>(); }
     const size_t lds = qp_kernel_lds_bytes(d);
     if ((rc = set_lds_limit(locp_entry(d), lds))) return rc;
+    if (d.lean && !getenv("SRH_LOCP_NO_LEAN")) {
+        // lean condensed kernel first; the fused kernel below then only takes what it could not finish (trust region
+        // active at the minimiser, interior point not converged)
+        const size_t llds = lean_kernel_lds_bytes(d);
+        if ((rc = lean_prepare(d, llds)) || (rc = lean_launch_locp(d, C.view(), b, (unsigned)batch, llds, nullptr))) return rc;
+        b.only_pending = 1;
+        if (want_dbg) {
+            SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+            std::vector<double> t(8 * 64);
+            dbg.download(t.data(), sizeof(double) * 8 * 64);
+            fprintf(stderr, "[locp lean] j0 %d lds %zu; status %.0f iters %.0f inside %.0f\n", d.lean_j0, llds, t[8*61+1], t[8*61+2], t[8*61+3]);
+            fprintf(stderr, "[locp lean] laps (SRH_PROFILE build): setup+rollout %.0f rows %.0f condense %.0f stage-factors %.0f gram %.0f cholesky %.0f grad+newton %.0f steps %.0f\n",
+                    t[8*60], t[8*60+1], t[8*60+2], t[8*60+3], t[8*60+4], t[8*60+5], t[8*60+6], t[8*60+7]);
+            fprintf(stderr, "[locp lean] newton laps: gradients %.0f gT_times(1) %.0f rhs+dinv %.0f g_times(1) %.0f k_solve %.0f gT_times(2) %.0f du %.0f g_times(2) %.0f\n",
+                    t[8*59], t[8*59+1], t[8*59+2], t[8*59+3], t[8*59+4], t[8*59+5], t[8*59+6], t[8*59+7]);
+            for (int i = 0; i < 59 && (t[8 * i + 3] != 0.0); ++i)
+                fprintf(stderr, "[locp lean] it %2d mu %.3e rd %.3e rp %.3e (sd %.2e sp %.2e) a_aff %.3e sigma %.3e a %.3e\n", i, t[8 * i], t[8 * i + 1], t[8 * i + 2], t[8 * i + 3], t[8 * i + 4], t[8 * i + 5], t[8 * i + 6], t[8 * i + 7]);
+            (void)hipMemset(dbg.p, 0, sizeof(double) * 8 * 64);
+        }
+    }
     {
         bool launched = false;
 #define X(SP, M, NX) if (!launched && variant_matches(d, SP, M, NX)) { locp_kernel<SP, M, NX><<<(unsigned)batch, NTHREADS, lds>>>(d, C.view(), b); launched = true; }

@@ -2,7 +2,7 @@
 // search, the list of kernel variants.  Everything has internal linkage: each unit carries its own copy.
 #pragma once
 #include "tpwl_host.h"
-#include "locp_dev.h"
+#include "locp_lean.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -15,7 +15,7 @@ namespace {
 constexpr int NTHREADS = 512;
 
 struct QPConstHost {
-    srh::DevBuf H, Qz, Qzf, R, xs, UA, Ub, XA, Xb, XfA, Xfb, Qx, QxN, HtQz2, HtQzf2, R2, Cq, Co, Sc, ScN, Tx, Txf, Cz2, Czf2;
+    srh::DevBuf H, Qz, Qzf, R, xs, UA, Ub, XA, Xb, XfA, Xfb, Qx, QxN, HtQz2, HtQzf2, R2, Cq, Co, Sc, ScN, Tx, Txf, Cz2, Czf2, gram_sched;
     QPDims dims{};
     QPConst view() const {
         QPConst c{};
@@ -27,6 +27,7 @@ struct QPConstHost {
         c.R2 = g(R2);
         c.Cq = g(Cq);
         c.Co = g(Co); c.Sc = g(Sc); c.ScN = g(ScN); c.Tx = g(Tx); c.Txf = g(Txf); c.Cz2 = g(Cz2); c.Czf2 = g(Czf2);
+        c.gram_sched = (cgiptr)gram_sched.as<int>();
         return c;
     }
 };
@@ -61,6 +62,48 @@ static void jacobi_eig(std::vector<double> A, int n, std::vector<double> &w, std
     }
     w.resize(n);
     for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+
+// Gram tile tasks of the lean kernels: tile row I (KT - I upper tiles, k-steps = min(N, 8 (I + 1)) m / 4 each) is cut into
+// chunks of at most 4 tiles whose cost stays near the per-wave share, the chunks go to the waves longest first onto the least
+// loaded wave (waves w and w + 4 share a SIMD: the load of a SIMD is what is balanced).  Output: nw x 4 x {I, J0, nJ, 0}.
+static bool lean_gram_schedule(int N, int m, int KT, int nw, std::vector<int> &out) {
+    struct Task { int I, J0, nJ; double cost; };
+    std::vector<Task> tasks;
+    double total = 0.0;
+    auto ksteps = [&](int I) { return std::min(N, 8 * (I + 1)) * (m / 4); };
+    for (int I = 0; I < KT; ++I) total += (double)(KT - I + 0.5) * ksteps(I);
+    const double share = total / nw;
+    for (int I = 0; I < KT; ++I) {
+        const int nt = KT - I;
+        int per = 4;
+        while (per > 1 && (per + 0.5) * ksteps(I) > 0.8 * share) --per;
+        for (int J = I; J < KT; J += per) {
+            const int nJ = std::min(per, KT - J);
+            tasks.push_back({I, J, nJ, (nJ + 0.5) * ksteps(I)});
+        }
+        (void)nt;
+    }
+    std::sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
+    std::vector<double> load(nw, 0.0);
+    std::vector<int> cnt(nw, 0);
+    out.assign((size_t)nw * 16, 0);
+    for (const Task &t : tasks) {
+        int best = -1;
+        double bl = 0.0;
+        for (int w = 0; w < nw; ++w) {
+            if (cnt[w] >= 4) continue;
+            const double simd = load[w] + (nw > 4 ? load[(w + nw / 2) % nw] : 0.0);      // the two waves of a SIMD
+            const double key = simd + 0.5 * load[w];
+            if (best < 0 || key < bl) { best = w; bl = key; }
+        }
+        if (best < 0) return false;
+        int *o = &out[((size_t)best * 4 + cnt[best]) * 4];
+        o[0] = t.I; o[1] = t.J0; o[2] = t.nJ; o[3] = 0;
+        load[best] += t.cost;
+        ++cnt[best];
+    }
+    return true;
 }
 
 int build_consts(const slocp_problem *pr, QPConstHost &C) {
@@ -133,7 +176,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.max_iter = 60;
     d.tol = 1e-12;
     d.reg = 1e-8;
-    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0; d.diagD = 0;
+    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0; d.diagD = 0; d.lean = 0; d.lean_j0 = 0;
     std::vector<double> Qx(n * n), QxN(n * n), Ht2(n * nz), Htf2(n * nz, 0.0), R2(m * m), xs(n, 1.0);
     std::vector<double> QzH(nz * n), QzfH(nz * n, 0.0);
     for (int a = 0; a < nz; ++a)
@@ -292,6 +335,19 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             d.cond = 1;
             if (qpc::lds_doubles(d, NTHREADS) * sizeof(double) > (size_t)160 * 1024) { d.cond = 0; d.po = 0; d.KT = 0; }
         }
+        // ---- lean kernels (locp_lean.h): p_o = 2, diagonal input Hessians, n_u = 4 or 8, whole W panel variant only;
+        // j0 = the smallest first LDS-resident stage for which the carve fits; the Gram tile tasks of the 8 waves
+        if (d.cond && d.po == 2 && d.diagD && (m == 4 || m == 8) && !d.split && !getenv("SRH_QP_NO_LEAN")) {
+            int j0 = -1;
+            for (int t = 0; t <= N; ++t)
+                if (ql::lds_doubles(d, NTHREADS, t) * sizeof(double) <= (size_t)160 * 1024) { j0 = t; break; }
+            std::vector<int> sched;
+            if (j0 >= 0 && j0 < N && lean_gram_schedule(N, m, d.KT, NTHREADS / 64, sched)) {
+                d.lean = 1;
+                d.lean_j0 = j0;
+                if ((rc = C.gram_sched.upload(sched.data(), sizeof(int) * sched.size()))) return rc;
+            }
+        }
         if (d.cond) {
             if ((rc = up(C.Co, Co.data(), Co.size())) || (rc = up(C.Sc, Sc.data(), Sc.size())) || (rc = up(C.ScN, ScN.data(), ScN.size())) ||
                 (rc = up(C.Tx, Tx.data(), (size_t)pr->nX * po)) || (rc = up(C.Txf, Txf.data(), (size_t)pr->nXf * po)) ||
@@ -305,7 +361,10 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
 // dynamic LDS of a QP / GuSTO kernel: the larger of the two layouts
 inline size_t qp_kernel_lds_bytes(const QPDims &d) {
     const size_t a = qp_lds_bytes(d, NTHREADS), b = d.cond ? qpc::lds_doubles(d, NTHREADS) * sizeof(double) : 0;
-    return std::max(a, b);
+    return srh::lds_request(std::max(a, b));
+}
+inline size_t lean_kernel_lds_bytes(const QPDims &d) {
+    return srh::lds_request(ql::lds_doubles(d, NTHREADS, d.lean_j0) * sizeof(double));
 }
 
 int set_lds_limit(const void *kernel, size_t bytes) {

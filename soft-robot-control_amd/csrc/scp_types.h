@@ -1,0 +1,60 @@
+// Kernel argument blocks shared by the fused kernels (scp.hip, gusto.hip) and the lean condensed kernels (lean.hip), and
+// the launch entry points of the latter (lean.hip is its own translation unit: the variants compile in parallel).
+#pragma once
+#include "scp_host.h"
+
+struct GustoPar {
+    double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh, dt;
+    int max_iters, max_trace;
+};
+
+struct GustoBatch {
+    const double *x0, *u_init, *x_init, *z, *zf, *ud;
+    const double *fs;                   // 1/|f_char| (n)
+    double *xopt, *uopt, *zopt;
+    int32_t *iters, *status;
+    double *trace;
+    double *work;                       // per problem: [qp work | xk | uk | acc | ints | resume record | condensed block]
+    size_t work_stride;
+    const int32_t *order;               // workgroup -> rollout (longest expected solve first), or null
+    int32_t *last_iters;                // SCP iterations of this solve per rollout: the next solve's dispatch key
+    int mode;                           // fused kernel: 0 = solve every rollout, 2 = only those a lean launch handed over
+};
+
+struct LocpBatch {
+    const double *Ad, *AdT, *Bd, *BdT, *dd;     // (batch x N x ...)
+    const double *x0, *xk, *delta, *omega, *z, *zf, *ud;
+    double *x, *u, *s, *J;
+    int32_t *status, *iters;
+    double *work;
+    size_t work_stride;
+    double *dbg;
+    int only_pending;                   // fused kernel: 1 = only the problems a lean launch left with status LEAN_PENDING
+};
+
+namespace {
+
+constexpr int LEAN_PENDING = -77;       // status of a QP / rollout the lean kernel hands to the fused kernel
+constexpr int GUSTO_REC = 8;            // doubles of the resume record behind the SCP loop's index arrays
+
+// offsets (doubles) of the SCP loop's own arrays inside a rollout's work block
+struct GustoWork { size_t xk, uk, acc, idx, rec, end; };
+__host__ __device__ inline GustoWork gusto_work(const QPDims &d) {
+    GustoWork g;
+    const size_t N = d.N, n = d.n, m = d.m;
+    g.xk = qp_work_doubles(d);
+    g.uk = g.xk + (N + 1) * n;
+    g.acc = g.uk + N * m;
+    g.idx = g.acc + 2 * N;
+    g.rec = g.idx + (2 * N + 1) / 2;
+    g.end = g.rec + GUSTO_REC;
+    return g;
+}
+
+}  // namespace
+
+// lean.hip
+int lean_prepare(const QPDims &d, size_t lds);
+int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
+                      size_t lds, hipStream_t stream);
+int lean_launch_locp(const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream);

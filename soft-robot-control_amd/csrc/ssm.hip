@@ -259,7 +259,7 @@ int sssm_create(sssm_t **out, int n_x, int n_u, int n_o, int rom_order, int ssm_
         }
         h->has_discrete = true;
     }
-    h->lds = lds_bytes(h);
+    h->lds = srh::lds_request(lds_bytes(h));
     if (h->lds > 160 * 1024) {
         delete h;
         srh::set_error("sssm_create: the polynomial basis does not fit the 160 KB LDS");

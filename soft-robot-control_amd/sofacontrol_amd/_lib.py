@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsofacontrol_hip.so')
+# SRH_LIB_PATH: another build of the same library (e.g. a -DSRH_PROFILE build for tools/probes/*); default = the in-tree one
+LIB_PATH = os.environ.get('SRH_LIB_PATH') or os.path.join(_HERE, 'libsofacontrol_hip.so')
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -1,0 +1,60 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'soft-robot-control_amd'), os.path.join(ROOT, 'tests')]
+import numpy as np
+import workloads as wl
+import test_lean_gpu as T
+from oracle import gusto as ogusto, tpwl as otpwl
+which = sys.argv[1] if len(sys.argv) > 1 else 'c5'
+w = wl.diamond_c2() if which == 'c2' else wl.trunk_c5()
+qp = T.first_qp(w, b=0, B=8, seed=9 if which == 'c5' else 2)
+model = dict(w['tab'], w_q=1.0, w_v=0.0)
+for it in range(3):
+    rl = T.locp_solve(w, qp, 1e4, True)
+    rf = T.locp_solve(w, qp, 1e4, False)
+    print('QP %d: lean J %.10e it %d | fused J %.10e it %d | rel x %.2e u %.2e' % (it, rl[0], rl[2], rf[0], rf[2], T.rel(rl[3], rf[3]), T.rel(rl[4], rf[4])))
+    xk = rf[3]
+    A_k, B_k, d_k, idx = ogusto.traj_dynamics(model, w['Ad'], w['Bd'], w['dd'], xk)
+    print('   regions', idx[:20], 'changes', int((np.diff(idx) != 0).sum()))
+    qp = dict(qp, A=A_k, B=B_k, d=d_k, xk=xk)
+# where do lean and fused differ on QP 1?
+qp = T.first_qp(w, b=0, B=8, seed=9 if which == 'c5' else 2)
+rf = T.locp_solve(w, qp, 1e4, False)
+xk = rf[3]
+A_k, B_k, d_k, idx = ogusto.traj_dynamics(model, w['Ad'], w['Bd'], w['dd'], xk)
+qp = dict(qp, A=A_k, B=B_k, d=d_k, xk=xk)
+rl = T.locp_solve(w, qp, 1e4, True); rf = T.locp_solve(w, qp, 1e4, False)
+np.set_printoptions(linewidth=200, precision=3, suppress=True)
+print('regions', idx)
+du = np.abs(rl[4] - rf[4]).max(axis=1)
+print('max |du| per stage', du)
+print('lean u[0:3]', rl[4][:3]); print('fused u[0:3]', rf[4][:3])
+# same QP with xk replaced by the zero-input rollout (only the trust-region test sees xk)
+qp2 = dict(qp, xk=T.first_qp(w, b=0, B=8, seed=9 if which == 'c5' else 2)['xk'])
+rl2 = T.locp_solve(w, qp2, 1e4, True)
+print('lean with the other xk: J %.10e' % rl2[0])
+# consistency of the lean result: x against a host rollout of its u; J from both
+def host_rollout(A, B, d, x0, u):
+    x = [x0]
+    for k in range(len(A)):
+        x.append(A[k] @ x[-1] + B[k] @ u[k] + d[k])
+    return np.array(x)
+for name, r in (('lean', rl), ('fused', rf)):
+    xh = host_rollout(A_k, B_k, d_k, qp['x0'], r[4])
+    e = (w['H'] @ xh.T).T - qp['z']
+    Jh = np.einsum('ka,ab,kb->', e, w['Qz'], e) + np.einsum('ka,ab,kb->', r[4], w['R'], r[4])
+    print(name, 'x vs host rollout of its own u: %.2e;  J reported %.10e  J host %.10e' % (np.abs(xh - r[3]).max(), r[0], Jh))
+for name, r in (('lean', rl), ('fused', rf)):
+    e = (w['H'] @ r[3].T).T - qp['z']
+    Jd = np.einsum('ka,ab,kb->', e, w['Qz'], e) + np.einsum('ka,ab,kb->', r[4], w['R'], r[4])
+    print(name, 'objective of the returned (x, u): %.10e' % Jd)
+xh = host_rollout(A_k, B_k, d_k, qp['x0'], rl[4])
+print('per-stage |x_lean - rollout(u_lean)|', np.abs(xh - rl[3]).max(axis=1)[:14])
+print('per-stage |x_lean - x_fused|', np.abs(rf[3] - rl[3]).max(axis=1)[:14])
+xz = host_rollout(A_k, B_k, d_k, qp['x0'], 0 * rl[4])
+print('per-stage |x_lean - zero-input rollout|', np.abs(xz - rl[3]).max(axis=1)[:14])
+print('per-stage |x_lean - rollout(u_lean)| all', np.abs(xh - rl[3]).max(axis=1))
+print('regions', idx)
+np.set_printoptions(precision=6, suppress=True)
+print('returned lean u[40][0..3]', rl[4][40][:4], 'x[41][0..1]', rl[3][41][:2], 'x[40][:2]', rl[3][40][:2])
+print('host x41 from returned x40,u40', (A_k[40] @ rl[3][40] + B_k[40] @ rl[4][40] + d_k[40])[:2], ' with stage-0 matrices:', (A_k[0] @ rl[3][40] + B_k[0] @ rl[4][40] + d_k[0])[:2])
