@@ -60,12 +60,15 @@ def usable_cpus():
 
 def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
     """The CPU side of the same workload on a bounded sample, on this box's host cores (oracle/ only: never the product):
-      * native twin (oracle/csrc/sofacontrol_cpu.cpp: stage-structured Riccati interior point with the kernel's
-        trust-region prescreen, nearest-point TPWL, the GuSTO loop) on ONE thread and on ALL cores, one rollout per thread;
+      * native twin (oracle/csrc/sofacontrol_cpu.cpp) running THE ALGORITHM OF THE GPU KERNEL -- condensed (output-space)
+        interior point for the QP without its trust-region rows, stage-wise Riccati interior point of the full QP when
+        that minimiser leaves the trust region, nearest-point TPWL, the GuSTO loop -- on ONE thread and on ALL usable
+        cores (one rollout per thread);
+      * the same twin with the stage-wise Riccati interior point throughout (round 1's algorithm), one thread;
       * the numpy port (oracle.gusto around oracle.riccati_ipm) on a few rollouts;
       * the reference's solver class -- OSQP at cvxpy's default tolerances -- as restated in oracle.locp.solve_osqp, on
         the first QP of the first rollout: what it costs in ADMM iterations and what accuracy it delivers.
-    `value` is the all-cores native number (the strongest CPU figure); `cores` = threads actually used."""
+    `value` is the all-cores condensed number (the strongest CPU figure); `cores` = threads actually used."""
     from oracle import gusto as ogusto, pod as opod, locp as olocp, tpwl as otpwl, cpu_twin
     import workloads as wl
     model = dict(w['tab'], w_q=1.0, w_v=0.0)
@@ -73,16 +76,17 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
     kw = dict(z=None, U=(w['UA'], w['Ub']), X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, max_gusto_iters=max_iters)
     u0 = np.zeros((n_roll, N, m))
 
-    def twin(nr, threads):
+    def twin(nr, threads, algo):
         t0 = time.perf_counter()
         xo, uo, it, _ = cpu_twin.gusto_solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, w['dt'], w['Qz'], w['R'], x0[:nr], u0[:nr],
-                                             x_init[:nr], **dict(kw, z=z[:nr]), threads=threads)
+                                             x_init[:nr], **dict(kw, z=z[:nr]), threads=threads, algo=algo)
         return time.perf_counter() - t0, xo, uo, it
     cpu_twin.lib()
     ncpu = usable_cpus()
-    t1, xo1, uo1, it1 = twin(min(6, n_roll), 1)
-    nall = min(n_roll, 4 * ncpu)
-    tall, xoa, uoa, ita = twin(nall, ncpu)
+    t1, xo1, uo1, it1 = twin(min(16, n_roll), 1, 'condensed')
+    tr1, _, _, itr1 = twin(min(4, n_roll), 1, 'riccati')
+    nall = min(n_roll, 16 * ncpu)
+    tall, xoa, uoa, ita = twin(nall, ncpu, 'condensed')
     sols = [(xoa[b], uoa[b], int(ita[b])) for b in range(nall)]
     # numpy port, a few rollouts
     nnp = min(3, n_roll)
@@ -127,12 +131,17 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
     except Exception:
         pass
     out = dict(value=float(ita.sum()) / tall, unit='SCP iterations/s', cores=ncpu, kind='port',
+               algorithm='condensed (output-space) interior point + Riccati interior point for trust-region-active QPs: the algorithm of '
+                         'the GPU kernels (oracle/condensed_ipm.py, csrc/locp_lean.h); native C++, -O3 -march=x86-64-v3, no BLAS',
                host='%s, %d logical CPUs, %d usable by this process (affinity / cgroup quota)' % (cpu, os.cpu_count() or 1, ncpu),
-               sample='native CPU twin (oracle/csrc), one rollout per thread: %d rollouts = %d SCP iterations in %.2f s on %d threads; '
-                      'single thread: %d rollouts = %d SCP iterations in %.2f s' % (nall, int(ita.sum()), tall, ncpu, len(it1), int(it1.sum()), t1),
+               sample='native CPU twin (oracle/csrc), condensed algorithm, one rollout per thread: %d rollouts = %d SCP iterations in %.2f s on '
+                      '%d threads; single thread: %d rollouts = %d SCP iterations in %.2f s' %
+                      (nall, int(ita.sum()), tall, ncpu, len(it1), int(it1.sum()), t1),
                single_thread=dict(scp_iterations_per_s=float(it1.sum()) / t1, ms_per_scp_iteration=t1 / float(it1.sum()) * 1e3,
-                                  ms_per_solve=t1 / len(it1) * 1e3, rollouts=len(it1)),
-               all_cores=dict(scp_iterations_per_s=float(ita.sum()) / tall, threads=ncpu, rollouts=nall, seconds=tall),
+                                  ms_per_solve=t1 / len(it1) * 1e3, rollouts=len(it1), algorithm='condensed'),
+               all_cores=dict(scp_iterations_per_s=float(ita.sum()) / tall, threads=ncpu, rollouts=nall, seconds=tall, algorithm='condensed'),
+               riccati_single_thread=dict(scp_iterations_per_s=float(itr1.sum()) / tr1, ms_per_scp_iteration=tr1 / float(itr1.sum()) * 1e3,
+                                          rollouts=len(itr1), algorithm='stage-wise Riccati interior point throughout (rounds 1-2 baseline)'),
                numpy_port=dict(scp_iterations_per_s=np_iters / t_np, rollouts=nnp, seconds=t_np,
                                what='oracle.gusto around oracle.riccati_ipm (numpy + BLAS threads)'),
                osqp_restated_eps1e_5=dict(what='oracle.locp.solve_osqp (published OSQP algorithm, cvxpy defaults eps_abs = eps_rel = 1e-5, no polish) '
@@ -329,13 +338,13 @@ def secondary(L, _lib, rank, world, dist):
     from sofacontrol_amd.utils import QuadraticCost
     out = {}
     # ---- C3
-    n, m, N, dt, Bn = 10, 8, 100, 0.01, 256
+    n, m, N, dt, Bn = 10, 8, 100, 0.05, 256          # C3 at dt = 0.05 (examples/trunk/trunk.py:365)
     model = wl.ssm_model(n, m, 3, 2, seed=95)
 
     def mat(v):
         a = np.empty((1, 1), dtype=object); a[0, 0] = np.asarray(v); return a
     sc = lambda v: mat(np.array([[v]]))
-    s = SSMDynamics(model['z_ref'].copy(), discrete=False, discr_method='fe',
+    s = SSMDynamics(model['z_ref'].copy(), discrete=False, discr_method='be',
                     model=dict(Ts=sc(dt), w_coeff=mat(model['W']), v_coeff=mat(model['V']), r_coeff=mat(model['R']),
                                B=mat(model['B']), rd_coeff=mat(model['Rd']), Bd=mat(model['Bd'])),
                     params=dict(state_dim=sc(n), input_dim=sc(m), output_dim=sc(n), SSM_order=sc(2), ROM_order=sc(3)))
@@ -537,9 +546,18 @@ def main():
     zi = interp1d(w['t'], w['z'], axis=0, bounds_error=False, fill_value=(w['z'][0], w['z'][-1]))
     phase = (np.arange(R_) + R_ * rank) * (10.0 / max(1, R_ * world))
     z = np.stack([zi(phase[b] + dt * np.arange(N + 1)) for b in range(R_)])
+    _lib.sync()
+    t_ctor = time.perf_counter()
     gusto = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']),
                   X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, batch=R_, max_trace=0,
                   max_gusto_iters=args.max_gusto_iters)
+    t_ctor = time.perf_counter() - t_ctor
+    # the constructor solves with the reference's default cap of 500 SCP iterations (gusto.py:142-147): its throughput is
+    # reported next to the capped (real-time iteration) headline; host buffers + plan creation inside this wall time
+    uncapped = {'what': 'GuSTO constructor: plan creation + one solve of the %d rollouts at the reference-default cap of 500 SCP '
+                        'iterations (trust-region-active QPs included), host buffers' % R_,
+                'seconds': t_ctor, 'scp_iterations': int(gusto.iters.sum()), 'max_iterations_of_a_rollout': int(gusto.iters.max()),
+                'scp_iterations_per_s': float(gusto.iters.sum()) / t_ctor, 'not_converged': int((gusto.status != 0).sum())}
     gusto.max_gusto_iters = args.max_gusto_iters
     _lib.check(L.sgusto_plan_set_max_iters(gusto.plan, C.c_int(args.max_gusto_iters)), 'set_max_iters')
     d = {k: _lib.DeviceBuffer.from_array(v) for k, v in dict(x0=x0, u_init=u_init, x_init=x_init, z=z).items()}
@@ -550,12 +568,18 @@ def main():
         _lib.check(L.srh_event_create(C.byref(e)), 'event')
 
     def step(timed):
+        """One pass of the hot path over one batch, everything resident: POD projection of the snapshot batch -> reduced
+        states x0 = [0 ; q_r] of the first R rows (utils.qv2x) -> zero-input TPWL rollout = the initial guess of the solve
+        (scp/ros.py:78-79) -> the receding-horizon SCP solves.  Nothing visits the host in between."""
         for i in range(args.proj_launches):
             if timed:
                 L.srh_event_record(ev[2 * i], None)
             _lib.check(L.srom_project_dev(rom.handle, 0, dX.ptr, C.c_int64(B), C.c_int64(n_f), dXr.ptr, C.c_int64(r), None), 'project')
             if timed:
                 L.srh_event_record(ev[2 * i + 1], None)
+        _lib.check(L.srom_qv2x_dev(dXr.ptr, C.c_int64(r), None, C.c_int64(0), C.c_int64(R_), C.c_int(r), d['x0'].ptr, C.c_int64(n), None), 'qv2x')
+        _lib.check(L.stpwl_rollout_dev(tp.handle_for(dt), d['x0'].ptr, d['u_init'].ptr, C.c_int(N), C.c_int64(R_), d['x_init'].ptr, None, None),
+                   'rollout')
         _lib.check(L.sgusto_plan_solve_dev(gusto.plan, d['x0'].ptr, d['u_init'].ptr, d['x_init'].ptr, d['z'].ptr, None, None,
                                            o['xopt'].ptr, o['uopt'].ptr, o['zopt'].ptr, o['iters'].ptr, o['status'].ptr,
                                            None, None), 'gusto')
@@ -621,13 +645,16 @@ def main():
     alg_bytes = B * n_f * 8 + n_f * r * 8 + n_f * 8 + B * r * 8
     # HBM traffic of the same kernel at the same shape from PMC counters (separate rocprofv3 --pmc passes,
     # corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_proj_pmc.json')))
-        if pmc.get('algorithmic_bytes_per_launch') == alg_bytes:
-            traffic = pmc['traffic_bytes_per_launch']
-    except Exception:
-        traffic = None
+    traffic, traffic_source = None, None
+    for name in ('r03_proj_pmc.json', 'r02_proj_pmc.json'):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            if pmc.get('algorithmic_bytes_per_launch') == alg_bytes:
+                traffic = pmc['traffic_bytes_per_launch']
+                traffic_source = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; not measured in this run)' % name
+                break
+        except Exception:
+            pass
     avg_ms = float(np.mean(proj_ms))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     out = {
@@ -642,17 +669,20 @@ def main():
                    'solves_not_converged_rank0': int((status != 0).sum())},
         'roofline': {'kernel': 'proj_kernel (srom_project_dev)', 'bound': 'hbm', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': alg_bytes},
+                     'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': alg_bytes, 'traffic_source': traffic_source},
     }
+    if sec is not None and isinstance(sec, dict):
+        sec['scp_uncapped_500'] = uncapped
     if world == 1 and not args.no_cpu_baseline:
+      try:
         out['cpu_baseline'], sols, np_sols = cpu_baseline(w, x0, x_init, z, xc, fc, n_roll=R_, proj_rows=4096,
                                                           max_iters=args.max_gusto_iters)
         rel = lambda a, b: float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
         n_par = min(n_par, len(sols))
         out['parity_sample'] = {
             'what': 'trajectories and SCP iteration counts of the timed GPU launch vs the numpy oracle (oracle.gusto around '
-                    'oracle.riccati_ipm; first %d rollouts) and vs the native CPU twin (first %d rollouts) on the same inputs' %
-                    (len(np_sols), n_par),
+                    'oracle.riccati_ipm; first %d rollouts) and vs the native CPU twin (condensed algorithm; first %d rollouts) on the '
+                    'same inputs' % (len(np_sols), n_par),
             'kernel_variant': list(gusto.variant),
             'max_rel_traj': max(max(rel(gx[b], np_sols[b][0]), rel(gu[b], np_sols[b][1])) for b in range(len(np_sols))),
             'iters_equal': bool(all(int(iters[b]) == np_sols[b][2] for b in range(len(np_sols)))),
@@ -661,11 +691,21 @@ def main():
         cb = out['cpu_baseline']
         if sec is not None and 'scp_single_rollout' in sec:
             g1 = sec['scp_single_rollout']
-            cb['gpu_vs_cpu'] = {'throughput_vs_all_cores': out['value'] / cb['value'],
+            cb['gpu_vs_cpu'] = {'what': 'both sides run the same algorithm (condensed interior point; Riccati for trust-region-active QPs)',
+                                'throughput_vs_all_cores': out['value'] / cb['value'],
                                 'throughput_vs_single_thread': out['value'] / cb['single_thread']['scp_iterations_per_s'],
                                 'single_rollout_ms_per_scp_iteration': {'gpu': g1['ms_per_scp_iteration'],
                                                                         'cpu_single_thread': cb['single_thread']['ms_per_scp_iteration'],
-                                                                        'ratio': cb['single_thread']['ms_per_scp_iteration'] / g1['ms_per_scp_iteration']}}
+                                                                        'ratio': cb['single_thread']['ms_per_scp_iteration'] / g1['ms_per_scp_iteration'],
+                                                                        'cpu_riccati_single_thread': cb['riccati_single_thread']['ms_per_scp_iteration']}}
+            # BASELINE.md holds no published number for this metric (the reference reports none): following the round-2 review,
+            # vs_baseline = the north star's own ratio -- wall clock of ONE SCP iteration of one Diamond solve on the CPU (one
+            # core, same algorithm) over the same on one MI355X (one rollout at a time, host buffers)
+            out['vs_baseline'] = cb['gpu_vs_cpu']['single_rollout_ms_per_scp_iteration']['ratio']
+            out['vs_baseline_definition'] = ('no published reference number exists (BASELINE.md); this is CPU-twin ms per SCP iteration (one core, '
+                                             'condensed algorithm = the GPU kernel\'s) / GPU ms per SCP iteration, one Diamond C2 rollout at a time')
+      except Exception as exc:            # never lose the headline line to the CPU leg
+        out['cpu_baseline'] = {'error': repr(exc)}
     if sec is not None:
         out['secondary'] = sec
     print(json.dumps(out))

@@ -78,6 +78,11 @@ int srom_dims(const srom_t *h, int64_t *n_f, int *r);
 int srom_project(srom_t *h, int which, const double *X, int64_t B, double *out);
 int srom_project_dev(srom_t *h, int which, const double *X_dev, int64_t B, int64_t ldx,
                      double *out_dev, int64_t ldo, void *stream);
+/* utils.qv2x (sofacontrol/utils.py:129-130) on resident reduced coordinates: x (B x 2r, row pitch ldx) = [v ; q] from
+ * q_dev (B x r, pitch ldq) and v_dev (B x r, pitch ldv; NULL: zero velocities) -- what the controllers do with the two
+ * halves of compute_RO_state before the model / solver sees a reduced state (tpwl/controllers.py:96). */
+int srom_qv2x_dev(const double *q_dev, int64_t ldq, const double *v_dev, int64_t ldv, int64_t B, int r,
+                  double *x_dev, int64_t ldx, void *stream);
 
 /* POD.compute_FO_state (pod.py:22-37), batched: Xr (B x r | B x 2r) -> out (B x n_f | B x 2 n_f). */
 int srom_lift(srom_t *h, int which, const double *Xr, int64_t B, double *out);
@@ -145,6 +150,10 @@ int stpwl_linearize_weighted(stpwl_t *h, const double *X, int64_t B, double beta
  * x0 (batch x n_x), U (batch x N x n_u) -> X (batch x (N+1) x n_x), Z (batch x (N+1) x n_z) or NULL */
 int stpwl_rollout(stpwl_t *h, const double *x0, const double *U, int N, int64_t batch, double *X,
                   double *Z);
+/* the same on resident buffers, asynchronous on `stream` (Z_dev may be NULL): the zero-input initial guess of a
+ * receding-horizon solve (scp/ros.py:78-79) without leaving the device */
+int stpwl_rollout_dev(stpwl_t *h, const double *x0_dev, const double *U_dev, int N, int64_t batch,
+                      double *X_dev, double *Z_dev, void *stream);
 /* TPWLGuSTO.get_characteristic_vals (scp/models/tpwl.py:66-84): x_char, f_char (n_x,) */
 int stpwl_characteristic(stpwl_t *h, double *x_char, double *f_char);
 

@@ -605,6 +605,13 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
         }
     };
 
+    // The reference restarts the backward pass with a larger rho for as long as Q~_uu is not positive definite
+    // (ilqr.py:276-287) -- for ever when the trajectory has gone non-finite (an unstable discretisation: every Cholesky
+    // of NaNs fails).  On the device that would hang the GPU: rho saturates at rho_max after ~30 increases, so after
+    // MAX_RESTARTS consecutive failures of one backward pass the problem is given up (iters = -1, cost as it stands).
+    constexpr int MAX_RESTARTS = 100;
+    int restarts = 0;
+    bool diverged = false;
     // c_xx = H^T Q H (constant), terminal uses Qf
     // backward pass (ilqr.py:219-300) on the trajectory (X, U, idx); writes K2? no: Kout, kff, Qu, Quu
     auto backward = [&]() {
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 }
                 if (!ok) { restart = true; break; }
             }
-            if (restart) continue;
+            if (restart) { if (++restarts > MAX_RESTARTS) { diverged = true; break; } continue; }
             reg_update(false);
             break;
         }
@@ -967,7 +974,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 for (int e = tid; e < n; e += nt) L.v1[e] = L.v3[e];
                 __syncthreads();
             }
-            if (restart) continue;
+            if (restart) { if (++restarts > MAX_RESTARTS) { diverged = true; break; } continue; }
             reg_update(false);
             break;
         }
@@ -991,8 +998,10 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     bool converged = false;
     while (!converged && it <= P_.max_iter) {
         IL_T0();
+        restarts = 0;
         if (a.mfma) backward_m(); else backward();
         IL_ACC(tb);
+        if (diverged) break;
         const double prev_cost = cost;
         double alpha = P_.alpha0, new_cost = cost;
         bool improved = false, failed = false;
@@ -1046,7 +1055,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
         }
         ++it;
     }
-    if (tid == 0) { a.cost[p] = cost; a.iters[p] = it; }
+    if (tid == 0) { a.cost[p] = cost; a.iters[p] = diverged ? -1 : it; }
 #ifdef SRH_PROFILE
     if (tid == 0 && p == 0) printf("[ilqr] forward laps per step: control %.0f zerr %.0f jacobians %.0f discretize %.0f cost+store+update %.0f\n",
                                    (double)fp[0] / (nf + 1) / N, (double)fp[1] / (nf + 1) / N, (double)fp[2] / (nf + 1) / N, (double)fp[3] / (nf + 1) / N, (double)fp[4] / (nf + 1) / N);

@@ -674,7 +674,30 @@ static int launch_lift(const LiftArgs &a, int mt, dim3 grid, hipStream_t s) {
     return SRH_OK;
 }
 
+namespace {
+// x = [v ; q] rows from reduced velocities / positions (utils.qv2x): a strided copy, one row per workgroup column
+__global__ void qv2x_kernel(const double *__restrict__ q, int64_t ldq, const double *__restrict__ v, int64_t ldv, int64_t B, int r,
+                            double *__restrict__ x, int64_t ldx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * 2 * r) return;
+    const int64_t b = e / (2 * r);
+    const int j = (int)(e - b * 2 * r);
+    x[b * ldx + j] = j < r ? (v ? v[b * ldv + j] : 0.0) : q[b * ldq + (j - r)];
+}
+}  // namespace
+
 extern "C" {
+
+int srom_qv2x_dev(const double *q_dev, int64_t ldq, const double *v_dev, int64_t ldv, int64_t B, int r, double *x_dev, int64_t ldx,
+                  void *stream) {
+    SRH_REQUIRE(q_dev && x_dev && B >= 0 && r >= 1 && ldq >= r && ldx >= 2 * r && (v_dev == nullptr || ldv >= r),
+                "srom_qv2x_dev: bad argument");
+    if (B == 0) return SRH_OK;
+    qv2x_kernel<<<(unsigned)srh::cdiv(B * 2 * r, 256), 256, 0, (hipStream_t)stream>>>(q_dev, ldq, v_dev, ldv, B, r, x_dev, ldx);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
 
 int srom_create(srom_t **out, const double *U, int64_t n_f, int r, const double *q_ref,
                 const double *v_ref) {

@@ -364,6 +364,19 @@ int stpwl_rollout(stpwl_t *h, const double *x0, const double *U, int N, int64_t 
     return SRH_OK;
 }
 
+int stpwl_rollout_dev(stpwl_t *h, const double *x0_dev, const double *U_dev, int N, int64_t batch, double *X_dev, double *Z_dev,
+                      void *stream) {
+    SRH_REQUIRE(h && x0_dev && U_dev && X_dev, "stpwl_rollout_dev: null argument");
+    SRH_REQUIRE(h->has_discrete, "stpwl_rollout_dev: model has not been pre-discretised");
+    SRH_REQUIRE(N >= 0 && batch >= 0, "stpwl_rollout_dev: negative size");
+    SRH_REQUIRE(Z_dev == nullptr || h->nz > 0, "stpwl_rollout_dev: Need to set output or meas. model");
+    if (batch == 0) return SRH_OK;
+    const size_t lds = sizeof(double) * (2 * h->n + ((h->m + 3) & ~3) + 256) + 16;
+    rollout_kernel<<<(unsigned)batch, 256, lds, (hipStream_t)stream>>>(h->view(), x0_dev, U_dev, N, X_dev, Z_dev);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
 int stpwl_characteristic(stpwl_t *h, double *x_char, double *f_char) {
     SRH_REQUIRE(h && x_char && f_char, "stpwl_characteristic: null argument");
     const int n = h->n;

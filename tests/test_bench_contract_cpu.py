@@ -19,7 +19,10 @@ def test_bench_line_schema():
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
-    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic'
+    # BASELINE.md holds no published number: null, or (round 3, as the round-2 review asked) the CPU / GPU single-solve ratio
+    # with its definition spelled out in the line
+    assert d['vs_baseline'] is None or (d['vs_baseline'] > 0 and isinstance(d.get('vs_baseline_definition'), str))
     assert d['dtype'] == 'f64' and 'workload' in d['config'] and 'model' not in d['config']
     if isinstance(base.get('metric'), str):
         assert d['metric'] == base['metric'] or base['metric'] in d['metric'] or d['metric'] in base['metric']
