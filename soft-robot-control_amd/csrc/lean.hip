@@ -22,6 +22,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     qp::specialise<MSEL, NSEL>(d);
     ql::Lds L;
     ql::lds_carve(L, (lptr)smem, d, NTHREADS);
+    if (threadIdx.x == 0) L.flag[2] = 0;               // no condensation in LDS yet (ql::ipm)
     const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
     qp::specialise<MSEL, NSEL>(d);
     ql::Lds L;
     ql::lds_carve(L, (lptr)smem, d, NTHREADS);
+    if (threadIdx.x == 0) L.flag[2] = 0;
 #ifdef QL_POISON
     {   // debug build: every LDS word starts as a NaN, the problem's work block as NaNs too
         const size_t total = ql::lds_doubles(d, NTHREADS, d.lean_j0);

@@ -167,43 +167,63 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
     const int MT = NPa >> 4;
     const int KS = (n + 3) >> 2;
     const int goff0 = goff(j0, m, NP);
+    // Work items of a stage = (column tile ti of Theta^T that already has columns, row tile ci of [A | B]^T): spread over
+    // ALL waves (a wave per column tile left most SIMDs idle late in the recursion, when few output stages are "born").
+    // Phase A: every wave multiplies its items (operands from LDS, results in registers); barrier; phase B: results into
+    // Theta^T / the packed G, the C_o columns of the next output stage, the panel of the next stage if its region differs.
+    (void)qp::panel_load(d, dyn, P, N - 1);
+    for (int e = tid; e < po * n; e += nt) { const int a = e / n, r = e - a * n; L.B[r * ldT + (N - 1) * po + a] = c.Co[(size_t)a * n + r]; }
+    __syncthreads();
+    constexpr int KSMAX = NSEL > 0 ? (NSEL + 3) / 4 : 32;
     for (int j = N - 1; j >= 0; --j) {
-        const int sel = __builtin_amdgcn_readfirstlane(L.idxl[j]);
-        const bool reload = dyn.idx == nullptr || __builtin_amdgcn_readfirstlane(P.psel) != sel;
-        if (reload) __syncthreads();
-        if (qp::panel_load(d, dyn, P, j)) __syncthreads();
         const int t_first = (j * po) >> 4;
+        const int count = (KT - t_first) * MT;
         const int len = NP - po * j, gj = goff(j, m, NP);
-        for (int ti = wave; ti < KT; ti += nw) {
-            if (ti < t_first) continue;
-            for (int e = lane; e < po * n; e += 64) {
-                const int a = e / n, r = e - a * n, i = j * po + a;
-                if ((i >> 4) == ti) L.B[r * ldT + i] = c.Co[(size_t)a * n + r];
-            }
-            __builtin_amdgcn_wave_barrier();
-            constexpr int KSMAX = NSEL > 0 ? (NSEL + 3) / 4 : 32;
-            double bop[KSMAX];
+        constexpr int RMAX = 5;                          // item slots per wave: KT * MT <= 8 * 5 items over 8 waves
+        wg::qp_d4 acc[RMAX];
 #pragma unroll
-            for (int s = 0; s < KSMAX; ++s) bop[s] = s < KS ? L.B[(4 * s + kk) * ldT + 16 * ti + l16] : 0.0;
-            for (int ci = 0; ci < MT; ++ci) {
-                wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < RMAX; ++r) {
+            acc[r] = {0.0, 0.0, 0.0, 0.0};
+            const int it = wave + nw * r;
+            if (it < count) {
+                const int ti = t_first + it / MT, ci = it - (it / MT) * MT;
+                double aop[KSMAX], bop[KSMAX];
+#pragma unroll
+                for (int s = 0; s < KSMAX; ++s) {
+                    aop[s] = s < KS ? L.panel[(4 * s + kk) * ld + 16 * ci + l16] : 0.0;
+                    bop[s] = s < KS ? L.B[(4 * s + kk) * ldT + 16 * ti + l16] : 0.0;
+                }
 #pragma unroll
                 for (int s = 0; s < KSMAX; ++s)
-                    if (s < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L.panel[(4 * s + kk) * ld + 16 * ci + l16], bop[s], acc, 0, 0, 0);
+                    if (s < KS) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s], bop[s], acc[r], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int it = wave + nw * r;
+            if (it < count) {
+                const int ti = t_first + it / MT, ci = it - (it / MT) * MT;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = 16 * ci + kk + 4 * q, i = 16 * ti + l16;
-                    if (row < n) {
-                        L.B[row * ldT + i] = acc[q];
-                    } else if (row < n + m && i >= po * j && i < NP) {
-                        const int at = gj + (row - n) * len + (i - po * j);
-                        if (j < j0) gh[at] = acc[q]; else L.Gt[at - goff0] = acc[q];
+                    if (i >= po * j && i < NP) {                 // columns of the output stages k > j ("born")
+                        if (row < n) {
+                            L.B[row * ldT + i] = acc[r][q];
+                        } else if (row < n + m) {
+                            const int at = gj + (row - n) * len + (i - po * j);
+                            if (j < j0) gh[at] = acc[r][q]; else L.Gt[at - goff0] = acc[r][q];
+                        }
                     }
                 }
             }
         }
+        if (j > 0) {
+            for (int e = tid; e < po * n; e += nt) { const int a = e / n, r = e - a * n; L.B[r * ldT + (j - 1) * po + a] = c.Co[(size_t)a * n + r]; }
+            (void)qp::panel_load(d, dyn, P, j - 1);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------ products with G
@@ -447,6 +467,66 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     __syncthreads();
 }
 
+// v <- K^-1 v by wave 0 (qpc::k_solve with another lane layout): lane = 4 c + part, the four partial sums of an entry sit in
+// adjacent lanes and are added by two DPP moves instead of two ds_bpermute round trips per tile row.
+__device__ __forceinline__ void k_solve(const QPDims &d, Lds &L, lptr v) {
+    const int KT = d.KT, tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        const int c = lane >> 2, part = lane & 3;
+        for (int J = 0; J < KT; ++J) {                                   // forward: R^T z = v
+            double acc = 0.0, acc2 = 0.0;
+            for (int I = 0; I < J; ++I) {
+                clptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ;
+                acc = fma(T[(4 * part) * TS + c], v[16 * I + 4 * part], acc);
+                acc2 = fma(T[(4 * part + 1) * TS + c], v[16 * I + 4 * part + 1], acc2);
+                acc = fma(T[(4 * part + 2) * TS + c], v[16 * I + 4 * part + 2], acc);
+                acc2 = fma(T[(4 * part + 3) * TS + c], v[16 * I + 4 * part + 3], acc2);
+            }
+            acc += acc2;
+            acc += wg::dpp_mov<0xB1>(acc);
+            acc += wg::dpp_mov<0x4E>(acc);
+            const double tmp = v[16 * J + c] - acc;
+            __builtin_amdgcn_wave_barrier();
+            if (part == 0) L.Qu[c] = tmp;
+            __builtin_amdgcn_wave_barrier();
+            clptr Ri = L.Rinv + (size_t)J * TSZ;
+            double z = 0.0;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) { const int k = 4 * part + kq; z = fma(Ri[k * TS + c], L.Qu[k], z); }     // Rinv^T
+            z += wg::dpp_mov<0xB1>(z);
+            z += wg::dpp_mov<0x4E>(z);
+            __builtin_amdgcn_wave_barrier();
+            if (part == 0) v[16 * J + c] = z;
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int J = KT - 1; J >= 0; --J) {                              // backward: R x = z
+            double acc = 0.0, acc2 = 0.0;
+            for (int Jp = J + 1; Jp < KT; ++Jp) {
+                clptr T = L.B + (size_t)qpc::tile_index(J, Jp, KT) * TSZ + c * TS + 4 * part;
+                clptr vv = v + 16 * Jp + 4 * part;
+                acc = fma(T[0], vv[0], acc); acc2 = fma(T[1], vv[1], acc2); acc = fma(T[2], vv[2], acc); acc2 = fma(T[3], vv[3], acc2);
+            }
+            acc += acc2;
+            acc += wg::dpp_mov<0xB1>(acc);
+            acc += wg::dpp_mov<0x4E>(acc);
+            const double tmp = v[16 * J + c] - acc;
+            __builtin_amdgcn_wave_barrier();
+            if (part == 0) L.Qu[c] = tmp;
+            __builtin_amdgcn_wave_barrier();
+            clptr Ri = L.Rinv + (size_t)J * TSZ + c * TS + 4 * part;
+            double z = 0.0;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) z = fma(Ri[kq], L.Qu[4 * part + kq], z);                                   // Rinv
+            z += wg::dpp_mov<0xB1>(z);
+            z += wg::dpp_mov<0x4E>(z);
+            __builtin_amdgcn_wave_barrier();
+            if (part == 0) v[16 * J + c] = z;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+}
+
 // Newton direction (qpc::newton_solve with the products from the packed store)
 template <int MSEL>
 __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
@@ -468,7 +548,7 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Ld
     qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc);
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
-    qpc::k_solve(d, L, L.yc);
+    k_solve(d, L, L.yc);
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
     QC_SUB(pf, 12);
@@ -593,6 +673,21 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
     for (int e = tid; e < d.nU * m; e += nt) L.UA[e] = c.UA[e];
     for (int e = tid; e < (d.nX + d.nXf) * po; e += nt) L.Tx[e] = e < d.nX * po ? c.Tx[e] : c.Txf[e - d.nX * po];
     __syncthreads();
+    // The condensation (G, free response) depends on the linearisation only: when the region sequence of this QP equals
+    // the one G was built from (a rejected SCP step: only delta / omega change, gusto.py:341 `update(full=new)`; or an
+    // accepted step whose trajectory stays in the same regions) it is still in LDS / the L2 block.  `x0` does not change
+    // inside a solve; the single-QP kernel (no region index) always condenses.
+    bool reuse = false;
+    if (dyn.idx != nullptr) {
+        int same = L.flag[2];
+        for (int k = tid; k < N; k += nt) same = same && (L.goff[k] == L.idxl[k]);
+        if (tid == 0) L.flag[3] = 1;                       // (__syncthreads_and brings static LDS of its own: the carve uses all 160 KB)
+        __syncthreads();
+        if (!same) L.flag[3] = 0;
+        __syncthreads();
+        reuse = L.flag[3] != 0;
+    }
+    if (!reuse) {
     rollout<MSEL, NSEL>(d, dyn, q.x0, (cgptr) nullptr, w.x, L);
     QL_LAP(0);
     condense<MSEL, NSEL>(d, c, dyn, w.x, gh, L);
@@ -624,6 +719,9 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
         __syncthreads();
     }
 #endif
+    for (int k = tid; k < N; k += nt) L.goff[k] = L.idxl[k];
+    if (tid == 0) L.flag[2] = 1;
+    }
     for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yf[e]; L.dy[e] = 0.0; }
     __syncthreads();
     QL_LAP(2);
