@@ -467,66 +467,6 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     __syncthreads();
 }
 
-// v <- K^-1 v by wave 0 (qpc::k_solve with another lane layout): lane = 4 c + part, the four partial sums of an entry sit in
-// adjacent lanes and are added by two DPP moves instead of two ds_bpermute round trips per tile row.
-__device__ __forceinline__ void k_solve(const QPDims &d, Lds &L, lptr v) {
-    const int KT = d.KT, tid = threadIdx.x, lane = tid & 63;
-    if (tid < 64) {
-        const int c = lane >> 2, part = lane & 3;
-        for (int J = 0; J < KT; ++J) {                                   // forward: R^T z = v
-            double acc = 0.0, acc2 = 0.0;
-            for (int I = 0; I < J; ++I) {
-                clptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ;
-                acc = fma(T[(4 * part) * TS + c], v[16 * I + 4 * part], acc);
-                acc2 = fma(T[(4 * part + 1) * TS + c], v[16 * I + 4 * part + 1], acc2);
-                acc = fma(T[(4 * part + 2) * TS + c], v[16 * I + 4 * part + 2], acc);
-                acc2 = fma(T[(4 * part + 3) * TS + c], v[16 * I + 4 * part + 3], acc2);
-            }
-            acc += acc2;
-            acc += wg::dpp_mov<0xB1>(acc);
-            acc += wg::dpp_mov<0x4E>(acc);
-            const double tmp = v[16 * J + c] - acc;
-            __builtin_amdgcn_wave_barrier();
-            if (part == 0) L.Qu[c] = tmp;
-            __builtin_amdgcn_wave_barrier();
-            clptr Ri = L.Rinv + (size_t)J * TSZ;
-            double z = 0.0;
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) { const int k = 4 * part + kq; z = fma(Ri[k * TS + c], L.Qu[k], z); }     // Rinv^T
-            z += wg::dpp_mov<0xB1>(z);
-            z += wg::dpp_mov<0x4E>(z);
-            __builtin_amdgcn_wave_barrier();
-            if (part == 0) v[16 * J + c] = z;
-            __builtin_amdgcn_wave_barrier();
-        }
-        for (int J = KT - 1; J >= 0; --J) {                              // backward: R x = z
-            double acc = 0.0, acc2 = 0.0;
-            for (int Jp = J + 1; Jp < KT; ++Jp) {
-                clptr T = L.B + (size_t)qpc::tile_index(J, Jp, KT) * TSZ + c * TS + 4 * part;
-                clptr vv = v + 16 * Jp + 4 * part;
-                acc = fma(T[0], vv[0], acc); acc2 = fma(T[1], vv[1], acc2); acc = fma(T[2], vv[2], acc); acc2 = fma(T[3], vv[3], acc2);
-            }
-            acc += acc2;
-            acc += wg::dpp_mov<0xB1>(acc);
-            acc += wg::dpp_mov<0x4E>(acc);
-            const double tmp = v[16 * J + c] - acc;
-            __builtin_amdgcn_wave_barrier();
-            if (part == 0) L.Qu[c] = tmp;
-            __builtin_amdgcn_wave_barrier();
-            clptr Ri = L.Rinv + (size_t)J * TSZ + c * TS + 4 * part;
-            double z = 0.0;
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) z = fma(Ri[kq], L.Qu[4 * part + kq], z);                                   // Rinv
-            z += wg::dpp_mov<0xB1>(z);
-            z += wg::dpp_mov<0x4E>(z);
-            __builtin_amdgcn_wave_barrier();
-            if (part == 0) v[16 * J + c] = z;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-}
-
 // Newton direction (qpc::newton_solve with the products from the packed store)
 template <int MSEL>
 __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
@@ -548,7 +488,7 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Ld
     qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc);
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
-    k_solve(d, L, L.yc);
+    qpc::k_solve(d, L, L.yc);
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
     QC_SUB(pf, 12);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
     long long tch = 0;
     for (int r = 0; r < REPS; ++r) { fillK(); __syncthreads(); t0 = clock64(); qpc::tile_cholesky(d, L); __syncthreads(); tch += clock64() - t0; }
     if (tid == 0) out[slot] = tch / REPS; ++slot;                                              // 4
-    TIME(ql::k_solve(d, L, L.yc));                                                             // 5
+    TIME(qpc::k_solve(d, L, L.yc));                                                            // 5
     { long long tc = 0; for (int r = 0; r < REPS; ++r) { fillK(); __syncthreads(); t0 = clock64(); if (tid < 64) qpc::chol16(L.B, L.Rinv); __syncthreads(); tc += clock64() - t0; }
       if (tid == 0) out[20] = tc / REPS; }
     { long long tc = 0; for (int r = 0; r < REPS; ++r) { fillK(); __syncthreads(); t0 = clock64(); if (tid < 64) qpc::tile_update(L.B + 7 * ql::TSZ, L.B + ql::TSZ, L.B + ql::TSZ, tid & 15, (tid & 63) >> 4); __syncthreads(); tc += clock64() - t0; }
