@@ -106,6 +106,13 @@ int srom_gramian(const double *S, int64_t n_s, int64_t n_f, double *G);
  * above): on return row j of G_dev is
  * the eigenvector of the j-th smallest eigenvalue, w_dev (n) ascending.  Replaces the SVD of pod.py:190. */
 int srom_eigh_dev(double *G_dev, int64_t n, double *w_dev, void *stream);
+/* The k LARGEST eigenpairs of the symmetric positive semidefinite G (n x n, left untouched) by blocked subspace iteration +
+ * Rayleigh-Ritz (block = k + oversample <= 128; oversample < 0: max(16, k / 2)) -- what compute_POD keeps of the SVD
+ * (pod.py:190-200) without the other n - k singular values: w_dev (k) descending; Wk_dev (n x k) = eigenvector columns
+ * scaled by 1 / sqrt(w_i) (the input of srom_modes_dev) or NULL; Vt_dev (k x n) = eigenvector rows or NULL; *trace_out
+ * = trace(G) (the truncation rule's denominator: tail energy = trace - sum w); *iters_out = subspace iterations. */
+int srom_eigh_topk_dev(const double *G_dev, int64_t n, int k, int oversample, double *w_dev, double *Wk_dev,
+                       double *Vt_dev, double *trace_out, int *iters_out, void *stream);
 /* W_k (n x k, row-major) = the k leading eigenvectors as columns, scaled by 1/sigma_i = 1/sqrt(w_i) */
 int srom_select_modes_dev(const double *V_dev, const double *w_dev, int64_t n, int k, double *Wk_dev,
                           void *stream);

@@ -37,6 +37,13 @@ class _HostSteps:
         self._W = W[:, ::-1]
         return np.maximum(w[::-1], 0.0)
 
+    def leading(self, G, k):
+        """(k largest eigenvalues, trace) -- stand-in for srom_eigh_topk_dev."""
+        Gh = G.numpy()
+        w, W = self._eigh(Gh)
+        self._W = W[:, ::-1]
+        return np.maximum(w[::-1][:k], 0.0), float(np.trace(Gh))
+
     def modes(self, S, G, k, sigma):
         return self._modes(S, np.ascontiguousarray(self._W[:, :k] / sigma[:k]))
 
@@ -100,9 +107,32 @@ class _DeviceSteps:
         w = self._w.cpu().numpy() if self.use_torch else self._w.to_array((n_s,))
         return np.maximum(w[::-1], 0.0)
 
+    def leading(self, G, k):
+        """The k largest eigenpairs of the (reduced) Gramian by blocked subspace iteration (srom_eigh_topk_dev): returns
+        (eigenvalues descending (k,), trace(G)); the scaled eigenvector columns W_k stay on the device for `modes`."""
+        import ctypes as C
+        n_s = self.shape[0]
+        self._wk, self._Wk = self._alloc((k,)), self._alloc((n_s, k))
+        tr, it = C.c_double(0.0), C.c_int(0)
+        self.sync()
+        self._lib.check(self.L.srom_eigh_topk_dev(self._ptr(G), C.c_int64(n_s), C.c_int(k), C.c_int(-1), self._ptr(self._wk), self._ptr(self._Wk),
+                                                  None, C.byref(tr), C.byref(it), None), 'srom_eigh_topk_dev')
+        self._lib.sync()
+        self.subspace_iterations = it.value
+        w = self._wk.cpu().numpy() if self.use_torch else self._wk.to_array((k,))
+        return np.maximum(w, 0.0), tr.value
+
     def modes(self, S, G, k, sigma):
         import ctypes as C
         n_s, n_f = self.shape
+        if getattr(self, '_Wk', None) is not None:          # leading eigenpairs: W_k is there already
+            U = self._alloc((n_f, k))
+            self.sync()
+            self._lib.check(self.L.srom_modes_dev(self._ptr(S), C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), self._ptr(self._Wk), C.c_int(k),
+                                                  self._ptr(U), None), 'srom_modes_dev')
+            self._lib.sync()
+            self._k = k
+            return U
         Wk, U = self._alloc((n_s, k)), self._alloc((n_f, k))
         self.sync()
         self._lib.check(self.L.srom_select_modes_dev(self._ptr(G), self._ptr(self._w), C.c_int64(n_s), C.c_int(k), self._ptr(Wk), None),
@@ -145,14 +175,23 @@ def reduce_gramian(G, group=None, collective='auto'):
     return 'all_reduce'
 
 
+LEADING_MIN_SNAPSHOTS = 2048      # above this many snapshots the full spectrum is a library call (rocSOLVER dsyevd, ~1 s at 10 000)
+LEADING_MAX_MODES = 112           # block of the subspace iteration <= 128 including its oversampling
+
+
 def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian=None, local_modes=None,
-                           local_eigh=None, collective='auto', timings=None, keep_on_device=False, force_torch=False):
+                           local_eigh=None, collective='auto', timings=None, keep_on_device=False, force_torch=False,
+                           spectrum='auto'):
     """Distributed method-of-snapshots POD (sofacontrol/mor/pod.py:181-200 for a snapshot matrix sharded by DoF columns).
 
     S_shard: this rank's (n_s x n_f_local) block of snapshot columns -- a numpy array (uploaded once) or a CUDA float64
     torch tensor (used in place).  Steps: local Gramian (f64 MFMA kernel) -> `reduce_gramian` (the only collective) ->
     replicated eigen-decomposition on the device -> this rank's rows of U = S^T W Sigma^-1.  The Gramian never visits the
     host.  Returns (U_local (n_f_local x k), k, Sigma); U_local is a numpy array unless keep_on_device.
+    spectrum: 'full' = every eigenvalue of the Gramian (what the reference's SVD returns as `Sigma`); 'leading' = only the
+    kept modes by blocked subspace iteration, the truncation rule evaluated as (trace(G) - sum of the leading eigenvalues) /
+    trace(G) (pod.py:192-197 needs nothing else), `Sigma` then holds the computed leading singular values only; 'auto' =
+    'leading' for more than 2048 snapshots when at most 112 modes are asked for (rom_dim) or suffice (tol), else 'full'.
     `local_gramian` / `local_eigh` / `local_modes`: numpy stand-ins for the device steps (CPU tests of the exchange
     logic).  `timings`: optional dict that receives the seconds of each phase.  keep_on_device: return the device
     array (a torch tensor with a process group or force_torch, else a _lib.DeviceBuffer)."""
@@ -180,10 +219,37 @@ def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian
     t0 = lap('collective_s', t0)
     if timings is not None:
         timings['collective'] = how
-    w = steps.eigenvalues_descending(G)
+    n_s = int(np.shape(S_shard)[0])
+    lead = spectrum == 'leading' or (spectrum == 'auto' and n_s > LEADING_MIN_SNAPSHOTS and (rom_dim is None or int(rom_dim) <= LEADING_MAX_MODES))
+    k = None
+    if lead:
+        # leading eigenpairs only: with rom_dim that many; with a tolerance blocks of growing size until the tail energy fits
+        for kk in ([int(rom_dim)] if rom_dim is not None else [32, 64, LEADING_MAX_MODES]):
+            kk = min(kk, n_s)
+            w, trace = steps.leading(G, kk)
+            Sigma = np.sqrt(w)
+            if rom_dim is not None:
+                k = kk
+                break
+            tail = np.maximum(trace - np.cumsum(w), 0.0) / trace        # tail[i]: energy beyond the first i + 1 modes
+            ok = np.nonzero(tail <= tol)[0]
+            if ok.size and ok[0] + 1 < kk:                              # (the last value of a block is not trusted)
+                k = int(ok[0]) + 1
+                w, trace = steps.leading(G, k)                          # W_k in the layout of exactly k modes
+                Sigma = np.sqrt(w)
+                break
+        if timings is not None:
+            timings['spectrum'] = 'leading' if k is not None else 'full (leading blocks did not reach the tolerance)'
+            timings['subspace_iterations'] = getattr(steps, 'subspace_iterations', None)
+    if k is None:
+        if hasattr(steps, '_Wk'):
+            steps._Wk = None
+        w = steps.eigenvalues_descending(G)
+        Sigma = np.sqrt(w)
+        k = _pod.energy_truncation(Sigma, tol) if rom_dim is None else int(rom_dim)
+        if timings is not None and 'spectrum' not in timings:
+            timings['spectrum'] = 'full'
     t0 = lap('eigh_s', t0)
-    Sigma = np.sqrt(w)
-    k = _pod.energy_truncation(Sigma, tol) if rom_dim is None else int(rom_dim)
     U_local = steps.modes(S, G, k, Sigma)
     lap('modes_s', t0)
     if not host and not keep_on_device:

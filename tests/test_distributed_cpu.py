@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, S, tol, out, collective='auto'):
+def _worker(rank, world, port, S, tol, out, collective='auto', spectrum='auto', rom_dim=None):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -29,8 +29,8 @@ def _worker(rank, world, port, S, tol, out, collective='auto'):
     tm = {}
     U_loc, k, Sig = pod_from_column_shards(S[:, lo:hi], tol, local_gramian=lambda A: A @ A.T,
                                            local_modes=lambda A, W: A.T @ W, local_eigh=np.linalg.eigh,
-                                           collective=collective, timings=tm)
-    out[rank] = (lo, hi, U_loc, k, Sig, tm.get('collective'))
+                                           collective=collective, timings=tm, spectrum=spectrum, rom_dim=rom_dim)
+    out[rank] = (lo, hi, U_loc, k, Sig, tm.get('collective'), tm.get('spectrum'))
     dist.destroy_process_group()
 
 
@@ -50,7 +50,7 @@ def test_pod_column_shards_two_ranks(collective, n_s, used):
     mp.spawn(_worker, args=(2, port, S, tol, out, collective), nprocs=2, join=True)
     U = np.zeros((n_f, out[0][3]))
     for r in range(2):
-        lo, hi, U_loc, k, Sig, coll = out[r]
+        lo, hi, U_loc, k, Sig, coll, _ = out[r]
         U[lo:hi] = U_loc
         assert coll == used
     _, U_ref, k_ref, S_ref = opod.compute_pod(S.T, tol)
@@ -58,6 +58,31 @@ def test_pod_column_shards_two_ranks(collective, n_s, used):
     np.testing.assert_allclose(out[0][4][:6], S_ref[:6], rtol=1e-9)
     np.testing.assert_allclose(np.abs(U), np.abs(U_ref), rtol=0, atol=1e-8)
     np.testing.assert_allclose(U.T @ U, np.eye(k_ref), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('rom_dim', [None, 4])
+def test_pod_column_shards_two_ranks_leading_spectrum(rom_dim):
+    """The leading-eigenpair route (what more than 2048 snapshots take: blocked subspace iteration on the device, here its
+    numpy stand-in) through the same exchange: tail energy from trace(G) - sum of the leading eigenvalues gives the reference's
+    k; the mode rows of the two ranks assemble the reference basis."""
+    rng = np.random.default_rng(1)
+    n_s, n_f = 48, 257
+    L = rng.standard_normal((n_s, 6)) * np.array([50, 20, 8, 3, 1, 0.3])
+    S = L @ rng.standard_normal((6, n_f)) + 1e-3 * rng.standard_normal((n_s, n_f))
+    tol = 1e-4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), S, tol, out, 'auto', 'leading', rom_dim), nprocs=2, join=True)
+    _, U_ref, k_ref, S_ref = opod.compute_pod(S.T, tol)
+    k = rom_dim or k_ref
+    assert out[0][3] == out[1][3] == k and out[0][6] == out[1][6] == 'leading'
+    U = np.zeros((n_f, k))
+    for r in range(2):
+        U[out[r][0]:out[r][1]] = out[r][2]
+    assert len(out[0][4]) == k                          # only the computed leading singular values
+    np.testing.assert_allclose(out[0][4], S_ref[:k], rtol=1e-9)
+    Ur = np.linalg.svd(S.T, full_matrices=False)[0][:, :k]
+    np.testing.assert_allclose(np.abs(U), np.abs(Ur), rtol=0, atol=1e-8)
 
 
 def test_shard_range_covers_everything():

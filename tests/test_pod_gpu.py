@@ -319,6 +319,91 @@ def test_gramian_full_size_c4_shard_properties():
     assert float((got - ref).abs().max()) <= 1e-10 * float(ref.abs().max())
 
 
+def test_leading_eigenpairs_vs_numpy():
+    """srom_eigh_topk_dev (blocked subspace iteration + Rayleigh-Ritz) against numpy.linalg.eigh on Gramians with a decaying
+    and with a clustered spectrum: eigenvalues to 1e-10 relative, residuals |G v - lambda v|, orthonormality, trace."""
+    import ctypes as C
+    from sofacontrol_amd import _lib
+    rng = np.random.default_rng(5)
+    for n, k, spec in ((600, 20, 'decay'), (900, 64, 'cluster'), (300, 8, 'lowrank')):
+        Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        if spec == 'decay':
+            lam = 10.0 ** (-0.08 * np.arange(n))
+        elif spec == 'cluster':
+            lam = np.concatenate((1.0 + 0.01 * rng.standard_normal(70) ** 2, 1e-6 * rng.uniform(0.5, 1.0, n - 70)))
+            lam = np.sort(lam)[::-1]
+        else:
+            lam = np.concatenate((np.linspace(5.0, 1.0, 12), np.zeros(n - 12)))
+        G = (Qm * lam) @ Qm.T
+        G = 0.5 * (G + G.T)
+        dG = _lib.DeviceBuffer.from_array(G)
+        dw, dV, dW = _lib.DeviceBuffer(k * 8), _lib.DeviceBuffer(k * n * 8), _lib.DeviceBuffer(k * n * 8)
+        tr, it = C.c_double(), C.c_int()
+        _lib.check(_lib.lib().srom_eigh_topk_dev(dG.ptr, C.c_int64(n), C.c_int(k), C.c_int(-1), dw.ptr, dW.ptr, dV.ptr, C.byref(tr),
+                                                 C.byref(it), None), 'srom_eigh_topk_dev')
+        w, Vt, Wk = dw.to_array((k,)), dV.to_array((k, n)), dW.to_array((n, k))
+        wref = np.linalg.eigvalsh(G)[::-1][:k]
+        np.testing.assert_allclose(w, wref, rtol=1e-10, atol=1e-12 * wref[0], err_msg=spec)
+        assert abs(tr.value - np.trace(G)) <= 1e-12 * np.trace(G)
+        assert np.abs(Vt @ Vt.T - np.eye(k)).max() <= 1e-10, spec
+        assert np.abs(G @ Vt.T - Vt.T * w).max() <= 1e-9 * wref[0], (spec, np.abs(G @ Vt.T - Vt.T * w).max())
+        np.testing.assert_allclose(Wk, Vt.T / np.sqrt(w), rtol=1e-12, atol=0)
+        assert 1 <= it.value <= 60
+
+
+def test_sharded_pod_build_leading_modes_vs_svd():
+    """More than 2048 snapshots with rom_dim given: pod_from_column_shards takes the leading-eigenpair route
+    (srom_eigh_topk_dev) -- modes and singular values against numpy's SVD (pod.py:190) of the same snapshot matrix; with a
+    tolerance instead of rom_dim the block grows until the tail energy fits and the same k as the reference rule comes out."""
+    from sofacontrol_amd.distributed import pod_from_column_shards
+    from sofacontrol_amd.mor.pod import energy_truncation
+    rng = np.random.default_rng(3)
+    n_s, n_f, rank = 2600, 700, 24
+    S = (rng.standard_normal((n_s, rank)) * np.linspace(30.0, 2.0, rank)) @ rng.standard_normal((rank, n_f)) + 1e-3 * rng.standard_normal((n_s, n_f))
+    Uref, Sref, _ = np.linalg.svd(S.T, full_matrices=False)
+    tm = {}
+    U, k, Sig = pod_from_column_shards(S, 1e-4, rom_dim=16, timings=tm)
+    assert tm['spectrum'] == 'leading' and k == 16 and U.shape == (n_f, 16)
+    np.testing.assert_allclose(Sig[:16], Sref[:16], rtol=1e-9)
+    np.testing.assert_allclose(np.abs(U), np.abs(Uref[:, :16]), rtol=0, atol=1e-7)
+    tm = {}
+    U2, k2, Sig2 = pod_from_column_shards(S, 1e-6, timings=tm)
+    assert tm['spectrum'] == 'leading' and k2 == energy_truncation(Sref, 1e-6), (k2, energy_truncation(Sref, 1e-6))
+    np.testing.assert_allclose(np.abs(U2), np.abs(Uref[:, :k2]), rtol=0, atol=1e-6)
+    # the full spectrum on request (what the reference stores as Sigma)
+    tm = {}
+    U3, k3, Sig3 = pod_from_column_shards(S, 1e-6, timings=tm, spectrum='full')
+    assert tm['spectrum'] == 'full' and k3 == k2 and len(Sig3) == n_s
+    np.testing.assert_allclose(Sig3[:rank], Sref[:rank], rtol=1e-8)
+
+
+def test_pod_build_c4_shard_end_to_end_properties():
+    """BASELINE config C4 at its per-GPU size, END TO END (Gramian -> leading eigenpairs -> modes) on a resident shard of
+    10 000 snapshots x 6250 DoF columns (low rank 64 + noise, as bench.py): size-independent properties checked in float64
+    on the host -- U^T U = I, G W = W Lambda through S (S^T W) on the kept modes, tail energy = trace - sum, sigma_i = |S u_i|."""
+    import torch
+    from sofacontrol_amd.distributed import pod_from_column_shards
+    n_s, n_f, k = 10000, 6250, 64
+    gen = torch.Generator(device='cuda'); gen.manual_seed(21)
+    Lr = torch.randn((n_s, k), dtype=torch.float64, device='cuda', generator=gen) * torch.linspace(40.0, 4.0, k, dtype=torch.float64, device='cuda')
+    S_t = Lr @ torch.randn((k, n_f), dtype=torch.float64, device='cuda', generator=gen) + 1e-3 * torch.randn((n_s, n_f), dtype=torch.float64, device='cuda', generator=gen)
+    del Lr
+    tm = {}
+    U_t, kk, Sig = pod_from_column_shards(S_t, 1e-4, rom_dim=k, timings=tm, keep_on_device=True, force_torch=True)
+    assert kk == k and tm['spectrum'] == 'leading' and tm['subspace_iterations'] <= 10, tm
+    U = U_t.cpu().numpy()
+    S = S_t.cpu().numpy()
+    assert np.abs(U.T @ U - np.eye(k)).max() <= 1e-9
+    SU = S @ U                                         # = W Sigma
+    np.testing.assert_allclose(np.linalg.norm(SU, axis=0), Sig[:k], rtol=1e-10)
+    W = SU / Sig[:k]
+    R = S @ (S.T @ W) - W * Sig[:k] ** 2               # G W - W Lambda
+    assert np.abs(R).max() <= 1e-9 * Sig[0] ** 2, np.abs(R).max()
+    fro2 = float((S * S).sum())
+    tail = (fro2 - float((Sig[:k] ** 2).sum())) / fro2
+    assert 0.0 <= tail <= 1e-6                          # the 1e-3 noise floor
+
+
 def test_shipped_pod_model(golden):
     """The reference's shipped Diamond POD model (examples/diamond/pod_model.pkl: U 4884 x 36 -- two 16-column MFMA tiles
     + one 4-column tile -- q_ref, v_ref) and rest state through the device kernels, against what the imported reference
