@@ -256,7 +256,7 @@ struct sgusto_plan {
     hipEvent_t adone = nullptr;
     char *pin = nullptr;               // one pinned block: [inputs | outputs]
     size_t pin_bytes = 0;
-    bool pending = false, want_trace = false;
+    bool pending = false, want_trace = false, launching = false;
     ~sgusto_plan() {
         if (pending && adone) (void)hipEventSynchronize(adone);
         if (adone) (void)hipEventDestroy(adone);
@@ -369,6 +369,9 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
                           double *zopt, int32_t *iters, int32_t *status, double *trace, void *stream) {
     SRH_REQUIRE(pl && x0 && u_init && x_init && xopt && uopt && zopt && iters && status,
                 "sgusto_plan_solve_dev: null argument");
+    // an asynchronous request in flight (sgusto_plan_solve_begin) is using the plan's work blocks on its own stream
+    SRH_REQUIRE(!pl->pending || (pl->astream && stream == (void *)pl->astream && pl->launching),
+                "sgusto_plan_solve_dev: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
     GustoBatch b{x0, u_init, x_init, z, zf, u_des, pl->fs.as<double>(), xopt, uopt, zopt, iters, status, trace,
                  pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>(), 0};
     if (pl->have_last && pl->batch > 256 && !getenv("SRH_GUSTO_NO_LPT")) {      // more rollouts than CUs: order matters
@@ -401,6 +404,7 @@ int sgusto_plan_solve(sgusto_plan_t *pl, const double *x0, const double *u_init,
                       const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
                       double *zopt, int32_t *iters, int32_t *status, double *trace) {
     SRH_REQUIRE(pl && x0 && u_init && x_init && xopt && uopt && zopt, "sgusto_plan_solve: null argument");
+    SRH_REQUIRE(!pl->pending, "sgusto_plan_solve: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
     const QPDims &d = pl->C.dims;
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz, B = pl->batch;
     SRH_CHECK_HIP(hipMemcpy(pl->x0.p, x0, sizeof(double) * B * n, hipMemcpyHostToDevice));
@@ -449,29 +453,42 @@ int sgusto_plan_solve_begin(sgusto_plan_t *pl, const double *x0, const double *u
         memcpy(pl->pin + off, src, bytes);
         return hipMemcpyAsync(dst, pl->pin + off, bytes, hipMemcpyHostToDevice, pl->astream);
     };
-    SRH_CHECK_HIP(stage(L.x0, x0, D * B * n, pl->x0.p));
-    SRH_CHECK_HIP(stage(L.u_init, u_init, D * B * N * m, pl->u_init.p));
-    SRH_CHECK_HIP(stage(L.x_init, x_init, D * B * (N + 1) * n, pl->x_init.p));
-    if (z) SRH_CHECK_HIP(stage(L.z, z, D * B * (N + 1) * nz, pl->z.p));
-    if (zf) SRH_CHECK_HIP(stage(L.zf, zf, D * B * nz, pl->zf.p));
-    if (u_des) SRH_CHECK_HIP(stage(L.ud, u_des, D * B * N * m, pl->ud.p));
-    pl->want_trace = want_trace != 0 && pl->par.max_trace > 0;
-    int rc = sgusto_plan_solve_dev(pl, pl->x0.as<double>(), pl->u_init.as<double>(), pl->x_init.as<double>(),
-                                   z ? pl->z.as<double>() : nullptr, zf ? pl->zf.as<double>() : nullptr,
-                                   u_des ? pl->ud.as<double>() : nullptr, pl->xopt.as<double>(), pl->uopt.as<double>(),
-                                   pl->zopt.as<double>(), pl->iters.as<int32_t>(), pl->status.as<int32_t>(),
-                                   pl->want_trace ? pl->trace.as<double>() : nullptr, (void *)pl->astream);
-    if (rc) return rc;
-    auto back = [&](size_t off, const void *src, size_t bytes) {
-        return hipMemcpyAsync(pl->pin + off, src, bytes, hipMemcpyDeviceToHost, pl->astream);
+    // from here on work is enqueued on the plan's stream: on any error the stream is drained before returning, so that
+    // nothing is still writing into the pinned block / the plan's buffers while `pending` is false
+    auto body = [&]() -> int {
+        SRH_CHECK_HIP(stage(L.x0, x0, D * B * n, pl->x0.p));
+        SRH_CHECK_HIP(stage(L.u_init, u_init, D * B * N * m, pl->u_init.p));
+        SRH_CHECK_HIP(stage(L.x_init, x_init, D * B * (N + 1) * n, pl->x_init.p));
+        if (z) SRH_CHECK_HIP(stage(L.z, z, D * B * (N + 1) * nz, pl->z.p));
+        if (zf) SRH_CHECK_HIP(stage(L.zf, zf, D * B * nz, pl->zf.p));
+        if (u_des) SRH_CHECK_HIP(stage(L.ud, u_des, D * B * N * m, pl->ud.p));
+        pl->want_trace = want_trace != 0 && pl->par.max_trace > 0;
+        pl->launching = true;
+        int rc = sgusto_plan_solve_dev(pl, pl->x0.as<double>(), pl->u_init.as<double>(), pl->x_init.as<double>(),
+                                       z ? pl->z.as<double>() : nullptr, zf ? pl->zf.as<double>() : nullptr,
+                                       u_des ? pl->ud.as<double>() : nullptr, pl->xopt.as<double>(), pl->uopt.as<double>(),
+                                       pl->zopt.as<double>(), pl->iters.as<int32_t>(), pl->status.as<int32_t>(),
+                                       pl->want_trace ? pl->trace.as<double>() : nullptr, (void *)pl->astream);
+        pl->launching = false;
+        if (rc) return rc;
+        auto back = [&](size_t off, const void *src, size_t bytes) {
+            return hipMemcpyAsync(pl->pin + off, src, bytes, hipMemcpyDeviceToHost, pl->astream);
+        };
+        SRH_CHECK_HIP(back(L.xopt, pl->xopt.p, D * B * (N + 1) * n));
+        SRH_CHECK_HIP(back(L.uopt, pl->uopt.p, D * B * N * m));
+        SRH_CHECK_HIP(back(L.zopt, pl->zopt.p, D * B * (N + 1) * nz));
+        SRH_CHECK_HIP(back(L.iters, pl->iters.p, sizeof(int32_t) * B));
+        SRH_CHECK_HIP(back(L.status, pl->status.p, sizeof(int32_t) * B));
+        if (pl->want_trace) SRH_CHECK_HIP(back(L.trace, pl->trace.p, D * B * (size_t)pl->par.max_trace * 4));
+        SRH_CHECK_HIP(hipEventRecord(pl->adone, pl->astream));
+        return SRH_OK;
     };
-    SRH_CHECK_HIP(back(L.xopt, pl->xopt.p, D * B * (N + 1) * n));
-    SRH_CHECK_HIP(back(L.uopt, pl->uopt.p, D * B * N * m));
-    SRH_CHECK_HIP(back(L.zopt, pl->zopt.p, D * B * (N + 1) * nz));
-    SRH_CHECK_HIP(back(L.iters, pl->iters.p, sizeof(int32_t) * B));
-    SRH_CHECK_HIP(back(L.status, pl->status.p, sizeof(int32_t) * B));
-    if (pl->want_trace) SRH_CHECK_HIP(back(L.trace, pl->trace.p, D * B * (size_t)pl->par.max_trace * 4));
-    SRH_CHECK_HIP(hipEventRecord(pl->adone, pl->astream));
+    const int rcb = body();
+    if (rcb) {
+        pl->launching = false;
+        (void)hipStreamSynchronize(pl->astream);
+        return rcb;
+    }
     pl->pending = true;
     return SRH_OK;
 }

@@ -16,8 +16,11 @@ struct sekf {
     // pinned host mirrors of the per-step input (u, y) and output (x, status): one copy each way per step
     double *pin_in = nullptr, *pin_out = nullptr;
     hipStream_t side = nullptr;          // sekf_step_projected: the projection runs beside the filter kernel
+
+    hipEvent_t side_gate = nullptr;    // orders the side stream behind earlier work of stream 0 on the same rom
     ~sekf() {
         if (side) (void)hipStreamDestroy(side);
+        if (side_gate) (void)hipEventDestroy(side_gate);
         if (pin_in) (void)hipHostFree(pin_in);
         if (pin_out) (void)hipHostFree(pin_out);
     }
@@ -865,12 +868,18 @@ int sekf_step_projected(sekf_t *h, srom_t *rom, const double *x_full, const doub
     SRH_REQUIRE(!u || h->model->has_discrete, "sekf_step_projected: model has not been pre-discretised");
     int rc;
     if (!h->side) SRH_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    if (!h->side_gate) SRH_CHECK_HIP(hipEventCreateWithFlags(&h->side_gate, hipEventDisableTiming));
+    // the side stream uses the rom's shared staging / split-K workspace: it starts behind whatever stream 0 has been
+    // given before this call (un-synchronised srom_*_dev(stream = NULL) launches on the same rom)
+    SRH_CHECK_HIP(hipEventRecord(h->side_gate, nullptr));
+    SRH_CHECK_HIP(hipStreamWaitEvent(h->side, h->side_gate, 0));
     // the two halves are independent (the filter never reads the projected state): filter on stream 0 -- enqueued
     // first, its one-workgroup kernel is the long pole -- projection on the side stream, one wait for each
-    if ((rc = ekf_enqueue(h, u, y, nullptr, nullptr, nullptr))) return rc;
-    if ((rc = srom_stage_project(rom, SROM_X, x_full, 1, h->side))) return rc;
-    SRH_CHECK_HIP(hipStreamSynchronize(h->side));
-    if ((rc = srom_stage_collect(rom, x_reduced_out, 1, SROM_X))) return rc;
+    auto drain = [&](int code) { (void)hipStreamSynchronize(h->side); (void)hipStreamSynchronize(nullptr); return code; };
+    if ((rc = ekf_enqueue(h, u, y, nullptr, nullptr, nullptr))) return drain(rc);
+    if ((rc = srom_stage_project(rom, SROM_X, x_full, 1, h->side))) return drain(rc);
+    if (hipStreamSynchronize(h->side) != hipSuccess) { srh::set_error("sekf_step_projected: side stream failed"); return drain(SRH_EHIP); }
+    if ((rc = srom_stage_collect(rom, x_reduced_out, 1, SROM_X))) return drain(rc);
     SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return ekf_collect(h, x_hat_out, "sekf_step_projected");
 }

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void poly_project_kernel(PolyArgs a) {
         return true;
     };
     auto max_step = [&](double v, double dv) { return (act && dv < 0.0) ? -v / dv : INFINITY; };
+    double last_rpn = INFINITY;
     for (; it < a.max_iter; ++it) {
         // residuals
         double rdn = 0.0;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(64) void poly_project_kernel(PolyArgs a) {
         }
         const double rp = act ? adot(p) + s - bi : 0.0;
         const double rpn = wg::wave_max(fabs(rp));
+        last_rpn = rpn;
         const double mu = wg::wave_sum(act ? s * lam : 0.0) / mc;
         if (mu <= a.tol * scale && rpn <= 1e-10 * scale && rdn <= 1e-10 * scale) break;
         double dla, dsa, dpa[PN], dl, dsv, dp[PN];
@@ -102,6 +104,9 @@ __global__ __launch_bounds__(64) void poly_project_kernel(PolyArgs a) {
         if (act) { s += al * dsv; lam += al * dl; }
     }
     if (st == 0 && it >= a.max_iter) st = 1;
+    // a polyhedron without strict interior (rows with lb == ub) has no central path to follow to a 1e-13 gap: the last
+    // iterate is returned when it is feasible to 1e-6 (the reference's OSQP returns such an approximate point too)
+    if (st != 0 && last_rpn <= 1e-6 * scale) st = 0;
     if (lane < n) a.out[(size_t)blockIdx.x * n + lane] = p[lane < PN ? lane : 0];
     if (lane == 0) a.status[blockIdx.x] = st;
 }

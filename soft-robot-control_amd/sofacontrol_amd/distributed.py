@@ -64,6 +64,9 @@ class _DeviceSteps:
         self._lib, self.L, self.use_torch = _lib, _lib.lib(), use_torch
         if use_torch:
             import torch
+            if not torch.cuda.is_available():
+                raise RuntimeError('pod_from_column_shards: torch sees no HIP GPU -- in a process that uses both, torch.cuda must be '
+                                   'initialised (torch.cuda.init()) BEFORE the first call into libsofacontrol_hip')
             self.torch = torch
 
     def _alloc(self, shape):
@@ -153,12 +156,26 @@ class _DeviceSteps:
             self._lib.sync()
 
 
+def _usable_modes(Sigma, k):
+    """rom_dim larger than the numerical rank: U = S^T W Sigma^-1 would divide by (numerically) zero singular values -- the
+    reference's SVD truncation has no such division (pod.py:190-200); refuse with a clear message instead of returning inf / nan."""
+    Sigma = np.asarray(Sigma)
+    if k > len(Sigma) or Sigma[k - 1] <= 1e-13 * max(Sigma[0], 1e-300):
+        rank = int((Sigma > 1e-13 * max(Sigma[0], 1e-300)).sum())
+        raise RuntimeError('rom_dim = %d exceeds the numerical rank %d of the snapshot matrix (singular value %d is %.3e of the largest)'
+                           % (k, rank, k, (Sigma[k - 1] / Sigma[0]) if k <= len(Sigma) and Sigma[0] > 0 else 0.0))
+    return k
+
+
 def reduce_gramian(G, group=None, collective='auto'):
     """The one exchange step of the path: sum the partial Gramians over the ranks, in place on the tensor G (HBM with
     the nccl = RCCL backend, host memory with gloo).  'rs_ag' = reduce-scatter of row blocks + all-gather (keeps all
     xGMI links of a node busy; needs n_s divisible by the world size), 'all_reduce' = the plain collective; 'auto' picks
     rs_ag when it applies."""
-    import torch.distributed as dist
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 'none'
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 'none'
     world = dist.get_world_size(group)
@@ -201,8 +218,11 @@ def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian
     if host:
         steps = _HostSteps(local_gramian or (lambda A: A @ A.T), local_eigh or np.linalg.eigh, local_modes or (lambda A, W: A.T @ W))
     else:
-        import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        try:
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        except ImportError:                  # a single rank needs no torch at all
+            multi = False
         steps = _DeviceSteps(use_torch=multi or force_torch)
 
     def lap(name, t0):
@@ -250,6 +270,7 @@ def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian
         if timings is not None and 'spectrum' not in timings:
             timings['spectrum'] = 'full'
     t0 = lap('eigh_s', t0)
+    k = _usable_modes(Sigma, k)
     U_local = steps.modes(S, G, k, Sigma)
     lap('modes_s', t0)
     if not host and not keep_on_device:

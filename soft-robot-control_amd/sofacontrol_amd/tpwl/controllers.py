@@ -109,8 +109,9 @@ class GuSTOClient:
 
     def send_request(self, t0, x0, wait=True):
         x0 = np.asarray(x0, dtype=np.float64)
+        self.force_wait()                 # a request still in flight owns the plan's buffers: collect (and discard) it first
         self._result = None
-        if wait or not self.node.supports_async:
+        if wait or not getattr(self.node, 'supports_async', False):
             self._result = self.node.gusto_callback(t0, x0)
             self._pending = False
         else:
