@@ -106,7 +106,13 @@ __global__ __launch_bounds__(64) void poly_project_kernel(PolyArgs a) {
     if (st == 0 && it >= a.max_iter) st = 1;
     // a polyhedron without strict interior (rows with lb == ub) has no central path to follow to a 1e-13 gap: the last
     // iterate is returned when it is feasible to 1e-6 (the reference's OSQP returns such an approximate point too)
-    if (st != 0 && last_rpn <= 1e-6 * scale) st = 0;
+    {
+        const double vend = wg::wave_max(act ? adot(p) - bi : -INFINITY);     // the actual violation of the last iterate
+        bool finite = true;                 // (fmax / fmin drop NaNs: a diverged iterate must not pass as feasible)
+#pragma unroll
+        for (int k = 0; k < PN; ++k) finite = finite && (p[k] == p[k]) && fabs(p[k]) < 1e300;
+        if (st != 0 && finite && vend > -1e300 && vend <= 1e-6 * scale && last_rpn <= 1e-6 * scale) st = 0;
+    }
     if (lane < n) a.out[(size_t)blockIdx.x * n + lane] = p[lane < PN ? lane : 0];
     if (lane == 0) a.status[blockIdx.x] = st;
 }
