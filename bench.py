@@ -370,6 +370,39 @@ def secondary(L, _lib, rank, world, dist):
                                   '(PCIe copies inside the time); best of 3 calls' % Bn,
                       'iterations_per_s': float(il.iters.sum()) / t, 'ms': t * 1e3, 'ms_all_calls': [x * 1e3 for x in ts],
                       'iterations': int(il.iters.sum())}
+    # ---- the reference's real-time hardware driver: SSM + GuSTO as a real-time iteration (examples/hardware/diamond_SSM.py:
+    # 193, 218, 359-361: n_x = 6, n_u = 4, N = 3, dt = 0.02, max_gusto_iters = 0, replanned every 2 steps = 40 ms)
+    try:
+        from sofacontrol_amd.scp.models.ssm import SSMGuSTO
+        from sofacontrol_amd.scp.gusto import GuSTO
+        from sofacontrol_amd.utils import HyperRectangle
+        n6, m4, N3, dt2 = 6, 4, 3, 0.02
+        mdl = wl.ssm_model(n6, m4, 3, 2, seed=96)
+        s6 = SSMDynamics(mdl['z_ref'].copy(), discrete=False, discr_method='be',
+                         model=dict(Ts=sc(dt2), w_coeff=mat(mdl['W']), v_coeff=mat(mdl['V']), r_coeff=mat(mdl['R']),
+                                    B=mat(mdl['B']), rd_coeff=mat(mdl['Rd']), Bd=mat(mdl['Bd'])),
+                         params=dict(state_dim=sc(n6), input_dim=sc(m4), output_dim=sc(n6), SSM_order=sc(2), ROM_order=sc(3)))
+        gm6 = SSMGuSTO(s6)
+        Qz6 = np.zeros((n6, n6)); Qz6[0, 0] = Qz6[1, 1] = 100.0
+        R6 = 0.003 * np.eye(m4)
+        x06 = np.zeros(n6)
+        u6 = np.zeros((N3, m4))
+        xi6, _ = s6.rollout(x06, u6, dt2)
+        z6 = np.tile(np.array([0.02, -0.01, 0, 0, 0, 0.0]), (N3 + 1, 1))
+        g6 = GuSTO(gm6, N3, dt2, Qz6, R6, x06, u6, xi6, z=z6, U=HyperRectangle([1500.0] * m4, [0.0] * m4), verbose=0,
+                   max_gusto_iters=0, convg_thresh=1e-3, warm_start=True)
+        ts6 = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            g6.solve(x06, u6, xi6, z6, None, None)
+            ts6.append(time.perf_counter() - t0)
+        ts6.sort()
+        out['ssm_gusto_rti'] = {'workload': 'SSM (n_x = 6, n_u = 4, cubic) + GuSTO real-time iteration: N = 3, dt = 0.02, max_gusto_iters = 0 '
+                                            '(one QP per call), U box; host loop around the device QP (the model is not TPWL), host buffers',
+                                'ms_median': ts6[len(ts6) // 2] * 1e3, 'ms_p95': ts6[int(len(ts6) * 0.95)] * 1e3,
+                                'budget_ms': 40.0, 'within_budget': bool(ts6[int(len(ts6) * 0.95)] * 1e3 <= 40.0)}
+    except Exception as exc:
+        out['ssm_gusto_rti'] = {'error': repr(exc)}
     # ---- C4 (per-GPU column shard): the local Gramian alone, then the whole sharded POD build of the product
     # (distributed.pod_from_column_shards: Gramian -> reduce-scatter + all-gather over RCCL when world > 1 -> replicated
     # eigen-decomposition -> local mode rows), everything resident in HBM, phases timed separately
@@ -378,7 +411,14 @@ def secondary(L, _lib, rank, world, dist):
     n_s, n_f = 10000, 50000 // 8
     gen = torch.Generator(device='cuda')
     gen.manual_seed(7 + rank)
-    S_t = torch.randn((n_s, n_f), dtype=torch.float64, device='cuda', generator=gen)
+    # low rank (64) + 1e-3 noise; the left factor is the same on every rank (it is a property of the
+    # snapshots, seed 7), the right factor and the noise are this rank's DoF columns
+    gl = torch.Generator(device='cuda')
+    gl.manual_seed(7)
+    Lr = torch.randn((n_s, 64), dtype=torch.float64, device='cuda', generator=gl) * torch.linspace(40.0, 4.0, 64, dtype=torch.float64, device='cuda')
+    S_t = Lr @ torch.randn((64, n_f), dtype=torch.float64, device='cuda', generator=gen)
+    S_t += 1e-3 * torch.randn((n_s, n_f), dtype=torch.float64, device='cuda', generator=gen)
+    del Lr
     G_t = torch.empty((n_s, n_s), dtype=torch.float64, device='cuda')
     torch.cuda.synchronize()
     sptr, gptr = C.c_void_p(S_t.data_ptr()), C.c_void_p(G_t.data_ptr())

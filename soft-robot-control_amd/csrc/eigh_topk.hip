@@ -260,7 +260,7 @@ int srom_eigh_topk_dev(const double *G_dev, int64_t n, int k, int oversample, do
     if ((rc = orthonormalise(dZ, dQ))) return rc;
     std::vector<double> prev(b, 0.0), cur(b + 1, 0.0);
     int it = 0;
-    const int max_it = 60;
+    const int max_it = 30;               // a block that has not settled by then sits in a flat part of the spectrum (the caller falls back)
     for (; it < max_it; ++it) {
         if ((rc = abt.run(dQ, n, b, G_dev, n, n, n, dZ, n, st))) return rc;          // Z = Q G   (G symmetric: Q G^T)
         if ((rc = orthonormalise(dZ, dQ))) return rc;

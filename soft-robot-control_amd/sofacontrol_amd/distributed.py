@@ -194,6 +194,7 @@ def reduce_gramian(G, group=None, collective='auto'):
 
 LEADING_MIN_SNAPSHOTS = 2048      # above this many snapshots the full spectrum is a library call (rocSOLVER dsyevd, ~1 s at 10 000)
 LEADING_MAX_MODES = 112           # block of the subspace iteration <= 128 including its oversampling
+LEADING_MAX_ITERATIONS = 30       # srom_eigh_topk_dev gives up after this many (no gap behind the block): full spectrum then
 
 
 def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian=None, local_modes=None,
@@ -248,6 +249,8 @@ def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian
             kk = min(kk, n_s)
             w, trace = steps.leading(G, kk)
             Sigma = np.sqrt(w)
+            if getattr(steps, 'subspace_iterations', 0) >= LEADING_MAX_ITERATIONS:
+                break                                                   # a flat spectrum: the iteration has not settled -> full spectrum
             if rom_dim is not None:
                 k = kk
                 break

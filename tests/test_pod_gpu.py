@@ -348,7 +348,7 @@ def test_leading_eigenpairs_vs_numpy():
         assert np.abs(Vt @ Vt.T - np.eye(k)).max() <= 1e-10, spec
         assert np.abs(G @ Vt.T - Vt.T * w).max() <= 1e-9 * wref[0], (spec, np.abs(G @ Vt.T - Vt.T * w).max())
         np.testing.assert_allclose(Wk, Vt.T / np.sqrt(w), rtol=1e-12, atol=0)
-        assert 1 <= it.value <= 60
+        assert 1 <= it.value < 30
 
 
 def test_sharded_pod_build_leading_modes_vs_svd():
