@@ -12,7 +12,7 @@ namespace {
 #define GU_LAP(i) ((void)0)
 #endif
 
-template <int MSEL, int NSEL>
+template <int MSEL, int NSEL, int GXSEL>
 __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long prof[24] = {0};
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         double J;
         int qit;
         GU_LAP(1);
-        const int st = ql::solve_qp<MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, w, prof);
+        const int st = ql::solve_qp<MSEL, NSEL, GXSEL>(d, c, dyn, q, base, L, &J, &qit, w, prof);
         GU_LAP(2);
         if (st != 0) {                               // the fused kernel takes this rollout from here
             if (tid == 0) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     if (tid == 0) { rec[0] = 0.0; b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; }
 }
 
-template <int MSEL, int NSEL>
+template <int MSEL, int NSEL, int GXSEL>
 __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c, LocpBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long prof[24] = {0};
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
              (gptr)((b.dbg && p == 0) ? b.dbg : nullptr)};
     double J = 0.0;
     int it = 0;
-    const int st = ql::solve_qp<MSEL, NSEL>(d, c, dyn, q, wbase, L, &J, &it, w, prof);
+    const int st = ql::solve_qp<MSEL, NSEL, GXSEL>(d, c, dyn, q, wbase, L, &J, &it, w, prof);
     if (q.dbg && threadIdx.x == 0) {
         q.dbg[8 * 61] = 2.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; q.dbg[8 * 61 + 3] = st == 100 ? 0.0 : 1.0;
 #ifdef SRH_PROFILE
@@ -272,17 +272,26 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
     if (threadIdx.x == 0) { b.J[p] = J; b.status[p] = 0; b.iters[p] = it; }
 }
 
-// instantiated shapes: the reference's 4- and 8-cable robots, n_x fixed for the benchmark's r = 30 next to any n_x <= 64
-#define SRH_LEAN_VARIANTS(X) X(4, 60) X(8, 60) X(4, 0) X(8, 0)
-inline bool lean_matches(const QPDims &d, int msel, int nsel) { return d.m == msel && (nsel == 0 || d.n == nsel); }
+// instantiated shapes: the reference's 4- and 8-cable robots at the benchmark's r = 30 with the row layout their drivers use
+// (U box; Diamond: 4 state rows, Trunk: none), then n_x fixed / free with the general row handling (GX = 0)
+#define SRH_LEAN_VARIANTS(X) X(4, 60, 4) X(8, 60, 1) X(4, 60, 0) X(8, 60, 0) X(4, 0, 0) X(8, 0, 0)
+inline int lean_gx(const QPDims &d) {
+    if (d.lean != 2) return 0;
+    const int RXa = d.nX + d.nXf;
+    return RXa == 0 ? 1 : (RXa <= 2 ? 2 : (RXa <= 4 ? 4 : 8));
+}
+inline bool lean_matches(const QPDims &d, int msel, int nsel, int gx) {
+    if (d.m != msel || (nsel != 0 && d.n != nsel)) return false;
+    return gx == 0 || gx == lean_gx(d);
+}
 
 }  // namespace
 
 int lean_prepare(const QPDims &d, size_t lds) {
     SRH_REQUIRE(lds <= 160 * 1024, "lean kernels: %zu bytes of LDS needed, 160 KiB available", lds);
-#define X(M, NX) if (lean_matches(d, M, NX)) { \
-        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_lean_kernel<M, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)locp_lean_kernel<M, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+#define X(M, NX, GX) if (lean_matches(d, M, NX, GX)) { \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_lean_kernel<M, NX, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)locp_lean_kernel<M, NX, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
@@ -292,7 +301,8 @@ int lean_prepare(const QPDims &d, size_t lds) {
 
 int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
                       size_t lds, hipStream_t stream) {
-#define X(M, NX) if (lean_matches(d, M, NX)) { gusto_lean_kernel<M, NX><<<grid, NTHREADS, lds, stream>>>(d, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+    QPDims dd = d;
+#define X(M, NX, GX) if (lean_matches(d, M, NX, GX)) { if (GX == 0) dd.lean = 1; gusto_lean_kernel<M, NX, GX><<<grid, NTHREADS, lds, stream>>>(dd, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
     SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
@@ -300,7 +310,8 @@ int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const
 }
 
 int lean_launch_locp(const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream) {
-#define X(M, NX) if (lean_matches(d, M, NX)) { locp_lean_kernel<M, NX><<<grid, NTHREADS, lds, stream>>>(d, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+    QPDims dd = d;
+#define X(M, NX, GX) if (lean_matches(d, M, NX, GX)) { if (GX == 0) dd.lean = 1; locp_lean_kernel<M, NX, GX><<<grid, NTHREADS, lds, stream>>>(dd, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
     SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);

@@ -842,17 +842,310 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
     return status;
 }
 
+// ------------------------------------------------------------------ the same interior point, rows next to their sums
+// ipm() above keeps qpc::solve's row handling: every inequality row in the registers of "some" thread, its weight D and
+// gradient shift rho through L2 arrays, then stage_factors / gradients re-read them per stage -- three L2 round trips and
+// ~35 k clocks per Newton system that do no arithmetic to speak of.  ipm_box() maps the rows so that the sums are LOCAL:
+//   * input rows: the reference's HyperRectangle layout (rows 2 b and 2 b + 1 bound input b, utils.py:390-414): thread
+//     (k, b) owns both, so D_kb = 2 R_bb + a0^2 D0 + a1^2 D1 and the input gradient need no other thread;
+//   * state rows of stage k: GX = 1, 2, 4 or 8 adjacent lanes; S_k = S* + sum_r D_r t_r t_r^T and the output gradient by
+//     DPP sums, the 2 x 2 (semidefinite) Cholesky factor in closed form by the first lane.
+// Same iteration, same quantities (sums in another order: rounding-level differences).  QPDims::lean == 2 selects it.
+__device__ __forceinline__ void reduce2(double &a, int opa, double &b, int opb, lptr scratch) {
+    auto wr = [](double v, int op) { return op == 0 ? wg::wave_sum(v) : (op == 1 ? wg::wave_max(v) : wg::wave_min(v)); };
+    const double wa = wr(a, opa), wb = wr(b, opb);
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { scratch[wave] = wa; scratch[8 + wave] = wb; }
+    __syncthreads();
+    auto comb = [](double x, double y, int op) { return op == 0 ? x + y : (op == 1 ? fmax(x, y) : fmin(x, y)); };
+    double ra = scratch[0], rb = scratch[8];
+    for (int i = 1; i < nw; ++i) { ra = comb(ra, scratch[i], opa); rb = comb(rb, scratch[8 + i], opb); }
+    a = ra; b = rb;
+}
+
+template <int G>
+__device__ __forceinline__ double gsum(double v) {
+    if constexpr (G == 1) return v;
+    else if constexpr (G == 2) return v + wg::dpp_mov<0xB1>(v);
+    else return wg::group_sum<G>(v);
+}
+
+template <int MSEL, int NSEL, int GX>
+__device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
+                                       Lds &L, int *iters_out, QPWork &wout, long long *prof) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    QPDims d = dfull;
+    d.tr = 0;
+    d.nrx = d.nX;
+    d.RX = d.nrx + d.nXf;
+    d.NR = d.N * d.RX + d.N * d.nU;
+    d.ng = d.N * d.nrx + d.nXf + d.N * d.nU;
+    QPWork w;
+    qp_carve(w, work_base, d);
+    wout = w;
+    gptr gh = work_base + dfull.qc_off;
+    const int N = d.N, m = d.m, nm = N * m, ldG = 16 * d.KT, NP = 2 * N, nz = d.nz;
+    GPack g{(cgptr)gh, (clptr)(L.Gt), d.lean_j0, m, NP};
+    Prof pf;
+#ifdef SRH_PROFILE
+    for (int i = 0; i < 24; ++i) pf.t[i] = 0;
+    long long tq_last = clock64();
+    auto qlap = [&](int slot) { const long long now = clock64(); prof[slot] += now - tq_last; tq_last = now; };
+#define QB_LAP(x) qlap(x)
+#else
+#define QB_LAP(x) ((void)0)
+#endif
+    for (int e = tid; e < nm; e += nt) { w.u[e] = 0.0; L.u[e] = 0.0; }
+    for (int e = tid; e < ldG + YPAD; e += nt) { L.ya[e] = 0.0; L.yd[e] = 0.0; L.yg[e] = 0.0; }     // padding stays zero for good
+    for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
+    for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+    __syncthreads();
+    bool reuse = false;
+    if (dyn.idx != nullptr) {
+        int same = L.flag[2];
+        for (int k = tid; k < N; k += nt) same = same && (L.goff[k] == L.idxl[k]);
+        if (tid == 0) L.flag[3] = 1;
+        __syncthreads();
+        if (!same) L.flag[3] = 0;
+        __syncthreads();
+        reuse = L.flag[3] != 0;
+    }
+    if (!reuse) {
+        rollout<MSEL, NSEL>(d, dyn, q.x0, (cgptr) nullptr, w.x, L);
+        QB_LAP(0);
+        condense<MSEL, NSEL>(d, c, dyn, w.x, gh, L);
+        for (int k = tid; k < N; k += nt) L.goff[k] = L.idxl[k];
+        if (tid == 0) L.flag[2] = 1;
+    }
+    for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yf[e]; L.dy[e] = 0.0; }
+    __syncthreads();
+    QB_LAP(2);
+    // ---- this thread's rows
+    const bool isu = tid < nm;
+    const int tx = tid - nm;
+    const bool isx = tx >= 0 && tx < N * GX;
+    const int ku = isu ? tid / m : 0, bu = isu ? tid - ku * m : 0;
+    const int kx = isx ? tx / GX + 1 : 1, rx = isx ? tx - (kx - 1) * GX : 0;        // stage 1..N, row slot
+    const int nrk = d.nX + (kx == N ? d.nXf : 0);
+    const bool xrow = isx && rx < nrk;                                               // the slot holds a state row
+    const bool xlead = isx && rx == 0;                                               // first lane of the stage group
+    double ca[2] = {0.0, 0.0}, rh[2] = {0.0, 0.0};                                   // row coefficients / right-hand sides
+    if (isu) {
+        ca[0] = c.UA[(size_t)(2 * bu) * m + bu]; ca[1] = c.UA[(size_t)(2 * bu + 1) * m + bu];
+        rh[0] = c.Ub[2 * bu]; rh[1] = c.Ub[2 * bu + 1];
+    } else if (xrow) {
+        cgptr T = rx < d.nX ? c.Tx + (size_t)rx * 2 : c.Txf + (size_t)(rx - d.nX) * 2;
+        ca[0] = T[0]; ca[1] = T[1];
+        rh[0] = rx < d.nX ? c.Xb[rx] : c.Xfb[rx - d.nX];
+    }
+    const double r2bb = isu ? c.R2[bu * m + bu] : 0.0;
+    const double udv = (isu && q.ud) ? q.ud[(size_t)ku * m + bu] : 0.0;
+    // constant part of the output gradient of this stage (lead lane): -Cz2 z_k (- Czf2 zf at k = N)
+    double gc0 = 0.0, gc1 = 0.0, s00 = 0.0, s01 = 0.0, s11 = 0.0;
+    if (xlead) {
+        cgptr S = (kx == N) ? c.ScN : c.Sc;
+        s00 = S[0]; s01 = S[1]; s11 = S[3];
+        if (q.z) for (int b = 0; b < nz; ++b) { gc0 = fma(-c.Cz2[b], q.z[(size_t)kx * nz + b], gc0); gc1 = fma(-c.Cz2[nz + b], q.z[(size_t)kx * nz + b], gc1); }
+        if (kx == N && c.Qzf && q.zf) for (int b = 0; b < nz; ++b) { gc0 = fma(-c.Czf2[b], q.zf[b], gc0); gc1 = fma(-c.Czf2[nz + b], q.zf[b], gc1); }
+    }
+    const int nrow = isu ? 2 : (xrow ? 1 : 0);
+    double rt[2] = {0.0, 0.0}, rlam[2] = {0.0, 0.0}, rrg[2] = {0.0, 0.0}, rrc[2] = {0.0, 0.0}, rdt[2] = {0.0, 0.0}, rdl[2] = {0.0, 0.0};
+    // a_row . (y, u) for row slot s2
+    auto row_val = [&](int s2, clptr vy, clptr vu) -> double {
+        if (isu) return ca[s2] * vu[tid];
+        return fma(ca[1], vy[(kx - 1) * 2 + 1], ca[0] * vy[(kx - 1) * 2]);
+    };
+    int status = 1, it = 0;
+    enum { INIT = 0, PRED = 1, CORR = 2 };
+    int mode = INIT;
+    double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
+    bool near_opt = false;
+    while (true) {
+        QB_LAP(7);
+        // ---------------- rows -> weights, gradient shifts, and their per-stage sums, all in place
+        double musum = 0.0, rpm = 0.0;
+        double Dw[2] = {0.0, 0.0}, rho[2] = {0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 >= nrow) continue;
+            if (mode == INIT) {
+                const double gq = row_val(s2, L.y, L.u) - rh[s2];
+                Dw[s2] = 1.0; rho[s2] = gq; rlam[s2] = 0.0;
+            } else if (mode == PRED) {
+                const double gq = row_val(s2, L.y, L.u) - rh[s2];
+                const double t = rt[s2], lam = rlam[s2], rg = gq + t;
+                rrg[s2] = rg;
+                Dw[s2] = lam / (t + dreg * lam);
+                rho[s2] = Dw[s2] * (rg + dreg * lam);
+                musum += lam * t;
+                rpm = fmax(rpm, fabs(rg));
+            } else {
+                const double t = rt[s2], lam = rlam[s2];
+                const double rc = lam * t + rdt[s2] * rdl[s2] - sig * mu;
+                rrc[s2] = rc;
+                rho[s2] = lam + (lam * rrg[s2] - rc) / (t + dreg * lam);
+            }
+        }
+        if (isu) {
+            const double du0 = r2bb * (L.u[tid] - udv);
+            if (mode != CORR) {
+                double v = fma(ca[0] * Dw[0], ca[0], r2bb);
+                v = fma(ca[1] * Dw[1], ca[1], v);
+                L.Ldi[tid] = 1.0 / sqrt(v);
+            }
+            L.ta[tid] = fma(ca[1], rho[1], fma(ca[0], rho[0], du0));
+            if (mode == PRED) L.tb[tid] = fma(ca[1], rlam[1], fma(ca[0], rlam[0], du0));
+        }
+        if (isx) {                                           // whole stage groups: the DPP sums see every lane of a group
+            const double y0 = L.y[(kx - 1) * 2], y1 = L.y[(kx - 1) * 2 + 1];
+            if (mode != CORR) {
+                const double a00 = gsum<GX>(ca[0] * Dw[0] * ca[0]), a01 = gsum<GX>(ca[0] * Dw[0] * ca[1]), a11 = gsum<GX>(ca[1] * Dw[0] * ca[1]);
+                if (xlead) {
+                    const double S00 = s00 + a00, S01 = s01 + a01, S11 = s11 + a11;
+                    const double dmax = fmax(fabs(S00), fabs(S11));
+                    const double l00 = S00 > 1e-14 * dmax ? sqrt(S00) : 0.0;
+                    const double l10 = l00 > 0.0 ? S01 / l00 : 0.0;
+                    const double v = fma(-l10, l10, S11);
+                    const double l11 = v > 1e-14 * dmax ? sqrt(v) : 0.0;
+                    lptr Lk = L.Ls + (size_t)(kx - 1) * 4;
+                    Lk[0] = l00; Lk[1] = 0.0; Lk[2] = l10; Lk[3] = l11;
+                }
+            }
+            const double r0 = gsum<GX>(ca[0] * rho[0]), r1 = gsum<GX>(ca[1] * rho[0]);
+            double l0 = 0.0, l1 = 0.0;
+            if (mode == PRED) { l0 = gsum<GX>(ca[0] * rlam[0]); l1 = gsum<GX>(ca[1] * rlam[0]); }
+            if (xlead) {
+                const double c0 = fma(s01, y1, s00 * y0) + gc0, c1 = fma(s11, y1, s01 * y0) + gc1;
+                L.ya[(kx - 1) * 2] = c0 + r0; L.ya[(kx - 1) * 2 + 1] = c1 + r1;
+                if (mode == PRED) { L.yg[(kx - 1) * 2] = c0 + l0; L.yg[(kx - 1) * 2 + 1] = c1 + l1; }
+            }
+        }
+        if (mode == PRED) {
+            reduce2(musum, 0, rpm, 1, L.red);
+            mu = musum / d.ng;
+            rp = rpm;
+        }
+        __syncthreads();
+        QB_LAP(1);
+        // ---------------- Newton system
+        double rd = 0.0;
+        bool ok = true;
+        if (mode != CORR) {
+            QB_LAP(3);
+            gram<MSEL>(d, c, g, L);
+            QB_LAP(4);
+            ok = qpc::tile_cholesky(d, L);
+            QB_LAP(5);
+        }
+#ifdef SRH_PROFILE
+        pf.last = clock64();
+#endif
+        if (ok) newton_solve<MSEL>(d, g, L, mode == PRED ? (clptr)L.yg : (clptr) nullptr, &rd, pf);
+        QB_LAP(6);
+        // ---------------- use the direction
+        if (mode == INIT) {
+            if (!ok) { status = 2; break; }
+            for (int e = tid; e < nm; e += nt) L.u[e] += L.du[e];
+            for (int e = tid; e < ldG; e += nt) L.y[e] += L.dy[e];
+            __syncthreads();
+            if (d.ng == 0) { status = 0; break; }
+            double zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 >= nrow) continue;
+                const double gq = row_val(s2, L.y, L.u) - rh[s2];
+                rrg[s2] = gq;
+                zmin = fmin(zmin, gq); zmax = fmax(zmax, gq);
+            }
+            reduce2(zmin, 2, zmax, 1, L.red);
+            const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { rt[s2] = -rrg[s2] + sh_t; rlam[s2] = rrg[s2] + sh_l; }
+            for (int e = tid; e < d.n; e += nt) {
+                double gq = 0.0;
+                if (q.z) for (int a = 0; a < nz; ++a) gq = fma(c.HtQz2[e * nz + a], -q.z[nz + a], gq);
+                sd = fmax(sd, fabs(gq));
+            }
+            for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
+            reduce2(sd, 1, sp, 1, L.red);
+            sd = fmax(sd, q.omega);
+            sp = fmax(sp, fabs(q.delta));
+            dreg = d.reg / sd;
+            mode = PRED;
+            continue;
+        }
+        double amax = 1e300, dummy = 0.0;
+        if (ok) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 >= nrow) continue;
+                const double t = rt[s2], lam = rlam[s2], rga = rrg[s2] + row_val(s2, L.dy, L.du);
+                const double dl = ((mode == PRED ? -lam * t : -rrc[s2]) + lam * rga) / (t + dreg * lam);
+                const double dtv = -rga + dreg * dl;
+                rdl[s2] = dl; rdt[s2] = dtv;
+                if (dtv < 0.0) amax = fmin(amax, -t / dtv);
+                if (dl < 0.0) amax = fmin(amax, -lam / dl);
+            }
+        }
+        reduce2(amax, 2, dummy, 0, L.red);
+        if (mode == PRED) {
+            if (!ok) { status = near_opt ? 0 : 2; break; }
+            if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
+            if (!(rd == rd)) { status = near_opt ? 0 : 6; break; }
+            if (q.dbg && tid == 0) { gptr gd = q.dbg + 8 * it; gd[0] = mu; gd[1] = rd; gd[2] = rp; gd[3] = sd; gd[4] = sp; }
+            const double ltol = fmax(d.tol, 1e-9);
+            if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
+            near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
+            if (it >= d.max_iter) { status = 1; break; }
+            const double a_aff = fmin(1.0, amax);
+            double ma = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                if (s2 < nrow) ma += (rlam[s2] + a_aff * rdl[s2]) * (rt[s2] + a_aff * rdt[s2]);
+            reduce2(ma, 0, dummy, 0, L.red);
+            const double mu_aff = ma / d.ng;
+            sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+            if (q.dbg && tid == 0) { gptr gd = q.dbg + 8 * it; gd[5] = a_aff; gd[6] = sig; }
+            mode = CORR;
+            continue;
+        }
+        if (!ok) { status = 2; break; }
+        const double a = fmin(1.0, 0.99 * amax);
+        if (q.dbg && tid == 0) { gptr gd = q.dbg + 8 * it; gd[7] = a; }
+        for (int e = tid; e < nm; e += nt) L.u[e] += a * L.du[e];
+        for (int e = tid; e < ldG; e += nt) L.y[e] += a * L.dy[e];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { rt[s2] += a * rdt[s2]; rlam[s2] += a * rdl[s2]; }
+        __syncthreads();
+        ++it;
+        mode = PRED;
+    }
+    __syncthreads();
+    for (int e = tid; e < nm; e += nt) w.u[e] = L.u[e];
+    __syncthreads();
+#ifdef SRH_PROFILE
+    for (int i = 0; i < 8; ++i) prof[8 + i] += pf.t[8 + i];
+#endif
+    if (iters_out) *iters_out = it;
+    return status;
+}
+
 // The QP as the SCP loop needs it: condensed interior point, states by a rollout of the minimiser, objective, trust-region
 // test.  Returns 0 when the result IS the minimiser of the full QP (converged, inside the trust region); anything else
 // means "hand this QP to the fused kernel" (status of the interior point, or 100 = minimiser outside the trust region).
-template <int MSEL, int NSEL>
+template <int MSEL, int NSEL, int GXSEL>
 __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                         Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof) {
     const int tid = threadIdx.x, nt = blockDim.x;
     QPLds Lq{};
     Lq.v1 = L.v1; Lq.v2 = L.v2; Lq.Qu = L.Qu; Lq.part = L.part; Lq.red = L.red; Lq.idxl = L.idxl; Lq.flag = L.flag;
     int it = 0;
-    const int st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
+    int st;
+    // GXSEL > 0: box-structured input rows, rows next to their sums, GXSEL lanes per stage for the state rows (one variant per
+    // kernel: both interior points in one kernel thrash the instruction cache -- measured -8 % on everything)
+    if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof);
+    else st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
     if (iters_out) *iters_out = it;
     if (st != 0) return st;
     QPDims d0 = dfull;

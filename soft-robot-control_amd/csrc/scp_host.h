@@ -345,6 +345,17 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             if (j0 >= 0 && j0 < N && lean_gram_schedule(N, m, d.KT, NTHREADS / 64, sched)) {
                 d.lean = 1;
                 d.lean_j0 = j0;
+                // rows next to their sums (ql::ipm_box): the reference's HyperRectangle layout of the input rows (rows 2 b,
+                // 2 b + 1 act on input b alone, utils.py:390-414), at most 8 state rows per stage, everything in 512 threads
+                bool box = pr->nU == 2 * m && !getenv("SRH_QP_NO_BOX");
+                for (int r = 0; r < pr->nU && box; ++r)
+                    for (int b = 0; b < m; ++b) {
+                        const bool want = b == r / 2;
+                        if ((pr->UA[r * m + b] != 0.0) != want) { box = false; break; }
+                    }
+                const int RXa = pr->nX + pr->nXf;
+                const int GX = RXa == 0 ? 1 : (RXa <= 2 ? 2 : (RXa <= 4 ? 4 : 8));
+                if (box && RXa <= 8 && N * m + N * GX <= NTHREADS && (N * m) % GX == 0) d.lean = 2;
                 if ((rc = C.gram_sched.upload(sched.data(), sizeof(int) * sched.size()))) return rc;
             }
         }
