@@ -10,6 +10,4 @@ cp $R/*.h $R/*.hip /tmp/prof/csrc/
 ( cd $R && /opt/rocm/bin/hipcc $F -c lean.hip -o lean.o && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 *.o -o ../sofacontrol_amd/libsofacontrol_hip.so ) &
 ( cd /tmp/prof/csrc && /opt/rocm/bin/hipcc -DSRH_PROFILE $F -c lean.hip -o lean.o && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 *.o -o ../sofacontrol_amd/libsofacontrol_hip.so && cp ../sofacontrol_amd/libsofacontrol_hip.so /root/repo/gpurun_variants/libsofacontrol_hip_prof.so ) &
 wait
-# keep make's view consistent: the other objects are up to date with respect to the headers
-touch $R/*.o $R/../sofacontrol_amd/libsofacontrol_hip.so
 echo built

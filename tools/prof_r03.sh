@@ -1,0 +1,7 @@
+# rocprofv3 passes behind profiles/r03* (run on the GPU box from the repository root: bash tools/prof_r03.sh)
+R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_trace -o r03 -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/r03_bench_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r03_pmc_fetch -o f -- python3 $R/tools/pmc_kernels.py > $R/gpurun_out/r03_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r03_pmc_write -o w -- python3 $R/tools/pmc_kernels.py > $R/gpurun_out/r03_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/r03_pmc_mfma -o m -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > $R/gpurun_out/r03_pmc_mfma.log 2>&1
+cd $R; python3 tools/prof_r03_summarise.py
