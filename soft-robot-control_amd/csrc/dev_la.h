@@ -73,7 +73,7 @@ __device__ __forceinline__ double wave_min(double v) { return wave_reduce<2>(v);
 // op: 0 sum, 1 max, 2 min.  Result broadcast to every thread.  Deterministic (fixed tree).
 __device__ inline double reduce(double v, int op, lptr scratch) {
     double w = op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v));
-    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x + 63) >> 6;
     __syncthreads();  // scratch may still be read from a previous reduction
     if ((threadIdx.x & 63) == 0) scratch[wave] = w;
     __syncthreads();
@@ -218,7 +218,7 @@ typedef double qp_d4 __attribute__((ext_vector_type(4)));
 // D reg q of lane l is C[row = (l>>4) + 4q][col = l&15].
 __device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, int K, int MT, int NTl, int ld, int vrows,
                                          int srows = 1 << 30) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
     for (int t0 = wave; t0 < ntiles; t0 += 2 * nw) {

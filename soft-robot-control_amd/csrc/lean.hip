@@ -26,7 +26,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     gptr base = (gptr)(b.work + p * b.work_stride);
     QPWork w;
     qp_carve(w, base, d);

@@ -188,7 +188,7 @@ template <int MSEL, int NSEL>
 __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, const QPDyn &dyn, cgptr x, QCWork &w, Lds &L) {
     const int N = d.N, n = d.n, m = d.m, po = d.po, ld = d.ld, KT = d.KT, ldG = qc_ldg(d), ldT = ldG + 1;
     const int nk = d.NK, NPa = d.NPa;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     for (int e = tid; e < ldG; e += nt) {
         double v = 0.0;
@@ -371,7 +371,7 @@ __device__ __forceinline__ void gram(const QPDims &d, const QCWork &w, Lds &L) {
     constexpr int MB = PIPE ? MSEL : 16;                                   // bound of the register block
     constexpr int IT = PIPE ? (SR / MB * 128 + 511) / 512 : 1;             // (stage, column) items per thread and slab
     const int N = d.N, m = d.m, po = d.po, KT = d.KT, ldG = qc_ldg(d), NP = N * po;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int cj = SR / m > 0 ? SR / m : 1;        // stages per slab
     const int rows_used = (cj * m + 3) & ~3;
@@ -511,12 +511,18 @@ __device__ __forceinline__ void gram(const QPDims &d, const QCWork &w, Lds &L) {
 }
 
 // ------------------------------------------------------------------ tile Cholesky K = R^T R (upper), in place
-// diagonal tile: factor + inverse in registers, lane c (mod 16) holds column c; values of other columns by v_readlane
+// diagonal tile: factor + inverse in registers.  Lanes 0..15 hold the columns of the tile, lanes 16..31 the columns of the
+// identity; the elimination is a sequence of ROW operations M (M A = R, so M = R^-T) whose multipliers are wave-uniform
+// (v_readlane from lanes 0..15), so the same instructions carry the identity to M = Rinv^T at no extra cost -- no
+// separate back-substitution for the inverse on the one wave that is the critical path of the factorisation.
 __device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
-    const int c = threadIdx.x & 15;
-    double a[16], x[16], dinv[16];
+    const int lane = threadIdx.x & 63, c = lane & 15, grp = lane >> 4;
+    double a[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = T[r * TS + c];
+    for (int r = 0; r < 16; ++r) {
+        const double t = T[r * TS + c];
+        a[r] = grp == 0 ? t : ((grp == 1 && r == c) ? 1.0 : 0.0);
+    }
     bool ok = true;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -524,24 +530,16 @@ __device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
         ok = ok && (piv > 0.0);
         const double di = rsqrt(piv);
         const double di2 = di * (1.5 - 0.5 * piv * di * di);       // one Newton step: full double accuracy
-        dinv[s] = di2;
         a[s] *= di2;
 #pragma unroll
         for (int r = s + 1; r < 16; ++r) a[r] = fma(-readlane_d(a[s], r), a[s], a[r]);
     }
+    if (grp == 0) {
 #pragma unroll
-    for (int r = 15; r >= 0; --r) {
-        double sum = (r == c) ? 1.0 : 0.0;
+        for (int r = 0; r < 16; ++r) T[r * TS + c] = (r <= c) ? a[r] : 0.0;
+    } else if (grp == 1) {                                         // a[r] = M[r][c] = Rinv[c][r]
 #pragma unroll
-        for (int k = r + 1; k < 16; ++k) sum = fma(-readlane_d(a[r], k), x[k], sum);
-        x[r] = (r <= c) ? sum * dinv[r] : 0.0;
-    }
-    if ((threadIdx.x & 63) < 16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            T[r * TS + c] = (r <= c) ? a[r] : 0.0;
-            Rinv[r * TS + c] = x[r];
-        }
+        for (int r = 0; r < 16; ++r) Rinv[c * TS + r] = a[r];
     }
     return ok;
 }
@@ -561,7 +559,7 @@ __device__ __forceinline__ void tile_update(lptr T, clptr Ra, clptr Rb, int l16,
 // Right-looking over tile rows.  Wave 0 owns the critical path: it updates the next diagonal tile first and factors it
 // while the other waves finish the trailing update of the step.
 __device__ __forceinline__ bool tile_cholesky(const QPDims &d, Lds &L) {
-    const int KT = d.KT, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     if (wave == 0) {
         const bool ok = chol16(L.B, L.Rinv);
@@ -611,7 +609,7 @@ __device__ __forceinline__ bool tile_cholesky(const QPDims &d, Lds &L) {
 // ---- products with the factor (tile rows / columns over the waves; vectors of 16 KT entries in LDS)
 // out = R x   (R upper: tile row J needs tiles (J, J') for J' >= J)
 __device__ __forceinline__ void r_times(const QPDims &d, Lds &L, clptr x, lptr out) {
-    const int KT = d.KT, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int c = lane & 15, part = lane >> 4;
     for (int J = wave; J < KT; J += nw) {
         double acc = 0.0;
@@ -628,7 +626,7 @@ __device__ __forceinline__ void r_times(const QPDims &d, Lds &L, clptr x, lptr o
 }
 // out = R^T x   (tile column J needs tiles (I, J) for I <= J)
 __device__ __forceinline__ void rT_times(const QPDims &d, Lds &L, clptr x, lptr out) {
-    const int KT = d.KT, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int c = lane & 15, part = lane >> 4;
     for (int J = wave; J < KT; J += nw) {
         double acc = 0.0;

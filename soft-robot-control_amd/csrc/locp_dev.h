@@ -331,7 +331,7 @@ __device__ __forceinline__ void stage_prepass(const QPDims &d, const QPConst &c,
         w.ez[e] = v;
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     for (int k = 1 + wave; k <= N; k += nw) {
         cgptr Dk = w.D + (size_t)(k - 1) * d.RX, rk = w.rho + (size_t)(k - 1) * d.RX;
         cgptr lk = w.lam + (size_t)(k - 1) * d.RX;
@@ -420,7 +420,7 @@ using wg::mfma_atb;
 template <int NR>
 __device__ __forceinline__ void mfma_acc(qp_d4 (&acc)[NR], clptr Lm, clptr Rm, int K, int MT, int NTl, int ld) {
     static_assert(NR % 2 == 0, "tiles are processed in pairs");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
 #pragma unroll
@@ -448,7 +448,7 @@ __device__ __forceinline__ void mfma_acc(qp_d4 (&acc)[NR], clptr Lm, clptr Rm, i
 // C rows < srows of the accumulated tiles (no barrier inside)
 template <int NR>
 __device__ __forceinline__ void mfma_put(const qp_d4 (&acc)[NR], lptr C, int ldc, int MT, int NTl, int srows) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
 #pragma unroll
@@ -681,7 +681,7 @@ __device__ __forceinline__ void panel_T_vec(const QPDims &d, QPLds &L, clptr v, 
 template <int MSEL, int NSEL>
 __device__ __forceinline__ void vector_sweep_back(const QPDims &d, const QPDyn &dyn, QPWork &w, QPLds &L) {
     const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     constexpr int NP = 2;                                   // column passes of 64: n <= 128
     lptr pv = L.pv, pn = L.v3;
     const int c = lane >> 3, g8 = lane & 7;
@@ -753,7 +753,7 @@ __device__ __forceinline__ void vector_sweep_back(const QPDims &d, const QPDyn &
 template <int MSEL, int NSEL>
 __device__ __forceinline__ void vector_sweep_fwd(const QPDims &d, const QPDyn &dyn, QPWork &w, QPLds &L) {
     const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6, nm = n + m;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6, nm = n + m;
     for (int e = tid; e < n; e += nt) { L.v1[e] = 0.0; w.dx[e] = 0.0; }
     __syncthreads();
     lptr xu = L.v1, xn = L.v2;
@@ -843,7 +843,7 @@ __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c,
                                      bool full, bool with_dual, double *rd_out) {
     const int n = d.n, m = MSEL > 0 ? MSEL : d.m, N = d.N, ld = d.ld, NK = d.NK, NPa = d.NPa, n16 = (d.n + 15) & ~15;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int xoff = d.tr ? 2 * n + 1 : 0;
     double rd = 0.0;
 #ifdef SRH_PROFILE

@@ -102,7 +102,7 @@ struct GPack {
 template <int MSEL, int NSEL>
 __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr x0, cgptr u, gptr x, Lds &L) {
     const int N = d.N, n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, nk = d.NK;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l = lane & 15, il = l >> 3, sl = l & 7;
     const int i = 8 * wave + 2 * (lane >> 4) + il, ic = i < n ? i : n - 1;
     const int vlen = (int)(((size_t)ld + 3) & ~(size_t)3);
@@ -147,7 +147,7 @@ template <int MSEL, int NSEL>
 __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, const QPDyn &dyn, cgptr x, gptr gh, Lds &L) {
     const int N = d.N, n = d.n, m = d.m, po = d.po, ld = d.ld, KT = d.KT, ldG = 16 * d.KT, ldT = ldG + 1;
     const int nk = d.NK, NPa = d.NPa, NP = N * po, j0 = d.lean_j0;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     for (int e = tid; e < ldG; e += nt) {
         double v = 0.0;
@@ -347,7 +347,7 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     static_assert(MSEL == 4 || MSEL == 8, "lean Gram: n_u = 4 or 8");
     constexpr int M = MSEL, SPS = M / 4;                       // k-steps per stage
     const int N = d.N, KT = d.KT, NP = g.NP;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l16 = lane & 15, kk = lane >> 4;
     const int goff0 = goff(g.j0, M, NP);
     lptr w2 = L.tc;                                            // 1 / D per packed row
@@ -467,6 +467,114 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ K^-1 v with the factor in unit-block-diagonal form
+// qpc::k_solve substitutes through the 2 KT block rows on one wave with a diagonal solve, two LDS round trips and four
+// ds_bpermute sums per block row (23 k clocks per right-hand side, two or three per factorisation).  Here the factor is
+// rewritten once per factorisation as R = Dh Uh, Dh = blockdiag(R_JJ), Uh_IJ = Rinv_I R_IJ (unit block diagonal, in place
+// of R_IJ: one MFMA product per tile, all waves), so that
+//     K^-1 v = Uh^-1 ( Dh^-1 Dh^-T ( Uh^-T v ) )
+// and both block substitutions have NO diagonal solve: right-looking on one wave, the partial sums of every block row that
+// is still open live in registers (the updates of the rows further down are independent work that covers the latency of
+// the one LDS round trip per step), the 4 partial sums of an entry sit in one quad (two DPP adds).  The block-diagonal
+// scaling in the middle is one tile per wave.  (An explicit inverse T = R^-1 with x = T T^T v was measured as well: 2.5 k
+// clocks per solve, but its residual costs the interior point an iteration on some QPs -- slower overall.)
+__device__ __forceinline__ void unit_tiles(const QPDims &d, Lds &L) {
+    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int l16 = lane & 15, kk = lane >> 4, noff = KT * (KT - 1) / 2;
+    for (int t = wave; t < noff; t += 8) {
+        int tt = t, I = 0;
+        while (tt >= KT - 1 - I) { tt -= KT - 1 - I; ++I; }
+        const int J = I + 1 + tt;
+        lptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ;
+        clptr Ri = L.Rinv + (size_t)I * TSZ;
+        double av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { av[s] = Ri[l16 * TS + 4 * s + kk]; bv[s] = T[(4 * s + kk) * TS + l16]; }
+        wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[(kk + 4 * q) * TS + l16] = acc[q];
+    }
+    __syncthreads();
+}
+
+// v <- K^-1 v (scaled K; v: 16 KT doubles of LDS).  KT <= 8; KTC > 0 fixes KT at compile time (no branch between the tile
+// updates of a step: their LDS reads are issued together instead of one tile at a time).
+template <int KTC>
+__device__ __forceinline__ void k_solve_unit_impl(const QPDims &d, Lds &L, lptr v) {
+    constexpr int KMAX = KTC > 0 ? KTC : 8;
+    const int KT = KTC > 0 ? KTC : d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c = lane >> 2, part = lane & 3;
+    if (wave == 0) {                                                     // y = Uh^-T v
+        double acc[KMAX];
+#pragma unroll
+        for (int J = 0; J < KMAX; ++J) acc[J] = 0.0;
+#pragma unroll
+        for (int I = 0; I < KMAX; ++I) {
+            if (KTC > 0 || I < KT) {
+                const double yI = v[16 * I + c] - wg::group_sum<4>(acc[I]);
+                __builtin_amdgcn_wave_barrier();
+                if (part == 0) v[16 * I + c] = yI;
+                __builtin_amdgcn_wave_barrier();
+                const double y0 = v[16 * I + 4 * part], y1 = v[16 * I + 4 * part + 1], y2 = v[16 * I + 4 * part + 2], y3 = v[16 * I + 4 * part + 3];
+#pragma unroll
+                for (int J = I + 1; J < KMAX; ++J) {
+                    if (KTC > 0 || J < KT) {
+                        clptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ + (4 * part) * TS + c;
+                        acc[J] = fma(T[0], y0, fma(T[TS], y1, fma(T[2 * TS], y2, fma(T[3 * TS], y3, acc[J]))));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < KT) {                                                     // w_J = Rinv_J (Rinv_J^T y_J)
+        const int J = wave;
+        clptr Ri = L.Rinv + (size_t)J * TSZ;
+        double t = 0.0;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) t = fma(Ri[(4 * part + kq) * TS + c], v[16 * J + 4 * part + kq], t);
+        t = wg::group_sum<4>(t);
+        __builtin_amdgcn_wave_barrier();
+        if (part == 0) v[16 * J + c] = t;
+        __builtin_amdgcn_wave_barrier();
+        double w = 0.0;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) w = fma(Ri[c * TS + 4 * part + kq], v[16 * J + 4 * part + kq], w);
+        w = wg::group_sum<4>(w);
+        __builtin_amdgcn_wave_barrier();
+        if (part == 0) v[16 * J + c] = w;
+    }
+    __syncthreads();
+    if (wave == 0) {                                                     // x = Uh^-1 w
+        double acc[KMAX];
+#pragma unroll
+        for (int J = 0; J < KMAX; ++J) acc[J] = 0.0;
+#pragma unroll
+        for (int Jp = KMAX - 1; Jp >= 0; --Jp) {
+            if (KTC > 0 || Jp < KT) {
+                const double xJ = v[16 * Jp + c] - wg::group_sum<4>(acc[Jp]);
+                __builtin_amdgcn_wave_barrier();
+                if (part == 0) v[16 * Jp + c] = xJ;
+                __builtin_amdgcn_wave_barrier();
+                const double x0 = v[16 * Jp + 4 * part], x1 = v[16 * Jp + 4 * part + 1], x2 = v[16 * Jp + 4 * part + 2], x3 = v[16 * Jp + 4 * part + 3];
+#pragma unroll
+                for (int J = 0; J < Jp; ++J) {
+                    clptr T = L.B + (size_t)qpc::tile_index(J, Jp, KT) * TSZ + c * TS + 4 * part;
+                    acc[J] = fma(T[0], x0, fma(T[1], x1, fma(T[2], x2, fma(T[3], x3, acc[J]))));
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void k_solve_unit(const QPDims &d, Lds &L, lptr v) {
+    if (d.KT == 7) k_solve_unit_impl<7>(d, L, v);            // N p_o = 100: the benchmark horizons
+    else k_solve_unit_impl<0>(d, L, v);
+}
+
 // Newton direction (qpc::newton_solve with the products from the packed store)
 template <int MSEL>
 __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
@@ -488,7 +596,11 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Ld
     qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc);
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
+#ifdef QL_KSOLVE_SUBST
     qpc::k_solve(d, L, L.yc);
+#else
+    k_solve_unit(d, L, L.yc);
+#endif
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
     QC_SUB(pf, 12);
@@ -740,6 +852,9 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
 #endif
                 QL_LAP(4);
                 ok = qpc::tile_cholesky(d, L);
+#ifndef QL_KSOLVE_SUBST
+                if (ok) unit_tiles(d, L);
+#endif
                 QL_LAP(5);
             }
         }
@@ -854,7 +969,7 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
 __device__ __forceinline__ void reduce2(double &a, int opa, double &b, int opb, lptr scratch) {
     auto wr = [](double v, int op) { return op == 0 ? wg::wave_sum(v) : (op == 1 ? wg::wave_max(v) : wg::wave_min(v)); };
     const double wa = wr(a, opa), wb = wr(b, opb);
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { scratch[wave] = wa; scratch[8 + wave] = wb; }
     __syncthreads();
@@ -1036,6 +1151,9 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
             gram<MSEL>(d, c, g, L);
             QB_LAP(4);
             ok = qpc::tile_cholesky(d, L);
+#ifndef QL_KSOLVE_SUBST
+            if (ok) unit_tiles(d, L);
+#endif
             QB_LAP(5);
         }
 #ifdef SRH_PROFILE

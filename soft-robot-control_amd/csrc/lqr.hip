@@ -400,7 +400,7 @@ struct IlqrOp {
 
 __device__ __forceinline__ void ilqr_mm(lptr C, int ldc, const IlqrOp &Lo, const IlqrOp &Ro, int K, int MT, int NTl, int vrows,
                                         int srows) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     for (int t = wave; t < MT * NTl; t += nw) {
         const int ti = t / NTl, tj = t - ti * NTl;

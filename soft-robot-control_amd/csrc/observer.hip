@@ -535,7 +535,7 @@ __global__ __launch_bounds__(EKF_NT) void ekf_mfma_kernel(EkfArgs a) {
 template <bool LG, bool RG, typename LP, typename RP, typename EPI>
 __device__ __forceinline__ void ekf_mm(lptr C, int ldc, int crows, int ccols, LP Lm, int ldl, int nl, RP Rm, int ldr, int nr,
                                        int K, int MT, int NTl, EPI epi, bool use_epi) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     for (int t = wave; t < MT * NTl; t += nw) {
         const int ti = t / NTl, tj = t - ti * NTl;

@@ -6,7 +6,7 @@
 namespace {
 
 __global__ void nearest_kernel(TpwlDev T, const double *__restrict__ X, int64_t B, int32_t *__restrict__ idx) {
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int64_t k = (int64_t)blockIdx.x * nw + wave;
     if (k >= B) return;
     const int i = tpwl::nearest_wave(T, X + k * T.n);

@@ -68,7 +68,7 @@ __device__ inline int nearest_wave(const TpwlDev &T, XP x) {
 // All waves of the workgroup participate; ends with __syncthreads().
 template <typename XP, typename IP>
 __device__ inline void nearest_many(const TpwlDev &T, XP X, int ldx, int count, IP idx) {
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     for (int k = wave; k < count; k += nw) {
         const int i = nearest_wave(T, X + (size_t)k * ldx);
         if ((threadIdx.x & 63) == 0) idx[k] = i;

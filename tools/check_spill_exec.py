@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Toolchain guard: VGPR spills that are stored only while EXEC is narrowed and reloaded while it is wider.
+
+hipcc (ROCm 7.2 LLVM) places 'Folded Spill' scratch stores of values that live across a divergent `if` at the top of the
+join block BEFORE the `s_or_b64 exec, exec, s[..]` that re-enables the lanes, or inside the region; scratch stores honour
+EXEC, so the lanes that sat the region out never reach the stack slot, and a reload after the region hands them whatever
+the slot held before.  (Seen in round 3: the final rollout of the lean LOCP kernel loaded its stage matrices through
+garbage addresses in threads 400..479 after an `if (tid < N n_u)` region -- a wrong result that came and went with
+unrelated edits.)
+
+The check looks for the placement itself: inside one basic block of the -S output, a 'Folded Spill' scratch store that
+precedes an `s_or_b64 exec, exec, s[..]` (the lanes come back AFTER the store) with no EXEC write in between, and whose
+stack slot is reloaded somewhere else in the function.  A store whose register is written between the matching EXEC
+narrowing (`s_and_saveexec_b64 s[a:b]` / `s_mov_b64 s[a:b], exec`) and the store is left alone: that is a value the
+region itself produced for its own lanes (the other side of the branch fills the rest of the slot).
+
+`--fix` rewrites the file: every flagged store moves to just behind the EXEC restore (the register still holds the
+value in every lane there -- nothing between the two writes it, which the tool verifies), followed by the wait states a
+wide store wants before its data registers may be overwritten.  The build (csrc/Makefile) compiles device code to
+assembly, runs this, and assembles the result, so what ships has been through the check.  Usage: check_spill_exec.py [--fix] file.s [...]
+(exit status 1 when something is flagged and not fixed)
+"""
+import re, sys
+
+FUNC = re.compile(r'^(_Z\w+|\w+):\s*; @')
+LABEL = re.compile(r'^\.LBB\w+:')
+BRANCH = re.compile(r'^\s*s_(c?branch|endpgm|setpc)')
+EXEC_WRITE = re.compile(r'^\s*(s_\w+saveexec_b64|s_\w+ exec,)')
+POP = re.compile(r'^\s*s_or_b64 exec, exec,')
+SPILL = re.compile(r'^\s*scratch_store_dword\w*\s+off, (v\[?[\d:]+\]?), off(?: offset:(\d+))?\s*; .*Folded Spill')
+RELOAD = re.compile(r'^\s*scratch_load_dword\w*\s+(v\[?[\d:]+\]?), off, off(?: offset:(\d+))?\s*; .*Folded Reload')
+
+
+def regs_of(tok):
+    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+
+
+DEST = re.compile(r'^\s*(?:v_\w+|ds_read\w*|global_load\w*|scratch_load\w*|buffer_load\w*|flat_load\w*)\s+(v\[\d+:\d+\]|v\d+)')
+
+
+def defined_in_region(lines, store_ln, restore_ln, reg_tok):
+    """is the stored register written between the narrowing of EXEC that `restore_ln` undoes and the store?"""
+    m = re.search(r's_or_b64 exec, exec, (s\[\d+:\d+\])', lines[restore_ln - 1])
+    if not m:
+        return False
+    saved = re.escape(m.group(1))
+    opener = re.compile(r'^\s*(s_\w*saveexec_b64 %s,|s_mov_b64 %s, exec)' % (saved, saved))
+    want = regs_of(reg_tok)
+    for i in range(store_ln - 2, max(0, store_ln - 6000), -1):
+        line = lines[i]
+        if opener.match(line):
+            return False
+        d = DEST.match(line)
+        if d and regs_of(d.group(1)) & want:
+            return True
+    return False
+
+
+def scan(path):
+    """-> [(function, slot, line of the store, line of the exec restore)]"""
+    flagged, func, pending, cand, reloaded = [], None, [], [], set()
+    lines = open(path).read().split('\n')
+
+    def close():
+        for f, off, ln, lr in cand:
+            if off in reloaded:
+                reg = SPILL.match(lines[ln - 1]).group(1)
+                if not defined_in_region(lines, ln, lr, reg):
+                    flagged.append((f, off, ln, lr))
+
+    with open(path) as fh:
+        for ln, line in enumerate(fh, 1):
+            m = FUNC.match(line)
+            if m:
+                close()
+                func, pending, cand, reloaded = m.group(1), [], [], set()
+                continue
+            if func is None:
+                continue
+            if LABEL.match(line) or BRANCH.match(line):
+                pending = []
+                continue
+            if POP.match(line):
+                cand.extend((func, off, l, ln) for off, l in pending)
+                pending = []
+                continue
+            if EXEC_WRITE.match(line):
+                pending = []
+                continue
+            m = SPILL.match(line)
+            if m:
+                pending.append((int(m.group(2) or 0), ln))
+                continue
+            m = RELOAD.match(line)
+            if m:
+                reloaded.add(int(m.group(2) or 0))
+    close()
+    return flagged
+
+
+def fix(path):
+    """move the flagged stores behind their EXEC restore, in place; -> (moved, refused)"""
+    flagged = scan(path)
+    if not flagged:
+        return 0, 0
+    lines = open(path).read().split('\n')
+    moves, refused = {}, 0
+    for func, off, ln, lr in flagged:
+        reg = regs_of(SPILL.match(lines[ln - 1]).group(1))
+        clobbered = any(DEST.match(lines[i]) and regs_of(DEST.match(lines[i]).group(1)) & reg for i in range(ln, lr))
+        # the vmcnt bookkeeping of the surrounding code stays valid only if the store does not pass another vector memory
+        # operation or a wait on the way
+        crossed = any(re.match(r'^\s*(s_waitcnt|global_|flat_|buffer_|scratch_load)', lines[i]) or
+                      (re.match(r'^\s*scratch_store', lines[i]) and not SPILL.match(lines[i])) for i in range(ln, lr - 1))
+        if clobbered or crossed:
+            refused += 1
+            continue
+        moves.setdefault(lr, []).append(ln)
+    drop = {ln for lns in moves.values() for ln in lns}
+    out = []
+    for i, line in enumerate(lines, 1):
+        if i in drop:
+            continue
+        out.append(line)
+        if i in moves:
+            for ln in moves[i]:
+                out.append(lines[ln - 1].split(';')[0].rstrip() + ' ; spill moved behind the EXEC restore (check_spill_exec.py)')
+            out.append('\ts_nop 1')
+    open(path, 'w').write('\n'.join(out))
+    return len(drop), refused
+
+
+def main(argv):
+    do_fix = '--fix' in argv
+    argv = [a for a in argv if a != '--fix']
+    bad = 0
+    for path in argv:
+        if do_fix:
+            moved, refused = fix(path)
+            if moved or refused:
+                print('%s: %d spill(s) moved behind their EXEC restore, %d refused' % (path, moved, refused))
+        for func, off, ln, lr in scan(path):
+            bad += 1
+            print('%s:%d: %s: spill to stack slot %d sits before the EXEC restore at line %d' % (path, ln, func[:100], off, lr))
+    print('%d spill(s) stored under a narrowed EXEC' % bad)
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main(sys.argv[1:]))
