@@ -44,6 +44,7 @@ int srh_malloc(void **dptr, size_t bytes);
 int srh_free(void *dptr);
 int srh_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int srh_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int srh_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
 int srh_memset(void *dptr, int value, size_t bytes);
 int srh_sync(void);
 /* The host-pointer entry points keep the device blocks they release in a size-class cache (<= 2 GiB per process)
@@ -102,6 +103,28 @@ int srom_reduce_matrix_dev(srom_t *h, const double *M_dev, int64_t ncols, int le
 int srom_gramian_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, double *G_dev,
                      void *stream);
 int srom_gramian(const double *S, int64_t n_s, int64_t n_f, double *G);
+/* process_snapshots (pod.py:157-178) on a resident snapshot matrix S (n_s x n_f, one snapshot per row, row pitch lds >= n_f).
+ * Column statistics over the snapshots (each output n_f doubles on the device, any of them may be NULL):
+ * min / max for 'normalize' (pod.py:165), mean for 'substract_mean' (pod.py:168). */
+int srom_snapshot_stats_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, double *min_dev, double *max_dev,
+                            double *mean_dev, void *stream);
+/* 'normalize' in place: S <- (S - min) / (max + 1e-15 - min)   (pod.py:165) */
+int srom_snapshot_normalize_dev(double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, const double *min_dev,
+                                const double *max_dev, void *stream);
+/* 'substract_mean' in place: S <- S - mean   (pod.py:168) */
+int srom_snapshot_center_dev(double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, const double *mean_dev, void *stream);
+/* 'clustering' (pod.py:170-174 -> compute_kmeans_centroids, pod.py:207-216: sklearn KMeans(k, n_init=100, max_iter=1000,
+ * random_state=0)); the estimator's dense Lloyd algorithm restated on the device, one run from given centres:
+ * C_dev (k x n_f) holds the initial centres and receives the final ones; labels_dev (n_s int32); tol = the absolute
+ * threshold on the summed squared centre shift (sklearn: 1e-4 * mean column variance); *iters_out = Lloyd iterations.
+ * srom_row_sqnorms_dev / srom_sqdist_rows_dev provide what the k-means++ seeding needs: |x_i|^2 and the squared
+ * distances max(0, |y_c|^2 - 2 y_c . x_i + |x_i|^2) of every snapshot to nc given rows Y (nc x n_f) -> out (nc x n_s);
+ * the seeding's random draws stay with the caller (numpy's RandomState in the reference's stack). */
+int srom_row_sqnorms_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, double *out_dev, void *stream);
+int srom_sqdist_rows_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, const double *Y_dev, int nc,
+                         const double *xnorm_dev, double *out_dev, void *stream);
+int srom_kmeans_lloyd_dev(const double *S_dev, int64_t n_s, int64_t n_f, int64_t lds, int k, double *C_dev, int max_iter,
+                          double tol, int32_t *labels_dev, double *inertia_out, int *iters_out, void *stream);
 /* eigh of the (symmetric) Gramian in place on the device (cyclic Jacobi kernels up to n = 2048, rocSOLVER dsyevd
  * above): on return row j of G_dev is
  * the eigenvector of the j-th smallest eigenvalue, w_dev (n) ascending.  Replaces the SVD of pod.py:190. */

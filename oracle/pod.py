@@ -67,6 +67,93 @@ def get_snapshots(data, pod_type):
     raise ValueError(pod_type)
 
 
+def process_snapshots(snapshots, preprocess, args):
+    """sofacontrol/mor/pod.py:157-178 (snapshots: n_s x n_f, one per row)."""
+    snapshots = np.array(snapshots, dtype=float)
+    if 'normalize' in preprocess:
+        snapshots = (snapshots - snapshots.min(axis=0)) / (snapshots.max(axis=0) + 1e-15 - snapshots.min(axis=0))
+    if 'substract_mean' in preprocess:
+        snapshots = snapshots - snapshots.mean(axis=0, keepdims=True)
+    if 'clustering' in preprocess and args.get('nbr_clusters', 0) > 0:
+        snapshots = kmeans_centroids(snapshots, args['nbr_clusters'])
+    return snapshots
+
+
+def kmeans_centroids(X, k, n_init=100, max_iter=1000, random_state=0, tol=1e-4):
+    """sofacontrol/mor/pod.py:207-216 calls sklearn.cluster.KMeans(k, n_init=100, max_iter=1000, random_state=0) -- a
+    third-party dependency of the reference (scikit-learn, unpinned there; 1.7.2 in this image).  This is a plain-numpy
+    restatement of that estimator's published dense algorithm (`sklearn/cluster/_kmeans.py`: centring, k-means++ seeding
+    with 2 + int(log k) local trials, Lloyd iterations, empty-cluster relocation, best of n_init by inertia), pinned by
+    tests/golden g19 (the imported reference's own output) and, where sklearn is installed, against sklearn itself."""
+    X = np.array(X, dtype=float)
+    n_s, n_f = X.shape
+    mean = X.mean(axis=0)
+    X = X - mean
+    xn = (X * X).sum(axis=1)
+    tol_abs = np.mean(np.var(X, axis=0)) * tol
+    rs = np.random.RandomState(random_state)
+    n_trials = 2 + int(np.log(k))
+
+    def sqdist(Y):
+        return np.maximum((Y * Y).sum(axis=1)[:, None] - 2.0 * Y @ X.T + xn[None, :], 0.0)
+
+    def labels_of(Cc):
+        return np.argmin((Cc * Cc).sum(axis=1)[None, :] - 2.0 * X @ Cc.T, axis=1)
+
+    best = None
+    for _ in range(n_init):
+        idx = np.empty(k, dtype=int)
+        idx[0] = rs.choice(n_s, p=np.full(n_s, 1.0 / n_s))
+        closest = sqdist(X[idx[:1]])[0]
+        pot = closest.sum()
+        for c in range(1, k):
+            cand = np.searchsorted(np.cumsum(closest), rs.uniform(size=n_trials) * pot)
+            np.clip(cand, None, n_s - 1, out=cand)
+            d = np.minimum(closest, sqdist(X[cand]))
+            pots = d.sum(axis=1)
+            b = int(np.argmin(pots))
+            pot, closest, idx[c] = pots[b], d[b], cand[b]
+        Cc = X[idx].copy()
+        labels_old = np.full(n_s, -1)
+        strict = False
+        for _it in range(max_iter):
+            labels = labels_of(Cc)
+            sums = np.zeros_like(Cc)
+            np.add.at(sums, labels, X)
+            counts = np.bincount(labels, minlength=k).astype(float)
+            empty = np.where(counts == 0)[0]
+            if len(empty):
+                dist = ((X - Cc[labels]) ** 2).sum(axis=1)
+                far = np.argsort(-dist, kind='stable')[:len(empty)]
+                for e, f in zip(empty, far):
+                    sums[labels[f]] -= X[f]; sums[e] = X[f]; counts[e] = 1; counts[labels[f]] -= 1
+            Cn = np.where(counts[:, None] > 0, sums / np.maximum(counts, 1)[:, None], Cc)
+            shift = ((Cn - Cc) ** 2).sum()
+            Cc = Cn
+            if np.array_equal(labels, labels_old):
+                strict = True
+                break
+            if shift <= tol_abs:
+                break
+            labels_old = labels
+        if not strict:
+            labels = labels_of(Cc)
+        inertia = ((X - Cc[labels]) ** 2).sum()
+        if best is None or (inertia < best[0] and not _same_clustering(labels, best[1], k)):
+            best = (inertia, labels, Cc)
+    return best[2] + mean
+
+
+def _same_clustering(a, b, k):
+    m = np.full(k, -1)
+    for la, lb in zip(a, b):
+        if m[la] == -1:
+            m[la] = lb
+        elif m[la] != lb:
+            return False
+    return True
+
+
 def energy_truncation(S, tol):
     """sofacontrol/mor/pod.py:192-197 -- smallest k>=1 with sum(S[k:]^2)/sum(S^2) <= tol."""
     s2 = S ** 2

@@ -24,7 +24,11 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int KC = 64;        // columns of X per chunk
+#ifndef SRH_PROJ_KC
+#define SRH_PROJ_KC 64
+#endif
+constexpr int KC = SRH_PROJ_KC;   // columns of X per chunk (a row is read in runs of 8 KC bytes)
+constexpr int TSTEP = KC / 4;     // MFMA k-steps per chunk
 #ifndef SRH_PROJ_MT
 #define SRH_PROJ_MT 2
 #endif
@@ -56,14 +60,14 @@ __global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, 
     //              four row blocks (lane>>2)&3                                (B operand of v_mfma_f64_4x4x4, 4 blocks)
     const int NF = NTF + NQ;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)nchunks * 16 * NF * 64;
+    int64_t total = (int64_t)nchunks * TSTEP * NF * 64;
     if (idx >= total) return;
     int lane = idx & 63;
     int64_t rest = idx >> 6;
     int f = rest % NF;
     rest /= NF;
-    int t = rest & 15;
-    int64_t c = rest >> 4;
+    int t = rest % TSTEP;
+    int64_t c = rest / TSTEP;
     int64_t i = c * KC + 8 * (t >> 1) + 2 * (lane >> 4) + (t & 1);
     int j = f < NTF ? 16 * f + (lane & 15) : 16 * NTF + 4 * (f - NTF) + (lane & 3);
     ufrag[idx] = (i < n_f && j < r) ? U[i * r + j] : 0.0;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NF = NTF + NQ;
     constexpr int NT = NTF > 0 ? NTF : 1, NQA = NQ > 0 ? NQ : 1;   // array extents
-    constexpr int UCH = 16 * NF * 64;         // doubles of U fragments per chunk
+    constexpr int UCH = TSTEP * NF * 64;      // doubles of U fragments per chunk
     constexpr int BUF = UCH + KC;             // + reference chunk
     double *lds = reinterpret_cast<double *>(smem);
 
@@ -125,10 +129,10 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
         xrow[mt] = X + row * a.ldx;
     }
 
-    double xr[MTP][16];
+    double xr[MTP][TSTEP];
     // register t of a lane holds column 64c + 8*(t>>1) + 2*kgrp + (t&1): the four k-groups of a row read
     // adjacent 16-byte pieces, so one load instruction covers 64 contiguous bytes of each of its 16 rows
-    auto load_x = [&](int c, double (&dst)[MTP][16]) {
+    auto load_x = [&](int c, double (&dst)[MTP][TSTEP]) {
         const int64_t col0 = (int64_t)c * KC + 2 * kgrp;
         if ((int64_t)c * KC + KC <= a.n_f) {
 #pragma unroll
@@ -136,21 +140,21 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
                 const double *p = xrow[mt] + col0;
                 if (VEC2) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
+                    for (int q = 0; q < TSTEP / 2; ++q) {
                         d2 v = *reinterpret_cast<const d2 *>(p + 8 * q);
                         dst[mt][2 * q] = v.x;
                         dst[mt][2 * q + 1] = v.y;
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { dst[mt][2 * q] = p[8 * q]; dst[mt][2 * q + 1] = p[8 * q + 1]; }
+                    for (int q = 0; q < TSTEP / 2; ++q) { dst[mt][2 * q] = p[8 * q]; dst[mt][2 * q + 1] = p[8 * q + 1]; }
                 }
             }
         } else {
 #pragma unroll
             for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < TSTEP / 2; ++q) {
                     const int64_t cc = col0 + 8 * q;
                     dst[mt][2 * q] = (cc < a.n_f) ? xrow[mt][cc] : 0.0;
                     dst[mt][2 * q + 1] = (cc + 1 < a.n_f) ? xrow[mt][cc + 1] : 0.0;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
     __syncthreads();
     for (int c = c0; c < c1; ++c) {
         const int b = (c - c0) & 1;
-        double xn[MTP][16];
+        double xn[MTP][TSTEP];
         const bool more = (c + 1 < c1);
         if (more) {
             stage_load(c + 1);
@@ -212,14 +216,14 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
         if (HAS_REF) {
             const double *rb = ub + UCH + 2 * kgrp;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < TSTEP; ++q) {
                 double rv = rb[8 * (q >> 1) + (q & 1)];
 #pragma unroll
                 for (int mt = 0; mt < MTP; ++mt) xr[mt][q] -= rv;
             }
         }
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < TSTEP; ++t) {
 #pragma unroll
             for (int nt = 0; nt < NTF; ++nt) {
                 double bv = ub[(t * NF + nt) * 64 + lane];
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MTP; ++mt)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) xr[mt][q] = xn[mt][q];
+                for (int q = 0; q < TSTEP; ++q) xr[mt][q] = xn[mt][q];
         }
     }
 
@@ -642,28 +646,36 @@ static int proj_ksplit(const srom *h, int64_t B, int nblk, int *chunks_per_split
     return (int)srh::cdiv(h->nchunks, *chunks_per_split);
 }
 
-template <int NTF, int NQ>
-static int launch_utmu(const ProjArgs &a, bool vec2, dim3 grid, hipStream_t s) {
-    constexpr int LDP = 16 * (NTF + (NQ ? 1 : 0)), LDT = (LDP % 32 == 0) ? LDP + 16 : LDP;
-    size_t lds = std::max<size_t>(2 * (size_t)(16 * (NTF + NQ) * 64 + KC), (size_t)ROWS_WG * LDT) * sizeof(double);
-    if (vec2) proj_kernel<NTF, NQ, false, true, true><<<grid, 256, lds, s>>>(a);
-    else proj_kernel<NTF, NQ, false, false, true><<<grid, 256, lds, s>>>(a);
+// one launch of a projection kernel instantiation; dynamic LDS above the 64 KB default is requested once per instantiation
+template <void (*KERN)(ProjArgs)>
+static int launch_proj_kernel(const ProjArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool raised = false;
+    lds = srh::lds_request(lds);
+    if (!raised && lds > 64 * 1024) {
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    KERN<<<grid, 256, lds, s>>>(a);
     SRH_CHECK_HIP(hipGetLastError());
     return SRH_OK;
 }
 
 template <int NTF, int NQ>
+static int launch_utmu(const ProjArgs &a, bool vec2, dim3 grid, hipStream_t s) {
+    constexpr int LDP = 16 * (NTF + (NQ ? 1 : 0)), LDT = (LDP % 32 == 0) ? LDP + 16 : LDP;
+    size_t lds = std::max<size_t>(2 * (size_t)(TSTEP * (NTF + NQ) * 64 + KC), (size_t)ROWS_WG * LDT) * sizeof(double);
+    return vec2 ? launch_proj_kernel<proj_kernel<NTF, NQ, false, true, true>>(a, grid, lds, s)
+                : launch_proj_kernel<proj_kernel<NTF, NQ, false, false, true>>(a, grid, lds, s);
+}
+
+template <int NTF, int NQ>
 static int launch_proj(const ProjArgs &a, bool has_ref, bool vec2, dim3 grid, hipStream_t s) {
-    size_t lds = 2 * (size_t)(16 * (NTF + NQ) * 64 + KC) * sizeof(double);
-    if (has_ref) {
-        if (vec2) proj_kernel<NTF, NQ, true, true><<<grid, 256, lds, s>>>(a);
-        else proj_kernel<NTF, NQ, true, false><<<grid, 256, lds, s>>>(a);
-    } else {
-        if (vec2) proj_kernel<NTF, NQ, false, true><<<grid, 256, lds, s>>>(a);
-        else proj_kernel<NTF, NQ, false, false><<<grid, 256, lds, s>>>(a);
-    }
-    SRH_CHECK_HIP(hipGetLastError());
-    return SRH_OK;
+    size_t lds = 2 * (size_t)(TSTEP * (NTF + NQ) * 64 + KC) * sizeof(double);
+    if (has_ref)
+        return vec2 ? launch_proj_kernel<proj_kernel<NTF, NQ, true, true>>(a, grid, lds, s)
+                    : launch_proj_kernel<proj_kernel<NTF, NQ, true, false>>(a, grid, lds, s);
+    return vec2 ? launch_proj_kernel<proj_kernel<NTF, NQ, false, true>>(a, grid, lds, s)
+                : launch_proj_kernel<proj_kernel<NTF, NQ, false, false>>(a, grid, lds, s);
 }
 
 template <int KS>
@@ -719,12 +731,12 @@ int srom_create(srom_t **out, const double *U, int64_t n_f, int r, const double 
     if ((rc = h->U.upload(U, sizeof(double) * n_f * r)) ||
         (rc = h->q_ref.upload(q_ref ? q_ref : zeros.data(), sizeof(double) * n_f)) ||
         (rc = h->v_ref.upload(v_ref ? v_ref : zeros.data(), sizeof(double) * n_f)) ||
-        (rc = h->ufrag.alloc(sizeof(double) * (size_t)h->nchunks * 16 * (h->NTF + h->NQ) * 64)) ||
+        (rc = h->ufrag.alloc(sizeof(double) * (size_t)h->nchunks * TSTEP * (h->NTF + h->NQ) * 64)) ||
         (rc = h->ut.alloc(sizeof(double) * (size_t)(16 * h->ntiles + 32) * 4 * ((r + 3) / 4)))) {
         delete h;
         return rc;
     }
-    int64_t tot = (int64_t)h->nchunks * 16 * (h->NTF + h->NQ) * 64;
+    int64_t tot = (int64_t)h->nchunks * TSTEP * (h->NTF + h->NQ) * 64;
     pack_u_kernel<<<(unsigned)srh::cdiv(tot, 256), 256>>>(h->U.as<double>(), n_f, r, h->NTF, h->NQ, h->nchunks,
                                                          h->ufrag.as<double>());
     h->ldu = 16 * h->ntiles + 32;

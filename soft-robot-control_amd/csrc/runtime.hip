@@ -136,6 +136,10 @@ int srh_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     SRH_CHECK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return SRH_OK;
 }
+int srh_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+    SRH_CHECK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return SRH_OK;
+}
 int srh_memset(void *dptr, int value, size_t bytes) {
     SRH_CHECK_HIP(hipMemset(dptr, value, bytes));
     return SRH_OK;

@@ -147,14 +147,119 @@ def get_snapshots(data, pod_type):
 
 
 def process_snapshots(snapshots, preprocess, args):
-    """pod.py:157-178 (clustering is an sklearn call in the reference and is outside the hot path)."""
-    if 'normalize' in preprocess:
-        snapshots = (snapshots - snapshots.min(axis=0)) / (snapshots.max(axis=0) + 1e-15 - snapshots.min(axis=0))
-    if 'substract_mean' in preprocess:
-        snapshots = snapshots - snapshots.mean(axis=0, keepdims=True)
-    if 'clustering' in preprocess and args.get('nbr_clusters', 0) > 0:
-        raise NotImplementedError('kmeans clustering preprocess is outside the hot path')
-    return snapshots
+    """pod.py:157-178 on the device: the snapshot matrix (n_s x n_f, one snapshot per row) is uploaded once, 'normalize',
+    'substract_mean' and 'clustering' run on the resident copy (csrc/snapshots.hip), the result comes back as an array."""
+    wanted = [p_ for p_ in ('normalize', 'substract_mean', 'clustering') if p_ in preprocess]
+    if 'clustering' in wanted and not args.get('nbr_clusters', 0) > 0:
+        print('Not using kmeans because nbr_clusters not specified in config.preprocess_args dictionary')
+        wanted.remove('clustering')
+    if not wanted:
+        return snapshots
+    S = np.ascontiguousarray(snapshots, dtype=np.float64)
+    dS, n_s, n_f = _process_snapshots_dev(_lib.DeviceBuffer.from_array(S), S.shape[0], S.shape[1], wanted, args)
+    return dS.to_array((n_s, n_f))
+
+
+def _process_snapshots_dev(dS, n_s, n_f, wanted, args):
+    """The preprocessing steps on a resident snapshot matrix; returns (buffer, n_s, n_f) -- clustering replaces the
+    snapshots by the k centroids."""
+    L = _lib.lib()
+    n64 = (C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f))
+    if 'normalize' in wanted:
+        dmin, dmax = _lib.DeviceBuffer(n_f * 8), _lib.DeviceBuffer(n_f * 8)
+        _lib.check(L.srom_snapshot_stats_dev(dS.ptr, *n64, dmin.ptr, dmax.ptr, None, None), 'srom_snapshot_stats_dev')
+        _lib.check(L.srom_snapshot_normalize_dev(dS.ptr, *n64, dmin.ptr, dmax.ptr, None), 'srom_snapshot_normalize_dev')
+    if 'substract_mean' in wanted:
+        dmean = _lib.DeviceBuffer(n_f * 8)
+        _lib.check(L.srom_snapshot_stats_dev(dS.ptr, *n64, None, None, dmean.ptr, None), 'srom_snapshot_stats_dev')
+        _lib.check(L.srom_snapshot_center_dev(dS.ptr, *n64, dmean.ptr, None), 'srom_snapshot_center_dev')
+    if 'clustering' in wanted:
+        k = int(args['nbr_clusters'])
+        print('Computing %d centroids for an initial snapshot size of %d using k-means clustering' % (k, n_s))
+        dS = _kmeans_centroids_dev(dS, n_s, n_f, k)
+        n_s = k
+    _lib.sync()
+    return dS, n_s, n_f
+
+
+def compute_kmeans_centroids(snapshot, k, n_init=100, max_iter=1000, random_state=0, tol=1e-4):
+    """pod.py:207-216: the centroids sklearn's KMeans(k, n_init=100, max_iter=1000, random_state=0) returns, with the
+    distance products, assignments and centroid sums on the device (see _kmeans_centroids_dev)."""
+    S = np.ascontiguousarray(snapshot, dtype=np.float64)
+    print('Computing %d centroids for an initial snapshot size of %d using k-means clustering' % (k, S.shape[0]))
+    dC = _kmeans_centroids_dev(_lib.DeviceBuffer.from_array(S), S.shape[0], S.shape[1], int(k), n_init, max_iter, random_state, tol)
+    return dC.to_array((int(k), S.shape[1]))
+
+
+def _same_clustering(a, b, k):
+    """sklearn's _is_same_clustering: equal up to a permutation of the labels."""
+    mapping = np.full(k, -1, dtype=np.int64)
+    for la, lb in zip(a, b):
+        if mapping[la] == -1:
+            mapping[la] = lb
+        elif mapping[la] != lb:
+            return False
+    return True
+
+
+def _kmeans_centroids_dev(dS, n_s, n_f, k, n_init=100, max_iter=1000, random_state=0, tol=1e-4):
+    """scikit-learn's KMeans.fit (dense Lloyd, k-means++ seeding) restated around device kernels.  The data are centred
+    first (as the estimator does, for the accuracy of the distance products), every one of the n_init runs is seeded by
+    k-means++ with draws from ONE numpy RandomState(random_state) in the estimator's order (`choice` for the first
+    centre, 2 + int(log k) `uniform` trials per further centre), and the best run is the first with the smallest inertia
+    whose clustering differs.  The random draws, the cumulative sums they are compared with and the bookkeeping are host
+    work on n_s-vectors; every pass over the n_s x n_f data runs on the device."""
+    L = _lib.lib()
+    n64 = (C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f))
+    dX = _lib.DeviceBuffer(n_s * n_f * 8)
+    _lib.check(L.srh_memcpy_d2d(dX.ptr, dS.ptr, C.c_size_t(n_s * n_f * 8)), 'srh_memcpy_d2d')
+    dmean, dxn = _lib.DeviceBuffer(n_f * 8), _lib.DeviceBuffer(n_s * 8)
+    _lib.check(L.srom_snapshot_stats_dev(dX.ptr, *n64, None, None, dmean.ptr, None), 'srom_snapshot_stats_dev')
+    _lib.check(L.srom_snapshot_center_dev(dX.ptr, *n64, dmean.ptr, None), 'srom_snapshot_center_dev')
+    _lib.check(L.srom_row_sqnorms_dev(dX.ptr, *n64, dxn.ptr, None), 'srom_row_sqnorms_dev')
+    _lib.sync()
+    xn = dxn.to_array((n_s,))
+    tol_abs = float(xn.sum() / (n_s * n_f)) * tol          # mean column variance of the centred data x tol
+    rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    n_trials = 2 + int(np.log(k))
+    dY, dD = _lib.DeviceBuffer(n_trials * n_f * 8), _lib.DeviceBuffer(n_trials * n_s * 8)
+    dC, dlab = _lib.DeviceBuffer(k * n_f * 8), _lib.DeviceBuffer(n_s * 4)
+    row_bytes = n_f * 8
+
+    def rows_to(dst, ids):
+        for t, i in enumerate(ids):
+            _lib.check(L.srh_memcpy_d2d(C.c_void_p(dst.ptr.value + t * row_bytes), C.c_void_p(dX.ptr.value + int(i) * row_bytes),
+                                        C.c_size_t(row_bytes)), 'srh_memcpy_d2d')
+
+    def dist_rows(ids):
+        rows_to(dY, ids)
+        _lib.check(L.srom_sqdist_rows_dev(dX.ptr, *n64, dY.ptr, C.c_int(len(ids)), dxn.ptr, dD.ptr, None), 'srom_sqdist_rows_dev')
+        return dD.to_array((n_trials, n_s))[:len(ids)]
+
+    best = None
+    for _ in range(n_init):
+        # k-means++ (sklearn _kmeans_plusplus, unit sample weights)
+        indices = np.empty(k, dtype=np.int64)
+        indices[0] = rs.choice(n_s, p=np.full(n_s, 1.0 / n_s))
+        closest = dist_rows([indices[0]])[0].copy()
+        pot = closest.sum()
+        for c in range(1, k):
+            rand_vals = rs.uniform(size=n_trials) * pot
+            cand = np.searchsorted(np.cumsum(closest, dtype=np.float64), rand_vals)
+            np.clip(cand, None, n_s - 1, out=cand)
+            d = np.minimum(closest, dist_rows(cand))
+            pots = d.sum(axis=1)
+            b = int(np.argmin(pots))
+            pot, closest, indices[c] = pots[b], d[b].copy(), cand[b]
+        rows_to(dC, indices)
+        inertia, iters = C.c_double(), C.c_int()
+        _lib.check(L.srom_kmeans_lloyd_dev(dX.ptr, *n64, C.c_int(k), dC.ptr, C.c_int(max_iter), C.c_double(tol_abs), dlab.ptr,
+                                           C.byref(inertia), C.byref(iters), None), 'srom_kmeans_lloyd_dev')
+        labels = dlab.to_array((n_s,), dtype=np.int32)
+        if best is None or (inertia.value < best[0] and not _same_clustering(labels, best[1], k)):
+            best = (inertia.value, labels, dC.to_array((k, n_f)))
+    centers = best[2] + dmean.to_array((n_f,))
+    return _lib.DeviceBuffer.from_array(np.ascontiguousarray(centers))
 
 
 def energy_truncation(S, tol):

@@ -846,7 +846,26 @@ def g14_locp(out):
     np.savez_compressed(os.path.join(out, 'g14_locp.npz'), **res)
 
 
-GENERATORS = dict(g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
+def g19_preprocess(out):
+    """process_snapshots / compute_kmeans_centroids of the imported reference (pod.py:157-178, 207-216; sklearn is a
+    dependency of the reference and is installed in the build container) on small seeded snapshot sets."""
+    rng = np.random.default_rng(19)
+    res = {}
+    # three well separated blobs + a structureless cloud
+    blobs = np.concatenate([c + 0.3 * rng.standard_normal((20, 37)) for c in (np.zeros(37), 4.0 * np.ones(37), -3.0 * np.arange(37) / 37)])
+    cloud = rng.standard_normal((90, 23)) * (1.0 + np.arange(23))
+    for name, S, k in (('blobs', blobs, 3), ('cloud', cloud, 7)):
+        res[name] = S
+        res[name + '_normalize'] = rpod.process_snapshots(S.copy(), ['normalize'], {})
+        res[name + '_mean'] = rpod.process_snapshots(S.copy(), ['substract_mean'], {})
+        res[name + '_both'] = rpod.process_snapshots(S.copy(), ['normalize', 'substract_mean'], {})
+        res[name + '_k'] = k
+        res[name + '_centroids'] = rpod.process_snapshots(S.copy(), ['clustering'], dict(nbr_clusters=k))
+        res[name + '_all'] = rpod.process_snapshots(S.copy(), ['normalize', 'substract_mean', 'clustering'], dict(nbr_clusters=k))
+    np.savez_compressed(os.path.join(out, 'g19_preprocess.npz'), **res)
+
+
+GENERATORS = dict(g19_preprocess=g19_preprocess, g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
                   g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
                   g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers,
                   g16_dubins=g16_dubins, g17_ssm_hardware=g17_ssm_hardware, g18_pod_shipped=g18_pod_shipped)

@@ -360,3 +360,17 @@ def test_pod_oracle_on_the_shipped_model(golden):
     M = np.random.default_rng(int(g['seed']) + 1).standard_normal((n_f, n_f))
     close(opod.reduce_matrix(U, M), g['UMU'], 1e-11)
     assert np.abs(U.T @ U - np.eye(r)).max() < 1e-13
+
+
+@pytest.mark.parametrize('name', ['blobs', 'cloud'])
+def test_g19_snapshot_preprocessing_and_kmeans_restatement(name):
+    """oracle.pod.process_snapshots (incl. the numpy restatement of sklearn's KMeans that the reference calls) against the
+    imported reference's outputs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g19_preprocess.npz'))
+    S, k = g[name], int(g[name + '_k'])
+    assert np.abs(opod.process_snapshots(S, ['normalize'], {}) - g[name + '_normalize']).max() == 0.0
+    assert np.abs(opod.process_snapshots(S, ['substract_mean'], {}) - g[name + '_mean']).max() == 0.0
+    assert np.abs(opod.process_snapshots(S, ['normalize', 'substract_mean'], {}) - g[name + '_both']).max() == 0.0
+    assert np.abs(opod.process_snapshots(S, ['clustering'], dict(nbr_clusters=k)) - g[name + '_centroids']).max() <= 1e-13 * np.abs(S).max()
+    assert np.abs(opod.process_snapshots(S, ['normalize', 'substract_mean', 'clustering'], dict(nbr_clusters=k)) - g[name + '_all']).max() <= 1e-13
