@@ -57,10 +57,12 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
     bool converged = false;
     int itr = 0, status = 0;
+    bool tr_hot = false;                               // expect the trust region to bind in the next QP (see qp::solve, full_first)
     if (b.mode == 2) {
         // only the rollouts a lean launch (lean.hip) could not finish: xk, uk, idx are where it left them
         if (rec[0] != 1.0) return;
         delta = rec[1]; omega = rec[2]; J_prev = rec[3]; d_prev = rec[4]; o_prev = rec[5]; itr = (int)rec[6];
+        tr_hot = rec[7] == 100.0;                      // the lean kernel found this QP's relaxed minimiser outside the trust region
         __syncthreads();
         if (tid == 0) rec[0] = 0.0;
     } else {
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         double J;
         int qit;
         GU_LAP(1);
-        const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w);
+        const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w, tr_hot);
         GU_LAP(2);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         for (int e = tid; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (w.x[e] - xk[e])));
         md = wg::reduce(md, 1, L.red);
         const bool tr_ok = !(md - delta > par.epsilon);
+        const bool on_boundary = md >= delta * (1.0 - 1e-9);      // this QP's minimiser used the whole trust region
         bool new_solution = false;
         double rho_k = -1.0;
         const double d_cur = delta, o_cur = omega;
@@ -197,6 +200,9 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
             double *tr = b.trace + (p * par.max_trace + itr) * 4;
             tr[0] = J; tr[1] = d_cur; tr[2] = o_cur; tr[3] = rho_k;
         }
+        // the next QP keeps this linearisation point when the step was rejected (smaller delta or larger omega, same relaxed
+        // minimiser): if this one already ended on the boundary of its trust region the next one is certain to bind
+        tr_hot = on_boundary && !new_solution;
         ++itr;
         GU_LAP(6);
         if (new_solution) {

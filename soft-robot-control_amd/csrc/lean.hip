@@ -58,6 +58,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         if (st != 0) {                               // the fused kernel takes this rollout from here
             if (tid == 0) {
                 rec[0] = 1.0; rec[1] = delta; rec[2] = omega; rec[3] = J_prev; rec[4] = d_prev; rec[5] = o_prev; rec[6] = (double)itr;
+                rec[7] = (double)st;                  // 100: relaxed minimiser outside the trust region (the fused kernel skips its own relaxed attempts)
             }
             handed_over = true;
             break;

@@ -1062,16 +1062,19 @@ namespace qp {
 // when the relaxed minimiser leaves the trust region.
 template <bool SPLIT, int MSEL, int NSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
-                                     QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout) {
+                                     QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout, bool full_first = false) {
     const int tid = threadIdx.x, nt = blockDim.x;
     int status = 1, it = 0;
     double J = 0.0;
     const int npass = (prescreen && dfull.tr) ? 2 : 1;
-    int first_pass = 0;
+    // full_first: the caller expects the trust region to bind (the previous QP of this rollout ended on its boundary, or a
+    // lean kernel has just found this QP's relaxed minimiser outside): skip the relaxed attempts -- the full QP has the same
+    // minimiser either way, the relaxed solves (~6 ms at C2) would only be discarded
+    int first_pass = (full_first && npass == 2) ? 1 : 0;
     // ---- fast path: the QP without its trust-region rows by the condensed interior point (locp_cond.h).  Accepted when
     // it converges and (trust region present) its minimiser lies inside the trust region -- the same argument as the
     // prescreen below; otherwise the stage-wise Riccati solve of the full QP follows.
-    if (dfull.cond && (npass == 2 || !dfull.tr)) {
+    if (dfull.cond && (npass == 2 || !dfull.tr) && first_pass == 0) {
         const int st = qpc::solve<MSEL, NSEL>(dfull, c, dyn, q, work_base, L.base, L, &it, wout);
         qp_lds_carve(L, L.base, dfull, nt);            // back to the Riccati layout (its constants are gone: ready = false)
         if (q.dbg && tid == 0) { q.dbg[8 * 61] = 1.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; }
