@@ -41,6 +41,32 @@ def make_problem(N, H, Qz, R, Qzf=None, U=None, X=None, Xf=None, dU=None, x_scal
     return p, [H, Qz, R, Qzf, xs, UA, Ub, XA, Xb, XfA, Xfb, dUA, dUb]
 
 
+def _rate_start(dU):
+    """The increment e_1 the augmented dynamics start from (u_0 has no predecessor in the reference's constraint set,
+    locp.py:305-308, so e_1 is a constant of the QP and only has to satisfy dU.A e_1 <= dU.b with room to spare): zero
+    when that is feasible, otherwise the Chebyshev centre of the rate polyhedron (one small LP at construction)."""
+    A, b = np.asarray(dU.A, dtype=np.float64), np.asarray(dU.b, dtype=np.float64)
+    m = A.shape[1]
+    if np.all(b >= 0):
+        return np.zeros(m)
+    from scipy.optimize import linprog
+    nrm = np.linalg.norm(A, axis=1)
+    res = linprog(np.concatenate((np.zeros(m), [-1.0])), A_ub=np.hstack((A, nrm[:, None])), b_ub=b,
+                  bounds=[(None, None)] * m + [(0.0, 1e6)], method='highs')
+    if res.status != 0 or res.x[-1] <= 0:
+        raise ValueError('dU: the rate polyhedron dU.A e <= dU.b has no interior point')
+    return res.x[:m]
+
+
+def _rate_dynamics(Aa, Ba, da, off, m, e1):
+    """p_{k+1} = u_k, e_{k+1} = u_k - p_k (k >= 1), e_1 = e1, for the extra states [p; e] at offset `off`."""
+    I = np.eye(m)
+    Ba[:, off:off + m] = I
+    Ba[1:, off + m:off + 2 * m] = I
+    Aa[1:, off + m:off + 2 * m, off:off + m] = -I
+    da[0, off + m:off + 2 * m] = e1
+
+
 class LOCP:
     def __init__(self, N, H, Qz, R, Qzf=None, U=None, X=None, Xf=None, dU=None, verbose=False, warm_start=True,
                  x_char=None, **kwargs):
@@ -58,8 +84,6 @@ class LOCP:
         self.tr_active = kwargs.pop('is_tr_active', True)
         self._du_aug = False
         if self.nonlinear_observer:
-            if dU is not None:
-                raise NotImplementedError('dU together with a nonlinear observer is not covered')
             self._init_augmented(N, Qz, R, Qzf, U, X, Xf, dU, kwargs)
             return
         if dU is not None:
@@ -88,12 +112,20 @@ class LOCP:
             raise NotImplementedError('terminal cost through a non-zero constant H together with a nonlinear '
                                       'observer (locp.py:251-252) is not covered')
         self.solver_args = kwargs
-        n, nz = self.n_x, self.n_z
-        Ha = np.hstack((np.zeros((nz, n)), np.eye(nz)))
-        Xa = None if X is None else Polyhedron(np.hstack((np.zeros((X.A.shape[0], n)), X.A)), X.b)
-        Xfa = None if Xf is None else Polyhedron(np.hstack((Xf.A, np.zeros((Xf.A.shape[0], nz)))), Xf.b)
-        xs = np.concatenate((self.x_scale, np.zeros(nz)))
-        self._prob, self._keep = make_problem(N, Ha, Qz, R, None, U, Xa, Xfa, dU, xs, self.tr_active)
+        n, nz, m = self.n_x, self.n_z, self.n_u
+        ne = 0 if dU is None else 2 * m                 # + [u_prev; du] for input-rate rows (see _init_rate_augmented)
+        Ha = np.hstack((np.zeros((nz, n)), np.eye(nz), np.zeros((nz, ne))))
+        rows, rhs = [], []
+        if X is not None:
+            rows.append(np.hstack((np.zeros((X.A.shape[0], n)), X.A, np.zeros((X.A.shape[0], ne))))); rhs.append(np.asarray(X.b, dtype=np.float64))
+        if dU is not None:
+            rows.append(np.hstack((np.zeros((dU.A.shape[0], n + nz + m)), np.asarray(dU.A, dtype=np.float64)))); rhs.append(np.asarray(dU.b, dtype=np.float64))
+            self._e1 = _rate_start(dU)
+        Xa = Polyhedron(np.vstack(rows), np.concatenate(rhs)) if rows else None
+        Xfa = None if Xf is None else Polyhedron(np.hstack((Xf.A, np.zeros((Xf.A.shape[0], nz + ne)))), Xf.b)
+        xs = np.concatenate((self.x_scale, np.zeros(nz + ne)))
+        self._ne = ne
+        self._prob, self._keep = make_problem(N, Ha, Qz, R, None, U, Xa, Xfa, None, xs, self.tr_active)
         self._data = None
         self._sol = None
 
@@ -102,10 +134,10 @@ class LOCP:
         stages; the stage-structured kernel takes pure state rows and pure input rows.  The previous input and the
         input increment are carried as extra states: xa_k = [x_k; p_k; e_k], p_{k+1} = u_k, e_{k+1} = u_k - p_k
         (e_1 = 0: u_0 has no predecessor in the reference's constraint set), and the rate rows become the state
-        rows [0 0 dU.A] xa_k <= dU.b on k = 1..N -- the same QP in (x, u, s).  Needs dU.b >= 0 (e_1 = 0 feasible)."""
+        rows [0 0 dU.A] xa_k <= dU.b on k = 1..N -- the same QP in (x, u, s).  The row at k = 1 acts on the constant e_1
+        (_rate_start: zero, or an interior point of the rate polyhedron when dU.b has negative entries)."""
         from ..utils import Polyhedron
-        if np.any(np.asarray(dU.b) < 0):
-            raise NotImplementedError('dU with negative bounds (the zero increment infeasible) is not covered')
+        self._e1 = _rate_start(dU)
         n, m, nz = self.n_x, self.n_u, self.n_z
         na = n + 2 * m
         Ha = np.hstack((self.H, np.zeros((nz, 2 * m))))
@@ -131,10 +163,7 @@ class LOCP:
         Aa[:, :n, :n] = Ad
         Ba[:, :n] = Bd
         da[:, :n] = dd
-        I = np.eye(m)
-        Ba[:, n:n + m] = I                       # p_{k+1} = u_k
-        Ba[1:, n + m:] = I                       # e_{k+1} = u_k - p_k   (k >= 1; e_1 = 0)
-        Aa[1:, n + m:, n:n + m] = -I
+        _rate_dynamics(Aa, Ba, da, n, m, self._e1)
         x0 = np.asarray(x0).reshape(n)
         xka = np.zeros((N + 1, na))
         if xk is not None:
@@ -149,19 +178,22 @@ class LOCP:
         N, n, m, nz = self.N, self.n_x, self.n_u, self.n_z
         Ad = np.asarray(Ad).reshape(N, n, n); Bd = np.asarray(Bd).reshape(N, n, m); dd = np.asarray(dd).reshape(N, n)
         Hd = np.asarray(Hd).reshape(N + 1, nz, n); cd = np.asarray(cd).reshape(N + 1, nz)
-        na = n + nz
+        ne = self._ne
+        na = n + nz + ne
         Aa = np.zeros((N, na, na)); Ba = np.zeros((N, na, m)); da = np.zeros((N, na))
         Aa[:, :n, :n] = Ad
-        Aa[:, n:, :n] = np.einsum('kij,kjl->kil', Hd[1:], Ad)
+        Aa[:, n:n + nz, :n] = np.einsum('kij,kjl->kil', Hd[1:], Ad)
         Ba[:, :n] = Bd
-        Ba[:, n:] = np.einsum('kij,kjl->kil', Hd[1:], Bd)
+        Ba[:, n:n + nz] = np.einsum('kij,kjl->kil', Hd[1:], Bd)
         da[:, :n] = dd
-        da[:, n:] = np.einsum('kij,kj->ki', Hd[1:], dd) + cd[1:]
+        da[:, n:n + nz] = np.einsum('kij,kj->ki', Hd[1:], dd) + cd[1:]
+        if ne:
+            _rate_dynamics(Aa, Ba, da, n + nz, m, self._e1)
         x0 = np.asarray(x0).reshape(n)
         xk = np.asarray(xk).reshape(N + 1, n)
         self._data = dict(Ad=_lib.f64(Aa), Bd=_lib.f64(Ba), dd=_lib.f64(da),
-                          x0=_lib.f64(np.concatenate((x0, Hd[0] @ x0 + cd[0]))),
-                          xk=_lib.f64(np.hstack((xk, np.einsum('kij,kj->ki', Hd, xk) + cd))),
+                          x0=_lib.f64(np.concatenate((x0, Hd[0] @ x0 + cd[0], np.zeros(ne)))),
+                          xk=_lib.f64(np.hstack((xk, np.einsum('kij,kj->ki', Hd, xk) + cd, np.zeros((N + 1, ne))))),
                           z=None if z is None else _lib.f64(np.ravel(z)), zf=None,
                           u=None if u is None else _lib.f64(np.ravel(u)))
 
@@ -189,7 +221,7 @@ class LOCP:
         d = self._data
         N, n, m = self.N, self.n_x, self.n_u
         if self.nonlinear_observer:
-            n = n + self.n_z
+            n = n + self.n_z + self._ne
         if self._du_aug:
             n = self._na
         x = np.empty((N + 1, n)); u = np.empty((N, m)); s = np.empty(N + 1)

@@ -140,8 +140,8 @@ def test_errors_are_loud():
     from sofacontrol_amd.lqr.ilqr import iLQR
     from sofacontrol_amd.utils import QuadraticCost, Polyhedron
     from sofacontrol_amd.scp.locp import LOCP
-    with pytest.raises(NotImplementedError, match='dU'):
-        LOCP(3, np.eye(2), np.eye(2), np.eye(1), dU=Polyhedron(np.eye(1), -np.ones(1)))   # zero increment infeasible
+    with pytest.raises(ValueError, match='dU'):
+        LOCP(3, np.eye(2), np.eye(2), np.eye(1), dU=Polyhedron(np.array([[1.0], [-1.0]]), -np.ones(2)))   # empty rate polyhedron
     locp = LOCP(3, np.eye(2), np.eye(2), np.eye(1))
     locp.update([np.eye(2)] * 3, [np.ones((2, 1))] * 3, [np.zeros(2)] * 3, np.zeros(2), None, 1.0, 1.0)
     with pytest.raises(RuntimeError, match='xk'):

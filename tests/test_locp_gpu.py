@@ -228,3 +228,59 @@ def test_locp_input_rate_constraints(shape):
     assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
     assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je))
     assert np.abs(np.diff(u, axis=0)).max() <= db[0] * (1 + 1e-6)
+
+
+def test_locp_input_rate_constraints_with_negative_bounds():
+    """dU.b with negative entries (every input has to rise by at least 0.3 per step): the zero increment is infeasible, the
+    augmented dynamics start from an interior point of the rate polyhedron instead (locp.py:305-308)."""
+    from sofacontrol_amd.scp.locp import LOCP
+    case, _ = make_case(seed=57, N=10)
+    m = case['Bd'][0].shape[1]
+    dA = np.kron(np.eye(m), np.array([[1.], [-1.]]))
+    db = np.tile(np.array([6.0, -0.3]), m)                         # 0.3 <= u_{k+1} - u_k <= 6
+    U = (case['U'][0], case['U'][1] + 100.0)                       # room for ten rising steps
+    qp = olocp.build_qp(case['N'], case['H'], case['Qz'], case['R'], case['Ad'], case['Bd'], case['dd'], case['x0'],
+                        case['xk'], case['delta'], case['omega'], z=case['z'], U=U, dU=(dA, db), x_scale=case['x_scale'])
+    w, _, info = olocp.solve_exact(qp, tol=1e-12)
+    assert info.get('status', 'optimal') == 'optimal'
+    xe, ue, se = olocp.split(qp, w)
+    assert np.diff(ue, axis=0).min() < 0.3 * (1 + 1e-6)            # the lower rate bound is active somewhere
+    locp = LOCP(case['N'], case['H'], case['Qz'], case['R'], U=Poly(*U), dU=Poly(dA, db), x_char=1. / case['x_scale'])
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'], case['omega'], z=case['z'])
+    J, ok, _ = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4 and abs(J - olocp.objective(qp, w)) <= 1e-7 * max(1.0, abs(olocp.objective(qp, w)))
+    assert np.diff(u, axis=0).min() >= 0.3 * (1 - 1e-6)
+    with pytest.raises(ValueError, match='no interior'):
+        LOCP(3, np.eye(2), np.eye(2), np.eye(1), dU=Poly(np.array([[1.0], [-1.0]]), np.array([-1.0, -1.0])))   # e >= 1 and e <= -1
+
+
+def test_locp_input_rate_constraints_with_nonlinear_observer():
+    """dU together with the per-stage observer linearisation (locp.py:231-245, 305-308, 312-329): both augmentations at once,
+    xa = [x; zeta; u_prev; du]."""
+    from sofacontrol_amd.scp.locp import LOCP
+    case, _ = make_case(seed=58, N=9)
+    N, n = case['N'], case['Ad'][0].shape[0]
+    m, nz = case['Bd'][0].shape[1], case['H'].shape[0]
+    rng = np.random.default_rng(58)
+    Hd = case['H'][None] + 0.05 * rng.standard_normal((N + 1, nz, n))
+    cd = 0.02 * rng.standard_normal((N + 1, nz))
+    dA = np.kron(np.eye(m), np.array([[1.], [-1.]]))
+    db = np.full(2 * m, 5.0)
+    Xz = (np.vstack((np.eye(nz), -np.eye(nz))), np.full(2 * nz, 50.0))          # rows on the outputs (locp.py:312-329)
+    qp = olocp.build_qp(N, np.zeros_like(case['H']), case['Qz'], case['R'], case['Ad'], case['Bd'], case['dd'], case['x0'], case['xk'],
+                        case['delta'], case['omega'], z=case['z'], U=case['U'], X=Xz, dU=(dA, db), x_scale=case['x_scale'], Hd=Hd, cd=cd)
+    w, _, info = olocp.solve_exact(qp, tol=1e-12)
+    assert info.get('status', 'optimal') == 'optimal'
+    xe, ue, se = olocp.split(qp, w)
+    assert np.abs(np.diff(ue, axis=0)).max() > 0.99 * db[0]
+    locp = LOCP(N, np.zeros_like(case['H']), case['Qz'], case['R'], U=Poly(*case['U']), X=Poly(*Xz), dU=Poly(dA, db),
+                x_char=1. / case['x_scale'], nonlinear_observer=True)
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'], case['omega'],
+                z=case['z'], Hd=list(Hd), cd=list(cd))
+    J, ok, _ = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    assert x.shape == xe.shape and rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
+    assert abs(J - olocp.objective(qp, w)) <= 1e-7 * max(1.0, abs(olocp.objective(qp, w)))
