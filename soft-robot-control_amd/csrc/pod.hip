@@ -457,12 +457,15 @@ __global__ __launch_bounds__(256) void lift_kernel(LiftArgs a) {
             for (int mt = 0; mt < MT; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[mt][t], b[t], acc[mt], 0, 0, 0);
         const int64_t i = 16 * it + col - al;
+        // the lifted states are written once and not read back by this kernel: non-temporal stores (no L2 write-allocate)
+        // took the kernel from 4.56 to 4.9 - 5.5 TB/s at r = 30, 4.34 -> 5.1 at r = 36 (tools/bench_lift.py, round 3; the
+        // spread is between GPU boxes, the gain was measured on the same box)
         double *o = out + (R0 + (int64_t)c * kgrp) * a.ldo + i;
         if (!decltype(guard)::value) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) o[(int64_t)c * (4 * reg + 16 * mt) * a.ldo] = acc[mt][reg] + r;
+                for (int mt = 0; mt < MT; ++mt) __builtin_nontemporal_store(acc[mt][reg] + r, &o[(int64_t)c * (4 * reg + 16 * mt) * a.ldo]);
         } else if (i >= 0 && i < a.n_f) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
