@@ -394,6 +394,11 @@ int sgusto_plan_solve_done(sgusto_plan_t *plan, int *done);
 int sgusto_plan_solve_end(sgusto_plan_t *plan, double *xopt, double *uopt, double *zopt, int32_t *iters,
                           int32_t *status, double *trace);
 
+/* The device-side duration (ms) of the last request collected by sgusto_plan_solve_end: from the first host-to-device copy
+ * to the last device-to-host copy on the plan's stream (HIP events) -- the solver's own time, what the reference reports
+ * as its solve time (scp/ros.py:116-124), independent of when the caller came back for the result; -1 before the first. */
+int sgusto_plan_last_async_ms(sgusto_plan_t *plan, double *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,13 +259,15 @@ struct sgusto_plan {
     bool has_z = false, has_zf = false, has_ud = false;
     // asynchronous requests (sgusto_plan_solve_begin / _done / _end): own stream, completion event, pinned staging
     hipStream_t astream = nullptr;
-    hipEvent_t adone = nullptr;
+    hipEvent_t adone = nullptr, abegin = nullptr;       // timing enabled: the device-side duration of a request
+    double last_ms = -1.0;
     char *pin = nullptr;               // one pinned block: [inputs | outputs]
     size_t pin_bytes = 0;
     bool pending = false, want_trace = false, launching = false;
     ~sgusto_plan() {
         if (pending && adone) (void)hipEventSynchronize(adone);
         if (adone) (void)hipEventDestroy(adone);
+        if (abegin) (void)hipEventDestroy(abegin);
         if (astream) (void)hipStreamDestroy(astream);
         if (pin) (void)hipHostFree(pin);
     }
@@ -440,7 +442,8 @@ int sgusto_plan_prepare_async(sgusto_plan_t *pl) {
     if (pl->astream) return SRH_OK;
     const PinLayout L = pin_layout(pl);
     SRH_CHECK_HIP(hipStreamCreateWithFlags(&pl->astream, hipStreamNonBlocking));
-    SRH_CHECK_HIP(hipEventCreateWithFlags(&pl->adone, hipEventDisableTiming));
+    SRH_CHECK_HIP(hipEventCreate(&pl->adone));
+    SRH_CHECK_HIP(hipEventCreate(&pl->abegin));
     SRH_CHECK_HIP(hipHostMalloc((void **)&pl->pin, L.total, hipHostMallocDefault));
     pl->pin_bytes = L.total;
     return SRH_OK;
@@ -462,6 +465,7 @@ int sgusto_plan_solve_begin(sgusto_plan_t *pl, const double *x0, const double *u
     // from here on work is enqueued on the plan's stream: on any error the stream is drained before returning, so that
     // nothing is still writing into the pinned block / the plan's buffers while `pending` is false
     auto body = [&]() -> int {
+        SRH_CHECK_HIP(hipEventRecord(pl->abegin, pl->astream));
         SRH_CHECK_HIP(stage(L.x0, x0, D * B * n, pl->x0.p));
         SRH_CHECK_HIP(stage(L.u_init, u_init, D * B * N * m, pl->u_init.p));
         SRH_CHECK_HIP(stage(L.x_init, x_init, D * B * (N + 1) * n, pl->x_init.p));
@@ -515,6 +519,7 @@ int sgusto_plan_solve_end(sgusto_plan_t *pl, double *xopt, double *uopt, double 
     SRH_REQUIRE(pl->pending, "sgusto_plan_solve_end: no request in flight");
     SRH_CHECK_HIP(hipEventSynchronize(pl->adone));
     pl->pending = false;
+    { float ms = -1.0f; if (hipEventElapsedTime(&ms, pl->abegin, pl->adone) == hipSuccess) pl->last_ms = ms; else pl->last_ms = -1.0; }
     const QPDims &d = pl->C.dims;
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz, B = pl->batch, D = sizeof(double);
     const PinLayout L = pin_layout(pl);
@@ -524,6 +529,12 @@ int sgusto_plan_solve_end(sgusto_plan_t *pl, double *xopt, double *uopt, double 
     if (iters) memcpy(iters, pl->pin + L.iters, sizeof(int32_t) * B);
     if (status) memcpy(status, pl->pin + L.status, sizeof(int32_t) * B);
     if (trace && pl->want_trace) memcpy(trace, pl->pin + L.trace, D * B * (size_t)pl->par.max_trace * 4);
+    return SRH_OK;
+}
+
+int sgusto_plan_last_async_ms(sgusto_plan_t *pl, double *ms) {
+    SRH_REQUIRE(pl && ms, "sgusto_plan_last_async_ms: null argument");
+    *ms = pl->last_ms;
     return SRH_OK;
 }
 

@@ -952,7 +952,12 @@ int srom_reduce_matrix_dev(srom_t *h, const double *M, int64_t ncols, int left, 
             a.X = M; a.ldx = ncols; a.ufrag = h->ufrag.as<double>(); a.B = h->n_f; a.n_f = h->n_f; a.r = h->r;
             a.nchunks = h->nchunks; a.Urows = h->U.as<double>();
             const int64_t rowtiles = srh::cdiv(h->n_f, ROWS_WG);
-            const int ksplit = proj_ksplit(h, h->n_f, 1, &a.chunks_per_split);
+            int ksplit = proj_ksplit(h, h->n_f, 1, &a.chunks_per_split);
+            if (const char *e = getenv("SRH_UTMU_KSPLIT")) {       // A/B: K-slices per row tile (default: ~512 workgroups)
+                const int want = std::max(1, std::min(atoi(e), h->nchunks));
+                a.chunks_per_split = (int)srh::cdiv(h->nchunks, want);
+                ksplit = (int)srh::cdiv(h->nchunks, a.chunks_per_split);
+            }
             const int ldp = 16 * (h->NTF + (h->NQ ? 1 : 0));
             const int nwg = (int)(rowtiles * ksplit);
             int rc = ensure_work(h, sizeof(double) * (size_t)nwg * ldp * ldp);

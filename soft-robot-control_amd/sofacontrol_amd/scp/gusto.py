@@ -243,7 +243,12 @@ class GuSTO:
         trace = np.full((B, self.max_trace, 4), np.nan) if self.max_trace > 0 else None
         _lib.check(_lib.lib().sgusto_plan_solve_end(self._plan, _lib.dptr(xo), _lib.dptr(uo), _lib.dptr(zo), _lib.iptr(iters),
                                                     _lib.iptr(status), _lib.dptr(trace)), 'sgusto_plan_solve_end')
-        self.locp_solve_time = time.time() - self._t_begin
+        # the solver's own time (device events around the request: copies in, kernels, copies out), as the reference reports
+        # it -- not the begin-to-collect wall time, which contains whatever the caller did in between
+        ms = C.c_double(-1.0)
+        _lib.check(_lib.lib().sgusto_plan_last_async_ms(self._plan, C.byref(ms)), 'sgusto_plan_last_async_ms')
+        self.request_wall_time = time.time() - self._t_begin
+        self.locp_solve_time = ms.value * 1e-3 if ms.value >= 0 else self.request_wall_time
         self.iters, self.status, self.trace = iters, status, trace
         if B == 1:
             self.xopt, self.uopt, self.zopt = xo[0], uo[0], zo[0]

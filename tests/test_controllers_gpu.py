@@ -180,6 +180,13 @@ def test_gusto_client_wait_false_is_asynchronous():
     np.testing.assert_array_equal(ta, ts)
     np.testing.assert_array_equal(ua, us)
     np.testing.assert_array_equal(xa, xs)
+    # the reported solve time of an asynchronous request is the solver's own (device events), not the begin-to-collect wall
+    # time: collect a second request late and compare
+    ca.send_request(t0, x0, wait=False)
+    time.sleep(0.25)
+    ca.force_wait()
+    g = node_a.gusto
+    assert g.request_wall_time >= 0.25 and 1e-4 < g.locp_solve_time < 0.5 * g.request_wall_time, (g.locp_solve_time, g.request_wall_time)
 
 
 def test_scp_controller_wait_false_overlaps_solve_with_simulation_steps():
