@@ -104,7 +104,8 @@ __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr
     const int N = d.N, n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, nk = d.NK;
     const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l = lane & 15, il = l >> 3, sl = l & 7;
-    const int i = 8 * wave + 2 * (lane >> 4) + il, ic = i < n ? i : n - 1;
+    const int i_lo = 8 * wave + 2 * (lane >> 4) + il;                 // + 64 per row block (n_x > 64: a second pass)
+    constexpr bool ONE_BLOCK = NSEL > 0 && NSEL <= 64;
     const int vlen = (int)(((size_t)ld + 3) & ~(size_t)3);
     lptr va = L.v1, vb = L.v2;
     for (int e = tid; e < nk * ld; e += nt) L.panel[e] = 0.0;
@@ -120,16 +121,19 @@ __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr
     const int nq = NPa >> 4;
     for (int k = 0; k < N; ++k) {
         const int sel = __builtin_amdgcn_readfirstlane(L.idxl[k]);
-        const double dk = dyn.d[(size_t)sel * n + ic];
         const double un = (tid < m && u && k + 1 < N) ? u[(size_t)(k + 1) * m + tid] : 0.0;
-        clptr row = L.panel + ic * ld + 2 * sl;
-        double acc = 0.0;
-        for (int q = 0; q < nq; ++q) {
-            acc = fma(row[16 * q], va[2 * sl + 16 * q], acc);
-            acc = fma(row[16 * q + 1], va[2 * sl + 16 * q + 1], acc);
+        for (int ib = 0; ib < (ONE_BLOCK ? 1 : n); ib += 64) {
+            const int i = i_lo + ib, ic = i < n ? i : n - 1;
+            const double dk = dyn.d[(size_t)sel * n + ic];
+            clptr row = L.panel + ic * ld + 2 * sl;
+            double acc = 0.0;
+            for (int q = 0; q < nq; ++q) {
+                acc = fma(row[16 * q], va[2 * sl + 16 * q], acc);
+                acc = fma(row[16 * q + 1], va[2 * sl + 16 * q + 1], acc);
+            }
+            acc = wg::group_sum<8>(acc) + dk;
+            if (sl == 0 && i < n) { vb[i] = acc; x[(size_t)(k + 1) * n + i] = acc; }
         }
-        acc = wg::group_sum<8>(acc) + dk;
-        if (sl == 0 && i < n) { vb[i] = acc; x[(size_t)(k + 1) * n + i] = acc; }
         if (tid < m) vb[n + tid] = un;
         __syncthreads();
         if (k + 1 < N) {

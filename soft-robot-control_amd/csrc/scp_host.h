@@ -335,9 +335,10 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             d.cond = 1;
             if (qpc::lds_doubles(d, NTHREADS) * sizeof(double) > (size_t)160 * 1024) { d.cond = 0; d.po = 0; d.KT = 0; }
         }
-        // ---- lean kernels (locp_lean.h): p_o = 2, diagonal input Hessians, n_u = 4 or 8, whole W panel variant only;
+        // ---- lean kernels (locp_lean.h): p_o = 2, diagonal input Hessians, n_u = 4 or 8 (the split-panel shapes too: the lean
+        // kernels have no W panel; what they hand over goes to the split fused kernel);
         // j0 = the smallest first LDS-resident stage for which the carve fits; the Gram tile tasks of the 8 waves
-        if (d.cond && d.po == 2 && d.diagD && (m == 4 || m == 8) && !d.split && !getenv("SRH_QP_NO_LEAN")) {
+        if (d.cond && d.po == 2 && d.diagD && (m == 4 || m == 8) && !getenv("SRH_QP_NO_LEAN")) {
             int j0 = -1;
             for (int t = 0; t <= N; ++t)
                 if (ql::lds_doubles(d, NTHREADS, t) * sizeof(double) <= (size_t)160 * 1024) { j0 = t; break; }
