@@ -308,10 +308,14 @@ def compute_POD(snapshots, tol, rom_dim=None):
     the kept modes are recovered (U = S^T W Sigma^-1)."""
     S_rows = np.ascontiguousarray(np.asarray(snapshots, dtype=np.float64).T)
     n_s, n_f = S_rows.shape
+    return _compute_POD_dev(_lib.DeviceBuffer.from_array(S_rows), n_s, n_f, tol, rom_dim)
+
+
+def _compute_POD_dev(dS, n_s, n_f, tol, rom_dim=None):
+    """compute_POD on a resident snapshot matrix (n_s x n_f, one snapshot per row)."""
     L = _lib.lib()
     # everything stays in HBM: Gramian (MFMA kernel) -> eigh (Jacobi kernels; rocSOLVER above 2048 snapshots) -> mode selection -> U = S^T W Sigma^-1;
     # only the n_s eigenvalues cross to the host for the energy truncation
-    dS = _lib.DeviceBuffer.from_array(S_rows)
     dG, dw = _lib.DeviceBuffer(n_s * n_s * 8), _lib.DeviceBuffer(n_s * 8)
     _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), dG.ptr, None), 'srom_gramian_dev')
     _lib.check(L.srom_eigh_dev(dG.ptr, C.c_int64(n_s), dw.ptr, None), 'srom_eigh_dev')
@@ -330,9 +334,16 @@ def compute_POD(snapshots, tol, rom_dim=None):
 def run_POD(snapshots_file, POD_file, config, rom_dim=None):
     """pod.py:110-141."""
     data = scutils.load_data(snapshots_file)
-    snapshots = get_snapshots(data, config.pod_type)
-    snapshots = process_snapshots(snapshots, config.preprocess, config.preprocess_args)
-    U_full, U, rom_dim, Sigma = compute_POD(snapshots.T, config.pod_tolerance)
+    snapshots = np.ascontiguousarray(get_snapshots(data, config.pod_type), dtype=np.float64)
+    # one upload: preprocessing (pod.py:157-178) and the decomposition (pod.py:181-200) share the resident snapshot matrix
+    wanted = [p_ for p_ in ('normalize', 'substract_mean', 'clustering') if p_ in config.preprocess]
+    if 'clustering' in wanted and not config.preprocess_args.get('nbr_clusters', 0) > 0:
+        print('Not using kmeans because nbr_clusters not specified in config.preprocess_args dictionary')
+        wanted.remove('clustering')
+    dS, n_s, n_f = _lib.DeviceBuffer.from_array(snapshots), snapshots.shape[0], snapshots.shape[1]
+    if wanted:
+        dS, n_s, n_f = _process_snapshots_dev(dS, n_s, n_f, wanted, config.preprocess_args)
+    U_full, U, rom_dim, Sigma = _compute_POD_dev(dS, n_s, n_f, config.pod_tolerance)
     print('Computed POD with tolerance {}, resulting in {} dimensional system'.format(config.pod_tolerance, rom_dim))
     POD_info = {'U': U, 'q_ref': data['q'][0], 'v_ref': np.zeros(data['v'][0].shape)}
     results = {'POD_info': POD_info, 'config': vars(config), 'Sigma': Sigma}

@@ -105,3 +105,28 @@ def test_kmeans_against_sklearn_on_a_larger_set():
     ref = sk.KMeans(5, n_init=3, max_iter=1000, random_state=0).fit(X.copy()).cluster_centers_
     got = pod.compute_kmeans_centroids(X, 5, n_init=3)
     assert np.abs(got - ref).max() <= 1e-10 * np.abs(X).max()
+
+
+def test_run_pod_with_preprocessing_matches_the_reference_pipeline(tmp_path):
+    """run_POD (pod.py:110-141) with config.preprocess = ['substract_mean', 'clustering']: get_snapshots -> process_snapshots
+    -> compute_POD on one resident copy; the basis spans what the reference pipeline (numpy + the KMeans restatement + SVD)
+    spans and the singular values agree."""
+    import contextlib, io
+    from oracle import pod as opod
+    from sofacontrol_amd import utils as scutils
+    from sofacontrol_amd.mor.pod import run_POD, pod_config
+    rng = np.random.default_rng(21)
+    centres = 5.0 * rng.standard_normal((6, 4)) @ rng.standard_normal((4, 70))          # rank 4 structure
+    q = np.concatenate([c + 0.05 * rng.standard_normal((12, 70)) for c in centres])
+    snap, podf = str(tmp_path / 's.pkl'), str(tmp_path / 'p.pkl')
+    scutils.save_data(snap, {'q': list(q), 'v': list(q)})
+    cfg = pod_config(); cfg.pod_type = 'v'; cfg.pod_tolerance = 1e-8
+    cfg.preprocess = ['substract_mean', 'clustering']; cfg.preprocess_args = dict(nbr_clusters=6)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = run_POD(snap, podf, cfg)
+    ref_snap = opod.process_snapshots(opod.get_snapshots({'q': list(q), 'v': list(q)}, 'v'), cfg.preprocess, cfg.preprocess_args)
+    _, Uref, kref, Sref = opod.compute_pod(ref_snap.T, cfg.pod_tolerance)
+    U = res['POD_info']['U']
+    assert U.shape == Uref.shape == (70, kref)
+    np.testing.assert_allclose(res['Sigma'][:kref], Sref[:kref], rtol=1e-8)
+    assert np.abs(U @ (U.T @ Uref) - Uref).max() <= 1e-7            # same subspace
