@@ -338,6 +338,24 @@ int slocp_solve(const slocp_problem *prob, int64_t batch, const double *Ad, cons
                 const double *omega, const double *z, const double *zf, const double *u_des,
                 double *x, double *u, double *s, double *J, int32_t *status, int32_t *iters);
 
+/* The same QP with everything resident (round 3): constants, horizon buffers, work blocks and result buffers are created once
+ * for a fixed batch and reused by every solve -- what the host loops around the device QP call once per SCP iteration
+ * (GuSTO over SSM / weighting-mode models: scp/gusto.py:371-402; linear MPC: the LOCP of locp.py with is_tr_active=False).
+ * slocp_plan_solve: host pointers as slocp_solve; Ad = Bd = dd = NULL keeps the horizon of the previous call resident
+ * (LOCP.update(full=False), locp.py:139-141: only delta / omega / x0 change); xk, z, zf, u_des NULL keep theirs.
+ * slocp_plan_solve_dev: every array already in HBM (the linearisation kernels' outputs can be passed straight in), results
+ * written to device pointers, asynchronous on `stream`; s_dev / iters_dev may be NULL. */
+typedef struct slocp_plan slocp_plan_t;
+int slocp_plan_create(slocp_plan_t **out, const slocp_problem *prob, int64_t batch);
+void slocp_plan_destroy(slocp_plan_t *plan);
+int slocp_plan_solve(slocp_plan_t *plan, const double *Ad, const double *Bd, const double *dd, const double *x0,
+                     const double *xk, const double *delta, const double *omega, const double *z, const double *zf,
+                     const double *u_des, double *x, double *u, double *s, double *J, int32_t *status, int32_t *iters);
+int slocp_plan_solve_dev(slocp_plan_t *plan, const double *Ad_dev, const double *Bd_dev, const double *dd_dev,
+                         const double *x0_dev, const double *xk_dev, const double *delta_dev, const double *omega_dev,
+                         const double *z_dev, const double *zf_dev, const double *ud_dev, double *x_dev, double *u_dev,
+                         double *s_dev, double *J_dev, int32_t *status_dev, int32_t *iters_dev, void *stream);
+
 /* Whether QPs of this shape take the condensed (output-space) interior point for their trust-region-free pass
  * (csrc/locp_cond.h): enabled, the number of output directions found (rows of C_o spanning Cq, X.A, Xf.A) and whether
  * the input Hessian blocks 2R + U.A^T D U.A are diagonal for every D.  For tests and records. */

@@ -226,13 +226,23 @@ class LOCP:
             n = self._na
         x = np.empty((N + 1, n)); u = np.empty((N, m)); s = np.empty(N + 1)
         J = np.empty(1); status = np.empty(1, dtype=np.int32); iters = np.empty(1, dtype=np.int32)
+        L = _lib.lib()
+        if getattr(self, '_plan', None) is None:
+            # resident QP (slocp_plan_*): constants, horizon and work buffers are created once per LOCP object
+            self._plan = C.c_void_p()
+            _lib.check(L.slocp_plan_create(C.byref(self._plan), C.byref(self._prob), C.c_int64(1)), 'slocp_plan_create')
+            self._resident = None
+        if d.get('xk') is None and self.tr_active:
+            raise RuntimeError('LOCP.solve: xk is required when the trust region is active')
+        # the horizon arrays go up only when update(full=True) replaced them (locp.py:139-141: a delta / omega update keeps them)
+        fresh = self._resident is not d
         t0 = time.time()
-        _lib.check(_lib.lib().slocp_solve(C.byref(self._prob), C.c_int64(1), _lib.dptr(d['Ad']), _lib.dptr(d['Bd']),
-                                          _lib.dptr(d['dd']), _lib.dptr(d['x0']), _lib.dptr(d['xk']),
-                                          _lib.dptr(self._delta), _lib.dptr(self._omega), _lib.dptr(d['z']),
-                                          _lib.dptr(d['zf']), _lib.dptr(d['u']), _lib.dptr(x), _lib.dptr(u),
-                                          _lib.dptr(s), _lib.dptr(J), _lib.iptr(status), _lib.iptr(iters)),
-                   'slocp_solve')
+        _lib.check(L.slocp_plan_solve(self._plan, _lib.dptr(d['Ad']) if fresh else None, _lib.dptr(d['Bd']) if fresh else None,
+                                      _lib.dptr(d['dd']) if fresh else None, _lib.dptr(d['x0']),
+                                      _lib.dptr(d['xk']) if fresh else None, _lib.dptr(self._delta), _lib.dptr(self._omega),
+                                      _lib.dptr(d['z']), _lib.dptr(d['zf']), _lib.dptr(d['u']), _lib.dptr(x), _lib.dptr(u),
+                                      _lib.dptr(s), _lib.dptr(J), _lib.iptr(status), _lib.iptr(iters)), 'slocp_plan_solve')
+        self._resident = d
         t1 = time.time()
         if status[0] == 0:
             if self.nonlinear_observer:
@@ -247,3 +257,11 @@ class LOCP:
     def get_solution(self):
         """locp.py:192-203."""
         return self._sol
+
+    def __del__(self):
+        try:
+            if getattr(self, '_plan', None):
+                _lib.lib().slocp_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass

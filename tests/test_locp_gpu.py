@@ -284,3 +284,51 @@ def test_locp_input_rate_constraints_with_nonlinear_observer():
     x, u, s = locp.get_solution()
     assert x.shape == xe.shape and rel(x, xe) <= 1e-4 and rel(u, ue) <= 1e-4
     assert abs(J - olocp.objective(qp, w)) <= 1e-7 * max(1.0, abs(olocp.objective(qp, w)))
+
+
+def test_resident_locp_plan_keeps_the_horizon_and_takes_device_pointers():
+    """slocp_plan_* (round 3): LOCP.update(full=False) (locp.py:139-141) re-solves on the resident horizon -- nothing but delta,
+    omega, x0 goes up; slocp_plan_solve_dev takes every array from HBM and leaves the results there.  Both give what the
+    one-shot slocp_solve gives, bit for bit."""
+    import ctypes as C
+    from sofacontrol_amd import _lib
+    from sofacontrol_amd.scp.locp import LOCP, make_problem
+    case, _ = make_case(seed=61, N=12)
+    N, n, m = case['N'], case['Ad'][0].shape[0], case['Bd'][0].shape[1]
+
+    def fresh(delta, omega):
+        lo = LOCP(N, case['H'], case['Qz'], case['R'], U=Poly(*case['U']), X=Poly(*case['X']), x_char=1. / case['x_scale'])
+        lo.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], delta, omega, z=case['z'])
+        J, ok, st = lo.solve()
+        assert ok
+        return (J,) + lo.get_solution()
+
+    locp = LOCP(N, case['H'], case['Qz'], case['R'], U=Poly(*case['U']), X=Poly(*case['X']), x_char=1. / case['x_scale'])
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'], case['omega'], z=case['z'])
+    J1, ok, _ = locp.solve()
+    assert ok
+    ref1 = fresh(case['delta'], case['omega'])
+    assert J1 == ref1[0] and all(np.array_equal(a, b) for a, b in zip(locp.get_solution(), ref1[1:]))
+    used = np.abs(case['x_scale'] * (locp.get_solution()[0] - case['xk'])).max()
+    d2, o2 = 0.5 * used, 10.0 * case['omega']                        # a trust region that binds, a larger penalty
+    locp.update(None, None, None, None, None, d2, o2, full=False)
+    J2, ok, _ = locp.solve()
+    assert ok and J2 != J1
+    ref2 = fresh(d2, o2)
+    assert J2 == ref2[0] and all(np.array_equal(a, b) for a, b in zip(locp.get_solution(), ref2[1:]))
+    # device pointers in, device pointers out
+    L = _lib.lib()
+    prob, keep = make_problem(N, case['H'], case['Qz'], case['R'], None, Poly(*case['U']), Poly(*case['X']), None, None, case['x_scale'], True)
+    plan = C.c_void_p()
+    _lib.check(L.slocp_plan_create(C.byref(plan), C.byref(prob), C.c_int64(1)), 'create')
+    up = lambda a: _lib.DeviceBuffer.from_array(np.ascontiguousarray(a, dtype=np.float64))
+    dA, dB, dd, dx0, dxk, dz = up(np.stack(case['Ad'])), up(np.stack(case['Bd'])), up(np.stack(case['dd'])), up(case['x0']), up(case['xk']), up(case['z'])
+    ddel, dom = up(np.array([d2])), up(np.array([o2]))
+    ox, ou, os_, oJ = _lib.DeviceBuffer((N + 1) * n * 8), _lib.DeviceBuffer(N * m * 8), _lib.DeviceBuffer((N + 1) * 8), _lib.DeviceBuffer(8)
+    ost, oit = _lib.DeviceBuffer(4), _lib.DeviceBuffer(4)
+    _lib.check(L.slocp_plan_solve_dev(plan, dA.ptr, dB.ptr, dd.ptr, dx0.ptr, dxk.ptr, ddel.ptr, dom.ptr, dz.ptr, None, None,
+                                      ox.ptr, ou.ptr, os_.ptr, oJ.ptr, ost.ptr, oit.ptr, None), 'solve_dev')
+    _lib.sync()
+    assert ost.to_array((1,), dtype=np.int32)[0] == 0 and oJ.to_array((1,))[0] == ref2[0]
+    assert np.array_equal(ox.to_array((N + 1, n)), ref2[1]) and np.array_equal(ou.to_array((N, m)), ref2[2])
+    L.slocp_plan_destroy(plan)
