@@ -84,7 +84,9 @@ def kmeans_centroids(X, k, n_init=100, max_iter=1000, random_state=0, tol=1e-4):
     third-party dependency of the reference (scikit-learn, unpinned there; 1.7.2 in this image).  This is a plain-numpy
     restatement of that estimator's published dense algorithm (`sklearn/cluster/_kmeans.py`: centring, k-means++ seeding
     with 2 + int(log k) local trials, Lloyd iterations, empty-cluster relocation, best of n_init by inertia), pinned by
-    tests/golden g19 (the imported reference's own output) and, where sklearn is installed, against sklearn itself."""
+    tests/golden g19 (the imported reference's own output) and, where sklearn is installed, against sklearn itself.  Not
+    reproduced: the estimator's tie-breaking when k exceeds the number of DISTINCT snapshots (all distances zero; it warns
+    about that case itself)."""
     X = np.array(X, dtype=float)
     n_s, n_f = X.shape
     mean = X.mean(axis=0)
@@ -124,7 +126,7 @@ def kmeans_centroids(X, k, n_init=100, max_iter=1000, random_state=0, tol=1e-4):
             empty = np.where(counts == 0)[0]
             if len(empty):
                 dist = ((X - Cc[labels]) ** 2).sum(axis=1)
-                far = np.argsort(-dist, kind='stable')[:len(empty)]
+                far = np.argpartition(dist, -len(empty))[:-len(empty) - 1:-1]      # the estimator's own selection (ties included)
                 for e, f in zip(empty, far):
                     sums[labels[f]] -= X[f]; sums[e] = X[f]; counts[e] = 1; counts[labels[f]] -= 1
             Cn = np.where(counts[:, None] > 0, sums / np.maximum(counts, 1)[:, None], Cc)
