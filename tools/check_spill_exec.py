@@ -14,6 +14,10 @@ stack slot is reloaded somewhere else in the function.  A store whose register i
 narrowing (`s_and_saveexec_b64 s[a:b]` / `s_mov_b64 s[a:b], exec`) and the store is left alone: that is a value the
 region itself produced for its own lanes (the other side of the branch fills the rest of the slot).
 
+Other ways EXEC grows were checked on the round-3 tree and are not flagged: in the else sequence (`s_or_saveexec_b64 d, s` ...
+`s_xor_b64 exec, exec, d`) and around whole-wave sections (`s_or_saveexec_b64 d, -1` ... `s_mov_b64 exec, d`) hipcc places
+its spill stores behind the widening instruction, i.e. with the lanes already enabled.
+
 `--fix` rewrites the file: every flagged store moves to just behind the EXEC restore (the register still holds the
 value in every lane there -- nothing between the two writes it, which the tool verifies), followed by the wait states a
 wide store wants before its data registers may be overwritten.  The build (csrc/Makefile) compiles device code to
