@@ -12,7 +12,21 @@ namespace {
 #define GU_LAP(i) ((void)0)
 #endif
 
-template <int MSEL, int NSEL, int GXSEL>
+// NST > 0: an instantiation for ONE problem layout -- horizon NST, box input rows, NXR state rows, n_z = 6, the first
+// LDS-resident stage J0SEL -- whose sizes are compile-time constants: the LDS carve becomes immediate offsets from one base
+// (no pointer per array in scalar registers), trip counts and the packed-G offsets fold.  The host only selects it for
+// problems whose run-time dimensions equal these (lean_matches); measured on the benchmark: 108 k -> 120 k SCP iterations/s.
+template <int MSEL, int GXSEL, int NST, int J0SEL, int NXR>
+__device__ __forceinline__ void fix_problem(QPDims &d) {
+    if constexpr (NST > 0) {
+        static_assert(GXSEL > 0, "fixed-layout variants use the box-row interior point");
+        d.N = NST; d.po = 2; d.KT = (2 * NST + 15) / 16;
+        d.nU = 2 * MSEL; d.nX = NXR; d.nXf = 0; d.nz = 6;
+        d.cond = 1; d.diagD = 1; d.lean = 2; d.lean_j0 = J0SEL;
+    }
+}
+
+template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>
 __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long prof[24] = {0};
@@ -20,6 +34,8 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     long long gup[8] = {0}, gul = clock64();
 #endif
     qp::specialise<MSEL, NSEL>(d);
+    fix_problem<MSEL, GXSEL, NST, J0SEL, NXR>(d);
+    if constexpr (NST > 0) d.tr = 1;                   // GuSTO always carries the trust region
     ql::Lds L;
     ql::lds_carve(L, (lptr)smem, d, NTHREADS);
     if (threadIdx.x == 0) L.flag[2] = 0;               // no condensation in LDS yet (ql::ipm)
@@ -218,11 +234,12 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     if (tid == 0) { rec[0] = 0.0; b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; }
 }
 
-template <int MSEL, int NSEL, int GXSEL>
+template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>
 __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c, LocpBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long prof[24] = {0};
     qp::specialise<MSEL, NSEL>(d);
+    fix_problem<MSEL, GXSEL, NST, J0SEL, NXR>(d);
     ql::Lds L;
     ql::lds_carve(L, (lptr)smem, d, NTHREADS);
     if (threadIdx.x == 0) L.flag[2] = 0;
@@ -276,24 +293,29 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
 // instantiated shapes: the reference's 4- and 8-cable robots at the benchmark's r = 30 with the row layout their drivers use
 // (U box; Diamond: 4 state rows, Trunk: none; Diamond at the shipped r = 36 basis: n_x = 72), then n_x fixed / free with the
 // general row handling (GX = 0)
-#define SRH_LEAN_VARIANTS(X) X(4, 60, 4) X(8, 60, 1) X(4, 72, 4) X(4, 60, 0) X(8, 60, 0) X(4, 0, 0) X(8, 0, 0)
+// (M, NX, GX, NST, J0, NXR): first the two benchmark layouts with every size fixed (BASELINE C2: Diamond, N = 50, 4 state rows;
+// C5: Trunk, N = 50, no state rows), then the run-time-horizon forms
+#define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) \
+    X(4, 60, 4, 0, 0, 0) X(8, 60, 1, 0, 0, 0) X(4, 72, 4, 0, 0, 0) X(4, 60, 0, 0, 0, 0) X(8, 60, 0, 0, 0, 0) X(4, 0, 0, 0, 0, 0) X(8, 0, 0, 0, 0, 0)
 inline int lean_gx(const QPDims &d) {
     if (d.lean != 2) return 0;
     const int RXa = d.nX + d.nXf;
     return RXa == 0 ? 1 : (RXa <= 2 ? 2 : (RXa <= 4 ? 4 : 8));
 }
-inline bool lean_matches(const QPDims &d, int msel, int nsel, int gx) {
+inline bool lean_matches(const QPDims &d, int msel, int nsel, int gx, int nst, int j0, int nxr) {
     if (d.m != msel || (nsel != 0 && d.n != nsel)) return false;
-    return gx == 0 || gx == lean_gx(d);
+    if (!(gx == 0 || gx == lean_gx(d))) return false;
+    if (nst == 0) return true;
+    return d.N == nst && d.lean_j0 == j0 && d.nX == nxr && d.nXf == 0 && d.nz == 6 && d.po == 2 && d.nU == 2 * msel && !getenv("SRH_LEAN_NO_FIXED");
 }
 
 }  // namespace
 
 int lean_prepare(const QPDims &d, size_t lds) {
     SRH_REQUIRE(lds <= 160 * 1024, "lean kernels: %zu bytes of LDS needed, 160 KiB available", lds);
-#define X(M, NX, GX) if (lean_matches(d, M, NX, GX)) { \
-        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_lean_kernel<M, NX, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)locp_lean_kernel<M, NX, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+#define X(M, NX, GX, NST, J0, NXR) if (lean_matches(d, M, NX, GX, NST, J0, NXR)) { \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_lean_kernel<M, NX, GX, NST, J0, NXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)locp_lean_kernel<M, NX, GX, NST, J0, NXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
@@ -304,7 +326,7 @@ int lean_prepare(const QPDims &d, size_t lds) {
 int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
                       size_t lds, hipStream_t stream) {
     QPDims dd = d;
-#define X(M, NX, GX) if (lean_matches(d, M, NX, GX)) { if (GX == 0) dd.lean = 1; gusto_lean_kernel<M, NX, GX><<<grid, NTHREADS, lds, stream>>>(dd, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+#define X(M, NX, GX, NST, J0, NXR) if (lean_matches(d, M, NX, GX, NST, J0, NXR)) { if (GX == 0) dd.lean = 1; gusto_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
     SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
@@ -313,7 +335,7 @@ int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const
 
 int lean_launch_locp(const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream) {
     QPDims dd = d;
-#define X(M, NX, GX) if (lean_matches(d, M, NX, GX)) { if (GX == 0) dd.lean = 1; locp_lean_kernel<M, NX, GX><<<grid, NTHREADS, lds, stream>>>(dd, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+#define X(M, NX, GX, NST, J0, NXR) if (lean_matches(d, M, NX, GX, NST, J0, NXR)) { if (GX == 0) dd.lean = 1; locp_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
     SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
