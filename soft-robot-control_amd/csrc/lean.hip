@@ -293,9 +293,9 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
 // instantiated shapes: the reference's 4- and 8-cable robots at the benchmark's r = 30 with the row layout their drivers use
 // (U box; Diamond: 4 state rows, Trunk: none; Diamond at the shipped r = 36 basis: n_x = 72), then n_x fixed / free with the
 // general row handling (GX = 0)
-// (M, NX, GX, NST, J0, NXR): first the two benchmark layouts with every size fixed (BASELINE C2: Diamond, N = 50, 4 state rows;
-// C5: Trunk, N = 50, no state rows), then the run-time-horizon forms
-#define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) \
+// (M, NX, GX, NST, J0, NXR): first the layouts with every size fixed (BASELINE C2: Diamond, N = 50, 4 state rows; C5: Trunk,
+// N = 50, no state rows; the Diamond at its shipped r = 36 basis), then the run-time-horizon forms
+#define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) X(4, 72, 4, 50, 18, 4) \
     X(4, 60, 4, 0, 0, 0) X(8, 60, 1, 0, 0, 0) X(4, 72, 4, 0, 0, 0) X(4, 60, 0, 0, 0, 0) X(8, 60, 0, 0, 0, 0) X(4, 0, 0, 0, 0, 0) X(8, 0, 0, 0, 0, 0)
 inline int lean_gx(const QPDims &d) {
     if (d.lean != 2) return 0;
