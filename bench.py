@@ -130,7 +130,20 @@ def cpu_baseline(w, x0, x_init, z, xc, fc, n_roll, proj_rows, max_iters):
                 break
     except Exception:
         pass
-    out = dict(value=float(ita.sum()) / tall, unit='SCP iterations/s', cores=ncpu, kind='port',
+    # SURVEY 8(d), CPU baseline (3): a cvxpy model of locp.py is timed only if cvxpy + osqp import on this box
+    third_party = {}
+    for mod in ('cvxpy', 'osqp'):
+        try:
+            __import__(mod)
+            third_party[mod] = True
+        except Exception as exc:
+            third_party[mod] = '%s: %s' % (type(exc).__name__, exc)
+    have_cvx = all(v is True for v in third_party.values())
+    cvxpy_osqp = {'available': have_cvx,
+                  'why': ('importable, but no cvxpy model is timed: the restated OSQP leg below stands in' if have_cvx else
+                          'not installed on this box (no network): ' + '; '.join('%s -> %s' % kv for kv in third_party.items() if kv[1] is not True)),
+                  'stand_in': 'osqp_restated_eps1e_5 (oracle.locp.solve_osqp: the published OSQP algorithm at cvxpy\'s default tolerances)'}
+    out = dict(value=float(ita.sum()) / tall, unit='SCP iterations/s', cores=ncpu, kind='port', cvxpy_osqp=cvxpy_osqp,
                algorithm='condensed (output-space) interior point + Riccati interior point for trust-region-active QPs: the algorithm of '
                          'the GPU kernels (oracle/condensed_ipm.py, csrc/locp_lean.h); native C++, -O3 -march=x86-64-v3, no BLAS',
                host='%s, %d logical CPUs, %d usable by this process (affinity / cgroup quota)' % (cpu, os.cpu_count() or 1, ncpu),
@@ -238,17 +251,26 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
     g.solve_batch(x0, u_init, x_init, z=z)
     el = time.perf_counter() - t0
     its = float(g.iters.sum())
+    # the reduction step of the sharded batch: one all_gather of the per-rollout optimal costs, every rank
+    # learns the global best rollout (outside the solve's wall time: 256 doubles)
+    from sofacontrol_amd.distributed import gather_rollout_costs
+    J_loc = g.costs
     if dist is not None:
         import torch
+        J_all, best = gather_rollout_costs(torch.from_numpy(J_loc).cuda(), total)
         tt = torch.tensor([el, its], dtype=torch.float64, device='cuda')
         tm = tt.clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         el, its = float(tm[0]), float(tt[1])
-    return {'workload': 'C5: Trunk n_f=2127, r=30 (n_x=60, n_u=8), N=50, U box; %d rollouts in total, %d per rank, '
-                        'strong scaling; host buffers' % (total, Bn),
+    else:
+        J_all, best = gather_rollout_costs(J_loc, Bn)
+    return {'workload': 'C5: Trunk n_f=2127, r=30 (n_x=60, n_u=8), N=50, dt=%g, U box; %d rollouts in total, %d per rank, '
+                        'strong scaling; host buffers' % (dt, total, Bn),
             'iterations_per_s': its / el, 'ms': el * 1e3, 'iterations': its,
-            'not_converged_rank0': int((g.status != 0).sum())}
+            'not_converged_rank0': int((g.status != 0).sum()), 'kernel': g.kernel_info['kernel'],
+            'best_rollout': {'global_index': best, 'cost': float(J_all[best]) if best >= 0 else None, 'costs_gathered': int(J_all.size),
+                             'how': 'distributed.gather_rollout_costs: all_gather of the per-rollout optimal LOCP values (sgusto_plan_costs)'}}
 
 
 def scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, max_iters):
@@ -338,26 +360,20 @@ def secondary(L, _lib, rank, world, dist):
     from sofacontrol_amd.utils import QuadraticCost
     out = {}
     # ---- C3
-    n, m, N, dt, Bn = 10, 8, 100, 0.05, 256          # C3 at dt = 0.05 (examples/trunk/trunk.py:365)
-    model = wl.ssm_model(n, m, 3, 2, seed=95)
+    c3 = wl.ssm_c3(256, rank)                        # C3 at dt = 0.05, backward Euler (examples/trunk/trunk.py:365);
+    n, m, N, dt, Bn = c3['n'], c3['m'], c3['N'], c3['dt'], c3['x0'].shape[0]      # tests/test_ssm_gpu.py checks the same construction
+    model = c3['model']
 
     def mat(v):
         a = np.empty((1, 1), dtype=object); a[0, 0] = np.asarray(v); return a
     sc = lambda v: mat(np.array([[v]]))
-    s = SSMDynamics(model['z_ref'].copy(), discrete=False, discr_method='be',
+    s = SSMDynamics(model['z_ref'].copy(), discrete=False, discr_method=c3['discr'],
                     model=dict(Ts=sc(dt), w_coeff=mat(model['W']), v_coeff=mat(model['V']), r_coeff=mat(model['R']),
                                B=mat(model['B']), rd_coeff=mat(model['Rd']), Bd=mat(model['Bd'])),
                     params=dict(state_dim=sc(n), input_dim=sc(m), output_dim=sc(n), SSM_order=sc(2), ROM_order=sc(3)))
     s.H = model['W'][:, :n].copy()
-    Qz = np.diag([100.] * 3 + [1.] * 7)
-    rng = np.random.default_rng(2 + rank)
-    x0 = 0.05 * rng.standard_normal((Bn, n))
-    th = np.linspace(0, 2 * np.pi, N + 1)
-    zt = np.zeros((Bn, N + 1, n))
-    zt[:, :, 0] = 0.1 * np.sin(th)[None, :] * (1 + np.arange(Bn)[:, None] / Bn)
-    zt[:, :, 1] = 0.1 * (1 - np.cos(th))[None, :]
-    zt = zt + model['z_ref']
-    il = iLQR(dt, s, QuadraticCost(Q=Qz, R=np.eye(m), Qf=Qz), N)
+    Qz, x0, zt = c3['Qz'], c3['x0'], c3['zt']
+    il = iLQR(dt, s, QuadraticCost(Q=Qz, R=c3['R'], Qf=c3['Qf']), N)
     il.set_target(zt)
     il.ilqr_computation(x0)
     ts = []
@@ -366,7 +382,7 @@ def secondary(L, _lib, rank, world, dist):
         il.ilqr_computation(x0)
         ts.append(time.perf_counter() - t0)
     t = min(ts)
-    out['ilqr_c3'] = {'workload': 'C3 shape: SSM n_x=10 (285 monomials), n_u=8, horizon 100, %d problems, host buffers '
+    out['ilqr_c3'] = {'workload': 'C3 (workloads.ssm_c3): SSM n_x=10 (285 monomials), n_u=8, horizon 100, dt=0.05 backward Euler, %d problems, host buffers '
                                   '(PCIe copies inside the time); best of 3 calls' % Bn,
                       'iterations_per_s': float(il.iters.sum()) / t, 'ms': t * 1e3, 'ms_all_calls': [x * 1e3 for x in ts],
                       'iterations': int(il.iters.sum())}
@@ -446,6 +462,11 @@ def secondary(L, _lib, rank, world, dist):
                                            'S resident in HBM' % (n_f, world), 'world': world,
                                'phases_ms': {kk: (v * 1e3 if isinstance(v, float) else v) for kk, v in tm.items()},
                                'allreduce_payload_bytes': n_s * n_s * 8}
+        if dist is not None:          # the one exchange step as every rank saw it
+            cs = torch.tensor([tm.get('collective_s', 0.0) * 1e3], dtype=torch.float64, device='cuda')
+            call = torch.empty((world,), dtype=torch.float64, device='cuda')
+            dist.all_gather_into_tensor(call, cs)
+            out['pod_build_c4']['collective_ms_over_ranks'] = {'min': float(call.min()), 'max': float(call.max()), 'per_rank': [float(v) for v in call.cpu()]}
         del U_loc
     except Exception as exc:
         out['pod_build_c4'] = {'error': repr(exc)}
@@ -515,6 +536,46 @@ def launch_ranks(n, argv, dry, cmd=None):
     return rc
 
 
+def stub_main(args, rank, world):
+    """SRH_BENCH_STUB_DEVICE=1: the multi-rank skeleton of this file WITHOUT a GPU -- gloo instead of RCCL, a seeded stand-in
+    for the solve -- so that the launcher, the 127.0.0.1 rendezvous, the barrier-bracketed timing with its max over ranks,
+    the reduction step of the sharded rollout batch and rank-0-only printing run for real on a CPU box
+    (tests/test_bench_contract_cpu.py).  SRH_BENCH_STUB_FAIL_RANK=k makes rank k die before the first collective.
+    Never a measurement: the line says "stub": true and carries no value."""
+    import torch
+    import torch.distributed as dist
+    from sofacontrol_amd.distributed import gather_rollout_costs, shard_range
+    if os.environ.get('SRH_BENCH_STUB_FAIL_RANK') == str(rank):
+        print('bench.py (stub): rank %d exits before the rendezvous, as told' % rank, file=sys.stderr)
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    lo, hi = shard_range(256, rank, world)
+    J = 100.0 + np.random.default_rng(11).standard_normal(256)
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    J_all, best = gather_rollout_costs(J[lo:hi].copy(), 256)
+    per_rank = [elapsed]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        allt = torch.empty((world,), dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, per_rank = float(t[0]), [float(v) for v in allt]
+    if rank == 0:
+        print(json.dumps({'stub': True, 'metric': 'none (SRH_BENCH_STUB_DEVICE=1: launcher / rendezvous / reduction skeleton only)', 'value': None,
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / max(1, args.steps) * 1e3,
+                          'ms_per_step_per_rank': [v / max(1, args.steps) * 1e3 for v in per_rank],
+                          'best_rollout': best, 'best_is_global_argmin': bool(best == int(np.argmin(J))), 'costs_gathered': int(J_all.size)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -543,6 +604,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('SRH_BENCH_STUB_DEVICE') == '1':
+        return stub_main(args, rank, world)
     dist = None
     # torch (device memory for the RCCL collective, C4 secondary) brings its own HIP runtime: it has to initialise
     # before the first call into libsofacontrol_hip
@@ -646,14 +709,19 @@ def main():
     elapsed = time.perf_counter() - t0
     iters = o['iters'].to_array((R_,), dtype=np.int32)
     status = o['status'].to_array((R_,), dtype=np.int32)
+    kinfo = gusto.kernel_info          # the instantiation the timed launches ran + rollouts handed to the fused kernel in the last one
     n_par = min(R_, 512)         # the rollouts the CPU side may solve as well: GPU trajectories kept for `parity_sample`
     gx = o['xopt'].to_array((R_, N + 1, n))[:n_par].copy()
     gu = o['uopt'].to_array((R_, N, m))[:n_par].copy()
     it_per_step = int(iters.sum())
     total_iters = it_per_step * args.steps
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed, float(total_iters)], dtype=torch.float64, device='cuda')
+        allt = torch.empty((world,), dtype=torch.float64, device='cuda')
+        dist.all_gather_into_tensor(allt, t[:1].clone())
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in allt.cpu()]
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -701,11 +769,12 @@ def main():
         'metric': 'SCP iterations/sec (Diamond r=30 H=50) + POD projection GB/s vs HBM roofline',
         'value': total_iters / elapsed, 'unit': 'SCP iterations/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'ms_per_step_per_rank': per_rank_ms,
         'config': {'workload': 'C2: Diamond n_f=4884, POD r=30 (n_x=60, n_u=4), TPWL P=64 nn/zoh, SCP horizon N=50 '
                                'dt=0.05, U box + X box, figure-8 target; %d independent receding-horizon rollouts per GPU '
                                'per step + POD projection of %d snapshots x %d launches' % (R_, B, args.proj_launches),
                    'rollouts_per_gpu': R_, 'proj_batch': B, 'max_gusto_iters': args.max_gusto_iters, 'scp_iters_per_step_rank0': it_per_step,
+                   'scp_kernel': kinfo['kernel'], 'scp_rollouts_handed_to_fused_kernel': kinfo['handed_over'],
                    'solves_not_converged_rank0': int((status != 0).sum())},
         'roofline': {'kernel': 'proj_kernel (srom_project_dev)', 'bound': 'hbm', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -723,7 +792,7 @@ def main():
             'what': 'trajectories and SCP iteration counts of the timed GPU launch vs the numpy oracle (oracle.gusto around '
                     'oracle.riccati_ipm; first %d rollouts) and vs the native CPU twin (condensed algorithm; first %d rollouts) on the '
                     'same inputs' % (len(np_sols), n_par),
-            'kernel_variant': list(gusto.variant),
+            'kernel_variant': list(gusto.variant), 'kernel_info': kinfo,
             'max_rel_traj': max(max(rel(gx[b], np_sols[b][0]), rel(gu[b], np_sols[b][1])) for b in range(len(np_sols))),
             'iters_equal': bool(all(int(iters[b]) == np_sols[b][2] for b in range(len(np_sols)))),
             'max_rel_traj_vs_cpu_twin': max(max(rel(gx[b], sols[b][0]), rel(gu[b], sols[b][1])) for b in range(n_par)),

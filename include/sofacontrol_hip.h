@@ -133,7 +133,8 @@ int srom_eigh_dev(double *G_dev, int64_t n, double *w_dev, void *stream);
  * Rayleigh-Ritz (block = k + oversample <= 128; oversample < 0: max(16, k / 2)) -- what compute_POD keeps of the SVD
  * (pod.py:190-200) without the other n - k singular values: w_dev (k) descending; Wk_dev (n x k) = eigenvector columns
  * scaled by 1 / sqrt(w_i) (the input of srom_modes_dev) or NULL; Vt_dev (k x n) = eigenvector rows or NULL; *trace_out
- * = trace(G) (the truncation rule's denominator: tail energy = trace - sum w); *iters_out = subspace iterations. */
+ * = trace(G) (the truncation rule's denominator: tail energy = trace - sum w); *iters_out = subspace iterations until the
+ * leading k eigenvalues settled to 1e-13 (<= 30), or 31 when they did not (no gap behind the block: take srom_eigh_dev). */
 int srom_eigh_topk_dev(const double *G_dev, int64_t n, int k, int oversample, double *w_dev, double *Wk_dev,
                        double *Vt_dev, double *trace_out, int *iters_out, void *stream);
 /* W_k (n x k, row-major) = the k leading eigenvectors as columns, scaled by 1/sigma_i = 1/sqrt(w_i) */
@@ -356,6 +357,24 @@ int slocp_plan_solve_dev(slocp_plan_t *plan, const double *Ad_dev, const double 
                          const double *z_dev, const double *zf_dev, const double *ud_dev, double *x_dev, double *u_dev,
                          double *s_dev, double *J_dev, int32_t *status_dev, int32_t *iters_dev, void *stream);
 
+/* Which kernels a plan launches -- for tests and bench records (parity is claimed per instantiation; what ran is otherwise
+ * visible only in a rocprof trace).  family: 1 = the lean condensed kernel first (csrc/lean.hip) with the fused kernel
+ * (csrc/gusto.hip / scp.hip) taking what it hands over, 0 = the fused kernel alone.  lean_args = the template arguments of
+ * the lean instantiation <n_u, n_x (0: run time), lanes per stage for the state rows (0: general row handling), horizon
+ * (0: run time), first LDS-resident stage, state rows> (zeros when family = 0); fused_args = <split panel, n_u, n_x> of the
+ * fused instantiation (0: that extent is a run-time value).  handed_over = problems (LOCP) / rollouts (GuSTO) of the LAST
+ * solve that the lean kernel passed to the fused one (-1: no solve yet; 0 when family = 0).  The call waits for the plan's
+ * last solve.  The instantiation is chosen when the plan is created. */
+typedef struct srh_kernel_info {
+    int32_t family;
+    int32_t lean_args[6];
+    int32_t fused_args[3];
+    int32_t handed_over;
+    int32_t lds_bytes_lean, lds_bytes_fused;
+    int32_t threads;
+} srh_kernel_info;
+int slocp_plan_info(slocp_plan_t *plan, srh_kernel_info *info);
+
 /* Whether QPs of this shape take the condensed (output-space) interior point for their trust-region-free pass
  * (csrc/locp_cond.h): enabled, the number of output directions found (rows of C_o spanning Cq, X.A, Xf.A) and whether
  * the input Hessian blocks 2R + U.A^T D U.A are diagonal for every D.  For tests and records. */
@@ -393,6 +412,12 @@ int sgusto_plan_set_max_iters(sgusto_plan_t *plan, int max_gusto_iters);   /* gu
  * = the compile-time n_u / n_x of the instantiation (0: that extent is a run-time value; 0, 0 = the all-sizes
  * kernel).  For tests and bench records: parity is claimed per instantiation. */
 int sgusto_plan_variant(const sgusto_plan_t *plan, int *split, int *n_u_fixed, int *n_x_fixed);
+/* Optimal LOCP value of the solution each rollout of the plan's LAST solve returned (the cost `Jstar` of the last accepted
+ * SCP step, gusto.py:340-370; +inf for a rollout that never accepted a step): J (batch).  What a sharded batch gathers to
+ * pick its best rollout (distributed.gather_rollout_costs).  Waits for the solve. */
+int sgusto_plan_costs(sgusto_plan_t *plan, double *J);
+/* srh_kernel_info of a GuSTO plan (see slocp_plan_info). */
+int sgusto_plan_info(sgusto_plan_t *plan, srh_kernel_info *info);
 int sgusto_plan_solve(sgusto_plan_t *plan, const double *x0, const double *u_init, const double *x_init,
                       const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
                       double *zopt, int32_t *iters, int32_t *status, double *trace);

@@ -111,7 +111,7 @@ int srom_eigh_topk_dev(const double *G_dev, int64_t n, int k, int oversample, do
     if (b > n) b = (int)n;
     SRH_REQUIRE(k <= b && b <= 128, "srom_eigh_topk_dev: k + oversampling must be <= 128 (got k = %d, block %d); use srom_eigh_dev for more modes", k, b);
     hipStream_t st = (hipStream_t)stream;
-    static Abt abt;
+    Abt abt;                             // split-K scratch of this call (two calls on different streams must not share it)
     srh::DevBuf Qt, Zt, Mm, Wm, wv, est;
     int rc;
     if ((rc = Qt.alloc(sizeof(double) * (size_t)b * n)) || (rc = Zt.alloc(sizeof(double) * (size_t)b * n)) || (rc = Mm.alloc(sizeof(double) * b * b)) ||
@@ -134,8 +134,9 @@ int srom_eigh_topk_dev(const double *G_dev, int64_t n, int k, int oversample, do
     if ((rc = orthonormalise(dZ, dQ))) return rc;
     std::vector<double> prev(b, 0.0), cur(b + 1, 0.0);
     int it = 0;
+    bool settled = false;
     const int max_it = 30;               // a block that has not settled by then sits in a flat part of the spectrum (the caller falls back)
-    for (; it < max_it; ++it) {
+    for (; it < max_it && !settled; ++it) {
         if ((rc = abt.run(dQ, n, b, G_dev, n, n, n, dZ, n, st))) return rc;          // Z = Q G   (G symmetric: Q G^T)
         if ((rc = orthonormalise(dZ, dQ))) return rc;
         SRH_CHECK_HIP(hipMemcpyAsync(cur.data(), de, sizeof(double) * (b + 1), hipMemcpyDeviceToHost, st));
@@ -143,7 +144,7 @@ int srom_eigh_topk_dev(const double *G_dev, int64_t n, int k, int oversample, do
         double change = 0.0;
         for (int i = 0; i < k; ++i) change = std::max(change, std::fabs(cur[i] - prev[i]));
         std::copy(cur.begin(), cur.begin() + b, prev.begin());
-        if (it >= 1 && change <= 1e-13 * cur[0]) { ++it; break; }
+        settled = it >= 1 && change <= 1e-13 * cur[0];
     }
     // Rayleigh-Ritz on the converged block
     if ((rc = abt.run(dQ, n, b, G_dev, n, n, n, dZ, n, st))) return rc;
@@ -159,7 +160,7 @@ int srom_eigh_topk_dev(const double *G_dev, int64_t n, int k, int oversample, do
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipStreamSynchronize(st));
     if (trace_out) *trace_out = cur[b];
-    if (iters_out) *iters_out = it;
+    if (iters_out) *iters_out = settled ? it : max_it + 1;      // <= 30: settled after that many; 31: not settled
     return SRH_OK;
 }
 

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], xk[(size_t)k * n + j], v);
         b.zopt[p * (size_t)(N + 1) * nz + e] = v;
     }
-    if (tid == 0) { b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; }
+    if (tid == 0) { b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; if (b.Jopt) b.Jopt[p] = J_prev; }
 }
 
 
@@ -251,11 +251,15 @@ struct sgusto_plan {
     QPConstHost C;
     GustoPar par{};
     int64_t batch = 0;
-    srh::DevBuf fs, work, x0, u_init, x_init, z, zf, ud, xopt, uopt, zopt, iters, status, trace, order, last_iters;
+    srh::DevBuf fs, work, x0, u_init, x_init, z, zf, ud, xopt, uopt, zopt, iters, status, trace, order, last_iters, handed, Jopt;
     bool have_last = false;             // a previous solve left its iteration counts
     size_t work_stride = 0;
     size_t lds = 0, lean_lds = 0;
     bool lean = false;                  // the lean condensed kernel runs first, the fused kernel takes what it hands over
+    int lean_variant = -1;              // its instantiation (lean_select), fixed when the plan is created
+    int lean_args[6] = {0, 0, 0, 0, 0, 0};
+    bool use_lpt = true;                // longest-expected-rollout-first dispatch for batch > #CUs (SRH_GUSTO_NO_LPT=1 at creation: off)
+    bool solved = false;
     bool has_z = false, has_zf = false, has_ud = false;
     // asynchronous requests (sgusto_plan_solve_begin / _done / _end): own stream, completion event, pinned staging
     hipStream_t astream = nullptr;
@@ -336,15 +340,19 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
         (rc = pl->xopt.alloc(sizeof(double) * batch * (N + 1) * n)) || (rc = pl->uopt.alloc(sizeof(double) * batch * N * m)) ||
         (rc = pl->zopt.alloc(sizeof(double) * batch * (N + 1) * nz)) || (rc = pl->iters.alloc(sizeof(int32_t) * batch)) ||
         (rc = pl->status.alloc(sizeof(int32_t) * batch)) || (rc = pl->order.alloc(sizeof(int32_t) * batch)) ||
-        (rc = pl->last_iters.alloc(sizeof(int32_t) * batch)) ||
+        (rc = pl->last_iters.alloc(sizeof(int32_t) * batch)) || (rc = pl->handed.alloc(sizeof(int32_t))) || (rc = pl->Jopt.alloc(sizeof(double) * batch)) ||
         (rc = pl->trace.alloc(sizeof(double) * batch * (size_t)std::max(1, max_trace) * 4)) ||
         (rc = set_lds_limit(gusto_entry(d), pl->lds))) {
         delete pl;
         return rc;
     }
+    SRH_CHECK_HIP(hipMemset(pl->handed.p, 0, sizeof(int32_t)));
+    pl->use_lpt = getenv("SRH_GUSTO_NO_LPT") == nullptr;
     if (d.lean && !getenv("SRH_GUSTO_NO_LEAN")) {
+        pl->lean_variant = lean_select(d, pl->lean_args);
+        if (pl->lean_variant < 0) { delete pl; SRH_REQUIRE(false, "sgusto_plan_create: no lean kernel instantiation for n_u = %d", d.m); }
         pl->lean_lds = lean_kernel_lds_bytes(d);
-        if ((rc = lean_prepare(d, pl->lean_lds))) { delete pl; return rc; }
+        if ((rc = lean_prepare(pl->lean_variant, pl->lean_lds))) { delete pl; return rc; }
         pl->lean = true;
     }
     *out = pl;
@@ -381,8 +389,8 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
     SRH_REQUIRE(!pl->pending || (pl->astream && stream == (void *)pl->astream && pl->launching),
                 "sgusto_plan_solve_dev: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
     GustoBatch b{x0, u_init, x_init, z, zf, u_des, pl->fs.as<double>(), xopt, uopt, zopt, iters, status, trace,
-                 pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>(), 0};
-    if (pl->have_last && pl->batch > 256 && !getenv("SRH_GUSTO_NO_LPT")) {      // more rollouts than CUs: order matters
+                 pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>(), 0, pl->handed.as<int32_t>(), pl->Jopt.as<double>()};
+    if (pl->have_last && pl->batch > 256 && pl->use_lpt) {      // more rollouts than CUs: order matters
         lpt_order_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pl->last_iters.as<int32_t>(), pl->batch, pl->order.as<int32_t>());
         b.order = pl->order.as<int32_t>();
     }
@@ -392,7 +400,9 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
     if (pl->lean) {
         // lean condensed kernel over every rollout; the fused kernel then continues the handed-over ones (its other
         // workgroups leave at once)
-        int rc = lean_launch_gusto(pl->C.dims, pl->C.view(), pl->model->view(), par, b, (unsigned)pl->batch, pl->lean_lds, (hipStream_t)stream);
+        SRH_CHECK_HIP(hipMemsetAsync(pl->handed.p, 0, sizeof(int32_t), (hipStream_t)stream));
+        int rc = lean_launch_gusto(pl->lean_variant, pl->C.dims, pl->C.view(), pl->model->view(), par, b, (unsigned)pl->batch, pl->lean_lds,
+                                   (hipStream_t)stream);
         if (rc) return rc;
         b.mode = 2;
         b.order = nullptr;
@@ -405,6 +415,39 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
 #undef X
     }
     SRH_CHECK_HIP(hipGetLastError());
+    pl->solved = true;
+    return SRH_OK;
+}
+
+int sgusto_plan_costs(sgusto_plan_t *pl, double *J) {
+    SRH_REQUIRE(pl && J, "sgusto_plan_costs: null argument");
+    SRH_REQUIRE(pl->solved, "sgusto_plan_costs: no solve yet");
+    SRH_REQUIRE(!pl->pending, "sgusto_plan_costs: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
+    if (pl->astream) SRH_CHECK_HIP(hipStreamSynchronize(pl->astream));
+    SRH_CHECK_HIP(hipDeviceSynchronize());          // the _dev form may have run on any stream
+    return pl->Jopt.download(J, sizeof(double) * pl->batch);
+}
+
+int sgusto_plan_info(sgusto_plan_t *pl, srh_kernel_info *info) {
+    SRH_REQUIRE(pl && info, "sgusto_plan_info: null argument");
+    SRH_REQUIRE(!pl->pending, "sgusto_plan_info: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
+    memset(info, 0, sizeof(*info));
+    const QPDims &d = pl->C.dims;
+    info->family = pl->lean ? 1 : 0;
+    for (int i = 0; i < 6; ++i) info->lean_args[i] = pl->lean ? pl->lean_args[i] : 0;
+#define X(SP, M, NX) if (info->fused_args[2] == -1 && variant_matches(d, SP, M, NX)) { info->fused_args[0] = SP ? 1 : 0; info->fused_args[1] = M; info->fused_args[2] = NX; }
+    info->fused_args[2] = -1;
+    SRH_QP_VARIANTS(X)
+#undef X
+    info->lds_bytes_lean = pl->lean ? (int32_t)pl->lean_lds : 0;
+    info->lds_bytes_fused = (int32_t)pl->lds;
+    info->threads = NTHREADS;
+    info->handed_over = -1;
+    if (pl->solved) {
+        if (pl->astream) SRH_CHECK_HIP(hipStreamSynchronize(pl->astream));
+        SRH_CHECK_HIP(hipMemcpy(&info->handed_over, pl->handed.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (!pl->lean) info->handed_over = 0;
+    }
     return SRH_OK;
 }
 

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
             if (tid == 0) {
                 rec[0] = 1.0; rec[1] = delta; rec[2] = omega; rec[3] = J_prev; rec[4] = d_prev; rec[5] = o_prev; rec[6] = (double)itr;
                 rec[7] = (double)st;                  // 100: relaxed minimiser outside the trust region (the fused kernel skips its own relaxed attempts)
+                if (b.handed_over) atomicAdd(b.handed_over, 1);
             }
             handed_over = true;
             break;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], xk[(size_t)k * n + j], v);
         b.zopt[p * (size_t)(N + 1) * nz + e] = v;
     }
-    if (tid == 0) { rec[0] = 0.0; b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; }
+    if (tid == 0) { rec[0] = 0.0; b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; if (b.Jopt) b.Jopt[p] = J_prev; }
 }
 
 template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>
@@ -243,25 +244,6 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
     ql::Lds L;
     ql::lds_carve(L, (lptr)smem, d, NTHREADS);
     if (threadIdx.x == 0) L.flag[2] = 0;
-#ifdef QL_POISON
-    {   // debug build: every LDS word starts as a NaN, the problem's work block as NaNs too
-        const size_t total = ql::lds_doubles(d, NTHREADS, d.lean_j0);
-#if QL_POISON == 1
-        const double fill = __longlong_as_double(0x7ff8dead00000000LL);
-#elif QL_POISON == 2
-        const double fill = 1e30;
-#else
-        const double fill = 0.0;
-#endif
-#if QL_POISON != 4
-        for (size_t e = threadIdx.x; e < total; e += blockDim.x) ((lptr)smem)[e] = fill;
-#endif
-#if QL_POISON == 1 || QL_POISON == 2
-        for (size_t e = threadIdx.x; e < b.work_stride; e += blockDim.x) b.work[blockIdx.x * b.work_stride + e] = fill;
-#endif
-        __syncthreads();
-    }
-#endif
     const size_t p = blockIdx.x;
     const size_t N = d.N, n = d.n, m = d.m;
     QPWork w;
@@ -281,7 +263,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
 #endif
     }
     if (st != 0) {
-        if (threadIdx.x == 0) { b.status[p] = LEAN_PENDING; b.iters[p] = it; }
+        if (threadIdx.x == 0) { b.status[p] = LEAN_PENDING; b.iters[p] = it; if (b.handed_over) atomicAdd(b.handed_over, 1); }
         return;
     }
     for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
@@ -295,49 +277,68 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
 // general row handling (GX = 0)
 // (M, NX, GX, NST, J0, NXR): first the layouts with every size fixed (BASELINE C2: Diamond, N = 50, 4 state rows; C5: Trunk,
 // N = 50, no state rows; the Diamond at its shipped r = 36 basis), then the run-time-horizon forms
+// (a development build may pass its own, shorter list: tools/build_lean_dev.sh compiles the benchmark layouts only)
+#ifndef SRH_LEAN_VARIANTS
 #define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) X(4, 72, 4, 50, 18, 4) \
     X(4, 60, 4, 0, 0, 0) X(8, 60, 1, 0, 0, 0) X(4, 72, 4, 0, 0, 0) X(4, 60, 0, 0, 0, 0) X(8, 60, 0, 0, 0, 0) X(4, 0, 0, 0, 0, 0) X(8, 0, 0, 0, 0, 0)
+#endif
 inline int lean_gx(const QPDims &d) {
     if (d.lean != 2) return 0;
     const int RXa = d.nX + d.nXf;
     return RXa == 0 ? 1 : (RXa <= 2 ? 2 : (RXa <= 4 ? 4 : 8));
 }
-inline bool lean_matches(const QPDims &d, int msel, int nsel, int gx, int nst, int j0, int nxr) {
+inline bool lean_matches(const QPDims &d, bool allow_fixed, int msel, int nsel, int gx, int nst, int j0, int nxr) {
     if (d.m != msel || (nsel != 0 && d.n != nsel)) return false;
     if (!(gx == 0 || gx == lean_gx(d))) return false;
     if (nst == 0) return true;
-    return d.N == nst && d.lean_j0 == j0 && d.nX == nxr && d.nXf == 0 && d.nz == 6 && d.po == 2 && d.nU == 2 * msel && !getenv("SRH_LEAN_NO_FIXED");
+    return allow_fixed && d.N == nst && d.lean_j0 == j0 && d.nX == nxr && d.nXf == 0 && d.nz == 6 && d.po == 2 && d.nU == 2 * msel;
 }
 
 }  // namespace
 
-int lean_prepare(const QPDims &d, size_t lds) {
+// The instantiation a problem runs: the first row of SRH_LEAN_VARIANTS whose compile-time sizes equal the problem's
+// (decided ONCE, when a plan is created -- SRH_LEAN_NO_FIXED=1 in the environment at that time skips the fixed-layout rows
+// for A/B runs; nothing is read from the environment per launch).  args: <n_u, n_x, GX, N, j0, state rows>.
+int lean_select(const QPDims &d, int args[6]) {
+    const bool allow_fixed = getenv("SRH_LEAN_NO_FIXED") == nullptr;
+    int idx = 0;
+#define X(M, NX, GX, NST, J0, NXR) if (lean_matches(d, allow_fixed, M, NX, GX, NST, J0, NXR)) { \
+        if (args) { args[0] = M; args[1] = NX; args[2] = GX; args[3] = NST; args[4] = J0; args[5] = NXR; } return idx; } ++idx;
+    SRH_LEAN_VARIANTS(X)
+#undef X
+    return -1;
+}
+
+int lean_prepare(int variant, size_t lds) {
     SRH_REQUIRE(lds <= 160 * 1024, "lean kernels: %zu bytes of LDS needed, 160 KiB available", lds);
-#define X(M, NX, GX, NST, J0, NXR) if (lean_matches(d, M, NX, GX, NST, J0, NXR)) { \
+    int idx = 0;
+#define X(M, NX, GX, NST, J0, NXR) if (idx++ == variant) { \
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_lean_kernel<M, NX, GX, NST, J0, NXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)locp_lean_kernel<M, NX, GX, NST, J0, NXR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
-    SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
+    SRH_REQUIRE(false, "lean kernels: no variant %d", variant);
     return SRH_OK;
 }
 
-int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
+int lean_launch_gusto(int variant, const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
                       size_t lds, hipStream_t stream) {
     QPDims dd = d;
-#define X(M, NX, GX, NST, J0, NXR) if (lean_matches(d, M, NX, GX, NST, J0, NXR)) { if (GX == 0) dd.lean = 1; gusto_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+    int idx = 0;
+#define X(M, NX, GX, NST, J0, NXR) if (idx++ == variant) { if (GX == 0) dd.lean = 1; gusto_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
-    SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
+    SRH_REQUIRE(false, "lean kernels: no variant %d", variant);
     return SRH_OK;
 }
 
-int lean_launch_locp(const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream) {
+int lean_launch_locp(int variant, const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream) {
     QPDims dd = d;
-#define X(M, NX, GX, NST, J0, NXR) if (lean_matches(d, M, NX, GX, NST, J0, NXR)) { if (GX == 0) dd.lean = 1; locp_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+    int idx = 0;
+#define X(M, NX, GX, NST, J0, NXR) if (idx++ == variant) { if (GX == 0) dd.lean = 1; locp_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
-    SRH_REQUIRE(false, "lean kernels: no variant for n_u = %d", d.m);
+    SRH_REQUIRE(false, "lean kernels: no variant %d", variant);
     return SRH_OK;
 }

@@ -35,6 +35,10 @@ struct Lds : qpc::Lds {
 
 __host__ __device__ inline int goff(int j, int m, int NP) { return m * (j * NP - j * (j - 1)); }     // p_o = 2
 constexpr int YPAD = 48;               // zeros behind the y-space vectors that feed gT_times (see there)
+// condense(): item slots per wave.  A stage has at most KT * (NPa / 16) MFMA items spread over the 8 waves; the host only
+// enables the lean path when they fit (scp_host.h:build_consts) -- an item past the last slot would silently never be written.
+constexpr int CONDENSE_SLOTS = 5;
+__host__ __device__ inline bool condense_fits(const QPDims &d, int nwaves) { return d.KT * (d.NPa / 16) <= nwaves * CONDENSE_SLOTS; }
 
 struct Sizes { size_t regX, thetaT, tiles, rinv, nm4, gt, ldi, ls, ldG, ua, tx, ld, idx; };
 __host__ __device__ inline Sizes sizes(const QPDims &d, int nthreads, int j0) {
@@ -183,7 +187,7 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
         const int t_first = (j * po) >> 4;
         const int count = (KT - t_first) * MT;
         const int len = NP - po * j, gj = goff(j, m, NP);
-        constexpr int RMAX = 5;                          // item slots per wave: KT * MT <= 8 * 5 items over 8 waves
+        constexpr int RMAX = CONDENSE_SLOTS;             // item slots per wave: KT * MT <= 8 * 5 items over 8 waves (condense_fits)
         wg::qp_d4 acc[RMAX];
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
@@ -600,11 +604,7 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Ld
     qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc);
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
-#ifdef QL_KSOLVE_SUBST
-    qpc::k_solve(d, L, L.yc);
-#else
     k_solve_unit(d, L, L.yc);
-#endif
     for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
     __syncthreads();
     QC_SUB(pf, 12);
@@ -619,77 +619,6 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Ld
     QC_SUB(pf, 15);
 }
 
-#ifdef QL_SELFCHECK
-// Debug build only: the products and the Gram matrix of the CURRENT data against naive loops over the packed store.
-template <int MSEL>
-__device__ __noinline__ void selfcheck(const QPDims &d, const QPConst &c, const GPack &g, Lds &L, gptr chk, int where) {
-    const int tid = threadIdx.x, nt = blockDim.x, N = d.N, m = d.m, NP = g.NP, nm = N * m;
-    auto Gat = [&](int j, int b, int i) -> double {
-        if (i < 2 * j || i >= NP) return 0.0;
-        const int at = goff(j, m, NP) + b * (NP - 2 * j) + (i - 2 * j);
-        return j < g.j0 ? (double)g.gh[at] : (double)L.Gt[at - goff(g.j0, m, NP)];
-    };
-    __syncthreads();
-    for (int e = tid; e < nm; e += nt) L.ta[e] = 0.37 + 0.001 * e;
-    __syncthreads();
-    g_times<MSEL>(d, g, L, L.ta, L.yb);
-    double e0 = 0.0;
-    for (int i = tid; i < NP; i += nt) {
-        double sref = 0.0;
-        for (int j = 0; j < N; ++j) for (int b = 0; b < m; ++b) sref += Gat(j, b, i) * L.ta[j * m + b];
-        e0 = fmax(e0, fabs(sref - L.yb[i]) / (1e-30 + fabs(sref)));
-    }
-    e0 = wg::reduce(e0, 1, L.red);
-    for (int e = tid; e < 16 * d.KT + YPAD; e += nt) { L.ya[e] = e < NP ? 0.2 + 0.01 * e : 0.0; L.yg[e] = e < NP ? 1.0 - 0.003 * e : 0.0; }
-    __syncthreads();
-    gT_times<MSEL>(d, g, L, L.ya, L.yg, L.du, L.tb);
-    double e1 = 0.0;
-    for (int r = tid; r < nm; r += nt) {
-        const int j = r / m, b = r % m;
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = 0; i < NP; ++i) { s1 += Gat(j, b, i) * L.ya[i]; s2 += Gat(j, b, i) * L.yg[i]; }
-        e1 = fmax(e1, fmax(fabs(s1 - L.du[r]) / (1e-30 + fabs(s1)), fabs(s2 - L.tb[r]) / (1e-30 + fabs(s2))));
-    }
-    e1 = wg::reduce(e1, 1, L.red);
-    gT_times<MSEL>(d, g, L, L.ya, (clptr) nullptr, L.du, (lptr) nullptr);
-    double e1b = 0.0;
-    for (int r = tid; r < nm; r += nt) {
-        const int j = r / m, b = r % m;
-        double s1 = 0.0;
-        for (int i = 0; i < NP; ++i) s1 += Gat(j, b, i) * L.ya[i];
-        e1b = fmax(e1b, fabs(s1 - L.du[r]) / (1e-30 + fabs(s1)));
-    }
-    e1b = wg::reduce(e1b, 1, L.red);
-    if (tid == 0 && blockIdx.x == 0) printf("[selfcheck %d] gT_times single %.2e\n", where, e1b);
-    double e2 = 0.0;
-    for (int e = tid; e < NP * NP; e += nt) {
-        const int i1 = e / NP, i2 = e % NP;
-        if (i1 > i2) continue;
-        const int k1 = i1 >> 1, k2 = i2 >> 1;
-        double v = 0.0;
-        for (int a1 = 0; a1 < 2; ++a1) for (int a2 = 0; a2 < 2; ++a2) {
-            const double l1 = L.Ls[k1 * 4 + a1 * 2 + (i1 & 1)], l2 = L.Ls[k2 * 4 + a2 * 2 + (i2 & 1)];
-            if (l1 == 0.0 || l2 == 0.0) continue;
-            double ky = 0.0;
-            for (int j = 0; j < N; ++j) for (int b = 0; b < m; ++b) { const double sd = L.Ldi[j * m + b]; ky += Gat(j, b, 2 * k1 + a1) * Gat(j, b, 2 * k2 + a2) * sd * sd; }
-            v += l1 * ky * l2;
-        }
-        if (i1 == i2) v += 1.0;
-        chk[e] = v;
-    }
-    __syncthreads();
-    for (int e = tid; e < NP * NP; e += nt) {
-        const int i1 = e / NP, i2 = e % NP;
-        if (i1 > i2) continue;
-        const double ref = chk[e] / sqrt(chk[i1 * NP + i1] * chk[i2 * NP + i2]);
-        const double got = L.B[(size_t)qpc::tile_index(i1 >> 4, i2 >> 4, d.KT) * TSZ + (i1 & 15) * TS + (i2 & 15)];
-        e2 = fmax(e2, fabs(ref - got));
-    }
-    e2 = wg::reduce(e2, 1, L.red);
-    if (tid == 0 && blockIdx.x == 0) printf("[selfcheck %d] g_times %.2e gT_times %.2e gram %.2e\n", where, e0, e1, e2);
-    __syncthreads();
-}
-#endif
 
 // ------------------------------------------------------------------ the QP without its trust-region rows
 // Results: w.u, and -- after the final rollout of solve_qp below -- w.x.  Returns 0 optimal, 1 max iterations, 2 numerical failure.
@@ -709,9 +638,6 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
     gptr gh = work_base + dfull.qc_off;
     const int N = d.N, m = d.m, po = d.po, nm = N * m, ldG = 16 * d.KT, NP = N * po;
     GPack g{(cgptr)gh, (clptr)(L.Gt), d.lean_j0, m, NP};
-#ifdef QL_SELFCHECK
-    QCWork qwd; qwd.GT = work_base + dfull.qc_off + 80000;
-#endif
     Prof pf;
 #ifdef SRH_PROFILE
     for (int i = 0; i < 24; ++i) pf.t[i] = 0;
@@ -747,34 +673,6 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
     rollout<MSEL, NSEL>(d, dyn, q.x0, (cgptr) nullptr, w.x, L);
     QL_LAP(0);
     condense<MSEL, NSEL>(d, c, dyn, w.x, gh, L);
-#ifdef QL_SELFCHECK
-    {   // the packed G against qpc::condense (dense, L2), the free response against qp::rollout
-        gptr dense = work_base + dfull.qc_off + 80000, xref = dense + (size_t)nm * ldG + 64;
-        qpc::Lds Lc = L;
-        Lc.A = L.panel;
-        QCWork qw; qw.GT = dense;
-        for (int e = tid; e < ldG; e += nt) L.ya[e] = L.yf[e];
-        __syncthreads();
-        qpc::condense<MSEL, NSEL>(d, c, dyn, w.x, qw, Lc);
-        double e4 = 0.0, e5 = 0.0, e6 = 0.0;
-        for (int e = tid; e < nm * NP; e += nt) {
-            const int r = e / NP, i = e % NP, j = r / m, b = r % m;
-            const double ref = dense[(size_t)r * ldG + i];
-            double got = 0.0;
-            if (i >= 2 * j) { const int at = goff(j, m, NP) + b * (NP - 2 * j) + (i - 2 * j); got = j < g.j0 ? (double)gh[at] : (double)L.Gt[at - goff(g.j0, m, NP)]; }
-            e4 = fmax(e4, fabs(ref - got));
-            e5 = fmax(e5, fabs(ref));
-        }
-        for (int e = tid; e < ldG; e += nt) e6 = fmax(e6, fabs(L.ya[e] - L.yf[e]));
-        e4 = wg::reduce(e4, 1, L.red); e5 = wg::reduce(e5, 1, L.red); e6 = wg::reduce(e6, 1, L.red);
-        qp::rollout(d, dyn, q, w.u, xref, Lq);
-        double e7 = 0.0;
-        for (int e = tid; e < (N + 1) * d.n; e += nt) e7 = fmax(e7, fabs(xref[e] - w.x[e]));
-        e7 = wg::reduce(e7, 1, L.red);
-        if (tid == 0 && blockIdx.x == 0) printf("[selfcheck] condense max |dG| %.3e (max |G| %.3e) yf %.3e free rollout %.3e\n", e4, e5, e6, e7);
-        __syncthreads();
-    }
-#endif
     for (int k = tid; k < N; k += nt) L.goff[k] = L.idxl[k];
     if (tid == 0) L.flag[2] = 1;
     }
@@ -846,19 +744,10 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
             ok = qpc::stage_factors(d, c, w.D, L);
             QL_LAP(3);
             if (ok) {
-#ifdef QL_OLD_GRAM
-                { qpc::Lds Lc = L; Lc.A = L.panel; qpc::gram<MSEL>(d, qwd, Lc); }
-#else
                 gram<MSEL>(d, c, g, L);
-#endif
-#ifdef QL_SELFCHECK
-                if (mode == INIT || it == 3) selfcheck<MSEL>(d, c, g, L, work_base + dfull.qc_off + 60000, it);
-#endif
                 QL_LAP(4);
                 ok = qpc::tile_cholesky(d, L);
-#ifndef QL_KSOLVE_SUBST
                 if (ok) unit_tiles(d, L);
-#endif
                 QL_LAP(5);
             }
         }
@@ -868,11 +757,7 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
         if (ok) {
             if (mode == PRED) qpc::gradients(d, c, q, L, w.lam, L.tb, L.yg);
             qpc::gradients(d, c, q, L, w.rho, L.ta, L.ya);
-#ifdef QL_OLD_NEWTON
-            { qpc::Lds Lc = L; Lc.A = L.ta; qpc::newton_solve(d, qwd, L, mode == PRED ? (clptr)L.yg : (clptr) nullptr, &rd, pf); }
-#else
             newton_solve<MSEL>(d, g, L, mode == PRED ? (clptr)L.yg : (clptr) nullptr, &rd, pf);
-#endif
         }
         QL_LAP(6);
         if (mode == INIT) {
@@ -1155,9 +1040,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
             gram<MSEL>(d, c, g, L);
             QB_LAP(4);
             ok = qpc::tile_cholesky(d, L);
-#ifndef QL_KSOLVE_SUBST
             if (ok) unit_tiles(d, L);
-#endif
             QB_LAP(5);
         }
 #ifdef SRH_PROFILE
@@ -1280,24 +1163,6 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     __syncthreads();
     rollout<MSEL, NSEL>(d0, dyn, q.x0, (cgptr)w.u, w.x, L);
     __syncthreads();
-#ifdef QL_CHECK_ROLLOUT
-    {
-        gptr xref = work_base + dfull.qc_off + 100000;
-        qp::rollout(d0, dyn, q, w.u, xref, Lq);
-        double e7 = 0.0;
-        int worst = 0;
-        for (int e = tid; e < (N + 1) * n; e += nt) { const double dv = fabs(xref[e] - w.x[e]); if (dv > e7) { e7 = dv; worst = e; } }
-        const double emax = wg::reduce(e7, 1, L.red);
-        if (e7 == emax && emax > 0.0) printf("[check] final rollout max err %.3e at stage %d component %d (block %d)\n", emax, worst / n, worst % n, (int)blockIdx.x);
-        if (tid == 0) {
-            printf("[check] idxl[36..49]: %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", L.idxl[36], L.idxl[37], L.idxl[38], L.idxl[39], L.idxl[40], L.idxl[41], L.idxl[42],
-                   L.idxl[43], L.idxl[44], L.idxl[45], L.idxl[46], L.idxl[47], L.idxl[48], L.idxl[49]);
-            printf("[check] u[40][0..3] = %.6f %.6f %.6f %.6f  x[41][0..1] = %.6f %.6f  x[40][0..1] %.6f %.6f\n", (double)w.u[40 * dfull.m], (double)w.u[40 * dfull.m + 1],
-                   (double)w.u[40 * dfull.m + 2], (double)w.u[40 * dfull.m + 3], (double)w.x[41 * n], (double)w.x[41 * n + 1], (double)w.x[40 * n], (double)w.x[40 * n + 1]);
-        }
-        __syncthreads();
-    }
-#endif
     double J = qp::objective(d0, c, q, w.x, w.u, w.s, Lq);
     bool inside = true;
     if (dfull.tr) {
@@ -1312,3 +1177,4 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
 }
 
 }  // namespace ql
+

@@ -75,7 +75,12 @@ struct slocp_plan {
     QPConstHost C;
     int64_t batch = 0;
     size_t stride = 0;
-    bool have_horizon = false;
+    bool have_horizon = false, solved = false;
+    bool lean = false;                  // the lean condensed kernel runs first (decided at creation)
+    int lean_variant = -1;
+    int lean_args[6] = {0, 0, 0, 0, 0, 0};
+    size_t lean_lds = 0;
+    srh::DevBuf handed;
     srh::DevBuf dA, dAT, dB, dBT, dD, dx0, dxk, ddel, dom, dz, dzf, dud, ox, ou, os, oJ, ost, oit, work, dbg;
 };
 
@@ -94,7 +99,7 @@ static int slocp_plan_launch(slocp_plan *pl, const double *A, const double *B, c
         SRH_CHECK_HIP(hipGetLastError());
     }
     LocpBatch b{A, pl->dAT.as<double>(), B, pl->dBT.as<double>(), dv, x0, xk, delta, omega, z, zf, ud, x, u, sl, J, status, iters,
-                pl->work.as<double>(), pl->stride, nullptr, 0};
+                pl->work.as<double>(), pl->stride, nullptr, 0, pl->handed.as<int32_t>()};
     const bool want_dbg = getenv("SRH_LOCP_TRACE") != nullptr;
     if (want_dbg) {
         if (!pl->dbg.p && (rc = pl->dbg.alloc(sizeof(double) * 8 * 64))) return rc;
@@ -103,11 +108,12 @@ static int slocp_plan_launch(slocp_plan *pl, const double *A, const double *B, c
     }
     const size_t lds = qp_kernel_lds_bytes(d);
     if ((rc = set_lds_limit(locp_entry(d), lds))) return rc;
-    if (d.lean && !getenv("SRH_LOCP_NO_LEAN")) {
+    if (pl->lean) {
         // lean condensed kernel first; the fused kernel below then only takes what it could not finish (trust region
         // active at the minimiser, interior point not converged)
-        const size_t llds = lean_kernel_lds_bytes(d);
-        if ((rc = lean_prepare(d, llds)) || (rc = lean_launch_locp(d, pl->C.view(), b, (unsigned)batch, llds, st))) return rc;
+        const size_t llds = pl->lean_lds;
+        SRH_CHECK_HIP(hipMemsetAsync(pl->handed.p, 0, sizeof(int32_t), st));
+        if ((rc = lean_launch_locp(pl->lean_variant, d, pl->C.view(), b, (unsigned)batch, llds, st))) return rc;
         b.only_pending = 1;
         if (want_dbg) {
             SRH_CHECK_HIP(hipStreamSynchronize(st));
@@ -130,6 +136,7 @@ static int slocp_plan_launch(slocp_plan *pl, const double *A, const double *B, c
 #undef X
     }
     SRH_CHECK_HIP(hipGetLastError());
+    pl->solved = true;
     if (want_dbg) {
         SRH_CHECK_HIP(hipStreamSynchronize(st));
         std::vector<double> t(8 * 64);
@@ -166,14 +173,44 @@ int slocp_plan_create(slocp_plan_t **out, const slocp_problem *prob, int64_t bat
         (rc = pl->dz.alloc(D * B * (N + 1) * nz)) || (rc = pl->dzf.alloc(D * B * nz)) || (rc = pl->dud.alloc(D * B * N * m)) ||
         (rc = pl->ox.alloc(D * B * (N + 1) * n)) || (rc = pl->ou.alloc(D * B * N * m)) || (rc = pl->os.alloc(D * B * (N + 1))) ||
         (rc = pl->oJ.alloc(D * B)) || (rc = pl->ost.alloc(sizeof(int32_t) * B)) || (rc = pl->oit.alloc(sizeof(int32_t) * B)) ||
-        (rc = pl->work.alloc(D * pl->stride * B)))
+        (rc = pl->work.alloc(D * pl->stride * B)) || (rc = pl->handed.alloc(sizeof(int32_t))))
         return rc;
     SRH_CHECK_HIP(hipMemset(pl->dxk.p, 0, D * B * (N + 1) * n));          // no trust region: its centre is never read, but defined
+    SRH_CHECK_HIP(hipMemset(pl->handed.p, 0, sizeof(int32_t)));
+    if (d.lean && !getenv("SRH_LOCP_NO_LEAN")) {
+        pl->lean_variant = lean_select(d, pl->lean_args);
+        SRH_REQUIRE(pl->lean_variant >= 0, "slocp_plan_create: no lean kernel instantiation for n_u = %d", d.m);
+        pl->lean_lds = lean_kernel_lds_bytes(d);
+        if ((rc = lean_prepare(pl->lean_variant, pl->lean_lds))) return rc;
+        pl->lean = true;
+    }
     *out = pl.release();
     return SRH_OK;
 }
 
 void slocp_plan_destroy(slocp_plan_t *pl) { delete pl; }
+
+int slocp_plan_info(slocp_plan_t *pl, srh_kernel_info *info) {
+    SRH_REQUIRE(pl && info, "slocp_plan_info: null argument");
+    memset(info, 0, sizeof(*info));
+    const QPDims &d = pl->C.dims;
+    info->family = pl->lean ? 1 : 0;
+    for (int i = 0; i < 6; ++i) info->lean_args[i] = pl->lean ? pl->lean_args[i] : 0;
+    info->fused_args[2] = -1;
+#define X(SP, M, NX) if (info->fused_args[2] == -1 && variant_matches(d, SP, M, NX)) { info->fused_args[0] = SP ? 1 : 0; info->fused_args[1] = M; info->fused_args[2] = NX; }
+    SRH_QP_VARIANTS(X)
+#undef X
+    info->lds_bytes_lean = pl->lean ? (int32_t)pl->lean_lds : 0;
+    info->lds_bytes_fused = (int32_t)qp_kernel_lds_bytes(d);
+    info->threads = NTHREADS;
+    info->handed_over = -1;
+    if (pl->solved) {
+        SRH_CHECK_HIP(hipDeviceSynchronize());      // the _dev form may have run on any stream
+        SRH_CHECK_HIP(hipMemcpy(&info->handed_over, pl->handed.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (!pl->lean) info->handed_over = 0;
+    }
+    return SRH_OK;
+}
 
 int slocp_plan_solve(slocp_plan_t *pl, const double *Ad, const double *Bd, const double *dd, const double *x0, const double *xk,
                      const double *delta, const double *omega, const double *z, const double *zf, const double *u_des, double *x,

@@ -343,7 +343,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             for (int t = 0; t <= N; ++t)
                 if (ql::lds_doubles(d, NTHREADS, t) * sizeof(double) <= (size_t)160 * 1024) { j0 = t; break; }
             std::vector<int> sched;
-            if (j0 >= 0 && j0 < N && lean_gram_schedule(N, m, d.KT, NTHREADS / 64, sched)) {
+            if (j0 >= 0 && j0 < N && ql::condense_fits(d, NTHREADS / 64) && lean_gram_schedule(N, m, d.KT, NTHREADS / 64, sched)) {
                 d.lean = 1;
                 d.lean_j0 = j0;
                 // rows next to their sums (ql::ipm_box): the reference's HyperRectangle layout of the input rows (rows 2 b,

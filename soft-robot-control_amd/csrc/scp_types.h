@@ -19,6 +19,8 @@ struct GustoBatch {
     const int32_t *order;               // workgroup -> rollout (longest expected solve first), or null
     int32_t *last_iters;                // SCP iterations of this solve per rollout: the next solve's dispatch key
     int mode;                           // fused kernel: 0 = solve every rollout, 2 = only those a lean launch handed over
+    int32_t *handed_over;               // lean kernel: counts the rollouts it hands to the fused kernel (or null)
+    double *Jopt;                       // per rollout: LOCP optimal value of the solution returned (the last accepted step), or null
 };
 
 struct LocpBatch {
@@ -30,6 +32,7 @@ struct LocpBatch {
     size_t work_stride;
     double *dbg;
     int only_pending;                   // fused kernel: 1 = only the problems a lean launch left with status LEAN_PENDING
+    int32_t *handed_over;               // lean kernel: counts the QPs it hands to the fused kernel (or null)
 };
 
 namespace {
@@ -54,7 +57,8 @@ __host__ __device__ inline GustoWork gusto_work(const QPDims &d) {
 }  // namespace
 
 // lean.hip
-int lean_prepare(const QPDims &d, size_t lds);
-int lean_launch_gusto(const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
+int lean_select(const QPDims &d, int args[6]);          // index into the instantiation list (-1: none) + its template arguments
+int lean_prepare(int variant, size_t lds);
+int lean_launch_gusto(int variant, const QPDims &d, const QPConst &c, const TpwlDev &T, const GustoPar &par, const GustoBatch &b, unsigned grid,
                       size_t lds, hipStream_t stream);
-int lean_launch_locp(const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream);
+int lean_launch_locp(int variant, const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream);

@@ -33,6 +33,23 @@ class SGustoParams(C.Structure):
                 ('omega_max', C.c_double), ('convg_thresh', C.c_double), ('max_gusto_iters', C.c_int)]
 
 
+class SrhKernelInfo(C.Structure):
+    """include/sofacontrol_hip.h: srh_kernel_info -- which kernels a LOCP / GuSTO plan launches."""
+    _fields_ = [('family', C.c_int32), ('lean_args', C.c_int32 * 6), ('fused_args', C.c_int32 * 3),
+                ('handed_over', C.c_int32), ('lds_bytes_lean', C.c_int32), ('lds_bytes_fused', C.c_int32),
+                ('threads', C.c_int32)]
+
+    def as_dict(self):
+        """{'family': 'lean' | 'fused', 'kernel': the name rocprof shows, 'lean': (n_u, n_x, GX, N, j0, state rows) | None,
+        'fused': (split, n_u, n_x), 'handed_over': problems of the last solve the lean kernel passed on (-1: none yet)}."""
+        lean = tuple(int(v) for v in self.lean_args) if self.family == 1 else None
+        fused = (bool(self.fused_args[0]), int(self.fused_args[1]), int(self.fused_args[2]))
+        kern = ('lean<%d, %d, %d, %d, %d, %d>' % lean) if lean else ('fused<%s, %d, %d>' % (str(fused[0]).lower(), fused[1], fused[2]))
+        return {'family': 'lean' if self.family == 1 else 'fused', 'kernel': kern, 'lean': lean, 'fused': fused,
+                'handed_over': int(self.handed_over), 'lds_bytes_lean': int(self.lds_bytes_lean),
+                'lds_bytes_fused': int(self.lds_bytes_fused), 'threads': int(self.threads)}
+
+
 class SIlqrParams(C.Structure):
     _fields_ = [('max_iter', C.c_int), ('epsilon', C.c_double), ('alpha0', C.c_double),
                 ('alpha_scaling', C.c_double), ('improv_lb', C.c_double), ('improv_ub', C.c_double),

@@ -6,7 +6,8 @@ xGMI on the GPU box, "gloo" in the CPU tests).
   Gramian is the only collective; the eigen-decomposition is replicated and every rank recovers its own
   rows of U (U stays row-sharded for later projections).
 * Batched SCP rollouts (C5) and POD projection batches shard by independent rows: no data-path collective
-  (`shard_range`); only the bench gathers counts.
+  (`shard_range`); a sharded rollout batch ends with ONE all_gather of the per-rollout optimal costs
+  (`gather_rollout_costs`: every rank learns the global best rollout).
 """
 import numpy as np
 
@@ -16,6 +17,48 @@ def shard_range(n_items, rank, world):
     base, rem = divmod(int(n_items), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_rollout_costs(J_local, n_total=None, group=None):
+    """The reduction step of a batch of SCP rollouts sharded over the ranks ("final all_gather of the
+    costs / pick the best"; the solves themselves need no collective).  J_local: this rank's per-rollout optimal costs
+    (`GuSTO.costs`; +inf / nan for a rollout without an accepted step) in the order of its `shard_range(n_total, rank,
+    world)` slice.  Returns (J_all (n_total,), best): every rank gets the costs of ALL rollouts in global order and the
+    global index of the cheapest one (first index on ties, nan never wins; -1 when no rollout has a finite cost).
+    One all_gather of at most ceil(n_total / world) doubles per rank -- RCCL on device tensors with the nccl backend
+    (pass a CUDA tensor), gloo on host memory.  Without a process group (or world 1) it is the local argmin."""
+    try:
+        import torch
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    except ImportError:
+        multi = False
+    if not multi:
+        J_all = np.asarray(J_local.detach().cpu() if hasattr(J_local, 'detach') else J_local, dtype=np.float64).ravel()
+        if n_total is not None and J_all.size != int(n_total):
+            raise ValueError('gather_rollout_costs: %d local costs for %d rollouts on a single rank' % (J_all.size, int(n_total)))
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        on_device = torch.is_tensor(J_local) and J_local.is_cuda
+        Jt = J_local.to(torch.float64).reshape(-1) if torch.is_tensor(J_local) else torch.from_numpy(np.ascontiguousarray(J_local, dtype=np.float64).ravel())
+        if n_total is None:                          # equal shards assumed unless told otherwise: agree on the total
+            cnt = torch.tensor([Jt.numel()], dtype=torch.int64, device=Jt.device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+            n_total = int(cnt.item())
+        lo, hi = shard_range(n_total, rank, world)
+        if Jt.numel() != hi - lo:
+            raise ValueError('gather_rollout_costs: rank %d holds %d costs, its shard of %d rollouts has %d' % (rank, Jt.numel(), n_total, hi - lo))
+        width = -(-int(n_total) // world)            # shards differ by at most one: pad to the widest
+        mine = torch.full((width,), float('inf'), dtype=torch.float64, device=Jt.device)
+        mine[:hi - lo] = Jt
+        allv = torch.empty((world * width,), dtype=torch.float64, device=Jt.device)
+        dist.all_gather_into_tensor(allv, mine, group=group)
+        allv = allv.cpu().numpy() if on_device else allv.numpy()
+        J_all = np.concatenate([allv[r * width:r * width + (shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0])]
+                                for r in range(world)])
+    key = np.where(np.isfinite(J_all), J_all, np.inf)
+    best = int(np.argmin(key)) if key.size and np.isfinite(key).any() else -1
+    return J_all, best
 
 
 class _HostSteps:
@@ -156,12 +199,17 @@ class _DeviceSteps:
             self._lib.sync()
 
 
+RANK_FLOOR = 1e-7       # relative singular value below which a Gramian-derived mode is noise (see _usable_modes)
+
+
 def _usable_modes(Sigma, k):
-    """rom_dim larger than the numerical rank: U = S^T W Sigma^-1 would divide by (numerically) zero singular values -- the
-    reference's SVD truncation has no such division (pod.py:190-200); refuse with a clear message instead of returning inf / nan."""
+    """rom_dim larger than the numerical rank of the METHOD OF SNAPSHOTS: the spectrum comes from the Gramian, whose eigenvalues
+    carry an absolute error of ~1e-16 lambda_max, so a singular value below ~1e-8 sigma_0 is rounding noise and
+    U = S^T W Sigma^-1 for it is neither accurate nor orthonormal (the reference's SVD, pod.py:190-200, still returns orthonormal
+    vectors there: a documented deviation).  Refuse with a clear message instead of returning such modes."""
     Sigma = np.asarray(Sigma)
-    if k > len(Sigma) or Sigma[k - 1] <= 1e-13 * max(Sigma[0], 1e-300):
-        rank = int((Sigma > 1e-13 * max(Sigma[0], 1e-300)).sum())
+    if k > len(Sigma) or Sigma[k - 1] <= RANK_FLOOR * max(Sigma[0], 1e-300):
+        rank = int((Sigma > RANK_FLOOR * max(Sigma[0], 1e-300)).sum())
         raise RuntimeError('rom_dim = %d exceeds the numerical rank %d of the snapshot matrix (singular value %d is %.3e of the largest)'
                            % (k, rank, k, (Sigma[k - 1] / Sigma[0]) if k <= len(Sigma) and Sigma[0] > 0 else 0.0))
     return k
@@ -194,7 +242,8 @@ def reduce_gramian(G, group=None, collective='auto'):
 
 LEADING_MIN_SNAPSHOTS = 2048      # above this many snapshots the full spectrum is a library call (rocSOLVER dsyevd, ~1 s at 10 000)
 LEADING_MAX_MODES = 112           # block of the subspace iteration <= 128 including its oversampling
-LEADING_MAX_ITERATIONS = 30       # srom_eigh_topk_dev gives up after this many (no gap behind the block): full spectrum then
+LEADING_MAX_ITERATIONS = 30       # srom_eigh_topk_dev reports more than this many when the block did not settle: full spectrum then
+LEADING_MIN_TOL = 1e-12           # below this the tail energy trace - sum(w) is cancellation noise: full spectrum
 
 
 def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian=None, local_modes=None,
@@ -242,14 +291,20 @@ def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian
         timings['collective'] = how
     n_s = int(np.shape(S_shard)[0])
     lead = spectrum == 'leading' or (spectrum == 'auto' and n_s > LEADING_MIN_SNAPSHOTS and (rom_dim is None or int(rom_dim) <= LEADING_MAX_MODES))
+    if lead and rom_dim is None and tol < LEADING_MIN_TOL:
+        if spectrum == 'leading':
+            raise ValueError('pod_from_column_shards: spectrum="leading" evaluates the truncation rule as trace(G) - sum of the leading '
+                             'eigenvalues, which is rounding noise for tol < %g; use spectrum="full"' % LEADING_MIN_TOL)
+        lead = False
     k = None
+    settled = lambda: getattr(steps, 'subspace_iterations', 0) <= LEADING_MAX_ITERATIONS
     if lead:
         # leading eigenpairs only: with rom_dim that many; with a tolerance blocks of growing size until the tail energy fits
         for kk in ([int(rom_dim)] if rom_dim is not None else [32, 64, LEADING_MAX_MODES]):
             kk = min(kk, n_s)
             w, trace = steps.leading(G, kk)
             Sigma = np.sqrt(w)
-            if getattr(steps, 'subspace_iterations', 0) >= LEADING_MAX_ITERATIONS:
+            if not settled():
                 break                                                   # a flat spectrum: the iteration has not settled -> full spectrum
             if rom_dim is not None:
                 k = kk
@@ -258,8 +313,12 @@ def pod_from_column_shards(S_shard, tol, group=None, rom_dim=None, local_gramian
             ok = np.nonzero(tail <= tol)[0]
             if ok.size and ok[0] + 1 < kk:                              # (the last value of a block is not trusted)
                 k = int(ok[0]) + 1
-                w, trace = steps.leading(G, k)                          # W_k in the layout of exactly k modes
+                # W_k in the layout of exactly k modes: a second run with a smaller block (k + oversampling), i.e. a smaller
+                # gap behind it -- if THAT run does not settle its Ritz basis must not be used: full spectrum instead
+                w, trace = steps.leading(G, k)
                 Sigma = np.sqrt(w)
+                if not settled():
+                    k = None
                 break
         if timings is not None:
             timings['spectrum'] = 'leading' if k is not None else 'full (leading blocks did not reach the tolerance)'

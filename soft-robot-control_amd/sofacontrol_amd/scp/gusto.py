@@ -119,6 +119,27 @@ class GuSTO:
         _lib.check(_lib.lib().sgusto_plan_variant(self._plan, C.byref(sp), C.byref(mu), C.byref(nx)), 'sgusto_plan_variant')
         return bool(sp.value), mu.value, nx.value
 
+    @property
+    def costs(self):
+        """(batch,) optimal LOCP value of the solution every rollout of the last solve returned (sgusto_plan_costs; fused
+        TPWL plans only): what a sharded batch gathers to pick its best rollout (distributed.gather_rollout_costs)."""
+        if not self._fused:
+            raise NotImplementedError('GuSTO.costs: per-rollout costs are kept by the resident TPWL plan only')
+        J = np.empty(self.batch)
+        _lib.check(_lib.lib().sgusto_plan_costs(self._plan, _lib.dptr(J)), 'sgusto_plan_costs')
+        return J
+
+    @property
+    def kernel_info(self):
+        """What the last solve of this plan launched (sgusto_plan_info): the kernel family, the template arguments of
+        the instantiation -- the name a rocprof trace shows, e.g. 'lean<4, 60, 4, 50, 7, 4>' for BASELINE C2 -- and how
+        many rollouts the lean kernel handed to the fused one.  The host-loop models report their LOCP plan's kernels."""
+        if not self._fused:
+            return self.locp.kernel_info
+        info = _lib.SrhKernelInfo()
+        _lib.check(_lib.lib().sgusto_plan_info(self._plan, C.byref(info)), 'sgusto_plan_info')
+        return info.as_dict()
+
     # ---- helper tests with the reference's names (host arrays; used by the generic loop / by users)
     def is_converged(self, x, u):
         dx = (1. / self.n_x) * np.sum(np.linalg.norm(np.multiply(self.x_scale, x - self.x_k), axis=1))

@@ -254,6 +254,16 @@ class LOCP:
             return float(J[0]), True, _Stats(t1 - t0, int(iters[0]))
         return np.inf, False, None
 
+    @property
+    def kernel_info(self):
+        """Kernel family / instantiation of this QP's resident plan and the number of QPs of the last solve the lean
+        kernel handed to the fused one (slocp_plan_info); None before the first solve created the plan."""
+        if getattr(self, '_plan', None) is None:
+            return None
+        info = _lib.SrhKernelInfo()
+        _lib.check(_lib.lib().slocp_plan_info(self._plan, C.byref(info)), 'slocp_plan_info')
+        return info.as_dict()
+
     def get_solution(self):
         """locp.py:192-203."""
         return self._sol

@@ -75,3 +75,35 @@ def test_launcher_runs_children_and_propagates_failure():
         lines = out.stdout.strip().splitlines()
         assert 'rank 0 3' in lines and not any(l.startswith('rank 1') or l.startswith('rank 2') for l in lines)
         assert lines[-1] == 'rc %d' % want
+
+
+def _run_stub(extra_env, n=2, timeout=300):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update({'SRH_BENCH_STUB_DEVICE': '1'}, **extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '0'],
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_two_ranks_for_real_up_to_the_first_gpu_call():
+    """`python bench.py --gpus 2` run FOR REAL with SRH_BENCH_STUB_DEVICE=1 (gloo instead of RCCL, a stand-in for the solve):
+    the launcher starts two rank processes, they rendezvous on 127.0.0.1, time between barriers, take the max over ranks,
+    run the reduction step of the sharded rollout batch, and ONLY rank 0 prints the one JSON line."""
+    out = _run_stub({})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['stub'] is True and d['value'] is None and d['n_gpus'] == 2 and d['steps'] == 2
+    assert len(d['ms_per_step_per_rank']) == 2
+    # rank 1 sleeps twice as long per step: the reported time is the slowest rank's
+    assert d['ms_per_step'] >= max(d['ms_per_step_per_rank']) - 1e-6 and d['ms_per_step_per_rank'][1] >= 15.0
+    assert d['best_is_global_argmin'] and d['costs_gathered'] == 256
+
+
+def test_bench_two_ranks_exit_code_when_a_rank_dies():
+    """A rank that dies before the first collective must not leave the launcher waiting for ever: non-zero exit, no JSON line."""
+    out = _run_stub({'SRH_BENCH_STUB_FAIL_RANK': '1'}, timeout=200)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.strip().splitlines() if l.startswith('{"stub"')]

@@ -94,3 +94,51 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _cost_worker(rank, world, port, n_total, out):
+    """A sharded batch of SCP rollouts with a numpy stand-in for the solve (cost of rollout i = a seeded function of its
+    GLOBAL index, one rollout without an accepted step -> +inf, one nan): the product's sharding + reduction step."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sofacontrol_amd.distributed import gather_rollout_costs, shard_range
+    lo, hi = shard_range(n_total, rank, world)
+    J_all_true = _rollout_costs(n_total)
+    J_all, best = gather_rollout_costs(J_all_true[lo:hi].copy(), n_total)
+    J_all2, best2 = gather_rollout_costs(J_all_true[lo:hi].copy()) if n_total % world == 0 else (J_all, best)
+    out[rank] = (lo, hi, J_all, best, J_all2, best2)
+    dist.destroy_process_group()
+
+
+def _rollout_costs(n_total):
+    J = 100.0 + np.random.default_rng(5).standard_normal(n_total)
+    J[n_total // 3] = np.inf          # a rollout that never accepted a step
+    J[n_total // 2] = np.nan          # a failed rollout must never win
+    J[n_total - 2] = 42.0             # the global best sits on the last rank
+    return J
+
+
+@pytest.mark.parametrize('n_total', [256, 7])
+def test_gather_rollout_costs_two_ranks(n_total):
+    """SURVEY 8(e), batched SCP rollouts: every rank ends up with the costs of all rollouts in global order and the same
+    global best; uneven shards (7 over 2 ranks) are padded, inf / nan never win."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cost_worker, args=(2, _free_port(), n_total, out), nprocs=2, join=True)
+    ref = _rollout_costs(n_total)
+    assert out[0][0] == 0 and out[0][1] == out[1][0] and out[1][1] == n_total
+    for r in range(2):
+        np.testing.assert_array_equal(out[r][2], ref)
+        np.testing.assert_array_equal(out[r][4], ref)
+        assert out[r][3] == out[r][5] == n_total - 2
+
+
+def test_gather_rollout_costs_single_process():
+    from sofacontrol_amd.distributed import gather_rollout_costs
+    J, best = gather_rollout_costs(np.array([3.0, np.nan, 1.0, np.inf]))
+    assert best == 2 and J.shape == (4,)
+    assert gather_rollout_costs(np.array([np.inf, np.nan]))[1] == -1
+    with pytest.raises(ValueError):
+        gather_rollout_costs(np.zeros(3), n_total=4)

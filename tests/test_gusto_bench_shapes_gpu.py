@@ -1,7 +1,10 @@
-"""GPU parity of the fused GuSTO kernel at the shapes bench.py times: BASELINE config C2 (Diamond r = 30, n_u = 4,
-P = 64, N = 50, U box + X box, figure-8: kernel instantiation <false,4,60>) and C5 (Trunk r = 30, n_u = 8, U box:
-<false,8,60>), against the restated reference loop (oracle.gusto, sofacontrol/scp/gusto.py:283-487) around the
-stage-structured oracle QP.  Same iteration counts, (J, delta, omega) trace to 1e-6, trajectories <= 1e-4 relative."""
+"""GPU parity of the GuSTO kernels at the shapes bench.py times: BASELINE config C2 (Diamond r = 30, n_u = 4, P = 64,
+N = 50, U box + X box, figure-8: lean instantiation <4, 60, 4, 50, 7, 4>, fused <false, 4, 60> for what it hands over) and
+C5 (Trunk r = 30, n_u = 8, U box: lean <8, 60, 1, 50, 24, 0>, fused <false, 8, 60>), against the restated reference loop
+(oracle.gusto, sofacontrol/scp/gusto.py:283-487) around the stage-structured oracle QP.  Same iteration counts,
+(J, delta, omega) trace to 1e-6, trajectories <= 1e-4 relative.  Every case asserts WHICH instantiation answered
+(`GuSTO.kernel_info`, sgusto_plan_info): the run-time-horizon lean kernels (N = 20), the fixed layout of the shipped
+r = 36 Diamond basis and the fixed-vs-run-time pair at C2 each have a case that is guaranteed to reach them."""
 import numpy as np
 import pytest
 from scipy.interpolate import interp1d
@@ -51,7 +54,7 @@ def compare(g, b, ref, what):
     return rel(g.xopt[b], xe), rel(g.uopt[b], ue)
 
 
-def run_case(w, tip_node, B, seed, variant, what):
+def run_case(w, tip_node, B, seed, variant, what, lean=None, long_solves=2, capped_stays_lean=False):
     from sofacontrol_amd.scp.gusto import GuSTO
     from sofacontrol_amd.utils import Polyhedron
     gm, xc, fc, x0, u_init, x_init, z = problem(w, B, seed, tip_node)
@@ -60,26 +63,75 @@ def run_case(w, tip_node, B, seed, variant, what):
     g = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=X,
               x_char=xc, f_char=fc, convg_thresh=1e-3, batch=B, max_trace=512, max_gusto_iters=5)
     assert g._fused and g.variant == variant, g.variant
+    info = g.kernel_info
+    # the instantiation that answered (what a rocprof trace would show): lean kernel + fused kernel for the hand-overs
+    assert info['family'] == 'lean' and info['lean'] == lean and info['fused'] == variant, info
+    assert 0 <= info['handed_over'] <= B, info
     assert (g.status == 0).all(), g.status
     worst = [0.0, 0.0]
-    for b in range(min(B, 2)):                      # the long solves: two rollouts
+    for b in range(min(B, long_solves)):            # the long solves: two rollouts
         ex, eu = compare(g, b, oracle_solve(w, xc, fc, x0[b], u_init[b], x_init[b], z[b], 500), what + ' max 500')
         worst = [max(worst[0], ex), max(worst[1], eu)]
     # the cap bench.py uses (its real-time drivers use 0..5): every rollout
     g.solve_batch(x0, u_init, x_init, z=z)
     assert g.iters.max() <= 6
+    info = g.kernel_info
+    if capped_stays_lean:                           # the capped solves of the bench cases never shrink delta below 312
+        assert info['handed_over'] == 0, info
     for b in range(B):
         ex, eu = compare(g, b, oracle_solve(w, xc, fc, x0[b], u_init[b], x_init[b], z[b], 5), what + ' max 5')
         worst = [max(worst[0], ex), max(worst[1], eu)]
-    print('%s: worst relative trajectory error x %.2e u %.2e' % (what, worst[0], worst[1]))
+    print('%s: %s, worst relative trajectory error x %.2e u %.2e' % (what, info['kernel'], worst[0], worst[1]))
+    return g
 
 
 def test_fused_gusto_diamond_c2_matches_oracle():
     import workloads as wl
-    run_case(wl.diamond_c2(), 1354, B=6, seed=2, variant=(False, 4, 60), what='C2')
+    run_case(wl.diamond_c2(), 1354, B=6, seed=2, variant=(False, 4, 60), what='C2', lean=(4, 60, 4, 50, 7, 4), capped_stays_lean=True)
 
 
 def test_fused_gusto_trunk_c5_matches_oracle():
     import workloads as wl
     w = wl.trunk_c5()
-    run_case(w, w['tip_node'], B=4, seed=9, variant=(False, 8, 60), what='C5')
+    run_case(w, w['tip_node'], B=4, seed=9, variant=(False, 8, 60), what='C5', lean=(8, 60, 1, 50, 24, 0), capped_stays_lean=True)
+
+
+def test_lean_runtime_horizon_n20_matches_oracle():
+    """N = 20 at n_x = 60: no fixed-layout instantiation exists for it -- the run-time-horizon lean kernel
+    <4, 60, 4, 0, 0, 0> answers (box rows, 4 state rows)."""
+    import workloads as wl
+    run_case(wl.diamond_c2(N=20), 1354, B=3, seed=2, variant=(False, 4, 60), what='C2 with N = 20', lean=(4, 60, 4, 0, 0, 0),
+             long_solves=1)
+
+
+def test_lean_fixed_layout_r36_matches_oracle():
+    """The reference's SHIPPED Diamond basis size r = 36 (examples/diamond/pod_model.pkl): n_x = 72, N = 50, 4 state rows --
+    the fixed-layout instantiation <4, 72, 4, 50, 18, 4>; what it hands over goes to the split-panel fused kernel."""
+    import workloads as wl
+    run_case(wl.diamond_c2(r=36), 1354, B=3, seed=2, variant=(True, 4, 72), what='C2 at r = 36', lean=(4, 72, 4, 50, 18, 4),
+             long_solves=1)
+
+
+def test_lean_fixed_layout_equals_runtime_layout_at_c2(monkeypatch):
+    """SRH_LEAN_NO_FIXED=1 (read when the plan is created) selects the run-time-size lean kernel for the same problem: same
+    SCP iteration counts, same status, trajectories to rounding (the two differ in index arithmetic only)."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2()
+    B = 8
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, B, 2, 1354)
+    res = {}
+    for tag in ('fixed', 'runtime'):
+        if tag == 'runtime':
+            monkeypatch.setenv('SRH_LEAN_NO_FIXED', '1')
+        g = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']),
+                  X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, batch=B, max_trace=0, max_gusto_iters=5)
+        long_iters = g.iters.copy()
+        g.solve_batch(x0, u_init, x_init, z=z)
+        res[tag] = (g.kernel_info['lean'], long_iters, g.iters.copy(), g.status.copy(), g.xopt.copy(), g.uopt.copy())
+    monkeypatch.delenv('SRH_LEAN_NO_FIXED')
+    assert res['fixed'][0] == (4, 60, 4, 50, 7, 4) and res['runtime'][0] == (4, 60, 4, 0, 0, 0), (res['fixed'][0], res['runtime'][0])
+    assert (res['fixed'][1] == res['runtime'][1]).all() and (res['fixed'][2] == res['runtime'][2]).all()
+    assert (res['fixed'][3] == res['runtime'][3]).all()
+    assert rel(res['fixed'][4], res['runtime'][4]) <= 1e-9 and rel(res['fixed'][5], res['runtime'][5]) <= 1e-9

@@ -149,29 +149,27 @@ def test_ilqr_ssm_golden(golden, tag):
 
 
 def test_ilqr_ssm_c3_shape_batched():
-    """BASELINE config C3 shape (SSM r = 10, n_u = 8, horizon 100), a batch of problems, vs the oracle loop."""
+    """BASELINE config C3 exactly as bench.py times it (workloads.ssm_c3: SSM r = 10, n_u = 8, horizon 100, dt = 0.05,
+    backward Euler -- the in-kernel LDS Gauss-Jordan branch), the first problems of the bench's batch, vs the oracle loop."""
+    import workloads as wl
     from oracle import lqr as olqr
     from sofacontrol_amd.lqr.ilqr import iLQR
     from sofacontrol_amd.utils import QuadraticCost
-    n, m, N, dt = 10, 8, 100, 0.01
-    model = ossm.synthetic(n, m, 3, 2, seed=95)
-    s = product_ssm(model, discr='fe')
-    s.H = model['W'][:, :n].copy()
-    Qz = np.diag([100.] * 3 + [1.] * 7); R = 1.0 * np.eye(m)      # well conditioned: 1e-13 sensitivity to x0
-    rng = np.random.default_rng(2)
+    c3 = wl.ssm_c3(256)
     Bn = 3
-    x0 = 0.05 * rng.standard_normal((Bn, n))
-    th = np.linspace(0, 2 * np.pi, N + 1)
-    zt = np.zeros((Bn, N + 1, n))
-    for b in range(Bn):
-        zt[b, :, 0] = 0.1 * (b + 1) * np.sin(th); zt[b, :, 1] = 0.1 * (1 - np.cos(th))
-    zt = zt + model['z_ref']
-    il = iLQR(dt, s, QuadraticCost(Q=Qz, R=R, Qf=Qz), N)
+    n, m, N, dt, discr = c3['n'], c3['m'], c3['N'], c3['dt'], c3['discr']
+    assert (dt, discr) == (0.05, 'be')
+    model = ossm.synthetic(n, m, 3, 2, seed=95)
+    np.testing.assert_array_equal(model['R'], c3['model']['R'])
+    s = product_ssm(model, discr=discr)
+    s.H = model['W'][:, :n].copy()
+    Qz, R, x0, zt = c3['Qz'], c3['R'], c3['x0'][:Bn], c3['zt'][:Bn]
+    il = iLQR(dt, s, QuadraticCost(Q=Qz, R=R, Qf=c3['Qf']), N)
     il.set_target(zt)
     x, u, K = il.ilqr_computation(x0)
     for b in range(Bn):
-        o = olqr.ILQRGeneric(lambda xx, uu: ossm.jacobians(model, xx, uu, dt, 'fe'),
-                             lambda xx: ossm.observe(model, xx) + model['z_ref'], s.H, n, m, Qz, R, Qz, N)
+        o = olqr.ILQRGeneric(lambda xx, uu: ossm.jacobians(model, xx, uu, dt, discr),
+                             lambda xx: ossm.observe(model, xx) + model['z_ref'], s.H, n, m, Qz, R, c3['Qf'], N)
         xo, uo, Ko = o.solve(x0[b], zt[b])
         assert int(il.iters[b]) == len(o.trace) - 1
         close(x[b], xo, 1e-8); close(u[b], uo, 1e-7)

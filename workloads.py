@@ -90,9 +90,10 @@ def figure8(z_ref, T=10.0, M=1000, scale=1.0):
     return t, z
 
 
-def trunk_c5(r=30, N=50, dt=0.05, seed=20, P=64, n_f=2127, tip_node=51):
-    """BASELINE config C5: Trunk n_f = 2127 (3 x 709), POD r = 30 (n_x = 60), n_u = 8, SCP horizon N = 50
-    (examples/trunk/trunk.py:292-316): Qz = diag(0,0,0,100,100,0), R = 1e-5 I, U = [0,800]^8, X = None."""
+def trunk_c5(r=30, N=50, dt=0.1, seed=20, P=64, n_f=2127, tip_node=51):
+    """BASELINE config C5: Trunk n_f = 2127 (3 x 709), POD r = 30 (n_x = 60), n_u = 8, SCP horizon N = 50, dt = 0.1
+    (examples/trunk/trunk.py:292-316, dt: line 309): Qz = diag(0,0,0,100,100,0), R = 1e-5 I, U = [0,800]^8, X = None.
+    (The target is the Diamond's figure-8 of `figure8`, twice the Trunk driver's x amplitude.)"""
     m = 8
     U, q_ref, v_ref = pod_basis(n_f, r, seed=3)
     H = tip_selector_rows(U, tip_node)
@@ -154,3 +155,23 @@ def ssm_model(n, m, rom_order, ssm_order, seed=0):
     Bd = 0.01 * B
     z_ref = rng.standard_normal(n)
     return dict(n=n, m=m, rom_order=rom_order, ssm_order=ssm_order, R=R, B=B, W=W, V=V, Rd=Rd, Bd=Bd, z_ref=z_ref)
+
+
+def ssm_c3(problems=256, rank=0):
+    """BASELINE config C3 as bench.py times it and tests/test_ssm_gpu.py checks it: SSM reduction r = 10 (n_x = 10, cubic
+    reduced dynamics, quadratic maps: 285 / 65 monomials), n_u = 8, iLQR horizon N = 100 at dt = 0.05 with the backward-Euler
+    discretisation (examples/trunk/trunk.py:365), `problems` independent tracking problems (circle-like targets of growing
+    amplitude on the first two outputs).  Returns the seeded model and the problem arrays; the first k problems of a
+    larger batch are the k-problem batch (the parity test solves a prefix of what the bench solves)."""
+    n, m, N, dt = 10, 8, 100, 0.05
+    model = ssm_model(n, m, 3, 2, seed=95)
+    Qz = np.diag([100.] * 3 + [1.] * 7)
+    R = np.eye(m)
+    rng = np.random.default_rng(2 + rank)
+    x0 = 0.05 * rng.standard_normal((problems, n))
+    th = np.linspace(0, 2 * np.pi, N + 1)
+    zt = np.zeros((problems, N + 1, n))
+    zt[:, :, 0] = 0.1 * np.sin(th)[None, :] * (1 + np.arange(problems)[:, None] / 256.0)
+    zt[:, :, 1] = 0.1 * (1 - np.cos(th))[None, :]
+    zt = zt + model['z_ref']
+    return dict(n=n, m=m, N=N, dt=dt, discr='be', model=model, Qz=Qz, R=R, Qf=Qz, x0=x0, zt=zt)
