@@ -298,6 +298,52 @@ def scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, max_iters):
     return out
 
 
+def scp_reference_horizons(tip_node=1354):
+    """The horizons the reference's own drivers solve on the Diamond (BASELINE C2 keeps N = 50): the closed-loop drivers replan a
+    short horizon -- examples/diamond/diamond.py:309-316 (N = 5, dt = 0.05, U + X box, default cap of 500 SCP iterations) and
+    examples/hardware/diamond.py:393-399 (N = 3, dt = 0.1, U box only, max_gusto_iters = 5) -- and the open-loop planner solves the
+    whole figure-8 at once, examples/hardware/diamond.py:471-474 (N = 200, dt = 0.05, U box only, no warm start).  One rollout at a
+    time through the host-pointer API, as the drivers do; same synthetic C2 model (workloads.diamond_c2 at that N / dt)."""
+    import workloads as wl
+    from scipy.interpolate import interp1d
+    from sofacontrol_amd.mor.pod import POD
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    out = {}
+    for key, N, dt, with_X, cap, reps, ref in (('closed_loop_N5', 5, 0.05, True, 500, 8, 'examples/diamond/diamond.py:309-316'),
+                                             ('hardware_closed_loop_N3', 3, 0.1, False, 5, 8, 'examples/hardware/diamond.py:393-399'),
+                                             ('hardware_open_loop_N200', 200, 0.05, False, 500, 3, 'examples/hardware/diamond.py:471-474')):
+        try:
+            w = wl.diamond_c2(N=N, dt=dt, with_X=with_X)
+            m, r = w['m'], w['r']
+            rom = POD(dict(U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
+            tp, gm = build_model(w, tip_node)
+            xc, fc = gm.get_characteristic_vals()
+            X = wl.snapshots(w['q_ref'], reps, seed=2)
+            x0 = np.concatenate((np.zeros((reps, r)), rom.compute_RO_state(qf=X)), axis=1)
+            u0 = np.zeros((N, m))
+            x_init, _ = tp.rollout(x0, np.zeros((reps, N, m)), dt)
+            zi = interp1d(w['t'], w['z'], axis=0, bounds_error=False, fill_value=(w['z'][0], w['z'][-1]))
+            z = np.stack([zi(b * 10.0 / reps + dt * np.arange(N + 1)) for b in range(reps)])
+            g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0[0], u0, x_init[0], z=z[0], U=Polyhedron(w['UA'], w['Ub']),
+                      X=Polyhedron(w['XA'], w['Xb']) if with_X else None, x_char=xc, f_char=fc, convg_thresh=1e-3, max_trace=0, max_gusto_iters=cap)
+            ts, its, st = [], [], []
+            for b in range(reps):
+                t0 = time.perf_counter()
+                g.solve(x0[b], u0, x_init[b], z=z[b])
+                ts.append(time.perf_counter() - t0)
+                its.append(int(g.iters[0])); st.append(int(g.status[0]))
+            per = sorted(t / max(1, i) for t, i in zip(ts, its))
+            ki = g.kernel_info
+            out[key] = {'reference_driver': ref, 'N': N, 'dt': dt, 'X_rows': 4 if with_X else 0, 'max_gusto_iters': cap,
+                        'ms_per_solve_median': sorted(ts)[len(ts) // 2] * 1e3, 'ms_per_solve_max': max(ts) * 1e3, 'scp_iterations': its,
+                        'status': st, 'ms_per_scp_iteration_median': per[len(per) // 2] * 1e3, 'kernel': ki['kernel'],
+                        'handed_to_fused_kernel_last_solve': ki['handed_over']}
+        except Exception as exc:
+            out[key] = {'error': repr(exc)}
+    return out
+
+
 def pod_shapes(L, _lib, B=65536):
     """the projection at the shipped r = 36 as well, the lift (pod.py:54-66) and the full-state form
     (both blocks, `compute_RO_state(xf=...)`); resident buffers, HIP events over 100 launches after 30 warm-up ones."""
@@ -476,6 +522,8 @@ def secondary(L, _lib, rank, world, dist):
         out['pod_shapes'] = pod_shapes(L, _lib)
     except Exception as exc:
         out['pod_shapes'] = {'error': repr(exc)}
+    if rank == 0:
+        out['scp_reference_horizons'] = scp_reference_horizons()
     try:
         out['scp_c5'] = scp_c5(_lib, rank, world, dist)
         if world == 1:       # what one GPU of an 8-GPU node gets of the 256 rollouts

@@ -6,6 +6,8 @@
 
 namespace {
 
+static_assert(NTHREADS == 512, "ql::half_waves: the two wave sets are the SIMD halves of an 8-wave workgroup");
+
 #ifdef SRH_PROFILE
 #define GU_LAP(i) do { __syncthreads(); const long long now_ = clock64(); gup[i] += now_ - gul; gul = now_; } while (0)
 #else
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6], prof[7]);
         printf("lean newton laps: gradients %lld gT(1) %lld rhs+dinv %lld g(1) %lld k_solve %lld gT(2) %lld du %lld g(2) %lld\n",
                prof[8], prof[9], prof[10], prof[11], prof[12], prof[13], prof[14], prof[15]);
+        printf("lean split (factorisation on waves 0-3 beside the front of the Newton solve on waves 4-7): factorisation %lld front %lld\n", prof[16], prof[17]);
     }
 #endif
     if (handed_over) {

@@ -523,16 +523,26 @@ __device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
         const double t = T[r * TS + c];
         a[r] = grp == 0 ? t : ((grp == 1 && r == c) ? 1.0 : 0.0);
     }
+    // The row that carries the NEXT pivot is updated first and the reciprocal square root of that pivot (readlane, v_rsq_f64, a
+    // Newton step: a dependent chain of ~100 clocks) is started before the other row operations of the step, which do not depend
+    // on it -- the one wave that runs this is the critical path of the factorisation.  Same operations, same results.
     bool ok = true;
+    double piv = readlane_d(a[0], 0);
+    ok = ok && (piv > 0.0);
+    double di = rsqrt(piv);
+    double di2 = di * (1.5 - 0.5 * piv * di * di);                 // one Newton step: full double accuracy
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const double piv = readlane_d(a[s], s);
-        ok = ok && (piv > 0.0);
-        const double di = rsqrt(piv);
-        const double di2 = di * (1.5 - 0.5 * piv * di * di);       // one Newton step: full double accuracy
         a[s] *= di2;
+        if (s + 1 < 16) {
+            a[s + 1] = fma(-readlane_d(a[s], s + 1), a[s], a[s + 1]);
+            piv = readlane_d(a[s + 1], s + 1);
+            ok = ok && (piv > 0.0);
+            di = rsqrt(piv);
+            di2 = di * (1.5 - 0.5 * piv * di * di);
+        }
 #pragma unroll
-        for (int r = s + 1; r < 16; ++r) a[r] = fma(-readlane_d(a[s], r), a[s], a[r]);
+        for (int r = s + 2; r < 16; ++r) a[r] = fma(-readlane_d(a[s], r), a[s], a[r]);
     }
     if (grp == 0) {
 #pragma unroll

@@ -97,6 +97,50 @@ struct GPack {
     int j0, m, NP;
 };
 
+// ------------------------------------------------------------------ wave sets
+// The factorisation of K is a chain of seven one-wave 16 x 16 factorisations with short all-wave phases in between (35 k of
+// its 52 k clocks at C2 belong to wave 0 alone), and the first half of the Newton solve that follows -- G^T g_y, the dual
+// residual, D^-1, G t, Ls^T -- does not depend on the factor.  ipm_box() therefore splits the workgroup for that stretch:
+// one half of the waves factors, the other runs the products, and they meet again at an s_barrier.  The halves are taken BY
+// SIMD (a workgroup's waves w and w + 4 share one: set 0 = waves 0, 1, 4, 5, set 1 = waves 2, 3, 6, 7), so that the wave
+// with the one-wave factorisations shares its SIMD with a wave of its own set, which waits most of the time, and not with
+// a wave that streams the products.  Inside the stretch a set cannot use
+// s_barrier (it counts every wave of the workgroup): a set synchronises on its own monotone arrival counter in LDS -- each
+// wave adds one and waits for the next multiple of the set size (the LDS pipe is in order per wave, so a wave's earlier
+// LDS writes have landed when its arrival is seen; the workgroup-scope fences keep the compiler from moving accesses
+// across and drain the global-memory counters).  HALF = false: the whole workgroup, plain s_barrier.
+template <bool HALF>
+struct Waves {
+    int tid, nt, wave, nw;             // thread / wave index inside the set, set sizes
+    liptr ctr;                         // HALF: arrival counter of this set (zeroed by the caller before the split)
+    int target;
+    bool sleepy;                       // HALF: s_sleep between polls (the set whose waits are long; the other polls back to back)
+    __device__ __forceinline__ void sync() {
+        if constexpr (!HALF) {
+            __syncthreads();
+        } else {
+            target += nw;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if ((threadIdx.x & 63) == 0) {
+                __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { if (sleepy) __builtin_amdgcn_s_sleep(1); }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+};
+__device__ __forceinline__ Waves<false> all_waves() {
+    return Waves<false>{(int)threadIdx.x, (int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)blockDim.x >> 6, (liptr) nullptr, 0, false};
+}
+// the two halves of an 8-wave workgroup by SIMD: set (w >> 1) & 1, wave (w & 1) + 2 (w >> 2) inside it; ctr0: the arrival counter
+// of set 1 (set 0 synchronises through the counters of tile_cholesky_set)
+__device__ __forceinline__ int half_of_wave(int w) { return (w >> 1) & 1; }
+__device__ __forceinline__ Waves<true> half_waves(liptr ctr0) {
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), which = half_of_wave(w), lw = (w & 1) + 2 * (w >> 2);
+    return Waves<true>{lw * 64 + ((int)threadIdx.x & 63), 256, lw, 4, ctr0, 0, which == 1};      // (only set 1 calls sync(): one counter)
+}
+
 // ------------------------------------------------------------------ rollout x_{k+1} = A_k x_k + B_k u_k + d_k  (u null: zero inputs)
 // One dot product of length n + m per state row through the [A | B] panel in LDS (reloaded only when the TPWL region
 // changes: ~12 % of the stages), ONE barrier per stage: 8 lanes per row, lane (il, s) of a 16-lane DPP row takes the columns
@@ -242,10 +286,10 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
 // yv[i] = sum_{rows (j,b), 2 j <= i} G^T[(j,b)][i] uv[(j,b)]: thread = (column, input class b mod 4).  Stages j <= jlo (the
 // last stage that reaches EVERY column of the wave) need no mask; lanes read past "their" rows only inside LDS / the L2
 // block (the select discards what they get).  8 loads of G and of u per trip before the FMAs.
-template <int MSEL>
-__device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L, clptr uv, lptr yv) {
+template <int MSEL, bool HALF>
+__device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L, clptr uv, lptr yv, Waves<HALF> &W) {
     constexpr int M = MSEL, CH = 8, CW = 128;
-    const int ldG = 16 * d.KT, NP = g.NP, N = d.N, tid = threadIdx.x, nt = blockDim.x;
+    const int ldG = 16 * d.KT, NP = g.NP, N = d.N, tid = W.tid, nt = W.nt;
     const int GR = nt / CW, col = tid % CW, grp = tid / CW;          // GR = 4
     const int cc = col < NP ? col : NP - 1;
     const int jcnt = col < NP ? min(N, cc / 2 + 1) : 0;              // stages that reach this column
@@ -285,24 +329,30 @@ __device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L,
         span(g.gh, 0, min(g.j0, jany));
         span(g.gt - goff0, g.j0, jany);
     }
-    L.part[grp * CW + col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    __syncthreads();
+    lptr part = L.part;                                     // GR * CW slots: 512 for the workgroup, 256 for a half set
+    part[grp * CW + col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    W.sync();
     if (tid < ldG) {
         double s = 0.0;
-        if (tid < NP) for (int q = 0; q < GR; ++q) s += L.part[q * CW + tid];
+        if (tid < NP) for (int q = 0; q < GR; ++q) s += part[q * CW + tid];
         yv[tid] = s;
     }
-    __syncthreads();
+    W.sync();
+}
+template <int MSEL>
+__device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L, clptr uv, lptr yv) {
+    auto W = all_waves();
+    g_times<MSEL, false>(d, g, L, uv, yv, W);
 }
 
 // out1[row] = sum_{i >= 2 j} G^T[row][i] y1[i]  (and out2 with y2 when y2 != null): 8 lanes per row, 64 rows per pass; the
 // L2-resident rows (stages < j0) in passes of their own.  No masks: y1 / y2 must be zero from index NP up to NP + YPAD - 1
 // (the lanes run to the length of the longest row of the pass; what they read of G past the end of a row is the next
 // rows' data -- finite -- times those zeros).
-template <int MSEL>
-__device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2) {
+template <int MSEL, bool HALF>
+__device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2, Waves<HALF> &W) {
     constexpr int M = MSEL;
-    const int NP = g.NP, nm = d.N * M, tid = threadIdx.x, nt = blockDim.x;
+    const int NP = g.NP, nm = d.N * M, tid = W.tid, nt = W.nt;
     const int g8 = tid & 7, rpp = nt / 8;
     const int goff0 = goff(g.j0, M, NP);
     auto rows = [&](auto src, int rb, int re, auto TWO) {           // rows [rb, re) from `src` (indexed by the global offset)
@@ -341,7 +391,12 @@ __device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L
         if (rh > 0) rows(g.gh, 0, rh, std::false_type{});
         if (nm > rh) rows(g.gt - goff0, rh, nm, std::false_type{});
     }
-    __syncthreads();
+    W.sync();
+}
+template <int MSEL>
+__device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2) {
+    auto W = all_waves();
+    gT_times<MSEL, false>(d, g, L, y1, y2, out1, out2, W);
 }
 
 // ------------------------------------------------------------------ Gram matrix K = I + Ls^T (G D^-1 G^T) Ls -> upper tiles
@@ -475,6 +530,81 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ tile Cholesky on one wave set, without set-wide barriers
+// qpc::tile_cholesky synchronises the whole workgroup twice per tile row; its critical path is wave 0 (a 16 x 16 factorisation
+// per row, ~4.7 k clocks each) and every barrier on that path is paid in full.  Here wave 0 of the set never waits for a
+// barrier: the dependencies are three monotone counters in LDS (F[0]: trailing updates finished, one arrival per worker and
+// row; F[1]: inverses of the diagonal tiles published by wave 0; F[2]: panel tiles of a row written, one arrival per wave),
+//     wave 0:   [wait: the updates of the rows before are in]  R_J,J+1 = Rinv_J^T K_J,J+1   -> F[2]
+//               K_J+1,J+1 -= R_J,J+1^T R_J,J+1;  chol16                                     -> F[1]
+//     workers:  [wait F[1]: Rinv_J; wait F[0]: the rows before]  their panel tiles R_JJ'    -> F[2]
+//               [wait F[2]: the whole panel]  their trailing tiles                           -> F[0]
+// and what wave 0 waits for (the workers' trailing updates of the row before) has normally finished long before it asks: the
+// workers run one row behind, beside the factorisation of the next diagonal tile.  A wave's LDS writes reach the LDS before
+// its own later arrival (the LDS queue of a wave is in order), the fences keep the compiler from moving accesses across.
+// No early exit on a failed pivot (NaNs are harmless, the caller tests L.flag[1] after the halves have joined).
+__device__ __forceinline__ void set_signal(liptr c) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void set_wait(liptr c, int v) {
+    if ((threadIdx.x & 63) == 0) { while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {} }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void panel_tile(Lds &L, int KT, int J, int Jp, int l16, int kk) {      // R_JJ' = Rinv_J^T K_JJ'
+    clptr Ri = L.Rinv + (size_t)J * TSZ;
+    lptr T = L.B + (size_t)qpc::tile_index(J, Jp, KT) * TSZ;
+    double av[4], bv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { av[s] = Ri[(4 * s + kk) * TS + l16]; bv[s] = T[(4 * s + kk) * TS + l16]; }
+    wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) T[(kk + 4 * qd) * TS + l16] = acc[qd];
+}
+// F: three LDS counters, zero on entry.  Returns nothing: L.flag[1] = 1 iff every pivot was positive (valid after the caller's barrier).
+__device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const Waves<true> &W, liptr F) {
+    const int KT = d.KT, wave = W.wave, lane = W.tid & 63, nwk = W.nw - 1;
+    const int l16 = lane & 15, kk = lane >> 4;
+    liptr Ftrail = F, Frinv = F + 1, Fpanel = F + 2;
+    if (wave == 0) {
+        bool ok = qpc::chol16(L.B, L.Rinv);
+        set_signal(Frinv);
+        for (int J = 0; J + 1 < KT; ++J) {
+            set_wait(Ftrail, nwk * J);
+            panel_tile(L, KT, J, J + 1, l16, kk);
+            set_signal(Fpanel);
+            clptr Ra = L.B + (size_t)qpc::tile_index(J, J + 1, KT) * TSZ;
+            lptr T = L.B + (size_t)qpc::tile_index(J + 1, J + 1, KT) * TSZ;
+            __builtin_amdgcn_wave_barrier();
+            qpc::tile_update(T, Ra, Ra, l16, kk);
+            __builtin_amdgcn_wave_barrier();
+            ok = qpc::chol16(T, L.Rinv + (size_t)(J + 1) * TSZ) && ok;
+            set_signal(Frinv);
+        }
+        if (lane == 0) L.flag[1] = ok ? 1 : 0;
+    } else {
+        for (int J = 0; J + 1 < KT; ++J) {
+            set_wait(Frinv, J + 1);
+            set_wait(Ftrail, nwk * J);
+            for (int Jp = J + 2 + (wave - 1); Jp < KT; Jp += nwk) panel_tile(L, KT, J, Jp, l16, kk);      // (J, J + 1) is wave 0's
+            set_signal(Fpanel);
+            set_wait(Fpanel, (nwk + 1) * (J + 1));
+            const int rem = KT - J - 1, ntr = rem * (rem + 1) / 2;
+            for (int t = wave; t < ntr; t += nwk) {               // tiles 1 .. ntr-1 over the workers (tile 0 = (J+1, J+1) is wave 0's)
+                int tt = t, Ir = 0;
+                while (tt >= rem - Ir) { tt -= rem - Ir; ++Ir; }
+                const int I = J + 1 + Ir, Kc = I + tt;
+                qpc::tile_update(L.B + (size_t)qpc::tile_index(I, Kc, KT) * TSZ, L.B + (size_t)qpc::tile_index(J, I, KT) * TSZ,
+                                 L.B + (size_t)qpc::tile_index(J, Kc, KT) * TSZ, l16, kk);
+            }
+            set_signal(Ftrail);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ K^-1 v with the factor in unit-block-diagonal form
 // qpc::k_solve substitutes through the 2 KT block rows on one wave with a diagonal solve, two LDS round trips and four
 // ds_bpermute sums per block row (23 k clocks per right-hand side, two or three per factorisation).  Here the factor is
@@ -583,42 +713,76 @@ __device__ __forceinline__ void k_solve_unit(const QPDims &d, Lds &L, lptr v) {
     else k_solve_unit_impl<0>(d, L, v);
 }
 
-// Newton direction (qpc::newton_solve with the products from the packed store)
-template <int MSEL>
-__device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
-    const int nm = d.N * d.m, ldG = 16 * d.KT, tid = threadIdx.x, nt = blockDim.x;
+// Newton direction (qpc::newton_solve with the products from the packed store), in two halves:
+//   front (needs the gradients, D, Ls and the scaling ks of K -- NOT the factor): t = -D^-1 (g_u + G^T g_y), the reduced dual
+//          residual max |g_ud + G^T g_yd| when gyd != null (into L.Qu[0]), yc = ks Ls^T G t;  runs on any wave set
+//   back  (needs the factor): v = K^-1 yc, du = t - D^-1 G^T Ls ks v, dy = G du
+template <int MSEL, bool HALF>
+__device__ __forceinline__ void newton_front(const QPDims &d, const GPack &g, Lds &L, clptr gyd, Waves<HALF> &W, Prof &pf) {
+    const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = W.tid, nt = W.nt;
     QC_SUB(pf, 8);
-    gT_times<MSEL>(d, g, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr);
+    gT_times<MSEL, HALF>(d, g, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr, W);
     QC_SUB(pf, 9);
     if (gyd) {
         double r = 0.0;
         for (int e = tid; e < nm; e += nt) r = fmax(r, fabs(L.tb[e] + L.tc[e]));
-        *rd = wg::reduce(r, 1, L.red);
+        r = wg::wave_max(r);
+        if ((tid & 63) == 0) L.red[W.wave] = r;
     }
-    for (int e = tid; e < nm; e += nt) L.ta[e] = -(L.ta[e] + L.du[e]);
-    __syncthreads();
-    qpc::dinv_apply(d, L, L.ta);
+    for (int e = tid; e < nm; e += nt) { const double sd = L.Ldi[e]; L.ta[e] = -(L.ta[e] + L.du[e]) * (sd * sd); }       // t = -D^-1 g (diagonal D)
+    W.sync();
+    if (gyd && tid == 0) { double r = L.red[0]; for (int i = 1; i < W.nw; ++i) r = fmax(r, L.red[i]); L.Qu[0] = r; }
     QC_SUB(pf, 10);
-    g_times<MSEL>(d, g, L, L.ta, L.yb);
+    g_times<MSEL, HALF>(d, g, L, L.ta, L.yb, W);
     QC_SUB(pf, 11);
-    qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc);
-    for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
-    __syncthreads();
+    // yc = ks (Ls^T yb) per output stage (p_o = 2, Ls lower: out_0 = L00 v0 + L10 v1, out_1 = L11 v1); padding zeroed
+    for (int k = tid; k < ldG / 2; k += nt) {
+        double o0 = 0.0, o1 = 0.0;
+        if (k < N) {
+            clptr Lk = L.Ls + (size_t)k * 4;
+            const double v0 = L.yb[2 * k], v1 = L.yb[2 * k + 1];
+            o0 = fma(Lk[2], v1, Lk[0] * v0) * L.ks[2 * k];
+            o1 = Lk[3] * v1 * L.ks[2 * k + 1];
+        }
+        L.yc[2 * k] = o0; L.yc[2 * k + 1] = o1;
+    }
+    W.sync();
+}
+
+template <int MSEL>
+__device__ __forceinline__ void newton_back(const QPDims &d, const GPack &g, Lds &L, Prof &pf) {
+    const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = threadIdx.x, nt = blockDim.x;
     k_solve_unit(d, L, L.yc);
-    for (int e = tid; e < ldG; e += nt) L.yc[e] *= L.ks[e];
+    // yd = Ls (ks v) per output stage: out_0 = L00 v0, out_1 = L10 v0 + L11 v1
+    for (int k = tid; k < ldG / 2; k += nt) {
+        double o0 = 0.0, o1 = 0.0;
+        if (k < N) {
+            clptr Lk = L.Ls + (size_t)k * 4;
+            const double v0 = L.yc[2 * k] * L.ks[2 * k], v1 = L.yc[2 * k + 1] * L.ks[2 * k + 1];
+            o0 = Lk[0] * v0;
+            o1 = fma(Lk[3], v1, Lk[2] * v0);
+        }
+        L.yd[2 * k] = o0; L.yd[2 * k + 1] = o1;
+    }
     __syncthreads();
     QC_SUB(pf, 12);
-    qpc::ls_apply<qpc::LS_FWD>(d, L, L.yc, L.yd);
     gT_times<MSEL>(d, g, L, L.yd, (clptr) nullptr, L.du, (lptr) nullptr);
     QC_SUB(pf, 13);
-    qpc::dinv_apply(d, L, L.du);
-    for (int e = tid; e < nm; e += nt) L.du[e] = L.ta[e] - L.du[e];
+    for (int e = tid; e < nm; e += nt) { const double sd = L.Ldi[e]; L.du[e] = L.ta[e] - L.du[e] * (sd * sd); }
     __syncthreads();
     QC_SUB(pf, 14);
     g_times<MSEL>(d, g, L, L.du, L.dy);
     QC_SUB(pf, 15);
 }
 
+// the whole solve on the whole workgroup (the general-row interior point; corrector solves)
+template <int MSEL>
+__device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
+    auto W = all_waves();
+    newton_front<MSEL, false>(d, g, L, gyd, W, pf);
+    if (gyd) *rd = L.Qu[0];
+    newton_back<MSEL>(d, g, L, pf);
+}
 
 // ------------------------------------------------------------------ the QP without its trust-region rows
 // Results: w.u, and -- after the final rollout of solve_qp below -- w.x.  Returns 0 optimal, 1 max iterations, 2 numerical failure.
@@ -904,6 +1068,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     for (int e = tid; e < ldG + YPAD; e += nt) { L.ya[e] = 0.0; L.yd[e] = 0.0; L.yg[e] = 0.0; }     // padding stays zero for good
     for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
     for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+    if (tid < 4) L.flag[4 + tid] = 0;                          // counters of the two wave sets (Waves, tile_cholesky_set)
     __syncthreads();
     bool reuse = false;
     if (dyn.idx != nullptr) {
@@ -1039,14 +1204,47 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
             QB_LAP(3);
             gram<MSEL>(d, c, g, L);
             QB_LAP(4);
-            ok = qpc::tile_cholesky(d, L);
+            // the factorisation (waves 0-3: a chain of one-wave 16 x 16 factorisations) beside the half of the Newton solve that
+            // does not need the factor (waves 4-7), see Waves
+            const clptr gyd = mode == PRED ? (clptr)L.yg : (clptr) nullptr;
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SRH_PROFILE
+            pf.last = clock64();
+#endif
+#ifdef SRH_PROFILE
+            const long long tsplit = clock64();
+#endif
+            auto W = half_waves(L.flag + 4);
+            if (half_of_wave(wv) == 0) {
+                tile_cholesky_set(d, L, W, L.flag + 5);
+#ifdef SRH_PROFILE
+                if (tid == 0) L.Qu[2] = (double)(clock64() - tsplit);
+#endif
+            } else {
+                newton_front<MSEL, true>(d, g, L, gyd, W, pf);
+#ifdef SRH_PROFILE
+                if (W.tid == 0) L.Qu[3] = (double)(clock64() - tsplit);
+#endif
+            }
+            __syncthreads();
+#ifdef SRH_PROFILE
+            prof[16] += (long long)L.Qu[2]; prof[17] += (long long)L.Qu[3];
+#endif
+            ok = L.flag[1] != 0;
+            if (tid < 4) L.flag[4 + tid] = 0;                  // the product half's arrival counter and the factorising half's three, for the next split
+            if (gyd) rd = L.Qu[0];
             if (ok) unit_tiles(d, L);
             QB_LAP(5);
-        }
 #ifdef SRH_PROFILE
-        pf.last = clock64();
+            pf.last = clock64();
 #endif
-        if (ok) newton_solve<MSEL>(d, g, L, mode == PRED ? (clptr)L.yg : (clptr) nullptr, &rd, pf);
+            if (ok) newton_back<MSEL>(d, g, L, pf);
+        } else {
+#ifdef SRH_PROFILE
+            pf.last = clock64();
+#endif
+            newton_solve<MSEL>(d, g, L, (clptr) nullptr, &rd, pf);
+        }
         QB_LAP(6);
         // ---------------- use the direction
         if (mode == INIT) {

@@ -135,3 +135,26 @@ def test_lean_fixed_layout_equals_runtime_layout_at_c2(monkeypatch):
     assert (res['fixed'][1] == res['runtime'][1]).all() and (res['fixed'][2] == res['runtime'][2]).all()
     assert (res['fixed'][3] == res['runtime'][3]).all()
     assert rel(res['fixed'][4], res['runtime'][4]) <= 1e-9 and rel(res['fixed'][5], res['runtime'][5]) <= 1e-9
+
+
+@pytest.mark.parametrize('N,dt,with_X,cap,lean', [(5, 0.05, True, 500, (4, 60, 4, 0, 0, 0)), (3, 0.1, False, 5, (4, 60, 0, 0, 0, 0)),
+                                                   (200, 0.05, False, 500, None)])
+def test_reference_driver_horizons_match_oracle(N, dt, with_X, cap, lean):
+    """The horizons the reference's own Diamond drivers solve (bench.py: secondary.scp_reference_horizons): N = 5 / dt = 0.05 with
+    the X box (examples/diamond/diamond.py:309-316), N = 3 / dt = 0.1 capped at 5 SCP iterations (examples/hardware/diamond.py:
+    393-399; no state rows: the general-row lean kernel <4, 60, 0, 0, 0, 0>) -- run-time-horizon lean kernels -- and the open-loop N = 200 (examples/hardware/diamond.py:471-474): N p_o = 400
+    outputs exceed the condensed path's 128, the stage-wise Riccati kernel answers.  Against oracle.gusto at that N."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2(N=N, dt=dt, with_X=with_X)
+    B = 2 if N == 200 else 4
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, B, 2, 1354)
+    X = Polyhedron(w['XA'], w['Xb']) if with_X else None
+    g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=X, x_char=xc, f_char=fc,
+              convg_thresh=1e-3, batch=B, max_trace=512, max_gusto_iters=cap)
+    info = g.kernel_info
+    assert info['family'] == ('lean' if lean else 'fused') and info['lean'] == lean, info
+    g.solve_batch(x0, u_init, x_init, z=z)
+    for b in range(B if N < 200 else 1):
+        compare(g, b, oracle_solve(w, xc, fc, x0[b], u_init[b], x_init[b], z[b], cap), 'N = %d' % N)

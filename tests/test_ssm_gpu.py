@@ -150,7 +150,13 @@ def test_ilqr_ssm_golden(golden, tag):
 
 def test_ilqr_ssm_c3_shape_batched():
     """BASELINE config C3 exactly as bench.py times it (workloads.ssm_c3: SSM r = 10, n_u = 8, horizon 100, dt = 0.05,
-    backward Euler -- the in-kernel LDS Gauss-Jordan branch), the first problems of the bench's batch, vs the oracle loop."""
+    backward Euler -- the in-kernel LDS Gauss-Jordan branch), the first problems of the bench's batch, vs the oracle loop:
+    identical iteration counts, costs to 1e-5 relative.  Trajectories: this configuration is ill conditioned IN THE REFERENCE
+    ALGORITHM -- a relative perturbation of 1e-14 of x0 moves the oracle's own result by 1e-6 .. 1e-5 in x, up to 7e-5 in u and
+    1e-3 in the gains (the un-symmetrised Riccati recursion of ilqr.py:219-300 over 100 backward-Euler stages amplifies rounding
+    by ~1e10; at dt = 0.01 / forward Euler, `test_ilqr_ssm_fe_small_step_exact`, device and oracle agree to 1e-15).  The
+    tolerance is therefore MEASURED here: ten times what that perturbation does to the oracle, and never above the 1e-4 of
+    the north star for the state trajectory."""
     import workloads as wl
     from oracle import lqr as olqr
     from sofacontrol_amd.lqr.ilqr import iLQR
@@ -167,12 +173,45 @@ def test_ilqr_ssm_c3_shape_batched():
     il = iLQR(dt, s, QuadraticCost(Q=Qz, R=R, Qf=c3['Qf']), N)
     il.set_target(zt)
     x, u, K = il.ilqr_computation(x0)
-    for b in range(Bn):
+
+    def oracle(xs, b):
         o = olqr.ILQRGeneric(lambda xx, uu: ossm.jacobians(model, xx, uu, dt, discr),
                              lambda xx: ossm.observe(model, xx) + model['z_ref'], s.H, n, m, Qz, R, c3['Qf'], N)
-        xo, uo, Ko = o.solve(x0[b], zt[b])
+        xo, uo, Ko = o.solve(xs, zt[b])
+        return xo, uo, o
+    for b in range(Bn):
+        xo, uo, o = oracle(x0[b], b)
+        xp, up, _ = oracle(x0[b] * (1.0 + 1e-14), b)
+        sx, su = np.abs(xo - xp).max(), np.abs(uo - up).max()
         assert int(il.iters[b]) == len(o.trace) - 1
-        close(x[b], xo, 1e-8); close(u[b], uo, 1e-7)
+        assert abs(float(il.cost[b]) - o.trace[-1][1]) <= 1e-5 * abs(o.trace[-1][1])
+        ex, eu = np.abs(x[b] - xo).max(), np.abs(u[b] - uo).max()
+        assert ex <= max(1e-8, 10.0 * sx) and ex <= 1e-4 * np.abs(xo).max(), (b, ex, sx)
+        assert eu <= max(1e-7, 10.0 * su), (b, eu, su)
+
+
+def test_ilqr_ssm_fe_small_step_exact():
+    """The same C3 problems at dt = 0.01 with forward Euler (a well conditioned recursion): device and oracle agree to
+    rounding -- what separates them at the bench's dt = 0.05 / backward Euler is conditioning, not the kernel."""
+    import workloads as wl
+    from oracle import lqr as olqr
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    c3 = wl.ssm_c3(256)
+    n, m, N, dt = c3['n'], c3['m'], c3['N'], 0.01
+    model = ossm.synthetic(n, m, 3, 2, seed=95)
+    for discr in ('fe', 'be'):
+        s = product_ssm(model, discr=discr)
+        s.H = model['W'][:, :n].copy()
+        il = iLQR(dt, s, QuadraticCost(Q=c3['Qz'], R=c3['R'], Qf=c3['Qf']), N)
+        il.set_target(c3['zt'][:2])
+        x, u, K = il.ilqr_computation(c3['x0'][:2])
+        for b in range(2):
+            o = olqr.ILQRGeneric(lambda xx, uu: ossm.jacobians(model, xx, uu, dt, discr),
+                                 lambda xx: ossm.observe(model, xx) + model['z_ref'], s.H, n, m, c3['Qz'], c3['R'], c3['Qf'], N)
+            xo, uo, Ko = o.solve(c3['x0'][b], c3['zt'][b])
+            assert int(il.iters[b]) == len(o.trace) - 1
+            close(x[b], xo, 1e-10); close(u[b], uo, 1e-9)
 
 
 @pytest.mark.parametrize('tag', ['discrete', 'be', 'fe'])

@@ -38,4 +38,9 @@ for mi in (0, 1, 2, 3, 5, 100):
     xo, uo, Ko = o.solve(x0, zt)
     print('max_iter %3d: iters %d / %d cost %.12e / %.12e  dx %.2e du %.2e dK %.2e (|x| %.2e |u| %.2e) alphas %s' %
           (mi, int(il.iters[0]), len(o.trace) - 1, float(il.cost[0]), o.trace[-1][1], np.abs(x - xo).max(), np.abs(u - uo).max(), np.abs(K - Ko).max(),
-           np.abs(xo).max(), np.abs(uo).max(), [t[2] for t in o.trace]))
+           np.abs(xo).max(), np.abs(uo).max(), [t[2] for t in o.trace][:6]))
+    if mi == 0:
+        dKt = np.abs(K - Ko).reshape(N, -1).max(axis=1)
+        print('   dK per stage (last 6):', dKt[-6:], ' first 3:', dKt[:3], ' |K| last', np.abs(Ko[-1]).max())
+        dxt = np.abs(x - xo).max(axis=1)
+        print('   dx per stage first 4:', dxt[:4], 'du first 3', np.abs(u - uo).max(axis=1)[:3])

@@ -2,6 +2,7 @@
 // at the C2 (n_u = 4) or C5 (n_u = 8) shape: shader clocks per call, averaged over REPS calls.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I soft-robot-control_amd/csrc tools/probes/lean_probe.hip -o gpurun_variants/lean_probe
 #include "scp_host.h"
+#include "gram_chol_pipeline.h"
 #include <cstdio>
 #include <vector>
 #include <random>
@@ -124,6 +125,25 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
             __syncthreads();
         }
     }
+    {   // the pipelined Gram + Cholesky (ql::gram_chol) against the two-phase form (gram, then qpc::tile_cholesky) on the same data
+        double *keep = work + 260000;
+        const int nt_ = d.KT * (d.KT + 1) / 2;
+        ql::gram<PROBE_M>(d, c, g, L);
+        const bool ok1 = qpc::tile_cholesky(d, L);
+        __syncthreads();
+        for (int e = tid; e < nt_ * ql::TSZ; e += nt) keep[e] = L.B[e];
+        for (int e = tid; e < d.KT * ql::TSZ; e += nt) keep[nt_ * ql::TSZ + e] = L.Rinv[e];
+        for (int e = tid; e < ldG; e += nt) keep[(nt_ + d.KT) * ql::TSZ + e] = L.ks[e];
+        __syncthreads();
+        const bool ok2 = ql::gram_chol<PROBE_M>(d, g, L);
+        double e5 = 0.0, e6 = 0.0, e7 = 0.0;
+        for (int e = tid; e < nt_ * ql::TSZ; e += nt) { const int rr = (e % ql::TSZ) / ql::TS, cc = (e % ql::TSZ) % ql::TS; if (cc < 16 && rr < 16) e5 = fmax(e5, fabs(keep[e] - L.B[e])); }
+        for (int e = tid; e < d.KT * ql::TSZ; e += nt) { const int cc = (e % ql::TSZ) % ql::TS; if (cc < 16) e6 = fmax(e6, fabs(keep[nt_ * ql::TSZ + e] - L.Rinv[e])); }
+        for (int e = tid; e < ldG; e += nt) e7 = fmax(e7, fabs(keep[(nt_ + d.KT) * ql::TSZ + e] - L.ks[e]));
+        e5 = wg::reduce(e5, 1, L.red); e6 = wg::reduce(e6, 1, L.red); e7 = wg::reduce(e7, 1, L.red);
+        if (tid == 0) { ((double *)out)[37] = e5; ((double *)out)[38] = e6; ((double *)out)[39] = e7; ((double *)out)[40] = (ok1 ? 1.0 : 0.0) + (ok2 ? 2.0 : 0.0); }
+        __syncthreads();
+    }
     long long t0, t1;
     int slot = 0;
 #define TIME(...)                                                      \
@@ -160,6 +180,35 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
     TIME(qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc));                                         // 10
     { double v = tid; TIME(v = wg::reduce(v, 1, L.red)); if (v < 0) out[63] = 1; }           // 11
     TIME(__syncthreads());                                                                     // 12
+    TIME(ql::gram_chol<PROBE_M>(d, g, L));                                                        // 13
+    TIME(ql::gram<PROBE_M>(d, c, g, L); qpc::tile_cholesky(d, L));                                // 14
+    TIME(ql::unit_tiles(d, L));                                                                   // 15
+    TIME(ql::k_solve_unit(d, L, L.yc));                                                           // 16
+    // the factorisation on one SIMD half of the workgroup (counters in LDS, no set-wide barrier) while the other half waits; checked
+    // against qpc::tile_cholesky on the same tiles
+    {
+        double *keep = work + 260000;
+        const int nt_ = d.KT * (d.KT + 1) / 2;
+        fillK(); qpc::tile_cholesky(d, L); __syncthreads();
+        for (int e = tid; e < nt_ * ql::TSZ; e += nt) keep[e] = L.B[e];
+        for (int e = tid; e < d.KT * ql::TSZ; e += nt) keep[nt_ * ql::TSZ + e] = L.Rinv[e];
+        __syncthreads();
+        long long tc = 0;
+        for (int r = 0; r < REPS; ++r) {
+            fillK(); if (tid < 4) L.flag[4 + tid] = 0; __syncthreads(); t0 = clock64(); auto W = ql::half_waves(L.flag + 4);
+            if (ql::half_of_wave(tid >> 6) == 0) ql::tile_cholesky_set(d, L, W, L.flag + 5);
+            __syncthreads(); tc += clock64() - t0;
+        }
+        if (tid == 0) out[17] = tc / REPS;
+        double e5 = 0.0;
+        for (int e = tid; e < nt_ * ql::TSZ; e += nt) { const int cc = (e % ql::TSZ) % ql::TS; if (cc < 16) e5 = fmax(e5, fabs(keep[e] - L.B[e])); }
+        for (int e = tid; e < d.KT * ql::TSZ; e += nt) { const int cc = (e % ql::TSZ) % ql::TS; if (cc < 16) e5 = fmax(e5, fabs(keep[nt_ * ql::TSZ + e] - L.Rinv[e])); }
+        e5 = wg::reduce(e5, 1, L.red);
+        if (tid == 0) ((double *)out)[41] = e5;
+    }
+    { long long tc = 0; for (int r = 0; r < REPS; ++r) { if (tid < 4) L.flag[4 + tid] = 0; __syncthreads(); t0 = clock64(); auto W = ql::half_waves(L.flag + 4);
+        if (ql::half_of_wave(tid >> 6) == 1) { for (int q = 0; q < 16; ++q) W.sync(); } __syncthreads(); tc += clock64() - t0; }
+      if (tid == 0) out[18] = tc / REPS / 16; }
 }
 
 int main() {
@@ -211,9 +260,12 @@ int main() {
     long long out[64];
     hipMemcpy(out, dout, sizeof(out), hipMemcpyDeviceToHost);
     const char *names[] = {"g_times", "gT_times(1)", "gT_times(2)", "gram", "tile_cholesky", "k_solve", "stage_factors", "rollout", "condense",
-                           "dinv_apply", "ls_apply", "wg::reduce", "barrier"};
-    for (int i = 0; i < 13; ++i) printf("%-14s %8lld clocks\n", names[i], out[i]);
+                           "dinv_apply", "ls_apply", "wg::reduce", "barrier", "gram_chol", "gram+cholesky", "unit_tiles", "k_solve_unit", "chol 4 waves", "set sync (4 w)"};
+    for (int i = 0; i < 19; ++i) printf("%-14s %8lld clocks\n", names[i], out[i]);
     printf("self-check: g_times %.2e gT_times %.2e gram %.2e rollout %.2e condense %.2e\n", ((double *)out)[32], ((double *)out)[33], ((double *)out)[34], ((double *)out)[35], ((double *)out)[36]);
     printf("chol16 (one wave) %lld, tile_update (one wave) %lld\n", out[20], out[21]);
+    printf("tile_cholesky_set (4 waves, LDS counters) vs qpc::tile_cholesky: max |d| %.2e\n", ((double *)out)[41]);
+    printf("gram_chol vs gram + tile_cholesky: max |dR| %.2e max |dRinv| %.2e max |dks| %.2e ok flags %.0f (3 = both)\n", ((double *)out)[37], ((double *)out)[38],
+           ((double *)out)[39], ((double *)out)[40]);
     return 0;
 }
