@@ -290,6 +290,15 @@ typedef struct silqr_params {
     double alpha0, alpha_scaling, improv_lb, improv_ub, alpha_min;   /* config.py:13-17 */
     int    counter_limit;     /* config.py:19  5   */
     double rho0, drho0, rho_scaling, rho_increase_fp, rho_max, rho_min;  /* config.py:25-30 */
+    /* the four switches of config.py:6-9, 31 (all 1 in the reference's configuration):
+     *   include_input_var_constraint  1: the input term of the cost is (u_t - u_{t-1})' R (u_t - u_{t-1}) (u_{-1} = u_last),
+     *                                 0: u_t' R u_t                                          (ilqr.py:145-152, 250-256)
+     *   do_linesearch                 0: the first forward pass (alpha0) is always accepted     (ilqr.py:75-88)
+     *   regularize                    0: Q~_uu = Q_uu, Q~_ux = Q_ux; a Q_uu that is not positive definite ends the solve with
+     *                                    iters = -1 (the reference prints a warning and goes on with the inverse of an
+     *                                    indefinite matrix, ilqr.py:276-287)
+     *   state_regularization          0: Q~_uu = Q_uu + rho I, Q~_ux = Q_ux                    (ilqr.py:264-270) */
+    int    include_input_var_constraint, do_linesearch, regularize, state_regularization;
 } silqr_params;
 void silqr_default_params(silqr_params *p);
 

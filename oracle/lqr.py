@@ -62,11 +62,15 @@ class ILQRParams:
     rho_increase_fp = 10.
     rho_max = 1e5
     rho_min = 1e-3
+    include_input_var_constraint = True        # config.py:6
+    do_linesearch = True                       # config.py:8
+    regularize = True                          # config.py:9
+    state_regularization = True                # config.py:31
 
 
 class ILQR:
-    """sofacontrol/lqr/ilqr.py:6-300 (include_input_var_constraint, do_linesearch, regularize and
-    state_regularization all True as in config.py) on a prediscretised nn-TPWL model."""
+    """sofacontrol/lqr/ilqr.py:6-300 on a prediscretised nn-TPWL model; the four switches of config.py (input-variation cost,
+    line search, regularisation, state / input regularisation) live in `self.p` (an instance copy of ILQRParams)."""
 
     def __init__(self, model, Ad, Bd, dd, H, z_ref, Q, R, Qf, N):
         self.model, self.Ad, self.Bd, self.dd = model, Ad, Bd, dd
@@ -105,7 +109,10 @@ class ILQR:
         cost = 0.
         for t in range(N):
             u[t] = u_prev[t] + alpha * k[t] + K[t] @ (x[t] - x_prev[t])
-            cost += self._cost_terms(x[t], u[t], t, self.u_last if t == 0 else u[t - 1])
+            if self.p.include_input_var_constraint:
+                cost += self._cost_terms(x[t], u[t], t, self.u_last if t == 0 else u[t - 1])
+            else:
+                cost += self._cost_terms(x[t], u[t], t, np.zeros(m))                 # ilqr.py:150-152: u' R u
             A[t], B[t], d[t] = self._lin(x[t], u[t])
             x[t + 1] = A[t] @ x[t] + B[t] @ u[t] + d[t]
         zN = self._z(x[-1])
@@ -140,7 +147,7 @@ class ILQR:
             P = H.T @ self.Qf @ H
             restart = False
             for t in reversed(range(N)):
-                u_prev = self.u_last if t == 0 else u[t - 1]
+                u_prev = (self.u_last if t == 0 else u[t - 1]) if self.p.include_input_var_constraint else np.zeros(m)
                 z = self._z(x[t])
                 c_xx = H.T @ self.Q @ H
                 c_x = H.T @ self.Q @ (z - self.z_target[t])
@@ -151,15 +158,24 @@ class ILQR:
                 Q_xx = c_xx + A[t].T @ P @ A[t]
                 Q_uu[t] = c_uu + B[t].T @ P @ B[t]
                 Q_ux = B[t].T @ P @ A[t]
-                Preg = P + self.rho * np.eye(n)
-                Q_uu_t = c_uu + B[t].T @ Preg @ B[t]
-                Q_ux_t = B[t].T @ Preg @ A[t]
+                if self.p.regularize and self.p.state_regularization:
+                    Preg = P + self.rho * np.eye(n)
+                    Q_uu_t = c_uu + B[t].T @ Preg @ B[t]
+                    Q_ux_t = B[t].T @ Preg @ A[t]
+                elif self.p.regularize:                                                # ilqr.py:268-270
+                    Q_uu_t = Q_uu[t] + self.rho * np.eye(m)
+                    Q_ux_t = Q_ux
+                else:                                                                  # ilqr.py:272-274
+                    Q_uu_t = Q_uu[t]
+                    Q_ux_t = Q_ux
                 try:
                     np.linalg.cholesky(Q_uu_t)
                 except np.linalg.LinAlgError:
-                    self.update_regularization(increase=True)
-                    restart = True
-                    break
+                    if self.p.regularize:
+                        self.update_regularization(increase=True)
+                        restart = True
+                        break
+                    # (the reference goes on with the inverse of the indefinite matrix, ilqr.py:283-289; so does this statement)
                 inv = np.linalg.inv(Q_uu_t)
                 K[t] = -inv @ Q_ux_t
                 k[t] = -inv @ Q_u[t]
@@ -196,7 +212,7 @@ class ILQR:
                 for t in range(self.N):
                     dcost += alpha * k[t] @ Q_u[t] + alpha ** 2 * .5 * k[t] @ Q_uu[t] @ k[t]
                 ratio = (ct - prev_cost) / dcost
-                if ratio <= p.improv_lb or ratio > p.improv_ub:
+                if p.do_linesearch and (ratio <= p.improv_lb or ratio > p.improv_ub):
                     alpha = p.alpha_scaling * alpha
                     improved = False
                     if alpha < p.alpha_min:

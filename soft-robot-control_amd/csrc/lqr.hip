@@ -543,6 +543,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
             }
             if (tid < 64) {          // step cost (ilqr.py:168-176): the terms of both quadratic forms over the lanes of wave 0
                 auto dui = [&](int r) {
+                    if (!P_.include_input_var_constraint) return (double)L.u1[r];            // u' R u (ilqr.py:150-152)
                     return L.u1[r] - (t == 0 ? (a.u_last ? a.u_last[p * m + r] : 0.0) : uo[(size_t)(t - 1) * m + r]);
                 };
                 double c = 0.0;
@@ -616,6 +617,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     // backward pass (ilqr.py:219-300) on the trajectory (X, U, idx); writes K2? no: Kout, kff, Qu, Quu
     auto backward = [&]() {
         while (true) {
+            const double rho_b = P_.regularize ? rho : 0.0;            // config.py:9 / ilqr.py:264-274
+            const bool sreg = P_.state_regularization != 0;            // config.py:31: rho (B'B, B'A) or rho I
             // terminal: p = H^T Qf (z - z*), P = H^T Qf H
             for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)N * n + e];
             __syncthreads();
@@ -653,7 +656,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     const int r = tid - 64;
                     double v = 0.0;
                     for (int s = 0; s < m; ++s) {
-                        const double du = U[(size_t)t * m + s] - (t == 0 ? (a.u_last ? a.u_last[p * m + s] : 0.0) : U[(size_t)(t - 1) * m + s]);
+                        const double du = U[(size_t)t * m + s] - (!P_.include_input_var_constraint ? 0.0 :
+                                          (t == 0 ? (a.u_last ? a.u_last[p * m + s] : 0.0) : U[(size_t)(t - 1) * m + s]));
                         v = fma(Rg[r * m + s], du, v);
                     }
                     L.u1[r] = v;        // c_u
@@ -667,14 +671,14 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     double v = Rg[e], bb = 0.0;
                     for (int k = 0; k < n; ++k) { v = fma(Bt[k * m + r], L.PB[k * m + c], v); bb = fma(Bt[k * m + r], Bt[k * m + c], bb); }
                     Quu[(size_t)t * m * m + e] = v;
-                    L.Quu[e] = v + rho * bb;
+                    L.Quu[e] = v + (sreg ? rho_b * bb : (r == c ? rho_b : 0.0));
                 }
                 for (int e = tid; e < m * n; e += nt) {
                     const int r = e / n, c = e - r * n;
                     double v = 0.0, ba = 0.0;
                     for (int k = 0; k < n; ++k) { v = fma(Bt[k * m + r], L.W[k * n + c], v); ba = fma(Bt[k * m + r], At[k * n + c], ba); }
                     L.Kt[e] = v;                      // Q_ux
-                    L.BK[e] = v + rho * ba;           // Q~_ux
+                    L.BK[e] = v + (sreg ? rho_b * ba : 0.0);           // Q~_ux
                 }
                 // Q_x = c_x + A'p ; Q_u = c_u + B'p
                 for (int e = tid; e < n + m; e += nt) {
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 }
                 if (!ok) { restart = true; break; }
             }
-            if (restart) { if (++restarts > MAX_RESTARTS) { diverged = true; break; } continue; }
+            if (restart) { if (!P_.regularize || ++restarts > MAX_RESTARTS) { diverged = true; break; } continue; }
             reg_update(false);
             break;
         }
@@ -785,6 +789,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     // give Q_xx - c_xx, Q_ux, Q_uu - R and the rho-regularised variants; the rank-n_u corrections of P stay VALU.
     auto backward_m = [&]() {
         while (true) {
+            const double rho_b = P_.regularize ? rho : 0.0;            // config.py:9 / ilqr.py:264-274
+            const bool sreg = P_.state_regularization != 0;            // config.py:31: rho (B'B, B'A) or rho I
             for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)N * n + e];
             for (int e = tid; e < prow * ldp; e += nt) Pm[e] = 0.0;
             if (!abg) for (int e = tid; e < NPa * ldp; e += nt) ABm[e] = 0.0;
@@ -850,7 +856,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     const int r = tid - 64;
                     double v = 0.0;
                     for (int s = 0; s < m; ++s) {
-                        const double du = U[(size_t)t * m + s] - (t == 0 ? (a.u_last ? a.u_last[p * m + s] : 0.0) : U[(size_t)(t - 1) * m + s]);
+                        const double du = U[(size_t)t * m + s] - (!P_.include_input_var_constraint ? 0.0 :
+                                          (t == 0 ? (a.u_last ? a.u_last[p * m + s] : 0.0) : U[(size_t)(t - 1) * m + s]));
                         v = fma(Rg[r * m + s], du, v);
                     }
                     L.u1[r] = v;        // c_u
@@ -877,13 +884,13 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     const double v = Rg[e] + Pm[(n + r) * ldp + n + c];
                     Quu[(size_t)t * m * m + e] = v;
                     L.T[e] = v;                       // unregularised Q_uu stays in LDS for the updates below
-                    L.Quu[e] = v + rho * RBm[r * ldp + n + c];
+                    L.Quu[e] = v + (sreg ? rho_b * RBm[r * ldp + n + c] : (r == c ? rho_b : 0.0));
                 }
                 for (int e = tid; e < m * n; e += nt) {
                     const int r = e / n, c = e - r * n;
                     const double v = Pm[(n + r) * ldp + c];
                     L.Kt[e] = v;                      // Q_ux
-                    L.BK[e] = v + rho * RBm[r * ldp + c];
+                    L.BK[e] = v + (sreg ? rho_b * RBm[r * ldp + c] : 0.0);
                 }
                 // Q_x = c_x + A'p ; Q_u = c_u + B'p   (columns of the panel: odd leading dimension, conflict free)
                 for (int e = tid; e < n + m; e += nt) {
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 for (int e = tid; e < n; e += nt) L.v1[e] = L.v3[e];
                 __syncthreads();
             }
-            if (restart) { if (++restarts > MAX_RESTARTS) { diverged = true; break; } continue; }
+            if (restart) { if (!P_.regularize || ++restarts > MAX_RESTARTS) { diverged = true; break; } continue; }
             reg_update(false);
             break;
         }
@@ -1026,7 +1033,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
             }
             dc = wg::reduce(dc, 0, L.red);
             const double ratio = (new_cost - prev_cost) / dc;
-            if (ratio <= P_.improv_lb || ratio > P_.improv_ub) {
+            if (P_.do_linesearch && (ratio <= P_.improv_lb || ratio > P_.improv_ub)) {      // ilqr.py:75: without it alpha0 is taken
                 alpha = P_.alpha_scaling * alpha;
                 improved = false;
                 if (alpha < P_.alpha_min) {
@@ -1073,6 +1080,7 @@ void silqr_default_params(silqr_params *p) {
     p->max_iter = 50; p->epsilon = 0.1; p->alpha0 = 1.0; p->alpha_scaling = 0.5; p->improv_lb = 1e-4;
     p->improv_ub = 100.0; p->alpha_min = 5e-2; p->counter_limit = 5; p->rho0 = 0.0; p->drho0 = 0.0;
     p->rho_scaling = 1.5; p->rho_increase_fp = 10.0; p->rho_max = 1e5; p->rho_min = 1e-3;
+    p->include_input_var_constraint = 1; p->do_linesearch = 1; p->regularize = 1; p->state_regularization = 1;
 }
 
 static int tvlqr_impl(const double *dA, const double *dB, const int *didx, int n_steps, int n, int m, const double *Q,

@@ -55,7 +55,8 @@ class SIlqrParams(C.Structure):
                 ('alpha_scaling', C.c_double), ('improv_lb', C.c_double), ('improv_ub', C.c_double),
                 ('alpha_min', C.c_double), ('counter_limit', C.c_int), ('rho0', C.c_double),
                 ('drho0', C.c_double), ('rho_scaling', C.c_double), ('rho_increase_fp', C.c_double),
-                ('rho_max', C.c_double), ('rho_min', C.c_double)]
+                ('rho_max', C.c_double), ('rho_min', C.c_double), ('include_input_var_constraint', C.c_int),
+                ('do_linesearch', C.c_int), ('regularize', C.c_int), ('state_regularization', C.c_int)]
 
 
 _lib = None

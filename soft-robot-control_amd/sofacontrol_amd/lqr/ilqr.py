@@ -31,11 +31,12 @@ class iLQR:
 
     def _params(self):
         p = self.params
-        if not (p.include_input_var_constraint and p.do_linesearch and p.regularize and p.state_regularization):
-            raise NotImplementedError('the device iLQR implements the reference configuration (config.py:6-31)')
+        # the four switches of config.py:6-9, 31 are kernel parameters (csrc/lqr.hip); regularize = False with a Q_uu that is
+        # not positive definite ends the solve with iters = -1 (the reference goes on with the inverse of an indefinite matrix)
         return _lib.SIlqrParams(p.max_iter, p.epsilon, p.alpha0, p.alpha_scaling, p.improv_lb, float(p.improv_ub),
                                 p.alpha_min, p.counter_limit, p.rho0, p.drho0, p.rho_scaling, p.rho_increase_fp,
-                                p.rho_max, p.rho_min)
+                                p.rho_max, p.rho_min, int(bool(p.include_input_var_constraint)), int(bool(p.do_linesearch)),
+                                int(bool(p.regularize)), int(bool(p.state_regularization)))
 
     def ilqr_computation(self, x0, u_warmstart=None):
         """ilqr.py:27-107; batched when x0 is (B, n_x) (z_target (B, N+1, n_z), u_warmstart (B, N, n_u))."""

@@ -219,6 +219,47 @@ def g4_riccati(out):
     np.savez_compressed(os.path.join(out, 'g4_riccati.npz'), **res)
 
 
+def g20_ilqr_switches(out):
+    """The four switches of lqr/config.py:6-9, 31, one at a time and all together, on the g4 problem (r = 5, n_u = 4, N = 30):
+    what the imported reference iLQR returns with include_input_var_constraint / do_linesearch / regularize /
+    state_regularization = False."""
+    r, m, P = 5, 4, 9
+    model, U, q_ref, v_ref, Hf = make_problem(r, m, P, 30, 20)
+    tp = ref_tpwl(model, U, q_ref, v_ref, Hf)
+    dt, N = 0.05, 30
+    quiet(tp.pre_discretize, dt)
+    rng = np.random.default_rng(77)
+    n = 2 * r
+    Qz = np.diag([0, 0, 0, 100., 100., 0])
+    R = 1e-3 * np.eye(m)
+    cost = rutils.QuadraticCost(Q=Qz, R=R, Qf=10 * Qz)
+    th = np.linspace(0, 2 * np.pi * N / 100., N + 1)
+    zt = np.zeros((N + 1, 6))
+    zt[:, 3] = -2.0 * np.sin(th)
+    zt[:, 4] = 1.0 * np.sin(2 * th)
+    zt = zt + np.asarray(tp.z_ref)
+    x0 = 0.02 * rng.standard_normal(n)
+    uw = rng.uniform(0, 100, (N, m))
+    u_last = rng.uniform(0, 100, m)
+    res = dict(z_target=zt, x0=x0, uw=uw, u_last=u_last, Qz=Qz, R=R, Qf=10 * Qz, dt=dt, N=N)
+    flags = ('include_input_var_constraint', 'do_linesearch', 'regularize', 'state_regularization')
+    cases = {f: {f: False} for f in flags}
+    cases['all_off'] = {f: False for f in flags}
+    cases['reference'] = {}
+    for tag, off in cases.items():
+        for warm in (True, False):
+            il = rilqr.iLQR(dt, tp, cost, N)
+            for f, v in off.items():
+                setattr(il.params, f, v)
+            il.set_target(zt)
+            il.set_u_last(u_last)
+            (xs, us, Ks), log = quiet(il.ilqr_computation, x0, uw if warm else None)
+            key = tag + ('_warm' if warm else '_cold')
+            res[key + '_x'], res[key + '_u'], res[key + '_K'] = xs, us, Ks
+            res[key + '_iters'] = log.count('Iteration')
+    np.savez_compressed(os.path.join(out, 'g20_ilqr_switches.npz'), **res)
+
+
 class InjectedLOCP:
     """Stand-in for sofacontrol.scp.locp.LOCP (cvxpy is absent): same update/solve/get_solution
     protocol (locp.py:98,175,192), QP data from oracle.locp.build_qp, solved exactly."""
@@ -865,7 +906,7 @@ def g19_preprocess(out):
     np.savez_compressed(os.path.join(out, 'g19_preprocess.npz'), **res)
 
 
-GENERATORS = dict(g19_preprocess=g19_preprocess, g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
+GENERATORS = dict(g19_preprocess=g19_preprocess, g20_ilqr_switches=g20_ilqr_switches, g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
                   g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
                   g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers,
                   g16_dubins=g16_dubins, g17_ssm_hardware=g17_ssm_hardware, g18_pod_shipped=g18_pod_shipped)

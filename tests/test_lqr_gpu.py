@@ -67,6 +67,31 @@ def test_ilqr_full_solve(golden, tag, N):
     np.testing.assert_array_equal(xb[0], x); np.testing.assert_array_equal(xb[1], x)
 
 
+@pytest.mark.parametrize('case', ['reference', 'include_input_var_constraint', 'do_linesearch', 'regularize', 'state_regularization', 'all_off'])
+def test_ilqr_config_switches(golden, case):
+    """The four switches of lqr/config.py:6-9, 31 as kernel parameters (silqr_params): golden g20 = the imported reference
+    iLQR with each switch (and all of them) turned off -- same iteration counts, trajectories and gains."""
+    from sofacontrol_amd.lqr.ilqr import iLQR
+    from sofacontrol_amd.utils import QuadraticCost
+    g4, tp = setup(golden)
+    g = golden('g20_ilqr_switches')
+    flags = ('include_input_var_constraint', 'do_linesearch', 'regularize', 'state_regularization')
+    for warm in (True, False):
+        il = iLQR(0.05, tp, QuadraticCost(Q=g['Qz'], R=g['R'], Qf=g['Qf']), int(g['N']))
+        for f in flags:
+            setattr(il.params, f, not (case == f or case == 'all_off'))
+        il.set_target(g['z_target'])
+        il.set_u_last(g['u_last'])
+        x, u, K = il.ilqr_computation(g['x0'], g['uw'] if warm else None)
+        key = case + ('_warm' if warm else '_cold')
+        # all switches off: the problem is solved after ONE full Newton step; the reference's second and third iterations move
+        # the cost by -4e-12 and +3e-12 (5965.533874068984 -> ...988 -> ...985) and its stopping rule `0 <= decrease < epsilon`
+        # (ilqr.py:109-115) waits for the sign of that rounding noise: the count may differ by one, the result may not
+        slack = 1 if case == 'all_off' else 0
+        assert abs(int(il.iters[0]) - int(g[key + '_iters'])) <= slack, (key, int(il.iters[0]), int(g[key + '_iters']))
+        close(x, g[key + '_x'], 1e-6); close(u, g[key + '_u'], 1e-6); close(K, g[key + '_K'], 1e-5)
+
+
 @pytest.mark.parametrize('r,m', [(30, 4), (36, 4)])
 def test_ilqr_diamond_sizes_vs_oracle(r, m):
     """iLQR at the Diamond state sizes (n_x = 60 and the shipped r = 36 basis, n_x = 72) against the oracle loop."""

@@ -166,6 +166,34 @@ def test_ilqr_backward_and_full_solve(golden, tag, N):
     close(us, g[tag + '_sol0_u'], rtol=1e-7)
 
 
+G20_CASES = ['reference', 'include_input_var_constraint', 'do_linesearch', 'regularize', 'state_regularization', 'all_off']
+
+
+def _g20_flags(case):
+    flags = ('include_input_var_constraint', 'do_linesearch', 'regularize', 'state_regularization')
+    return {f: not (case == f or case == 'all_off') for f in flags}
+
+
+@pytest.mark.parametrize('case', G20_CASES)
+def test_ilqr_config_switches(golden, case):
+    """g20: the imported reference iLQR with each switch of lqr/config.py:6-9, 31 turned off (and all of them): the oracle
+    statement follows -- same iteration counts, trajectories and gains."""
+    g4, model, Ad, Bd, dd = _g4_setup(golden)
+    g = golden('g20_ilqr_switches')
+    N = int(g['N'])
+    for warm in (True, False):
+        il = olqr.ILQR(model, Ad, Bd, dd, g4['H'], g4['z_ref'], g['Qz'], g['R'], g['Qf'], N)
+        for f, v in _g20_flags(case).items():
+            setattr(il.p, f, v)
+        il.u_last = g['u_last']
+        xs, us, Ks = il.solve(g['x0'], g['z_target'], g['uw'] if warm else None)
+        key = case + ('_warm' if warm else '_cold')
+        assert len(il.trace) - 1 == int(g[key + '_iters']), (key, len(il.trace) - 1, int(g[key + '_iters']))
+        close(xs, g[key + '_x'], rtol=1e-7)
+        close(us, g[key + '_u'], rtol=1e-7)
+        close(Ks, g[key + '_K'], rtol=1e-6)
+
+
 # ---------------------------------------------------------------- G6: GuSTO
 def _g6_setup(golden):
     g = golden('g6_gusto')

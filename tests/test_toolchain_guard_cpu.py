@@ -80,3 +80,45 @@ def test_shipped_device_assembly_is_clean():
         pytest.skip('library not built here (the assembly is kept next to the objects by the Makefile)')
     for a in asms:
         assert guard.scan(a) == [], a
+        assert guard.audit(a) == [], a          # every spill store has the form the check examines; metadata and comments agree
+
+
+def test_audit_fails_closed_on_spill_code_it_cannot_read(tmp_path):
+    """Spill stores addressed through an SGPR frame register (non-inlined device functions), spilled kernels whose comments
+    are worded differently, and wave32 EXEC handling are NOT what the patterns were written for: the tool must say so and exit
+    non-zero instead of reporting '0 spills'."""
+    framed = HEAD + '\tscratch_store_dword off, v74, s33 offset:536 ; 4-byte Folded Spill\n\ts_or_b64 exec, exec, s[0:1]\n\ts_endpgm\n'
+    assert guard.scan(write(tmp_path, framed)) == [] and len(guard.audit(write(tmp_path, framed))) == 1
+    assert guard.main([write(tmp_path, framed)]) == 1
+    reworded = HEAD + '\tscratch_store_dword off, v74, off offset:536 ; 4-byte spill\n\ts_endpgm\n    .vgpr_spill_count: 3\n'
+    assert any('metadata' in m for m in guard.audit(write(tmp_path, reworded)))
+    w32 = HEAD + '\ts_or_b32 exec_lo, exec_lo, s0\n\ts_endpgm\n'
+    assert any('wave32' in m for m in guard.audit(write(tmp_path, w32)))
+    assert guard.audit(write(tmp_path, BAD)) == [] and guard.audit(write(tmp_path, OWN)) == []
+
+
+def test_scanner_reads_what_the_installed_compiler_emits(tmp_path):
+    """A kernel forced to spill, compiled with the installed hipcc: its assembly must pass the audit (the spill stores have
+    the examined form and carry the 'Folded Spill' comment) -- a compiler update that changes either shows up here."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc here')
+    src = tmp_path / 'spill.hip'
+    src.write_text('''#include <hip/hip_runtime.h>
+__global__ __launch_bounds__(1024) void k(double *p, int n) {
+    double a[96];
+    for (int i = 0; i < 96; ++i) a[i] = p[threadIdx.x + 1024 * i];
+    __syncthreads();
+    for (int r = 0; r < n; ++r) for (int i = 0; i < 96; ++i) a[i] = fma(a[i], a[(i + r) % 96], p[i]);
+    for (int i = 0; i < 96; ++i) p[threadIdx.x + 1024 * i] = a[i];
+}
+''')
+    out = tmp_path / 'spill.s'
+    r = subprocess.run([hipcc, '-O3', '--offload-arch=gfx950', '--cuda-device-only', '-S', str(src), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    assert guard.audit(str(out)) == []
+    if 'Folded Spill' in text:                      # it did spill: the stores must be in the examined form
+        assert any(guard.SPILL.match(l) for l in text.split('\n'))

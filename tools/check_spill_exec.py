@@ -22,7 +22,8 @@ its spill stores behind the widening instruction, i.e. with the lanes already en
 value in every lane there -- nothing between the two writes it, which the tool verifies), followed by the wait states a
 wide store wants before its data registers may be overwritten.  The build (csrc/Makefile) compiles device code to
 assembly, runs this, and assembles the result, so what ships has been through the check.  Usage: check_spill_exec.py [--fix] file.s [...]
-(exit status 1 when something is flagged and not fixed)
+(exit status 1 when something is flagged and not fixed, or when `audit` finds spill code in a form the patterns were not written
+for -- the tool fails closed instead of reporting "0 spills" on assembly it cannot read)
 """
 import re, sys
 
@@ -138,11 +139,46 @@ def fix(path):
     return len(drop), refused
 
 
+ANY_SPILL_STORE = re.compile(r'^\s*(scratch_store|buffer_store|flat_store|global_store)\w*\s.*;.*Folded Spill')
+ANY_SPILL_MARK = re.compile(r';.*Folded (Spill|Reload)')
+META_SPILLS = re.compile(r'^\s*\.vgpr_spill_count:\s*(\d+)')
+WAVE32_EXEC = re.compile(r'^\s*s_\w+_b32\s+exec_lo')
+
+
+def audit(path):
+    """Fail closed: is this still the assembly the patterns above were written for?  -> list of complaints.
+      * every spill STORE the compiler marks ('Folded Spill') must have the one form SPILL recognises (`scratch_store_dword*
+        off, vN, off [offset:]`): stores addressed through an SGPR frame register (non-inlined device functions), buffer
+        stores or a changed operand order would otherwise pass unexamined as "0 spills";
+      * the kernels' own metadata (.vgpr_spill_count) must not report spills in a file without a single 'Folded Spill' /
+        'Folded Reload' comment (a compiler that words the comment differently);
+      * EXEC must be manipulated as a 64-bit register (wave64): an `s_*_b32 exec_lo` restore is not looked for at all."""
+    text = open(path).read().split('\n')
+    any_store = [i for i, l in enumerate(text, 1) if ANY_SPILL_STORE.match(l)]
+    unknown = [i for i in any_store if not SPILL.match(text[i - 1])]
+    marks = sum(1 for l in text if ANY_SPILL_MARK.search(l))
+    meta = sum(int(m.group(1)) for m in (META_SPILLS.match(l) for l in text) if m)
+    out = []
+    if unknown:
+        out.append('%s: %d spill store(s) in a form this tool does not examine (first at line %d: %s)' %
+                   (path, len(unknown), unknown[0], text[unknown[0] - 1].strip()[:120]))
+    if meta > 0 and marks == 0:
+        out.append('%s: the kernel metadata reports %d spilled VGPRs but no instruction carries a "Folded Spill" / "Folded Reload" '
+                   'comment -- the compiler words its spill comments differently, nothing was examined' % (path, meta))
+    w32 = [i for i, l in enumerate(text, 1) if WAVE32_EXEC.match(l)]
+    if w32:
+        out.append('%s: EXEC is handled as a 32-bit register (line %d): wave32 code is not examined' % (path, w32[0]))
+    return out
+
+
 def main(argv):
     do_fix = '--fix' in argv
     argv = [a for a in argv if a != '--fix']
     bad = 0
     for path in argv:
+        for msg in audit(path):
+            bad += 1
+            print(msg)
         if do_fix:
             moved, refused = fix(path)
             if moved or refused:

@@ -50,6 +50,28 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
             e0 = fmax(e0, fabs(sref - L.yb[i]) / (1.0 + fabs(sref)));
         }
         e0 = wg::reduce(e0, 1, L.red);
+        {   // the balanced form against the same naive sums
+            auto Wa = ql::all_waves();
+            ql::g_times_pairs<PROBE_M, false>(d, g, L, L.u, L.yc, Wa);
+            double e0b = 0.0;
+            for (int i = tid; i < ldG; i += nt) {
+                double sref = 0.0;
+                if (i < NP) for (int j = 0; j < N; ++j) for (int b = 0; b < m; ++b) sref += Gat(j, b, i) * L.u[j * m + b];
+                e0b = fmax(e0b, fabs(sref - L.yc[i]) / (1.0 + fabs(sref)));
+            }
+            e0b = wg::reduce(e0b, 1, L.red);
+            if (tid < 2) L.flag[4 + tid] = 0;
+            __syncthreads();
+            auto Wh = ql::half_waves(L.flag + 4);
+            if (ql::half_of_wave(tid >> 6) == 1) ql::g_times_pairs<PROBE_M, true>(d, g, L, L.u, L.yd, Wh);
+            __syncthreads();
+            double e0c = 0.0;
+            for (int i = tid; i < ldG; i += nt) e0c = fmax(e0c, fabs(L.yd[i] - L.yc[i]));
+            e0c = wg::reduce(e0c, 1, L.red);
+            if (tid == 0) { ((double *)out)[42] = e0b; ((double *)out)[43] = e0c; }
+            for (int e = tid; e < ldG + ql::YPAD; e += nt) L.yd[e] = L.ya[e];
+            __syncthreads();
+        }
         ql::gT_times<PROBE_M>(d, g, L, L.ya, L.yg, L.du, L.tc);
         double e1 = 0.0;
         for (int r = tid; r < nm; r += nt) {
@@ -184,6 +206,8 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
     TIME(ql::gram<PROBE_M>(d, c, g, L); qpc::tile_cholesky(d, L));                                // 14
     TIME(ql::unit_tiles(d, L));                                                                   // 15
     TIME(ql::k_solve_unit(d, L, L.yc));                                                           // 16
+    { auto Wa = ql::all_waves(); __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::g_times_pairs<PROBE_M, false>(d, g, L, L.u, L.yb, Wa);
+      __syncthreads(); t1 = clock64(); if (tid == 0) out[19] = (t1 - t0) / REPS; }
     // the factorisation on one SIMD half of the workgroup (counters in LDS, no set-wide barrier) while the other half waits; checked
     // against qpc::tile_cholesky on the same tiles
     {
@@ -264,6 +288,7 @@ int main() {
     for (int i = 0; i < 19; ++i) printf("%-14s %8lld clocks\n", names[i], out[i]);
     printf("self-check: g_times %.2e gT_times %.2e gram %.2e rollout %.2e condense %.2e\n", ((double *)out)[32], ((double *)out)[33], ((double *)out)[34], ((double *)out)[35], ((double *)out)[36]);
     printf("chol16 (one wave) %lld, tile_update (one wave) %lld\n", out[20], out[21]);
+    printf("g_times_pairs: %lld clocks; vs naive sums %.2e, half set vs whole workgroup %.2e\n", out[19], ((double *)out)[42], ((double *)out)[43]);
     printf("tile_cholesky_set (4 waves, LDS counters) vs qpc::tile_cholesky: max |d| %.2e\n", ((double *)out)[41]);
     printf("gram_chol vs gram + tile_cholesky: max |dR| %.2e max |dRinv| %.2e max |dks| %.2e ok flags %.0f (3 = both)\n", ((double *)out)[37], ((double *)out)[38],
            ((double *)out)[39], ((double *)out)[40]);
