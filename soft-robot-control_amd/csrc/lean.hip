@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         double J;
         int qit;
         GU_LAP(1);
-        const int st = ql::solve_qp<MSEL, NSEL, GXSEL>(d, c, dyn, q, base, L, &J, &qit, w, prof);
+        const int st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, base, L, &J, &qit, w, prof);
         GU_LAP(2);
         if (st != 0) {                               // the fused kernel takes this rollout from here
             if (tid == 0) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
              (gptr)((b.dbg && p == 0) ? b.dbg : nullptr)};
     double J = 0.0;
     int it = 0;
-    const int st = ql::solve_qp<MSEL, NSEL, GXSEL>(d, c, dyn, q, wbase, L, &J, &it, w, prof);
+    const int st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, wbase, L, &J, &it, w, prof);
     if (q.dbg && threadIdx.x == 0) {
         q.dbg[8 * 61] = 2.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; q.dbg[8 * 61 + 3] = st == 100 ? 0.0 : 1.0;
 #ifdef SRH_PROFILE

@@ -21,6 +21,12 @@
 #pragma once
 #include "locp_dev.h"
 
+// compile-time loop: f(integral_constant<int, I>) for I = B .. E - 1
+template <int B, int E, class F>
+__device__ __forceinline__ void srh_static_for(F &&f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); srh_static_for<B + 1, E>(f); }
+}
+
 namespace ql {
 
 using qpc::TS;
@@ -91,11 +97,16 @@ __device__ inline void lds_carve(Lds &L, lptr base, const QPDims &d, int nthread
 }
 
 // packed G^T: head rows in the problem's L2 block, the rest in LDS
-struct GPack {
+// NF_ > 0: the horizon and the first LDS-resident stage are compile-time constants of the kernel instantiation (the fixed
+// layouts of lean.hip) -- the products can then address every stage with immediate offsets (g_times_fixed)
+template <int NF_ = 0, int J0F_ = 0>
+struct GPackT {
     cgptr gh;          // rows of the stages j < j0
     clptr gt;          // rows of the stages j >= j0, offset so that gt[goff(j) + ...] addresses stage j
     int j0, m, NP;
+    static constexpr int NF = NF_, J0F = J0F_;
 };
+using GPack = GPackT<0, 0>;
 
 // ------------------------------------------------------------------ wave sets
 // The factorisation of K is a chain of seven one-wave 16 x 16 factorisations with short all-wave phases in between (35 k of
@@ -283,11 +294,76 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
 //     R(j + 1, b) = R(j, b) + m (NP - 2 j) - 2 b - 2
 // -- the loops below walk the stages with two integer additions instead of re-deriving the offsets.
 
+// The same product for a kernel instantiation whose horizon NF and first LDS-resident stage J0F are compile-time constants
+// (same thread mapping as g_times below: thread = (column, input class), partial sums of the classes through LDS).  The
+// stage loop is unrolled completely: element (j, b, i) of the packed store sits at
+//     goff(j) - 2 j  +  (b NP + i)  -  2 j b
+// -- an immediate, a per-lane base, and a term that only needs one subtraction of the wave-uniform 2 b per stage -- so a stage
+// costs an address subtraction, two LDS reads (G and u, the latter at an immediate offset from a per-wave base) and one FMA,
+// plus a select in the triangular part; g_times spends about ten instructions per stage on the same (index arithmetic of
+// the run-time loop, clamps and masks of its eight-stage trips).  Stages in blocks of sixteen; a block no lane of the wave
+// needs is skipped, a block every lane needs whole runs without the selects.  C2: 7.9 k -> 5.5 k clocks, C5: 15.7 k -> 11.6 k.
+template <int MSEL, bool HALF, int NF, int J0F, class GP>
+__device__ __forceinline__ void g_times_fixed(const GP &g, Lds &L, clptr uv, lptr yv, int ldG, Waves<HALF> &W) {
+    constexpr int M = MSEL, CW = 128, NP = 2 * NF;
+    constexpr int BLK = 16;                 // stages per block: 16 + 16 loads in flight (8: 6.2 k clocks at C2, 16: 5.5 k)
+    constexpr int goff0 = M * (J0F * NP - J0F * (J0F - 1));
+    const int tid = W.tid, nt = W.nt;
+    const int GR = nt / CW, col = tid % CW, grp = __builtin_amdgcn_readfirstlane(tid / CW);
+    const int cc = col < NP ? col : NP - 1;
+    const int jlast = col < NP ? cc >> 1 : -1;                        // last stage that reaches this lane's column
+    const int c_lo = col & ~63, c_hi = min(NP - 1, col | 63);
+    const int jall = __builtin_amdgcn_readfirstlane((col | 63) < NP ? c_lo >> 1 : -1);      // every lane of the wave: stages 0 .. jall
+    const int jany = __builtin_amdgcn_readfirstlane(c_lo < NP ? c_hi >> 1 : -1);            // some lane of the wave: stages 0 .. jany
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = grp; b < M; b += GR) {                               // wave-uniform
+        clptr pu = uv + b;
+        // stages [JB, JE) from `pg` (pointing at element (0, b, column) of its store minus SHIFT), MASK: triangular part
+        auto block = [&](auto pg, auto JB_, auto JE_, auto SHIFT_, auto MASK) {
+            constexpr int JB = decltype(JB_)::value, JE = decltype(JE_)::value, SHIFT = decltype(SHIFT_)::value;
+            constexpr bool masked = decltype(MASK)::value;
+            double gv[JE - JB], uu[JE - JB];
+#pragma unroll
+            for (int j = JB; j < JE; ++j) {
+                gv[j - JB] = pg[(M * (j * NP - j * (j - 1)) - 2 * j - SHIFT) - 2 * j * b];
+                uu[j - JB] = pu[j * M];
+            }
+#pragma unroll
+            for (int j = JB; j < JE; ++j) {
+                if constexpr (masked) acc[j & 3] = fma(j <= jlast ? gv[j - JB] : 0.0, uu[j - JB], acc[j & 3]);
+                else acc[j & 3] = fma(gv[j - JB], uu[j - JB], acc[j & 3]);
+            }
+        };
+        auto span = [&](auto pg, auto LO_, auto HI_, auto SHIFT_) {   // compile-time range [LO, HI) in blocks of BLK
+            constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value;
+            srh_static_for<0, (HI - LO + BLK - 1) / BLK>([&](auto K_) {
+                constexpr int JB = LO + decltype(K_)::value * BLK, JE = JB + BLK < HI ? JB + BLK : HI;
+                if (JB <= jany) {                                     // uniform
+                    if (JE - 1 <= jall) block(pg, std::integral_constant<int, JB>{}, std::integral_constant<int, JE>{}, SHIFT_, std::false_type{});
+                    else block(pg, std::integral_constant<int, JB>{}, std::integral_constant<int, JE>{}, SHIFT_, std::true_type{});
+                }
+            });
+        };
+        if constexpr (J0F > 0) span(g.gh + (b * NP + cc), std::integral_constant<int, 0>{}, std::integral_constant<int, (J0F < NF ? J0F : NF)>{}, std::integral_constant<int, 0>{});
+        if constexpr (J0F < NF) span(g.gt + (b * NP + cc), std::integral_constant<int, J0F>{}, std::integral_constant<int, NF>{}, std::integral_constant<int, goff0>{});
+    }
+    lptr part = L.part;
+    part[grp * CW + col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    W.sync();
+    if (tid < ldG) {
+        double s = 0.0;
+        if (tid < NP) for (int q = 0; q < GR; ++q) s += part[q * CW + tid];
+        yv[tid] = s;
+    }
+    W.sync();
+}
+
 // yv[i] = sum_{rows (j,b), 2 j <= i} G^T[(j,b)][i] uv[(j,b)]: thread = (column, input class b mod 4).  Stages j <= jlo (the
 // last stage that reaches EVERY column of the wave) need no mask; lanes read past "their" rows only inside LDS / the L2
 // block (the select discards what they get).  8 loads of G and of u per trip before the FMAs.
-template <int MSEL, bool HALF>
-__device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L, clptr uv, lptr yv, Waves<HALF> &W) {
+template <int MSEL, bool HALF, class GP>
+__device__ __forceinline__ void g_times(const QPDims &d, const GP &g, Lds &L, clptr uv, lptr yv, Waves<HALF> &W) {
+    if constexpr (GP::NF > 0) { g_times_fixed<MSEL, HALF, GP::NF, GP::J0F>(g, L, uv, yv, 16 * d.KT, W); return; }
     constexpr int M = MSEL, CH = 8, CW = 128;
     const int ldG = 16 * d.KT, NP = g.NP, N = d.N, tid = W.tid, nt = W.nt;
     const int GR = nt / CW, col = tid % CW, grp = tid / CW;          // GR = 4
@@ -339,87 +415,18 @@ __device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L,
     }
     W.sync();
 }
-template <int MSEL>
-__device__ __forceinline__ void g_times(const QPDims &d, const GPack &g, Lds &L, clptr uv, lptr yv) {
+template <int MSEL, class GP>
+__device__ __forceinline__ void g_times(const QPDims &d, const GP &g, Lds &L, clptr uv, lptr yv) {
     auto W = all_waves();
     g_times<MSEL, false>(d, g, L, uv, yv, W);
-}
-
-// The same product with the work BALANCED over the lanes.  Column i of G has n_u (i / 2 + 1) entries: in g_times() the lanes
-// of the last columns walk all N stages while the first columns' lanes finish at once, and the four input classes of a
-// column meet through an LDS round trip.  Column i and column NP - 1 - i TOGETHER always have n_u (N + 1) entries: a pair
-// gets 2 n_u lanes -- lane = (input b, stage parity h) -- every lane walks the stages j = h, h + 2, ... of BOTH columns in
-// one loop (the two packed addresses differ by a constant, the u values are shared), ~N / 2 stages instead of N, and the
-// 2 n_u partial sums of a column meet in DPP adds.  Trips of 8 stages; the masks are compiled out of the trips in which
-// every lane of the wave is inside its column (long column) / no lane is (short column).
-template <int MSEL, bool HALF>
-__device__ __forceinline__ void g_times_pairs(const QPDims &d, const GPack &g, Lds &L, clptr uv, lptr yv, Waves<HALF> &W) {
-    constexpr int M = MSEL, LP = 2 * M, CH = 8, WPAIRS = 64 / LP;
-    const int ldG = 16 * d.KT, NP = g.NP, N = d.N, tid = W.tid, nt = W.nt;
-    const int npairs = NP >> 1, PP = nt / LP;
-    const int gl = tid % LP, b = gl % M, h = gl / M;
-    const int goff0 = goff(g.j0, M, NP), nm1 = N * M - 1;
-    for (int q0 = 0; q0 < npairs; q0 += PP) {
-        const int q = q0 + tid / LP;
-        const bool live = q < npairs;
-        const int qc = live ? q : npairs - 1;
-        const int chi = NP - 1 - qc, clo = qc, dc = chi - clo;
-        const int jhi = live ? chi >> 1 : -1, jlo = live ? clo >> 1 : -1;          // this lane's last stage of either column
-        // wave-uniform: the pairs of this wave are wq .. wq + WPAIRS - 1 (clipped)
-        const int wq = __builtin_amdgcn_readfirstlane(q0 + (tid & ~63) / LP);
-        const int wql = min(wq + WPAIRS - 1, npairs - 1);
-        const int jhi_any = wq < npairs ? (NP - 1 - wq) >> 1 : -1;                 // some lane needs stages up to here (long column)
-        const int jhi_all = wq + WPAIRS - 1 < npairs ? (NP - 1 - wql) >> 1 : -1;   // every lane needs stages up to here
-        const int jlo_any = wq < npairs ? wql >> 1 : -1;                           // (short column)
-        double ahi[2] = {0.0, 0.0}, alo[2] = {0.0, 0.0};
-        // stages js, js + 2, ... (js of parity h) up to jend (inclusive, wave-uniform bound) from `src`
-        auto stream = [&](auto src, int jfirst, int jend) {
-            int js = jfirst + ((jfirst ^ h) & 1);                                  // first stage >= jfirst of this lane's parity
-            int R = goff(js, M, NP) + b * (NP - 2 * js) + chi - 2 * js;
-            int dl = M * (2 * NP - 4 * js - 2) - 4 * b - 4;
-            int ui = js * M + b;
-            auto trip = [&](auto HIM, auto LO) {
-                constexpr bool himask = decltype(HIM)::value, lo = decltype(LO)::value;
-                double gh[CH], gq[CH], uu[CH];
-#pragma unroll
-                for (int t = 0; t < CH; ++t) {
-                    gh[t] = src[R];
-                    if constexpr (lo) gq[t] = src[R - dc];
-                    uu[t] = uv[min(ui, nm1)];
-                    R += dl; dl -= 8 * M; ui += 2 * M;
-                }
-#pragma unroll
-                for (int t = 0; t < CH; ++t) {
-                    const int j = js + 2 * t;
-                    if constexpr (himask) ahi[t & 1] = fma((j <= jhi && j <= jend) ? gh[t] : 0.0, uu[t], ahi[t & 1]);
-                    else ahi[t & 1] = fma(gh[t], uu[t], ahi[t & 1]);
-                    if constexpr (lo) alo[t & 1] = fma((j <= jlo && j <= jend) ? gq[t] : 0.0, uu[t], alo[t & 1]);
-                }
-                js += 2 * CH;
-            };
-            for (int jt = jfirst; jt <= jend; jt += 2 * CH) {
-                // the trip covers the stages jt .. jt + 2 CH of either parity
-                const bool full = jt + 2 * CH <= min(jhi_all, jend);               // uniform: no lane leaves its long column
-                const bool lo = jt <= jlo_any;                                     // uniform: some lane is still in its short column
-                if (full) { if (lo) trip(std::false_type{}, std::true_type{}); else trip(std::false_type{}, std::false_type{}); }
-                else { if (lo) trip(std::true_type{}, std::true_type{}); else trip(std::true_type{}, std::false_type{}); }
-            }
-        };
-        if (g.j0 > 0 && jhi_any >= 0) stream(g.gh, 0, min(g.j0 - 1, jhi_any));
-        if (jhi_any >= g.j0) stream(g.gt - goff0, g.j0, jhi_any);
-        const double shi = wg::group_sum<LP>(ahi[0] + ahi[1]), slo = wg::group_sum<LP>(alo[0] + alo[1]);
-        if (live && gl == 0) { yv[chi] = shi; yv[clo] = slo; }
-    }
-    for (int e = NP + tid; e < ldG; e += nt) yv[e] = 0.0;
-    W.sync();
 }
 
 // out1[row] = sum_{i >= 2 j} G^T[row][i] y1[i]  (and out2 with y2 when y2 != null): 8 lanes per row, 64 rows per pass; the
 // L2-resident rows (stages < j0) in passes of their own.  No masks: y1 / y2 must be zero from index NP up to NP + YPAD - 1
 // (the lanes run to the length of the longest row of the pass; what they read of G past the end of a row is the next
 // rows' data -- finite -- times those zeros).
-template <int MSEL, bool HALF>
-__device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2, Waves<HALF> &W) {
+template <int MSEL, bool HALF, class GP>
+__device__ __forceinline__ void gT_times(const QPDims &d, const GP &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2, Waves<HALF> &W) {
     constexpr int M = MSEL;
     const int NP = g.NP, nm = d.N * M, tid = W.tid, nt = W.nt;
     const int g8 = tid & 7, rpp = nt / 8;
@@ -462,8 +469,8 @@ __device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L
     }
     W.sync();
 }
-template <int MSEL>
-__device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2) {
+template <int MSEL, class GP>
+__device__ __forceinline__ void gT_times(const QPDims &d, const GP &g, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2) {
     auto W = all_waves();
     gT_times<MSEL, false>(d, g, L, y1, y2, out1, out2, W);
 }
@@ -474,8 +481,8 @@ __device__ __forceinline__ void gT_times(const QPDims &d, const GPack &g, Lds &L
 // runs over the stages that reach it: 2 j < 16 (I + 1).  Stages with 2 j <= 16 I reach every lane of the tile row (no
 // masks); the last seven are triangular.  sched: per wave 4 tasks x {I, J0, nJ, 0} (host-built, longest first onto the
 // least loaded SIMD; nJ = 0: no more tasks).
-template <int MSEL>
-__device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GPack &g, Lds &L) {
+template <int MSEL, class GP>
+__device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP &g, Lds &L) {
     static_assert(MSEL == 4 || MSEL == 8, "lean Gram: n_u = 4 or 8");
     constexpr int M = MSEL, SPS = M / 4;                       // k-steps per stage
     const int N = d.N, KT = d.KT, NP = g.NP;
@@ -786,8 +793,8 @@ __device__ __forceinline__ void k_solve_unit(const QPDims &d, Lds &L, lptr v) {
 //   front (needs the gradients, D, Ls and the scaling ks of K -- NOT the factor): t = -D^-1 (g_u + G^T g_y), the reduced dual
 //          residual max |g_ud + G^T g_yd| when gyd != null (into L.Qu[0]), yc = ks Ls^T G t;  runs on any wave set
 //   back  (needs the factor): v = K^-1 yc, du = t - D^-1 G^T Ls ks v, dy = G du
-template <int MSEL, bool HALF>
-__device__ __forceinline__ void newton_front(const QPDims &d, const GPack &g, Lds &L, clptr gyd, Waves<HALF> &W, Prof &pf) {
+template <int MSEL, bool HALF, class GP>
+__device__ __forceinline__ void newton_front(const QPDims &d, const GP &g, Lds &L, clptr gyd, Waves<HALF> &W, Prof &pf) {
     const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = W.tid, nt = W.nt;
     QC_SUB(pf, 8);
     gT_times<MSEL, HALF>(d, g, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr, W);
@@ -818,8 +825,8 @@ __device__ __forceinline__ void newton_front(const QPDims &d, const GPack &g, Ld
     W.sync();
 }
 
-template <int MSEL>
-__device__ __forceinline__ void newton_back(const QPDims &d, const GPack &g, Lds &L, Prof &pf) {
+template <int MSEL, class GP>
+__device__ __forceinline__ void newton_back(const QPDims &d, const GP &g, Lds &L, Prof &pf) {
     const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = threadIdx.x, nt = blockDim.x;
     k_solve_unit(d, L, L.yc);
     // yd = Ls (ks v) per output stage: out_0 = L00 v0, out_1 = L10 v0 + L11 v1
@@ -845,8 +852,8 @@ __device__ __forceinline__ void newton_back(const QPDims &d, const GPack &g, Lds
 }
 
 // the whole solve on the whole workgroup (the general-row interior point; corrector solves)
-template <int MSEL>
-__device__ __forceinline__ void newton_solve(const QPDims &d, const GPack &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
+template <int MSEL, class GP>
+__device__ __forceinline__ void newton_solve(const QPDims &d, const GP &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
     auto W = all_waves();
     newton_front<MSEL, false>(d, g, L, gyd, W, pf);
     if (gyd) *rd = L.Qu[0];
@@ -1108,7 +1115,7 @@ __device__ __forceinline__ double gsum(double v) {
     else return wg::group_sum<G>(v);
 }
 
-template <int MSEL, int NSEL, int GX>
+template <int MSEL, int NSEL, int GX, int NST = 0, int J0SEL = 0>
 __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                        Lds &L, int *iters_out, QPWork &wout, long long *prof) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1123,7 +1130,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     wout = w;
     gptr gh = work_base + dfull.qc_off;
     const int N = d.N, m = d.m, nm = N * m, ldG = 16 * d.KT, NP = 2 * N, nz = d.nz;
-    GPack g{(cgptr)gh, (clptr)(L.Gt), d.lean_j0, m, NP};
+    GPackT<NST, J0SEL> g{(cgptr)gh, (clptr)(L.Gt), d.lean_j0, m, NP};
     Prof pf;
 #ifdef SRH_PROFILE
     for (int i = 0; i < 24; ++i) pf.t[i] = 0;
@@ -1406,7 +1413,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 // The QP as the SCP loop needs it: condensed interior point, states by a rollout of the minimiser, objective, trust-region
 // test.  Returns 0 when the result IS the minimiser of the full QP (converged, inside the trust region); anything else
 // means "hand this QP to the fused kernel" (status of the interior point, or 100 = minimiser outside the trust region).
-template <int MSEL, int NSEL, int GXSEL>
+template <int MSEL, int NSEL, int GXSEL, int NST = 0, int J0SEL = 0>
 __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                         Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1416,7 +1423,7 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     int st;
     // GXSEL > 0: box-structured input rows, rows next to their sums, GXSEL lanes per stage for the state rows (one variant per
     // kernel: both interior points in one kernel thrash the instruction cache -- measured -8 % on everything)
-    if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof);
+    if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL, NST, J0SEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof);
     else st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
     if (iters_out) *iters_out = it;
     if (st != 0) return st;

@@ -3,6 +3,8 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I soft-robot-control_amd/csrc tools/probes/lean_probe.hip -o gpurun_variants/lean_probe
 #include "scp_host.h"
 #include "gram_chol_pipeline.h"
+#include "g_times_pairs.h"
+#include "gT_times_fixed.h"
 #include <cstdio>
 #include <vector>
 #include <random>
@@ -208,6 +210,47 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
     TIME(ql::k_solve_unit(d, L, L.yc));                                                           // 16
     { auto Wa = ql::all_waves(); __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::g_times_pairs<PROBE_M, false>(d, g, L, L.u, L.yb, Wa);
       __syncthreads(); t1 = clock64(); if (tid == 0) out[19] = (t1 - t0) / REPS; }
+    {   // the fixed-layout product (N = 50 and the probe's j0 as compile-time constants) against the run-time form
+        constexpr int PJ0 = PROBE_M == 4 ? 7 : 24;
+        if (d.lean_j0 == PJ0 && d.N == 50) {
+            ql::GPackT<50, PJ0> gf{g.gh, g.gt, g.j0, g.m, g.NP};
+            ql::g_times<PROBE_M>(d, g, L, L.u, L.yb);
+            ql::g_times<PROBE_M>(d, gf, L, L.u, L.yc);
+            double ef = 0.0;
+            for (int i = tid; i < ldG; i += nt) ef = fmax(ef, fabs(L.yb[i] - L.yc[i]) / (1.0 + fabs(L.yb[i])));
+            ef = wg::reduce(ef, 1, L.red);
+            if (tid < 2) L.flag[4 + tid] = 0;
+            __syncthreads();
+            auto Wh = ql::half_waves(L.flag + 4);
+            if (ql::half_of_wave(tid >> 6) == 1) ql::g_times<PROBE_M, true>(d, gf, L, L.u, L.yd, Wh);
+            __syncthreads();
+            double eh = 0.0;
+            for (int i = tid; i < ldG; i += nt) eh = fmax(eh, fabs(L.yd[i] - L.yc[i]));
+            eh = wg::reduce(eh, 1, L.red);
+            __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::g_times<PROBE_M>(d, gf, L, L.u, L.yb);
+            __syncthreads(); t1 = clock64();
+            if (tid == 0) { out[22] = (t1 - t0) / REPS; ((double *)out)[44] = ef; ((double *)out)[45] = eh; }
+            // gT_times, fixed layout against the run-time form (two right-hand sides), whole workgroup and half set
+            ql::gT_times<PROBE_M>(d, g, L, L.ya, L.yg, L.du, L.tc);
+            { auto Wq = ql::all_waves(); ql::gT_times_fixed_or_not<PROBE_M, false>(d, gf, L, L.ya, L.yg, L.ta, L.tb, Wq); }
+            double eg = 0.0;
+            for (int e = tid; e < nm; e += nt) eg = fmax(eg, fmax(fabs(L.du[e] - L.ta[e]), fabs(L.tc[e] - L.tb[e])) / (1.0 + fabs(L.du[e])));
+            eg = wg::reduce(eg, 1, L.red);
+            if (tid < 2) L.flag[4 + tid] = 0;
+            __syncthreads();
+            auto Wg = ql::half_waves(L.flag + 4);
+            if (ql::half_of_wave(tid >> 6) == 1) ql::gT_times_fixed_or_not<PROBE_M, true>(d, gf, L, L.ya, (clptr) nullptr, L.tb, (lptr) nullptr, Wg);
+            __syncthreads();
+            double eg2 = 0.0;
+            for (int e = tid; e < nm; e += nt) eg2 = fmax(eg2, fabs(L.tb[e] - L.ta[e]));
+            eg2 = wg::reduce(eg2, 1, L.red);
+            __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) { auto Wq = ql::all_waves(); ql::gT_times_fixed_or_not<PROBE_M, false>(d, gf, L, L.ya, (clptr) nullptr, L.du, (lptr) nullptr, Wq); }
+            __syncthreads(); t1 = clock64(); const long long tg1 = (t1 - t0) / REPS;
+            __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) { auto Wq = ql::all_waves(); ql::gT_times_fixed_or_not<PROBE_M, false>(d, gf, L, L.ya, L.yg, L.du, L.tc, Wq); }
+            __syncthreads(); t1 = clock64();
+            if (tid == 0) { out[23] = tg1; out[24] = (t1 - t0) / REPS; ((double *)out)[46] = eg; ((double *)out)[47] = eg2; }
+        }
+    }
     // the factorisation on one SIMD half of the workgroup (counters in LDS, no set-wide barrier) while the other half waits; checked
     // against qpc::tile_cholesky on the same tiles
     {
@@ -289,6 +332,8 @@ int main() {
     printf("self-check: g_times %.2e gT_times %.2e gram %.2e rollout %.2e condense %.2e\n", ((double *)out)[32], ((double *)out)[33], ((double *)out)[34], ((double *)out)[35], ((double *)out)[36]);
     printf("chol16 (one wave) %lld, tile_update (one wave) %lld\n", out[20], out[21]);
     printf("g_times_pairs: %lld clocks; vs naive sums %.2e, half set vs whole workgroup %.2e\n", out[19], ((double *)out)[42], ((double *)out)[43]);
+    printf("g_times_fixed: %lld clocks; vs g_times %.2e, half set vs whole workgroup %.2e\n", out[22], ((double *)out)[44], ((double *)out)[45]);
+    printf("gT_times_fixed: %lld / %lld clocks (one / two right-hand sides); vs gT_times %.2e, half set vs whole workgroup %.2e\n", out[23], out[24], ((double *)out)[46], ((double *)out)[47]);
     printf("tile_cholesky_set (4 waves, LDS counters) vs qpc::tile_cholesky: max |d| %.2e\n", ((double *)out)[41]);
     printf("gram_chol vs gram + tile_cholesky: max |dR| %.2e max |dRinv| %.2e max |dks| %.2e ok flags %.0f (3 = both)\n", ((double *)out)[37], ((double *)out)[38],
            ((double *)out)[39], ((double *)out)[40]);
