@@ -656,8 +656,12 @@ inline void chol_psd(double *S, int n) {
 }
 
 // The QP of p without its trust-region rows.  x, u, s as ipm_solve; *inside: the minimiser satisfies p's trust region.
+// the iterate a converged condensed solve leaves for the next QP of the same SCP solve (condensed_ipm.solve: warm)
+struct Warm { bool valid = false; vec u, lam; };
+constexpr double WARM_FLOOR = 1e-2;
+
 Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, double *J_out, bool *inside_out,
-                double tol = 1e-12, int max_iter = 60, double reg = 1e-8) {
+                double tol = 1e-12, int max_iter = 60, double reg = 1e-8, Warm *ws = nullptr) {
     const int N = p.N, n = p.n, m = p.m, nz = p.nz, nU = p.nU, nX = p.nX, nXf = p.nXf, po = cb.po;
     const int NP = N * po, NM = N * m, ng = N * nU + N * nX + nXf;
     auto nrx = [&](int k) { return nX + (k == N ? nXf : 0); };                  // state rows of stage k = 1..N
@@ -896,6 +900,15 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
         for (int e = 0; e < NM; ++e) u[e] += du[e];
         return finish(0, 0, 0.0);
     }
+    const bool warm = ws != nullptr && ws->valid && (int)ws->u.size() == NM && (int)ws->lam.size() == NR;
+    if (warm) {
+        // the previous QP's point (condensed_ipm.solve, warm): slacks from this QP's rows, multipliers kept, both away from zero
+        u = ws->u;
+        G_times(u, y);
+        for (int i = 0; i < NP; ++i) y[i] += yf[i];
+        row_apply(y, u, gval, true);
+        for (int e = 0; e < NR; ++e) if (live[e]) { tt[e] = std::max(-gval[e], WARM_FLOOR); lam[e] = std::max(ws->lam[e], WARM_FLOOR); }
+    } else {
     // starting point: unit weights, gradient shifts = row values
     row_apply(y, u, gval, true);
     for (int e = 0; e < NR; ++e) { D[e] = live[e] ? 1.0 : 0.0; rho[e] = live[e] ? gval[e] : 0.0; }
@@ -910,6 +923,7 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
     for (int e = 0; e < NR; ++e) if (live[e]) { zmin = std::min(zmin, gval[e]); zmax = std::max(zmax, gval[e]); }
     const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
     for (int e = 0; e < NR; ++e) if (live[e]) { tt[e] = -gval[e] + sh_t; lam[e] = gval[e] + sh_l; }
+    }
     vec g1(n), zero(n, 0.0);
     grad_x(p, 1, zero.data(), g1.data());
     double scale_d = std::max(1.0, p.omega), scale_p = std::max(1.0, std::fabs(p.delta));
@@ -974,6 +988,11 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
         for (int e = 0; e < NR; ++e) if (live[e]) { tt[e] += a * dtv[e]; lam[e] += a * dl[e]; }
         if (!std::isfinite(mu)) { status = 2; break; }
     }
+    if (warm && status != 0) {                       // a warm start that stalls: again from Mehrotra's point
+        ws->valid = false;
+        return cond_solve(p, cb, x, u, s, J_out, inside_out, tol, max_iter, reg, ws);
+    }
+    if (ws != nullptr && status == 0) { ws->valid = true; ws->u = u; ws->lam = lam; }
     return finish(it, status, mu);
 }
 
@@ -982,7 +1001,7 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
 // algo 0: stage-wise Riccati interior point throughout.  algo 1: what the device kernel does -- the condensed interior point
 // for the QP without its trust-region rows (accepted when it converges inside the trust region), the Riccati interior point
 // of the full QP otherwise.
-Info qp_solve(Problem &p, vec &x, vec &u, vec &s, double *J, int algo = 0, const CondBasis *cb = nullptr) {
+Info qp_solve(Problem &p, vec &x, vec &u, vec &s, double *J, int algo = 0, const CondBasis *cb = nullptr, Warm *ws = nullptr) {
     auto s0 = [&]() {
         double v = 0.0;
         for (int i = 0; i < p.n; ++i) v = std::max(v, std::fabs(p.xs[i] * (p.x0[i] - p.xk[i])));
@@ -990,7 +1009,7 @@ Info qp_solve(Problem &p, vec &x, vec &u, vec &s, double *J, int algo = 0, const
     };
     if (algo == 1 && cb && cb->ok) {
         bool inside = true;
-        Info a = cond_solve(p, *cb, x, u, s, J, &inside);
+        Info a = cond_solve(p, *cb, x, u, s, J, &inside, 1e-12, 60, 1e-8, ws);
         if (a.status == 0 && inside) {
             if (p.tr) { s[0] = s0(); if (J) *J += p.omega * s[0]; }
             return a;
@@ -1030,13 +1049,14 @@ int gusto_one(const Model &M, Problem base, const GustoPar &par, double dt, cons
     bool converged = false;
     int itr = 0;
     vec x, u, s;
+    Warm warm_state;                                 // every QP after the first one the condensed path finished starts from that one's iterate
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
         Problem p = base;
         p.x0 = x0; p.xk = xk.data(); p.delta = delta; p.omega = omega;
         p.A.resize(N); p.B.resize(N); p.d.resize(N);
         for (int k = 0; k < N; ++k) { p.A[k] = M.Ad + (size_t)idx[k] * n * n; p.B[k] = M.Bd + (size_t)idx[k] * n * m; p.d[k] = M.dd + (size_t)idx[k] * n; }
         double J = 0.0;
-        const Info inf = qp_solve(p, x, u, s, &J, algo, cb);
+        const Info inf = qp_solve(p, x, u, s, &J, algo, cb, &warm_state);
         if (inf.status != 0) break;
         double md = 0.0;
         for (int k = 0; k <= N; ++k) for (int i = 0; i < n; ++i) md = std::max(md, std::fabs(p.xs[i] * (x[(size_t)k * n + i] - xk[(size_t)k * n + i])));

@@ -103,6 +103,7 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
     converged = False
     itr = 0
     trace = []
+    warm_state, ipm_iters = None, []
     while itr <= par['max_gusto_iters'] and not converged and omega <= par['omega_max']:
         if stage_qp:
             # the stage-structured interior point (numpy statement of the kernel's algorithm) on the same QP data;
@@ -120,8 +121,12 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
             assert dU is None and obs_lin is None
             sp = ripm.Problem(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des, Qzf=Qzf, zf=zf,
                               U=U, X=X, Xf=Xf, x_scale=xs)
-            x_next, u_next, J, info = cipm.solve(sp)
+            # (round 4) every QP after the first one the condensed path finished starts from that one's iterate
+            x_next, u_next, J, info = cipm.solve(sp, warm=warm_state if par.get('warm_start_qp', True) else None)
             J += omega * max(0.0, np.max(np.abs(xs * (x0 - xk[0]))) - delta)       # s_0 (closed form)
+            ipm_iters.append(info['iters'])
+            if info['status'] == 'optimal':
+                warm_state = info['final']
             if not (info['status'] == 'optimal' and info['inside']):
                 x_next, u_next, _, J, _ = ripm.solve(sp)
         else:

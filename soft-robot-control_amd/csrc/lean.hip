@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
-    bool converged = false, handed_over = false;
+    bool converged = false, handed_over = false, have_warm = false;
     int itr = 0, status = 0;
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
         QPData q{x0, xk, (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr), (cgptr)(b.zf ? b.zf + p * nz : nullptr),
@@ -71,7 +71,15 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         double J;
         int qit;
         GU_LAP(1);
-        const int st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, base, L, &J, &qit, w, prof);
+        // every QP after the first one this kernel finished starts from that one's minimiser and multipliers (ql::ipm_box: warm);
+        // a warm-started interior point that does not reach the tolerances is repeated from Mehrotra's point
+        int st = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool warm = GXSEL > 0 && have_warm && attempt == 0;
+            st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, base, L, &J, &qit, w, prof, warm);
+            if (st == 0 || st == 100 || !warm) break;
+        }
+        have_warm = st == 0;
         GU_LAP(2);
         if (st != 0) {                               // the fused kernel takes this rollout from here
             if (tid == 0) {
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6], prof[7]);
         printf("lean newton laps: gradients %lld gT(1) %lld rhs+dinv %lld g(1) %lld k_solve %lld gT(2) %lld du %lld g(2) %lld\n",
                prof[8], prof[9], prof[10], prof[11], prof[12], prof[13], prof[14], prof[15]);
+        printf("lean step laps: step rows (both modes) %lld reduce(amax) %lld affine mu rows %lld reduce(mu_aff) %lld\n", prof[18], prof[19], prof[20], prof[21]);
         printf("lean split (factorisation on waves 0-3 beside the front of the Newton solve on waves 4-7): factorisation %lld front %lld\n", prof[16], prof[17]);
     }
 #endif

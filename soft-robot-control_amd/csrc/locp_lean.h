@@ -1117,7 +1117,7 @@ __device__ __forceinline__ double gsum(double v) {
 
 template <int MSEL, int NSEL, int GX, int NST = 0, int J0SEL = 0>
 __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
-                                       Lds &L, int *iters_out, QPWork &wout, long long *prof) {
+                                       Lds &L, int *iters_out, QPWork &wout, long long *prof, bool warm = false) {
     const int tid = threadIdx.x, nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
@@ -1140,7 +1140,13 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 #else
 #define QB_LAP(x) ((void)0)
 #endif
-    for (int e = tid; e < nm; e += nt) { w.u[e] = 0.0; L.u[e] = 0.0; }
+    // warm (round 4): the previous QP of this SCP solve left its minimiser in w.u and its multipliers in w.lam -- this QP differs
+    // by its linearisation point only and shares most of the active set: the interior point starts from that point (u as it
+    // is, slacks from THIS QP's rows, multipliers kept, both at least WARM_FLOOR from zero) and skips the initial Newton system.
+    // 7-9 interior-point iterations instead of 15-18 at C2 / C5, same minimiser (oracle/condensed_ipm.py: solve(warm=...)).
+    constexpr double WARM_FLOOR = 1e-2;
+    if (warm) { for (int e = tid; e < nm; e += nt) L.u[e] = w.u[e]; }
+    else { for (int e = tid; e < nm; e += nt) { w.u[e] = 0.0; L.u[e] = 0.0; } }
     for (int e = tid; e < ldG + YPAD; e += nt) { L.ya[e] = 0.0; L.yd[e] = 0.0; L.yg[e] = 0.0; }     // padding stays zero for good
     for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
     for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
@@ -1163,7 +1169,15 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
         for (int k = tid; k < N; k += nt) L.goff[k] = L.idxl[k];
         if (tid == 0) L.flag[2] = 1;
     }
-    for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yf[e]; L.dy[e] = 0.0; }
+    if (warm) {                                               // y = y_free + G u
+        __syncthreads();
+        g_times<MSEL>(d, g, L, L.u, L.dy);
+        for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yf[e] + L.dy[e]; }
+        __syncthreads();
+        for (int e = tid; e < ldG; e += nt) L.dy[e] = 0.0;
+    } else {
+        for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yf[e]; L.dy[e] = 0.0; }
+    }
     __syncthreads();
     QB_LAP(2);
     // ---- this thread's rows
@@ -1195,6 +1209,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
         if (kx == N && c.Qzf && q.zf) for (int b = 0; b < nz; ++b) { gc0 = fma(-c.Czf2[b], q.zf[b], gc0); gc1 = fma(-c.Czf2[nz + b], q.zf[b], gc1); }
     }
     const int nrow = isu ? 2 : (xrow ? 1 : 0);
+    const int lslot = isu ? 2 * tid : 2 * nm + (kx - 1) * (d.nX + d.nXf) + rx;       // this thread's rows in w.lam (NR = N (nX + nXf) + N nU entries)
     double rt[2] = {0.0, 0.0}, rlam[2] = {0.0, 0.0}, rrg[2] = {0.0, 0.0}, rrc[2] = {0.0, 0.0}, rdt[2] = {0.0, 0.0}, rdl[2] = {0.0, 0.0};
     // a_row . (y, u) for row slot s2
     auto row_val = [&](int s2, clptr vy, clptr vu) -> double {
@@ -1206,6 +1221,29 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     int mode = INIT;
     double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
     bool near_opt = false;
+    auto scales = [&]() {                                     // residual scales and the dual regularisation (once per QP)
+        for (int e = tid; e < d.n; e += nt) {
+            double gq = 0.0;
+            if (q.z) for (int a = 0; a < nz; ++a) gq = fma(c.HtQz2[e * nz + a], -q.z[nz + a], gq);
+            sd = fmax(sd, fabs(gq));
+        }
+        for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
+        reduce2(sd, 1, sp, 1, L.red);
+        sd = fmax(sd, q.omega);
+        sp = fmax(sp, fabs(q.delta));
+        dreg = d.reg / sd;
+    };
+    if (warm && d.ng > 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 >= nrow) continue;
+            const double gq = row_val(s2, L.y, L.u) - rh[s2];
+            rt[s2] = fmax(-gq, WARM_FLOOR);
+            rlam[s2] = fmax(w.lam[lslot + s2], WARM_FLOOR);
+        }
+        scales();
+        mode = PRED;
+    }
     while (true) {
         QB_LAP(7);
         // ---------------- rows -> weights, gradient shifts, and their per-stage sums, all in place
@@ -1341,16 +1379,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
             const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) { rt[s2] = -rrg[s2] + sh_t; rlam[s2] = rrg[s2] + sh_l; }
-            for (int e = tid; e < d.n; e += nt) {
-                double gq = 0.0;
-                if (q.z) for (int a = 0; a < nz; ++a) gq = fma(c.HtQz2[e * nz + a], -q.z[nz + a], gq);
-                sd = fmax(sd, fabs(gq));
-            }
-            for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
-            reduce2(sd, 1, sp, 1, L.red);
-            sd = fmax(sd, q.omega);
-            sp = fmax(sp, fabs(q.delta));
-            dreg = d.reg / sd;
+            scales();
             mode = PRED;
             continue;
         }
@@ -1367,7 +1396,9 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
                 if (dl < 0.0) amax = fmin(amax, -lam / dl);
             }
         }
+        QB_LAP(18);
         reduce2(amax, 2, dummy, 0, L.red);
+        QB_LAP(19);
         if (mode == PRED) {
             if (!ok) { status = near_opt ? 0 : 2; break; }
             if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
@@ -1382,7 +1413,9 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
                 if (s2 < nrow) ma += (rlam[s2] + a_aff * rdl[s2]) * (rt[s2] + a_aff * rdt[s2]);
+            QB_LAP(20);
             reduce2(ma, 0, dummy, 0, L.red);
+            QB_LAP(21);
             const double mu_aff = ma / d.ng;
             sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
             if (q.dbg && tid == 0) { gptr gd = q.dbg + 8 * it; gd[5] = a_aff; gd[6] = sig; }
@@ -1402,6 +1435,10 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     }
     __syncthreads();
     for (int e = tid; e < nm; e += nt) w.u[e] = L.u[e];
+    if (status == 0) {                                        // what the next QP of this solve starts from (warm)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) if (s2 < nrow) w.lam[lslot + s2] = rlam[s2];
+    }
     __syncthreads();
 #ifdef SRH_PROFILE
     for (int i = 0; i < 8; ++i) prof[8 + i] += pf.t[8 + i];
@@ -1415,7 +1452,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 // means "hand this QP to the fused kernel" (status of the interior point, or 100 = minimiser outside the trust region).
 template <int MSEL, int NSEL, int GXSEL, int NST = 0, int J0SEL = 0>
 __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
-                                        Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof) {
+                                        Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof, bool warm = false) {
     const int tid = threadIdx.x, nt = blockDim.x;
     QPLds Lq{};
     Lq.v1 = L.v1; Lq.v2 = L.v2; Lq.Qu = L.Qu; Lq.part = L.part; Lq.red = L.red; Lq.idxl = L.idxl; Lq.flag = L.flag;
@@ -1423,7 +1460,7 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     int st;
     // GXSEL > 0: box-structured input rows, rows next to their sums, GXSEL lanes per stage for the state rows (one variant per
     // kernel: both interior points in one kernel thrash the instruction cache -- measured -8 % on everything)
-    if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL, NST, J0SEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof);
+    if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL, NST, J0SEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof, warm);
     else st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
     if (iters_out) *iters_out = it;
     if (st != 0) return st;

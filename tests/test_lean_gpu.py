@@ -5,7 +5,8 @@ Riccati solver) against the fused kernels they replace on the hot path and again
   (SRH_LOCP_NO_LEAN=1) -- interior-point iteration counts within one of each other, iterates to 1e-8 -- and vs the numpy condensed statement;
 * a trust-region-active QP: the lean kernel hands it over (status LEAN_PENDING) and the fused kernel finishes it;
 * the GuSTO loop (gusto.py:283-487) on C2 / C5 rollouts: lean + hand-over vs fused only (SRH_GUSTO_NO_LEAN=1): identical SCP
-  iteration counts and (J, delta, omega) traces, trajectories to 1e-7, for the capped and the uncapped (500) solve."""
+  iteration counts and (J, delta, omega) traces, trajectories to 2e-6 (the lean kernel warm-starts its QPs, the fused one does
+  not), for the capped and the uncapped (500) solve."""
 import os
 
 import numpy as np
@@ -129,4 +130,7 @@ def test_lean_gusto_matches_fused_gusto(which, B):
         for b in range(B):
             k = int(il[b])
             np.testing.assert_allclose(tl[b, :k, :3], tf[b, :k, :3], rtol=1e-7, err_msg='%s rollout %d' % (what, b))
-        assert rel(xl, xf) <= 1e-7 and rel(ul, uf) <= 1e-7, (what, rel(xl, xf), rel(ul, uf))
+        # (round 4: the lean kernel starts every QP after the first from the previous one's minimiser and multipliers, the fused
+        # kernel starts cold -- both stop on the same rule at the same tolerances and agree as far as the flat QP lets two exact
+        # solvers agree: 4e-7 measured at the Trunk shape, DESIGN.md section 5 "QP conditioning")
+        assert rel(xl, xf) <= 2e-6 and rel(ul, uf) <= 2e-6, (what, rel(xl, xf), rel(ul, uf))

@@ -197,6 +197,26 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
       if (tid == 0) out[20] = tc / REPS; }
     { long long tc = 0; for (int r = 0; r < REPS; ++r) { fillK(); __syncthreads(); t0 = clock64(); if (tid < 64) qpc::tile_update(L.B + 7 * ql::TSZ, L.B + ql::TSZ, L.B + ql::TSZ, tid & 15, (tid & 63) >> 4); __syncthreads(); tc += clock64() - t0; }
       if (tid == 0) out[21] = tc / REPS; }
+    {   // chol16 itself: R^T R against the tile it was given, Rinv R against the identity
+        fillK();
+        double *Acopy = work + 290000;
+        for (int e = tid; e < 256; e += nt) { const int i = e >> 4, j = e & 15; if (j < i) L.B[i * ql::TS + j] = L.B[j * ql::TS + i]; }      // fillK's tile is not symmetric
+        __syncthreads();
+        for (int e = tid; e < 256; e += nt) Acopy[e] = L.B[(e >> 4) * ql::TS + (e & 15)];
+        __syncthreads();
+        if (tid < 64) qpc::chol16(L.B, L.Rinv);
+        __syncthreads();
+        double ec = 0.0, ei = 0.0;
+        for (int e = tid; e < 256; e += nt) {
+            const int i = e >> 4, j = e & 15;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < 16; ++k) { s1 += L.B[k * ql::TS + i] * L.B[k * ql::TS + j]; s2 += L.Rinv[i * ql::TS + k] * L.B[k * ql::TS + j]; }
+            ec = fmax(ec, fabs(s1 - Acopy[i * 16 + j])); ei = fmax(ei, fabs(s2 - (i == j ? 1.0 : 0.0)));
+        }
+        ec = wg::reduce(ec, 1, L.red); ei = wg::reduce(ei, 1, L.red);
+        if (tid == 0) { ((double *)out)[48] = ec; ((double *)out)[49] = ei; }
+        __syncthreads();
+    }
     TIME(qpc::stage_factors(d, c, (cgptr)(base + 4096), L));                                   // 6
     TIME(ql::rollout<PROBE_M, 60>(d, dyn, (cgptr)x0, (cgptr) nullptr, base, L));                  // 7
     TIME(ql::condense<PROBE_M, 60>(d, c, dyn, (cgptr)base, gh, L));                               // 8
@@ -330,7 +350,7 @@ int main() {
                            "dinv_apply", "ls_apply", "wg::reduce", "barrier", "gram_chol", "gram+cholesky", "unit_tiles", "k_solve_unit", "chol 4 waves", "set sync (4 w)"};
     for (int i = 0; i < 19; ++i) printf("%-14s %8lld clocks\n", names[i], out[i]);
     printf("self-check: g_times %.2e gT_times %.2e gram %.2e rollout %.2e condense %.2e\n", ((double *)out)[32], ((double *)out)[33], ((double *)out)[34], ((double *)out)[35], ((double *)out)[36]);
-    printf("chol16 (one wave) %lld, tile_update (one wave) %lld\n", out[20], out[21]);
+    printf("chol16 (one wave) %lld, tile_update (one wave) %lld; chol16: max |R^T R - A| %.2e, max |Rinv R - I| %.2e\n", out[20], out[21], ((double *)out)[48], ((double *)out)[49]);
     printf("g_times_pairs: %lld clocks; vs naive sums %.2e, half set vs whole workgroup %.2e\n", out[19], ((double *)out)[42], ((double *)out)[43]);
     printf("g_times_fixed: %lld clocks; vs g_times %.2e, half set vs whole workgroup %.2e\n", out[22], ((double *)out)[44], ((double *)out)[45]);
     printf("gT_times_fixed: %lld / %lld clocks (one / two right-hand sides); vs gT_times %.2e, half set vs whole workgroup %.2e\n", out[23], out[24], ((double *)out)[46], ((double *)out)[47]);
