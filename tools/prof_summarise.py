@@ -41,6 +41,27 @@ if tr:
     json.dump({'source': 'same trace', 'kernels': [{'kernel': k, 'calls': len(v), 'total_ms': sum(v), 'max_ms': max(v), 'last_ms': v[-4:]} for k, v in top]},
               open(os.path.join(P, TAG + '_kernel_launches_top.json'), 'w'), indent=1)
 
+# ---- the other POD launches of the same trace (pod_shapes of bench.py): per-launch durations by kernel instantiation and grid size
+if tr:
+    shapes = {}
+    for r in tr:
+        k = r['Kernel_Name']
+        if not any(s in k for s in ('proj_kernel<', 'lift_kernel<', 'utmu_reduce_kernel', 'splitk_reduce')):
+            continue
+        name = k.replace('void (anonymous namespace)::', '').split('(')[0]
+        shapes.setdefault((name, int(r.get('Grid_Size', r.get('Grid_Size_X', 0))), int(r.get('Workgroup_Size', r.get('Workgroup_Size_X', 0)))), []).append(dur_ms(r))
+    rows_out = []
+    for (name, grid, wgs), v in sorted(shapes.items(), key=lambda kv: -sum(kv[1])):
+        rows_out.append({'kernel': name, 'grid_threads': grid, 'workgroup': wgs, 'workgroups': grid // wgs if wgs else None, 'launches': len(v),
+                         'ms_mean': statistics.mean(v), 'ms_median': statistics.median(v), 'ms_min': min(v), 'ms_max': max(v),
+                         'ms_last_32': [round(x, 6) for x in v[-32:]]})
+    json.dump({'source': 'rocprofv3 --kernel-trace of `python3 bench.py --no-cpu-baseline --steps 3 --warmup 1` (tools/prof_round.sh): every launch of the POD kernels '
+                         '(projection r = 30 / 36, both state forms; U^T M U = proj_kernel<..., true> + utmu_reduce_kernel; lift), grouped by instantiation and grid',
+               'template_arguments': 'proj_kernel<NTF full 16-column tiles, NQ 4-column tiles, HAS_REF, VEC2, UTMU>; lift_kernel<KS, MT>',
+               'algorithmic_bytes': {'project B=65536 r=30': 8 * (65536 * 4884 + 4884 * 30 + 4884 + 65536 * 30), 'project B=65536 r=36': 8 * (65536 * 4884 + 4884 * 36 + 4884 + 65536 * 36),
+                                     'utmu': 8 * 4884 * 4884},
+               'launch_groups': rows_out}, open(os.path.join(P, TAG + '_pod_shapes_launches.json'), 'w'), indent=1)
+
 # ---- PMC: HBM traffic of the projection kernel
 def counter_rows(d, name):
     rs = rows(d + '/**/*counter_collection.csv')
@@ -58,6 +79,19 @@ if fv and wvv:
                'traffic_bytes_per_launch': (2 * fm + wm) * 1024, 'algorithmic_bytes_per_launch': 8 * (65536 * 4884 + 4884 * 30 + 4884 + 65536 * 30),
                'launches_sampled': len(fv), 'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_round.sh), ' + TAG + ' tree'},
               open(os.path.join(P, TAG + '_proj_pmc.json'), 'w'), indent=1)
+
+# the one-pass U^T M U of tools/pmc_kernels.py (M 4884 x 4884; the UTMU instantiation of the projection kernel + its reduction)
+selu = lambda rs, pat: [float(r['Counter_Value']) for r in rs if pat in r['Kernel_Name']]
+fu, wu = selu(f, 'true, true>'), selu(wv, 'true, true>')
+if fu and wu:
+    fm, wm = statistics.median(fu), statistics.median(wu)
+    fr, wr = selu(f, 'utmu_reduce_kernel'), selu(wv, 'utmu_reduce_kernel')
+    json.dump({'kernel': 'proj_kernel<2, 0, false, true, true> (U^T M U, r = 30) + utmu_reduce_kernel', 'workload': 'M 4884 x 4884 f64, r = 30 (tools/pmc_kernels.py)',
+               'FETCH_SIZE_KiB_median': fm, 'WRITE_SIZE_KiB_median': wm, 'fetch_correction': 'x2 (gfx950 wide coalesced reads, MI355X_MICROARCH.md HBM section)',
+               'traffic_bytes_per_launch': (2 * fm + wm) * 1024, 'algorithmic_bytes_per_launch': 8 * 4884 * 4884,
+               'reduce_kernel_FETCH_SIZE_KiB_median': statistics.median(fr) if fr else None, 'reduce_kernel_WRITE_SIZE_KiB_median': statistics.median(wr) if wr else None,
+               'launches_sampled': len(fu), 'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_round.sh), ' + TAG + ' tree'},
+              open(os.path.join(P, TAG + '_utmu_pmc.json'), 'w'), indent=1)
 
 # ---- PMC: MFMA-busy fraction of the SCP kernels of one bench step
 m = rows(TAG + '_pmc_mfma/**/*counter_collection.csv')
