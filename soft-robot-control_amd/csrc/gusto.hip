@@ -58,6 +58,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     bool converged = false;
     int itr = 0, status = 0;
     bool tr_hot = false;                               // expect the trust region to bind in the next QP (see qp::solve, full_first)
+    bool warm_relaxed = false;                         // the previous QP ended in the relaxed Riccati pass (qp::solve, warm)
     if (b.mode == 2) {
         // only the rollouts a lean launch (lean.hip) could not finish: xk, uk, idx are where it left them
         if (rec[0] != 1.0) return;
@@ -80,7 +81,9 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         double J;
         int qit;
         GU_LAP(1);
-        const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w, tr_hot);
+        int qpass = -1;
+        const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w, tr_hot, warm_relaxed, &qpass);
+        warm_relaxed = st == 0 && qpass == 0;        // the next QP's relaxed Riccati pass may start from this one's (u, lambda)
         GU_LAP(2);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)

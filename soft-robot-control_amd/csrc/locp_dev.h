@@ -1062,9 +1062,16 @@ namespace qp {
 // when the relaxed minimiser leaves the trust region.
 template <bool SPLIT, int MSEL, int NSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
-                                     QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout, bool full_first = false) {
+                                     QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout, bool full_first = false,
+                                     bool warm = false, int *pass_out = nullptr) {
+    // warm (round 4, as ql::ipm_box): the caller's PREVIOUS QP was finished by the relaxed Riccati pass below, so w.u and
+    // w.lam of that layout still hold its minimiser and multipliers -- the relaxed pass of this QP starts from them
+    // (t = max(-g(u), floor), lam = max(lam, floor), no starting system); a warm attempt that fails is repeated cold.
+    // pass_out: -1 condensed path, 0 relaxed Riccati pass, 1 full QP -- what produced the result.
+    constexpr double WARM_FLOOR = 1e-2;
     const int tid = threadIdx.x, nt = blockDim.x;
     int status = 1, it = 0;
+    if (pass_out) *pass_out = -1;
     double J = 0.0;
     const int npass = (prescreen && dfull.tr) ? 2 : 1;
     // full_first: the caller expects the trust region to bind (the previous QP of this rollout ended on its boundary, or a
@@ -1131,6 +1138,9 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         QPWork w;
         qp_carve(w, work_base, d);
         wout = w;
+        if (pass_out) *pass_out = pass;
+        const bool warm_now = warm && npass == 2 && pass == 0;
+        warm = false;                                  // (a repeated pass starts cold)
         const int N = d.N, n = d.n, m = d.m;
         w.tprof = q.dbg ? q.dbg + 8 * 63 : (gptr)nullptr;
 #ifdef SRH_PROFILE
@@ -1139,7 +1149,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         auto lap = [&](int slot) { const long long now = clock64(); tm[slot] += now - t_last; t_last = now; };
 #endif
         const double s0 = slack0(dfull, c, q, L);
-        for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
+        if (!warm_now) for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
         for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
         for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
         __syncthreads();
@@ -1150,6 +1160,30 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         int mode = INIT;
         double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
         bool near_opt = false;
+        // scales for the stopping test (as oracle/riccati_ipm.py)
+        auto scales = [&]() {
+            for (int e = tid; e < n; e += nt) {
+                double g = 0.0;
+                if (q.z) for (int a = 0; a < d.nz; ++a) g = fma(c.HtQz2[e * d.nz + a], -q.z[d.nz + a], g);
+                sd = fmax(sd, fabs(g));
+            }
+            for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
+            sd = fmax(wg::reduce(sd, 1, L.red), q.omega);
+            sp = fmax(wg::reduce(sp, 1, L.red), fabs(q.delta));
+            dreg = d.reg / sd;
+        };
+        if (warm_now && d.ng > 0) {
+            rows_apply(d, c, w.x, w.s, w.u, w.rg);
+            __syncthreads();
+            for_rows(d, [&](int row, bool isU, int k, int r) {
+                const double g = w.rg[row] - row_h(d, c, q, isU, k, r);
+                w.t[row] = fmax(-g, WARM_FLOOR);
+                w.lam[row] = fmax(w.lam[row], WARM_FLOOR);
+            });
+            __syncthreads();
+            scales();
+            mode = PRED;
+        }
         while (true) {
             // ---------------- rows: weights D and gradient shifts rho for this Newton system
             if (mode != CORR) {
@@ -1216,16 +1250,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
                     w.t[row] = -g + sh_t; w.lam[row] = g + sh_l;
                 });
                 __syncthreads();
-                // scales for the stopping test (as oracle/riccati_ipm.py)
-                for (int e = tid; e < n; e += nt) {
-                    double g = 0.0;
-                    if (q.z) for (int a = 0; a < d.nz; ++a) g = fma(c.HtQz2[e * d.nz + a], -q.z[d.nz + a], g);
-                    sd = fmax(sd, fabs(g));
-                }
-                for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
-                sd = fmax(wg::reduce(sd, 1, L.red), q.omega);
-                sp = fmax(wg::reduce(sp, 1, L.red), fabs(q.delta));
-                dreg = d.reg / sd;
+                scales();
                 mode = PRED;
                 continue;
             }
@@ -1285,6 +1310,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             mode = PRED;
         }
         SRH_LAP(1);
+        if (warm_now && status != 0) { --pass; continue; }      // the warm attempt did not reach the tolerances: the same pass from the cold start
         // final consistency: x is exactly the rollout of u
         rollout(d, dyn, q, w.u, w.x, L);
         J = objective(d, c, q, w.x, w.u, w.s, L);
