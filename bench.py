@@ -247,9 +247,12 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
     if dist is not None:
         dist.barrier()
     _lib.sync()
-    t0 = time.perf_counter()
-    g.solve_batch(x0, u_init, x_init, z=z)
-    el = time.perf_counter() - t0
+    els = []
+    for _ in range(3):       # best of 3 calls, all reported (ms_all_calls): the first call after other work in the process can carry a
+        t0 = time.perf_counter()            # one-off allocation of the runtime (measured: 43 ms once, then 13.5 ms)
+        g.solve_batch(x0, u_init, x_init, z=z)
+        els.append(time.perf_counter() - t0)
+    el = min(els)
     its = float(g.iters.sum())
     # the reduction step of the sharded batch: one all_gather of the per-rollout optimal costs, every rank
     # learns the global best rollout (outside the solve's wall time: 256 doubles)
@@ -266,9 +269,10 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
     else:
         J_all, best = gather_rollout_costs(J_loc, Bn)
     return {'workload': 'C5: Trunk n_f=2127, r=30 (n_x=60, n_u=8), N=50, dt=%g, U box; %d rollouts in total, %d per rank, '
-                        'strong scaling; host buffers' % (dt, total, Bn),
-            'iterations_per_s': its / el, 'ms': el * 1e3, 'iterations': its,
+                        'strong scaling; host buffers; best of 3 calls' % (dt, total, Bn),
+            'iterations_per_s': its / el, 'ms': el * 1e3, 'ms_all_calls': [e * 1e3 for e in els], 'iterations': its,
             'not_converged_rank0': int((g.status != 0).sum()), 'kernel': g.kernel_info['kernel'],
+            'rollouts_handed_to_fused_kernel': int(g.kernel_info['handed_over']),
             'best_rollout': {'global_index': best, 'cost': float(J_all[best]) if best >= 0 else None, 'costs_gathered': int(J_all.size),
                              'how': 'distributed.gather_rollout_costs: all_gather of the per-rollout optimal LOCP values (sgusto_plan_costs)'}}
 

@@ -138,6 +138,33 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbos
         gu = np.stack([p.Ru @ (u[k] - p.ud[k]) + UA.T @ wu[k] for k in range(N)])
         return gu.ravel() + Gm.T @ gy.ravel()
 
+    def spd_small(S):
+        L = np.zeros_like(S); dmax = np.abs(np.diag(S)).max()
+        for i in range(S.shape[0]):
+            for j in range(i + 1):
+                v = S[i, j] - L[i, :j] @ L[j, :j]
+                if i == j:
+                    if not v > 1e-8 * dmax:
+                        return False
+                    L[i, i] = np.sqrt(v)
+                else:
+                    L[i, j] = v / L[j, j]
+        return True
+    # both constant output blocks positive definite: every Ls_k is invertible, and dy = G du follows from the solved system
+    # itself (round 4; kernels: ql::newton_back / qpc::newton_solve, twin: direction_y) -- with w = ks v the output-space system
+    # reads (I + Ls^T Ky Ls) w = Ls^T G t, Ky = G D^-1 G^T, hence G du = G t - Ky Ls w = Ls^-T w: no second product with G, and
+    # the error of the K solve is not multiplied by K on its way into dy
+    ls_pd = newton == 'output' and refine == 0 and spd_small(Sc) and spd_small(ScN)
+    last = {}
+
+    def direction_y(du):
+        if not ls_pd:
+            return (Gm @ du.ravel()).reshape(N + 1, po)
+        dy = np.zeros((N + 1, po))
+        for k in range(1, N + 1):
+            dy[k] = np.linalg.solve(last['Ls'][k].T, last['w'][(k - 1) * po:k * po])
+        return dy
+
     def newton_solve(Du, Dx, rhs):
         """du with  M du = rhs."""
         Dblk = [p.Ru + UA.T @ (Du[k][:, None] * UA) for k in range(N)]
@@ -175,6 +202,7 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbos
         def woodbury(r):
             t = Dinv(r)
             v = ks * np.linalg.solve(Kc.T, np.linalg.solve(Kc, ks * (Gs @ t)))
+            last['w'], last['Ls'] = v, Ls
             return t - Dinv(Gs.T @ v)
         du = woodbury(rhs)
         for _ in range(refine):
@@ -260,7 +288,7 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbos
             status = 'optimal'
             break
         du = newton_solve(Du, Dx, -grad_parts(u, y, rhox, rhou)).reshape(N, m)
-        dy = (Gm @ du.ravel()).reshape(N + 1, po)
+        dy = direction_y(du)
         ax, au = row_dirs(du, dy)
         dlx = [None] + [(-lx[k] * tx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
         dlu = [(-lu[k] * tu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]
@@ -275,7 +303,7 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbos
         rhox = [None] + [lx[k] + (lx[k] * rgx[k] - rcx[k]) / ex[k] for k in range(1, N + 1)]
         rhou = [lu[k] + (lu[k] * rgu[k] - rcu[k]) / eu[k] for k in range(N)]
         du = newton_solve(Du, Dx, -grad_parts(u, y, rhox, rhou)).reshape(N, m)
-        dy = (Gm @ du.ravel()).reshape(N + 1, po)
+        dy = direction_y(du)
         ax, au = row_dirs(du, dy)
         dlx = [None] + [(-rcx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
         dlu = [(-rcu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]

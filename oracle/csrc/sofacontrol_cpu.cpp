@@ -849,7 +849,24 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
             for (int a = 0; a < po; ++a) b[a] = o[a];
         }
     };
-    // du = M^-1 rhs:  t = D^-1 rhs;  K v = Ls^T G t;  du = t - D^-1 G^T Ls v
+    // S*_k positive definite (both constant output blocks): every Ls_k is invertible and dy = G du follows from the solved
+    // system itself -- with w = ks v: (I + Ls^T Ky Ls) w = Ls^T G t, Ky = G D^-1 G^T, so G du = G t - Ky Ls w = Ls^-T w
+    // (condensed_ipm.py: newton_solve; kernels: ql::newton_back, qpc::newton_solve)
+    auto spd_small = [&](const vec &S) {
+        vec L(S);
+        double dmax = 0.0;
+        for (int a = 0; a < po; ++a) dmax = std::max(dmax, std::fabs(S[(size_t)a * po + a]));
+        for (int i = 0; i < po; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double v = L[(size_t)i * po + j];
+                for (int q = 0; q < j; ++q) v -= L[(size_t)i * po + q] * L[(size_t)j * po + q];
+                if (i == j) { if (!(v > 1e-8 * dmax)) return false; L[(size_t)i * po + i] = std::sqrt(v); }
+                else L[(size_t)i * po + j] = v / L[(size_t)j * po + j];
+            }
+        return true;
+    };
+    const bool ls_pd = spd_small(cb.Sc) && spd_small(cb.ScN);
+    // du = M^-1 rhs:  t = D^-1 rhs;  K v = Ls^T G t;  du = t - D^-1 G^T Ls v;  wv = ks v (for dy_from_w)
     auto newton_solve = [&](const vec &rhs, vec &duo) {
         tv = rhs;
         Dinv(tv);
@@ -859,11 +876,23 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
         for (int i = 0; i < NP; ++i) { double s1 = yv[i]; for (int q = 0; q < i; ++q) s1 -= K[(size_t)i * NP + q] * yv[q]; yv[i] = s1 / K[(size_t)i * NP + i]; }
         for (int i = NP - 1; i >= 0; --i) { double s1 = yv[i]; for (int q = i + 1; q < NP; ++q) s1 -= K[(size_t)q * NP + i] * yv[q]; yv[i] = s1 / K[(size_t)i * NP + i]; }
         for (int i = 0; i < NP; ++i) yv[i] *= ks[i];
+        wv = yv;
         Ls_apply(yv, false);
         std::fill(t2.begin(), t2.end(), 0.0);
         GT_add(yv, t2);
         Dinv(t2);
         for (int e = 0; e < NM; ++e) duo[e] = tv[e] - t2[e];
+    };
+    auto direction_y = [&](const vec &duv, vec &dyv) {          // dy = G du
+        if (!ls_pd) { G_times(duv, dyv); return; }
+        for (int k = 0; k < N; ++k) {                           // Ls_k^T dy_k = w_k (back substitution, Ls lower)
+            const double *L = &Ls[(size_t)k * po * po];
+            for (int a = po - 1; a >= 0; --a) {
+                double s1 = wv[(size_t)k * po + a];
+                for (int c = a + 1; c < po; ++c) s1 -= L[(size_t)c * po + a] * dyv[(size_t)k * po + c];
+                dyv[(size_t)k * po + a] = s1 / L[(size_t)a * po + a];
+            }
+        }
     };
     auto finish = [&](int it, int status, double mu) {
         x.assign((size_t)(N + 1) * n, 0.0);
@@ -959,7 +988,7 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
         if (!factor()) { status = 2; break; }
         neg_grad(rho);
         newton_solve(rhs, du);
-        G_times(du, dy);
+        direction_y(du, dy);
         row_apply(dy, du, aval, false);
         for (int e = 0; e < NR; ++e) if (live[e]) {
             dl[e] = (-lam[e] * tt[e] + lam[e] * (rg[e] + aval[e])) / ev[e];
@@ -976,7 +1005,7 @@ Info cond_solve(const Problem &p, const CondBasis &cb, vec &x, vec &u, vec &s, d
         }
         neg_grad(rho);
         newton_solve(rhs, du);
-        G_times(du, dy);
+        direction_y(du, dy);
         row_apply(dy, du, aval, false);
         for (int e = 0; e < NR; ++e) if (live[e]) {
             dl[e] = (-rc[e] + lam[e] * (rg[e] + aval[e])) / ev[e];

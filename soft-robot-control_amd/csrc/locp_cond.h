@@ -808,7 +808,11 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, QCWork &qw, Lds &L
     for (int e = tid; e < nm; e += nt) L.du[e] = L.ta[e] - L.du[e];
     __syncthreads();
     QC_SUB(pf, 14);
-    g_times(d, qw, L, L.du, L.dy);                                            // dy = G du
+    // dy = G du.  With w = ks v (in L.yc) the solved system reads (I + Ls^T Ky Ls) w = Ls^T G t, Ky = G D^-1 G^T, so that
+    // G du = G t - Ky Ls w = Ls^-T w: a back substitution per output stage instead of the product (d.ls_pd: every Ls_k is
+    // invertible), and the error of the K solve does not pass through K on its way into dy
+    if (d.ls_pd) ls_apply<LS_INVT>(d, L, L.yc, L.dy);
+    else g_times(d, qw, L, L.du, L.dy);
     QC_SUB(pf, 15);
 }
 

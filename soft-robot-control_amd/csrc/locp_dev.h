@@ -36,6 +36,9 @@ struct QPDims {
     int diagD;          // 1: 2R + U.A^T D U.A is diagonal for every weight vector D (R diagonal, one entry per U.A row)
     int lean;           // 1: the lean condensed kernels (locp_lean.h: packed G resident in LDS) serve this problem
     int lean_j0;        // first stage whose packed G^T rows live in LDS (the stages before it stay in the L2 block)
+    int ls_pd;          // 1 (p_o = 2): the constant output blocks S*_k are positive definite, so every S_k = S*_k + T^T D_x T has an
+                        // invertible Cholesky factor Ls_k -- the lean Newton solve then gets dy from the solved system itself
+                        // (ql::newton_back) instead of a second product with G
 };
 
 namespace qp {

@@ -623,8 +623,11 @@ __device__ __forceinline__ void set_signal(liptr c) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// SLEEP: the workers' waits (one row behind wave 0, long): s_sleep between polls -- same time as polling back to back
+// (58.7 vs 58.7-59.2 ms per 4096 rollouts), fewer instructions issued beside the wave that factorises
+template <bool SLEEP = false>
 __device__ __forceinline__ void set_wait(liptr c, int v) {
-    if ((threadIdx.x & 63) == 0) { while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {} }
+    if ((threadIdx.x & 63) == 0) { while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) { if (SLEEP) __builtin_amdgcn_s_sleep(4); } }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -663,11 +666,11 @@ __device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const
         if (lane == 0) L.flag[1] = ok ? 1 : 0;
     } else {
         for (int J = 0; J + 1 < KT; ++J) {
-            set_wait(Frinv, J + 1);
-            set_wait(Ftrail, nwk * J);
+            set_wait<true>(Frinv, J + 1);
+            set_wait<true>(Ftrail, nwk * J);
             for (int Jp = J + 2 + (wave - 1); Jp < KT; Jp += nwk) panel_tile(L, KT, J, Jp, l16, kk);      // (J, J + 1) is wave 0's
             set_signal(Fpanel);
-            set_wait(Fpanel, (nwk + 1) * (J + 1));
+            set_wait<true>(Fpanel, (nwk + 1) * (J + 1));
             const int rem = KT - J - 1, ntr = rem * (rem + 1) / 2;
             for (int t = wave; t < ntr; t += nwk) {               // tiles 1 .. ntr-1 over the workers (tile 0 = (J+1, J+1) is wave 0's)
                 int tt = t, Ir = 0;
@@ -829,16 +832,24 @@ template <int MSEL, class GP>
 __device__ __forceinline__ void newton_back(const QPDims &d, const GP &g, Lds &L, Prof &pf) {
     const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = threadIdx.x, nt = blockDim.x;
     k_solve_unit(d, L, L.yc);
-    // yd = Ls (ks v) per output stage: out_0 = L00 v0, out_1 = L10 v0 + L11 v1
+    // yd = Ls (ks v) per output stage: out_0 = L00 v0, out_1 = L10 v0 + L11 v1.
+    // dy: with w = ks v the solved system reads (I + Ls^T Ky Ls) w = Ls^T yb, Ky = G D^-1 G^T, yb = G t, so that
+    //     dy = G du = yb - Ky Ls w = Ls^-T w
+    // -- one 2 x 2 back substitution per output stage instead of the product G du (d.ls_pd: every Ls_k is invertible; what the
+    // two forms differ by is the residual of the K solve)
+    const bool dy_here = d.ls_pd != 0;
     for (int k = tid; k < ldG / 2; k += nt) {
-        double o0 = 0.0, o1 = 0.0;
+        double o0 = 0.0, o1 = 0.0, e0 = 0.0, e1 = 0.0;
         if (k < N) {
             clptr Lk = L.Ls + (size_t)k * 4;
             const double v0 = L.yc[2 * k] * L.ks[2 * k], v1 = L.yc[2 * k + 1] * L.ks[2 * k + 1];
             o0 = Lk[0] * v0;
             o1 = fma(Lk[3], v1, Lk[2] * v0);
+            e1 = v1 / Lk[3];
+            e0 = fma(-Lk[2], e1, v0) / Lk[0];
         }
         L.yd[2 * k] = o0; L.yd[2 * k + 1] = o1;
+        if (dy_here) { L.dy[2 * k] = e0; L.dy[2 * k + 1] = e1; }
     }
     __syncthreads();
     QC_SUB(pf, 12);
@@ -847,7 +858,7 @@ __device__ __forceinline__ void newton_back(const QPDims &d, const GP &g, Lds &L
     for (int e = tid; e < nm; e += nt) { const double sd = L.Ldi[e]; L.du[e] = L.ta[e] - L.du[e] * (sd * sd); }
     __syncthreads();
     QC_SUB(pf, 14);
-    g_times<MSEL>(d, g, L, L.du, L.dy);
+    if (!dy_here) g_times<MSEL>(d, g, L, L.du, L.dy);
     QC_SUB(pf, 15);
 }
 

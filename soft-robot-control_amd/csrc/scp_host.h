@@ -176,7 +176,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.max_iter = 60;
     d.tol = 1e-12;
     d.reg = 1e-8;
-    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0; d.diagD = 0; d.lean = 0; d.lean_j0 = 0;
+    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0; d.diagD = 0; d.lean = 0; d.lean_j0 = 0; d.ls_pd = 0;
     std::vector<double> Qx(n * n), QxN(n * n), Ht2(n * nz), Htf2(n * nz, 0.0), R2(m * m), xs(n, 1.0);
     std::vector<double> QzH(nz * n), QzfH(nz * n, 0.0);
     for (int a = 0; a < nz; ++a)
@@ -334,6 +334,22 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             d.KT = (N * po + 15) / 16;
             d.cond = 1;
             if (qpc::lds_doubles(d, NTHREADS) * sizeof(double) > (size_t)160 * 1024) { d.cond = 0; d.po = 0; d.KT = 0; }
+            // both constant output blocks positive definite (Cholesky with pivots above 1e-8 of the largest diagonal entry, as
+            // oracle/condensed_ipm.py: spd_small): the Newton solves take dy from the solved system (qpc::newton_solve)
+            auto spd_small = [&](const std::vector<double> &S) {
+                std::vector<double> Lc(S);
+                double dmax = 0.0;
+                for (int a = 0; a < po; ++a) dmax = std::max(dmax, std::fabs(S[(size_t)a * po + a]));
+                for (int i = 0; i < po; ++i)
+                    for (int j = 0; j <= i; ++j) {
+                        double v = Lc[(size_t)i * po + j];
+                        for (int q = 0; q < j; ++q) v -= Lc[(size_t)i * po + q] * Lc[(size_t)j * po + q];
+                        if (i == j) { if (!(v > 1e-8 * dmax)) return false; Lc[(size_t)i * po + i] = std::sqrt(v); }
+                        else Lc[(size_t)i * po + j] = v / Lc[(size_t)j * po + j];
+                    }
+                return true;
+            };
+            d.ls_pd = (d.cond && spd_small(Sc) && spd_small(ScN)) ? 1 : 0;
         }
         // ---- lean kernels (locp_lean.h): p_o = 2, diagonal input Hessians, n_u = 4 or 8 (the split-panel shapes too: the lean
         // kernels have no W panel; what they hand over goes to the split fused kernel);
@@ -346,6 +362,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             if (j0 >= 0 && j0 < N && ql::condense_fits(d, NTHREADS / 64) && lean_gram_schedule(N, m, d.KT, NTHREADS / 64, sched)) {
                 d.lean = 1;
                 d.lean_j0 = j0;
+
                 // rows next to their sums (ql::ipm_box): the reference's HyperRectangle layout of the input rows (rows 2 b,
                 // 2 b + 1 act on input b alone, utils.py:390-414), at most 8 state rows per stage, everything in 512 threads
                 bool box = pr->nU == 2 * m && !getenv("SRH_QP_NO_BOX");

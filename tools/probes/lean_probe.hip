@@ -3,6 +3,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I soft-robot-control_amd/csrc tools/probes/lean_probe.hip -o gpurun_variants/lean_probe
 #include "scp_host.h"
 #include "gram_chol_pipeline.h"
+#include "gram_exp.h"
 #include "g_times_pairs.h"
 #include "gT_times_fixed.h"
 #include <cstdio>
@@ -224,6 +225,17 @@ __global__ __launch_bounds__(512) void probe(QPDims d, QPConst c, QPDyn dyn, dou
     TIME(qpc::ls_apply<qpc::LS_TR>(d, L, L.yb, L.yc));                                         // 10
     { double v = tid; TIME(v = wg::reduce(v, 1, L.red)); if (v < 0) out[63] = 1; }           // 11
     TIME(__syncthreads());                                                                     // 12
+    {   // where the Gram fill's clocks go: parts switched off, per-wave clocks up to the first barrier (out[64 ..])
+        long long *wt = out + 64;
+        long long tg[5];
+        __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::gram_exp<PROBE_M, 0>(d, c, g, L, wt); __syncthreads(); tg[0] = (clock64() - t0) / REPS;
+        __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::gram_exp<PROBE_M, 1>(d, c, g, L, wt + 8); __syncthreads(); tg[1] = (clock64() - t0) / REPS;
+        __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::gram_exp<PROBE_M, 2>(d, c, g, L, wt + 16); __syncthreads(); tg[2] = (clock64() - t0) / REPS;
+        __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::gram_exp<PROBE_M, 4>(d, c, g, L, wt + 24); __syncthreads(); tg[3] = (clock64() - t0) / REPS;
+        __syncthreads(); t0 = clock64(); for (int r = 0; r < REPS; ++r) ql::gram_exp<PROBE_M, 7>(d, c, g, L, wt + 32); __syncthreads(); tg[4] = (clock64() - t0) / REPS;
+        if (tid == 0) for (int i = 0; i < 5; ++i) out[56 + i] = tg[i];
+        __syncthreads();
+    }
     TIME(ql::gram_chol<PROBE_M>(d, g, L));                                                        // 13
     TIME(ql::gram<PROBE_M>(d, c, g, L); qpc::tile_cholesky(d, L));                                // 14
     TIME(ql::unit_tiles(d, L));                                                                   // 15
@@ -330,12 +342,12 @@ int main() {
     for (int k = 0; k < N; ++k) idx[k] = (k / 8) % P;          // the region changes every 8 stages (12 % of the stages)
     double *dA, *dAT, *dB, *dBT, *dD, *dW, *dx0; int *dI; long long *dout;
     hipMalloc(&dA, Ad.size() * 8); hipMalloc(&dAT, Ad.size() * 8); hipMalloc(&dB, Bd.size() * 8); hipMalloc(&dBT, Bd.size() * 8);
-    hipMalloc(&dD, dd.size() * 8); hipMalloc(&dW, wk.size() * 8); hipMalloc(&dx0, n * 8); hipMalloc(&dI, N * 4); hipMalloc(&dout, 64 * 8);
+    hipMalloc(&dD, dd.size() * 8); hipMalloc(&dW, wk.size() * 8); hipMalloc(&dx0, n * 8); hipMalloc(&dI, N * 4); hipMalloc(&dout, 128 * 8);
     hipMemcpy(dA, Ad.data(), Ad.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dAT, AdT.data(), Ad.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dB, Bd.data(), Bd.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dBT, BdT.data(), Bd.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dD, dd.data(), dd.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dW, wk.data(), wk.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dx0, x0.data(), n * 8, hipMemcpyHostToDevice); hipMemcpy(dI, idx.data(), N * 4, hipMemcpyHostToDevice);
-    hipMemset(dout, 0, 64 * 8);
+    hipMemset(dout, 0, 128 * 8);
     QPDyn dyn{(cgptr)dA, (cgptr)dAT, (cgptr)dB, (cgptr)dBT, (cgptr)dD, (cgiptr)dI};
     const size_t lds = lean_kernel_lds_bytes(d);
     hipFuncSetAttribute((const void *)probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -344,7 +356,7 @@ int main() {
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(e)); return 1; }
     }
-    long long out[64];
+    long long out[128];
     hipMemcpy(out, dout, sizeof(out), hipMemcpyDeviceToHost);
     const char *names[] = {"g_times", "gT_times(1)", "gT_times(2)", "gram", "tile_cholesky", "k_solve", "stage_factors", "rollout", "condense",
                            "dinv_apply", "ls_apply", "wg::reduce", "barrier", "gram_chol", "gram+cholesky", "unit_tiles", "k_solve_unit", "chol 4 waves", "set sync (4 w)"};
@@ -355,6 +367,8 @@ int main() {
     printf("g_times_fixed: %lld clocks; vs g_times %.2e, half set vs whole workgroup %.2e\n", out[22], ((double *)out)[44], ((double *)out)[45]);
     printf("gT_times_fixed: %lld / %lld clocks (one / two right-hand sides); vs gT_times %.2e, half set vs whole workgroup %.2e\n", out[23], out[24], ((double *)out)[46], ((double *)out)[47]);
     printf("tile_cholesky_set (4 waves, LDS counters) vs qpc::tile_cholesky: max |d| %.2e\n", ((double *)out)[41]);
+    printf("gram_exp: full %lld, no head %lld, no epilogue %lld, no LDS ranges %lld, none of the three %lld clocks\n", out[56], out[57], out[58], out[59], out[60]);
+    for (int v = 0; v < 5; ++v) { printf("  per-wave clocks to the first barrier (variant %d):", v); for (int w8 = 0; w8 < 8; ++w8) printf(" %lld", out[64 + 8 * v + w8]); printf("\n"); }
     printf("gram_chol vs gram + tile_cholesky: max |dR| %.2e max |dRinv| %.2e max |dks| %.2e ok flags %.0f (3 = both)\n", ((double *)out)[37], ((double *)out)[38],
            ((double *)out)[39], ((double *)out)[40]);
     return 0;
