@@ -211,7 +211,9 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
             for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = w.x[e];
             for (int e = tid; e < N * m; e += nt) uk[e] = w.u[e];
             __syncthreads();
-            if (par.max_iters >= 1) tpwl::nearest_many(T, xk, n, N, idx);
+            // the nearest points of the accepted trajectory are the ones the model-accuracy test found for it above (idx2 of
+            // w.x, same function, same data: gusto.py:466 recomputes them)
+            if (par.max_iters >= 1) { for (int k = tid; k < N; k += nt) idx[k] = idx2[k]; __syncthreads(); }
         }
         GU_LAP(7);
     }
