@@ -796,11 +796,16 @@ __device__ __forceinline__ void k_solve_unit(const QPDims &d, Lds &L, lptr v) {
 //   front (needs the gradients, D, Ls and the scaling ks of K -- NOT the factor): t = -D^-1 (g_u + G^T g_y), the reduced dual
 //          residual max |g_ud + G^T g_yd| when gyd != null (into L.Qu[0]), yc = ks Ls^T G t;  runs on any wave set
 //   back  (needs the factor): v = K^-1 yc, du = t - D^-1 G^T Ls ks v, dy = G du
+// keep_gt / reuse_gt (problems without state rows: the y-space gradient g_y = L.ya is the cost's alone and does not change between
+// the predictor and the corrector of an iteration): the predictor leaves G^T g_y in L.tb (free once the dual residual has been
+// taken), the corrector reads it there instead of repeating the product.
 template <int MSEL, bool HALF, class GP>
-__device__ __forceinline__ void newton_front(const QPDims &d, const GP &g, Lds &L, clptr gyd, Waves<HALF> &W, Prof &pf) {
+__device__ __forceinline__ void newton_front(const QPDims &d, const GP &g, Lds &L, clptr gyd, Waves<HALF> &W, Prof &pf,
+                                             bool keep_gt = false, bool reuse_gt = false) {
     const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = W.tid, nt = W.nt;
     QC_SUB(pf, 8);
-    gT_times<MSEL, HALF>(d, g, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr, W);
+    if (!reuse_gt) gT_times<MSEL, HALF>(d, g, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr, W);
+    clptr gty = reuse_gt ? (clptr)L.tb : (clptr)L.du;
     QC_SUB(pf, 9);
     if (gyd) {
         double r = 0.0;
@@ -808,7 +813,11 @@ __device__ __forceinline__ void newton_front(const QPDims &d, const GP &g, Lds &
         r = wg::wave_max(r);
         if ((tid & 63) == 0) L.red[W.wave] = r;
     }
-    for (int e = tid; e < nm; e += nt) { const double sd = L.Ldi[e]; L.ta[e] = -(L.ta[e] + L.du[e]) * (sd * sd); }       // t = -D^-1 g (diagonal D)
+    for (int e = tid; e < nm; e += nt) {                                                                            // t = -D^-1 g (diagonal D)
+        const double sd = L.Ldi[e], gt = gty[e];
+        L.ta[e] = -(L.ta[e] + gt) * (sd * sd);
+        if (keep_gt) L.tb[e] = gt;
+    }
     W.sync();
     if (gyd && tid == 0) { double r = L.red[0]; for (int i = 1; i < W.nw; ++i) r = fmax(r, L.red[i]); L.Qu[0] = r; }
     QC_SUB(pf, 10);
@@ -864,9 +873,9 @@ __device__ __forceinline__ void newton_back(const QPDims &d, const GP &g, Lds &L
 
 // the whole solve on the whole workgroup (the general-row interior point; corrector solves)
 template <int MSEL, class GP>
-__device__ __forceinline__ void newton_solve(const QPDims &d, const GP &g, Lds &L, clptr gyd, double *rd, Prof &pf) {
+__device__ __forceinline__ void newton_solve(const QPDims &d, const GP &g, Lds &L, clptr gyd, double *rd, Prof &pf, bool reuse_gt = false) {
     auto W = all_waves();
-    newton_front<MSEL, false>(d, g, L, gyd, W, pf);
+    newton_front<MSEL, false>(d, g, L, gyd, W, pf, false, reuse_gt);
     if (gyd) *rd = L.Qu[0];
     newton_back<MSEL>(d, g, L, pf);
 }
@@ -1232,6 +1241,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     int mode = INIT;
     double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
     bool near_opt = false;
+    const bool ya_const = d.nX + d.nXf == 0;                  // no state rows: L.ya is the same in the predictor and the corrector (newton_front)
     auto scales = [&]() {                                     // residual scales and the dual regularisation (once per QP)
         for (int e = tid; e < d.n; e += nt) {
             double gq = 0.0;
@@ -1346,7 +1356,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
                 if (tid == 0) L.Qu[2] = (double)(clock64() - tsplit);
 #endif
             } else {
-                newton_front<MSEL, true>(d, g, L, gyd, W, pf);
+                newton_front<MSEL, true>(d, g, L, gyd, W, pf, ya_const && mode == PRED);
 #ifdef SRH_PROFILE
                 if (W.tid == 0) L.Qu[3] = (double)(clock64() - tsplit);
 #endif
@@ -1368,7 +1378,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 #ifdef SRH_PROFILE
             pf.last = clock64();
 #endif
-            newton_solve<MSEL>(d, g, L, (clptr) nullptr, &rd, pf);
+            newton_solve<MSEL>(d, g, L, (clptr) nullptr, &rd, pf, ya_const);
         }
         QB_LAP(6);
         // ---------------- use the direction
