@@ -90,11 +90,13 @@ def condense(p, Co):
 WARM_FLOOR = 1e-2      # warm start: slacks and multipliers are pushed at least this far from zero (kernel: locp_lean.h, twin: cond_solve)
 
 
-def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbose=False, warm=None):
+def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbose=False, warm=None, dy_from_system=True):
     """The QP of `p` (riccati_ipm.Problem) WITHOUT its trust-region rows.  Returns x, u, J (objective without the
     omega * s term), info (iters, status, `inside`: whether the minimiser satisfies the trust region of p, and `final`:
     the last iterate (u, slacks, multipliers)).
 
+    dy_from_system = False keeps the product dy = G du (what the kernels do when a constant output block is only semi-definite;
+    tests compare the two forms).
     warm = the `final` of the previous QP of the same SCP solve (round 4): the interior point then starts from that
     point instead of Mehrotra's -- u as it is, every slack t = max(-g(u), WARM_FLOOR) from the row values of THIS QP, every
     multiplier max(lambda_prev, WARM_FLOOR) -- and skips the initial Newton system.  Successive QPs of an SCP solve differ
@@ -154,7 +156,7 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbos
     # itself (round 4; kernels: ql::newton_back / qpc::newton_solve, twin: direction_y) -- with w = ks v the output-space system
     # reads (I + Ls^T Ky Ls) w = Ls^T G t, Ky = G D^-1 G^T, hence G du = G t - Ky Ls w = Ls^-T w: no second product with G, and
     # the error of the K solve is not multiplied by K on its way into dy
-    ls_pd = newton == 'output' and refine == 0 and spd_small(Sc) and spd_small(ScN)
+    ls_pd = dy_from_system and newton == 'output' and refine == 0 and spd_small(Sc) and spd_small(ScN)
     last = {}
 
     def direction_y(du):
@@ -321,7 +323,7 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbos
             status = 'failed'
             break
     if warm is not None and status != 'optimal':
-        return solve(p, tol, max_iter, reg, newton, refine, verbose, warm=None)       # a warm start that stalls: again from Mehrotra's point
+        return solve(p, tol, max_iter, reg, newton, refine, verbose, warm=None, dy_from_system=dy_from_system)       # a warm start that stalls: again from Mehrotra's point
     res = finish(u, it, status, mu)
     res[3]['final'] = dict(u=u.copy(), lx=lx, lu=lu)
     res[3]['warm'] = warm is not None

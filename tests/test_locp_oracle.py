@@ -127,3 +127,21 @@ def test_condensed_ipm_reports_a_minimiser_outside_the_trust_region():
     args = [kw.pop(k) for k in ('N', 'H', 'Qz', 'R', 'Ad', 'Bd', 'dd', 'x0', 'xk', 'delta', 'omega')]
     x, u, J, info = cipm.solve(ripm.Problem(*args, **kw))
     assert info['status'] == 'optimal' and not info['inside']      # -> the full stage-wise solve takes over
+
+
+@pytest.mark.parametrize('name', ['box_X', 'box_only_tr_loose', 'terminal_cost'])
+def test_condensed_ipm_direction_from_the_solved_system(name):
+    """Round 4: dy = G du is read off the solved output-space system (dy_k = Ls_k^-T w_k) instead of a second product with G
+    (condensed_ipm.direction_y; kernels: ql::newton_back, qpc::newton_solve; twin: direction_y).  Both forms are the same Newton
+    direction: same minimiser, iteration counts within two of each other (the product form passes the K-solve error through K)."""
+    from oracle import condensed_ipm as cipm
+    case, _ = make_case(**CASES[name])
+    kw = dict(case)
+    args = [kw.pop(k) for k in ('N', 'H', 'Qz', 'R', 'Ad', 'Bd', 'dd', 'x0', 'xk', 'delta', 'omega')]
+    sp = ripm.Problem(*args, **kw)
+    xa, ua, Ja, ia = cipm.solve(sp)
+    xb, ub, Jb, ib = cipm.solve(sp, dy_from_system=False)
+    assert ia['status'] == ib['status'] == 'optimal'
+    assert abs(ia['iters'] - ib['iters']) <= 2
+    assert np.abs(xa - xb).max() <= 1e-8 * np.abs(xb).max() and np.abs(ua - ub).max() <= 1e-8 * max(1.0, np.abs(ub).max())
+    assert abs(Ja - Jb) <= 1e-10 * abs(Jb)
