@@ -113,10 +113,78 @@ __device__ inline void inverse(lptr M, lptr Minv, int n, int ld, liptr piv) {
     }
 }
 
+// The same elimination executed by ONE wave (n <= 64): the steps of `inverse` are separated by workgroup barriers -- six per
+// pivot, ~450 clocks each with eight waves, 54 k clocks per backward-Euler discretisation of a 10 x 10 model (two inverses), 70 %
+// of an iLQR forward step on the C3 shape -- while a 10 x 10 matrix has no work for more than one wave anyway.  Here the phases
+// are ordered by the wave's own LDS queue (in order per wave) plus a fence for the compiler; every element goes through the same
+// operations in the same order as in `inverse` (bit-identical results), and two matrices can be inverted side by side on two
+// waves.  Pivot: first maximum of |M[i][k]|, i >= k, as the sequential scan of `inverse`.
+__device__ inline void inverse_wave(lptr M, lptr Minv, int n, int ld) {
+    const int lane = threadIdx.x & 63;
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (int e = lane; e < n * n; e += 64) Minv[(e / n) * ld + e % n] = (e / n == e % n) ? 1.0 : 0.0;
+    wsync();
+    constexpr int EP = 4;                                          // elements per lane in the elimination: n * n <= 256
+    for (int k = 0; k < n; ++k) {
+        const bool cand = lane >= k && lane < n;
+        const double v = cand ? fabs(M[lane * ld + k]) : -1.0;
+        const double mx = wg::wave_max(v);
+        const unsigned long long hit = __ballot(cand && v == mx);
+        const int p = hit ? __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1) : k;
+        // rows k and p change places while row k is scaled: lane j reads both entries of its column, divides the pivot
+        // row's by d (read by every lane before anything is written), and writes them back swapped
+        const double d = M[p * ld + k];
+        {
+            const int jc = lane < n ? lane : 0;
+            const double mp = M[p * ld + jc], ip = Minv[p * ld + jc], mk = M[k * ld + jc], ik = Minv[k * ld + jc];
+            wsync();
+            if (lane < n) {
+                M[k * ld + jc] = mp / d; Minv[k * ld + jc] = ip / d;
+                if (p != k) { M[p * ld + jc] = mk; Minv[p * ld + jc] = ik; }
+            }
+        }
+        wsync();
+        // eliminate column k from the other rows and clear it: every lane reads what it needs (multiplier, pivot row, own
+        // entries) before the first write of the phase
+        if (n * n <= 64 * EP) {
+            double f[EP], rk[EP], ri[EP], om[EP], oi[EP];
+#pragma unroll
+            for (int q = 0; q < EP; ++q) {
+                const int e = lane + 64 * q, ec = e < n * n ? e : 0, i2 = ec / n, j2 = ec % n;
+                f[q] = M[i2 * ld + k]; rk[q] = M[k * ld + j2]; ri[q] = Minv[k * ld + j2]; om[q] = M[i2 * ld + j2]; oi[q] = Minv[i2 * ld + j2];
+            }
+            wsync();
+#pragma unroll
+            for (int q = 0; q < EP; ++q) {
+                const int e = lane + 64 * q, i2 = e / n, j2 = e % n;
+                if (e < n * n && i2 != k) {
+                    Minv[i2 * ld + j2] = fma(-f[q], ri[q], oi[q]);
+                    M[i2 * ld + j2] = j2 != k ? fma(-f[q], rk[q], om[q]) : 0.0;
+                }
+            }
+        } else {
+            for (int e = lane; e < n * n; e += 64) {
+                const int i2 = e / n, j2 = e % n;
+                if (i2 == k) continue;
+                const double f = M[i2 * ld + k];
+                Minv[i2 * ld + j2] = fma(-f, Minv[k * ld + j2], Minv[i2 * ld + j2]);
+                if (j2 != k) M[i2 * ld + j2] = fma(-f, M[k * ld + j2], M[i2 * ld + j2]);
+            }
+            wsync();
+            for (int i2 = lane; i2 < n; i2 += 64) if (i2 != k) M[i2 * ld + k] = 0.0;
+        }
+        wsync();
+    }
+}
+
 struct Work {
     lptr phi;      // max(nr, ns)
     lptr D;        // max(nr * n, ns * no)
-    lptr M1, M2, M3;   // n x ld each (discretisation scratch)
+    lptr M1, M2, M3, M4;   // n x ld each (discretisation scratch)
     lptr f;        // n
     liptr piv;
 };
@@ -125,7 +193,7 @@ __host__ __device__ inline size_t work_doubles(int n, int m, int no, int nr, int
     const int ld = n | 1;
     const size_t nb = (size_t)(nr > ns ? nr : ns);
     const size_t nd = (size_t)nr * n > (size_t)ns * no ? (size_t)nr * n : (size_t)ns * no;
-    return nb + nd + 3 * (size_t)n * ld + n + 4;
+    return nb + nd + 4 * (size_t)n * ld + n + 4;
 }
 
 __device__ inline void carve(Work &w, lptr base, const SsmDev &S) {
@@ -133,7 +201,8 @@ __device__ inline void carve(Work &w, lptr base, const SsmDev &S) {
     const size_t nb = (size_t)(S.nr > S.ns ? S.nr : S.ns);
     const size_t nd = (size_t)S.nr * S.n > (size_t)S.ns * S.no ? (size_t)S.nr * S.n : (size_t)S.ns * S.no;
     w.phi = base; w.D = w.phi + nb; w.M1 = w.D + nd; w.M2 = w.M1 + (size_t)S.n * ld; w.M3 = w.M2 + (size_t)S.n * ld;
-    w.f = w.M3 + (size_t)S.n * ld;
+    w.M4 = w.M3 + (size_t)S.n * ld;
+    w.f = w.M4 + (size_t)S.n * ld;
     w.piv = (liptr)(w.f + S.n + 2);
 }
 
@@ -191,7 +260,16 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
         w.M3[i * ld + j] = A[i * lda + j];
     }
     __syncthreads();
-    inverse(w.M1, w.M2, n, ld, w.piv);                           // M2 = inv(I - h A)
+    // M2 = inv(I - h A) and M4 = inv(A_c): independent, one wave each (a single-wave workgroup does them in turn)
+    if (n <= 64) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x + 63) >> 6;
+        if (wave == 0) inverse_wave(w.M1, w.M2, n, ld);
+        if (wave == (nw > 1 ? 1 : 0)) inverse_wave(w.M3, w.M4, n, ld);
+        __syncthreads();
+    } else {
+        inverse(w.M1, w.M2, n, ld, w.piv);
+        inverse(w.M3, w.M4, n, ld, w.piv);
+    }
     if (mode == SSM_BIL) {
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e % n;
@@ -203,11 +281,10 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
         for (int e = tid; e < n * n; e += nt) w.M2[(e / n) * ld + e % n] = w.M1[(e / n) * ld + e % n];
         __syncthreads();
     }
-    inverse(w.M3, w.M1, n, ld, w.piv);                           // M1 = inv(A_c)
     for (int e = tid; e < n * n; e += nt) {                      // M3 = sep = inv(A_c) (A_d - I)
         const int i = e / n, j = e % n;
         double s = 0.0;
-        for (int k = 0; k < n; ++k) s = fma(w.M1[i * ld + k], w.M2[k * ld + j] - (k == j ? 1.0 : 0.0), s);
+        for (int k = 0; k < n; ++k) s = fma(w.M4[i * ld + k], w.M2[k * ld + j] - (k == j ? 1.0 : 0.0), s);
         w.M3[i * ld + j] = s;
     }
     __syncthreads();
