@@ -436,6 +436,42 @@ def secondary(L, _lib, rank, world, dist):
                                   '(PCIe copies inside the time); best of 3 calls' % Bn,
                       'iterations_per_s': float(il.iters.sum()) / t, 'ms': t * 1e3, 'ms_all_calls': [x * 1e3 for x in ts],
                       'iterations': int(il.iters.sum())}
+    # ---- iLQR on the Diamond TPWL model of the headline configuration (the north star names "the reference CPU SCP/iLQR solve on the
+    # Diamond robot (r = 30, horizon = 50)"; lqr/ilqr.py:27-300 through examples/diamond/diamond.py:190-230): one problem at a time
+    # (the controller's use) and 256 problems in one launch; parity: tests/test_lqr_gpu.py
+    try:
+        wd = wl.diamond_c2()
+        tpd, _ = build_model(wd, 1354)
+        Nd, md, rd, dtd = wd['N'], wd['m'], wd['r'], wd['dt']
+        romd = None
+        Xs = wl.snapshots(wd['q_ref'], 256, seed=2)
+        from sofacontrol_amd.mor.pod import POD
+        romd = POD(dict(U=wd['U'], q_ref=wd['q_ref'], v_ref=wd['v_ref']))
+        x0d = np.concatenate((np.zeros((256, rd)), romd.compute_RO_state(qf=Xs)), axis=1)
+        zr = np.asarray(tpd.z_ref) if getattr(tpd, 'z_ref', None) is not None else np.zeros(6)
+        ztd = wd['z'][:Nd + 1] + zr
+        ild = iLQR(dtd, tpd, QuadraticCost(Q=wd['Qz'], R=1e-3 * np.eye(md), Qf=10 * wd['Qz']), Nd)
+        ild.set_target(ztd)
+        ild.ilqr_computation(x0d[0])
+        per = []
+        for b in range(8):
+            t0 = time.perf_counter()
+            ild.ilqr_computation(x0d[32 * b])
+            per.append((time.perf_counter() - t0) * 1e3 / max(1, int(np.atleast_1d(ild.iters)[0])))
+        per.sort()
+        ild.ilqr_computation(x0d)
+        tb = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ild.ilqr_computation(x0d)
+            tb.append(time.perf_counter() - t0)
+        out['ilqr_diamond'] = {'workload': 'Diamond TPWL (workloads.diamond_c2: n_x = 60, n_u = 4, P = 64), iLQR horizon %d, dt = %g, figure-8 target, '
+                                           'R = 1e-3 I, Qf = 10 Qz; host buffers' % (Nd, dtd),
+                               'ms_per_iteration_one_problem_median': per[4], 'ms_per_iteration_one_problem_min_max': [per[0], per[-1]],
+                               'batch_256_ms': min(tb) * 1e3, 'batch_256_ms_all_calls': [t * 1e3 for t in tb],
+                               'batch_256_iterations': int(ild.iters.sum()), 'batch_256_iterations_per_s': float(ild.iters.sum()) / min(tb)}
+    except Exception as exc:                      # a secondary measurement never takes the line down
+        out['ilqr_diamond'] = {'error': repr(exc)}
     # ---- the reference's real-time hardware driver: SSM + GuSTO as a real-time iteration (examples/hardware/diamond_SSM.py:
     # 193, 218, 359-361: n_x = 6, n_u = 4, N = 3, dt = 0.02, max_gusto_iters = 0, replanned every 2 steps = 40 ms)
     try:
