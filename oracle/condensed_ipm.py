@@ -271,57 +271,60 @@ def solve(p, tol=1e-12, max_iter=60, reg=1e-8, newton='output', refine=0, verbos
     def maxstep(v, dv):
         neg = dv < 0
         return float(np.min(-v[neg] / dv[neg])) if neg.any() else np.inf
-    for it in range(max_iter):
-        gx, gu = row_vals(u, y)
-        rgx = [None] + [gx[k] + tx[k] for k in range(1, N + 1)]
-        rgu = [gu[k] + tu[k] for k in range(N)]
-        mu = (sum(float(lx[k] @ tx[k]) for k in range(1, N + 1)) + sum(float(lu[k] @ tu[k]) for k in range(N))) / ng
-        ex = [None] + [tx[k] + dreg * lx[k] for k in range(1, N + 1)]
-        eu = [tu[k] + dreg * lu[k] for k in range(N)]
-        Dx = [None] + [lx[k] / ex[k] for k in range(1, N + 1)]
-        Du = [lu[k] / eu[k] for k in range(N)]
-        rhox = [None] + [lx[k] + (lx[k] * rgx[k] - lx[k] * tx[k]) / ex[k] for k in range(1, N + 1)]
-        rhou = [lu[k] + (lu[k] * rgu[k] - lu[k] * tu[k]) / eu[k] for k in range(N)]
-        rd = float(np.abs(grad_parts(u, y, lx, lu)).max())
-        rp = float(np.abs(cat(rgx, rgu)).max())
-        if verbose:
-            print(it, 'rd %.3e rp %.3e mu %.3e' % (rd, rp, mu))
-        if rd <= max(tol, 1e-9) * scale_d and rp <= max(tol, 1e-9) * scale_p and mu <= tol:
-            status = 'optimal'
-            break
-        du = newton_solve(Du, Dx, -grad_parts(u, y, rhox, rhou)).reshape(N, m)
-        dy = direction_y(du)
-        ax, au = row_dirs(du, dy)
-        dlx = [None] + [(-lx[k] * tx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
-        dlu = [(-lu[k] * tu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]
-        dtx = [None] + [-rgx[k] - ax[k] + dreg * dlx[k] for k in range(1, N + 1)]
-        dtu = [-rgu[k] - au[k] + dreg * dlu[k] for k in range(N)]
-        T, DT, Lm, DL = cat(tx, tu), cat(dtx, dtu), cat(lx, lu), cat(dlx, dlu)
-        a_aff = min(1.0, maxstep(T, DT), maxstep(Lm, DL))
-        mu_aff = float((Lm + a_aff * DL) @ (T + a_aff * DT)) / ng
-        sigma = (mu_aff / mu) ** 3 if mu > 0 else 0.0
-        rcx = [None] + [lx[k] * tx[k] + dtx[k] * dlx[k] - sigma * mu for k in range(1, N + 1)]
-        rcu = [lu[k] * tu[k] + dtu[k] * dlu[k] - sigma * mu for k in range(N)]
-        rhox = [None] + [lx[k] + (lx[k] * rgx[k] - rcx[k]) / ex[k] for k in range(1, N + 1)]
-        rhou = [lu[k] + (lu[k] * rgu[k] - rcu[k]) / eu[k] for k in range(N)]
-        du = newton_solve(Du, Dx, -grad_parts(u, y, rhox, rhou)).reshape(N, m)
-        dy = direction_y(du)
-        ax, au = row_dirs(du, dy)
-        dlx = [None] + [(-rcx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
-        dlu = [(-rcu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]
-        dtx = [None] + [-rgx[k] - ax[k] + dreg * dlx[k] for k in range(1, N + 1)]
-        dtu = [-rgu[k] - au[k] + dreg * dlu[k] for k in range(N)]
-        T, DT, Lm, DL = cat(tx, tu), cat(dtx, dtu), cat(lx, lu), cat(dlx, dlu)
-        a = min(1.0, 0.99 * min(maxstep(T, DT), maxstep(Lm, DL)))
-        u = u + a * du
-        y = y + a * dy
-        tx = [None] + [tx[k] + a * dtx[k] for k in range(1, N + 1)]
-        tu = [tu[k] + a * dtu[k] for k in range(N)]
-        lx = [None] + [lx[k] + a * dlx[k] for k in range(1, N + 1)]
-        lu = [lu[k] + a * dlu[k] for k in range(N)]
-        if not np.isfinite(mu):
-            status = 'failed'
-            break
+    try:                                  # a factorisation numpy refuses (non-finite or indefinite system) = the kernels' status 2
+        for it in range(max_iter):
+            gx, gu = row_vals(u, y)
+            rgx = [None] + [gx[k] + tx[k] for k in range(1, N + 1)]
+            rgu = [gu[k] + tu[k] for k in range(N)]
+            mu = (sum(float(lx[k] @ tx[k]) for k in range(1, N + 1)) + sum(float(lu[k] @ tu[k]) for k in range(N))) / ng
+            ex = [None] + [tx[k] + dreg * lx[k] for k in range(1, N + 1)]
+            eu = [tu[k] + dreg * lu[k] for k in range(N)]
+            Dx = [None] + [lx[k] / ex[k] for k in range(1, N + 1)]
+            Du = [lu[k] / eu[k] for k in range(N)]
+            rhox = [None] + [lx[k] + (lx[k] * rgx[k] - lx[k] * tx[k]) / ex[k] for k in range(1, N + 1)]
+            rhou = [lu[k] + (lu[k] * rgu[k] - lu[k] * tu[k]) / eu[k] for k in range(N)]
+            rd = float(np.abs(grad_parts(u, y, lx, lu)).max())
+            rp = float(np.abs(cat(rgx, rgu)).max())
+            if verbose:
+                print(it, 'rd %.3e rp %.3e mu %.3e' % (rd, rp, mu))
+            if rd <= max(tol, 1e-9) * scale_d and rp <= max(tol, 1e-9) * scale_p and mu <= tol:
+                status = 'optimal'
+                break
+            du = newton_solve(Du, Dx, -grad_parts(u, y, rhox, rhou)).reshape(N, m)
+            dy = direction_y(du)
+            ax, au = row_dirs(du, dy)
+            dlx = [None] + [(-lx[k] * tx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
+            dlu = [(-lu[k] * tu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]
+            dtx = [None] + [-rgx[k] - ax[k] + dreg * dlx[k] for k in range(1, N + 1)]
+            dtu = [-rgu[k] - au[k] + dreg * dlu[k] for k in range(N)]
+            T, DT, Lm, DL = cat(tx, tu), cat(dtx, dtu), cat(lx, lu), cat(dlx, dlu)
+            a_aff = min(1.0, maxstep(T, DT), maxstep(Lm, DL))
+            mu_aff = float((Lm + a_aff * DL) @ (T + a_aff * DT)) / ng
+            sigma = (mu_aff / mu) ** 3 if mu > 0 else 0.0
+            rcx = [None] + [lx[k] * tx[k] + dtx[k] * dlx[k] - sigma * mu for k in range(1, N + 1)]
+            rcu = [lu[k] * tu[k] + dtu[k] * dlu[k] - sigma * mu for k in range(N)]
+            rhox = [None] + [lx[k] + (lx[k] * rgx[k] - rcx[k]) / ex[k] for k in range(1, N + 1)]
+            rhou = [lu[k] + (lu[k] * rgu[k] - rcu[k]) / eu[k] for k in range(N)]
+            du = newton_solve(Du, Dx, -grad_parts(u, y, rhox, rhou)).reshape(N, m)
+            dy = direction_y(du)
+            ax, au = row_dirs(du, dy)
+            dlx = [None] + [(-rcx[k] + lx[k] * (rgx[k] + ax[k])) / ex[k] for k in range(1, N + 1)]
+            dlu = [(-rcu[k] + lu[k] * (rgu[k] + au[k])) / eu[k] for k in range(N)]
+            dtx = [None] + [-rgx[k] - ax[k] + dreg * dlx[k] for k in range(1, N + 1)]
+            dtu = [-rgu[k] - au[k] + dreg * dlu[k] for k in range(N)]
+            T, DT, Lm, DL = cat(tx, tu), cat(dtx, dtu), cat(lx, lu), cat(dlx, dlu)
+            a = min(1.0, 0.99 * min(maxstep(T, DT), maxstep(Lm, DL)))
+            u = u + a * du
+            y = y + a * dy
+            tx = [None] + [tx[k] + a * dtx[k] for k in range(1, N + 1)]
+            tu = [tu[k] + a * dtu[k] for k in range(N)]
+            lx = [None] + [lx[k] + a * dlx[k] for k in range(1, N + 1)]
+            lu = [lu[k] + a * dlu[k] for k in range(N)]
+            if not np.isfinite(mu):
+                status = 'failed'
+                break
+    except np.linalg.LinAlgError:
+        status = 'failed'
     if warm is not None and status != 'optimal':
         return solve(p, tol, max_iter, reg, newton, refine, verbose, warm=None, dy_from_system=dy_from_system)       # a warm start that stalls: again from Mehrotra's point
     res = finish(u, it, status, mu)

@@ -110,3 +110,47 @@ def test_gusto_loop_matches_numpy_loop():
         assert int(iters[b]) == len(tr)
         np.testing.assert_allclose(trace[b, :len(tr), :3], np.array([t[:3] for t in tr]), rtol=1e-6)
         assert rel(xo[b], xe) <= 1e-4 and rel(uo[b], ue) <= 1e-4
+
+
+def test_gusto_loop_warm_started_qps_follow_the_cold_started_loop():
+    """Round 4: inside one GuSTO solve every QP after the first starts from the previous QP's minimiser and multipliers
+    (oracle.gusto: warm_start_qp, default on; the twin and the lean kernels do the same).  The SCP loop it drives is the one the
+    cold-started QPs drive -- same iteration counts, same (J, delta, omega) trace, trajectories to 1e-6 -- with fewer interior-point
+    iterations, and the native twin follows the numpy statement."""
+    model = otpwl.synthetic_model(4, 3, 7, seed=30)
+    model['q'] = model['q'] * 0.05
+    dt, N = 0.05, 12
+    Ad, Bd, dd = otpwl.pre_discretize(model, dt, 'zoh')
+    H = otpwl.synthetic_output_matrix(4, 6, 31)
+    Qz = np.diag([0, 0, 0, 100., 100., 0]); R = 1e-5 * np.eye(3)
+    th = np.linspace(0, 1.5, N + 1)
+    z = np.zeros((N + 1, 6)); z[:, 3] = -0.15 * np.sin(th); z[:, 4] = 0.075 * np.sin(2 * th)
+    UA = np.kron(np.eye(3), np.array([[1.], [-1.]])); Ub = np.tile([800., 0.], 3)
+    xc, fc = otpwl.characteristic_vals(model)
+    x0 = 1e-3 * np.random.default_rng(2).standard_normal(8)
+    u_init = np.zeros((N, 3))
+    x_init = otpwl.rollout(model, Ad, Bd, dd, x0, u_init)
+    counts = {}
+    orig = cipm.solve
+
+    def counting(p, **kw):
+        out = orig(p, **kw)
+        counts[key].append(out[3]['iters'])
+        return out
+    res = {}
+    cipm.solve = counting
+    try:
+        for key, flag in (('warm', True), ('cold', False)):
+            counts[key] = []
+            res[key] = ogusto.solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=z, U=(UA, Ub), x_char=xc, f_char=fc,
+                                    convg_thresh=1e-3, max_gusto_iters=8, qp_solver='condensed_ipm', warm_start_qp=flag)
+    finally:
+        cipm.solve = orig
+    (xw, uw, _, tw), (xc_, uc_, _, tc) = res['warm'], res['cold']
+    assert len(tw) == len(tc) >= 2
+    np.testing.assert_allclose(np.array([t[:3] for t in tw]), np.array([t[:3] for t in tc]), rtol=1e-6)
+    assert rel(xw, xc_) <= 1e-6 and rel(uw, uc_) <= 1e-6
+    assert counts['warm'][0] == counts['cold'][0] and sum(counts['warm']) < sum(counts['cold'])
+    xo, uo, iters, trace = cpu_twin.gusto_solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0[None], u_init[None], x_init[None], z=z[None], U=(UA, Ub),
+                                                x_char=xc, f_char=fc, convg_thresh=1e-3, max_gusto_iters=8, threads=1, max_trace=16, algo='condensed')
+    assert int(iters[0]) == len(tw) and rel(xo[0], xw) <= 1e-8 and rel(uo[0], uw) <= 1e-8

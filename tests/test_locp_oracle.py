@@ -145,3 +145,38 @@ def test_condensed_ipm_direction_from_the_solved_system(name):
     assert abs(ia['iters'] - ib['iters']) <= 2
     assert np.abs(xa - xb).max() <= 1e-8 * np.abs(xb).max() and np.abs(ua - ub).max() <= 1e-8 * max(1.0, np.abs(ub).max())
     assert abs(Ja - Jb) <= 1e-10 * abs(Jb)
+
+
+def _problem(name, **over):
+    case, extra = make_case(**dict(CASES[name], **over))
+    kw = dict(case)
+    args = [kw.pop(k) for k in ('N', 'H', 'Qz', 'R', 'Ad', 'Bd', 'dd', 'x0', 'xk', 'delta', 'omega')]
+    return ripm.Problem(*args, **kw)
+
+
+def test_condensed_ipm_warm_start_same_minimiser_fewer_iterations():
+    """Round 4 (condensed_ipm.solve(warm=), the rule the lean kernels and the CPU twin follow): a QP started from the minimiser and
+    multipliers of a neighbouring QP -- here the same horizon with a slightly different target amplitude, as between two SCP
+    iterations -- reaches the same minimiser in fewer interior-point iterations; info['warm'] says which start produced the result."""
+    from oracle import condensed_ipm as cipm
+    xa, ua, Ja, ia = cipm.solve(_problem('box_X'))
+    pb = _problem('box_X', amp=0.16)
+    xc, uc, Jc, ic = cipm.solve(pb)
+    xw, uw, Jw, iw = cipm.solve(pb, warm=ia['final'])
+    assert ia['status'] == ic['status'] == iw['status'] == 'optimal' and iw['warm'] and not ic['warm']
+    assert iw['iters'] < ic['iters']
+    assert np.abs(xw - xc).max() <= 1e-7 * np.abs(xc).max() and np.abs(uw - uc).max() <= 1e-7 * max(1.0, np.abs(uc).max())
+    assert abs(Jw - Jc) <= 1e-9 * abs(Jc)
+
+
+def test_condensed_ipm_warm_start_that_fails_is_repeated_cold():
+    """A warm start the interior point cannot use (non-finite multipliers: the iteration stops as 'failed') must not be the answer:
+    the solve is repeated from Mehrotra's point and says so."""
+    from oracle import condensed_ipm as cipm
+    p = _problem('box_X')
+    xc, uc, Jc, ic = cipm.solve(p)
+    bad = dict(u=ic['final']['u'].copy(), lx=[None] + [np.full_like(l, np.nan) for l in ic['final']['lx'][1:]],
+               lu=[np.full_like(l, np.nan) for l in ic['final']['lu']])
+    xw, uw, Jw, iw = cipm.solve(p, warm=bad)
+    assert iw['status'] == 'optimal' and not iw['warm'] and iw['iters'] == ic['iters']
+    assert np.array_equal(xw, xc) and np.array_equal(uw, uc)
