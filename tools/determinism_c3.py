@@ -27,3 +27,13 @@ for discr in ('be', 'bil'):
         x, u, K = il.ilqr_computation(c3['x0'])
         bad.append((float(np.abs(x - first[0]).max()), float(np.abs(u - first[1]).max()), float(np.abs(K - first[2]).max()), int((il.iters != first[3]).sum())))
     print(discr, 'max differences over 10 repeated solves of 256 problems (x, u, K, iteration counts):', max(b[0] for b in bad), max(b[1] for b in bad), max(b[2] for b in bad), max(b[3] for b in bad))
+    # --dump file.npz / --compare file.npz: the results of another build of the library, bit for bit
+    for flag in ('--dump', '--compare'):
+        if flag in sys.argv:
+            f = sys.argv[sys.argv.index(flag) + 1].replace('.npz', '_%s.npz' % discr)
+            if flag == '--dump':
+                np.savez(f, x=first[0], u=first[1], K=first[2], iters=first[3])
+            else:
+                g = np.load(f)
+                print(discr, 'against', f, ': max |dx| %.3e |du| %.3e |dK| %.3e, iteration counts differ in %d problems' %
+                      (np.abs(g['x'] - first[0]).max(), np.abs(g['u'] - first[1]).max(), np.abs(g['K'] - first[2]).max(), int((g['iters'] != first[3]).sum())))
