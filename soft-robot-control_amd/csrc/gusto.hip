@@ -330,7 +330,8 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
     if (rc) { delete pl; return rc; }
     QPDims &d = pl->C.dims;
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
-                       par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace};
+                       par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace,
+                       getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0};
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
     size_t doubles = gusto_work(d).end;
     doubles = (doubles + 3) & ~(size_t)3;
@@ -351,11 +352,18 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
         delete pl;
         return rc;
     }
-    SRH_CHECK_HIP(hipMemset(pl->handed.p, 0, sizeof(int32_t)));
+    if (hipMemset(pl->handed.p, 0, sizeof(int32_t)) != hipSuccess) {
+        delete pl;
+        SRH_REQUIRE(false, "sgusto_plan_create: hipMemset of the hand-over counter failed");
+    }
     pl->use_lpt = getenv("SRH_GUSTO_NO_LPT") == nullptr;
     if (d.lean && !getenv("SRH_GUSTO_NO_LEAN")) {
         pl->lean_variant = lean_select(d, pl->lean_args);
-        if (pl->lean_variant < 0) { delete pl; SRH_REQUIRE(false, "sgusto_plan_create: no lean kernel instantiation for n_u = %d", d.m); }
+        if (pl->lean_variant < 0) {
+            const int n_u = d.m;                   // (d refers into the plan)
+            delete pl;
+            SRH_REQUIRE(false, "sgusto_plan_create: no lean kernel instantiation for n_u = %d", n_u);
+        }
         pl->lean_lds = lean_kernel_lds_bytes(d);
         if ((rc = lean_prepare(pl->lean_variant, pl->lean_lds))) { delete pl; return rc; }
         pl->lean = true;
@@ -449,7 +457,9 @@ int sgusto_plan_info(sgusto_plan_t *pl, srh_kernel_info *info) {
     info->threads = NTHREADS;
     info->handed_over = -1;
     if (pl->solved) {
-        if (pl->astream) SRH_CHECK_HIP(hipStreamSynchronize(pl->astream));
+        // the last solve may sit on a caller's non-blocking stream (sgusto_plan_solve_dev): wait for the device, as
+        // slocp_plan_info and sgusto_plan_costs do
+        SRH_CHECK_HIP(hipDeviceSynchronize());
         SRH_CHECK_HIP(hipMemcpy(&info->handed_over, pl->handed.p, sizeof(int32_t), hipMemcpyDeviceToHost));
         if (!pl->lean) info->handed_over = 0;
     }

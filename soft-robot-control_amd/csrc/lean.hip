@@ -31,7 +31,7 @@ __device__ __forceinline__ void fix_problem(QPDims &d) {
 template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>
 __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    long long prof[24] = {0};
+    long long prof[32] = {0};
 #ifdef SRH_PROFILE
     long long gup[8] = {0}, gul = clock64();
 #endif
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         int st = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool warm = GXSEL > 0 && have_warm && attempt == 0;
-            st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, base, L, &J, &qit, w, prof, warm);
+            st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, base, L, &J, &qit, w, prof, warm ? (par.poison_warm ? 2 : 1) : 0);
             if (st == 0 || st == 100 || !warm) break;
         }
         have_warm = st == 0;
@@ -226,6 +226,8 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         printf("lean newton laps: gradients %lld gT(1) %lld rhs+dinv %lld g(1) %lld k_solve %lld gT(2) %lld du %lld g(2) %lld\n",
                prof[8], prof[9], prof[10], prof[11], prof[12], prof[13], prof[14], prof[15]);
         printf("lean step laps: step rows (both modes) %lld reduce(amax) %lld affine mu rows %lld reduce(mu_aff) %lld\n", prof[18], prof[19], prof[20], prof[21]);
+        printf("lean qp tail: rollout-of-minimiser %lld objective+tr-test %lld ipm-iterations %lld qps %lld warm-qps %lld\n",
+               prof[22], prof[23], prof[24], prof[25], prof[26]);
         printf("lean split (factorisation on waves 0-3 beside the front of the Newton solve on waves 4-7): factorisation %lld front %lld\n", prof[16], prof[17]);
     }
 #endif
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
 template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>
 __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c, LocpBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    long long prof[24] = {0};
+    long long prof[32] = {0};
     qp::specialise<MSEL, NSEL>(d);
     fix_problem<MSEL, GXSEL, NST, J0SEL, NXR>(d);
     ql::Lds L;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
 // (a development build may pass its own, shorter list: tools/build_lean_dev.sh compiles the benchmark layouts only)
 #ifndef SRH_LEAN_VARIANTS
 #define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) X(4, 72, 4, 50, 18, 4) \
-    X(4, 60, 4, 0, 0, 0) X(8, 60, 1, 0, 0, 0) X(4, 72, 4, 0, 0, 0) X(4, 60, 0, 0, 0, 0) X(8, 60, 0, 0, 0, 0) X(4, 0, 0, 0, 0, 0) X(8, 0, 0, 0, 0, 0)
+    X(4, 60, 4, 0, 0, 0) X(4, 60, 1, 0, 0, 0) X(8, 60, 1, 0, 0, 0) X(4, 72, 4, 0, 0, 0) X(4, 60, 0, 0, 0, 0) X(8, 60, 0, 0, 0, 0) X(4, 0, 0, 0, 0, 0) X(8, 0, 0, 0, 0, 0)
 #endif
 inline int lean_gx(const QPDims &d) {
     if (d.lean != 2) return 0;

@@ -1086,6 +1086,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
     // prescreen below; otherwise the stage-wise Riccati solve of the full QP follows.
     if (dfull.cond && (npass == 2 || !dfull.tr) && first_pass == 0) {
         const int st = qpc::solve<MSEL, NSEL>(dfull, c, dyn, q, work_base, L.base, L, &it, wout);
+        warm = false;                                  // the condensed attempt has overwritten w.u / w.lam: what follows starts cold
         qp_lds_carve(L, L.base, dfull, nt);            // back to the Riccati layout (its constants are gone: ready = false)
         if (q.dbg && tid == 0) { q.dbg[8 * 61] = 1.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; }
 #ifdef SRH_PROFILE

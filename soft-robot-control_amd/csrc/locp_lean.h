@@ -1137,7 +1137,11 @@ __device__ __forceinline__ double gsum(double v) {
 
 template <int MSEL, int NSEL, int GX, int NST = 0, int J0SEL = 0>
 __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
-                                       Lds &L, int *iters_out, QPWork &wout, long long *prof, bool warm = false) {
+                                       Lds &L, int *iters_out, QPWork &wout, long long *prof, int warm_mode = 0) {
+    // warm_mode: 0 cold start, 1 warm start (below), 2 warm start whose multipliers are replaced by +inf -- a test knob
+    // (GustoPar::poison_warm, SRH_LEAN_POISON_WARM=1 at plan creation) that makes the warm attempt fail so that the caller's cold
+    // retry runs under a test
+    const bool warm = warm_mode != 0, poison = warm_mode == 2;
     const int tid = threadIdx.x, nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
@@ -1260,7 +1264,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
             if (s2 >= nrow) continue;
             const double gq = row_val(s2, L.y, L.u) - rh[s2];
             rt[s2] = fmax(-gq, WARM_FLOOR);
-            rlam[s2] = fmax(w.lam[lslot + s2], WARM_FLOOR);
+            rlam[s2] = poison ? INFINITY : fmax(w.lam[lslot + s2], WARM_FLOOR);
         }
         scales();
         mode = PRED;
@@ -1463,6 +1467,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     __syncthreads();
 #ifdef SRH_PROFILE
     for (int i = 0; i < 8; ++i) prof[8 + i] += pf.t[8 + i];
+    prof[24] += it; prof[25] += 1; prof[26] += warm ? 1 : 0;
 #endif
     if (iters_out) *iters_out = it;
     return status;
@@ -1473,7 +1478,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 // means "hand this QP to the fused kernel" (status of the interior point, or 100 = minimiser outside the trust region).
 template <int MSEL, int NSEL, int GXSEL, int NST = 0, int J0SEL = 0>
 __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
-                                        Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof, bool warm = false) {
+                                        Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof, int warm = 0) {
     const int tid = threadIdx.x, nt = blockDim.x;
     QPLds Lq{};
     Lq.v1 = L.v1; Lq.v2 = L.v2; Lq.Qu = L.Qu; Lq.part = L.part; Lq.red = L.red; Lq.idxl = L.idxl; Lq.flag = L.flag;
@@ -1485,6 +1490,9 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     else st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
     if (iters_out) *iters_out = it;
     if (st != 0) return st;
+#ifdef SRH_PROFILE
+    long long tail_last = clock64();
+#endif
     QPDims d0 = dfull;
     d0.tr = 0;
     QPWork w = wout;
@@ -1495,6 +1503,9 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     __syncthreads();
     rollout<MSEL, NSEL>(d0, dyn, q.x0, (cgptr)w.u, w.x, L);
     __syncthreads();
+#ifdef SRH_PROFILE
+    { const long long now_ = clock64(); prof[22] += now_ - tail_last; tail_last = now_; }
+#endif
     double J = qp::objective(d0, c, q, w.x, w.u, w.s, Lq);
     bool inside = true;
     if (dfull.tr) {
@@ -1504,6 +1515,9 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
         inside = md <= q.delta;
         J += q.omega * s0;
     }
+#ifdef SRH_PROFILE
+    { const long long now_ = clock64(); prof[23] += now_ - tail_last; }
+#endif
     if (J_out) *J_out = J;
     return inside ? 0 : 100;
 }

@@ -432,9 +432,16 @@ __device__ __forceinline__ void ilqr_mm(lptr C, int ldc, const IlqrOp &Lo, const
 // and discretised at every step of the forward pass (ilqr.py:155: model.get_jacobians(x[t], u=u[t], dt)).
 // NSEL / MSEL > 0: instantiation for exactly that n_x / n_u (compile-time extents: the index arithmetic and the small
 // loops of the passes fold); 0: any size.
-template <int MODEL, int NSEL, int MSEL>
-__global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs a) {
+// NTH: threads per workgroup = per problem.  512 (NT) for the robot-sized models; 64 for small ones (n_x + n_u <= 32: the C3 SSM
+// shape, n_x = 10, n_u = 8): a 10 x 10 problem has no work for eight waves, every phase boundary is a workgroup barrier that seven
+// of them spend waiting, and ONE wave needs no barrier at all (its LDS queue is in order; s_barrier of a one-wave workgroup is
+// free).  Same code, same per-element arithmetic in the same order: the wave-specialised phases (`tid >= O1`) run one after the
+// other on the single wave, the only workgroup reduction whose tree depends on the wave count (the expected cost decrease) sums
+// per 64 stages in stage order in both forms.
+template <int MODEL, int NSEL, int MSEL, int NTH = NT>
+__global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int O1 = NTH > 64 ? 64 : 0, O2 = NTH > 64 ? 128 : 0;      // first thread of the second / third wave-specialised phase
     const int N = a.N, n = NSEL > 0 ? NSEL : a.n, m = MSEL > 0 ? MSEL : a.m, nz = a.nz;
     LqrLds L;
     lqr_carve(L, (lptr)smem, n, m, a.mfma ? 256 : 0);
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
     lptr part = zt + 16;                      // blockDim
     // SSM scratch (MODEL 1): polynomial work space, per-step (A, B, d), observed output
     ssm::Work sw;
-    lptr zs = part + NT, xl = zs + 16;        // observed output, a state vector (both models)
+    lptr zs = part + NTH, xl = zs + 16;        // observed output, a state vector (both models)
     lptr Al = xl + n, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m;      // MODEL 1 only (not allocated for MODEL 0)
     SsmLds ST;
     if constexpr (MODEL == 1) {
@@ -519,13 +526,13 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 uo[(size_t)t * m + tid] = v;
             }
             if constexpr (MODEL == 0) {
-                if (tid >= 64 && tid < 128) {
+                if (tid >= O1 && tid < O1 + 64) {
                     const int i = tpwl::nearest_wave(T, (clptr)L.v1);
-                    if (tid == 64) { io[t] = i; *L.flag = i; }
+                    if (tid == O1) { io[t] = i; *L.flag = i; }
                 }
                 // z - z*  (z = H x + z_ref)
-                if (tid >= 128 && tid < 128 + nz) {
-                    const int r = tid - 128;
+                if (tid >= O2 && tid < O2 + nz) {
+                    const int r = tid - O2;
                     double v = zref[r] - ztar[(size_t)t * nz + r];
                     for (int j = 0; j < n; ++j) v = fma(Hm[r * n + j], L.v1[j], v);
                     zt[r] = v;
@@ -652,8 +659,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 for (int e = tid; e < n; e += nt) xl[e] = X[(size_t)t * n + e];
                 __syncthreads();
                 zerr((clptr)xl, t);
-                if (tid >= 64 && tid < 64 + m) {
-                    const int r = tid - 64;
+                if (tid >= O1 && tid < O1 + m) {
+                    const int r = tid - O1;
                     double v = 0.0;
                     for (int s = 0; s < m; ++s) {
                         const double du = U[(size_t)t * m + s] - (!P_.include_input_var_constraint ? 0.0 :
@@ -852,8 +859,8 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                 } else {
                     zerr((clptr)xl, t);
                 }
-                if (tid >= 64 && tid < 64 + m) {
-                    const int r = tid - 64;
+                if (tid >= O1 && tid < O1 + m) {
+                    const int r = tid - O1;
                     double v = 0.0;
                     for (int s = 0; s < m; ++s) {
                         const double du = U[(size_t)t * m + s] - (!P_.include_input_var_constraint ? 0.0 :
@@ -1020,8 +1027,9 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
 #ifdef SRH_PROFILE
             ++nf;
 #endif
-            double dc = 0.0;
-            for (int t = tid; t < N; t += nt) {
+            // expected decrease (ilqr.py:71-73): the stages in blocks of 64 -- one wave sum per block, the blocks added in stage
+            // order (N <= 512: exactly what wg::reduce over one stage per thread does; the one-wave form walks the same blocks)
+            auto dc_stage = [&](int t) {
                 double s1 = 0.0, s2 = 0.0;
                 for (int r = 0; r < m; ++r) {
                     s1 = fma(kff[(size_t)t * m + r], Qu[(size_t)t * m + r], s1);
@@ -1029,9 +1037,15 @@ __global__ __launch_bounds__(NT) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs 
                     for (int s = 0; s < m; ++s) q = fma(Quu[(size_t)t * m * m + r * m + s], kff[(size_t)t * m + s], q);
                     s2 = fma(kff[(size_t)t * m + r], q, s2);
                 }
-                dc += alpha * s1 + alpha * alpha * 0.5 * s2;
+                return alpha * s1 + alpha * alpha * 0.5 * s2;
+            };
+            double dc = 0.0;
+            if constexpr (NTH == 64) {
+                for (int t0 = 0; t0 < N; t0 += 64) dc += wg::wave_sum(t0 + tid < N ? 0.0 + dc_stage(t0 + tid) : 0.0);
+            } else {
+                for (int t = tid; t < N; t += nt) dc += dc_stage(t);
+                dc = wg::reduce(dc, 0, L.red);
             }
-            dc = wg::reduce(dc, 0, L.red);
             const double ratio = (new_cost - prev_cost) / dc;
             if (P_.do_linesearch && (ratio <= P_.improv_lb || ratio > P_.improv_ub)) {      // ilqr.py:75: without it alpha0 is taken
                 alpha = P_.alpha_scaling * alpha;
@@ -1244,18 +1258,25 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
     SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
     lds = srh::lds_request(lds);
     // variants: the reference's robots at the benchmark / shipped basis sizes (TPWL), the C3 SSM shape; else all sizes
-#define SRH_ILQR_VARIANTS(X) X(0, 60, 4) X(0, 60, 8) X(0, 72, 4) X(1, 10, 8) X(0, 0, 0) X(1, 0, 0)
+    // (model, n_x, n_u, threads): the one-wave forms first -- small models, where eight waves only wait for each other
+#define SRH_ILQR_VARIANTS(X) X(1, 10, 8, 64) X(1, 10, 8, 128) X(1, 10, 8, 256) X(1, 0, 0, 64) X(0, 60, 4, NT) X(0, 60, 8, NT) X(0, 72, 4, NT) X(1, 10, 8, NT) X(0, 0, 0, NT) X(1, 0, 0, NT)
     {
         const int model = ht ? 0 : 1;
+        // one wave per problem: SSM models whose padded [A | B] panel is two MFMA tiles wide at most and N <= 512 (the expected-
+        // decrease sum above); SRH_ILQR_THREADS=512 / 64 forces a form (A/B runs, tests of both)
+        const char *force = getenv("SRH_ILQR_THREADS");
+        const bool small = hs && a.mfma == 1 && n + m <= 32 && N <= 512;
+        const int threads = force ? (atoi(force) < NT && hs && a.mfma == 1 ? atoi(force) : NT) : (small ? 64 : NT);
         bool launched = false;
-#define X(MD, NX, MU)                                                                                                           \
-    if (!launched && model == MD && (NX == 0 || n == NX) && (MU == 0 || m == MU)) {                                             \
-        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<MD, NX, MU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        ilqr_kernel<MD, NX, MU><<<(unsigned)batch, NT, lds>>>(ht ? ht->view() : TpwlDev{}, hs ? hs->view() : SsmDev{}, a);      \
+#define X(MD, NX, MU, TH)                                                                                                       \
+    if (!launched && model == MD && (NX == 0 || n == NX) && (MU == 0 || m == MU) && threads == TH) {                            \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)ilqr_kernel<MD, NX, MU, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        ilqr_kernel<MD, NX, MU, TH><<<(unsigned)batch, TH, lds>>>(ht ? ht->view() : TpwlDev{}, hs ? hs->view() : SsmDev{}, a);  \
         launched = true;                                                                                                        \
     }
         SRH_ILQR_VARIANTS(X)
 #undef X
+        SRH_REQUIRE(launched, "silqr_solve: no kernel variant for model %d, n_x %d, n_u %d, %d threads", model, n, m, threads);
     }
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipStreamSynchronize(nullptr));

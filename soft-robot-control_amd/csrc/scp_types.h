@@ -6,6 +6,7 @@
 struct GustoPar {
     double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh, dt;
     int max_iters, max_trace;
+    int poison_warm;                    // test knob (SRH_LEAN_POISON_WARM=1 when the plan is created): lean kernel, every warm-started QP fails and is repeated cold
 };
 
 struct GustoBatch {

@@ -46,8 +46,13 @@ def gather_rollout_costs(J_local, n_total=None, group=None):
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
             n_total = int(cnt.item())
         lo, hi = shard_range(n_total, rank, world)
-        if Jt.numel() != hi - lo:
-            raise ValueError('gather_rollout_costs: rank %d holds %d costs, its shard of %d rollouts has %d' % (rank, Jt.numel(), n_total, hi - lo))
+        # a wrong shard size on ONE rank must fail on EVERY rank: agree on validity before the data collective (a rank that
+        # raised alone would leave the others waiting in all_gather until the backend's timeout)
+        ok = torch.tensor([1 if Jt.numel() == hi - lo else 0], dtype=torch.int64, device=Jt.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise ValueError('gather_rollout_costs: rank %d holds %d costs, its shard of %d rollouts has %d (a shard size is wrong on at least '
+                             'one rank)' % (rank, Jt.numel(), n_total, hi - lo))
         width = -(-int(n_total) // world)            # shards differ by at most one: pad to the widest
         mine = torch.full((width,), float('inf'), dtype=torch.float64, device=Jt.device)
         mine[:hi - lo] = Jt

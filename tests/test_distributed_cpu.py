@@ -135,6 +135,30 @@ def test_gather_rollout_costs_two_ranks(n_total):
         assert out[r][3] == out[r][5] == n_total - 2
 
 
+def _mismatch_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sofacontrol_amd.distributed import gather_rollout_costs
+    # 5 rollouts over 2 ranks: shards of 3 and 2 -- rank 0 holds the right number, rank 1 one too many
+    try:
+        gather_rollout_costs(np.zeros(3), 5)
+        out[rank] = 'no error'
+    except ValueError as e:
+        out[rank] = 'ValueError'
+    dist.destroy_process_group()
+
+
+def test_gather_rollout_costs_shard_mismatch_raises_on_every_rank():
+    """A wrong shard size on one rank is an error on ALL ranks (agreed by an all_reduce before the data collective): the rank
+    whose size happens to match must not be left waiting in all_gather."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_mismatch_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == 'ValueError' and out[1] == 'ValueError', dict(out)
+
+
 def test_gather_rollout_costs_single_process():
     from sofacontrol_amd.distributed import gather_rollout_costs
     J, best = gather_rollout_costs(np.array([3.0, np.nan, 1.0, np.inf]))

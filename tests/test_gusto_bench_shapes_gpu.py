@@ -137,12 +137,12 @@ def test_lean_fixed_layout_equals_runtime_layout_at_c2(monkeypatch):
     assert rel(res['fixed'][4], res['runtime'][4]) <= 1e-9 and rel(res['fixed'][5], res['runtime'][5]) <= 1e-9
 
 
-@pytest.mark.parametrize('N,dt,with_X,cap,lean', [(5, 0.05, True, 500, (4, 60, 4, 0, 0, 0)), (3, 0.1, False, 5, (4, 60, 0, 0, 0, 0)),
+@pytest.mark.parametrize('N,dt,with_X,cap,lean', [(5, 0.05, True, 500, (4, 60, 4, 0, 0, 0)), (3, 0.1, False, 5, (4, 60, 1, 0, 0, 0)),
                                                    (200, 0.05, False, 500, None)])
 def test_reference_driver_horizons_match_oracle(N, dt, with_X, cap, lean):
     """The horizons the reference's own Diamond drivers solve (bench.py: secondary.scp_reference_horizons): N = 5 / dt = 0.05 with
     the X box (examples/diamond/diamond.py:309-316), N = 3 / dt = 0.1 capped at 5 SCP iterations (examples/hardware/diamond.py:
-    393-399; no state rows: the general-row lean kernel <4, 60, 0, 0, 0, 0>) -- run-time-horizon lean kernels -- and the open-loop N = 200 (examples/hardware/diamond.py:471-474): N p_o = 400
+    393-399; no state rows: the box-row lean kernel <4, 60, 1, 0, 0, 0>) -- run-time-horizon lean kernels -- and the open-loop N = 200 (examples/hardware/diamond.py:471-474): N p_o = 400
     outputs exceed the condensed path's 128, the stage-wise Riccati kernel answers.  Against oracle.gusto at that N."""
     import workloads as wl
     from sofacontrol_amd.scp.gusto import GuSTO
@@ -156,5 +156,46 @@ def test_reference_driver_horizons_match_oracle(N, dt, with_X, cap, lean):
     info = g.kernel_info
     assert info['family'] == ('lean' if lean else 'fused') and info['lean'] == lean, info
     g.solve_batch(x0, u_init, x_init, z=z)
-    for b in range(B if N < 200 else 1):
+    for b in range(B):
         compare(g, b, oracle_solve(w, xc, fc, x0[b], u_init[b], x_init[b], z[b], cap), 'N = %d' % N)
+
+
+def test_lean_cold_retry_after_failed_warm_start(monkeypatch):
+    """The lean kernel warm-starts every QP after the first of a solve and REPEATS a QP cold when the warm-started interior point
+    does not converge (csrc/lean.hip, the `attempt` loop; never taken on the bench batch).  The test knob SRH_LEAN_POISON_WARM=1
+    (read when the plan is created -> GustoPar::poison_warm) replaces the warm multipliers by +inf: every warm attempt fails at
+    once and the retry answers.  The poisoned plan must (1) give the SCP trace of the numpy statement with every QP cold-started
+    (oracle.gusto(..., qp_solver='condensed_ipm', warm_start_qp=False): the same QP sequence), (2) agree with the unpoisoned plan:
+    equal SCP iteration counts and status, trajectories to 1e-6 (two exact solves of the same QPs stopped at the same gap)."""
+    import workloads as wl
+    from oracle import gusto as ogusto
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2()
+    B, cap = 4, 5
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, B, 2, 1354)
+    res = {}
+    for tag in ('plain', 'poisoned'):
+        if tag == 'poisoned':
+            monkeypatch.setenv('SRH_LEAN_POISON_WARM', '1')
+        else:
+            monkeypatch.delenv('SRH_LEAN_POISON_WARM', raising=False)
+        g = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+                  x_char=xc, f_char=fc, convg_thresh=1e-3, batch=B, max_trace=64, max_gusto_iters=cap)
+        assert g.kernel_info['family'] == 'lean', g.kernel_info
+        g.solve_batch(x0, u_init, x_init, z=z)
+        assert int(g.kernel_info['handed_over']) == 0, g.kernel_info          # the retry answered inside the lean kernel
+        res[tag] = (g.iters.copy(), g.status.copy(), g.xopt.copy(), g.uopt.copy(), g.trace.copy())
+    monkeypatch.delenv('SRH_LEAN_POISON_WARM', raising=False)
+    a, p = res['plain'], res['poisoned']
+    assert (a[0] == p[0]).all() and (a[1] == p[1]).all(), (a[0], p[0], a[1], p[1])
+    assert (p[0] >= 2).all()                                                  # at least one QP per rollout took the retry
+    assert rel(p[2], a[2]) <= 1e-6 and rel(p[3], a[3]) <= 1e-6, (rel(p[2], a[2]), rel(p[3], a[3]))
+    model = dict(w['tab'], w_q=1.0, w_v=0.0)
+    for b in range(2):
+        xe, ue, ze, tr = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], w['N'], w['dt'], w['Qz'], w['R'], x0[b], u_init[b], x_init[b],
+                                      z=z[b], U=(w['UA'], w['Ub']), X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3,
+                                      qp_solver='condensed_ipm', warm_start_qp=False, max_gusto_iters=cap)
+        assert int(p[0][b]) == len(tr)
+        np.testing.assert_allclose(p[4][b, :len(tr), :3], np.array([t[:3] for t in tr]), rtol=1e-6)
+        assert rel(p[2][b], xe) <= 1e-6 and rel(p[3][b], ue) <= 1e-6, (rel(p[2][b], xe), rel(p[3][b], ue))

@@ -12,10 +12,13 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-un
 mkdir -p $ROOT/gpurun_variants /tmp/leandev/prod /tmp/leandev/prof /tmp/include
 cp $ROOT/include/*.h /tmp/include/            # common.h includes "../../include/sofacontrol_hip.h"
 OTHERS=$(ls $R/*.o | grep -v '/lean.o$')
+rm -f $ROOT/gpurun_variants/libsofacontrol_hip_dev.so $ROOT/gpurun_variants/libsofacontrol_hip_devprof.so     # never leave a stale library behind a failed compile
+pids=()
 for flavour in prod prof; do
   ( cd /tmp/leandev/$flavour && rm -f *.h *.hip && cp $R/*.h $R/lean.hip . &&
     $ROOT/tools/hipcc_guarded.sh lean.hip lean.o "$V" $([ $flavour = prof ] && echo -DSRH_PROFILE) "$@" $F &&
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OTHERS lean.o -o $ROOT/gpurun_variants/libsofacontrol_hip_dev$([ $flavour = prof ] && echo prof).so ) &
+  pids+=($!)
 done
-wait
+for p in "${pids[@]}"; do wait $p || { echo "build_lean_dev.sh: a compile failed" >&2; exit 1; }; done
 ls -la $ROOT/gpurun_variants/libsofacontrol_hip_dev*.so

@@ -1,7 +1,7 @@
 """Debug helper: where do the device iLQR and the oracle loop part on the C3 configuration (dt = 0.05, backward Euler)?
 Runs both with max_iter = 0, 1, 2, ... and prints the differences of cost, x, u; also the 'be' Jacobians at random points."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soft-robot-control_amd'), os.path.join(ROOT, 'tests')]
 import numpy as np
 import workloads as wl

@@ -1,6 +1,6 @@
 """Why does secondary.scp_c5 take 43 ms inside bench.py and 14 ms alone?  The secondary sequence, then scp_c5 three more times."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, 'soft-robot-control_amd')]
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [ROOT, os.path.join(ROOT, 'soft-robot-control_amd')]
 import torch; torch.cuda.init()
 import bench
 from sofacontrol_amd import _lib

@@ -1,5 +1,5 @@
 import sys, os, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'soft-robot-control_amd'))
 import numpy as np, io, contextlib
 import workloads as wl

@@ -1,4 +1,5 @@
 # rocprofv3 passes behind profiles/r03* (run on the GPU box from the repository root: bash tools/prof_r03.sh)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT    # the repository root (gpurun exports it; derived from $0 elsewhere)
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03_trace -o r03 -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/r03_bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r03_pmc_fetch -o f -- python3 $R/tools/pmc_kernels.py > $R/gpurun_out/r03_pmc_fetch.log 2>&1

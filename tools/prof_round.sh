@@ -3,6 +3,7 @@
 # than --kernel-trace): HBM traffic of the projection, MFMA-busy, and for the lean GuSTO kernel the instruction mix, where its
 # wave cycles go (parked / issue-stalled / active), LDS bank conflicts and instruction-cache misses.
 TAG=${1:-r04}
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT    # the repository root (gpurun exports it; derived from $0 elsewhere)
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 B1="python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace -o $TAG -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_bench_under_rocprof.log 2>&1

@@ -1,4 +1,5 @@
 # development run on the GPU box: probes, A/B of the dev build of the lean kernels, phase clocks (see tools/build_lean_dev.sh)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT    # the repository root (gpurun exports it; derived from $0 elsewhere)
 cd $GRAFT_REPO_ROOT
 timeout 60 ./gpurun_variants/lean_probe > gpurun_out/probe4.log 2>&1; echo "probe rc $?"; grep "tile_chol\|chol16\|chol 4\|set sync\|k_solve" gpurun_out/probe4.log
 export SRH_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_variants/libsofacontrol_hip_dev.so
