@@ -44,7 +44,7 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             build()
         _lib = C.CDLL(LIB_PATH)
-        if _lib.scpu_version() < 2:          # a stale build from an earlier round
+        if _lib.scpu_version() < 3:          # a stale build from an earlier round
             build()
             _lib = C.CDLL(LIB_PATH)
     return _lib
@@ -122,3 +122,63 @@ def gusto_solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0, u_init, x_init, z=None, 
                                 _p(zf), _p(u_des), _p(x_char), _p(f_char), _p(xo), _p(uo), iters.ctypes.data_as(C.POINTER(C.c_int32)),
                                 _p(trace) if max_trace > 0 else None, C.c_int(max_trace), C.c_int(threads), C.c_int(ALGO[algo]))
     return xo, uo, iters, trace
+
+
+class _IlqrParams(C.Structure):
+    _fields_ = [('max_iter', C.c_int), ('epsilon', C.c_double), ('alpha0', C.c_double), ('alpha_scaling', C.c_double), ('improv_lb', C.c_double),
+                ('improv_ub', C.c_double), ('alpha_min', C.c_double), ('counter_limit', C.c_int), ('rho0', C.c_double), ('drho0', C.c_double),
+                ('rho_scaling', C.c_double), ('rho_increase_fp', C.c_double), ('rho_max', C.c_double), ('rho_min', C.c_double),
+                ('include_input_var_constraint', C.c_int), ('do_linesearch', C.c_int), ('regularize', C.c_int), ('state_regularization', C.c_int)]
+
+
+def _ilqr_params(**kw):
+    from .lqr import ILQRParams as P
+    g = lambda k: kw.get(k, getattr(P, k))
+    return _IlqrParams(int(g('max_iter')), g('epsilon'), g('alpha0'), g('alpha_scaling'), g('improv_lb'), g('improv_ub'), g('alpha_min'),
+                       int(g('counter_limit')), g('rho0'), g('drho0'), g('rho_scaling'), g('rho_increase_fp'), g('rho_max'), g('rho_min'),
+                       int(bool(g('include_input_var_constraint'))), int(bool(g('do_linesearch'))), int(bool(g('regularize'))),
+                       int(bool(g('state_regularization'))))
+
+
+def _ilqr_out(B, N, n, m):
+    return (np.empty((B, N + 1, n)), np.empty((B, N, m)), np.empty((B, N, m, n)), np.empty(B), np.empty(B, dtype=np.int32))
+
+
+def ilqr_tpwl(model, Ad, Bd, dd, H, z_ref, Q, R, Qf, N, x0, z_target, u_warm=None, u_last=None, threads=1, **params):
+    """oracle.lqr.ILQR.solve for a batch (leading axis) of problems on the nearest-point TPWL model; returns x, u, K, cost, iters."""
+    t = [_a(model[k]) for k in ('q', 'v', 'A_c', 'B_c', 'd_c')] + [_a(Ad), _a(Bd), _a(dd)]
+    mo = _Model(t[0].shape[0], t[0].shape[1], t[3].shape[2], float(model['w_q']), float(model['w_v']), *[_p(a) for a in t])
+    H, z_ref, Q, R, Qf, x0, z_target, u_warm, u_last = map(_a, (H, z_ref, Q, R, Qf, x0, z_target, u_warm, u_last))
+    if x0.ndim == 1:
+        x0, z_target = x0[None], z_target[None]
+        u_warm = None if u_warm is None else u_warm[None]
+        u_last = None if u_last is None else u_last[None]
+    B, n = x0.shape
+    m = t[3].shape[2]
+    x, u, K, cost, iters = _ilqr_out(B, N, n, m)
+    par = _ilqr_params(**params)
+    lib().scpu_ilqr_tpwl(C.byref(mo), _p(H), _p(z_ref), C.c_int(H.shape[0]), _p(Q), _p(R), _p(Qf), C.byref(par), C.c_int(N), C.c_int64(B), _p(x0),
+                         _p(z_target), _p(u_warm), _p(u_last), _p(x), _p(u), _p(K), _p(cost), iters.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(threads))
+    return x, u, K, cost, iters
+
+
+SSM_MODES = {'fe': 1, 'be': 2, 'bil': 3}
+
+
+def ilqr_ssm(n, m, rom_order, ssm_order, r_coeff, Bc, w_coeff, z_ref, H, method, dt, Q, R, Qf, N, x0, z_target, u_warm=None, u_last=None,
+             threads=1, **params):
+    """oracle.lqr.ILQRGeneric.solve over oracle.ssm (continuous model discretised per `method`) for a batch of problems."""
+    r_coeff, Bc, w_coeff, z_ref, H, Q, R, Qf, x0, z_target, u_warm, u_last = map(_a, (r_coeff, Bc, w_coeff, z_ref, H, Q, R, Qf, x0, z_target, u_warm, u_last))
+    if x0.ndim == 1:
+        x0, z_target = x0[None], z_target[None]
+        u_warm = None if u_warm is None else u_warm[None]
+        u_last = None if u_last is None else u_last[None]
+    B = x0.shape[0]
+    no = w_coeff.shape[0]
+    x, u, K, cost, iters = _ilqr_out(B, N, n, m)
+    par = _ilqr_params(**params)
+    lib().scpu_ilqr_ssm(C.c_int(n), C.c_int(m), C.c_int(no), C.c_int(rom_order), C.c_int(ssm_order), _p(r_coeff), _p(Bc), _p(w_coeff), _p(z_ref),
+                        _p(H), C.c_int(SSM_MODES[method]), C.c_double(dt), _p(Q), _p(R), _p(Qf), C.byref(par), C.c_int(N), C.c_int64(B), _p(x0),
+                        _p(z_target), _p(u_warm), _p(u_last), _p(x), _p(u), _p(K), _p(cost), iters.ctypes.data_as(C.POINTER(C.c_int32)),
+                        C.c_int(threads))
+    return x, u, K, cost, iters

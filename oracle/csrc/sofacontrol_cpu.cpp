@@ -9,6 +9,8 @@
 //     trust-region prescreen of the device kernel (the QP without its 2n+1 trust-region rows per stage first; the full
 //     QP only when that minimiser leaves the trust region)
 //   * the GuSTO outer loop          sofacontrol/scp/gusto.py:283-487 (oracle/gusto.py)
+//   * iLQR                          sofacontrol/lqr/ilqr.py:27-300 + lqr/config.py (oracle/lqr.py: ILQR / ILQRGeneric) on the
+//     nearest-point TPWL model and on the SSM polynomial model (sofacontrol/SSM/ssm.py:158-301, oracle/ssm.py)
 // so that bench.py can put an honest native number next to the GPU one: single thread, and all cores with one rollout
 // per thread (`threads` = the number actually used).  tests/test_cpu_twin.py holds it to the numpy oracle.
 #include <algorithm>
@@ -1157,6 +1159,310 @@ int gusto_one(const Model &M, Problem base, const GustoPar &par, double dt, cons
     return itr;
 }
 
+
+// ------------------------------------------------------------------ iLQR (oracle/lqr.py: ILQR.solve; ilqr.py:27-300)
+struct IlqrPar {
+    int max_iter; double epsilon, alpha0, alpha_scaling, improv_lb, improv_ub, alpha_min; int counter_limit;
+    double rho0, drho0, rho_scaling, rho_increase_fp, rho_max, rho_min;
+    int include_input_var_constraint, do_linesearch, regularize, state_regularization;
+};
+
+// in-place Gauss-Jordan inverse with partial pivoting (first maximum), A (n x n) -> Ainv; false if singular
+inline bool gj_inverse(vec &A, int n, vec &Ainv) {
+    Ainv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) Ainv[(size_t)i * n + i] = 1.0;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = std::fabs(A[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; ++i) { const double v = std::fabs(A[(size_t)i * n + k]); if (v > best) { best = v; p = i; } }
+        if (!(best > 0.0)) return false;
+        if (p != k) for (int j = 0; j < n; ++j) { std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]); std::swap(Ainv[(size_t)k * n + j], Ainv[(size_t)p * n + j]); }
+        const double d = A[(size_t)k * n + k];
+        for (int j = 0; j < n; ++j) { A[(size_t)k * n + j] /= d; Ainv[(size_t)k * n + j] /= d; }
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double f = A[(size_t)i * n + k];
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; ++j) { A[(size_t)i * n + j] -= f * A[(size_t)k * n + j]; Ainv[(size_t)i * n + j] -= f * Ainv[(size_t)k * n + j]; }
+        }
+    }
+    return true;
+}
+
+// SSM polynomial model (oracle/ssm.py): graded monomial basis, analytic derivatives, discretisation of ssm.py:279-301
+struct SsmModel {
+    int n, m, no, nr, ns, order_r, order_s;
+    const double *R, *B, *W, *z_ref;          // r_coeff (n x nr), B (n x m), w_coeff (no x ns), z_ref (no)
+    std::vector<int> Er, Es, par_r, var_r, par_s, var_s;      // exponents, parent monomial / multiplied variable
+    std::vector<int> nzk, nzq, nze, nzoff;    // per variable j: monomials with e_kj > 0, the index of e_k - 1_j (-2: constant), e_kj
+    int mode; double dt;                      // 1 fe, 2 be, 3 bil (SSM_FE / SSM_BE / SSM_BIL)
+};
+inline void exponents(int dim, int order, std::vector<int> &out) {
+    std::vector<int> cur(dim, 0);
+    struct Rec { std::vector<int> &out, &cur; int dim;
+        void go(int pos, int left) {
+            if (pos == dim - 1) { cur[pos] = left; out.insert(out.end(), cur.begin(), cur.end()); return; }
+            for (int e = left; e >= 0; --e) { cur[pos] = e; go(pos + 1, left - e); }
+        } } rec{out, cur, dim};
+    for (int deg = 1; deg <= order; ++deg) rec.go(0, deg);
+}
+inline int find_monomial(const std::vector<int> &E, int dim, const std::vector<int> &e) {
+    const int nm = (int)(E.size() / dim);
+    for (int j = 0; j < nm; ++j) if (std::equal(e.begin(), e.end(), E.begin() + (size_t)j * dim)) return j;
+    return -1;
+}
+inline void basis_tables(const std::vector<int> &E, int dim, std::vector<int> &par, std::vector<int> &var) {
+    const int nm = (int)(E.size() / dim);
+    par.assign(nm, -1); var.assign(nm, 0);
+    for (int j = 0; j < nm; ++j) {
+        std::vector<int> e(E.begin() + (size_t)j * dim, E.begin() + (size_t)(j + 1) * dim);
+        int deg = 0, last = 0;
+        for (int i = 0; i < dim; ++i) { deg += e[i]; if (e[i] > 0) last = i; }
+        var[j] = last;
+        if (deg > 1) { e[last] -= 1; par[j] = find_monomial(E, dim, e); }
+    }
+}
+inline void ssm_prepare(SsmModel &S) {
+    exponents(S.n, S.order_r, S.Er); exponents(S.no, S.order_s, S.Es);
+    S.nr = (int)(S.Er.size() / S.n); S.ns = (int)(S.Es.size() / S.no);
+    basis_tables(S.Er, S.n, S.par_r, S.var_r); basis_tables(S.Es, S.no, S.par_s, S.var_s);
+    S.nzoff.assign(S.n + 1, 0);
+    for (int j = 0; j < S.n; ++j) {
+        for (int k = 0; k < S.nr; ++k) {
+            const int ekj = S.Er[(size_t)k * S.n + j];
+            if (ekj == 0) continue;
+            std::vector<int> e(S.Er.begin() + (size_t)k * S.n, S.Er.begin() + (size_t)(k + 1) * S.n);
+            int deg = 0;
+            for (int v : e) deg += v;
+            e[j] -= 1;
+            S.nzk.push_back(k); S.nze.push_back(ekj); S.nzq.push_back(deg == 1 ? -2 : find_monomial(S.Er, S.n, e));
+        }
+        S.nzoff[j + 1] = (int)S.nzk.size();
+    }
+}
+inline void ssm_phi(const std::vector<int> &par, const std::vector<int> &var, const double *x, double *phi) {
+    const int nm = (int)par.size();
+    for (int j = 0; j < nm; ++j) phi[j] = (par[j] < 0 ? 1.0 : phi[par[j]]) * x[var[j]];       // parents come first (graded order)
+}
+// (A_d, B_d, d_d) at (x, u): continuous Jacobians of f = R phi(x) + B u, d = f - A x - B u, then the discretisation
+inline void ssm_lin(const SsmModel &S, const double *x, const double *u, double *A, double *Bm, double *d, vec &phi, vec &tmp) {
+    const int n = S.n, m = S.m, nr = S.nr;
+    phi.resize(nr);
+    ssm_phi(S.par_r, S.var_r, x, phi.data());
+    vec Ac((size_t)n * n, 0.0), f(n), dc(n);
+    for (int j = 0; j < n; ++j)
+        for (int t = S.nzoff[j]; t < S.nzoff[j + 1]; ++t) {
+            const double dv = (double)S.nze[t] * (S.nzq[t] == -2 ? 1.0 : phi[S.nzq[t]]);
+            const int k = S.nzk[t];
+            for (int i = 0; i < n; ++i) Ac[(size_t)i * n + j] += S.R[(size_t)i * nr + k] * dv;
+        }
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0, bu = 0.0, ax = 0.0;
+        for (int k = 0; k < nr; ++k) s += S.R[(size_t)i * nr + k] * phi[k];
+        for (int k = 0; k < m; ++k) bu += S.B[(size_t)i * m + k] * u[k];
+        for (int k = 0; k < n; ++k) ax += Ac[(size_t)i * n + k] * x[k];
+        f[i] = s + bu; dc[i] = f[i] - ax - bu;
+    }
+    if (S.mode == 1) {
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[(size_t)i * n + j] = (i == j ? 1.0 : 0.0) + S.dt * Ac[(size_t)i * n + j];
+        for (int e = 0; e < n * m; ++e) Bm[e] = S.dt * S.B[e];
+        for (int i = 0; i < n; ++i) d[i] = S.dt * dc[i];
+        return;
+    }
+    const double h = S.mode == 2 ? S.dt : 0.5 * S.dt;
+    vec M1((size_t)n * n), M2, M3(Ac), M4, Ad((size_t)n * n), sep((size_t)n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) M1[(size_t)i * n + j] = (i == j ? 1.0 : 0.0) - h * Ac[(size_t)i * n + j];
+    gj_inverse(M1, n, M2);
+    gj_inverse(M3, n, M4);
+    if (S.mode == 3) {
+        vec T((size_t)n * n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) T[(size_t)i * n + j] = (i == j ? 1.0 : 0.0) + h * Ac[(size_t)i * n + j];
+        matmul(T.data(), M2.data(), n, n, n, Ad.data());
+    } else {
+        Ad = M2;
+    }
+    vec AmI(Ad);
+    for (int i = 0; i < n; ++i) AmI[(size_t)i * n + i] -= 1.0;
+    matmul(M4.data(), AmI.data(), n, n, n, sep.data());
+    std::copy(Ad.begin(), Ad.end(), A);
+    matmul(sep.data(), S.B, n, n, m, Bm);
+    matvec(sep.data(), n, n, dc.data(), d);
+}
+inline void ssm_out(const SsmModel &S, const double *x, double *z, vec &phi) {           // z = W phi_s(x) + z_ref
+    phi.resize(S.ns);
+    ssm_phi(S.par_s, S.var_s, x, phi.data());
+    for (int i = 0; i < S.no; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < S.ns; ++k) s += S.W[(size_t)i * S.ns + k] * phi[k];
+        z[i] = s + S.z_ref[i];
+    }
+}
+
+// One problem.  lin(x, u, A, B, d): discrete Jacobians at (x, u); out(x, z): the performance output (absolute).  H: the constant
+// output Jacobian of the cost derivatives (nz x n).  Returns the iteration count (-1: gave up, Q~_uu never positive definite).
+template <class Lin, class Out>
+int ilqr_one(int N, int n, int m, int nz, const double *H, const double *Q, const double *R, const double *Qf, const IlqrPar &p,
+             const double *x0, const double *zt, const double *u_warm, const double *u_last, Lin lin, Out out, double *x, double *u,
+             double *K, double *cost_out) {
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    vec A(N * nn), B(N * nm), dd((size_t)N * n), A2(N * nn), B2(N * nm), d2((size_t)N * n);
+    vec x2((size_t)(N + 1) * n), u2((size_t)N * m), kff((size_t)N * m), Qu((size_t)N * m), Quu((size_t)N * m * m), z(nz), dz(nz);
+    vec HtQH(nn), HtQfH(nn), QH((size_t)nz * n), QfH((size_t)nz * n), ulast(m, 0.0);
+    if (u_last) ulast.assign(u_last, u_last + m);
+    matmul(Q, H, nz, nz, n, QH.data()); matmul(Qf, H, nz, nz, n, QfH.data());
+    matTmul(H, QH.data(), nz, n, n, HtQH.data()); matTmul(H, QfH.data(), nz, n, n, HtQfH.data());
+    double rho = p.rho0, drho = p.drho0;
+    auto reg = [&](bool increase) {
+        if (increase) { drho = std::max(drho * p.rho_scaling, p.rho_scaling); rho = std::max(rho * drho, p.rho_min); if (rho > p.rho_max) rho = p.rho_max; }
+        else { const double dh = std::min(drho / p.rho_scaling, 1.0 / p.rho_scaling); rho = rho * dh; if (rho <= p.rho_min) rho = p.rho_min; }
+    };
+    auto quad = [&](const double *M, const double *v, int k) { double s = 0.0; for (int i = 0; i < k; ++i) { double r = 0.0; for (int j = 0; j < k; ++j) r += M[(size_t)i * k + j] * v[j]; s += v[i] * r; } return s; };
+    // forward pass from (xp, up) with gains (Kg, kg, alpha) into (xo, uo, Ao, Bo, do_); returns the cost (ilqr.py:117-162)
+    auto forward = [&](const double *xp, const double *up, double alpha, const double *Kg, const double *kg, double *xo, double *uo,
+                       double *Ao, double *Bo, double *do_) {
+        double cost = 0.0;
+        vec du(m);
+        std::copy(x0, x0 + n, xo);
+        for (int t = 0; t < N; ++t) {
+            const double *xt = xo + (size_t)t * n;
+            double *ut = uo + (size_t)t * m;
+            for (int r = 0; r < m; ++r) {
+                double v = up[(size_t)t * m + r];
+                if (kg) v += alpha * kg[(size_t)t * m + r];
+                if (Kg) for (int j = 0; j < n; ++j) v += Kg[((size_t)t * m + r) * n + j] * (xt[j] - xp[(size_t)t * n + j]);
+                ut[r] = v;
+            }
+            out(xt, z.data());
+            for (int a = 0; a < nz; ++a) dz[a] = z[a] - zt[(size_t)t * nz + a];
+            for (int r = 0; r < m; ++r) du[r] = ut[r] - (p.include_input_var_constraint ? (t == 0 ? ulast[r] : uo[(size_t)(t - 1) * m + r]) : 0.0);
+            cost += 0.5 * quad(Q, dz.data(), nz) + 0.5 * quad(R, du.data(), m);
+            double *At = Ao + (size_t)t * nn, *Bt = Bo + (size_t)t * nm, *dt_ = do_ + (size_t)t * n;
+            lin(xt, ut, At, Bt, dt_);
+            double *xn = xo + (size_t)(t + 1) * n;
+            for (int i = 0; i < n; ++i) {
+                double s = dt_[i];
+                for (int j = 0; j < n; ++j) s += At[(size_t)i * n + j] * xt[j];
+                for (int j = 0; j < m; ++j) s += Bt[(size_t)i * m + j] * ut[j];
+                xn[i] = s;
+            }
+        }
+        out(xo + (size_t)N * n, z.data());
+        for (int a = 0; a < nz; ++a) dz[a] = z[a] - zt[(size_t)N * nz + a];
+        return cost + 0.5 * quad(Qf, dz.data(), nz);
+    };
+    // backward pass (ilqr.py:219-300); false: gave up
+    auto backward = [&]() {
+        vec P(nn), pv(n), PA(nn), PB(nm), Qxx(nn), Qux(nm), Quut((size_t)m * m), Quxt(nm), Qx(n), Lc((size_t)m * m), Kt(nm), kt(m), tmp(n), cu(m), g(nz);
+        int restarts = 0;
+        while (true) {
+            out(x + (size_t)N * n, z.data());
+            for (int a = 0; a < nz; ++a) dz[a] = z[a] - zt[(size_t)N * nz + a];
+            matvec(Qf, nz, nz, dz.data(), g.data());
+            std::fill(pv.begin(), pv.end(), 0.0); matTvec_add(H, nz, n, g.data(), pv.data());
+            P = HtQfH;
+            bool restart = false;
+            for (int t = N - 1; t >= 0; --t) {
+                const double *At = A.data() + (size_t)t * nn, *Bt = B.data() + (size_t)t * nm, *xt = x + (size_t)t * n, *ut = u + (size_t)t * m;
+                out(xt, z.data());
+                for (int a = 0; a < nz; ++a) dz[a] = z[a] - zt[(size_t)t * nz + a];
+                matvec(Q, nz, nz, dz.data(), g.data());
+                std::fill(Qx.begin(), Qx.end(), 0.0); matTvec_add(H, nz, n, g.data(), Qx.data());          // c_x
+                matTvec_add(At, n, n, pv.data(), Qx.data());                                                  // + A' p
+                for (int r = 0; r < m; ++r) {
+                    double s = 0.0;
+                    for (int q = 0; q < m; ++q) s += R[(size_t)r * m + q] * (ut[q] - (p.include_input_var_constraint ? (t == 0 ? ulast[q] : u[(size_t)(t - 1) * m + q]) : 0.0));
+                    cu[r] = s;
+                }
+                double *Qut = Qu.data() + (size_t)t * m, *Quu_t = Quu.data() + (size_t)t * m * m;
+                for (int r = 0; r < m; ++r) Qut[r] = cu[r];
+                matTvec_add(Bt, n, m, pv.data(), Qut);                                                        // Q_u = c_u + B' p
+                matmul(P.data(), At, n, n, n, PA.data()); matmul(P.data(), Bt, n, n, m, PB.data());
+                matTmul(At, PA.data(), n, n, n, Qxx.data());
+                for (size_t e = 0; e < nn; ++e) Qxx[e] += HtQH[e];
+                matTmul(Bt, PB.data(), n, m, m, Quu_t);
+                for (int e = 0; e < m * m; ++e) Quu_t[e] += R[e];
+                matTmul(Bt, PA.data(), n, m, n, Qux.data());
+                std::copy(Quu_t, Quu_t + m * m, Quut.begin()); Quxt = Qux;
+                if (p.regularize && p.state_regularization) {
+                    vec BB((size_t)m * m), BA(nm);
+                    matTmul(Bt, Bt, n, m, m, BB.data()); matTmul(Bt, At, n, m, n, BA.data());
+                    for (int e = 0; e < m * m; ++e) Quut[e] += rho * BB[e];
+                    for (size_t e = 0; e < nm; ++e) Quxt[e] += rho * BA[e];
+                } else if (p.regularize) {
+                    for (int r = 0; r < m; ++r) Quut[(size_t)r * m + r] += rho;
+                }
+                Lc = Quut;
+                if (!cholesky(Lc.data(), m)) {
+                    if (!p.regularize || ++restarts > 100) return false;
+                    reg(true); restart = true; break;
+                }
+                double *Kk = K + (size_t)t * nm;
+                chol_solve_neg(Lc.data(), m, Quxt.data(), n, Kk);                                             // K = -Q~uu^-1 Q~ux
+                chol_solve_neg(Lc.data(), m, Qut, 1, kt.data());                                              // k = -Q~uu^-1 Q_u
+                std::copy(kt.begin(), kt.end(), kff.begin() + (size_t)t * m);
+                // p = Q_x + K' Quu k + K' Q_u + Q_ux' k ;  P = Q_xx + K' Quu K + K' Q_ux + Q_ux' K
+                vec QuuK(nm), Quuk(m);
+                matmul(Quu_t, Kk, m, m, n, QuuK.data()); matvec(Quu_t, m, m, kt.data(), Quuk.data());
+                for (int i = 0; i < n; ++i) {
+                    double s = Qx[i];
+                    for (int r = 0; r < m; ++r) s += Kk[(size_t)r * n + i] * (Quuk[r] + Qut[r]) + Qux[(size_t)r * n + i] * kt[r];
+                    tmp[i] = s;
+                }
+                pv = tmp;
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) {
+                        double s = Qxx[(size_t)i * n + j];
+                        for (int r = 0; r < m; ++r) s += Kk[(size_t)r * n + i] * (QuuK[(size_t)r * n + j] + Qux[(size_t)r * n + j]) + Qux[(size_t)r * n + i] * Kk[(size_t)r * n + j];
+                        P[(size_t)i * n + j] = s;
+                    }
+            }
+            if (restart) continue;
+            reg(false);
+            return true;
+        }
+    };
+    std::fill(x2.begin(), x2.end(), 0.0);
+    std::copy(x0, x0 + n, x2.begin());
+    if (u_warm) std::copy(u_warm, u_warm + (size_t)N * m, u2.begin()); else std::fill(u2.begin(), u2.end(), 0.0);
+    double cost = forward(x2.data(), u2.data(), 1.0, nullptr, nullptr, x, u, A.data(), B.data(), dd.data());
+    int failed_counter = 0, it = 0;
+    bool converged = false;
+    while (!converged && it <= p.max_iter) {
+        if (!backward()) { it = -1; break; }
+        const double prev = cost;
+        double alpha = p.alpha0, nc = cost;
+        bool improved = false, failed = false;
+        while (!improved && !failed) {
+            improved = true;
+            nc = forward(x, u, alpha, K, kff.data(), x2.data(), u2.data(), A2.data(), B2.data(), d2.data());
+            double dc = 0.0;
+            for (int t = 0; t < N; ++t) {
+                const double *kt = kff.data() + (size_t)t * m;
+                double s1 = 0.0;
+                for (int r = 0; r < m; ++r) s1 += kt[r] * Qu[(size_t)t * m + r];
+                dc += alpha * s1 + alpha * alpha * 0.5 * quad(Quu.data() + (size_t)t * m * m, kt, m);
+            }
+            const double ratio = (nc - prev) / dc;
+            if (p.do_linesearch && (ratio <= p.improv_lb || ratio > p.improv_ub)) {
+                alpha *= p.alpha_scaling; improved = false;
+                if (alpha < p.alpha_min) { reg(true); rho += p.rho_increase_fp; failed = true; }
+            }
+        }
+        if (!failed) {
+            std::copy(x2.begin(), x2.end(), x); std::copy(u2.begin(), u2.end(), u);
+            A.swap(A2); B.swap(B2); dd.swap(d2);
+            cost = nc;
+            converged = (prev - cost) < p.epsilon && (prev - cost) >= 0.0;
+            failed_counter = 0;
+        } else if (++failed_counter >= p.counter_limit) {
+            converged = true;
+        }
+        ++it;
+    }
+    if (cost_out) *cost_out = cost;
+    return it;
+}
+
 template <typename F>
 void parallel_for(int64_t count, int threads, F f) {
     threads = std::max(1, std::min<int>(threads, (int)count));
@@ -1182,7 +1488,7 @@ struct scpu_problem {       // mirrors slocp_problem (include/sofacontrol_hip.h)
 struct scpu_model { int P, r, m; double w_q, w_v; const double *q, *v, *Ac, *Bc, *dc, *Ad, *Bd, *dd; };
 struct scpu_gusto_params { double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh; int max_gusto_iters; };
 
-int scpu_version(void) { return 2; }
+int scpu_version(void) { return 3; }
 
 // out (B x r) = (X (B x n_f) - ref) U (n_f x r), rows split over `threads`
 int scpu_project(const double *U, int64_t n_f, int r, const double *ref, const double *X, int64_t B, double *out, int threads) {
@@ -1272,6 +1578,58 @@ int scpu_gusto_solve(const scpu_model *mo, const scpu_problem *pr, const scpu_gu
                      double *trace, int max_trace, int threads) {
     return scpu_gusto_solve_algo(mo, pr, gp, dt, batch, x0, u_init, x_init, z, zf, u_des, x_char, f_char, xopt, uopt, iters, trace,
                                  max_trace, threads, 0);
+}
+
+struct scpu_ilqr_params {
+    int max_iter; double epsilon, alpha0, alpha_scaling, improv_lb, improv_ub, alpha_min; int counter_limit;
+    double rho0, drho0, rho_scaling, rho_increase_fp, rho_max, rho_min;
+    int include_input_var_constraint, do_linesearch, regularize, state_regularization;
+};
+static IlqrPar ilqr_par(const scpu_ilqr_params *p) {
+    return IlqrPar{p->max_iter, p->epsilon, p->alpha0, p->alpha_scaling, p->improv_lb, p->improv_ub, p->alpha_min, p->counter_limit, p->rho0,
+                   p->drho0, p->rho_scaling, p->rho_increase_fp, p->rho_max, p->rho_min, p->include_input_var_constraint, p->do_linesearch,
+                   p->regularize, p->state_regularization};
+}
+// iLQR on the prediscretised nearest-point TPWL model (oracle/lqr.py: ILQR): z = H x + z_ref; `batch` problems, one per thread
+int scpu_ilqr_tpwl(const scpu_model *mo, const double *H, const double *z_ref, int n_z, const double *Q, const double *R, const double *Qf,
+                   const scpu_ilqr_params *par, int N, int64_t batch, const double *x0, const double *z_target, const double *u_warm,
+                   const double *u_last, double *x, double *u, double *K, double *cost, int32_t *iters, int threads) {
+    Model M{mo->P, mo->r, 2 * mo->r, mo->m, mo->w_q, mo->w_v, mo->q, mo->v, mo->Ac, mo->Bc, mo->dc, mo->Ad, mo->Bd, mo->dd};
+    const int n = M.n, m = M.m;
+    const IlqrPar p = ilqr_par(par);
+    parallel_for(batch, threads, [&](int64_t b) {
+        auto lin = [&](const double *xx, const double *, double *A, double *B, double *d) {
+            const size_t i = (size_t)nearest(M, xx);
+            std::copy(M.Ad + i * n * n, M.Ad + (i + 1) * n * n, A); std::copy(M.Bd + i * n * m, M.Bd + (i + 1) * n * m, B);
+            std::copy(M.dd + i * n, M.dd + (i + 1) * n, d);
+        };
+        auto out = [&](const double *xx, double *z) { matvec(H, n_z, n, xx, z); for (int a = 0; a < n_z; ++a) z[a] += z_ref[a]; };
+        iters[b] = ilqr_one(N, n, m, n_z, H, Q, R, Qf, p, x0 + (size_t)b * n, z_target + (size_t)b * (N + 1) * n_z,
+                            u_warm ? u_warm + (size_t)b * N * m : nullptr, u_last ? u_last + (size_t)b * m : nullptr, lin, out,
+                            x + (size_t)b * (N + 1) * n, u + (size_t)b * N * m, K + (size_t)b * N * m * n, cost ? cost + b : nullptr);
+    });
+    return 0;
+}
+// iLQR on the SSM polynomial model (oracle/lqr.py: ILQRGeneric over oracle/ssm.py): mode 1 fe / 2 be / 3 bil, z = W phi_s(x) + z_ref,
+// constant H for the cost Jacobians
+int scpu_ilqr_ssm(int n, int m, int no, int rom_order, int ssm_order, const double *r_coeff, const double *B, const double *w_coeff,
+                  const double *z_ref, const double *H, int mode, double dt, const double *Q, const double *R, const double *Qf,
+                  const scpu_ilqr_params *par, int N, int64_t batch, const double *x0, const double *z_target, const double *u_warm,
+                  const double *u_last, double *x, double *u, double *K, double *cost, int32_t *iters, int threads) {
+    SsmModel S{};
+    S.n = n; S.m = m; S.no = no; S.order_r = rom_order; S.order_s = ssm_order; S.R = r_coeff; S.B = B; S.W = w_coeff; S.z_ref = z_ref;
+    S.mode = mode; S.dt = dt;
+    ssm_prepare(S);
+    const IlqrPar p = ilqr_par(par);
+    parallel_for(batch, threads, [&](int64_t b) {
+        vec phi, tmp, phis;
+        auto lin = [&](const double *xx, const double *uu, double *A, double *Bm, double *d) { ssm_lin(S, xx, uu, A, Bm, d, phi, tmp); };
+        auto out = [&](const double *xx, double *z) { ssm_out(S, xx, z, phis); };
+        iters[b] = ilqr_one(N, n, m, no, H, Q, R, Qf, p, x0 + (size_t)b * n, z_target + (size_t)b * (N + 1) * no,
+                            u_warm ? u_warm + (size_t)b * N * m : nullptr, u_last ? u_last + (size_t)b * m : nullptr, lin, out,
+                            x + (size_t)b * (N + 1) * n, u + (size_t)b * N * m, K + (size_t)b * N * m * n, cost ? cost + b : nullptr);
+    });
+    return 0;
 }
 
 }  // extern "C"

@@ -291,11 +291,13 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
 // instantiated shapes: the reference's 4- and 8-cable robots at the benchmark's r = 30 with the row layout their drivers use
 // (U box; Diamond: 4 state rows, Trunk: none; Diamond at the shipped r = 36 basis: n_x = 72), then n_x fixed / free with the
 // general row handling (GX = 0)
-// (M, NX, GX, NST, J0, NXR): first the layouts with every size fixed (BASELINE C2: Diamond, N = 50, 4 state rows; C5: Trunk,
+// (M, NX, GX, NST, J0, NXR); NST = -1: short horizons (N p_o <= 16), the interior point on one wave (ql::ipm_wave).
+// First the layouts with every size fixed (BASELINE C2: Diamond, N = 50, 4 state rows; C5: Trunk,
 // N = 50, no state rows; the Diamond at its shipped r = 36 basis), then the run-time-horizon forms
 // (a development build may pass its own, shorter list: tools/build_lean_dev.sh compiles the benchmark layouts only)
 #ifndef SRH_LEAN_VARIANTS
 #define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) X(4, 72, 4, 50, 18, 4) \
+    X(4, 60, 4, -1, 0, 0) X(4, 60, 1, -1, 0, 0) X(4, 72, 4, -1, 0, 0) X(8, 60, 1, -1, 0, 0) \
     X(4, 60, 4, 0, 0, 0) X(4, 60, 1, 0, 0, 0) X(8, 60, 1, 0, 0, 0) X(4, 72, 4, 0, 0, 0) X(4, 60, 0, 0, 0, 0) X(8, 60, 0, 0, 0, 0) X(4, 0, 0, 0, 0, 0) X(8, 0, 0, 0, 0, 0)
 #endif
 inline int lean_gx(const QPDims &d) {
@@ -307,6 +309,9 @@ inline bool lean_matches(const QPDims &d, bool allow_fixed, int msel, int nsel, 
     if (d.m != msel || (nsel != 0 && d.n != nsel)) return false;
     if (!(gx == 0 || gx == lean_gx(d))) return false;
     if (nst == 0) return true;
+    // nst < 0: the short-horizon form (ql::ipm_wave): K is one tile, one lane per input and per state-row slot, the whole packed
+    // G in LDS; SRH_LEAN_NO_WAVE=1 at plan creation skips it (A/B runs, tests of both forms)
+    if (nst < 0) return gx > 0 && d.KT == 1 && d.N * d.m <= 64 && d.N * gx <= 64 && d.lean_j0 == 0 && d.po == 2 && getenv("SRH_LEAN_NO_WAVE") == nullptr;
     return allow_fixed && d.N == nst && d.lean_j0 == j0 && d.nX == nxr && d.nXf == 0 && d.nz == 6 && d.po == 2 && d.nU == 2 * msel;
 }
 

@@ -1473,6 +1473,456 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     return status;
 }
 
+// ------------------------------------------------------------------ short horizons: the interior point on ONE wave
+// The reference's closed-loop drivers replan N = 5 (examples/diamond/diamond.py:309-316) and N = 3 (examples/hardware/diamond.py:
+// 393-399): N p_o <= 16 outputs -- K is ONE 16 x 16 tile -- and N n_u <= 64 inputs.  ipm_box() spends ~80 k clocks per interior-point
+// iteration on such a problem (profiles/r05_lean_phase_clocks.json: N = 5) although nothing in it is larger than a tile: some 35
+// workgroup barriers, each with seven waves that have nothing to do.  Here the iteration runs on wave 0 alone, without a single
+// workgroup barrier (the other waves wait at the one behind it):
+//   * lane e < N m owns input e = (stage, input): its value, its two box rows and their slacks / multipliers, its row of G^T
+//     (16 registers) -- G^T y is a lane-local dot product with the 16 broadcast entries of y;
+//   * lane l < N GX also owns a state-row slot (stage, slot) like the state-row threads of ipm_box (per-stage sums by DPP);
+//   * lane (i, kk) of 16 x 4 holds G in the MFMA layout G^T[4 s + kk][i], s < N m / 4: G u = one FMA per k-step + the sum over kk,
+//     and Ky = G D^-1 G^T is N m / 4 MFMA instructions whose A and B operands are THE SAME registers;
+//   * y-space vectors live in LDS (16 entries), exchanged under a wave-level fence (the LDS queue of a wave is in order).
+// Same iteration as ipm_box (same starting points, weights, stopping rule, warm start): sums in another order, rounding-level
+// differences.  Requirements (lean_matches): KT == 1, N m <= 64, N GX <= 64, the whole packed G in LDS (lean_j0 == 0).
+// what one wave needs between an LDS write and the read of it by another lane: nothing from the hardware (the LDS queue of a
+// wave is in order), only that the compiler keeps the accesses on their sides -- a wavefront-scope fence waits for no counter
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MSEL, int NSEL, int GX>
+__device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
+                                        Lds &L, int *iters_out, QPWork &wout, long long *prof, int warm_mode = 0) {
+    static_assert(MSEL == 4 || MSEL == 8, "one-wave interior point: n_u = 4 or 8");
+    const bool warm = warm_mode != 0, poison = warm_mode == 2;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    QPDims d = dfull;
+    d.tr = 0;
+    d.nrx = d.nX;
+    d.RX = d.nrx + d.nXf;
+    d.NR = d.N * d.RX + d.N * d.nU;
+    d.ng = d.N * d.nrx + d.nXf + d.N * d.nU;
+    QPWork w;
+    qp_carve(w, work_base, d);
+    wout = w;
+    gptr gh = work_base + dfull.qc_off;
+    constexpr int M = MSEL, SMAX = 2 * M;                      // k-steps of a product with G: N m / 4 <= 8 m / 4 (N <= 8)
+    const int N = d.N, nm = N * M, ldG = 16, NP = 2 * N, nz = d.nz;
+#ifdef SRH_PROFILE
+    long long tq_last = clock64();
+    auto qlap = [&](int slot) { const long long now = clock64(); prof[slot] += now - tq_last; tq_last = now; };
+#define QW_LAP(x) qlap(x)
+#else
+#define QW_LAP(x) ((void)0)
+#endif
+    // ---- the preamble of ipm_box: starting point, condensation (all waves)
+    constexpr double WARM_FLOOR = 1e-2;
+    if (warm) { for (int e = tid; e < nm; e += nt) L.u[e] = w.u[e]; }
+    else { for (int e = tid; e < nm; e += nt) { w.u[e] = 0.0; L.u[e] = 0.0; } }
+    for (int e = tid; e < ldG + YPAD; e += nt) { L.ya[e] = 0.0; L.yd[e] = 0.0; L.yg[e] = 0.0; }
+    for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
+    for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+    __syncthreads();
+    bool reuse = false;
+    if (dyn.idx != nullptr) {
+        int same = L.flag[2];
+        for (int k = tid; k < N; k += nt) same = same && (L.goff[k] == L.idxl[k]);
+        if (tid == 0) L.flag[3] = 1;
+        __syncthreads();
+        if (!same) L.flag[3] = 0;
+        __syncthreads();
+        reuse = L.flag[3] != 0;
+    }
+    if (!reuse) {
+        rollout<MSEL, NSEL>(d, dyn, q.x0, (cgptr) nullptr, w.x, L);
+        QW_LAP(0);
+        condense<MSEL, NSEL>(d, c, dyn, w.x, gh, L);
+        for (int k = tid; k < N; k += nt) L.goff[k] = L.idxl[k];
+        if (tid == 0) L.flag[2] = 1;
+    }
+    __syncthreads();
+    QW_LAP(2);
+    int status = 1, it = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave == 0) {
+        const int lane = tid, i16 = lane & 15, kk = lane >> 4;
+        const int S = nm >> 2;                                     // k-steps of the products with G (n_u is a multiple of 4)
+        // ---- G in registers, twice: by input row (gR) and in the MFMA operand layout (gM)
+        const bool isu = lane < nm;
+        const int ku = isu ? lane / M : 0, bu = isu ? lane - ku * M : 0;
+        auto g_at = [&](int e, int i) -> double {                 // G^T[e][i] from the packed rows (structural zeros: i < 2 j)
+            const int j = e / M, b = e - j * M;
+            return (i >= 2 * j && i < NP) ? L.Gt[goff(j, M, NP) + b * (NP - 2 * j) + (i - 2 * j)] : 0.0;
+        };
+        double gR[16], gM[SMAX];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gR[i] = isu ? g_at(lane, i) : 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; ++s2) gM[s2] = s2 < S ? g_at(4 * s2 + kk, i16) : 0.0;
+        // ---- this lane's rows: the two box rows of input `lane`, and one state-row slot
+        const bool isx = lane < N * GX;
+        const int kx = isx ? lane / GX + 1 : 1, rx = isx ? lane - (kx - 1) * GX : 0;
+        const int nrk = d.nX + (kx == N ? d.nXf : 0);
+        const bool xrow = isx && rx < nrk, xlead = isx && rx == 0;
+        double cu[2] = {0.0, 0.0}, hu[2] = {0.0, 0.0}, cx[2] = {0.0, 0.0}, hx = 0.0;
+        if (isu) {
+            cu[0] = c.UA[(size_t)(2 * bu) * M + bu]; cu[1] = c.UA[(size_t)(2 * bu + 1) * M + bu];
+            hu[0] = c.Ub[2 * bu]; hu[1] = c.Ub[2 * bu + 1];
+        }
+        if (xrow) {
+            cgptr T = rx < d.nX ? c.Tx + (size_t)rx * 2 : c.Txf + (size_t)(rx - d.nX) * 2;
+            cx[0] = T[0]; cx[1] = T[1];
+            hx = rx < d.nX ? c.Xb[rx] : c.Xfb[rx - d.nX];
+        }
+        const double r2bb = isu ? c.R2[bu * M + bu] : 0.0;
+        const double udv = (isu && q.ud) ? q.ud[(size_t)ku * M + bu] : 0.0;
+        double gc0 = 0.0, gc1 = 0.0, s00 = 0.0, s01 = 0.0, s11 = 0.0;
+        if (xlead) {
+            cgptr Sm = (kx == N) ? c.ScN : c.Sc;
+            s00 = Sm[0]; s01 = Sm[1]; s11 = Sm[3];
+            if (q.z) for (int b = 0; b < nz; ++b) { gc0 = fma(-c.Cz2[b], q.z[(size_t)kx * nz + b], gc0); gc1 = fma(-c.Cz2[nz + b], q.z[(size_t)kx * nz + b], gc1); }
+            if (kx == N && c.Qzf && q.zf) for (int b = 0; b < nz; ++b) { gc0 = fma(-c.Czf2[b], q.zf[b], gc0); gc1 = fma(-c.Czf2[nz + b], q.zf[b], gc1); }
+        }
+        const int lsu = 2 * lane, lsx = 2 * nm + (kx - 1) * (d.nX + d.nXf) + rx;           // this lane's rows in w.lam (layout of ipm_box)
+        double u_r = isu ? L.u[lane] : 0.0, du_r = 0.0, ldi = 0.0, w2 = 0.0, ta_r = 0.0, tb_r = 0.0;
+        double tu[2] = {0.0, 0.0}, lu[2] = {0.0, 0.0}, gu[2] = {0.0, 0.0}, ru[2] = {0.0, 0.0}, dtu[2] = {0.0, 0.0}, dlu[2] = {0.0, 0.0};
+        double tx = 0.0, lx = 0.0, gx = 0.0, rcx = 0.0, dtx = 0.0, dlx = 0.0;
+        // y = y_free (+ G u when warm), dy = 0: lanes (i, kk) with the sum over kk
+        auto g_times_w = [&](clptr uv) -> double {              // (G uv)[i16] on every lane; uv: N m entries of LDS
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < SMAX; s2 += 2) {
+                if (s2 < S) a0 = fma(gM[s2], uv[4 * s2 + kk], a0);
+                if (s2 + 1 < S) a1 = fma(gM[s2 + 1], uv[4 * (s2 + 1) + kk], a1);
+            }
+            double a = a0 + a1;
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            return a;
+        };
+        {
+            double y0 = L.yf[i16];
+            if (warm) y0 += g_times_w(L.u);
+            if (lane < 16) { L.y[lane] = lane < NP ? y0 : 0.0; L.dy[lane] = 0.0; }
+        }
+        wave_fence();
+        auto yval = [&](clptr vy) -> double { return fma(cx[1], vy[(kx - 1) * 2 + 1], cx[0] * vy[(kx - 1) * 2]); };
+        enum { INIT = 0, PRED = 1, CORR = 2 };
+        int mode = INIT;
+        double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
+        bool near_opt = false;
+        auto scales = [&]() {
+            for (int e = lane; e < d.n; e += 64) {
+                double gq = 0.0;
+                if (q.z) for (int a = 0; a < nz; ++a) gq = fma(c.HtQz2[e * nz + a], -q.z[nz + a], gq);
+                sd = fmax(sd, fabs(gq));
+            }
+            for (int e = lane; e < d.nU; e += 64) sp = fmax(sp, fabs(c.Ub[e]));
+            sd = fmax(wg::wave_max(sd), q.omega);
+            sp = fmax(wg::wave_max(sp), fabs(q.delta));
+            dreg = d.reg / sd;
+        };
+        if (warm && d.ng > 0) {
+            if (isu) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    tu[s2] = fmax(-(cu[s2] * u_r - hu[s2]), WARM_FLOOR);
+                    lu[s2] = poison ? INFINITY : fmax(w.lam[lsu + s2], WARM_FLOOR);
+                }
+            }
+            if (xrow) {
+                tx = fmax(-(yval(L.y) - hx), WARM_FLOOR);
+                lx = poison ? INFINITY : fmax(w.lam[lsx], WARM_FLOOR);
+            }
+            scales();
+            mode = PRED;
+        }
+        while (true) {
+            // ---------------- rows -> weights, gradient shifts, per-stage sums
+            double musum = 0.0, rpm = 0.0;
+            double Du[2] = {0.0, 0.0}, rhu[2] = {0.0, 0.0}, Dx = 0.0, rhx = 0.0;
+            if (isu) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (mode == INIT) {
+                        Du[s2] = 1.0; rhu[s2] = cu[s2] * u_r - hu[s2]; lu[s2] = 0.0;
+                    } else if (mode == PRED) {
+                        const double gq = cu[s2] * u_r - hu[s2], t = tu[s2], lam = lu[s2], rg = gq + t;
+                        gu[s2] = rg;
+                        Du[s2] = lam / (t + dreg * lam);
+                        rhu[s2] = Du[s2] * (rg + dreg * lam);
+                        musum += lam * t;
+                        rpm = fmax(rpm, fabs(rg));
+                    } else {
+                        const double t = tu[s2], lam = lu[s2], rc = lam * t + dtu[s2] * dlu[s2] - sig * mu;
+                        ru[s2] = rc;
+                        rhu[s2] = lam + (lam * gu[s2] - rc) / (t + dreg * lam);
+                    }
+                }
+                const double du0 = r2bb * (u_r - udv);
+                if (mode != CORR) {
+                    double v = fma(cu[0] * Du[0], cu[0], r2bb);
+                    v = fma(cu[1] * Du[1], cu[1], v);
+                    ldi = 1.0 / sqrt(v);
+                    w2 = ldi * ldi;
+                    L.tc[lane] = w2;                             // for the A operands of the Gram product
+                }
+                ta_r = fma(cu[1], rhu[1], fma(cu[0], rhu[0], du0));
+                if (mode == PRED) tb_r = fma(cu[1], lu[1], fma(cu[0], lu[0], du0));
+            }
+            if (xrow) {
+                if (mode == INIT) {
+                    Dx = 1.0; rhx = yval(L.y) - hx; lx = 0.0;
+                } else if (mode == PRED) {
+                    const double gq = yval(L.y) - hx, t = tx, lam = lx, rg = gq + t;
+                    gx = rg;
+                    Dx = lam / (t + dreg * lam);
+                    rhx = Dx * (rg + dreg * lam);
+                    musum += lam * t;
+                    rpm = fmax(rpm, fabs(rg));
+                } else {
+                    const double t = tx, lam = lx, rc = lam * t + dtx * dlx - sig * mu;
+                    rcx = rc;
+                    rhx = lam + (lam * gx - rc) / (t + dreg * lam);
+                }
+            }
+            {   // whole stage groups (every lane executes the DPP sums; lanes without a row contribute zeros)
+                const double y0 = isx ? L.y[(kx - 1) * 2] : 0.0, y1 = isx ? L.y[(kx - 1) * 2 + 1] : 0.0;
+                if (mode != CORR) {
+                    const double a00 = gsum<GX>(cx[0] * Dx * cx[0]), a01 = gsum<GX>(cx[0] * Dx * cx[1]), a11 = gsum<GX>(cx[1] * Dx * cx[1]);
+                    if (xlead) {
+                        const double S00 = s00 + a00, S01 = s01 + a01, S11 = s11 + a11;
+                        const double dmax = fmax(fabs(S00), fabs(S11));
+                        const double l00 = S00 > 1e-14 * dmax ? sqrt(S00) : 0.0;
+                        const double l10 = l00 > 0.0 ? S01 / l00 : 0.0;
+                        const double v = fma(-l10, l10, S11);
+                        const double l11 = v > 1e-14 * dmax ? sqrt(v) : 0.0;
+                        lptr Lk = L.Ls + (size_t)(kx - 1) * 4;
+                        Lk[0] = l00; Lk[1] = 0.0; Lk[2] = l10; Lk[3] = l11;
+                    }
+                }
+                const double r0 = gsum<GX>(cx[0] * rhx), r1 = gsum<GX>(cx[1] * rhx);
+                double l0 = 0.0, l1 = 0.0;
+                if (mode == PRED) { l0 = gsum<GX>(cx[0] * lx); l1 = gsum<GX>(cx[1] * lx); }
+                if (xlead) {
+                    const double c0 = fma(s01, y1, s00 * y0) + gc0, c1 = fma(s11, y1, s01 * y0) + gc1;
+                    L.ya[(kx - 1) * 2] = c0 + r0; L.ya[(kx - 1) * 2 + 1] = c1 + r1;
+                    if (mode == PRED) { L.yg[(kx - 1) * 2] = c0 + l0; L.yg[(kx - 1) * 2 + 1] = c1 + l1; }
+                }
+            }
+            if (mode == PRED) {
+                mu = wg::wave_sum(musum) / d.ng;
+                rp = wg::wave_max(rpm);
+            }
+            wave_fence();
+            // ---------------- K = I + Ls^T (G D^-1 G^T) Ls, scaled to a unit diagonal, and its factor (one tile)
+            bool ok = true;
+            if (mode != CORR) {
+                wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s2 = 0; s2 < SMAX; ++s2)
+                    if (s2 < S) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gM[s2] * L.tc[4 * s2 + kk], gM[s2], acc, 0, 0, 0);
+                const int kb = min(i16 >> 1, N - 1), bc = i16 & 1;
+                clptr Lb = L.Ls + (size_t)kb * 4;
+                const double cb_own = bc == 0 ? Lb[0] : Lb[3], cb_oth = bc == 0 ? Lb[2] : 0.0;
+                double kv[4];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int r = kk + 4 * qd, ka = min(r >> 1, N - 1), ar = r & 1;
+                    clptr La = L.Ls + (size_t)ka * 4;
+                    double v = (r < NP && i16 < NP) ? acc[qd] : 0.0;
+                    const double vp = wg::dpp_mov<0xB1>(v);
+                    v = fma(vp, cb_oth, v * cb_own);
+                    const double vr = __shfl_xor(v, 16, 64);
+                    v = ar == 0 ? fma(La[2], vr, La[0] * v) : La[3] * v;
+                    const bool dg = r == i16;
+                    v += dg ? 1.0 : 0.0;
+                    const double ri = rsqrt(dg ? v : 1.0);
+                    if (dg) L.ks[r] = ri * (1.5 - 0.5 * v * ri * ri);
+                    kv[qd] = v;
+                }
+                wave_fence();
+                const double sc = L.ks[i16];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) { const int r = kk + 4 * qd; L.B[r * TS + i16] = kv[qd] * (L.ks[r] * sc); }
+                wave_fence();
+                ok = qpc::chol16(L.B, L.Rinv);
+                wave_fence();
+            }
+            // ---------------- Newton direction
+            double rd = 0.0;
+            if (ok) {
+                double gty = 0.0, gtd = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gty = fma(gR[i], L.ya[i], gty);
+                if (mode == PRED) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) gtd = fma(gR[i], L.yg[i], gtd);
+                    rd = wg::wave_max(isu ? fabs(tb_r + gtd) : 0.0);
+                }
+                const double tt = -(ta_r + gty) * w2;
+                if (isu) L.ta[lane] = tt;
+                wave_fence();
+                const double yb = g_times_w(L.ta);
+                {   // yc = ks Ls^T yb per output stage
+                    const double yo = wg::dpp_mov<0xB1>(yb);
+                    const int k = i16 >> 1;
+                    double o = 0.0;
+                    if (k < N) {
+                        clptr Lk = L.Ls + (size_t)k * 4;
+                        o = (i16 & 1) == 0 ? fma(Lk[2], yo, Lk[0] * yb) * L.ks[i16] : Lk[3] * yb * L.ks[i16];
+                    }
+                    if (lane < 16) L.yc[lane] = o;
+                }
+                wave_fence();
+                {   // v = K^-1 yc = Rinv (Rinv^T yc)   (k_solve_unit, one tile)
+                    const int cc = lane >> 2, part = lane & 3;
+                    double t = 0.0;
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) t = fma(L.Rinv[(4 * part + kq) * TS + cc], L.yc[4 * part + kq], t);
+                    t = wg::group_sum<4>(t);
+                    wave_fence();
+                    if (part == 0) L.yc[cc] = t;
+                    wave_fence();
+                    double wv = 0.0;
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) wv = fma(L.Rinv[cc * TS + 4 * part + kq], L.yc[4 * part + kq], wv);
+                    wv = wg::group_sum<4>(wv);
+                    wave_fence();
+                    if (part == 0) L.yc[cc] = wv;
+                    wave_fence();
+                }
+                if (lane < 8) {                                   // yd = Ls (ks v), dy = Ls^-T (ks v) per output stage
+                    const int k = lane;
+                    double o0 = 0.0, o1 = 0.0, e0 = 0.0, e1 = 0.0;
+                    if (k < N) {
+                        clptr Lk = L.Ls + (size_t)k * 4;
+                        const double v0 = L.yc[2 * k] * L.ks[2 * k], v1 = L.yc[2 * k + 1] * L.ks[2 * k + 1];
+                        o0 = Lk[0] * v0;
+                        o1 = fma(Lk[3], v1, Lk[2] * v0);
+                        e1 = v1 / Lk[3];
+                        e0 = fma(-Lk[2], e1, v0) / Lk[0];
+                    }
+                    L.yd[2 * k] = o0; L.yd[2 * k + 1] = o1;
+                    if (d.ls_pd) { L.dy[2 * k] = e0; L.dy[2 * k + 1] = e1; }
+                }
+                wave_fence();
+                double gyd = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gyd = fma(gR[i], L.yd[i], gyd);
+                du_r = tt - gyd * w2;
+                if (!d.ls_pd) {                                   // dy = G du
+                    if (isu) L.ta[lane] = du_r;
+                    wave_fence();
+                    const double dyv = g_times_w(L.ta);
+                    if (lane < 16) L.dy[lane] = lane < NP ? dyv : 0.0;
+                    wave_fence();
+                }
+            }
+            // ---------------- use the direction
+            if (mode == INIT) {
+                if (!ok) { status = 2; break; }
+                u_r += du_r;
+                if (lane < 16) L.y[lane] += L.dy[lane];
+                wave_fence();
+                if (d.ng == 0) { status = 0; break; }
+                double zmin = INFINITY, zmax = -INFINITY;
+                if (isu) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) { gu[s2] = cu[s2] * u_r - hu[s2]; zmin = fmin(zmin, gu[s2]); zmax = fmax(zmax, gu[s2]); }
+                }
+                if (xrow) { gx = yval(L.y) - hx; zmin = fmin(zmin, gx); zmax = fmax(zmax, gx); }
+                zmin = wg::wave_min(zmin); zmax = wg::wave_max(zmax);
+                const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) { tu[s2] = -gu[s2] + sh_t; lu[s2] = gu[s2] + sh_l; }
+                tx = -gx + sh_t; lx = gx + sh_l;
+                scales();
+                mode = PRED;
+                continue;
+            }
+            double amax = 1e300;
+            if (ok) {
+                if (isu) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const double t = tu[s2], lam = lu[s2], rga = gu[s2] + cu[s2] * du_r;
+                        const double dl = ((mode == PRED ? -lam * t : -ru[s2]) + lam * rga) / (t + dreg * lam);
+                        const double dtv = -rga + dreg * dl;
+                        dlu[s2] = dl; dtu[s2] = dtv;
+                        if (dtv < 0.0) amax = fmin(amax, -t / dtv);
+                        if (dl < 0.0) amax = fmin(amax, -lam / dl);
+                    }
+                }
+                if (xrow) {
+                    const double t = tx, lam = lx, rga = gx + yval(L.dy);
+                    const double dl = ((mode == PRED ? -lam * t : -rcx) + lam * rga) / (t + dreg * lam);
+                    const double dtv = -rga + dreg * dl;
+                    dlx = dl; dtx = dtv;
+                    if (dtv < 0.0) amax = fmin(amax, -t / dtv);
+                    if (dl < 0.0) amax = fmin(amax, -lam / dl);
+                }
+            }
+            amax = wg::wave_min(amax);
+            if (mode == PRED) {
+                if (!ok) { status = near_opt ? 0 : 2; break; }
+                if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
+                if (!(rd == rd)) { status = near_opt ? 0 : 6; break; }
+                if (q.dbg && lane == 0) { gptr gd = q.dbg + 8 * it; gd[0] = mu; gd[1] = rd; gd[2] = rp; gd[3] = sd; gd[4] = sp; }
+                const double ltol = fmax(d.tol, 1e-9);
+                if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
+                near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
+                if (it >= d.max_iter) { status = 1; break; }
+                const double a_aff = fmin(1.0, amax);
+                double ma = 0.0;
+                if (isu) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) ma += (lu[s2] + a_aff * dlu[s2]) * (tu[s2] + a_aff * dtu[s2]);
+                }
+                if (xrow) ma += (lx + a_aff * dlx) * (tx + a_aff * dtx);
+                const double mu_aff = wg::wave_sum(ma) / d.ng;
+                sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+                if (q.dbg && lane == 0) { gptr gd = q.dbg + 8 * it; gd[5] = a_aff; gd[6] = sig; }
+                mode = CORR;
+                continue;
+            }
+            if (!ok) { status = 2; break; }
+            const double a = fmin(1.0, 0.99 * amax);
+            if (q.dbg && lane == 0) { gptr gd = q.dbg + 8 * it; gd[7] = a; }
+            u_r += a * du_r;
+            if (lane < 16) L.y[lane] += a * L.dy[lane];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { tu[s2] += a * dtu[s2]; lu[s2] += a * dlu[s2]; }
+            tx += a * dtx; lx += a * dlx;
+            wave_fence();
+            ++it;
+            mode = PRED;
+        }
+        // ---- results: the minimiser, and (converged) the multipliers the next QP of this solve starts from
+        if (isu) {
+            w.u[lane] = u_r;
+            if (status == 0) { w.lam[lsu] = lu[0]; w.lam[lsu + 1] = lu[1]; }
+        }
+        if (xrow && status == 0) w.lam[lsx] = lx;
+        if (lane == 0) { L.red[0] = (double)status; L.red[1] = (double)it; }
+    }
+    __syncthreads();
+    status = (int)L.red[0];
+    it = (int)L.red[1];
+    __syncthreads();
+    QW_LAP(6);
+#ifdef SRH_PROFILE
+    prof[24] += it; prof[25] += 1; prof[26] += warm ? 1 : 0;
+#endif
+    if (iters_out) *iters_out = it;
+    return status;
+}
+
 // The QP as the SCP loop needs it: condensed interior point, states by a rollout of the minimiser, objective, trust-region
 // test.  Returns 0 when the result IS the minimiser of the full QP (converged, inside the trust region); anything else
 // means "hand this QP to the fused kernel" (status of the interior point, or 100 = minimiser outside the trust region).
@@ -1486,7 +1936,9 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     int st;
     // GXSEL > 0: box-structured input rows, rows next to their sums, GXSEL lanes per stage for the state rows (one variant per
     // kernel: both interior points in one kernel thrash the instruction cache -- measured -8 % on everything)
-    if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL, NST, J0SEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof, warm);
+    // NST < 0: the short-horizon instantiations (one tile of K): the interior point on one wave
+    if constexpr (NST < 0) st = ipm_wave<MSEL, NSEL, GXSEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof, warm);
+    else if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL, NST, J0SEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof, warm);
     else st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
     if (iters_out) *iters_out = it;
     if (st != 0) return st;

@@ -376,6 +376,7 @@ struct IlqrArgs {
     size_t work_stride;
     double *lin;           // SSM model only, per problem: 2 x N x (n n + n m + n) per-step (A, B, d)
     int ssm_mode;          // SSM model only: discretisation mode (ssm_dev.h)
+    int jl_cap;            // SSM model only: slots per compact derivative list (ssm::jacobian_list_cap; 0: dense derivative table)
     int stage_ab;          // 1: the backward pass stages (A_t, B_t) in LDS
     size_t panel_off;      // doubles from the start of LDS to the MFMA panels
     int mfma;              // 1: backward pass on f64 MFMA products over padded LDS panels (n_x + n_u panels fit LDS)
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
     if constexpr (MODEL == 1) {
         ssm::carve(sw, dl + n, S);
         // coefficient rows and exponent tables of the polynomial model into LDS, once per kernel
-        ssm::stage(ST, dl + n + ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns), S, a.ssm_mode == SSM_DISCRETE_MAP);
+        ssm::stage(ST, dl + n + ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns), S, a.ssm_mode == SSM_DISCRETE_MAP, a.jl_cap);
     }
     // MFMA backward pass: padded panels P / G, [A|B], W = P [A|B] (NPa x ld each) and B^T [A|B] (16 x ld)
     const int NPa = (n + m + 15) & ~15, ldp = NPa + 1, NK4 = (n + 3) & ~3, n16 = (n + 15) & ~15;
@@ -479,6 +480,10 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
     gptr wk = (gptr)a.work + p * a.work_stride;
     gptr X2 = wk, U2 = X2 + (size_t)(N + 1) * n, kff = U2 + (size_t)N * m, Qu = kff + (size_t)N * m;
     gptr Quu = Qu + (size_t)N * m, K2 = Quu + (size_t)N * m * m;
+    // SSM model: z(x_t) - z*_t of the accepted trajectory (ZC) and of the forward pass in flight (ZC2), (N + 1) x nz each -- the
+    // backward pass takes them from here instead of evaluating the output polynomial of every x_t a second time (same values:
+    // the forward pass has just computed them from the same states)
+    gptr ZC = K2 + (size_t)N * m * n, ZC2 = ZC + (size_t)(N + 1) * nz;
     giptr idx = (giptr)a.iwork + p * 2 * (size_t)N, idx2 = idx + N;
     const silqr_params &P_ = a.par;
     gptr lin = MODEL == 1 ? (gptr)a.lin + p * 2 * (size_t)N * lstride : (gptr) nullptr;
@@ -502,6 +507,8 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
 
     // forward pass (ilqr.py:117-162): from (xp, up) with gains (Kg, kg, alpha) into (xo, uo, io); returns cost
 #ifdef SRH_PROFILE
+    long long dprof[6] = {0, 0, 0, 0, 0, 0};
+    sw.prof = dprof;
     long long fp[6] = {0, 0, 0, 0, 0, 0};
     long long fpl = 0;
 #define FP_T0() fpl = clock64()
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
 #define FP_LAP(i) ((void)0)
 #endif
     auto forward = [&](cgptr xp, cgptr up, double alpha, cgptr Kg, cgptr kg, gptr xo, gptr uo, giptr io,
-                       gptr lo) -> double {
+                       gptr lo, gptr zco) -> double {
         double cost = 0.0;
         for (int e = tid; e < n; e += nt) { L.v1[e] = x0[e]; xo[e] = x0[e]; }
         __syncthreads();
@@ -542,6 +549,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
                 __syncthreads();
                 FP_LAP(0);
                 zerr((clptr)L.v1, t);
+                if (tid < nz) zco[(size_t)t * nz + tid] = zt[tid];
                 FP_LAP(1);
                 ssm::jacobians_l(S, ST, a.ssm_mode == SSM_DISCRETE_MAP, (clptr)L.v1, (clptr)L.u1, sw, Al, n, Bl, dl);
                 FP_LAP(2);
@@ -587,6 +595,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
             FP_LAP(4);
         }
         zerr((clptr)L.v1, N);
+        if constexpr (MODEL == 1) { if (tid < nz) zco[(size_t)N * nz + tid] = zt[tid]; }
         if (tid < 64) {
             double c = 0.0;
             for (int e = tid; e < nz * nz; e += 64) c = fma(zt[e / nz] * Qfg[e], zt[e % nz], c);
@@ -802,7 +811,8 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
             for (int e = tid; e < prow * ldp; e += nt) Pm[e] = 0.0;
             if (!abg) for (int e = tid; e < NPa * ldp; e += nt) ABm[e] = 0.0;
             __syncthreads();
-            zerr((clptr)xl, N);
+            if constexpr (MODEL == 1) { if (tid < nz) zt[tid] = ZC[(size_t)N * nz + tid]; __syncthreads(); }
+            else zerr((clptr)xl, N);
             for (int e = tid; e < n * n; e += nt) {
                 const int r = e / n, c = e - r * n;
                 double v = 0.0;
@@ -857,7 +867,8 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
                     }
                     __syncthreads();
                 } else {
-                    zerr((clptr)xl, t);
+                    if (tid < nz) zt[tid] = ZC[(size_t)t * nz + tid];      // z(x_t) - z*_t as the forward pass computed it
+                    __syncthreads();
                 }
                 if (tid >= O1 && tid < O1 + m) {
                     const int r = tid - O1;
@@ -1007,7 +1018,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
 #define IL_T0() ((void)0)
 #define IL_ACC(v) ((void)0)
 #endif
-    double cost = forward((cgptr)X2, (cgptr)U2, 1.0, (cgptr)nullptr, (cgptr)nullptr, X, U, idx, lin);
+    double cost = forward((cgptr)X2, (cgptr)U2, 1.0, (cgptr)nullptr, (cgptr)nullptr, X, U, idx, lin, ZC);
     int failed_counter = 0, it = 0;
     bool converged = false;
     while (!converged && it <= P_.max_iter) {
@@ -1022,7 +1033,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
         while (!improved && !failed) {
             improved = true;
             IL_T0();
-            new_cost = forward((cgptr)X, (cgptr)U, alpha, (cgptr)Kout, (cgptr)kff, X2, U2, idx2, lin2);
+            new_cost = forward((cgptr)X, (cgptr)U, alpha, (cgptr)Kout, (cgptr)kff, X2, U2, idx2, lin2, ZC2);
             IL_ACC(tf);
 #ifdef SRH_PROFILE
             ++nf;
@@ -1065,6 +1076,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
                 for (int e = tid; e < N; e += nt) idx[e] = idx2[e];
             } else {
                 gptr tmp = lin; lin = lin2; lin2 = tmp;
+                tmp = ZC; ZC = ZC2; ZC2 = tmp;
             }
             __syncthreads();
             cost = new_cost;
@@ -1080,6 +1092,8 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
 #ifdef SRH_PROFILE
     if (tid == 0 && p == 0) printf("[ilqr] forward laps per step: control %.0f zerr %.0f jacobians %.0f discretize %.0f cost+store+update %.0f\n",
                                    (double)fp[0] / (nf + 1) / N, (double)fp[1] / (nf + 1) / N, (double)fp[2] / (nf + 1) / N, (double)fp[3] / (nf + 1) / N, (double)fp[4] / (nf + 1) / N);
+    if (tid == 0 && p == 0) printf("[ilqr] discretize laps per step: build %.0f inverses %.0f sep %.0f products %.0f copy %.0f\n",
+                                   (double)dprof[0] / (nf + 1) / N, (double)dprof[1] / (nf + 1) / N, (double)dprof[2] / (nf + 1) / N, (double)dprof[3] / (nf + 1) / N, (double)dprof[4] / (nf + 1) / N);
     if (tid == 0 && p == 0) printf("[ilqr] problem 0: %d iterations, %d forward passes %lld clocks (%.0f per step), backward %lld clocks (%.0f per stage); mfma %d\n",
                                    it, nf, tf, (double)tf / (nf > 0 ? nf : 1) / N, tb, (double)tb / (it > 0 ? it : 1) / N, a.mfma);
 #endif
@@ -1213,7 +1227,7 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
     if (p) par = *p; else silqr_default_params(&par);
     srh::DevBuf d0, dz, duw, dul, dQ, dR, dQf, ox, ou, oK, oc, oi, work, iwork, lin;
     int rc;
-    const size_t stride = (size_t)(N + 1) * n + (size_t)N * m * 3 + (size_t)N * m * m + (size_t)N * m * n + 8;
+    const size_t stride = (size_t)(N + 1) * n + (size_t)N * m * 3 + (size_t)N * m * m + (size_t)N * m * n + 2 * (size_t)(N + 1) * nz + 8;
     const size_t lstride = (size_t)n * n + (size_t)n * m + n;
     if ((rc = d0.upload(x0, sizeof(double) * batch * n)) || (rc = dz.upload(z_target, sizeof(double) * batch * (N + 1) * nz)) ||
         (rc = dQ.upload(Q, sizeof(double) * nz * nz)) || (rc = dR.upload(R, sizeof(double) * m * m)) ||
@@ -1228,9 +1242,13 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
     IlqrArgs a{N, n, m, nz, par, d0.as<double>(), dz.as<double>(), u_warm ? duw.as<double>() : nullptr,
                u_last ? dul.as<double>() : nullptr, dQ.as<double>(), dR.as<double>(), dQf.as<double>(), ox.as<double>(),
                ou.as<double>(), oK.as<double>(), oc.as<double>(), oi.as<int>(), work.as<double>(), iwork.as<int>(), stride,
-               hs ? lin.as<double>() : nullptr, ssm_mode, 0, 0, 0, dt};
+               hs ? lin.as<double>() : nullptr, ssm_mode, 0, 0, 0, 0, dt};
+    if (hs && !getenv("SRH_SSM_DENSE_JACOBIAN")) {
+        const std::vector<int> er = ssm_exponents(hs->n, hs->order_r);
+        a.jl_cap = ssm::jacobian_list_cap(er.data(), hs->nr, hs->n);
+    }
     const size_t tail = 20 + (size_t)16 * n + 16 + NT + 16 + n +
-                        (hs ? lstride + ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns) + ssm::lds_tab_doubles(hs->n, hs->no, hs->nr, hs->ns) : 0);
+                        (hs ? lstride + ssm::work_doubles(hs->n, hs->m, hs->no, hs->nr, hs->ns) + ssm::lds_tab_doubles(hs->n, hs->no, hs->nr, hs->ns, a.jl_cap) : 0);
     // preferred: backward pass on f64 MFMA products over three padded (NPa x ld) panels + one 16-row panel
     const size_t NPa = (size_t)((n + m + 15) & ~15), ldp = NPa + 1;
     const size_t mf_off = lqr_lds_doubles(n, m, 256) + tail;
@@ -1258,15 +1276,15 @@ static int ilqr_impl(stpwl_t *ht, sssm_t *hs, int ssm_mode, double dt, int N, in
     SRH_REQUIRE(lds <= 160 * 1024, "silqr_solve: state dimension too large for LDS (%zu bytes)", lds);
     lds = srh::lds_request(lds);
     // variants: the reference's robots at the benchmark / shipped basis sizes (TPWL), the C3 SSM shape; else all sizes
-    // (model, n_x, n_u, threads): the one-wave forms first -- small models, where eight waves only wait for each other
-#define SRH_ILQR_VARIANTS(X) X(1, 10, 8, 64) X(1, 10, 8, 128) X(1, 10, 8, 256) X(1, 0, 0, 64) X(0, 60, 4, NT) X(0, 60, 8, NT) X(0, 72, 4, NT) X(1, 10, 8, NT) X(0, 0, 0, NT) X(1, 0, 0, NT)
+    // (model, n_x, n_u, threads)
+#define SRH_ILQR_VARIANTS(X) X(1, 10, 8, 64) X(0, 60, 4, NT) X(0, 60, 8, NT) X(0, 72, 4, NT) X(1, 10, 8, NT) X(0, 0, 0, NT) X(1, 0, 0, NT)
     {
         const int model = ht ? 0 : 1;
-        // one wave per problem: SSM models whose padded [A | B] panel is two MFMA tiles wide at most and N <= 512 (the expected-
-        // decrease sum above); SRH_ILQR_THREADS=512 / 64 forces a form (A/B runs, tests of both)
+        // SRH_ILQR_THREADS=64: one wave per problem for the C3 shape (A/B runs; measured SLOWER than eight waves -- 21 ms against
+        // 10.4 ms -- because the parallel phases, 110 dot products of length 285 and 2850 table entries per step, then run on 64
+        // lanes: DESIGN.md section 13); results bit-identical to the 512-thread form
         const char *force = getenv("SRH_ILQR_THREADS");
-        const bool small = hs && a.mfma == 1 && n + m <= 32 && N <= 512;
-        const int threads = force ? (atoi(force) < NT && hs && a.mfma == 1 ? atoi(force) : NT) : (small ? 64 : NT);
+        const int threads = (force && atoi(force) == 64 && hs && a.mfma == 1 && n == 10 && m == 8 && N <= 512) ? 64 : NT;
         bool launched = false;
 #define X(MD, NX, MU, TH)                                                                                                       \
     if (!launched && model == MD && (NX == 0 || n == NX) && (MU == 0 || m == MU) && threads == TH) {                            \

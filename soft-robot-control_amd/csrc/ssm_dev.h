@@ -3,6 +3,7 @@
 // discretize_dynamics 279-301, update_dynamics 331-333.
 #pragma once
 #include "dev_la.h"
+#include <type_traits>
 
 struct SsmDev {
     int n, m, no;              // reduced state, input, observed dimension
@@ -128,55 +129,75 @@ __device__ inline void inverse_wave(lptr M, lptr Minv, int n, int ld) {
     };
     for (int e = lane; e < n * n; e += 64) Minv[(e / n) * ld + e % n] = (e / n == e % n) ? 1.0 : 0.0;
     wsync();
-    constexpr int EP = 4;                                          // elements per lane in the elimination: n * n <= 256
+    if (n * n <= 256) {
+        // Round 5: ONE read phase and ONE write phase per pivot.  The three steps of `inverse` -- exchange rows k and p, divide
+        // the pivot row by d, eliminate column k from the other rows -- read only OLD values when every lane gathers, for each of
+        // its entries (i, j): the pivot row's M[p][j] and Minv[p][j], the multiplier and its own entries from the row that the
+        // exchange puts in place i (row p for i = k, row k for i = p), and d.  The pivot row's new entries M[p][j] / d are formed
+        // by every lane that needs them (the same IEEE division `inverse` performs once per column: same bits), the other rows
+        // by the same FMAs.  ~0.9 k clocks per pivot instead of ~2 k (three LDS round trips and three fences less).
+        auto run = [&](auto EP_) {
+            constexpr int EP = decltype(EP_)::value;
+            for (int k = 0; k < n; ++k) {
+                const bool cand = lane >= k && lane < n;
+                const double v = cand ? fabs(M[lane * ld + k]) : -1.0;
+                const double mx = wg::wave_max(v);
+                const unsigned long long hit = __ballot(cand && v == mx);
+                const int p = hit ? __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1) : k;
+                const double d = M[p * ld + k];
+                double mp[EP], ip[EP], om[EP], oi[EP], f[EP];
+#pragma unroll
+                for (int q = 0; q < EP; ++q) {
+                    const int e = lane + 64 * q, ec = e < n * n ? e : 0, i2 = ec / n, j2 = ec - i2 * n;
+                    const int is = i2 == k ? p : (i2 == p ? k : i2);          // the row that stands in place i2 after the exchange
+                    mp[q] = M[p * ld + j2]; ip[q] = Minv[p * ld + j2];
+                    om[q] = M[is * ld + j2]; oi[q] = Minv[is * ld + j2]; f[q] = M[is * ld + k];
+                }
+                wsync();
+#pragma unroll
+                for (int q = 0; q < EP; ++q) {
+                    const int e = lane + 64 * q, i2 = e / n, j2 = e - i2 * n;
+                    if (e < n * n) {
+                        const double rk = mp[q] / d, ri = ip[q] / d;
+                        if (i2 == k) {
+                            M[i2 * ld + j2] = rk; Minv[i2 * ld + j2] = ri;
+                        } else {
+                            Minv[i2 * ld + j2] = fma(-f[q], ri, oi[q]);
+                            M[i2 * ld + j2] = j2 != k ? fma(-f[q], rk, om[q]) : 0.0;
+                        }
+                    }
+                }
+                wsync();
+            }
+        };
+        if (n * n <= 64) run(std::integral_constant<int, 1>{});
+        else if (n * n <= 128) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 4>{});
+        return;
+    }
     for (int k = 0; k < n; ++k) {
         const bool cand = lane >= k && lane < n;
         const double v = cand ? fabs(M[lane * ld + k]) : -1.0;
         const double mx = wg::wave_max(v);
         const unsigned long long hit = __ballot(cand && v == mx);
         const int p = hit ? __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1) : k;
-        // rows k and p change places while row k is scaled: lane j reads both entries of its column, divides the pivot
-        // row's by d (read by every lane before anything is written), and writes them back swapped
         const double d = M[p * ld + k];
-        {
-            const int jc = lane < n ? lane : 0;
+        for (int jc = lane; jc < n; jc += 64) {                       // n <= 64: one trip
             const double mp = M[p * ld + jc], ip = Minv[p * ld + jc], mk = M[k * ld + jc], ik = Minv[k * ld + jc];
             wsync();
-            if (lane < n) {
-                M[k * ld + jc] = mp / d; Minv[k * ld + jc] = ip / d;
-                if (p != k) { M[p * ld + jc] = mk; Minv[p * ld + jc] = ik; }
-            }
+            M[k * ld + jc] = mp / d; Minv[k * ld + jc] = ip / d;
+            if (p != k) { M[p * ld + jc] = mk; Minv[p * ld + jc] = ik; }
         }
         wsync();
-        // eliminate column k from the other rows and clear it: every lane reads what it needs (multiplier, pivot row, own
-        // entries) before the first write of the phase
-        if (n * n <= 64 * EP) {
-            double f[EP], rk[EP], ri[EP], om[EP], oi[EP];
-#pragma unroll
-            for (int q = 0; q < EP; ++q) {
-                const int e = lane + 64 * q, ec = e < n * n ? e : 0, i2 = ec / n, j2 = ec % n;
-                f[q] = M[i2 * ld + k]; rk[q] = M[k * ld + j2]; ri[q] = Minv[k * ld + j2]; om[q] = M[i2 * ld + j2]; oi[q] = Minv[i2 * ld + j2];
-            }
-            wsync();
-#pragma unroll
-            for (int q = 0; q < EP; ++q) {
-                const int e = lane + 64 * q, i2 = e / n, j2 = e % n;
-                if (e < n * n && i2 != k) {
-                    Minv[i2 * ld + j2] = fma(-f[q], ri[q], oi[q]);
-                    M[i2 * ld + j2] = j2 != k ? fma(-f[q], rk[q], om[q]) : 0.0;
-                }
-            }
-        } else {
-            for (int e = lane; e < n * n; e += 64) {
-                const int i2 = e / n, j2 = e % n;
-                if (i2 == k) continue;
-                const double f = M[i2 * ld + k];
-                Minv[i2 * ld + j2] = fma(-f, Minv[k * ld + j2], Minv[i2 * ld + j2]);
-                if (j2 != k) M[i2 * ld + j2] = fma(-f, M[k * ld + j2], M[i2 * ld + j2]);
-            }
-            wsync();
-            for (int i2 = lane; i2 < n; i2 += 64) if (i2 != k) M[i2 * ld + k] = 0.0;
+        for (int e = lane; e < n * n; e += 64) {
+            const int i2 = e / n, j2 = e % n;
+            if (i2 == k) continue;
+            const double f = M[i2 * ld + k];
+            Minv[i2 * ld + j2] = fma(-f, Minv[k * ld + j2], Minv[i2 * ld + j2]);
+            if (j2 != k) M[i2 * ld + j2] = fma(-f, M[k * ld + j2], M[i2 * ld + j2]);
         }
+        wsync();
+        for (int i2 = lane; i2 < n; i2 += 64) if (i2 != k) M[i2 * ld + k] = 0.0;
         wsync();
     }
 }
@@ -187,23 +208,29 @@ struct Work {
     lptr M1, M2, M3, M4;   // n x ld each (discretisation scratch)
     lptr f;        // n
     liptr piv;
+#ifdef SRH_PROFILE
+    long long *prof;   // discretize(): 6 lap counters of the calling thread (or null)
+#endif
 };
 
 __host__ __device__ inline size_t work_doubles(int n, int m, int no, int nr, int ns) {
     const int ld = n | 1;
     const size_t nb = (size_t)(nr > ns ? nr : ns);
     const size_t nd = (size_t)nr * n > (size_t)ns * no ? (size_t)nr * n : (size_t)ns * no;
-    return nb + nd + 4 * (size_t)n * ld + n + 4;
+    return nb + nd + 4 * (size_t)n + 4 * (size_t)n * ld + n + 4;      // (+ 4 n: the compact derivative table of jacobians_l may exceed nr n by 3 n)
 }
 
 __device__ inline void carve(Work &w, lptr base, const SsmDev &S) {
     const int ld = S.n | 1;
     const size_t nb = (size_t)(S.nr > S.ns ? S.nr : S.ns);
     const size_t nd = (size_t)S.nr * S.n > (size_t)S.ns * S.no ? (size_t)S.nr * S.n : (size_t)S.ns * S.no;
-    w.phi = base; w.D = w.phi + nb; w.M1 = w.D + nd; w.M2 = w.M1 + (size_t)S.n * ld; w.M3 = w.M2 + (size_t)S.n * ld;
+    w.phi = base; w.D = w.phi + nb; w.M1 = w.D + nd + 4 * (size_t)S.n; w.M2 = w.M1 + (size_t)S.n * ld; w.M3 = w.M2 + (size_t)S.n * ld;
     w.M4 = w.M3 + (size_t)S.n * ld;
     w.f = w.M4 + (size_t)S.n * ld;
     w.piv = (liptr)(w.f + S.n + 2);
+#ifdef SRH_PROFILE
+    w.prof = nullptr;
+#endif
 }
 
 __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w, lptr A, int lda, lptr Bm, lptr d);
@@ -252,6 +279,12 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
         return;
     }
     // be:  A_d = inv(I - dt A);  bil: A_d = (I + dt/2 A) inv(I - dt/2 A);  sep = inv(A) (A_d - I)
+#ifdef SRH_PROFILE
+    long long dl_ = clock64();
+#define SSM_DLAP(i) do { if (w.prof) { const long long now_ = clock64(); w.prof[i] += now_ - dl_; dl_ = now_; } } while (0)
+#else
+#define SSM_DLAP(i) ((void)0)
+#endif
     const int ld = n | 1;
     const double h = mode == SSM_BE ? dt : 0.5 * dt;
     for (int e = tid; e < n * n; e += nt) {
@@ -260,6 +293,7 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
         w.M3[i * ld + j] = A[i * lda + j];
     }
     __syncthreads();
+    SSM_DLAP(0);
     // M2 = inv(I - h A) and M4 = inv(A_c): independent, one wave each (a single-wave workgroup does them in turn)
     if (n <= 64) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x + 63) >> 6;
@@ -270,6 +304,7 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
         inverse(w.M1, w.M2, n, ld, w.piv);
         inverse(w.M3, w.M4, n, ld, w.piv);
     }
+    SSM_DLAP(1);
     if (mode == SSM_BIL) {
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e % n;
@@ -288,6 +323,7 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
         w.M3[i * ld + j] = s;
     }
     __syncthreads();
+    SSM_DLAP(2);
     for (int e = tid; e < n * n; e += nt) A[(e / n) * lda + e % n] = w.M2[(e / n) * ld + e % n];
     for (int i = tid; i < n; i += nt) {
         double s = 0.0;
@@ -301,9 +337,11 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
         w.M1[i * ld + j] = s;                                    // m <= n assumed for the scratch (checked on host)
     }
     __syncthreads();
+    SSM_DLAP(3);
     for (int e = tid; e < n * m; e += nt) Bm[e] = w.M1[(e / m) * ld + e % m];
     for (int e = tid; e < n; e += nt) d[e] = w.f[e];
     __syncthreads();
+    SSM_DLAP(4);
 }
 
 // z = C_map(x) = W phi_s(x) (no z_ref); optional observer Jacobian Hj = W Dphi_s (no x n) and c = z - Hj x
@@ -345,22 +383,41 @@ struct SsmLds {
     liptr er, dmr, pr, vr;     // rom basis tables: exponents (nr x n), derivative monomial (nr x n), parent, variable (nr)
     liptr es, dms, ps, vs;     // ssm basis tables
     int lvr[8], lvs[8];        // first monomial of every degree (order <= 6)
+    // compact derivative lists of the rom basis (jacobians_l): column j of D = d phi / d x has a structural non-zero only where
+    // x_j divides the monomial (cubic basis in 10 variables: 66 of 285).  List (j, g), g = k mod 4, holds those monomials k in
+    // increasing order, jcap slots each (padded): jk = k, jq = index of the monomial e_k - 1_j (-2: the constant 1, -1: padding),
+    // je = the exponent e_kj.
+    liptr jk, jq, je;
+    int jcap;
 };
 
 namespace ssm {
 
-__host__ __device__ inline size_t lds_tab_doubles(int n, int no, int nr, int ns) {
-    const size_t ints = 2 * (size_t)nr * n + 2 * (size_t)nr + 2 * (size_t)ns * no + 2 * (size_t)ns;
+__host__ __device__ inline size_t lds_tab_doubles(int n, int no, int nr, int ns, int jcap = 0) {
+    const size_t ints = 2 * (size_t)nr * n + 2 * (size_t)nr + 2 * (size_t)ns * no + 2 * (size_t)ns + 3 * (size_t)4 * n * jcap;
     return (size_t)n * nr + (size_t)no * ns + (size_t)n * 16 + (ints + 1) / 2 + 8;       // m <= 16
+}
+// slots per compact derivative list: the longest list (j, k mod 4) of the basis with exponent table E (nr x n); host side
+inline int jacobian_list_cap(const int *E, int nr, int n) {
+    int cap = 0;
+    for (int j = 0; j < n; ++j)
+        for (int g = 0; g < 4; ++g) {
+            int c = 0;
+            for (int k = g; k < nr; k += 4) c += E[(size_t)k * n + j] > 0;
+            cap = c > cap ? c : cap;
+        }
+    return cap;
 }
 
 // copy the tables (all threads; ends with a sync)
-__device__ inline void stage(SsmLds &T, lptr base, const SsmDev &S, bool discrete_map) {
+__device__ inline void stage(SsmLds &T, lptr base, const SsmDev &S, bool discrete_map, int jcap = 0) {
     const int n = S.n, no = S.no, nr = S.nr, ns = S.ns, tid = threadIdx.x, nt = blockDim.x;
+    T.jcap = jcap;
     T.R = base; T.W = T.R + (size_t)n * nr; T.Bg = T.W + (size_t)no * ns;
     liptr ip = (liptr)(T.Bg + (size_t)n * 16);
     T.er = ip; T.dmr = T.er + nr * n; T.pr = T.dmr + nr * n; T.vr = T.pr + nr;
     T.es = T.vr + nr; T.dms = T.es + ns * no; T.ps = T.dms + ns * no; T.vs = T.ps + ns;
+    T.jk = T.vs + ns; T.jq = T.jk + 4 * n * jcap; T.je = T.jq + 4 * n * jcap;
     cgptr Rc = discrete_map ? S.Rd : S.R;
     for (int e = tid; e < n * nr; e += nt) T.R[e] = Rc[e];
     for (int e = tid; e < no * ns; e += nt) T.W[e] = S.Wc[e];
@@ -371,6 +428,18 @@ __device__ inline void stage(SsmLds &T, lptr base, const SsmDev &S, bool discret
     for (int e = tid; e < ns; e += nt) { T.ps[e] = S.ps[e]; T.vs[e] = S.vs[e]; }
     for (int q = 0; q < 8; ++q) { T.lvr[q] = q <= S.order_r ? S.lvr[q] : 0; T.lvs[q] = q <= S.order_s ? S.lvs[q] : 0; }
     __syncthreads();
+    if (jcap > 0) {                                              // one thread per list (j, g): scan its monomials in increasing order
+        for (int l = tid; l < 4 * n; l += nt) {
+            const int j = l >> 2, gq = l & 3;
+            int c = 0;
+            for (int k = gq; k < nr; k += 4) {
+                const int e = T.er[k * n + j];
+                if (e > 0 && c < jcap) { T.jk[l * jcap + c] = k; T.jq[l * jcap + c] = T.dmr[k * n + j]; T.je[l * jcap + c] = e; ++c; }
+            }
+            for (; c < jcap; ++c) { T.jk[l * jcap + c] = 0; T.jq[l * jcap + c] = -1; T.je[l * jcap + c] = 0; }
+        }
+        __syncthreads();
+    }
 }
 
 // monomials (and derivative table D) from LDS tables; as `basis`
@@ -405,6 +474,68 @@ __device__ inline void jacobians_l(const SsmDev &S, const SsmLds &T, bool dm, cl
                                    lptr d) {
     const int n = S.n, m = S.m, nr = S.nr, tid = threadIdx.x, nt = blockDim.x;
     clptr Bg = T.Bg;
+    if (T.jcap > 0) {
+        // Round 5: only the structural non-zeros of d phi / d x.  A[i][j] = sum_k R[i][k] D[k][j] runs over the monomials that
+        // contain x_j (66 of 285 for the cubic basis in 10 variables), in the SAME order on the same four lanes as the dense sum
+        // below (k = g mod 4, increasing): the skipped terms are exact zeros, the result is bit-identical.  f[i] = sum_k R[i][k]
+        // phi[k] stays dense (285 terms) and takes 16 lanes per row instead of 4 so that it does not outlast the A sums; its
+        // summation order differs from the dense form's (rounding-level difference in f).
+        const int cap = T.jcap, tot = 4 * n * cap;
+        basis_l(T.er, T.pr, T.vr, T.dmr, T.lvr, S.order_r, nr, n, x, w.phi, (lptr) nullptr);
+        lptr DC = w.D;                                           // compact derivative values, list (j, g) x slot
+        for (int e0 = tid; e0 < tot; e0 += 2 * nt) {             // two entries per trip: the look-ups overlap
+            int qa[2], ea[2];
+            double pv[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) { const int e = e0 + c2 * nt; const bool in = e < tot; qa[c2] = in ? T.jq[e] : -1; ea[c2] = in ? T.je[e] : 0; }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) pv[c2] = qa[c2] >= 0 ? w.phi[qa[c2]] : 1.0;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) { const int e = e0 + c2 * nt; if (e < tot) DC[e] = qa[c2] == -1 ? 0.0 : (double)ea[c2] * pv[c2]; }
+        }
+        {   // f[i]: 16 lanes per row
+            const int g16 = tid & 15;
+            for (int i0 = 0; i0 < n; i0 += nt / 16) {
+                const int i = i0 + (tid >> 4);
+                double acc = 0.0;
+                if (i < n) {
+                    clptr r = T.R + (size_t)i * nr;
+                    for (int k0 = g16; k0 < nr; k0 += 128) {
+                        double av[8], bv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { const int k = k0 + 16 * q; const bool in = k < nr; av[q] = in ? r[k] : 0.0; bv[q] = in ? w.phi[k] : 0.0; }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
+                    }
+                }
+                acc = wg::group_sum<16>(acc);
+                if (g16 == 0 && i < n) w.f[i] = acc;
+            }
+        }
+        __syncthreads();
+        const int g4 = tid & 3;
+        for (int o0 = 0; o0 < n * n; o0 += nt / 4) {             // uniform trip count
+            const int o = o0 + (tid >> 2);
+            const bool live = o < n * n;
+            const int i = live ? o / n : 0, j = live ? o - i * n : 0;
+            double acc = 0.0;
+            if (live) {
+                clptr r = T.R + (size_t)i * nr;
+                const int lb = (4 * j + g4) * cap;
+                for (int t0 = 0; t0 < cap; t0 += 8) {
+                    double av[8], bv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int t = t0 + q; const bool in = t < cap; av[q] = in ? r[T.jk[lb + (in ? t : 0)]] : 0.0; bv[q] = in ? DC[lb + t] : 0.0; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(av[q], bv[q], acc);
+                }
+            }
+            acc = wg::group_sum<4>(acc);
+            if (g4 == 0 && live) A[i * lda + j] = acc;
+        }
+        for (int e = tid; e < n * m; e += nt) Bm[e] = Bg[e];
+        __syncthreads();
+    } else {
     basis_l(T.er, T.pr, T.vr, T.dmr, T.lvr, S.order_r, nr, n, x, w.phi, w.D);
     // A[i][j] = sum_k R[i][k] D[k][j] and f[i] = sum_k R[i][k] phi[k]: n (n + 1) dot products of length nr, four lanes
     // each (the k range split four ways, DPP sum)
@@ -432,6 +563,7 @@ __device__ inline void jacobians_l(const SsmDev &S, const SsmLds &T, bool dm, cl
     }
     for (int e = tid; e < n * m; e += nt) Bm[e] = Bg[e];
     __syncthreads();
+    }
     {   // f = R phi + B u ;  d = f - A x - B u : eight lanes per row
         const int g8 = tid & 7;
         for (int i0 = 0; i0 < n; i0 += nt / 8) {

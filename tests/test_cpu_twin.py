@@ -154,3 +154,60 @@ def test_gusto_loop_warm_started_qps_follow_the_cold_started_loop():
     xo, uo, iters, trace = cpu_twin.gusto_solve(model, Ad, Bd, dd, H, N, dt, Qz, R, x0[None], u_init[None], x_init[None], z=z[None], U=(UA, Ub),
                                                 x_char=xc, f_char=fc, convg_thresh=1e-3, max_gusto_iters=8, threads=1, max_trace=16, algo='condensed')
     assert int(iters[0]) == len(tw) and rel(xo[0], xw) <= 1e-8 and rel(uo[0], uw) <= 1e-8
+
+
+def test_ilqr_twin_tpwl_matches_numpy_oracle():
+    """cpu_twin.ilqr_tpwl (the CPU number beside bench.py's `ilqr_diamond`) against oracle.lqr.ILQR -- the numpy restatement of
+    sofacontrol/lqr/ilqr.py that the goldens g4 / g20 pin to the imported reference -- on a small nearest-point TPWL model: same
+    iteration count, trajectory and gains; also with the four configuration switches off (lqr/config.py:6-9,31)."""
+    from oracle import lqr as olqr
+    from helpers import golden_problem
+    import workloads as wl
+    r, m, P, N, dt = 5, 4, 12, 10, 0.05
+    model, U, q_ref, v_ref, Hf = golden_problem(r, m, P, 40, 5, q_scale=0.2)
+    Ad, Bd, dd = wl.zoh_tables(dict(A_c=model['A_c'], B_c=model['B_c'], d_c=model['d_c']), dt)
+    rng = np.random.default_rng(3)
+    H = 0.3 * rng.standard_normal((6, 2 * r))
+    z_ref = 0.01 * rng.standard_normal(6)
+    Qz = np.diag([0., 0., 0., 100., 100., 10.]); R = 1e-3 * np.eye(m)
+    th = np.linspace(0, 1.0, N + 1)
+    zt = np.zeros((N + 1, 6)); zt[:, 3] = -0.02 * np.sin(th); zt[:, 4] = 0.01 * np.sin(2 * th)
+    zt = zt + z_ref
+    x0 = 1e-3 * rng.standard_normal((3, 2 * r))
+    for switches in ({}, dict(include_input_var_constraint=False, do_linesearch=False, regularize=False, state_regularization=False)):
+        x, u, K, cost, iters = cpu_twin.ilqr_tpwl(model, Ad, Bd, dd, H, z_ref, Qz, R, 10 * Qz, N, x0, np.stack([zt] * 3), threads=2, **switches)
+        for b in range(3):
+            o = olqr.ILQR(model, Ad, Bd, dd, H, z_ref, Qz, R, 10 * Qz, N)
+            for k, v in switches.items():
+                setattr(o.p, k, v)
+            xo, uo, Ko = o.solve(x0[b], zt)
+            # (all switches off: the iteration reaches a fixed point whose cost repeats EXACTLY in numpy -- the stopping rule
+            # 0 <= J_old - J_new then depends on the last bit, and the twin's FMA-contracted sums may take extra, identical passes)
+            if not switches:
+                assert int(iters[b]) == len(o.trace) - 1, (switches, b, iters[b], len(o.trace) - 1)
+            assert rel(x[b], xo) <= 1e-8 and rel(u[b], uo) <= 1e-7 and rel(K[b], Ko) <= 1e-6, (rel(x[b], xo), rel(u[b], uo), rel(K[b], Ko))
+            assert abs(cost[b] - o.trace[-1][1]) <= 1e-9 * max(1.0, abs(o.trace[-1][1]))
+
+
+@pytest.mark.parametrize('method,dt', [('fe', 0.01), ('be', 0.01), ('bil', 0.01)])
+def test_ilqr_twin_ssm_matches_numpy_oracle(method, dt):
+    """cpu_twin.ilqr_ssm (the CPU number beside bench.py's C3 entry) against oracle.lqr.ILQRGeneric over oracle.ssm (pinned to the
+    imported reference by g10 / g11) on a small cubic SSM model at a well-conditioned step: same iteration count, trajectories."""
+    from oracle import lqr as olqr, ssm as ossm
+    n, m, N = 4, 3, 20
+    model = ossm.synthetic(n, m, 3, 2, seed=7)
+    Hc = model['W'][:, :n].copy()
+    rng = np.random.default_rng(5)
+    Q = np.diag([100., 100., 1., 1.]); R = np.eye(m)
+    x0 = 0.05 * rng.standard_normal((2, n))
+    th = np.linspace(0, 2 * np.pi, N + 1)
+    zt = np.zeros((2, N + 1, n)); zt[:, :, 0] = 0.1 * np.sin(th); zt[1, :, 1] = 0.05 * (1 - np.cos(th))
+    zt = zt + model['z_ref']
+    x, u, K, cost, iters = cpu_twin.ilqr_ssm(n, m, 3, 2, model['R'], model['B'], model['W'], model['z_ref'], Hc, method, dt, Q, R, Q, N, x0, zt, threads=2)
+    for b in range(2):
+        o = olqr.ILQRGeneric(lambda xx, uu: ossm.jacobians(model, xx, uu, dt, method), lambda xx: ossm.observe(model, xx) + model['z_ref'],
+                             Hc, n, m, Q, R, Q, N)
+        xo, uo, Ko = o.solve(x0[b], zt[b])
+        assert int(iters[b]) == len(o.trace) - 1, (b, iters[b], len(o.trace) - 1)
+        assert rel(x[b], xo) <= 1e-8 and rel(u[b], uo) <= 1e-7, (rel(x[b], xo), rel(u[b], uo))
+        assert abs(cost[b] - o.trace[-1][1]) <= 1e-9 * max(1.0, abs(o.trace[-1][1]))

@@ -137,12 +137,12 @@ def test_lean_fixed_layout_equals_runtime_layout_at_c2(monkeypatch):
     assert rel(res['fixed'][4], res['runtime'][4]) <= 1e-9 and rel(res['fixed'][5], res['runtime'][5]) <= 1e-9
 
 
-@pytest.mark.parametrize('N,dt,with_X,cap,lean', [(5, 0.05, True, 500, (4, 60, 4, 0, 0, 0)), (3, 0.1, False, 5, (4, 60, 1, 0, 0, 0)),
+@pytest.mark.parametrize('N,dt,with_X,cap,lean', [(5, 0.05, True, 500, (4, 60, 4, -1, 0, 0)), (3, 0.1, False, 5, (4, 60, 1, -1, 0, 0)),
                                                    (200, 0.05, False, 500, None)])
 def test_reference_driver_horizons_match_oracle(N, dt, with_X, cap, lean):
     """The horizons the reference's own Diamond drivers solve (bench.py: secondary.scp_reference_horizons): N = 5 / dt = 0.05 with
     the X box (examples/diamond/diamond.py:309-316), N = 3 / dt = 0.1 capped at 5 SCP iterations (examples/hardware/diamond.py:
-    393-399; no state rows: the box-row lean kernel <4, 60, 1, 0, 0, 0>) -- run-time-horizon lean kernels -- and the open-loop N = 200 (examples/hardware/diamond.py:471-474): N p_o = 400
+    393-399; no state rows) -- the short-horizon lean kernels <4, 60, GX, -1, 0, 0>, interior point on one wave (ql::ipm_wave) -- and the open-loop N = 200 (examples/hardware/diamond.py:471-474): N p_o = 400
     outputs exceed the condensed path's 128, the stage-wise Riccati kernel answers.  Against oracle.gusto at that N."""
     import workloads as wl
     from sofacontrol_amd.scp.gusto import GuSTO
@@ -199,3 +199,41 @@ def test_lean_cold_retry_after_failed_warm_start(monkeypatch):
         assert int(p[0][b]) == len(tr)
         np.testing.assert_allclose(p[4][b, :len(tr), :3], np.array([t[:3] for t in tr]), rtol=1e-6)
         assert rel(p[2][b], xe) <= 1e-6 and rel(p[3][b], ue) <= 1e-6, (rel(p[2][b], xe), rel(p[3][b], ue))
+
+
+@pytest.mark.parametrize('which,N,dt,with_X', [('diamond', 5, 0.05, True), ('diamond', 3, 0.1, False), ('diamond', 8, 0.05, True), ('trunk', 8, 0.1, False),
+                                                ('trunk', 4, 0.1, False)])
+def test_short_horizon_wave_form_matches_box_form_and_oracle(which, N, dt, with_X, monkeypatch):
+    """Short horizons (N p_o <= 16: K is one tile) run the interior point on ONE wave (ql::ipm_wave, lean<M, NX, GX, -1, 0, 0>); with
+    SRH_LEAN_NO_WAVE=1 at plan creation the same problem takes the eight-wave form (ql::ipm_box, run-time horizon).  Both are the same
+    iteration: equal SCP iteration counts and status, trajectories to 1e-7; and the one-wave form against oracle.gusto.  Diamond
+    (n_u = 4, with / without the X box) and Trunk (n_u = 8: N = 8 fills all 64 lanes)."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    if which == 'diamond':
+        w, tip, seed = wl.diamond_c2(N=N, dt=dt, with_X=with_X), 1354, 2
+    else:
+        w = wl.trunk_c5(N=N, dt=dt)
+        tip, seed = w['tip_node'], 9
+    B, cap = 4, 5
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, B, seed, tip)
+    X = Polyhedron(w['XA'], w['Xb']) if (with_X and w['XA'] is not None) else None
+    res = {}
+    for tag in ('wave', 'box'):
+        if tag == 'box':
+            monkeypatch.setenv('SRH_LEAN_NO_WAVE', '1')
+        else:
+            monkeypatch.delenv('SRH_LEAN_NO_WAVE', raising=False)
+        g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=X, x_char=xc, f_char=fc,
+                  convg_thresh=1e-3, batch=B, max_trace=64, max_gusto_iters=cap)
+        info = g.kernel_info
+        assert info['family'] == 'lean' and (info['lean'][3] == -1) == (tag == 'wave'), info
+        g.solve_batch(x0, u_init, x_init, z=z)
+        res[tag] = (g, g.iters.copy(), g.status.copy(), g.xopt.copy(), g.uopt.copy())
+    monkeypatch.delenv('SRH_LEAN_NO_WAVE', raising=False)
+    a, b = res['wave'], res['box']
+    assert (a[1] == b[1]).all() and (a[2] == b[2]).all(), (a[1], b[1], a[2], b[2])
+    assert rel(a[3], b[3]) <= 1e-7 and rel(a[4], b[4]) <= 1e-7, (rel(a[3], b[3]), rel(a[4], b[4]))
+    for bi in range(2):
+        compare(a[0], bi, oracle_solve(w, xc, fc, x0[bi], u_init[bi], x_init[bi], z[bi], cap), '%s N = %d one-wave' % (which, N))
