@@ -214,14 +214,18 @@ def closed_loop_latency(w, rom, tp):
             'ekf_step_p99_us': ekf_p99, 'fused_step_us': fused_med, 'fused_step_p99_us': fused_p99,
             'fused_step_c_abi_us': abi_med, 'fused_step_c_abi_p99_us': abi_p99,
             'fused_step': 'sekf_step_projected: projection (side stream) + EKF predict/update in one call',
+            'cpu': 'no twin: per-step latencies of a 2 x 4884 -> 60 projection and a 60-state EKF step; numpy needs ~0.3 ms for the same two '
+                   'operations (oracle/observer.py), i.e. the host is at par here -- the fused device step exists to keep the state resident',
             'statistic': 'median (and 99th percentile) of per-call wall times',
 
             'workload': 'one full state (2 x %d) -> 2r = %d; EKF n_x = %d, n_y = 30; host-pointer API' % (n_f, 2 * r, 2 * r)}
 
 
-def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
+def scp_c5(_lib, rank, world, dist, total=256, max_iters=5, cpu=False):
     """BASELINE config C5: 256 parallel SCP rollouts on the Trunk shape (r = 30, n_u = 8, N = 50), STRONG scaling:
-    the 256 rollouts are split over the ranks (distributed.shard_range), no data-path collective."""
+    the `total` rollouts are split over the ranks (distributed.shard_range), no data-path collective (`scp_c5_weak` calls it
+    with total = 256 x world: 256 rollouts PER rank -- the curve that can scale).  cpu: also the native CPU twin on this rank's
+    shard, all usable cores (rank 0 of a single-GPU run only)."""
     import workloads as wl
     from scipy.interpolate import interp1d
     from sofacontrol_amd.distributed import shard_range
@@ -268,8 +272,26 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5):
         el, its = float(tm[0]), float(tt[1])
     else:
         J_all, best = gather_rollout_costs(J_loc, Bn)
+    cpu_entry = None
+    if cpu:
+        try:
+            from oracle import cpu_twin
+            model = dict(w['tab'], w_q=1.0, w_v=0.0)
+            ncpu = usable_cpus()
+            nb = min(Bn, 16 * ncpu)
+            t0 = time.perf_counter()
+            _, _, itc, _ = cpu_twin.gusto_solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, dt, w['Qz'], w['R'], x0[:nb], u_init[:nb], x_init[:nb],
+                                                z=z[:nb], U=(w['UA'], w['Ub']), x_char=xc, f_char=fc, convg_thresh=1e-3, max_gusto_iters=max_iters,
+                                                threads=ncpu, algo='condensed')
+            tc = time.perf_counter() - t0
+            cpu_entry = {'what': 'native CPU twin (same algorithm), %d rollouts on %d threads' % (nb, ncpu), 'seconds': tc,
+                         'iterations_per_s': float(itc.sum()) / tc, 'iterations_equal_gpu': bool((itc == g.iters[:nb]).all()),
+                         'gpu_over_cpu_throughput': (its / el) / (float(itc.sum()) / tc)}
+        except Exception as exc:
+            cpu_entry = {'error': repr(exc)}
     return {'workload': 'C5: Trunk n_f=2127, r=30 (n_x=60, n_u=8), N=50, dt=%g, U box; %d rollouts in total, %d per rank, '
-                        'strong scaling; host buffers; best of 3 calls' % (dt, total, Bn),
+                        '%s; host buffers; best of 3 calls' % (dt, total, Bn, 'weak scaling (256 per rank)' if total == 256 * world and world > 1 else 'strong scaling'),
+            'cpu': cpu_entry if cpu_entry is not None else 'no twin run on this rank / entry (see scp_c5 of a single-GPU run)',
             'iterations_per_s': its / el, 'ms': el * 1e3, 'ms_all_calls': [e * 1e3 for e in els], 'iterations': its,
             'not_converged_rank0': int((g.status != 0).sum()), 'kernel': g.kernel_info['kernel'],
             'rollouts_handed_to_fused_kernel': int(g.kernel_info['handed_over']),
@@ -297,6 +319,7 @@ def scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, max_iters):
         per_it = sorted(t / i for t, i in zip(ts, its))
         out[key] = {'max_gusto_iters': cap, 'ms_per_solve_median': sorted(ts)[len(ts) // 2] * 1e3, 'ms_per_solve_max': max(ts) * 1e3,
                     'scp_iterations': its, 'ms_per_scp_iteration_median': per_it[len(per_it) // 2] * 1e3}
+    out['cpu'] = 'cpu_baseline.gpu_vs_cpu.single_rollout_ms_per_scp_iteration (native twin, one thread, same problems)'
     out['ms_per_scp_iteration'] = out['capped']['ms_per_scp_iteration_median']
     out['within_replan_budget'] = bool(out['capped']['ms_per_solve_max'] <= 100.0)
     return out
@@ -314,6 +337,7 @@ def scp_reference_horizons(tip_node=1354):
     from sofacontrol_amd.scp.gusto import GuSTO
     from sofacontrol_amd.utils import Polyhedron
     out = {}
+    from oracle import cpu_twin
     for key, N, dt, with_X, cap, reps, ref in (('closed_loop_N5', 5, 0.05, True, 500, 8, 'examples/diamond/diamond.py:309-316'),
                                              ('hardware_closed_loop_N3', 3, 0.1, False, 5, 8, 'examples/hardware/diamond.py:393-399'),
                                              ('hardware_open_loop_N200', 200, 0.05, False, 500, 3, 'examples/hardware/diamond.py:471-474')):
@@ -332,17 +356,43 @@ def scp_reference_horizons(tip_node=1354):
             g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0[0], u0, x_init[0], z=z[0], U=Polyhedron(w['UA'], w['Ub']),
                       X=Polyhedron(w['XA'], w['Xb']) if with_X else None, x_char=xc, f_char=fc, convg_thresh=1e-3, max_trace=0, max_gusto_iters=cap)
             ts, its, st = [], [], []
-            for b in range(reps):
+            nsolve = reps if N >= 200 else 64          # the closed-loop horizons: 64 CONSECUTIVE solves (cycling through the problems), as a
+            for i in range(nsolve):                    # controller issues them -- first, median and worst are reported separately
+                b = i % reps
                 t0 = time.perf_counter()
                 g.solve(x0[b], u0, x_init[b], z=z[b])
                 ts.append(time.perf_counter() - t0)
                 its.append(int(g.iters[0])); st.append(int(g.status[0]))
             per = sorted(t / max(1, i) for t, i in zip(ts, its))
             ki = g.kernel_info
-            out[key] = {'reference_driver': ref, 'N': N, 'dt': dt, 'X_rows': 4 if with_X else 0, 'max_gusto_iters': cap,
-                        'ms_per_solve_median': sorted(ts)[len(ts) // 2] * 1e3, 'ms_per_solve_max': max(ts) * 1e3, 'scp_iterations': its,
-                        'status': st, 'ms_per_scp_iteration_median': per[len(per) // 2] * 1e3, 'kernel': ki['kernel'],
+            med = sorted(ts)[len(ts) // 2]
+            out[key] = {'reference_driver': ref, 'N': N, 'dt': dt, 'X_rows': 4 if with_X else 0, 'max_gusto_iters': cap, 'solves': nsolve,
+                        'ms_first_solve': ts[0] * 1e3, 'ms_per_solve_median': med * 1e3, 'ms_per_solve_max': max(ts) * 1e3,
+                        'ms_per_solve_max_excluding_first': max(ts[1:]) * 1e3, 'max_over_median': max(ts) / med,
+                        'ms_per_solve_first_8': [t * 1e3 for t in ts[:8]], 'scp_iterations': its[:reps],
+                        'status_nonzero': int(sum(1 for v in st if v != 0)), 'ms_per_scp_iteration_median': per[len(per) // 2] * 1e3, 'kernel': ki['kernel'],
                         'handed_to_fused_kernel_last_solve': ki['handed_over']}
+            # SURVEY 8(d) "CPU baseline (1)": the native twin (same algorithm) on the same problems, ONE thread -- what one host core
+            # needs for the solve a closed loop waits for
+            try:
+                model = dict(w['tab'], w_q=1.0, w_v=0.0)
+                nb = reps if N < 200 else 1
+                kw = dict(z=z[:nb], U=(w['UA'], w['Ub']), X=(w['XA'], w['Xb']) if with_X else None, x_char=xc, f_char=fc, convg_thresh=1e-3,
+                          max_gusto_iters=cap)
+                u0b = np.zeros((nb, N, m))
+                cpu_twin.gusto_solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, dt, w['Qz'], w['R'], x0[:1], u0b[:1], x_init[:1], **dict(kw, z=z[:1]),
+                                     threads=1, algo='condensed')
+                t0 = time.perf_counter()
+                _, _, itc, _ = cpu_twin.gusto_solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, dt, w['Qz'], w['R'], x0[:nb], u0b, x_init[:nb], **kw,
+                                                    threads=1, algo='condensed')
+                tc = time.perf_counter() - t0
+                cpu_ms = tc / max(1, int(itc.sum())) * 1e3
+                out[key]['cpu'] = {'what': 'native CPU twin, one thread, same algorithm, %d of the same problems' % nb,
+                                   'ms_per_scp_iteration': cpu_ms, 'scp_iterations': [int(v) for v in itc],
+                                   'iterations_equal_gpu': bool(all(int(a) == int(b_) for a, b_ in zip(itc, its[:nb]))),
+                                   'cpu_over_gpu_latency': cpu_ms / out[key]['ms_per_scp_iteration_median']}
+            except Exception as exc:
+                out[key]['cpu'] = {'error': repr(exc)}
         except Exception as exc:
             out[key] = {'error': repr(exc)}
     return out
@@ -367,7 +417,9 @@ def pod_shapes(L, _lib, B=65536):
         ms = C.c_float(); L.srh_event_elapsed_ms(e0, e1, C.byref(ms))
         return ms.value / reps * 1e-3
 
-    out = {'workload': 'B = %d snapshots x n_f = %d, f64, resident; GB/s of the algorithmic bytes' % (B, n_f)}
+    out = {'workload': 'B = %d snapshots x n_f = %d, f64, resident; GB/s of the algorithmic bytes' % (B, n_f),
+           'cpu': 'cpu_baseline.pod_projection_gbs (native twin, one thread / all cores, and numpy) is the CPU side of the projection; the lift and '
+                  'U^T M U have no twin (same memory-bound shape: the projection figure is representative)'}
     U0, q_ref, v_ref = wl.pod_basis(n_f, 30, seed=0)
     X = wl.snapshots(q_ref, B, seed=2)
     dX = _lib.DeviceBuffer.from_array(X)
@@ -432,10 +484,37 @@ def secondary(L, _lib, rank, world, dist):
         il.ilqr_computation(x0)
         ts.append(time.perf_counter() - t0)
     t = min(ts)
+    il1 = iLQR(dt, s, QuadraticCost(Q=Qz, R=c3['R'], Qf=c3['Qf']), N)
+    il1.set_target(zt[0])
+    il1.ilqr_computation(x0[0])
+    t1s = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        il1.ilqr_computation(x0[0])
+        t1s.append(time.perf_counter() - t0)
     out['ilqr_c3'] = {'workload': 'C3 (workloads.ssm_c3): SSM n_x=10 (285 monomials), n_u=8, horizon 100, dt=0.05 backward Euler, %d problems, host buffers '
                                   '(PCIe copies inside the time); best of 3 calls' % Bn,
                       'iterations_per_s': float(il.iters.sum()) / t, 'ms': t * 1e3, 'ms_all_calls': [x * 1e3 for x in ts],
-                      'iterations': int(il.iters.sum())}
+                      'iterations': int(il.iters.sum()), 'one_problem_ms': min(t1s) * 1e3, 'one_problem_iterations': int(np.atleast_1d(il1.iters)[0])}
+    if rank == 0:
+        try:      # SURVEY 8(d) "CPU baseline (1)": the native twin of the same iLQR (oracle/csrc, pinned to oracle/lqr.py), one thread and all cores
+            from oracle import cpu_twin
+            ncpu = usable_cpus()
+            cargs = (n, m, 3, 2, model['R'], model['B'], model['W'], model['z_ref'], s.H, c3['discr'], dt, Qz, c3['R'], c3['Qf'], N)
+            t0 = time.perf_counter()
+            _, _, _, _, it1 = cpu_twin.ilqr_ssm(*cargs, x0[:4], zt[:4], threads=1)
+            tc1 = (time.perf_counter() - t0) / 4
+            t0 = time.perf_counter()
+            _, _, _, _, ita = cpu_twin.ilqr_ssm(*cargs, x0, zt, threads=ncpu)
+            tca = time.perf_counter() - t0
+            out['ilqr_c3']['cpu'] = {'what': 'native CPU twin (oracle/csrc: analytic sparse Jacobians, Gauss-Jordan discretisation), same iLQR',
+                                     'one_problem_ms_one_thread': tc1 * 1e3, 'all_problems_ms': tca * 1e3, 'threads': ncpu,
+                                     'iterations_per_s_all_cores': float(ita.sum()) / tca,
+                                     'iterations_equal_gpu': bool((ita == il.iters).all()),
+                                     'gpu_over_cpu_throughput': (float(il.iters.sum()) / t) / (float(ita.sum()) / tca),
+                                     'cpu_over_gpu_latency_one_problem': tc1 / min(t1s)}
+        except Exception as exc:
+            out['ilqr_c3']['cpu'] = {'error': repr(exc)}
     # ---- iLQR on the Diamond TPWL model of the headline configuration (the north star names "the reference CPU SCP/iLQR solve on the
     # Diamond robot (r = 30, horizon = 50)"; lqr/ilqr.py:27-300 through examples/diamond/diamond.py:190-230): one problem at a time
     # (the controller's use) and 256 problems in one launch; parity: tests/test_lqr_gpu.py
@@ -470,6 +549,27 @@ def secondary(L, _lib, rank, world, dist):
                                'ms_per_iteration_one_problem_median': per[4], 'ms_per_iteration_one_problem_min_max': [per[0], per[-1]],
                                'batch_256_ms': min(tb) * 1e3, 'batch_256_ms_all_calls': [t * 1e3 for t in tb],
                                'batch_256_iterations': int(ild.iters.sum()), 'batch_256_iterations_per_s': float(ild.iters.sum()) / min(tb)}
+        if rank == 0:
+            try:
+                from oracle import cpu_twin
+                ncpu = usable_cpus()
+                modeld = dict(wd['tab'], w_q=1.0, w_v=0.0)
+                targs = (modeld, wd['Ad'], wd['Bd'], wd['dd'], np.asarray(tpd.H), zr, wd['Qz'], 1e-3 * np.eye(md), 10 * wd['Qz'], Nd)
+                ztb = np.broadcast_to(ztd, (256,) + ztd.shape).copy()
+                t0 = time.perf_counter()
+                _, _, _, _, itc1 = cpu_twin.ilqr_tpwl(*targs, x0d[:2], ztb[:2], threads=1)
+                tc1 = (time.perf_counter() - t0) / max(1, int(itc1.sum()))
+                t0 = time.perf_counter()
+                _, _, _, _, itca = cpu_twin.ilqr_tpwl(*targs, x0d, ztb, threads=ncpu)
+                tca = time.perf_counter() - t0
+                out['ilqr_diamond']['cpu'] = {'what': 'native CPU twin of the same iLQR on the same TPWL tables (oracle/csrc)', 'threads': ncpu,
+                                              'ms_per_iteration_one_problem_one_thread': tc1 * 1e3, 'batch_256_ms_all_cores': tca * 1e3,
+                                              'batch_256_iterations_per_s_all_cores': float(itca.sum()) / tca,
+                                              'iterations_equal_gpu': bool((itca == ild.iters).all()),
+                                              'gpu_over_cpu_throughput': out['ilqr_diamond']['batch_256_iterations_per_s'] / (float(itca.sum()) / tca),
+                                              'cpu_over_gpu_latency_one_problem': tc1 * 1e3 / per[4]}
+            except Exception as exc:
+                out['ilqr_diamond']['cpu'] = {'error': repr(exc)}
     except Exception as exc:                      # a secondary measurement never takes the line down
         out['ilqr_diamond'] = {'error': repr(exc)}
     # ---- the reference's real-time hardware driver: SSM + GuSTO as a real-time iteration (examples/hardware/diamond_SSM.py:
@@ -499,7 +599,9 @@ def secondary(L, _lib, rank, world, dist):
             g6.solve(x06, u6, xi6, z6, None, None)
             ts6.append(time.perf_counter() - t0)
         ts6.sort()
-        out['ssm_gusto_rti'] = {'workload': 'SSM (n_x = 6, n_u = 4, cubic) + GuSTO real-time iteration: N = 3, dt = 0.02, max_gusto_iters = 0 '
+        out['ssm_gusto_rti'] = {'cpu': 'no twin: the CPU twin has no SSM + GuSTO loop (its GuSTO is the nearest-point TPWL one); the numpy oracle of this '
+                                       'loop (oracle.gusto.solve_generic) is a correctness statement, not a timing',
+                                'workload': 'SSM (n_x = 6, n_u = 4, cubic) + GuSTO real-time iteration: N = 3, dt = 0.02, max_gusto_iters = 0 '
                                             '(one QP per call), U box; host loop around the device QP (the model is not TPWL), host buffers',
                                 'ms_median': ts6[len(ts6) // 2] * 1e3, 'ms_p95': ts6[int(len(ts6) * 0.95)] * 1e3,
                                 'budget_ms': 40.0, 'within_budget': bool(ts6[int(len(ts6) * 0.95)] * 1e3 <= 40.0)}
@@ -538,6 +640,19 @@ def secondary(L, _lib, rank, world, dist):
     out['gramian_c4'] = {'workload': 'C4 per-GPU shard: S %d x %d f64, G = S S^T' % (n_s, n_f), 'ms': ms.value,
                          'tflops_executed': flop / (ms.value * 1e-3) / 1e12,
                          'frac_of_f64_mfma_peak': flop / (ms.value * 1e-3) / 1e12 / 78.6}
+    if rank == 0:
+        try:      # CPU figure beside it: numpy (BLAS dgemm, its own threads) on a 2000-snapshot slice of the same shard shape
+            Sc = np.random.default_rng(7).standard_normal((2000, n_f))
+            Sc @ Sc[:64].T
+            t0 = time.perf_counter()
+            Gc = Sc @ Sc.T
+            tc = time.perf_counter() - t0
+            out['gramian_c4']['cpu'] = {'what': 'numpy S S^T (BLAS dgemm, all BLAS threads) on a 2000 x %d slice' % n_f, 'seconds': tc,
+                                        'tflops': 2.0 * 2000 * 2000 * n_f / tc / 1e12,
+                                        'gpu_over_cpu': out['gramian_c4']['tflops_executed'] / (2.0 * 2000 * 2000 * n_f / tc / 1e12)}
+            del Sc, Gc
+        except Exception as exc:
+            out['gramian_c4']['cpu'] = {'error': repr(exc)}
     del G_t
     try:
         tm = {}
@@ -547,7 +662,9 @@ def secondary(L, _lib, rank, world, dist):
         out['pod_build_c4'] = {'workload': 'C4: 10000 snapshots x %d DoF columns per GPU (50000 over 8), %d GPU(s); k = 64 modes kept; '
                                            'S resident in HBM' % (n_f, world), 'world': world,
                                'phases_ms': {kk: (v * 1e3 if isinstance(v, float) else v) for kk, v in tm.items()},
-                               'allreduce_payload_bytes': n_s * n_s * 8}
+                               'allreduce_payload_bytes': n_s * n_s * 8,
+                               'cpu': 'no twin: the build is Gramian (CPU figure under gramian_c4) + eigen-decomposition (LAPACK dsyevd of 10 000 x 10 000 '
+                                      'takes minutes on the host: outside the bounded CPU budget of this line)'}
         if dist is not None:          # the one exchange step as every rank saw it
             cs = torch.tensor([tm.get('collective_s', 0.0) * 1e3], dtype=torch.float64, device='cuda')
             call = torch.empty((world,), dtype=torch.float64, device='cuda')
@@ -562,12 +679,14 @@ def secondary(L, _lib, rank, world, dist):
         out['pod_shapes'] = pod_shapes(L, _lib)
     except Exception as exc:
         out['pod_shapes'] = {'error': repr(exc)}
-    if rank == 0:
-        out['scp_reference_horizons'] = scp_reference_horizons()
     try:
-        out['scp_c5'] = scp_c5(_lib, rank, world, dist)
+        out['scp_c5'] = scp_c5(_lib, rank, world, dist, cpu=(world == 1 and rank == 0))
         if world == 1:       # what one GPU of an 8-GPU node gets of the 256 rollouts
             out['scp_c5_32_rollouts'] = scp_c5(_lib, 0, 1, None, total=32)
+            out['scp_c5_weak'] = dict(out['scp_c5'], note='256 rollouts per rank; at one GPU this IS scp_c5 (same call), listed so that the '
+                                                           'N > 1 lines have their N = 1 point')
+        else:                # the sharding that can scale -- 256 rollouts PER rank, all_gather of the costs, global best
+            out['scp_c5_weak'] = scp_c5(_lib, rank, world, dist, total=256 * world)
     except Exception as exc:
         out['scp_c5'] = {'error': repr(exc)}
     return out
@@ -749,6 +868,20 @@ def main():
                         'iterations (trust-region-active QPs included), host buffers' % R_,
                 'seconds': t_ctor, 'scp_iterations': int(gusto.iters.sum()), 'max_iterations_of_a_rollout': int(gusto.iters.max()),
                 'scp_iterations_per_s': float(gusto.iters.sum()) / t_ctor, 'not_converged': int((gusto.status != 0).sum())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:      # the same uncapped solve on the host, all usable cores, bounded sample (the first 64 rollouts)
+            from oracle import cpu_twin
+            ncpu, nb = usable_cpus(), min(64, R_)
+            t0 = time.perf_counter()
+            _, _, itu, _ = cpu_twin.gusto_solve(dict(w['tab'], w_q=1.0, w_v=0.0), w['Ad'], w['Bd'], w['dd'], w['H'], N, dt, w['Qz'], w['R'], x0[:nb],
+                                                u_init[:nb], x_init[:nb], z=z[:nb], U=(w['UA'], w['Ub']), X=(w['XA'], w['Xb']), x_char=xc, f_char=fc,
+                                                convg_thresh=1e-3, max_gusto_iters=500, threads=ncpu, algo='condensed')
+            tu = time.perf_counter() - t0
+            uncapped['cpu'] = {'what': 'native CPU twin, same algorithm, first %d rollouts uncapped on %d threads' % (nb, ncpu), 'seconds': tu,
+                               'scp_iterations_per_s': float(itu.sum()) / tu, 'iterations_equal_gpu': bool((itu == gusto.iters[:nb]).all()),
+                               'gpu_over_cpu_throughput': uncapped['scp_iterations_per_s'] / (float(itu.sum()) / tu)}
+        except Exception as exc:
+            uncapped['cpu'] = {'error': repr(exc)}
     gusto.max_gusto_iters = args.max_gusto_iters
     _lib.check(L.sgusto_plan_set_max_iters(gusto.plan, C.c_int(args.max_gusto_iters)), 'set_max_iters')
     d = {k: _lib.DeviceBuffer.from_array(v) for k, v in dict(x0=x0, u_init=u_init, x_init=x_init, z=z).items()}
@@ -822,8 +955,12 @@ def main():
             # serves small synchronous calls ~100 us slower for the rest of the process (observed, ROCm 7.2)
             cl = closed_loop_latency(w, rom, tp) if rank == 0 else None
             single = scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, args.max_gusto_iters) if rank == 0 else None
+            # the closed-loop horizons of the reference's drivers too: a 64-solve latency series must not run in the ~100 ms after GB-sized
+            # buffers went back to the driver -- the kernel driver then evicts and restores the process' queues once (a 70-90 ms wait in
+            # hipStreamSynchronize with no kernel longer than 2 ms in the rocprof trace: tools/probes/solve_outliers.py)
+            horizons = scp_reference_horizons() if rank == 0 else None
         except Exception as exc:
-            cl, single = {'error': repr(exc)}, None
+            cl, single, horizons = {'error': repr(exc)}, None, None
         for b in list(d.values()) + list(o.values()) + [dX, dXr]:
             b.free()
         try:
@@ -832,6 +969,8 @@ def main():
                 sec['closed_loop_step'] = cl
             if single is not None:
                 sec['scp_single_rollout'] = single
+            if horizons is not None:
+                sec['scp_reference_horizons'] = horizons
         except Exception as exc:      # never lose the headline line to a secondary measurement
             sec = {'error': repr(exc)}
     if rank != 0:

@@ -1,6 +1,7 @@
 // GuSTO (SCP outer loop, sofacontrol/scp/gusto.py:283-487) on the device: one workgroup per rollout runs the whole
 // solve, each SCP iteration's QP through the device interior point of locp_dev.h; the resident plan API.
 #include "scp_types.h"
+#include <chrono>
 
 namespace {
 
@@ -473,6 +474,10 @@ int sgusto_plan_solve(sgusto_plan_t *pl, const double *x0, const double *u_init,
     SRH_REQUIRE(!pl->pending, "sgusto_plan_solve: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
     const QPDims &d = pl->C.dims;
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz, B = pl->batch;
+    // SRH_TRACE_SOLVE=<ms>: report the host-side segments of a call that takes longer than <ms> (attribution of latency outliers)
+    static const double trace_ms = getenv("SRH_TRACE_SOLVE") ? atof(getenv("SRH_TRACE_SOLVE")) : -1.0;
+    using clk = std::chrono::steady_clock;
+    const auto t_in = clk::now();
     SRH_CHECK_HIP(hipMemcpy(pl->x0.p, x0, sizeof(double) * B * n, hipMemcpyHostToDevice));
     SRH_CHECK_HIP(hipMemcpy(pl->u_init.p, u_init, sizeof(double) * B * N * m, hipMemcpyHostToDevice));
     SRH_CHECK_HIP(hipMemcpy(pl->x_init.p, x_init, sizeof(double) * B * (N + 1) * n, hipMemcpyHostToDevice));
@@ -485,13 +490,22 @@ int sgusto_plan_solve(sgusto_plan_t *pl, const double *x0, const double *u_init,
                                    pl->zopt.as<double>(), pl->iters.as<int32_t>(), pl->status.as<int32_t>(),
                                    trace ? pl->trace.as<double>() : nullptr, nullptr);
     if (rc) return rc;
+    const auto t_launch = clk::now();
     SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    const auto t_sync = clk::now();
     if ((rc = pl->xopt.download(xopt, sizeof(double) * B * (N + 1) * n)) || (rc = pl->uopt.download(uopt, sizeof(double) * B * N * m)) ||
         (rc = pl->zopt.download(zopt, sizeof(double) * B * (N + 1) * nz)))
         return rc;
     if (iters && (rc = pl->iters.download(iters, sizeof(int32_t) * B))) return rc;
     if (status && (rc = pl->status.download(status, sizeof(int32_t) * B))) return rc;
     if (trace && (rc = pl->trace.download(trace, sizeof(double) * B * pl->par.max_trace * 4))) return rc;
+    if (trace_ms >= 0.0) {
+        const auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_out = clk::now();
+        if (ms(t_in, t_out) > trace_ms)
+            fprintf(stderr, "[sgusto_plan_solve] %.3f ms: uploads + launches %.3f, wait for the kernels %.3f, downloads %.3f\n", ms(t_in, t_out),
+                    ms(t_in, t_launch), ms(t_launch, t_sync), ms(t_sync, t_out));
+    }
     return SRH_OK;
 }
 
