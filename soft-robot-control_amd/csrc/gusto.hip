@@ -273,6 +273,7 @@ struct sgusto_plan {
     double last_ms = -1.0;
     char *pin = nullptr;               // one pinned block: [inputs | outputs]
     size_t pin_bytes = 0;
+    int host_handed = -1;              // zero-copy solves: rollouts the last solve handed to the fused kernel (counted on the host), else -1
     bool pending = false, want_trace = false, launching = false;
     ~sgusto_plan() {
         if (pending && adone) (void)hipEventSynchronize(adone);
@@ -332,7 +333,8 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
     QPDims &d = pl->C.dims;
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
                        par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace,
-                       getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0};
+                       (getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0) |
+                       (getenv("SRH_LEAN_FORCE_HANDOVER") != nullptr ? (atoi(getenv("SRH_LEAN_FORCE_HANDOVER")) + 1) << 4 : 0)};
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
     size_t doubles = gusto_work(d).end;
     doubles = (doubles + 3) & ~(size_t)3;
@@ -394,11 +396,25 @@ int sgusto_plan_variant(const sgusto_plan_t *pl, int *split, int *n_u_fixed, int
     return SRH_OK;
 }
 
+// phase 0: everything (lean launch + the fused kernel behind it for what the lean kernel hands over -- or the fused kernel alone);
+// phase 1: the lean launch alone, without the hand-over counter (the caller looks at the status words itself: zero-copy solves);
+// phase 2: the fused kernel in resume mode alone (after phase 1 found handed-over rollouts)
+static int solve_dev_impl(sgusto_plan_t *pl, const double *x0, const double *u_init, const double *x_init,
+                          const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
+                          double *zopt, int32_t *iters, int32_t *status, double *trace, void *stream, int phase);
+
 int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_init, const double *x_init,
                           const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
                           double *zopt, int32_t *iters, int32_t *status, double *trace, void *stream) {
+    return solve_dev_impl(pl, x0, u_init, x_init, z, zf, u_des, xopt, uopt, zopt, iters, status, trace, stream, 0);
+}
+
+static int solve_dev_impl(sgusto_plan_t *pl, const double *x0, const double *u_init, const double *x_init,
+                          const double *z, const double *zf, const double *u_des, double *xopt, double *uopt,
+                          double *zopt, int32_t *iters, int32_t *status, double *trace, void *stream, int phase) {
     SRH_REQUIRE(pl && x0 && u_init && x_init && xopt && uopt && zopt && iters && status,
                 "sgusto_plan_solve_dev: null argument");
+    if (phase == 0) pl->host_handed = -1;
     // an asynchronous request in flight (sgusto_plan_solve_begin) is using the plan's work blocks on its own stream
     SRH_REQUIRE(!pl->pending || (pl->astream && stream == (void *)pl->astream && pl->launching),
                 "sgusto_plan_solve_dev: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
@@ -414,14 +430,17 @@ int sgusto_plan_solve_dev(sgusto_plan_t *pl, const double *x0, const double *u_i
     if (pl->lean) {
         // lean condensed kernel over every rollout; the fused kernel then continues the handed-over ones (its other
         // workgroups leave at once)
-        SRH_CHECK_HIP(hipMemsetAsync(pl->handed.p, 0, sizeof(int32_t), (hipStream_t)stream));
-        int rc = lean_launch_gusto(pl->lean_variant, pl->C.dims, pl->C.view(), pl->model->view(), par, b, (unsigned)pl->batch, pl->lean_lds,
-                                   (hipStream_t)stream);
-        if (rc) return rc;
+        if (phase != 2) {
+            if (phase == 0) SRH_CHECK_HIP(hipMemsetAsync(pl->handed.p, 0, sizeof(int32_t), (hipStream_t)stream));
+            else b.handed_over = nullptr;
+            int rc = lean_launch_gusto(pl->lean_variant, pl->C.dims, pl->C.view(), pl->model->view(), par, b, (unsigned)pl->batch, pl->lean_lds,
+                                       (hipStream_t)stream);
+            if (rc) return rc;
+        }
         b.mode = 2;
         b.order = nullptr;
     }
-    {
+    if (!(pl->lean && phase == 1)) {
         const QPDims &d = pl->C.dims;
         bool launched = false;
 #define X(SP, M, NX) if (!launched && variant_matches(d, SP, M, NX)) { gusto_kernel<SP, M, NX><<<(unsigned)pl->batch, NTHREADS, pl->lds, (hipStream_t)stream>>>(d, pl->C.view(), pl->model->view(), par, b); launched = true; }
@@ -461,7 +480,8 @@ int sgusto_plan_info(sgusto_plan_t *pl, srh_kernel_info *info) {
         // the last solve may sit on a caller's non-blocking stream (sgusto_plan_solve_dev): wait for the device, as
         // slocp_plan_info and sgusto_plan_costs do
         SRH_CHECK_HIP(hipDeviceSynchronize());
-        SRH_CHECK_HIP(hipMemcpy(&info->handed_over, pl->handed.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (pl->host_handed >= 0) info->handed_over = pl->host_handed;
+        else SRH_CHECK_HIP(hipMemcpy(&info->handed_over, pl->handed.p, sizeof(int32_t), hipMemcpyDeviceToHost));
         if (!pl->lean) info->handed_over = 0;
     }
     return SRH_OK;
@@ -478,6 +498,65 @@ int sgusto_plan_solve(sgusto_plan_t *pl, const double *x0, const double *u_init,
     static const double trace_ms = getenv("SRH_TRACE_SOLVE") ? atof(getenv("SRH_TRACE_SOLVE")) : -1.0;
     using clk = std::chrono::steady_clock;
     const auto t_in = clk::now();
+    // Small batches (one receding-horizon solve at a time: the reference's closed-loop use, scp/ros.py:94-127): ZERO-COPY.  The
+    // arguments go through one pinned, device-visible host block -- the kernels read the few KB of inputs and write the results
+    // across PCIe themselves -- so that a solve is memcpy + ONE launch + ONE stream synchronisation instead of nine synchronous
+    // hipMemcpy calls, a memset and two launches (~0.25 ms of runtime calls around a 0.5 ms kernel at the drivers' horizons).  The
+    // fused kernel is launched only if a status word says a rollout was handed over.  SRH_GUSTO_NO_ZEROCOPY=1: the copying form.
+    const bool no_zc = getenv("SRH_GUSTO_NO_ZEROCOPY") != nullptr;          // (per call: tests switch it)
+    const PinLayout PL = pin_layout(pl);
+    if (!no_zc && PL.total <= ((size_t)1 << 20)) {
+        if (!pl->pin) {
+            SRH_CHECK_HIP(hipHostMalloc((void **)&pl->pin, PL.total, hipHostMallocDefault));
+            pl->pin_bytes = PL.total;
+        }
+        char *dp = nullptr;
+        SRH_CHECK_HIP(hipHostGetDevicePointer((void **)&dp, pl->pin, 0));
+        const size_t D = sizeof(double);
+        memcpy(pl->pin + PL.x0, x0, D * B * n);
+        memcpy(pl->pin + PL.u_init, u_init, D * B * N * m);
+        memcpy(pl->pin + PL.x_init, x_init, D * B * (N + 1) * n);
+        if (z) memcpy(pl->pin + PL.z, z, D * B * (N + 1) * nz);
+        if (zf) memcpy(pl->pin + PL.zf, zf, D * B * nz);
+        if (u_des) memcpy(pl->pin + PL.ud, u_des, D * B * N * m);
+        auto dv = [&](size_t off) { return reinterpret_cast<double *>(dp + off); };
+        int32_t *st_host = reinterpret_cast<int32_t *>(pl->pin + PL.status);
+        auto launch = [&](int phase) {
+            return solve_dev_impl(pl, dv(PL.x0), dv(PL.u_init), dv(PL.x_init), z ? dv(PL.z) : nullptr, zf ? dv(PL.zf) : nullptr,
+                                  u_des ? dv(PL.ud) : nullptr, dv(PL.xopt), dv(PL.uopt), dv(PL.zopt), reinterpret_cast<int32_t *>(dp + PL.iters),
+                                  reinterpret_cast<int32_t *>(dp + PL.status), trace ? dv(PL.trace) : nullptr, nullptr, phase);
+        };
+        int rc = launch(pl->lean ? 1 : 0);
+        if (rc) return rc;
+        const auto t_launch = clk::now();
+        SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+        pl->host_handed = 0;
+        if (pl->lean) {
+            int handed = 0;
+            for (size_t bi = 0; bi < B; ++bi) handed += st_host[bi] == LEAN_PENDING;
+            pl->host_handed = handed;
+            if (handed > 0) {
+                if ((rc = launch(2))) return rc;
+                SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+                pl->host_handed = handed;                      // (solve_dev_impl leaves it alone in phase 2)
+            }
+        }
+        const auto t_sync = clk::now();
+        memcpy(xopt, pl->pin + PL.xopt, D * B * (N + 1) * n);
+        memcpy(uopt, pl->pin + PL.uopt, D * B * N * m);
+        memcpy(zopt, pl->pin + PL.zopt, D * B * (N + 1) * nz);
+        if (iters) memcpy(iters, pl->pin + PL.iters, sizeof(int32_t) * B);
+        if (status) memcpy(status, pl->pin + PL.status, sizeof(int32_t) * B);
+        if (trace) memcpy(trace, pl->pin + PL.trace, D * B * pl->par.max_trace * 4);
+        if (trace_ms >= 0.0) {
+            const auto ms = [](clk::time_point a, clk::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+            const auto t_out = clk::now();
+            if (ms(t_in, t_out) > trace_ms)
+                fprintf(stderr, "[sgusto_plan_solve, zero-copy] %.3f ms: staging + launch %.3f, wait for the kernels %.3f, copy out %.3f\n",
+                        ms(t_in, t_out), ms(t_in, t_launch), ms(t_launch, t_sync), ms(t_sync, t_out));
+        }
+        return SRH_OK;
+    }
     SRH_CHECK_HIP(hipMemcpy(pl->x0.p, x0, sizeof(double) * B * n, hipMemcpyHostToDevice));
     SRH_CHECK_HIP(hipMemcpy(pl->u_init.p, u_init, sizeof(double) * B * N * m, hipMemcpyHostToDevice));
     SRH_CHECK_HIP(hipMemcpy(pl->x_init.p, x_init, sizeof(double) * B * (N + 1) * n, hipMemcpyHostToDevice));
@@ -516,8 +595,10 @@ int sgusto_plan_prepare_async(sgusto_plan_t *pl) {
     SRH_CHECK_HIP(hipStreamCreateWithFlags(&pl->astream, hipStreamNonBlocking));
     SRH_CHECK_HIP(hipEventCreate(&pl->adone));
     SRH_CHECK_HIP(hipEventCreate(&pl->abegin));
-    SRH_CHECK_HIP(hipHostMalloc((void **)&pl->pin, L.total, hipHostMallocDefault));
-    pl->pin_bytes = L.total;
+    if (!pl->pin) {
+        SRH_CHECK_HIP(hipHostMalloc((void **)&pl->pin, L.total, hipHostMallocDefault));
+        pl->pin_bytes = L.total;
+    }
     return SRH_OK;
 }
 

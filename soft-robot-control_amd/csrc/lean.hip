@@ -54,6 +54,16 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     giptr idx2 = idx + N;
 
     cgptr x0 = (cgptr)(b.x0 + p * n);
+    cgptr zp = (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr);
+    if constexpr (NST < 0) {
+        // short horizons are solved one at a time through the zero-copy host path (gusto.hip): x0 and the target would be read
+        // across PCIe by every QP -- keep copies in the work block
+        gptr x0c = base + gw.x0c, zc = base + gw.zc;
+        for (int e = tid; e < n; e += nt) x0c[e] = x0[e];
+        if (zp) for (int e = tid; e < (N + 1) * nz; e += nt) zc[e] = zp[e];
+        x0 = (cgptr)x0c;
+        if (zp) zp = (cgptr)zc;
+    }
     for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = b.x_init[p * (size_t)(N + 1) * n + e];
     for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
     __syncthreads();
@@ -66,7 +76,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     bool converged = false, handed_over = false, have_warm = false;
     int itr = 0, status = 0;
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
-        QPData q{x0, xk, (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr), (cgptr)(b.zf ? b.zf + p * nz : nullptr),
+        QPData q{x0, xk, zp, (cgptr)(b.zf ? b.zf + p * nz : nullptr),
                  (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
         double J;
         int qit;
@@ -76,9 +86,13 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         int st = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool warm = GXSEL > 0 && have_warm && attempt == 0;
-            st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, base, L, &J, &qit, w, prof, warm ? (par.poison_warm ? 2 : 1) : 0);
+            st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, base, L, &J, &qit, w, prof, warm ? ((par.poison_warm & 1) ? 2 : 1) : 0);
             if (st == 0 || st == 100 || !warm) break;
         }
+        // test knob (SRH_LEAN_FORCE_HANDOVER=k at plan creation): hand SCP iteration k to the fused kernel as if its relaxed minimiser
+        // had left the trust region -- the full QP the fused kernel then solves has the same minimiser, so the solve must come out the
+        // same through the hand-over record, the resume launch and the host paths around them
+        if (st == 0 && (par.poison_warm >> 4) - 1 == itr) st = 100;
         have_warm = st == 0;
         GU_LAP(2);
         if (st != 0) {                               // the fused kernel takes this rollout from here

@@ -6,7 +6,8 @@
 struct GustoPar {
     double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh, dt;
     int max_iters, max_trace;
-    int poison_warm;                    // test knob (SRH_LEAN_POISON_WARM=1 when the plan is created): lean kernel, every warm-started QP fails and is repeated cold
+    int poison_warm;                    // test knobs of the lean kernel, read when the plan is created.  bit 0 (SRH_LEAN_POISON_WARM=1): every warm-started
+                                        // QP fails and is repeated cold; bits 4.. (SRH_LEAN_FORCE_HANDOVER=k): k + 1, SCP iteration k is handed to the fused kernel
 };
 
 struct GustoBatch {
@@ -42,7 +43,7 @@ constexpr int LEAN_PENDING = -77;       // status of a QP / rollout the lean ker
 constexpr int GUSTO_REC = 8;            // doubles of the resume record behind the SCP loop's index arrays
 
 // offsets (doubles) of the SCP loop's own arrays inside a rollout's work block
-struct GustoWork { size_t xk, uk, acc, idx, rec, end; };
+struct GustoWork { size_t xk, uk, acc, idx, rec, x0c, zc, end; };
 __host__ __device__ inline GustoWork gusto_work(const QPDims &d) {
     GustoWork g;
     const size_t N = d.N, n = d.n, m = d.m;
@@ -51,7 +52,9 @@ __host__ __device__ inline GustoWork gusto_work(const QPDims &d) {
     g.acc = g.uk + N * m;
     g.idx = g.acc + 2 * N;
     g.rec = g.idx + (2 * N + 1) / 2;
-    g.end = g.rec + GUSTO_REC;
+    g.x0c = g.rec + GUSTO_REC;                  // short-horizon lean kernels: copies of x0 and of the target (the arguments may sit in
+    g.zc = g.x0c + n;                           // host memory: zero-copy solves, gusto.hip)
+    g.end = g.zc + (N + 1) * d.nz;
     return g;
 }
 

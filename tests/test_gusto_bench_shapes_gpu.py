@@ -237,3 +237,39 @@ def test_short_horizon_wave_form_matches_box_form_and_oracle(which, N, dt, with_
     assert rel(a[3], b[3]) <= 1e-7 and rel(a[4], b[4]) <= 1e-7, (rel(a[3], b[3]), rel(a[4], b[4]))
     for bi in range(2):
         compare(a[0], bi, oracle_solve(w, xc, fc, x0[bi], u_init[bi], x_init[bi], z[bi], cap), '%s N = %d one-wave' % (which, N))
+
+
+@pytest.mark.parametrize('N,batch,zero_copy', [(5, 2, True), (5, 2, False), (50, 2, True), (50, 40, False)])
+def test_forced_hand_over_gives_the_same_solve(N, batch, zero_copy, monkeypatch):
+    """The hand-over protocol end to end, deterministically: SRH_LEAN_FORCE_HANDOVER=1 (read at plan creation) makes the lean kernel
+    hand SCP iteration 1 of EVERY rollout to the fused kernel as 'minimiser outside the trust region' (resume record -> fused kernel
+    in resume mode -> full QP on the Riccati path).  The full QP has the same minimiser, so iteration counts, status and trajectories
+    must equal the unforced solve's (1e-6).  Through both host paths of sgusto_plan_solve: zero-copy (small batches: the lean
+    launch alone, the host reads the status words and launches the fused kernel only then) and the copying form
+    (SRH_GUSTO_NO_ZEROCOPY=1 / batches above 1 MiB of arguments: hand-over counter + unconditional resume launch)."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2(N=N, dt=0.05)
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, batch, 2, 1354)
+    if not zero_copy and batch < 32:
+        monkeypatch.setenv('SRH_GUSTO_NO_ZEROCOPY', '1')
+    res = {}
+    for tag in ('plain', 'forced'):
+        if tag == 'forced':
+            monkeypatch.setenv('SRH_LEAN_FORCE_HANDOVER', '1')
+        else:
+            monkeypatch.delenv('SRH_LEAN_FORCE_HANDOVER', raising=False)
+        g = GuSTO(gm, N, 0.05, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+                  x_char=xc, f_char=fc, convg_thresh=1e-3, batch=batch, max_trace=16, max_gusto_iters=5)
+        assert g.kernel_info['family'] == 'lean'
+        g.solve_batch(x0, u_init, x_init, z=z)
+        ho = int(g.kernel_info['handed_over'])
+        res[tag] = (g.iters.copy(), g.status.copy(), g.xopt.copy(), g.uopt.copy(), ho)
+    monkeypatch.delenv('SRH_LEAN_FORCE_HANDOVER', raising=False)
+    a, f = res['plain'], res['forced']
+    assert a[4] == 0, a[4]
+    assert f[4] == int((a[0] >= 2).sum()), (f[4], a[0])          # every rollout that reaches SCP iteration 1 was handed over
+    assert f[4] > 0
+    assert (a[0] == f[0]).all() and (a[1] == f[1]).all(), (a[0], f[0], a[1], f[1])
+    assert rel(f[2], a[2]) <= 1e-6 and rel(f[3], a[3]) <= 1e-6, (rel(f[2], a[2]), rel(f[3], a[3]))
