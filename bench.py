@@ -18,6 +18,28 @@ import os
 import sys
 import time
 
+
+def _cpu_budget():
+    """CPUs this process may keep busy: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
+# BEFORE numpy / scipy load their BLAS: the thread pools follow the CPU budget, not the 256 logical CPUs the box shows.  With the default
+# (one spinning OpenBLAS / OpenMP worker per logical CPU) the container's CFS quota of 16 CPUs x 100 ms is used up ~25 ms into a period
+# after any BLAS-heavy host phase and the kernel freezes EVERY thread of the process -- including the one waiting in hipStreamSynchronize
+# -- until the period ends: the 70-90 ms "solve" outliers of rounds 3-4 (cpu.stat: nr_throttled 21, 69 s throttled in one bench run;
+# with the cap: none, max solve 0.7 ms -- tools/probes/check_horizon_outliers.py, DESIGN.md section 13).
+for _v in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(_v, str(_cpu_budget()))
+os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -355,7 +377,7 @@ def scp_reference_horizons(tip_node=1354):
             z = np.stack([zi(b * 10.0 / reps + dt * np.arange(N + 1)) for b in range(reps)])
             g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0[0], u0, x_init[0], z=z[0], U=Polyhedron(w['UA'], w['Ub']),
                       X=Polyhedron(w['XA'], w['Xb']) if with_X else None, x_char=xc, f_char=fc, convg_thresh=1e-3, max_trace=0, max_gusto_iters=cap)
-            ts, its, st = [], [], []
+            ts, its, st, slow = [], [], [], []
             nsolve = reps if N >= 200 else 64          # the closed-loop horizons: 64 CONSECUTIVE solves (cycling through the problems), as a
             for i in range(nsolve):                    # controller issues them -- first, median and worst are reported separately
                 b = i % reps
@@ -363,15 +385,30 @@ def scp_reference_horizons(tip_node=1354):
                 g.solve(x0[b], u0, x_init[b], z=z[b])
                 ts.append(time.perf_counter() - t0)
                 its.append(int(g.iters[0])); st.append(int(g.status[0]))
+                if ts[-1] > 0.02 and N < 200:           # an outlier: what was that solve?
+                    slow.append({'solve': i, 'problem': b, 'ms': ts[-1] * 1e3, 'scp_iterations': its[-1], 'status': st[-1],
+                                 'handed_to_fused_kernel': int(g.kernel_info['handed_over'])})
             per = sorted(t / max(1, i) for t, i in zip(ts, its))
             ki = g.kernel_info
             med = sorted(ts)[len(ts) // 2]
             out[key] = {'reference_driver': ref, 'N': N, 'dt': dt, 'X_rows': 4 if with_X else 0, 'max_gusto_iters': cap, 'solves': nsolve,
                         'ms_first_solve': ts[0] * 1e3, 'ms_per_solve_median': med * 1e3, 'ms_per_solve_max': max(ts) * 1e3,
                         'ms_per_solve_max_excluding_first': max(ts[1:]) * 1e3, 'max_over_median': max(ts) / med,
-                        'ms_per_solve_first_8': [t * 1e3 for t in ts[:8]], 'scp_iterations': its[:reps],
+                        'ms_per_solve_first_8': [t * 1e3 for t in ts[:8]], 'solves_above_20_ms': slow, 'scp_iterations': its[:reps],
                         'status_nonzero': int(sum(1 for v in st if v != 0)), 'ms_per_scp_iteration_median': per[len(per) // 2] * 1e3, 'kernel': ki['kernel'],
                         'handed_to_fused_kernel_last_solve': ki['handed_over']}
+            if N < 200:
+                # the same `reps` problems as ONE batched launch (one workgroup each, concurrently): where the GPU overtakes a host core
+                gb = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, np.zeros((reps, N, m)), x_init, z=z, U=Polyhedron(w['UA'], w['Ub']),
+                           X=Polyhedron(w['XA'], w['Xb']) if with_X else None, x_char=xc, f_char=fc, convg_thresh=1e-3, batch=reps, max_trace=0,
+                           max_gusto_iters=cap)
+                tb = []
+                for _ in range(8):
+                    t0 = time.perf_counter()
+                    gb.solve_batch(x0, np.zeros((reps, N, m)), x_init, z=z)
+                    tb.append(time.perf_counter() - t0)
+                out[key]['batch_of_%d' % reps] = {'ms_per_launch_median': sorted(tb)[len(tb) // 2] * 1e3, 'scp_iterations': int(gb.iters.sum()),
+                                                  'ms_per_scp_iteration_amortised': sorted(tb)[len(tb) // 2] * 1e3 / max(1, int(gb.iters.sum()))}
             # SURVEY 8(d) "CPU baseline (1)": the native twin (same algorithm) on the same problems, ONE thread -- what one host core
             # needs for the solve a closed loop waits for
             try:
@@ -391,6 +428,8 @@ def scp_reference_horizons(tip_node=1354):
                                    'ms_per_scp_iteration': cpu_ms, 'scp_iterations': [int(v) for v in itc],
                                    'iterations_equal_gpu': bool(all(int(a) == int(b_) for a, b_ in zip(itc, its[:nb]))),
                                    'cpu_over_gpu_latency': cpu_ms / out[key]['ms_per_scp_iteration_median']}
+                if 'batch_of_%d' % reps in out[key]:
+                    out[key]['cpu']['cpu_over_gpu_batch_of_%d' % reps] = cpu_ms / out[key]['batch_of_%d' % reps]['ms_per_scp_iteration_amortised']
             except Exception as exc:
                 out[key]['cpu'] = {'error': repr(exc)}
         except Exception as exc:
@@ -955,9 +994,7 @@ def main():
             # serves small synchronous calls ~100 us slower for the rest of the process (observed, ROCm 7.2)
             cl = closed_loop_latency(w, rom, tp) if rank == 0 else None
             single = scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, args.max_gusto_iters) if rank == 0 else None
-            # the closed-loop horizons of the reference's drivers too: a 64-solve latency series must not run in the ~100 ms after GB-sized
-            # buffers went back to the driver -- the kernel driver then evicts and restores the process' queues once (a 70-90 ms wait in
-            # hipStreamSynchronize with no kernel longer than 2 ms in the rocprof trace: tools/probes/solve_outliers.py)
+            # the closed-loop horizons of the reference's drivers too (latency series: taken with the other per-step latencies)
             horizons = scp_reference_horizons() if rank == 0 else None
         except Exception as exc:
             cl, single, horizons = {'error': repr(exc)}, None, None
@@ -981,7 +1018,7 @@ def main():
     # HBM traffic of the same kernel at the same shape from PMC counters (separate rocprofv3 --pmc passes,
     # corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/)
     traffic, traffic_source = None, None
-    for name in ('r04_proj_pmc.json', 'r03_proj_pmc.json', 'r02_proj_pmc.json'):
+    for name in ('r05_proj_pmc.json', 'r04_proj_pmc.json', 'r03_proj_pmc.json', 'r02_proj_pmc.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if pmc.get('algorithmic_bytes_per_launch') == alg_bytes:

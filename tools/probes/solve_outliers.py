@@ -57,3 +57,24 @@ for _ in range(50):
 torch.cuda.synchronize()
 burst('right after 50 torch matmuls')
 burst('again')
+# (c) right after a HEAVY phase (all 256 CUs busy for ~0.5 s: the 4096-rollout C2 solve of bench.py's timed loop), as in bench.py
+wc = wl.diamond_c2()
+tpc, gmc = bench.build_model(wc, 1354)
+xcc, fcc = gmc.get_characteristic_vals()
+R_ = 4096
+Xc = wl.snapshots(wc['q_ref'], R_, seed=2)
+romc = POD(dict(U=wc['U'], q_ref=wc['q_ref'], v_ref=wc['v_ref']))
+x0c = np.concatenate((np.zeros((R_, wc['r'])), romc.compute_RO_state(qf=Xc)), axis=1)
+uic = np.zeros((R_, wc['N'], wc['m']))
+xic, _ = tpc.rollout(x0c, uic, wc['dt'])
+zic = interp1d(wc['t'], wc['z'], axis=0, bounds_error=False, fill_value=(wc['z'][0], wc['z'][-1]))
+zc = np.stack([zic(b * 10.0 / R_ + wc['dt'] * np.arange(wc['N'] + 1)) for b in range(R_)])
+gc = GuSTO(gmc, wc['N'], wc['dt'], wc['Qz'], wc['R'], x0c, uic, xic, z=zc, U=Polyhedron(wc['UA'], wc['Ub']), X=Polyhedron(wc['XA'], wc['Xb']),
+           x_char=xcc, f_char=fcc, convg_thresh=1e-3, batch=R_, max_trace=0, max_gusto_iters=5)
+for _ in range(8):
+    gc.solve_batch(x0c, uic, xic, z=zc)
+burst('right after ~0.6 s of full-chip load (8 x 4096 rollouts)')
+burst('again, 64 more')
+burst('again, 64 more')
+time.sleep(1.0)
+burst('after 1 s of idle')
