@@ -36,8 +36,9 @@ def _cpu_budget():
 # after any BLAS-heavy host phase and the kernel freezes EVERY thread of the process -- including the one waiting in hipStreamSynchronize
 # -- until the period ends: the 70-90 ms "solve" outliers of rounds 3-4 (cpu.stat: nr_throttled 21, 69 s throttled in one bench run;
 # with the cap: none, max solve 0.7 ms -- tools/probes/check_horizon_outliers.py).
+# Half the budget: OpenBLAS workers keep spinning for a while after a call, and the thread that waits for the GPU spins as well.
 for _v in ('OPENBLAS_NUM_THREADS', 'OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
-    os.environ.setdefault(_v, str(_cpu_budget()))
+    os.environ.setdefault(_v, str(max(1, _cpu_budget() // 2)))
 os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
 
 import numpy as np
@@ -398,6 +399,22 @@ def scp_reference_horizons(tip_node=1354):
                         'status_nonzero': int(sum(1 for v in st if v != 0)), 'ms_per_scp_iteration_median': per[len(per) // 2] * 1e3, 'kernel': ki['kernel'],
                         'handed_to_fused_kernel_last_solve': ki['handed_over']}
             if N < 200:
+                # the reference's warm_start=True keeps the solver state across solves (locp.py:181): GuSTO(keep_solver_state=True) starts the
+                # first QP of every solve from the previous solve's minimiser and multipliers -- the same 64-solve series with it
+                gk = GuSTO(gm, N, dt, w['Qz'], w['R'], x0[0], u0, x_init[0], z=z[0], U=Polyhedron(w['UA'], w['Ub']),
+                           X=Polyhedron(w['XA'], w['Xb']) if with_X else None, x_char=xc, f_char=fc, convg_thresh=1e-3, max_trace=0, max_gusto_iters=cap,
+                           keep_solver_state=True)
+                tk, ik = [], []
+                for i in range(nsolve):
+                    b = i % reps
+                    t0 = time.perf_counter()
+                    gk.solve(x0[b], u0, x_init[b], z=z[b])
+                    tk.append(time.perf_counter() - t0)
+                    ik.append(int(gk.iters[0]))
+                perk = sorted(t / max(1, i) for t, i in zip(tk, ik))
+                out[key]['keep_solver_state'] = {'what': 'GuSTO(keep_solver_state=True): solver state kept across solves like the reference\'s warm_start=True',
+                                                 'ms_per_scp_iteration_median': perk[len(perk) // 2] * 1e3, 'ms_per_solve_median': sorted(tk)[len(tk) // 2] * 1e3,
+                                                 'scp_iterations_equal_cold': bool(ik == its)}
                 # the same `reps` problems as ONE batched launch (one workgroup each, concurrently): where the GPU overtakes a host core
                 gb = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, np.zeros((reps, N, m)), x_init, z=z, U=Polyhedron(w['UA'], w['Ub']),
                            X=Polyhedron(w['XA'], w['Xb']) if with_X else None, x_char=xc, f_char=fc, convg_thresh=1e-3, batch=reps, max_trace=0,

@@ -417,6 +417,11 @@ int sgusto_plan_create(sgusto_plan_t **plan, stpwl_t *h, const slocp_problem *pr
                        double dt, int64_t batch, const double *x_char, const double *f_char, int max_trace);
 int sgusto_plan_destroy(sgusto_plan_t *plan);
 int sgusto_plan_set_max_iters(sgusto_plan_t *plan, int max_gusto_iters);   /* gusto.py:142-147 */
+/* Solver state across solves (sofacontrol/scp/locp.py:181 `self.prob.solve(warm_start=self.warm_start, ...)`: the reference's cvxpy
+ * problem object lives as long as the GuSTO object, so with warm_start=True its solver starts EVERY QP -- also the first one of the next
+ * GuSTO.solve -- from the previous solution).  on = 1: the first QP of a solve starts from the minimiser and multipliers the same rollout's
+ * previous solve ended with (lean kernels; later QPs of a solve always do).  Default 0: every solve starts cold (what bench.py times). */
+int sgusto_plan_set_warm_across(sgusto_plan_t *plan, int on);
 /* Which kernel instantiation a solve of this plan launches: split (1: split W panel, n_x > 64), n_u_fixed / n_x_fixed
  * = the compile-time n_u / n_x of the instantiation (0: that extent is a run-time value; 0, 0 = the all-sizes
  * kernel).  For tests and bench records: parity is claimed per instantiation. */

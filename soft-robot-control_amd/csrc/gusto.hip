@@ -332,7 +332,7 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
     if (rc) { delete pl; return rc; }
     QPDims &d = pl->C.dims;
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
-                       par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace,
+                       par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace, 0,
                        (getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0) |
                        (getenv("SRH_LEAN_FORCE_HANDOVER") != nullptr ? (atoi(getenv("SRH_LEAN_FORCE_HANDOVER")) + 1) << 4 : 0)};
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
@@ -355,7 +355,8 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
         delete pl;
         return rc;
     }
-    if (hipMemset(pl->handed.p, 0, sizeof(int32_t)) != hipSuccess) {
+    // the resume / warm-start records of the work blocks start as "nothing there"
+    if (hipMemset(pl->work.p, 0, sizeof(double) * pl->work_stride * batch) != hipSuccess || hipMemset(pl->handed.p, 0, sizeof(int32_t)) != hipSuccess) {
         delete pl;
         SRH_REQUIRE(false, "sgusto_plan_create: hipMemset of the hand-over counter failed");
     }
@@ -377,6 +378,12 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
 
 int sgusto_plan_destroy(sgusto_plan_t *pl) {
     delete pl;
+    return SRH_OK;
+}
+
+int sgusto_plan_set_warm_across(sgusto_plan_t *pl, int on) {
+    SRH_REQUIRE(pl, "sgusto_plan_set_warm_across: null plan");
+    pl->par.warm_across = on ? 1 : 0;
     return SRH_OK;
 }
 

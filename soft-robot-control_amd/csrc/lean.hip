@@ -73,7 +73,8 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
-    bool converged = false, handed_over = false, have_warm = false;
+    // have_warm: w.u / w.lam of the work block hold a converged QP -- of this solve, or (warm_across) of the rollout's previous solve
+    bool converged = false, handed_over = false, have_warm = GXSEL > 0 && par.warm_across != 0 && rec[8] == 1.0;
     int itr = 0, status = 0;
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
         QPData q{x0, xk, zp, (cgptr)(b.zf ? b.zf + p * nz : nullptr),
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
             if (tid == 0) {
                 rec[0] = 1.0; rec[1] = delta; rec[2] = omega; rec[3] = J_prev; rec[4] = d_prev; rec[5] = o_prev; rec[6] = (double)itr;
                 rec[7] = (double)st;                  // 100: relaxed minimiser outside the trust region (the fused kernel skips its own relaxed attempts)
+                rec[8] = 0.0;                         // (the fused kernel carves the block differently: nothing to start the next solve from)
                 if (b.handed_over) atomicAdd(b.handed_over, 1);
             }
             handed_over = true;
@@ -180,7 +182,25 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                 d_prev = delta; J_prev = J; o_prev = omega;
                 // state-constraint violation (gusto.py:185-201): all k = 0..N
                 double viol = 0.0;
-                if (d.nX > 0) {
+                if (NST <= 0 && d.nX > 0 && d.nX <= nz) {        // (the fixed Diamond layouts keep the form below: measured, see ql::solve_qp)
+                    // one thread per (stage, row) for the n_x products of a row (one thread per stage walked n_X n_x = 240 of them),
+                    // then one thread per stage for the norm: the same sums in the same order
+                    gptr vr = w.ez;                      // (N + 1) n_z doubles of the QP's work block, free here
+                    __syncthreads();
+                    for (int e = tid; e < (N + 1) * d.nX; e += nt) {
+                        const int k = e / d.nX, r = e - k * d.nX;
+                        double v = -c.Xb[r];
+                        for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], w.x[(size_t)k * n + j], v);
+                        vr[e] = fmax(v, 0.0);
+                    }
+                    __syncthreads();
+                    for (int k = tid; k <= N; k += nt) {
+                        double v2 = 0.0;
+                        for (int r = 0; r < d.nX; ++r) { const double v = vr[(size_t)k * d.nX + r]; v2 = fma(v, v, v2); }
+                        viol = fmax(viol, sqrt(v2));
+                    }
+                    viol = wg::reduce(viol, 1, L.red);
+                } else if (d.nX > 0) {
                     for (int k = tid; k <= N; k += nt) {
                         double v2 = 0.0;
                         for (int r = 0; r < d.nX; ++r) {
@@ -262,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], xk[(size_t)k * n + j], v);
         b.zopt[p * (size_t)(N + 1) * nz + e] = v;
     }
-    if (tid == 0) { rec[0] = 0.0; b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; if (b.Jopt) b.Jopt[p] = J_prev; }
+    if (tid == 0) { rec[0] = 0.0; rec[8] = have_warm ? 1.0 : 0.0; b.iters[p] = itr; b.status[p] = status; if (b.last_iters) b.last_iters[p] = itr; if (b.Jopt) b.Jopt[p] = J_prev; }
 }
 
 template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>

@@ -554,6 +554,46 @@ __device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
     return ok;
 }
 
+// The same factorisation when only the leading NPC x NPC block of the tile is not the identity (short horizons: N p_o < 16 outputs,
+// ql::ipm_wave): the pivots and row operations beyond NPC are no-ops and are left out -- 45 row operations instead of 120 at NPC = 10.
+template <int NPC>
+__device__ __forceinline__ bool chol16_n(lptr T, lptr Rinv) {
+    static_assert(NPC >= 1 && NPC <= 16, "chol16_n: 1 <= NPC <= 16");
+    const int lane = threadIdx.x & 63, c = lane & 15, grp = lane >> 4;
+    double a[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const double t = T[r * TS + c];
+        a[r] = grp == 0 ? t : ((grp == 1 && r == c) ? 1.0 : 0.0);
+    }
+    bool ok = true;
+    double piv = readlane_d(a[0], 0);
+    ok = ok && (piv > 0.0);
+    double di = rsqrt(piv);
+    double di2 = di * (1.5 - 0.5 * piv * di * di);
+#pragma unroll
+    for (int s = 0; s < NPC; ++s) {
+        a[s] *= di2;
+        if (s + 1 < NPC) {
+            a[s + 1] = fma(-readlane_d(a[s], s + 1), a[s], a[s + 1]);
+            piv = readlane_d(a[s + 1], s + 1);
+            ok = ok && (piv > 0.0);
+            di = rsqrt(piv);
+            di2 = di * (1.5 - 0.5 * piv * di * di);
+        }
+#pragma unroll
+        for (int r = s + 2; r < NPC; ++r) a[r] = fma(-readlane_d(a[s], r), a[s], a[r]);
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[r * TS + c] = (r <= c) ? a[r] : 0.0;
+    } else if (grp == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rinv[c * TS + r] = a[r];
+    }
+    return ok;
+}
+
 // T <- T - Ra^T Rb (one 16 x 16 x 16 product)
 __device__ __forceinline__ void tile_update(lptr T, clptr Ra, clptr Rb, int l16, int kk) {
     wg::qp_d4 acc;

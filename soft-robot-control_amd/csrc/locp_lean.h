@@ -1751,7 +1751,8 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) { const int r = kk + 4 * qd; L.B[r * TS + i16] = kv[qd] * (L.ks[r] * sc); }
                 wave_fence();
-                ok = qpc::chol16(L.B, L.Rinv);
+                // (the padding rows / columns of a short horizon are the identity: only the leading N p_o pivots do anything)
+                ok = NP <= 6 ? qpc::chol16_n<6>(L.B, L.Rinv) : (NP <= 10 ? qpc::chol16_n<10>(L.B, L.Rinv) : qpc::chol16(L.B, L.Rinv));
                 wave_fence();
             }
             // ---------------- Newton direction
@@ -1923,6 +1924,40 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
     return status;
 }
 
+// Objective of the minimiser (qp::objective, locp.py:218-263): e = H x - z by one thread per (stage, output) -- 60 products each --
+// instead of one thread walking the n_z n_x = 360 products of its stage (28 k clocks per QP whatever the horizon:
+// profiles/r05_lean_phase_clocks.json), then one thread per stage for the small quadratic forms: the same sums in the same order.
+__device__ __forceinline__ double objective_par(const QPDims &d, const QPConst &c, const QPData &q, cgptr x, cgptr u, cgptr s, gptr ez, QPLds &L) {
+    const int n = d.n, nz = d.nz, m = d.m, N = d.N;
+    for (int e = threadIdx.x; e < (N + 1) * nz; e += blockDim.x) {
+        const int k = e / nz, a = e - k * nz;
+        double v = q.z ? -q.z[e] : 0.0;
+        for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], x[(size_t)k * n + j], v);
+        ez[e] = v;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int k = threadIdx.x; k <= N; k += blockDim.x) {
+        double e[16];
+        for (int a = 0; a < nz; ++a) e[a] = ez[(size_t)k * nz + a];
+        for (int a = 0; a < nz; ++a)
+            for (int b = 0; b < nz; ++b) acc = fma(e[a] * c.Qz[a * nz + b], e[b], acc);
+        if (k == N && c.Qzf) {
+            for (int a = 0; a < nz; ++a) e[a] += (q.z ? q.z[(size_t)k * nz + a] : 0.0) - (q.zf ? q.zf[a] : 0.0);
+            for (int a = 0; a < nz; ++a)
+                for (int b = 0; b < nz; ++b) acc = fma(e[a] * c.Qzf[a * nz + b], e[b], acc);
+        }
+        if (k < N) {
+            double ue[16];
+            for (int a = 0; a < m; ++a) ue[a] = u[(size_t)k * m + a] - (q.ud ? q.ud[(size_t)k * m + a] : 0.0);
+            for (int a = 0; a < m; ++a)
+                for (int b = 0; b < m; ++b) acc = fma(ue[a] * c.R[a * m + b], ue[b], acc);
+        }
+        if (d.tr) acc += q.omega * s[k];
+    }
+    return wg::reduce(acc, 0, L.red);
+}
+
 // The QP as the SCP loop needs it: condensed interior point, states by a rollout of the minimiser, objective, trust-region
 // test.  Returns 0 when the result IS the minimiser of the full QP (converged, inside the trust region); anything else
 // means "hand this QP to the fused kernel" (status of the interior point, or 100 = minimiser outside the trust region).
@@ -1958,7 +1993,11 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
 #ifdef SRH_PROFILE
     { const long long now_ = clock64(); prof[22] += now_ - tail_last; tail_last = now_; }
 #endif
-    double J = qp::objective(d0, c, q, w.x, w.u, w.s, Lq);
+    // (measured per layout on the full batch: the Diamond fixed layouts keep the one-thread-per-stage form -- 54.5 against 55.0 ms per
+    // 4096 rollouts, the extra pass through L2 costs more than the chain under load --, the Trunk layout gains 1.8 %, short horizons 5 %)
+    double J;
+    if constexpr (NST <= 0 || MSEL == 8) J = objective_par(d0, c, q, w.x, w.u, w.s, w.ez, Lq);
+    else J = qp::objective(d0, c, q, w.x, w.u, w.s, Lq);
     bool inside = true;
     if (dfull.tr) {
         double md = 0.0;

@@ -6,6 +6,8 @@
 struct GustoPar {
     double delta0, omega0, rho, beta_fail, gamma_fail, epsilon, omega_max, convg_thresh, dt;
     int max_iters, max_trace;
+    int warm_across;                    // 1: the first QP of a solve starts from the minimiser / multipliers the rollout's PREVIOUS solve left
+                                        // (the reference's `warm_start=True`: its cvxpy problem keeps the solver state between solves, locp.py:181)
     int poison_warm;                    // test knobs of the lean kernel, read when the plan is created.  bit 0 (SRH_LEAN_POISON_WARM=1): every warm-started
                                         // QP fails and is repeated cold; bits 4.. (SRH_LEAN_FORCE_HANDOVER=k): k + 1, SCP iteration k is handed to the fused kernel
 };
@@ -40,7 +42,8 @@ struct LocpBatch {
 namespace {
 
 constexpr int LEAN_PENDING = -77;       // status of a QP / rollout the lean kernel hands to the fused kernel
-constexpr int GUSTO_REC = 8;            // doubles of the resume record behind the SCP loop's index arrays
+constexpr int GUSTO_REC = 10;           // doubles of the resume record behind the SCP loop's index arrays ([8]: 1.0 = the work block holds a
+                                        // converged QP of the previous solve: GustoPar::warm_across)
 
 // offsets (doubles) of the SCP loop's own arrays inside a rollout's work block
 struct GustoWork { size_t xk, uk, acc, idx, rec, x0c, zc, end; };

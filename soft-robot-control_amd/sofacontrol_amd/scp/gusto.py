@@ -58,6 +58,9 @@ class GuSTO:
         self.f_scale = 1. / np.abs(self.f_char)
         self.jit = kwargs.pop('jit', True)      # meaningless here; accepted for signature parity
         user_max_iters = kwargs.pop('max_gusto_iters', MAX_ITERS)
+        # keep_solver_state=True: the first QP of every solve starts from the previous solve's minimiser and multipliers -- what the
+        # reference's warm_start=True does through its persistent cvxpy problem (locp.py:181).  Off by default: solves are independent.
+        self.keep_solver_state = bool(kwargs.pop('keep_solver_state', False))
         self.batch = int(kwargs.pop('batch', 1))
         self.max_trace = int(kwargs.pop('max_trace', 64))
         self.x_k = None
@@ -91,6 +94,8 @@ class GuSTO:
         self.max_gusto_iters = user_max_iters
         if self._fused:
             _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(user_max_iters))), 'set_max_iters')
+            if self.keep_solver_state:
+                _lib.check(_lib.lib().sgusto_plan_set_warm_across(self._plan, C.c_int(1)), 'set_warm_across')
 
     def _params(self, max_iters):
         return _lib.SGustoParams(float(self.delta0), float(self.omega0), float(self.rho), float(self.beta_fail),

@@ -273,3 +273,35 @@ def test_forced_hand_over_gives_the_same_solve(N, batch, zero_copy, monkeypatch)
     assert f[4] > 0
     assert (a[0] == f[0]).all() and (a[1] == f[1]).all(), (a[0], f[0], a[1], f[1])
     assert rel(f[2], a[2]) <= 1e-6 and rel(f[3], a[3]) <= 1e-6, (rel(f[2], a[2]), rel(f[3], a[3]))
+
+
+@pytest.mark.parametrize('N', [5, 50])
+def test_keep_solver_state_across_solves_same_results(N):
+    """`GuSTO(keep_solver_state=True)` -- the reference's warm_start=True semantics: its persistent cvxpy problem starts every QP, also the
+    first one of the next GuSTO.solve, from the previous solution (sofacontrol/scp/locp.py:181) -- only changes where the interior point of a
+    solve's first QP STARTS: a series of different problems solved one after the other must give the independent solves' SCP iteration
+    counts, status and trajectories (1e-6: same minimisers at the same gap), and the oracle's."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2(N=N, dt=0.05)
+    P_ = 6
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, P_, 2, 1354)
+    res = {}
+    for keep in (False, True):
+        g = GuSTO(gm, N, 0.05, w['Qz'], w['R'], x0[0], u_init[0], x_init[0], z=z[0], U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+                  x_char=xc, f_char=fc, convg_thresh=1e-3, max_trace=0, max_gusto_iters=5, keep_solver_state=keep)
+        out = []
+        for rep in range(2):
+            for b in range(P_):
+                g.solve(x0[b], u_init[b], x_init[b], z=z[b])
+                out.append((int(g.iters[0]), int(g.status[0]), g.xopt.copy(), g.uopt.copy()))
+        res[keep] = out
+    for a, k in zip(res[False], res[True]):
+        assert a[0] == k[0] and a[1] == k[1], (a[0], k[0], a[1], k[1])
+        assert rel(k[2], a[2]) <= 1e-6 and rel(k[3], a[3]) <= 1e-6, (rel(k[2], a[2]), rel(k[3], a[3]))
+    for b in range(2):
+        xe, ue, ze, tr = oracle_solve(w, xc, fc, x0[b], u_init[b], x_init[b], z[b], 5)
+        k = res[True][P_ + b]
+        assert k[0] == len(tr)
+        assert rel(k[2], xe) <= 1e-5 and rel(k[3], ue) <= 1e-5, (rel(k[2], xe), rel(k[3], ue))
