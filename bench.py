@@ -268,8 +268,12 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5, cpu=False):
     x_init, _ = tp.rollout(x0, u_init, dt)
     zi = interp1d(w['t'], w['z'], axis=0, bounds_error=False, fill_value=(w['z'][0], w['z'][-1]))
     z = np.stack([zi((lo + b) * (10.0 / total) + dt * np.arange(N + 1)) for b in range(Bn)])
+    # first_solve_cap: the constructor's own solve at the cap of the timed calls (the reference-default 500 costs 1.3-1.8 s here -- the
+    # trust-region-active tail of a few rollouts -- and was half of a bench run's GPU time; `scp_uncapped_500` reports that regime for C2)
+    t_c = time.perf_counter()
     g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), x_char=xc, f_char=fc,
-              convg_thresh=1e-3, batch=Bn, max_trace=0, max_gusto_iters=max_iters)
+              convg_thresh=1e-3, batch=Bn, max_trace=0, max_gusto_iters=max_iters, first_solve_cap=max_iters)
+    t_c = time.perf_counter() - t_c
     g.max_gusto_iters = max_iters
     if dist is not None:
         dist.barrier()
@@ -316,6 +320,7 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5, cpu=False):
                         '%s; host buffers; best of 3 calls' % (dt, total, Bn, 'weak scaling (256 per rank)' if total == 256 * world and world > 1 else 'strong scaling'),
             'cpu': cpu_entry if cpu_entry is not None else 'no twin run on this rank / entry (see scp_c5 of a single-GPU run)',
             'iterations_per_s': its / el, 'ms': el * 1e3, 'ms_all_calls': [e * 1e3 for e in els], 'iterations': its,
+            'constructor_s (plan creation + first solve at first_solve_cap = %d)' % max_iters: t_c,
             'not_converged_rank0': int((g.status != 0).sum()), 'kernel': g.kernel_info['kernel'],
             'rollouts_handed_to_fused_kernel': int(g.kernel_info['handed_over']),
             'best_rollout': {'global_index': best, 'cost': float(J_all[best]) if best >= 0 else None, 'costs_gathered': int(J_all.size),

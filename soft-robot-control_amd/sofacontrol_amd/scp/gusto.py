@@ -61,6 +61,9 @@ class GuSTO:
         # keep_solver_state=True: the first QP of every solve starts from the previous solve's minimiser and multipliers -- what the
         # reference's warm_start=True does through its persistent cvxpy problem (locp.py:181).  Off by default: solves are independent.
         self.keep_solver_state = bool(kwargs.pop('keep_solver_state', False))
+        # first_solve_cap: cap of the constructor's own solve (the reference runs it with its default of 500 SCP iterations whatever
+        # max_gusto_iters says, gusto.py:142-147 -- None keeps that); a caller that only wants the plan built can ask for less
+        first_solve_cap = kwargs.pop('first_solve_cap', None)
         self.batch = int(kwargs.pop('batch', 1))
         self.max_trace = int(kwargs.pop('max_trace', 64))
         self.x_k = None
@@ -86,7 +89,7 @@ class GuSTO:
                              dU=self.dU, verbose=(verbose == 2), warm_start=warm_start, x_char=self.x_char,
                              nonlinear_observer=self.nonlinear_observer, **kwargs)
         # gusto.py:142-147: the first solve may take up to MAX_ITERS, then the user's limit applies
-        self.max_gusto_iters = MAX_ITERS
+        self.max_gusto_iters = MAX_ITERS if first_solve_cap is None else int(first_solve_cap)
         if x0.ndim == 1:
             self.solve(x0, u_init, x_init, z, zf, u)
         else:

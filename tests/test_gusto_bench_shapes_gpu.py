@@ -305,3 +305,21 @@ def test_keep_solver_state_across_solves_same_results(N):
         k = res[True][P_ + b]
         assert k[0] == len(tr)
         assert rel(k[2], xe) <= 1e-5 and rel(k[3], ue) <= 1e-5, (rel(k[2], xe), rel(k[3], ue))
+
+
+def test_first_solve_cap_limits_the_constructor_solve():
+    """The constructor runs one solve at the reference-default cap of 500 SCP iterations whatever `max_gusto_iters` says (gusto.py:142-147);
+    `first_solve_cap` lets a caller who only wants the plan built cap that solve too (bench.py: C5)."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2(N=5, dt=0.05)
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, 4, 2, 1354)
+    kw = dict(z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, batch=4, max_trace=0)
+    g = GuSTO(gm, 5, 0.05, w['Qz'], w['R'], x0, u_init, x_init, max_gusto_iters=3, first_solve_cap=0, **kw)
+    assert (g.iters == 1).all(), g.iters               # cap 0: exactly one QP (the real-time iteration)
+    g.solve_batch(x0, u_init, x_init, z=z)
+    it_user = g.iters.copy()
+    assert (it_user >= 2).any() and (it_user <= 4).all(), it_user
+    g2 = GuSTO(gm, 5, 0.05, w['Qz'], w['R'], x0, u_init, x_init, max_gusto_iters=3, **kw)
+    assert (g2.iters >= 2).any(), g2.iters             # the default constructor solve is not capped at 0
