@@ -202,7 +202,7 @@ def test_lean_cold_retry_after_failed_warm_start(monkeypatch):
 
 
 @pytest.mark.parametrize('which,N,dt,with_X', [('diamond', 5, 0.05, True), ('diamond', 3, 0.1, False), ('diamond', 8, 0.05, True), ('trunk', 8, 0.1, False),
-                                                ('trunk', 4, 0.1, False)])
+                                                ('trunk', 4, 0.1, False), ('diamond', 1, 0.05, True), ('diamond', 2, 0.05, False)])
 def test_short_horizon_wave_form_matches_box_form_and_oracle(which, N, dt, with_X, monkeypatch):
     """Short horizons (N p_o <= 16: K is one tile) run the interior point on ONE wave (ql::ipm_wave, lean<M, NX, GX, -1, 0, 0>); with
     SRH_LEAN_NO_WAVE=1 at plan creation the same problem takes the eight-wave form (ql::ipm_box, run-time horizon).  Both are the same
