@@ -1,17 +1,21 @@
+# End-of-round measurement pass on the GPU box (gpurun -- bash tools/run_round.sh r05): the full GPU test suite, the default bench line, the rocprofv3 passes
+# of tools/prof_round.sh, the phase-clock table of the lean kernel, the determinism probe and the two C3 forms; everything under gpurun_out/<tag>/
+# (+ gpurun_out/profiles_<tag>/: the summaries to copy into profiles/).
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
+TAG=${1:?usage: bash tools/run_round.sh <tag, e.g. r05>}
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05n; mkdir -p $O
+O=gpurun_out/$TAG; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench.log 2> $O/bench.err; echo "bench rc $?"
-bash tools/prof_round.sh r05 > $O/prof_round.log 2>&1; echo "prof rc $?"; tail -2 $O/prof_round.log
+bash tools/prof_round.sh $TAG > $O/prof_round.log 2>&1; echo "prof rc $?"; tail -2 $O/prof_round.log
 timeout 600 python tools/probes/lean_phase_clocks.py $O/lean_phase_clocks.json > $O/phase.log 2>&1
-python tools/probes/summarise_phase_clocks.py profiles/r05a_lean_phase_clocks_raw.json $O/lean_phase_clocks.json $O/r05_lean_phase_clocks.json
+python tools/probes/summarise_phase_clocks.py profiles/r05a_lean_phase_clocks_raw.json $O/lean_phase_clocks.json $O/${TAG}_lean_phase_clocks.json
 timeout 300 python tools/determinism_probe.py c2 > $O/determinism.log 2>&1; tail -3 $O/determinism.log
 timeout 300 python tools/time_c3.py > $O/time_c3.log 2>&1; tail -6 $O/time_c3.log
-mkdir -p gpurun_out/profiles_r05; cp profiles/r05_* gpurun_out/profiles_r05/ 2>/dev/null; ls gpurun_out/profiles_r05
+mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null; ls gpurun_out/profiles_$TAG
 python - <<'PY'
 import json
-l=open('gpurun_out/r05n/bench.log').read().strip().splitlines()[-1]
+l=open('gpurun_out/$TAG/bench.log').read().strip().splitlines()[-1]
 d=json.loads(l)
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline', d['roofline'], 'vs', d.get('vs_baseline'))
 print('c5', {k:v for k,v in d['secondary']['scp_c5'].items() if k in ('ms','ms_all_calls','constructor_s (plan creation + first solve at first_solve_cap = 5)')})
