@@ -2,7 +2,7 @@
 # of tools/prof_round.sh, the phase-clock table of the lean kernel, the determinism probe and the two C3 forms; everything under gpurun_out/<tag>/
 # (+ gpurun_out/profiles_<tag>/: the summaries to copy into profiles/).
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
-TAG=${1:?usage: bash tools/run_round.sh <tag, e.g. r05>}
+TAG=${1:?usage: bash tools/run_round.sh <tag, e.g. r05>}; export TAG
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu.log
@@ -15,7 +15,8 @@ timeout 300 python tools/time_c3.py > $O/time_c3.log 2>&1; tail -6 $O/time_c3.lo
 mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null; ls gpurun_out/profiles_$TAG
 python - <<'PY'
 import json
-l=open('gpurun_out/$TAG/bench.log').read().strip().splitlines()[-1]
+import os
+l=open('gpurun_out/%s/bench.log' % os.environ['TAG']).read().strip().splitlines()[-1]
 d=json.loads(l)
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline', d['roofline'], 'vs', d.get('vs_baseline'))
 print('c5', {k:v for k,v in d['secondary']['scp_c5'].items() if k in ('ms','ms_all_calls','constructor_s (plan creation + first solve at first_solve_cap = 5)')})
