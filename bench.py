@@ -398,6 +398,9 @@ def scp_reference_horizons(tip_node=1354):
             ki = g.kernel_info
             med = sorted(ts)[len(ts) // 2]
             out[key] = {'reference_driver': ref, 'N': N, 'dt': dt, 'X_rows': 4 if with_X else 0, 'max_gusto_iters': cap, 'solves': nsolve,
+                        'problem': "the synthetic C2 model (workloads.diamond_c2) at the driver's N / dt / state rows / cap; costs and U box are C2's "
+                                   "(Qz on tip x and y, U in [0, 1500]) -- the hardware driver itself weights (y, z) and bounds U in [200, 2500] "
+                                   "(examples/hardware/diamond.py:376-386): same problem class and size, not the same numbers",
                         'ms_first_solve': ts[0] * 1e3, 'ms_per_solve_median': med * 1e3, 'ms_per_solve_max': max(ts) * 1e3,
                         'ms_per_solve_max_excluding_first': max(ts[1:]) * 1e3, 'max_over_median': max(ts) / med,
                         'ms_per_solve_first_8': [t * 1e3 for t in ts[:8]], 'solves_above_20_ms': slow, 'scp_iterations': its[:reps],

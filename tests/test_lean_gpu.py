@@ -1,5 +1,9 @@
 """GPU: the lean condensed kernels (csrc/lean.hip, locp_lean.h: packed G resident in LDS, own kernel without the inlined
-Riccati solver) against the fused kernels they replace on the hot path and against the oracle.
+Riccati solver) against the fused kernels they replace on the hot path and against the numpy statement of the algorithm.
+
+This file is a CONSISTENCY test (HIP path vs HIP path: two kernel families must agree); the parity tests of the same kernels against
+the oracle -- the restated reference loop -- are tests/test_gusto_bench_shapes_gpu.py (GuSTO at the bench shapes, the reference drivers'
+horizons, the one-wave form, forced hand-over and cold retry) and tests/test_locp_gpu.py / test_locp_cond_gpu.py (the QP).
 
 * one LOCP QP (sofacontrol/scp/locp.py:218-342) at the C2 / C5 stage shapes through `LOCP` (slocp_solve): lean vs fused
   (SRH_LOCP_NO_LEAN=1) -- interior-point iteration counts within one of each other, iterates to 1e-8 -- and vs the numpy condensed statement;
