@@ -34,6 +34,15 @@ __device__ __forceinline__ double dpp_mov(double v) {
     const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi2, lo2);
 }
+// the value of lane ^ 16 (the neighbouring row of 16 lanes).  v_permlane16_swap_b32 (gfx950) swaps the odd rows of its first operand
+// with the even rows of its second: with the same value in both, the first result carries the even rows' values in both rows of a
+// pair and the second the odd rows' -- two VALU instructions and a select per 32 bits instead of a ds_bpermute round trip.
+__device__ __forceinline__ double xor16(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const bool odd = (threadIdx.x >> 4) & 1;
+    return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
     static_assert(G == 4 || G == 8 || G == 16, "group_sum: G must be 4, 8 or 16");

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         printf("lean qp tail: rollout-of-minimiser %lld objective+tr-test %lld ipm-iterations %lld qps %lld warm-qps %lld\n",
                prof[22], prof[23], prof[24], prof[25], prof[26]);
         printf("lean split (factorisation on waves 0-3 beside the front of the Newton solve on waves 4-7): factorisation %lld front %lld\n", prof[16], prof[17]);
+        printf("lean factor chain (wave 0): wait %lld panel %lld update %lld factor %lld signals %lld\n", prof[27], prof[28], prof[29], prof[30], prof[31]);
     }
 #endif
     if (handed_over) {

@@ -511,85 +511,79 @@ __device__ __forceinline__ void gram(const QPDims &d, const QCWork &w, Lds &L) {
 }
 
 // ------------------------------------------------------------------ tile Cholesky K = R^T R (upper), in place
-// diagonal tile: factor + inverse in registers.  Lanes 0..15 hold the columns of the tile, lanes 16..31 the columns of the
-// identity; the elimination is a sequence of ROW operations M (M A = R, so M = R^-T) whose multipliers are wave-uniform
-// (v_readlane from lanes 0..15), so the same instructions carry the identity to M = Rinv^T at no extra cost -- no
-// separate back-substitution for the inverse on the one wave that is the critical path of the factorisation.
-__device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
-    const int lane = threadIdx.x & 63, c = lane & 15, grp = lane >> 4;
-    double a[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const double t = T[r * TS + c];
-        a[r] = grp == 0 ? t : ((grp == 1 && r == c) ? 1.0 : 0.0);
-    }
-    // The row that carries the NEXT pivot is updated first and the reciprocal square root of that pivot (readlane, v_rsq_f64, a
-    // Newton step: a dependent chain of ~100 clocks) is started before the other row operations of the step, which do not depend
-    // on it -- the one wave that runs this is the critical path of the factorisation.  Same operations, same results.
-    bool ok = true;
-    double piv = readlane_d(a[0], 0);
-    ok = ok && (piv > 0.0);
-    double di = rsqrt(piv);
-    double di2 = di * (1.5 - 0.5 * piv * di * di);                 // one Newton step: full double accuracy
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        a[s] *= di2;
-        if (s + 1 < 16) {
-            a[s + 1] = fma(-readlane_d(a[s], s + 1), a[s], a[s + 1]);
-            piv = readlane_d(a[s + 1], s + 1);
-            ok = ok && (piv > 0.0);
-            di = rsqrt(piv);
-            di2 = di * (1.5 - 0.5 * piv * di * di);
-        }
-#pragma unroll
-        for (int r = s + 2; r < 16; ++r) a[r] = fma(-readlane_d(a[s], r), a[s], a[r]);
-    }
-    if (grp == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[r * TS + c] = (r <= c) ? a[r] : 0.0;
-    } else if (grp == 1) {                                         // a[r] = M[r][c] = Rinv[c][r]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Rinv[c * TS + r] = a[r];
-    }
-    return ok;
+// diagonal tile: factor + inverse in registers on ONE wave -- the critical path of the factorisation.  Lane c of every row of 16
+// lanes holds column c of the tile (a[r] = row r) and column c of the identity (b[r]); the elimination is a sequence of ROW
+// operations M (M A = R, so M = R^-T) that carries the identity to M = Rinv^T -- no separate back-substitution for the inverse.
+// The multiplier of a row operation is entry r of the scaled pivot row, i.e. a[s] of lane r: it reaches the FMA through the DPP
+// network (`v_fmac_f64_dpp ... row_newbcast:r`, one instruction) instead of a v_readlane pair, a hazard s_nop and an FMA through
+// an SGPR pair (rounds 2-5).  On one wave an f64 VALU instruction costs ~8 shader clocks whether it depends on the one before or
+// not, the readlane-fed FMA ~18 (tools/probes/dpp_rate_probe.hip): the factorisation is bound by its instruction count, 5.1 k ->
+// 3.7 k clocks per tile (tools/probes/chol16_probe.hip).  The four rows of 16 lanes do the same work on the same data (a broadcast
+// cannot cross rows; splitting the rows of the tile over them costs more in pivot-row exchanges than it saves).
+// The inline asm carries no wait states: tools/check_dpp_hazard.py (part of the guarded build) places the s_nop the final
+// instruction order needs in front of a DPP read.  All 64 lanes must be active.
+// acc <- acc - src[lane R of this row of 16 lanes] * oth
+template <int R>
+__device__ __forceinline__ void fnma_bc(double &acc, double src, double oth) {
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(oth), "n"(R));
 }
-
-// The same factorisation when only the leading NPC x NPC block of the tile is not the identity (short horizons: N p_o < 16 outputs,
-// ql::ipm_wave): the pivots and row operations beyond NPC are no-ops and are left out -- 45 row operations instead of 120 at NPC = 10.
-template <int NPC>
-__device__ __forceinline__ bool chol16_n(lptr T, lptr Rinv) {
-    static_assert(NPC >= 1 && NPC <= 16, "chol16_n: 1 <= NPC <= 16");
-    const int lane = threadIdx.x & 63, c = lane & 15, grp = lane >> 4;
-    double a[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const double t = T[r * TS + c];
-        a[r] = grp == 0 ? t : ((grp == 1 && r == c) ? 1.0 : 0.0);
+template <int R>
+__device__ __forceinline__ double mov_bc(double src) {
+    double o;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(src), "n"(R));
+    return o;
+}
+// 1 / sqrt(p) for a positive normal p: v_rsq_f64 and the third-order correction of the library's rsqrt (without its class test:
+// the caller flags a pivot that is not positive)
+__device__ __forceinline__ double rsq3(double p) {
+    const double y0 = __builtin_amdgcn_rsq(p), e = fma(-(p * y0), y0, 1.0);
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+template <int S, int R, int NPC>
+__device__ __forceinline__ void chol16_rows(double (&a)[16], double (&b)[16]) {
+    if constexpr (R < NPC) {
+        fnma_bc<R>(a[R], a[S], a[S]);
+        fnma_bc<R>(b[R], a[S], b[S]);
+        chol16_rows<S, R + 1, NPC>(a, b);
     }
-    bool ok = true;
-    double piv = readlane_d(a[0], 0);
-    ok = ok && (piv > 0.0);
-    double di = rsqrt(piv);
-    double di2 = di * (1.5 - 0.5 * piv * di * di);
+}
+// A pivot that is not positive shows in the LAST scale factor: rsq of a negative number is NaN, of zero infinite, and either
+// reaches every later pivot through the row operations -- one test at the end instead of one per pivot.
+template <int S, int NPC>
+__device__ __forceinline__ void chol16_steps(double (&a)[16], double (&b)[16], double y, double &ylast) {
+    if constexpr (S < NPC) {
+        a[S] *= y;
+        b[S] *= y;
+        double yn = 0.0;
+        if constexpr (S + 1 < NPC) {
+            fnma_bc<S + 1>(a[S + 1], a[S], a[S]);
+            yn = rsq3(mov_bc<S + 1>(a[S + 1]));
+            fnma_bc<S + 1>(b[S + 1], a[S], b[S]);
+        } else ylast = y;
+        chol16_rows<S, S + 2, NPC>(a, b);
+        chol16_steps<S + 1, NPC>(a, b, yn, ylast);
+    }
+}
+// STORE_T: write the factor back (qpc::r_times / rT_times read the diagonal tiles; the lean kernels only ever use Rinv).
+// NPC: only the leading NPC x NPC block of the tile is not the identity (short horizons, ql::ipm_wave: N p_o < 16 outputs): the
+// pivots and row operations beyond it are no-ops and are left out -- 45 row operations instead of 120 at NPC = 10.
+template <bool STORE_T = true, int NPC = 16>
+__device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
+    static_assert(NPC >= 1 && NPC <= 16, "chol16: 1 <= NPC <= 16");
+    const int lane = threadIdx.x & 63, c = lane & 15, grp = lane >> 4;
+    double a[16], b[16];
 #pragma unroll
-    for (int s = 0; s < NPC; ++s) {
-        a[s] *= di2;
-        if (s + 1 < NPC) {
-            a[s + 1] = fma(-readlane_d(a[s], s + 1), a[s], a[s + 1]);
-            piv = readlane_d(a[s + 1], s + 1);
-            ok = ok && (piv > 0.0);
-            di = rsqrt(piv);
-            di2 = di * (1.5 - 0.5 * piv * di * di);
+    for (int r = 0; r < 16; ++r) { a[r] = T[r * TS + c]; b[r] = r == c ? 1.0 : 0.0; }
+    double ylast = 0.0;
+    chol16_steps<0, NPC>(a, b, rsq3(mov_bc<0>(a[0])), ylast);
+    const bool ok = ylast > 0.0 && ylast < INFINITY;
+    if (grp == 0) {
+        if constexpr (STORE_T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r * TS + c] = (r <= c) ? a[r] : 0.0;
         }
 #pragma unroll
-        for (int r = s + 2; r < NPC; ++r) a[r] = fma(-readlane_d(a[s], r), a[s], a[r]);
-    }
-    if (grp == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[r * TS + c] = (r <= c) ? a[r] : 0.0;
-    } else if (grp == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Rinv[c * TS + r] = a[r];
+        for (int r = 0; r < 16; ++r) Rinv[c * TS + r] = b[r];          // b[r] = M[r][c] = Rinv[c][r]
     }
     return ok;
 }

@@ -481,6 +481,9 @@ __device__ __forceinline__ void gT_times(const QPDims &d, const GP &g, Lds &L, c
 // runs over the stages that reach it: 2 j < 16 (I + 1).  Stages with 2 j <= 16 I reach every lane of the tile row (no
 // masks); the last seven are triangular.  sched: per wave 4 tasks x {I, J0, nJ, 0} (host-built, longest first onto the
 // least loaded SIMD; nJ = 0: no more tasks).
+#ifdef SRH_PROFILE
+__device__ long long g_prof_waves[16];         // per-wave clocks of the Gram fill (products, epilogue), cumulative over the launch's workgroup 0
+#endif
 template <int MSEL, class GP>
 __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP &g, Lds &L) {
     static_assert(MSEL == 4 || MSEL == 8, "lean Gram: n_u = 4 or 8");
@@ -490,8 +493,15 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     const int l16 = lane & 15, kk = lane >> 4;
     const int goff0 = goff(g.j0, M, NP);
     lptr w2 = L.tc;                                            // 1 / D per packed row
+#ifdef SRH_PROFILE
+    long long gl[6] = {0, 0, 0, 0, 0, 0}, g0 = clock64(), g1;   // 1/D pass + barrier, descriptors, products, epilogue, barrier, scaling + barrier  (wave 0 -> L.Qu[4..7], L.Qu[13..14])
+#define GR_LAP(i) do { g1 = clock64(); gl[i] += g1 - g0; g0 = g1; } while (0)
+#else
+#define GR_LAP(i) ((void)0)
+#endif
     for (int e = tid; e < N * M; e += nt) { const double s = L.Ldi[e]; w2[e] = s * s; }
     __syncthreads();
+    GR_LAP(0);
     // this wave's tasks: all descriptors requested at once (one L2 latency instead of one per task)
     int tI[4], tJ0[4], tnJ[4];
 #pragma unroll
@@ -504,6 +514,7 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
         tI[slot] = __builtin_amdgcn_readfirstlane(tI[slot]); tJ0[slot] = __builtin_amdgcn_readfirstlane(tJ0[slot]);
         tnJ[slot] = __builtin_amdgcn_readfirstlane(tnJ[slot]);
     }
+    GR_LAP(1);
     for (int slot = 0; slot < 4; ++slot) {
         const int I = tI[slot], J0 = tJ0[slot], nJ = tnJ[slot];
         if (nJ == 0) break;
@@ -565,7 +576,19 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
         else if (nJ == 3) task_body(std::integral_constant<int, 3>{});
         else if (nJ == 2) task_body(std::integral_constant<int, 2>{});
         else task_body(std::integral_constant<int, 1>{});
+        GR_LAP(2);
         // ---- Ls on both sides, + I, raw tile to the store; the diagonal feeds the Jacobi scaling
+        // (the factors of the rows are the same for every tile of the task; the row r ^ 1 of an output stage sits in the neighbouring
+        // row of 16 lanes: wg::xor16, two v_permlane16_swap instead of a ds_bpermute round trip; the scale factors of the Jacobi
+        // scaling only where the tile is a diagonal one -- round 5: 13 k of the 40 k clocks of a Gram fill were this epilogue)
+        double la0[4], la2[4], la3[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gi = 16 * I + kk + 4 * q, ka = min(gi >> 1, N - 1);
+            clptr La = L.Ls + (size_t)ka * 4;
+            la0[q] = La[0]; la2[q] = La[2]; la3[q] = La[3];
+        }
+        const bool ar0 = (kk & 1) == 0;                                  // row of the output stage: 16 I + 4 q are even
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t >= nJ) continue;
@@ -576,22 +599,25 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
             lptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = kk + 4 * q, gi = 16 * I + r, ka = min(gi >> 1, N - 1), ar = gi & 1;
-                clptr La = L.Ls + (size_t)ka * 4;
+                const int r = kk + 4 * q, gi = 16 * I + r;
                 double v = (gi < NP && gjc < NP) ? acc[t][q] : 0.0;      // padding rows / columns: exactly the identity
                 const double vp = wg::dpp_mov<0xB1>(v);                 // the other column of the output stage
                 v = fma(vp, cb_oth, v * cb_own);                        // (Ky Ls)
-                const double vr = __shfl_xor(v, 16, 64);                // the other row of the output stage (kk ^ 1)
-                v = ar == 0 ? fma(La[2], vr, La[0] * v) : La[3] * v;    // Ls^T (Ky Ls)
-                const bool dg = I == J && r == l16;
-                v += dg ? 1.0 : 0.0;
-                const double ri = rsqrt(dg ? v : 1.0);
-                if (dg) L.ks[gi] = ri * (1.5 - 0.5 * v * ri * ri);       // one Newton step: full double accuracy
+                const double vr = wg::xor16(v);                         // the other row of the output stage (kk ^ 1)
+                v = ar0 ? fma(la2[q], vr, la0[q] * v) : la3[q] * v;     // Ls^T (Ky Ls)
+                if (I == J) {                                           // (the whole wave)
+                    const bool dg = r == l16;
+                    v += dg ? 1.0 : 0.0;
+                    const double ri = qpc::rsq3(dg ? v : 1.0);
+                    if (dg) L.ks[gi] = ri;
+                }
                 T[r * TS + l16] = v;
             }
         }
+        GR_LAP(3);
     }
     __syncthreads();
+    GR_LAP(4);
     // ---- symmetric scaling to a unit diagonal (see qpc::gram for why it matters): every wave scales the tiles it wrote
     for (int slot = 0; slot < 4; ++slot) {
         const int I = tI[slot], J0 = tJ0[slot], nJ = tnJ[slot];
@@ -604,6 +630,12 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
         }
     }
     __syncthreads();
+    GR_LAP(5);
+#ifdef SRH_PROFILE
+    if (tid == 0) { for (int i = 0; i < 4; ++i) L.Qu[4 + i] += (double)gl[i]; L.Qu[13] += (double)gl[4]; L.Qu[14] += (double)gl[5]; }
+    if (lane == 0 && blockIdx.x == 0) { g_prof_waves[wave] += gl[2]; g_prof_waves[8 + wave] += gl[3]; }
+#endif
+#undef GR_LAP
 }
 
 // ------------------------------------------------------------------ tile Cholesky on one wave set, without set-wide barriers
@@ -644,26 +676,44 @@ __device__ __forceinline__ void panel_tile(Lds &L, int KT, int J, int Jp, int l1
     for (int qd = 0; qd < 4; ++qd) T[(kk + 4 * qd) * TS + l16] = acc[qd];
 }
 // F: three LDS counters, zero on entry.  Returns nothing: L.flag[1] = 1 iff every pivot was positive (valid after the caller's barrier).
-__device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const Waves<true> &W, liptr F) {
+__device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const Waves<true> &W, liptr F, liptr Fnext) {
     const int KT = d.KT, wave = W.wave, lane = W.tid & 63, nwk = W.nw - 1;
     const int l16 = lane & 15, kk = lane >> 4;
     liptr Ftrail = F, Frinv = F + 1, Fpanel = F + 2;
     if (wave == 0) {
-        bool ok = qpc::chol16(L.B, L.Rinv);
+#ifdef SRH_PROFILE
+        long long cl[5] = {0, 0, 0, 0, 0}, c0 = clock64(), c1;            // wait, panel, update, factor, signals (L.Qu[8..12])
+#define TC_LAP(i) do { c1 = clock64(); cl[i] += c1 - c0; c0 = c1; } while (0)
+#else
+#define TC_LAP(i) ((void)0)
+#endif
+        bool ok = qpc::chol16<false>(L.B, L.Rinv);
+        TC_LAP(3);
         set_signal(Frinv);
+        TC_LAP(4);
         for (int J = 0; J + 1 < KT; ++J) {
-            set_wait(Ftrail, nwk * J);
+            set_wait(Fnext, 2 * J);                               // (J, J + 1) and (J + 1, J + 1) carry the updates of row J - 1
+            TC_LAP(0);
             panel_tile(L, KT, J, J + 1, l16, kk);
+            TC_LAP(1);
             set_signal(Fpanel);
+            TC_LAP(4);
             clptr Ra = L.B + (size_t)qpc::tile_index(J, J + 1, KT) * TSZ;
             lptr T = L.B + (size_t)qpc::tile_index(J + 1, J + 1, KT) * TSZ;
             __builtin_amdgcn_wave_barrier();
             qpc::tile_update(T, Ra, Ra, l16, kk);
             __builtin_amdgcn_wave_barrier();
-            ok = qpc::chol16(T, L.Rinv + (size_t)(J + 1) * TSZ) && ok;
+            TC_LAP(2);
+            ok = qpc::chol16<false>(T, L.Rinv + (size_t)(J + 1) * TSZ) && ok;
+            TC_LAP(3);
             set_signal(Frinv);
+            TC_LAP(4);
         }
         if (lane == 0) L.flag[1] = ok ? 1 : 0;
+#ifdef SRH_PROFILE
+        if (lane == 0) for (int i = 0; i < 5; ++i) L.Qu[8 + i] = (double)cl[i];
+#endif
+#undef TC_LAP
     } else {
         for (int J = 0; J + 1 < KT; ++J) {
             set_wait<true>(Frinv, J + 1);
@@ -671,13 +721,18 @@ __device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const
             for (int Jp = J + 2 + (wave - 1); Jp < KT; Jp += nwk) panel_tile(L, KT, J, Jp, l16, kk);      // (J, J + 1) is wave 0's
             set_signal(Fpanel);
             set_wait<true>(Fpanel, (nwk + 1) * (J + 1));
-            const int rem = KT - J - 1, ntr = rem * (rem + 1) / 2;
-            for (int t = wave; t < ntr; t += nwk) {               // tiles 1 .. ntr-1 over the workers (tile 0 = (J+1, J+1) is wave 0's)
-                int tt = t, Ir = 0;
+            // tiles 1 .. ntr-1 over the workers (tile 0 = (J+1, J+1) is wave 0's).  The two tiles wave 0 needs for the NEXT row -- tile 1 =
+            // (J+1, J+2) and tile `rem` = (J+2, J+2) -- are the first tiles of workers 1 and 2 (tile `rem` changes places with tile 2),
+            // each announced on its own: wave 0 does not wait for the whole trailing update of a row (20 tiles on three waves in row 0).
+            const int rem = KT - J - 1, ntr = rem * (rem + 1) / 2, wB = nwk >= 2 ? 2 : 1;
+            for (int t = wave; t < ntr; t += nwk) {
+                int tt = (t == 2 && rem > 2) ? rem : ((t == rem && rem > 2) ? 2 : t), Ir = 0;
+                const bool first = (rem >= 2) && (t == 1 || tt == rem);
                 while (tt >= rem - Ir) { tt -= rem - Ir; ++Ir; }
                 const int I = J + 1 + Ir, Kc = I + tt;
                 qpc::tile_update(L.B + (size_t)qpc::tile_index(I, Kc, KT) * TSZ, L.B + (size_t)qpc::tile_index(J, I, KT) * TSZ,
                                  L.B + (size_t)qpc::tile_index(J, Kc, KT) * TSZ, l16, kk);
+                if (first) set_signal(Fnext);
             }
             set_signal(Ftrail);
         }
@@ -1174,7 +1229,10 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     for (int e = tid; e < ldG + YPAD; e += nt) { L.ya[e] = 0.0; L.yd[e] = 0.0; L.yg[e] = 0.0; }     // padding stays zero for good
     for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
     for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
-    if (tid < 4) L.flag[4 + tid] = 0;                          // counters of the two wave sets (Waves, tile_cholesky_set)
+#ifdef SRH_PROFILE
+    if (tid < 16) L.Qu[tid] = 0.0;
+#endif
+    if (tid < 5) L.flag[3 + tid] = 0;                          // counters of the two wave sets (Waves, tile_cholesky_set; [3]: idle between the region tests of two QPs)
     __syncthreads();
     bool reuse = false;
     if (dyn.idx != nullptr) {
@@ -1185,6 +1243,8 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
         if (!same) L.flag[3] = 0;
         __syncthreads();
         reuse = L.flag[3] != 0;
+        __syncthreads();
+        if (tid == 0) L.flag[3] = 0;                           // tile_cholesky_set's early-tile counter from here on
     }
     if (!reuse) {
         rollout<MSEL, NSEL>(d, dyn, q.x0, (cgptr) nullptr, w.x, L);
@@ -1355,7 +1415,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 #endif
             auto W = half_waves(L.flag + 4);
             if (half_of_wave(wv) == 0) {
-                tile_cholesky_set(d, L, W, L.flag + 5);
+                tile_cholesky_set(d, L, W, L.flag + 5, L.flag + 3);
 #ifdef SRH_PROFILE
                 if (tid == 0) L.Qu[2] = (double)(clock64() - tsplit);
 #endif
@@ -1368,9 +1428,10 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
             __syncthreads();
 #ifdef SRH_PROFILE
             prof[16] += (long long)L.Qu[2]; prof[17] += (long long)L.Qu[3];
+            for (int i = 0; i < 5; ++i) prof[27 + i] += (long long)L.Qu[8 + i];
 #endif
             ok = L.flag[1] != 0;
-            if (tid < 4) L.flag[4 + tid] = 0;                  // the product half's arrival counter and the factorising half's three, for the next split
+            if (tid < 5) L.flag[3 + tid] = 0;                  // the factorising half's early-tile counter, the product half's arrival counter and the factorising half's three, for the next split
             if (gyd) rd = L.Qu[0];
             if (ok) unit_tiles(d, L);
             QB_LAP(5);
@@ -1468,6 +1529,16 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
 #ifdef SRH_PROFILE
     for (int i = 0; i < 8; ++i) prof[8 + i] += pf.t[8 + i];
     prof[24] += it; prof[25] += 1; prof[26] += warm ? 1 : 0;
+    if (tid == 0 && blockIdx.x == 0)
+        printf("lean gram laps (this QP, wave 0): 1/D+barrier %.0f descriptors %.0f products %.0f epilogue %.0f barrier %.0f scaling+barrier %.0f\n",
+               L.Qu[4], L.Qu[5], L.Qu[6], L.Qu[7], L.Qu[13], L.Qu[14]);
+    if (tid == 0 && blockIdx.x == 0) {
+        printf("lean gram per wave (cumulative) products:");
+        for (int i = 0; i < 8; ++i) printf(" %lld", g_prof_waves[i]);
+        printf("  epilogue:");
+        for (int i = 0; i < 8; ++i) printf(" %lld", g_prof_waves[8 + i]);
+        printf("\n");
+    }
 #endif
     if (iters_out) *iters_out = it;
     return status;
@@ -1738,12 +1809,12 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
                     double v = (r < NP && i16 < NP) ? acc[qd] : 0.0;
                     const double vp = wg::dpp_mov<0xB1>(v);
                     v = fma(vp, cb_oth, v * cb_own);
-                    const double vr = __shfl_xor(v, 16, 64);
+                    const double vr = wg::xor16(v);
                     v = ar == 0 ? fma(La[2], vr, La[0] * v) : La[3] * v;
                     const bool dg = r == i16;
                     v += dg ? 1.0 : 0.0;
-                    const double ri = rsqrt(dg ? v : 1.0);
-                    if (dg) L.ks[r] = ri * (1.5 - 0.5 * v * ri * ri);
+                    const double ri = qpc::rsq3(dg ? v : 1.0);
+                    if (dg) L.ks[r] = ri;
                     kv[qd] = v;
                 }
                 wave_fence();
@@ -1752,7 +1823,7 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
                 for (int qd = 0; qd < 4; ++qd) { const int r = kk + 4 * qd; L.B[r * TS + i16] = kv[qd] * (L.ks[r] * sc); }
                 wave_fence();
                 // (the padding rows / columns of a short horizon are the identity: only the leading N p_o pivots do anything)
-                ok = NP <= 6 ? qpc::chol16_n<6>(L.B, L.Rinv) : (NP <= 10 ? qpc::chol16_n<10>(L.B, L.Rinv) : qpc::chol16(L.B, L.Rinv));
+                ok = NP <= 6 ? qpc::chol16<false, 6>(L.B, L.Rinv) : (NP <= 10 ? qpc::chol16<false, 10>(L.B, L.Rinv) : qpc::chol16<false>(L.B, L.Rinv));
                 wave_fence();
             }
             // ---------------- Newton direction

@@ -64,46 +64,58 @@ static void jacobi_eig(std::vector<double> A, int n, std::vector<double> &w, std
     for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
 }
 
-// Gram tile tasks of the lean kernels: tile row I (KT - I upper tiles, k-steps = min(N, 8 (I + 1)) m / 4 each) is cut into
-// chunks of at most 4 tiles whose cost stays near the per-wave share, the chunks go to the waves longest first onto the least
-// loaded wave (waves w and w + 4 share a SIMD: the load of a SIMD is what is balanced).  Output: nw x 4 x {I, J0, nJ, 0}.
+// Gram tile tasks of the lean kernels: tile row I (KT - I upper tiles, k-steps = min(N, 8 (I + 1)) m / 4 each) is cut into chunks
+// of at most 4 tiles that share the A operand; the chunks go to the waves longest first onto the least loaded wave (waves w and
+// w + 4 share a SIMD and its MFMA pipe: a quarter of the partner's load counts).  The cost of a chunk of nJ tiles over ks k-steps
+// is what the per-wave clocks of the profile build say (round 5, C2: t ~ 0.064 nJ ks + 0.034 ks + 0.16 nJ k clocks -- the MFMAs,
+// the operand loads + 1 / D product of a k-step, the epilogue of a tile): in MFMA units nJ ks + 0.53 ks + 2.5 nJ.  The chunk size
+// of every tile row is searched exhaustively (4^KT greedy assignments, KT <= 8: milliseconds at plan creation) for the smallest
+// maximum load -- the one-size rule of round 4 left the busiest wave 24 % above the mean.  Output: nw x 4 x {I, J0, nJ, 0}.
 static bool lean_gram_schedule(int N, int m, int KT, int nw, std::vector<int> &out) {
     struct Task { int I, J0, nJ; double cost; };
-    std::vector<Task> tasks;
-    double total = 0.0;
+    if (KT < 1 || KT > 8 || nw < 1 || nw > 16) return false;
     auto ksteps = [&](int I) { return std::min(N, 8 * (I + 1)) * (m / 4); };
-    for (int I = 0; I < KT; ++I) total += (double)(KT - I + 0.5) * ksteps(I);
-    const double share = total / nw;
-    for (int I = 0; I < KT; ++I) {
-        const int nt = KT - I;
-        int per = 4;
-        while (per > 1 && (per + 0.5) * ksteps(I) > 0.8 * share) --per;
-        for (int J = I; J < KT; J += per) {
-            const int nJ = std::min(per, KT - J);
-            tasks.push_back({I, J, nJ, (nJ + 0.5) * ksteps(I)});
+    auto cost = [&](int I, int nJ) { const double ks = ksteps(I); return nJ * ks + 0.53 * ks + 2.5 * nJ; };
+    double best_max = 0.0, best_sum = 0.0;
+    bool have = false;
+    std::vector<Task> tasks;
+    std::vector<int> cur;
+    int combos = 1;
+    for (int I = 0; I < KT; ++I) combos *= 4;
+    for (int code = 0; code < combos; ++code) {
+        tasks.clear();
+        int cd = code;
+        for (int I = 0; I < KT; ++I) {
+            const int per = 1 + (cd & 3);
+            cd >>= 2;
+            for (int J = I; J < KT; J += per) { const int nJ = std::min(per, KT - J); tasks.push_back({I, J, nJ, cost(I, nJ)}); }
         }
-        (void)nt;
-    }
-    std::sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
-    std::vector<double> load(nw, 0.0);
-    std::vector<int> cnt(nw, 0);
-    out.assign((size_t)nw * 16, 0);
-    for (const Task &t : tasks) {
-        int best = -1;
-        double bl = 0.0;
-        for (int w = 0; w < nw; ++w) {
-            if (cnt[w] >= 4) continue;
-            const double simd = load[w] + (nw > 4 ? load[(w + nw / 2) % nw] : 0.0);      // the two waves of a SIMD
-            const double key = simd + 0.5 * load[w];
-            if (best < 0 || key < bl) { best = w; bl = key; }
+        if ((int)tasks.size() > 4 * nw) continue;
+        std::stable_sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
+        double load[16] = {0.0};
+        int cnt[16] = {0};
+        cur.assign((size_t)nw * 16, 0);
+        bool ok = true;
+        for (const Task &t : tasks) {
+            int best = -1;
+            double bl = 0.0;
+            for (int w = 0; w < nw; ++w) {
+                if (cnt[w] >= 4) continue;
+                const double key = load[w] + (nw > 4 ? 0.25 * load[(w + nw / 2) % nw] : 0.0);
+                if (best < 0 || key < bl) { best = w; bl = key; }
+            }
+            if (best < 0) { ok = false; break; }
+            int *o = &cur[((size_t)best * 4 + cnt[best]) * 4];
+            o[0] = t.I; o[1] = t.J0; o[2] = t.nJ; o[3] = 0;
+            load[best] += t.cost;
+            ++cnt[best];
         }
-        if (best < 0) return false;
-        int *o = &out[((size_t)best * 4 + cnt[best]) * 4];
-        o[0] = t.I; o[1] = t.J0; o[2] = t.nJ; o[3] = 0;
-        load[best] += t.cost;
-        ++cnt[best];
+        if (!ok) continue;
+        double mx = 0.0, sum = 0.0;
+        for (int w = 0; w < nw; ++w) { mx = std::max(mx, load[w]); sum += load[w]; }
+        if (!have || mx < best_max - 1e-9 || (mx < best_max + 1e-9 && sum < best_sum - 1e-9)) { have = true; best_max = mx; best_sum = sum; out = cur; }
     }
-    return true;
+    return have;
 }
 
 int build_consts(const slocp_problem *pr, QPConstHost &C) {

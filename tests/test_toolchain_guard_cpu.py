@@ -1,5 +1,6 @@
-"""The toolchain guard of the build (tools/check_spill_exec.py): VGPR spills that hipcc places in front of the EXEC restore
-of a join block are found, repaired, and absent from the device assembly the shipped objects were assembled from."""
+"""The toolchain guard of the build (tools/check_spill_exec.py): VGPR spills and PHI copies that hipcc places in front of the EXEC
+restore of a join block are found, repaired, and absent from the device assembly the shipped objects were assembled from; and
+tools/check_dpp_hazard.py: the wait states in front of inline-asm DPP reads that the compiler's hazard recogniser does not see."""
 import glob
 import importlib.util
 import os
@@ -68,8 +69,90 @@ def test_value_produced_inside_the_region_is_left_alone(tmp_path):
 
 
 def test_store_that_would_pass_a_wait_is_refused(tmp_path):
+    """the spill mover refuses to carry a store over a wait; the whole tool (round 5) moves the EXEC restore up to the join label instead"""
     p = write(tmp_path, BAD.replace('	v_writelane_b32 v250, s47, 37\n', '	s_waitcnt vmcnt(0)\n'))
-    assert guard.fix(p) == (0, 1) and guard.main(['--fix', p]) == 1
+    assert guard.fix(p) == (0, 1) and guard.main(['--fix', p]) == 0
+    lines = open(p).read().split('\n')
+    lab = lines.index('.LBB0_2:')
+    assert lines[lab + 1].startswith('\ts_or_b64 exec, exec, s[0:1]') and guard.scan(p) == []
+
+
+# round 5: the copies of values that live across a divergent loop, placed at the join label IN FRONT of the EXEC restore (EXEC is empty
+# there: the loop ends when its last lane leaves, the branch around it is taken when no lane enters) -- the registers keep their old
+# contents and the code behind the join reads them (locp_kernel<*, 0, 0>: a QP that converged to a worse minimiser)
+STRANDED = HEAD + '''	s_and_saveexec_b64 s[2:3], s[12:13]
+	s_cbranch_execz .LBB0_3
+; %bb.1:
+	s_mov_b64 s[20:21], 0
+.LBB0_2:
+	v_add_u32_e32 v3, s12, v3
+	v_cmp_le_i32_e32 vcc, s4, v3
+	s_or_b64 s[20:21], vcc, s[20:21]
+	s_andn2_b64 exec, exec, s[20:21]
+	s_cbranch_execnz .LBB0_2
+.LBB0_3:
+	v_mov_b64_e32 v[166:167], v[154:155]
+	v_readlane_b32 s8, v250, 23
+	v_mov_b32_e32 v0, v139
+	s_or_b64 exec, exec, s[2:3]
+	v_mov_b64_e32 v[130:131], v[108:109]
+	s_endpgm
+'''
+
+
+def test_copies_in_front_of_the_exec_restore_of_a_join_are_flagged_and_repaired(tmp_path):
+    p = write(tmp_path, STRANDED)
+    found = guard.stranded(open(p).read().split('\n'))
+    assert [(f[1], f[2], f[3]) for f in found] == [(12, 16, None)]
+    assert guard.main([p]) == 1
+    assert guard.main(['--fix', p]) == 0
+    lines = open(p).read().split('\n')
+    lab = lines.index('.LBB0_3:')
+    assert lines[lab + 1].startswith('\ts_or_b64 exec, exec, s[2:3]') and 'v_mov_b64_e32 v[166:167]' in lines[lab + 2]
+    assert sum('s_or_b64 exec, exec' in l for l in lines) == 1 and guard.stranded(lines) == []
+    # lane accesses (SGPR spill code) do not look at EXEC: a join block that only has those in front of its restore is left alone
+    only_lanes = STRANDED.replace('\tv_mov_b64_e32 v[166:167], v[154:155]\n', '').replace('\tv_mov_b32_e32 v0, v139\n', '')
+    q = write(tmp_path, only_lanes)
+    assert guard.stranded(only_lanes.split('\n')) == [] and guard.main(['--fix', q]) == 0 and open(q).read() == only_lanes
+    # the saved mask reloaded between the label and the restore: the restore cannot move over it -- refused, the build fails
+    reload_mask = STRANDED.replace('v_readlane_b32 s8, v250, 23', 'v_readlane_b32 s2, v250, 23')
+    r = write(tmp_path, reload_mask)
+    assert guard.stranded(reload_mask.split('\n'))[0][3] is not None and guard.main(['--fix', r]) == 1
+
+
+def _dpp_tool():
+    sp = importlib.util.spec_from_file_location('check_dpp_hazard', os.path.join(ROOT, 'tools', 'check_dpp_hazard.py'))
+    m = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(m)
+    return m
+
+
+def test_wait_states_in_front_of_inline_asm_dpp_reads(tmp_path):
+    """VALU write -> DPP read of the same VGPR needs two wait states; the compiler does not see a DPP operand inside inline asm."""
+    dpp = _dpp_tool()
+    body = HEAD + '''	v_mul_f64 v[32:33], v[36:37], v[4:5]
+	;;#ASMSTART
+	v_fmac_f64_dpp v[38:39], -v[32:33], v[32:33] row_newbcast:1 row_mask:0xf bank_mask:0xf
+	;;#ASMEND
+	v_mul_f64 v[30:31], v[94:95], v[4:5]
+	;;#ASMSTART
+	v_mov_b64_dpp v[2:3], v[38:39] row_newbcast:1 row_mask:0xf bank_mask:0xf
+	;;#ASMEND
+	v_rsq_f64_e32 v[36:37], v[2:3]
+	;;#ASMSTART
+	v_mul_f64 v[40:41], v[36:37], v[36:37]
+	;;#ASMEND
+	v_mov_b32_dpp v7, v30 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf
+	s_endpgm
+'''
+    p = write(tmp_path, body)
+    found, _ = dpp.scan(open(p).read().splitlines(True), False)
+    # the fmac right behind the producer of its DPP operand (2), the mov one instruction behind the fmac that wrote v[38:39] (1), the
+    # asm consumer of a transcendental result (1); the compiler's own DPP move outside asm is the compiler's business
+    assert [(f[2].split()[0], f[3]) for f in found] == [('v_fmac_f64_dpp', 2), ('v_mov_b64_dpp', 1), ('v_mul_f64', 1)]
+    assert dpp.main([p]) == 1 and dpp.main(['--fix', p]) == 0 and dpp.main([p]) == 0
+    text = open(p).read()
+    assert text.count('s_nop 1') == 1 and text.count('s_nop 0') == 2
 
 
 def test_shipped_device_assembly_is_clean():
@@ -78,9 +161,12 @@ def test_shipped_device_assembly_is_clean():
     lib = os.path.join(ROOT, 'soft-robot-control_amd', 'sofacontrol_amd', 'libsofacontrol_hip.so')
     if not os.path.exists(lib) or not all(os.path.exists(a) for a in asms):
         pytest.skip('library not built here (the assembly is kept next to the objects by the Makefile)')
+    dpp = _dpp_tool()
     for a in asms:
         assert guard.scan(a) == [], a
+        assert guard.stranded(open(a).read().split('\n')) == [], a
         assert guard.audit(a) == [], a          # every spill store has the form the check examines; metadata and comments agree
+        assert dpp.scan(open(a).read().splitlines(True), False)[0] == [], a
 
 
 def test_audit_fails_closed_on_spill_code_it_cannot_read(tmp_path):

@@ -139,6 +139,96 @@ def fix(path):
     return len(drop), refused
 
 
+# ---- the same placement with other instructions (round 5).  The join block of a divergent region starts with the EXEC restore; hipcc
+# also puts PHI copies (`v_mov_b64 v[166:167], v[154:155]` ...) of the values that live across the region IN FRONT of it.  The label is
+# the target of the region's `s_cbranch_execz`: EXEC is empty there when the region was skipped or left through its loop exit and
+# narrowed otherwise, so the copies reach no lane (or not all of them) and the code behind the join reads stale registers.  Seen in
+# locp_kernel<*, 0, 0> after an unrelated change of the Cholesky tile code: a QP that "converged" to a 0.1 % worse minimiser.
+# Looked for: at a label that some s_cbranch_execz of the function targets, vector / memory instructions before the block's first EXEC
+# write when that write is `s_or_b64 exec, exec, s[a:b]`.  --fix moves the restore up to the label (nothing in between may be a scalar
+# instruction other than s_waitcnt / s_nop, touch EXEC or write s[a:b]: refused otherwise, and the build fails).
+EXECZ = re.compile(r'^\s*s_cbranch_execz\s+(\.LBB\w+)')
+ANY_INSTR = re.compile(r'^\s+([a-z][a-z0-9_]+)\b(.*)$')
+ANY_EXEC_WRITE = re.compile(r'^\s*(s_\w*saveexec\w*|s_\w+\s+exec\b|v_cmpx\w*)')
+HARMLESS_SCALAR = re.compile(r'^\s*(s_waitcnt|s_nop)\b')
+LANE_ACCESS = re.compile(r'^\s*v_(readlane|writelane|readfirstlane)_b32\b')      # SGPR spill code: does not look at EXEC
+
+
+def stranded(lines):
+    """-> [(function, line of the label, line of the restore, refusal or None)]   (1-based line numbers)"""
+    out, func, targets, start = [], None, set(), 0
+
+    def close(end):
+        for i in range(start, end):
+            m = LABEL.match(lines[i])
+            if not m or lines[i].split(':')[0] not in targets:
+                continue
+            body, j = [], i + 1
+            while j < end:
+                line = lines[j]
+                if LABEL.match(line) or FUNC.match(line):
+                    break
+                mi = ANY_INSTR.match(line)
+                if not mi or mi.group(1).startswith('.'):
+                    j += 1
+                    continue
+                mp = re.match(r'^\s*s_or_b64 exec, exec, (s\[\d+:\d+\])', line)
+                if mp:
+                    real = [b for b in body if not HARMLESS_SCALAR.match(lines[b]) and not LANE_ACCESS.match(lines[b]) and not re.match(r'^\s*s_', lines[b])]
+                    if real:
+                        sx = mp.group(1)
+                        lo, hi = (int(v) for v in re.match(r's\[(\d+):(\d+)\]', sx).groups())
+                        why = None
+                        for b in body:
+                            t = lines[b]
+                            if re.match(r'^\s*s_', t) and not HARMLESS_SCALAR.match(t):
+                                why = 'a scalar instruction stands between the label and the restore'
+                            if re.search(r'\bexec\b', t.split(';')[0]):
+                                why = 'an instruction between the label and the restore names EXEC'
+                            d = re.match(r'^\s*v_read(?:first)?lane_b32\s+s(\d+)', t)
+                            if d and lo <= int(d.group(1)) <= hi:
+                                why = 'the saved mask is written between the label and the restore'
+                        out.append((func, i + 1, j + 1, why))
+                    break
+                if ANY_EXEC_WRITE.match(line) or BRANCH.match(line) or re.match(r'^\s*s_barrier', line):
+                    break
+                body.append(j)
+                j += 1
+
+    for i, line in enumerate(lines):
+        m = FUNC.match(line)
+        if m:
+            if func is not None:
+                close(i)
+            func, targets, start = m.group(1), set(), i
+            continue
+        m = EXECZ.match(line)
+        if m:
+            targets.add(m.group(1))
+    if func is not None:
+        close(len(lines))
+    return out
+
+
+def fix_stranded(path):
+    """move the EXEC restore of every flagged join block up to its label, in place; -> (moved, refused)"""
+    lines = open(path).read().split('\n')
+    found = stranded(lines)
+    todo = [(ll, lr) for _, ll, lr, why in found if why is None]
+    if todo:
+        take = {lr for _, lr in todo}
+        put = {ll: lr for ll, lr in todo}
+        out = []
+        for i, line in enumerate(lines, 1):
+            if i in take:
+                continue
+            out.append(line)
+            if i in put:
+                out.append(lines[put[i] - 1].split(';')[0].rstrip() + ' ; EXEC restore moved up to the join label (check_spill_exec.py)')
+        open(path, 'w').write('\n'.join(out))
+    return len(todo), len(found) - len(todo)
+
+
 ANY_SPILL_STORE = re.compile(r'^\s*(scratch_store|buffer_store|flat_store|global_store)\w*\s.*;.*Folded Spill')
 ANY_SPILL_MARK = re.compile(r';.*Folded (Spill|Reload)')
 META_SPILLS = re.compile(r'^\s*\.vgpr_spill_count:\s*(\d+)')
@@ -180,13 +270,19 @@ def main(argv):
             bad += 1
             print(msg)
         if do_fix:
+            hoisted, refused = fix_stranded(path)
+            if hoisted or refused:
+                print('%s: %d EXEC restore(s) moved up to their join label, %d refused' % (path, hoisted, refused))
             moved, refused = fix(path)
             if moved or refused:
                 print('%s: %d spill(s) moved behind their EXEC restore, %d refused' % (path, moved, refused))
         for func, off, ln, lr in scan(path):
             bad += 1
             print('%s:%d: %s: spill to stack slot %d sits before the EXEC restore at line %d' % (path, ln, func[:100], off, lr))
-    print('%d spill(s) stored under a narrowed EXEC' % bad)
+        for func, ll, lr, why in stranded(open(path).read().split('\n')):
+            bad += 1
+            print('%s:%d: %s: vector instructions between the join label and its EXEC restore at line %d%s' % (path, ll, func[:100], lr, ' (%s)' % why if why else ''))
+    print('%d spill(s) / join block(s) with code under a narrowed EXEC' % bad)
     return 1 if bad else 0
 
 
