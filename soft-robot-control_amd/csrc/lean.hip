@@ -119,56 +119,72 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
             GU_LAP(3);
             tpwl::nearest_many(T, w.x, n, N, idx2);
             GU_LAP(4);
+            // One wave per stage, lane = row of the three products.  The stage vectors (old / new state and input) go through the wave's
+            // slot of the K-tile area (dead between two QPs) instead of being fetched from L2 by every lane and every column; the matrix
+            // columns are requested sixteen at a time; when the new point lies in the region of the old one -- most stages -- its matrices
+            // are the ones already loaded.  Same products in the same order (round 5: 207 k -> clocks per SCP iteration at C2 in
+            // profiles/r05_lean_phase_clocks.json; every stage paid eight dependent L2 round trips).
             for (int i = wave; i < N; i += nw) {
-                const size_t ia = idx[i], ib = idx2[i];
+                const size_t ia = (size_t)__builtin_amdgcn_readfirstlane(idx[i]), ib = (size_t)__builtin_amdgcn_readfirstlane(idx2[i]);
+                lptr sv = L.B + (size_t)wave * (2 * (n + m));
+                for (int e = lane; e < n; e += 64) { sv[e] = xk[(size_t)i * n + e]; sv[n + e] = w.x[(size_t)i * n + e]; }
+                if (lane < m) { sv[2 * n + lane] = uk[(size_t)i * m + lane]; sv[2 * n + m + lane] = w.u[(size_t)i * m + lane]; }
+                ql::wave_fence();
                 double e2 = 0.0, a2 = 0.0;
-                for (int r = lane; r < n; r += 64) {
-                    double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
-                    cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
-                    for (int c0 = 0; c0 < n; c0 += 8) {
-                        double av[8], anv[8], xo[8], xn[8];
+                auto rows = [&](auto SAME) {
+                    constexpr bool same = decltype(SAME)::value;
+                    for (int r = lane; r < n; r += 64) {
+                        double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
+                        cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
+                        for (int c0 = 0; c0 < n; c0 += 16) {
+                            double av[16], anv[16];
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            const int cc = c0 + qq < n ? c0 + qq : n - 1;
-                            av[qq] = Ak[(size_t)cc * n + r]; anv[qq] = An[(size_t)cc * n + r];
-                            xo[qq] = xk[(size_t)i * n + cc]; xn[qq] = w.x[(size_t)i * n + cc];
-                        }
+                            for (int qq = 0; qq < 16; ++qq) {
+                                const int cc = c0 + qq < n ? c0 + qq : n - 1;
+                                av[qq] = Ak[(size_t)cc * n + r];
+                                if constexpr (!same) anv[qq] = An[(size_t)cc * n + r];
+                            }
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            if (c0 + qq < n) {
-                                fk = fma(av[qq], xo[qq], fk);
-                                fl = fma(av[qq], xn[qq] - xo[qq], fl);
-                                f = fma(anv[qq], xn[qq], f);
+                            for (int qq = 0; qq < 16; ++qq) {
+                                if (c0 + qq < n) {
+                                    const double xo = sv[c0 + qq], xn = sv[n + c0 + qq];
+                                    fk = fma(av[qq], xo, fk);
+                                    fl = fma(av[qq], xn - xo, fl);
+                                    f = fma(same ? av[qq] : anv[qq], xn, f);
+                                }
                             }
                         }
-                    }
-                    cgptr Bk = T.BcT + ia * m * n, Bn = T.BcT + ib * m * n;
-                    for (int c0 = 0; c0 < m; c0 += 8) {
-                        double bv[8], bnv[8], uo[8], un[8];
+                        cgptr Bk = T.BcT + ia * m * n, Bn = T.BcT + ib * m * n;
+                        for (int c0 = 0; c0 < m; c0 += 8) {
+                            double bv[8], bnv[8];
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            const int cc = c0 + qq < m ? c0 + qq : m - 1;
-                            bv[qq] = Bk[(size_t)cc * n + r]; bnv[qq] = Bn[(size_t)cc * n + r];
-                            uo[qq] = uk[(size_t)i * m + cc]; un[qq] = w.u[(size_t)i * m + cc];
-                        }
+                            for (int qq = 0; qq < 8; ++qq) {
+                                const int cc = c0 + qq < m ? c0 + qq : m - 1;
+                                bv[qq] = Bk[(size_t)cc * n + r];
+                                if constexpr (!same) bnv[qq] = Bn[(size_t)cc * n + r];
+                            }
 #pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            if (c0 + qq < m) {
-                                fk = fma(bv[qq], uo[qq], fk);
-                                fl = fma(bv[qq], un[qq] - uo[qq], fl);
-                                f = fma(bnv[qq], un[qq], f);
+                            for (int qq = 0; qq < 8; ++qq) {
+                                if (c0 + qq < m) {
+                                    const double uo = sv[2 * n + c0 + qq], un = sv[2 * n + m + c0 + qq];
+                                    fk = fma(bv[qq], uo, fk);
+                                    fl = fma(bv[qq], un - uo, fl);
+                                    f = fma(same ? bv[qq] : bnv[qq], un, f);
+                                }
                             }
                         }
+                        const double fa = fk + fl;
+                        const double fsr = b.fs[r];
+                        const double de = fsr * (f - fa), da = fsr * fa;
+                        e2 = fma(de, de, e2);
+                        a2 = fma(da, da, a2);
                     }
-                    const double fa = fk + fl;
-                    const double fsr = b.fs[r];
-                    const double de = fsr * (f - fa), da = fsr * fa;
-                    e2 = fma(de, de, e2);
-                    a2 = fma(da, da, a2);
-                }
+                };
+                if (ia == ib) rows(std::true_type{}); else rows(std::false_type{});
                 e2 = wg::wave_sum(e2);
                 a2 = wg::wave_sum(a2);
                 if (lane == 0) { accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2); }
+                ql::wave_fence();                                        // the slot is rewritten for the wave's next stage
             }
             __syncthreads();
             GU_LAP(5);

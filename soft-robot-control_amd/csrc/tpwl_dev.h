@@ -66,12 +66,45 @@ __device__ inline int nearest_wave(const TpwlDev &T, XP x) {
 
 // nearest point for `count` states X (count x n, LDS or global) -> idx (LDS/global int array).
 // All waves of the workgroup participate; ends with __syncthreads().
+// Position-weighted tables of at most 64 points and 32 coordinates (every shipped model: w_v = 0, P = 64, r = 30 / 36 is the general
+// path): lane i keeps ITS point in registers for all the states of the call, the coordinates of a state arrive with one coalesced load
+// (requested one state ahead) and are broadcast lane by lane -- nearest_wave pays four L2 round trips, a library sqrt and eighteen
+// ds_bpermute per state (6-8 k clocks; 60 k per SCP iteration at C2).  Same sums in the same order, same first minimum.
 template <typename XP, typename IP>
 __device__ inline void nearest_many(const TpwlDev &T, XP X, int ldx, int count, IP idx) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    for (int k = wave; k < count; k += nw) {
-        const int i = nearest_wave(T, X + (size_t)k * ldx);
-        if ((threadIdx.x & 63) == 0) idx[k] = i;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+    if (T.w_v == 0.0 && T.P <= 64 && T.r <= 32) {
+        const int r = T.r;
+        const bool live = lane < T.P;
+        double tq[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) tq[j] = (j < r && live) ? T.qT[j * T.P + lane] : 0.0;
+        int k = wave;
+        double xv = (k < count && lane < r) ? (double)X[(size_t)k * ldx + r + lane] : 0.0;
+        while (k < count) {
+            const int kn = k + nw;
+            const double xn = (kn < count && lane < r) ? (double)X[(size_t)kn * ldx + r + lane] : 0.0;      // the next state, while this one is worked on
+            double sq = 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (j < r) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(xv), j), hi = __builtin_amdgcn_readlane(__double2hiint(xv), j);
+                    const double e = tq[j] - __hiloint2double(hi, lo);
+                    sq = fma(e, e, sq);
+                }
+            }
+            const double dist = live ? T.w_q * sqrt(sq) : INFINITY;
+            const double dmin = wg::wave_min(dist);
+            const int imin = (int)wg::wave_min(dist == dmin ? (double)lane : 1e9);        // first minimum (np.argmin)
+            if (lane == 0) idx[k] = imin < T.P ? imin : 0;          // (a state that is not a number: no minimum)
+            k = kn;
+            xv = xn;
+        }
+    } else {
+        for (int k = wave; k < count; k += nw) {
+            const int i = nearest_wave(T, X + (size_t)k * ldx);
+            if (lane == 0) idx[k] = i;
+        }
     }
     __syncthreads();
 }

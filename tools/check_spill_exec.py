@@ -34,6 +34,26 @@ EXEC_WRITE = re.compile(r'^\s*(s_\w+saveexec_b64|s_\w+ exec,)')
 POP = re.compile(r'^\s*s_or_b64 exec, exec,')
 SPILL = re.compile(r'^\s*scratch_store_dword\w*\s+off, (v\[?[\d:]+\]?), off(?: offset:(\d+))?\s*; .*Folded Spill')
 RELOAD = re.compile(r'^\s*scratch_load_dword\w*\s+(v\[?[\d:]+\]?), off, off(?: offset:(\d+))?\s*; .*Folded Reload')
+# frames beyond the 12-bit immediate (> 4 KB of scratch per lane: the generic fused kernels): the slot address comes in an SGPR that an
+# `s_movk_i32 / s_mov_b32 sK, imm` a few lines up sets.  Such stores are examined like the others (slot = imm + offset) but never MOVED by
+# fix() (the pair would have to move together): moving the EXEC restore up to the join label (fix_stranded) is the repair for them.
+SPILL_S = re.compile(r'^\s*scratch_store_dword\w*\s+off, (v\[?[\d:]+\]?), (s\d+)(?: offset:(\d+))?\s*; .*Folded Spill')
+RELOAD_S = re.compile(r'^\s*scratch_load_dword\w*\s+(v\[?[\d:]+\]?), off, (s\d+)(?: offset:(\d+))?\s*; .*Folded Reload')
+
+
+def sgpr_slot(lines, i, sreg, offset):
+    """slot address of an SGPR-addressed spill access at lines[i] (0-based): the immediate last moved into sreg, within 48 lines and
+    the same basic block; None when it cannot be read"""
+    for j in range(i - 1, max(-1, i - 49), -1):
+        line = lines[j]
+        if LABEL.match(line) or BRANCH.match(line):
+            return None
+        m = re.match(r'^\s*s_mov(?:k_i32|_b32)\s+%s,\s*(0x[0-9a-fA-F]+|\d+)\b' % sreg, line)
+        if m:
+            return int(m.group(1), 0) + int(offset or 0)
+        if re.match(r'^\s*[sv]_\w+\s+%s\b' % sreg, line):
+            return None                              # written by something else
+    return None
 
 
 def regs_of(tok):
@@ -73,7 +93,7 @@ def scan(path):
     def close():
         for f, off, ln, lr in cand:
             if off in reloaded:
-                reg = SPILL.match(lines[ln - 1]).group(1)
+                reg = (SPILL.match(lines[ln - 1]) or SPILL_S.match(lines[ln - 1])).group(1)
                 if not defined_in_region(lines, ln, lr, reg):
                     flagged.append((f, off, ln, lr))
 
@@ -100,9 +120,21 @@ def scan(path):
             if m:
                 pending.append((int(m.group(2) or 0), ln))
                 continue
+            m = SPILL_S.match(line)
+            if m:
+                slot = sgpr_slot(lines, ln - 1, m.group(2), m.group(3))
+                if slot is not None:
+                    pending.append((slot, ln))
+                continue
             m = RELOAD.match(line)
             if m:
                 reloaded.add(int(m.group(2) or 0))
+                continue
+            m = RELOAD_S.match(line)
+            if m:
+                slot = sgpr_slot(lines, ln - 1, m.group(2), m.group(3))
+                if slot is not None:
+                    reloaded.add(slot)
     close()
     return flagged
 
@@ -115,6 +147,9 @@ def fix(path):
     lines = open(path).read().split('\n')
     moves, refused = {}, 0
     for func, off, ln, lr in flagged:
+        if not SPILL.match(lines[ln - 1]):          # SGPR-addressed: not moved (see SPILL_S)
+            refused += 1
+            continue
         reg = regs_of(SPILL.match(lines[ln - 1]).group(1))
         clobbered = any(DEST.match(lines[i]) and regs_of(DEST.match(lines[i]).group(1)) & reg for i in range(ln, lr))
         # the vmcnt bookkeeping of the surrounding code stays valid only if the store does not pass another vector memory
@@ -145,8 +180,8 @@ def fix(path):
 # narrowed otherwise, so the copies reach no lane (or not all of them) and the code behind the join reads stale registers.  Seen in
 # locp_kernel<*, 0, 0> after an unrelated change of the Cholesky tile code: a QP that "converged" to a 0.1 % worse minimiser.
 # Looked for: at a label that some s_cbranch_execz of the function targets, vector / memory instructions before the block's first EXEC
-# write when that write is `s_or_b64 exec, exec, s[a:b]`.  --fix moves the restore up to the label (nothing in between may be a scalar
-# instruction other than s_waitcnt / s_nop, touch EXEC or write s[a:b]: refused otherwise, and the build fails).
+# write when that write is `s_or_b64 exec, exec, s[a:b]`.  --fix moves the restore up to the label (nothing in between may read SCC, name EXEC
+# or write s[a:b]: refused otherwise, and the build fails).
 EXECZ = re.compile(r'^\s*s_cbranch_execz\s+(\.LBB\w+)')
 ANY_INSTR = re.compile(r'^\s+([a-z][a-z0-9_]+)\b(.*)$')
 ANY_EXEC_WRITE = re.compile(r'^\s*(s_\w*saveexec\w*|s_\w+\s+exec\b|v_cmpx\w*)')
@@ -181,8 +216,13 @@ def stranded(lines):
                         why = None
                         for b in body:
                             t = lines[b]
-                            if re.match(r'^\s*s_', t) and not HARMLESS_SCALAR.match(t):
-                                why = 'a scalar instruction stands between the label and the restore'
+                            if re.match(r'^\s*s_(cselect|addc|subb|cmov|cbranch_scc)', t):
+                                why = 'an instruction between the label and the restore reads SCC, which the restore writes'
+                            ds = re.match(r'^\s*s_\w+\s+s(?:\[(\d+):(\d+)\]|(\d+))', t)
+                            if ds:
+                                a, b_ = (int(ds.group(1)), int(ds.group(2))) if ds.group(1) else (int(ds.group(3)), int(ds.group(3)))
+                                if a <= hi and b_ >= lo:
+                                    why = 'the saved mask is written between the label and the restore'
                             if re.search(r'\bexec\b', t.split(';')[0]):
                                 why = 'an instruction between the label and the restore names EXEC'
                             d = re.match(r'^\s*v_read(?:first)?lane_b32\s+s(\d+)', t)
@@ -245,7 +285,12 @@ def audit(path):
       * EXEC must be manipulated as a 64-bit register (wave64): an `s_*_b32 exec_lo` restore is not looked for at all."""
     text = open(path).read().split('\n')
     any_store = [i for i, l in enumerate(text, 1) if ANY_SPILL_STORE.match(l)]
-    unknown = [i for i in any_store if not SPILL.match(text[i - 1])]
+    def known(i):
+        if SPILL.match(text[i - 1]):
+            return True
+        m = SPILL_S.match(text[i - 1])
+        return bool(m) and sgpr_slot(text, i - 1, m.group(2), m.group(3)) is not None
+    unknown = [i for i in any_store if not known(i)]
     marks = sum(1 for l in text if ANY_SPILL_MARK.search(l))
     meta = sum(int(m.group(1)) for m in (META_SPILLS.match(l) for l in text) if m)
     out = []
