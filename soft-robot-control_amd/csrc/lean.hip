@@ -106,9 +106,17 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
             handed_over = true;
             break;
         }
+        // The tests of an SCP iteration (trust region, nearest points, model accuracy, state rows, convergence) and the copy of an
+        // accepted step all walk the new and the old trajectory: both go into the K-tile area of the LDS once (dead between two QPs;
+        // 2 (N + 1) n_x + 2 N n_u doubles fit wherever the lean layout does: scp_host.h) instead of being fetched from L2 by every one
+        // of them, stage by stage, in loops whose loads depend on nothing but were issued one product at a time.
+        lptr Xn = L.B, Xo = Xn + (size_t)(N + 1) * n, Un = Xo + (size_t)(N + 1) * n, Uo = Un + (size_t)N * m;
+        for (int e = tid; e < (N + 1) * n; e += nt) { Xn[e] = w.x[e]; Xo[e] = xk[e]; }
+        for (int e = tid; e < N * m; e += nt) { Un[e] = w.u[e]; Uo[e] = uk[e]; }
+        __syncthreads();
         // trust region test (gusto.py:174-183)
         double md = 0.0;
-        for (int e = tid; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (w.x[e] - xk[e])));
+        for (int e = tid; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (Xn[e] - Xo[e])));
         md = wg::reduce(md, 1, L.red);
         const bool tr_ok = !(md - delta > par.epsilon);
         bool new_solution = false;
@@ -117,19 +125,15 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         if (tr_ok) {
             // model accuracy (gusto.py:203-223) with continuous nearest-point dynamics
             GU_LAP(3);
-            tpwl::nearest_many(T, w.x, n, N, idx2);
+            tpwl::nearest_many(T, (clptr)Xn, n, N, idx2);
             GU_LAP(4);
-            // One wave per stage, lane = row of the three products.  The stage vectors (old / new state and input) go through the wave's
-            // slot of the K-tile area (dead between two QPs) instead of being fetched from L2 by every lane and every column; the matrix
-            // columns are requested sixteen at a time; when the new point lies in the region of the old one -- most stages -- its matrices
+            // One wave per stage, lane = row of the three products.  The stage vectors (old / new state and input) come from the staged
+            // copies in LDS instead of being fetched from L2 by every lane and every column; the matrix columns are requested sixteen at a time; when the new point lies in the region of the old one -- most stages -- its matrices
             // are the ones already loaded.  Same products in the same order (round 5: 207 k -> clocks per SCP iteration at C2 in
             // profiles/r05_lean_phase_clocks.json; every stage paid eight dependent L2 round trips).
             for (int i = wave; i < N; i += nw) {
                 const size_t ia = (size_t)__builtin_amdgcn_readfirstlane(idx[i]), ib = (size_t)__builtin_amdgcn_readfirstlane(idx2[i]);
-                lptr sv = L.B + (size_t)wave * (2 * (n + m));
-                for (int e = lane; e < n; e += 64) { sv[e] = xk[(size_t)i * n + e]; sv[n + e] = w.x[(size_t)i * n + e]; }
-                if (lane < m) { sv[2 * n + lane] = uk[(size_t)i * m + lane]; sv[2 * n + m + lane] = w.u[(size_t)i * m + lane]; }
-                ql::wave_fence();
+                clptr xo_ = Xo + (size_t)i * n, xn_ = Xn + (size_t)i * n, uo_ = Uo + (size_t)i * m, un_ = Un + (size_t)i * m;
                 double e2 = 0.0, a2 = 0.0;
                 auto rows = [&](auto SAME) {
                     constexpr bool same = decltype(SAME)::value;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
 #pragma unroll
                             for (int qq = 0; qq < 16; ++qq) {
                                 if (c0 + qq < n) {
-                                    const double xo = sv[c0 + qq], xn = sv[n + c0 + qq];
+                                    const double xo = xo_[c0 + qq], xn = xn_[c0 + qq];
                                     fk = fma(av[qq], xo, fk);
                                     fl = fma(av[qq], xn - xo, fl);
                                     f = fma(same ? av[qq] : anv[qq], xn, f);
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
 #pragma unroll
                             for (int qq = 0; qq < 8; ++qq) {
                                 if (c0 + qq < m) {
-                                    const double uo = sv[2 * n + c0 + qq], un = sv[2 * n + m + c0 + qq];
+                                    const double uo = uo_[c0 + qq], un = un_[c0 + qq];
                                     fk = fma(bv[qq], uo, fk);
                                     fl = fma(bv[qq], un - uo, fl);
                                     f = fma(same ? bv[qq] : bnv[qq], un, f);
@@ -184,7 +188,6 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                 e2 = wg::wave_sum(e2);
                 a2 = wg::wave_sum(a2);
                 if (lane == 0) { accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2); }
-                ql::wave_fence();                                        // the slot is rewritten for the wave's next stage
             }
             __syncthreads();
             GU_LAP(5);
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                     for (int e = tid; e < (N + 1) * d.nX; e += nt) {
                         const int k = e / d.nX, r = e - k * d.nX;
                         double v = -c.Xb[r];
-                        for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], w.x[(size_t)k * n + j], v);
+                        for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], Xn[(size_t)k * n + j], v);
                         vr[e] = fmax(v, 0.0);
                     }
                     __syncthreads();
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                         double v2 = 0.0;
                         for (int r = 0; r < d.nX; ++r) {
                             double v = -c.Xb[r];
-                            for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], w.x[(size_t)k * n + j], v);
+                            for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], Xn[(size_t)k * n + j], v);
                             v = fmax(v, 0.0);
                             v2 = fma(v, v, v2);
                         }
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                 for (int k = wave; k <= N; k += nw) {
                     double v2 = 0.0;
                     for (int j = lane; j < n; j += 64) {
-                        const double e = c.xs[j] * (w.x[(size_t)k * n + j] - xk[(size_t)k * n + j]);
+                        const double e = c.xs[j] * (Xn[(size_t)k * n + j] - Xo[(size_t)k * n + j]);
                         v2 = fma(e, e, v2);
                     }
                     v2 = wg::wave_sum(v2);
@@ -258,8 +261,8 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         GU_LAP(6);
         if (new_solution) {
             __syncthreads();
-            for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = w.x[e];
-            for (int e = tid; e < N * m; e += nt) uk[e] = w.u[e];
+            for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = Xn[e];
+            for (int e = tid; e < N * m; e += nt) uk[e] = Un[e];
             __syncthreads();
             // the nearest points of the accepted trajectory are the ones the model-accuracy test found for it above (idx2 of
             // w.x, same function, same data: gusto.py:466 recomputes them)

@@ -73,17 +73,18 @@ __device__ inline int nearest_wave(const TpwlDev &T, XP x) {
 template <typename XP, typename IP>
 __device__ inline void nearest_many(const TpwlDev &T, XP X, int ldx, int count, IP idx) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
-    if (T.w_v == 0.0 && T.P <= 64 && T.r <= 32) {
+    if (T.w_v == 0.0 && T.P <= 64 && T.r <= 32 && count >= 2 * nw) {            // (fewer states than two rounds: the table load does not pay)
         const int r = T.r;
         const bool live = lane < T.P;
+        const int pl = live ? lane : T.P - 1, xl = lane < r ? lane : r - 1;
         double tq[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) tq[j] = (j < r && live) ? T.qT[j * T.P + lane] : 0.0;
+        for (int j = 0; j < 32; ++j) tq[j] = T.qT[(j < r ? j : r - 1) * T.P + pl];     // unconditional (clamped) loads: all in flight at once
         int k = wave;
-        double xv = (k < count && lane < r) ? (double)X[(size_t)k * ldx + r + lane] : 0.0;
+        double xv = (double)X[(size_t)(k < count ? k : count - 1) * ldx + r + xl];
         while (k < count) {
             const int kn = k + nw;
-            const double xn = (kn < count && lane < r) ? (double)X[(size_t)kn * ldx + r + lane] : 0.0;      // the next state, while this one is worked on
+            const double xn = (double)X[(size_t)(kn < count ? kn : count - 1) * ldx + r + xl];             // the next state, while this one is worked on
             double sq = 0.0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
