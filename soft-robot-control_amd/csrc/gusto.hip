@@ -101,55 +101,61 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
             GU_LAP(3);
             tpwl::nearest_many(T, w.x, n, N, idx2);
             GU_LAP(4);
+            // (sixteen columns in flight; when the new point lies in the region of the old one its matrices are the ones already loaded:
+            // same products in the same order -- the lean kernel's form, lean.hip, without its LDS copies of the trajectories)
             for (int i = wave; i < N; i += nw) {
-                const size_t ia = idx[i], ib = idx2[i];
+                const size_t ia = (size_t)__builtin_amdgcn_readfirstlane(idx[i]), ib = (size_t)__builtin_amdgcn_readfirstlane(idx2[i]);
                 double e2 = 0.0, a2 = 0.0;
-                for (int r = lane; r < n; r += 64) {
-                    double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
-                    // columns in order, eight at a time: the 32 loads of a batch are in flight before its FMAs (the
-                    // rolled form paid the L2 latency per column: ~0.15 ms of an SCP iteration); same sums, same order
-                    cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
-                    for (int c0 = 0; c0 < n; c0 += 8) {
-                        double av[8], anv[8], xo[8], xn[8];
+                auto rows = [&](auto SAME) {
+                    constexpr bool same = decltype(SAME)::value;
+                    for (int r = lane; r < n; r += 64) {
+                        double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
+                        cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
+                        for (int c0 = 0; c0 < n; c0 += 16) {
+                            double av[16], anv[16], xo[16], xn[16];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int cc = c0 + q < n ? c0 + q : n - 1;
-                            av[q] = Ak[(size_t)cc * n + r]; anv[q] = An[(size_t)cc * n + r];
-                            xo[q] = xk[(size_t)i * n + cc]; xn[q] = w.x[(size_t)i * n + cc];
-                        }
+                            for (int q = 0; q < 16; ++q) {
+                                const int cc = c0 + q < n ? c0 + q : n - 1;
+                                av[q] = Ak[(size_t)cc * n + r];
+                                if constexpr (!same) anv[q] = An[(size_t)cc * n + r];
+                                xo[q] = xk[(size_t)i * n + cc]; xn[q] = w.x[(size_t)i * n + cc];
+                            }
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            if (c0 + q < n) {
-                                fk = fma(av[q], xo[q], fk);
-                                fl = fma(av[q], xn[q] - xo[q], fl);
-                                f = fma(anv[q], xn[q], f);
+                            for (int q = 0; q < 16; ++q) {
+                                if (c0 + q < n) {
+                                    fk = fma(av[q], xo[q], fk);
+                                    fl = fma(av[q], xn[q] - xo[q], fl);
+                                    f = fma(same ? av[q] : anv[q], xn[q], f);
+                                }
                             }
                         }
-                    }
-                    cgptr Bk = T.BcT + ia * m * n, Bn = T.BcT + ib * m * n;
-                    for (int c0 = 0; c0 < m; c0 += 8) {
-                        double bv[8], bnv[8], uo[8], un[8];
+                        cgptr Bk = T.BcT + ia * m * n, Bn = T.BcT + ib * m * n;
+                        for (int c0 = 0; c0 < m; c0 += 8) {
+                            double bv[8], bnv[8], uo[8], un[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int cc = c0 + q < m ? c0 + q : m - 1;
-                            bv[q] = Bk[(size_t)cc * n + r]; bnv[q] = Bn[(size_t)cc * n + r];
-                            uo[q] = uk[(size_t)i * m + cc]; un[q] = w.u[(size_t)i * m + cc];
-                        }
+                            for (int q = 0; q < 8; ++q) {
+                                const int cc = c0 + q < m ? c0 + q : m - 1;
+                                bv[q] = Bk[(size_t)cc * n + r];
+                                if constexpr (!same) bnv[q] = Bn[(size_t)cc * n + r];
+                                uo[q] = uk[(size_t)i * m + cc]; un[q] = w.u[(size_t)i * m + cc];
+                            }
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            if (c0 + q < m) {
-                                fk = fma(bv[q], uo[q], fk);
-                                fl = fma(bv[q], un[q] - uo[q], fl);
-                                f = fma(bnv[q], un[q], f);
+                            for (int q = 0; q < 8; ++q) {
+                                if (c0 + q < m) {
+                                    fk = fma(bv[q], uo[q], fk);
+                                    fl = fma(bv[q], un[q] - uo[q], fl);
+                                    f = fma(same ? bv[q] : bnv[q], un[q], f);
+                                }
                             }
                         }
+                        const double fa = fk + fl;
+                        const double fsr = b.fs[r];
+                        const double de = fsr * (f - fa), da = fsr * fa;
+                        e2 = fma(de, de, e2);
+                        a2 = fma(da, da, a2);
                     }
-                    const double fa = fk + fl;
-                    const double fsr = b.fs[r];
-                    const double de = fsr * (f - fa), da = fsr * fa;
-                    e2 = fma(de, de, e2);
-                    a2 = fma(da, da, a2);
-                }
+                };
+                if (ia == ib) rows(std::true_type{}); else rows(std::false_type{});
                 e2 = wg::wave_sum(e2);
                 a2 = wg::wave_sum(a2);
                 if (lane == 0) { accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2); }
