@@ -180,8 +180,9 @@ def fix(path):
 # narrowed otherwise, so the copies reach no lane (or not all of them) and the code behind the join reads stale registers.  Seen in
 # locp_kernel<*, 0, 0> after an unrelated change of the Cholesky tile code: a QP that "converged" to a 0.1 % worse minimiser.
 # Looked for: at a label that some s_cbranch_execz of the function targets, vector / memory instructions before the block's first EXEC
-# write when that write is `s_or_b64 exec, exec, s[a:b]`.  --fix moves the restore up to the label (nothing in between may read SCC, name EXEC
-# or write s[a:b]: refused otherwise, and the build fails).
+# write when that write is `s_or_b64 exec, exec, s[a:b]`.  --fix moves the restore up to the label when everything stranded is a register
+# copy or a spill access (what a join block can only mean for every lane) and nothing in between reads SCC, names EXEC or writes
+# s[a:b]; anything else is refused and the build fails: a person has to look.
 EXECZ = re.compile(r'^\s*s_cbranch_execz\s+(\.LBB\w+)')
 ANY_INSTR = re.compile(r'^\s+([a-z][a-z0-9_]+)\b(.*)$')
 ANY_EXEC_WRITE = re.compile(r'^\s*(s_\w*saveexec\w*|s_\w+\s+exec\b|v_cmpx\w*)')
@@ -214,6 +215,10 @@ def stranded(lines):
                         sx = mp.group(1)
                         lo, hi = (int(v) for v in re.match(r's\[(\d+):(\d+)\]', sx).groups())
                         why = None
+                        for b in real:                  # only what can only have been meant for every lane is moved under the full mask
+                            t = lines[b]
+                            if not (re.match(r'^\s*v_mov_b(32|64)_e32\s+v', t) or re.match(r'^\s*v_accvgpr_(read|write)_b32\b', t) or SPILL.match(t) or SPILL_S.match(t) or RELOAD.match(t) or RELOAD_S.match(t)):
+                                why = 'not a register copy or a spill access: ' + t.strip()[:60]
                         for b in body:
                             t = lines[b]
                             if re.match(r'^\s*s_(cselect|addc|subb|cmov|cbranch_scc)', t):
