@@ -111,8 +111,12 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
         // 2 (N + 1) n_x + 2 N n_u doubles fit wherever the lean layout does: scp_host.h) instead of being fetched from L2 by every one
         // of them, stage by stage, in loops whose loads depend on nothing but were issued one product at a time.
         lptr Xn = L.B, Xo = Xn + (size_t)(N + 1) * n, Un = Xo + (size_t)(N + 1) * n, Uo = Un + (size_t)N * m;
-        for (int e = tid; e < (N + 1) * n; e += nt) { Xn[e] = w.x[e]; Xo[e] = xk[e]; }
+        // (the new trajectory is there already: the QP's final rollout wrote it, ql::solve_qp)
+        for (int e = tid; e < (N + 1) * n; e += nt) Xo[e] = xk[e];
         for (int e = tid; e < N * m; e += nt) { Un[e] = w.u[e]; Uo[e] = uk[e]; }
+        lptr XAl = Uo + (size_t)N * m;                          // the state rows' matrix behind them (scp_host.h checks the room)
+        const bool xal = d.nX > 0;
+        if (xal) for (int e = tid; e < d.nX * n; e += nt) XAl[e] = c.XA[e];
         __syncthreads();
         // trust region test (gusto.py:174-183)
         double md = 0.0;
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                 d_prev = delta; J_prev = J; o_prev = omega;
                 // state-constraint violation (gusto.py:185-201): all k = 0..N
                 double viol = 0.0;
-                if (NST <= 0 && d.nX > 0 && d.nX <= nz) {        // (the fixed Diamond layouts keep the form below: measured, see ql::solve_qp)
+                if (d.nX > 0 && d.nX <= nz) {
                     // one thread per (stage, row) for the n_x products of a row (one thread per stage walked n_X n_x = 240 of them),
                     // then one thread per stage for the norm: the same sums in the same order
                     gptr vr = w.ez;                      // (N + 1) n_z doubles of the QP's work block, free here
@@ -209,7 +213,8 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                     for (int e = tid; e < (N + 1) * d.nX; e += nt) {
                         const int k = e / d.nX, r = e - k * d.nX;
                         double v = -c.Xb[r];
-                        for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], Xn[(size_t)k * n + j], v);
+                        if (xal) { for (int j = 0; j < n; ++j) v = fma(XAl[r * n + j], Xn[(size_t)k * n + j], v); }
+                        else { for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], Xn[(size_t)k * n + j], v); }
                         vr[e] = fmax(v, 0.0);
                     }
                     __syncthreads();

@@ -158,8 +158,11 @@ __device__ __forceinline__ Waves<true> half_waves(liptr ctr0) {
 // 2 s + h + 16 q of row 2 r + il (bank = (row + column) mod 16: conflict free), three DPP additions finish the row.
 // The stage vector [x_k ; u_k ; 0] is double buffered in v1 / v2.  (qp::rollout: two L2-fed products and four barriers
 // per stage, 7.6 k clocks per stage against ~0.8 k.)
-template <int MSEL, int NSEL>
-__device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr x0, cgptr u, gptr x, Lds &L) {
+// XS: the trajectory is ALSO written to xs (LDS: the start of the Theta^T area, free during a rollout) for the tests that follow it --
+// objective, trust region, and the SCP loop's tests in the GuSTO kernel.  (A flag, not a null test: the area starts at LDS offset 0,
+// which is what a null pointer of address space 3 compares equal to.)
+template <int MSEL, int NSEL, bool XS = false>
+__device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr x0, cgptr u, gptr x, Lds &L, lptr xs = nullptr) {
     const int N = d.N, n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, nk = d.NK;
     const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l = lane & 15, il = l >> 3, sl = l & 7;
@@ -171,7 +174,7 @@ __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr
     for (int e = tid; e < vlen; e += nt) {
         const double v = e < n ? x0[e] : (e < n + m && u ? u[e - n] : 0.0);
         va[e] = v; vb[e] = 0.0;
-        if (e < n) x[e] = v;
+        if (e < n) { x[e] = v; if constexpr (XS) xs[e] = v; }
     }
     __syncthreads();
     QPLds P{};
@@ -191,7 +194,7 @@ __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr
                 acc = fma(row[16 * q + 1], va[2 * sl + 16 * q + 1], acc);
             }
             acc = wg::group_sum<8>(acc) + dk;
-            if (sl == 0 && i < n) { vb[i] = acc; x[(size_t)(k + 1) * n + i] = acc; }
+            if (sl == 0 && i < n) { vb[i] = acc; x[(size_t)(k + 1) * n + i] = acc; if constexpr (XS) xs[(size_t)(k + 1) * n + i] = acc; }
         }
         if (tid < m) vb[n + tid] = un;
         __syncthreads();
@@ -1998,12 +2001,18 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
 // Objective of the minimiser (qp::objective, locp.py:218-263): e = H x - z by one thread per (stage, output) -- 60 products each --
 // instead of one thread walking the n_z n_x = 360 products of its stage (28 k clocks per QP whatever the horizon:
 // profiles/r05_lean_phase_clocks.json), then one thread per stage for the small quadratic forms: the same sums in the same order.
-__device__ __forceinline__ double objective_par(const QPDims &d, const QPConst &c, const QPData &q, cgptr x, cgptr u, cgptr s, gptr ez, QPLds &L) {
+// Round 5: x may be the LDS copy the rollout left (XP = clptr), and the output matrix goes through LDS as well (hs: n_z n_x doubles
+// behind that copy): a thread's 60 products then read LDS only -- from global memory they were 60 loads issued one product at a time.
+template <typename XP>
+__device__ __forceinline__ double objective_par(const QPDims &d, const QPConst &c, const QPData &q, XP x, cgptr u, cgptr s, gptr ez, QPLds &L, bool hl = false, lptr hs = nullptr) {
     const int n = d.n, nz = d.nz, m = d.m, N = d.N;
+    // hl: n_z n_x doubles of LDS at hs for the output matrix
+    if (hl) { for (int e = threadIdx.x; e < nz * n; e += blockDim.x) hs[e] = c.H[e]; __syncthreads(); }
     for (int e = threadIdx.x; e < (N + 1) * nz; e += blockDim.x) {
         const int k = e / nz, a = e - k * nz;
         double v = q.z ? -q.z[e] : 0.0;
-        for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], x[(size_t)k * n + j], v);
+        if (hl) { for (int j = 0; j < n; ++j) v = fma(hs[a * n + j], x[(size_t)k * n + j], v); }
+        else { for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], x[(size_t)k * n + j], v); }
         ez[e] = v;
     }
     __syncthreads();
@@ -2059,20 +2068,27 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
     for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
     __syncthreads();
-    rollout<MSEL, NSEL>(d0, dyn, q.x0, (cgptr)w.u, w.x, L);
+    lptr xs = L.B;                                        // (N + 1) n_x doubles at the start of the Theta^T area: free from here on
+    rollout<MSEL, NSEL, true>(d0, dyn, q.x0, (cgptr)w.u, w.x, L, xs);
     __syncthreads();
 #ifdef SRH_PROFILE
     { const long long now_ = clock64(); prof[22] += now_ - tail_last; tail_last = now_; }
 #endif
-    // (measured per layout on the full batch: the Diamond fixed layouts keep the one-thread-per-stage form -- 54.5 against 55.0 ms per
-    // 4096 rollouts, the extra pass through L2 costs more than the chain under load --, the Trunk layout gains 1.8 %, short horizons 5 %)
+    // (with x and H read from global memory the Diamond fixed layouts were better off with the one-thread-per-stage form -- 54.5 against
+    // 55.0 ms per 4096 rollouts --; with the rollout's LDS copy of the trajectory every layout takes the form below)
     double J;
-    if constexpr (NST <= 0 || MSEL == 8) J = objective_par(d0, c, q, w.x, w.u, w.s, w.ez, Lq);
+#ifdef SRH_LEAN_OBJECTIVE_SERIAL
+    if constexpr (NST <= 0 || MSEL == 8) J = objective_par(d0, c, q, (cgptr)w.x, w.u, w.s, w.ez, Lq);
     else J = qp::objective(d0, c, q, w.x, w.u, w.s, Lq);
+#else
+    // (the output matrix behind the trajectory copy when the Theta^T area has the room: always at the shipped shapes)
+    const bool hfit = (size_t)(N + 1 + d0.nz) * n <= (size_t)d0.NK * (16 * (size_t)d0.KT + 1);
+    J = objective_par(d0, c, q, (clptr)xs, w.u, w.s, w.ez, Lq, hfit, xs + (size_t)(N + 1) * n);
+#endif
     bool inside = true;
     if (dfull.tr) {
         double md = 0.0;
-        for (int e = tid + n; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (w.x[e] - q.xk[e])));
+        for (int e = tid + n; e < (N + 1) * n; e += nt) md = fmax(md, fabs(c.xs[e % n] * (xs[e] - q.xk[e])));
         md = wg::reduce(md, 1, L.red);
         inside = md <= q.delta;
         J += q.omega * s0;

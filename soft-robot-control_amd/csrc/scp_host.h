@@ -372,7 +372,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
                 if (ql::lds_doubles(d, NTHREADS, t) * sizeof(double) <= (size_t)160 * 1024) { j0 = t; break; }
             std::vector<int> sched;
             // (the SCP loop of the lean GuSTO kernel stages both trajectories in the K-tile area between two QPs: csrc/lean.hip)
-            const bool stage_fits = j0 >= 0 && ql::sizes(d, NTHREADS, j0).regX >= (size_t)2 * (N + 1) * n + (size_t)2 * N * m;
+            const bool stage_fits = j0 >= 0 && ql::sizes(d, NTHREADS, j0).regX >= (size_t)2 * (N + 1) * n + (size_t)2 * N * m + (size_t)pr->nX * n;
             if (j0 >= 0 && j0 < N && stage_fits && ql::condense_fits(d, NTHREADS / 64) && lean_gram_schedule(N, m, d.KT, NTHREADS / 64, sched)) {
                 d.lean = 1;
                 d.lean_j0 = j0;
