@@ -2006,37 +2006,47 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
 template <typename XP>
 __device__ __forceinline__ double objective_par(const QPDims &d, const QPConst &c, const QPData &q, XP x, cgptr u, cgptr s, gptr ez, QPLds &L, bool hl = false, lptr hs = nullptr) {
     const int n = d.n, nz = d.nz, m = d.m, N = d.N;
-    // hl: n_z n_x doubles of LDS at hs for the output matrix
-    if (hl) { for (int e = threadIdx.x; e < nz * n; e += blockDim.x) hs[e] = c.H[e]; __syncthreads(); }
+    // hl: objective_lds_doubles(d) doubles of LDS at hs: the output matrix, the weights Qz / Qzf / R and the output errors -- the second
+    // phase's n_z^2 + n_u^2 products then read LDS as well (from global memory: one dependent load per product on a handful of threads)
+    lptr Hl = hs, Qzl = Hl + (size_t)nz * n, Qfl = Qzl + nz * nz, Rl = Qfl + nz * nz, ezl = Rl + m * m;
+    if (hl) {
+        for (int e = threadIdx.x; e < nz * n; e += blockDim.x) Hl[e] = c.H[e];
+        for (int e = threadIdx.x; e < nz * nz; e += blockDim.x) { Qzl[e] = c.Qz[e]; Qfl[e] = c.Qzf ? c.Qzf[e] : 0.0; }
+        for (int e = threadIdx.x; e < m * m; e += blockDim.x) Rl[e] = c.R[e];
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < (N + 1) * nz; e += blockDim.x) {
         const int k = e / nz, a = e - k * nz;
         double v = q.z ? -q.z[e] : 0.0;
-        if (hl) { for (int j = 0; j < n; ++j) v = fma(hs[a * n + j], x[(size_t)k * n + j], v); }
+        if (hl) { for (int j = 0; j < n; ++j) v = fma(Hl[a * n + j], x[(size_t)k * n + j], v); }
         else { for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], x[(size_t)k * n + j], v); }
         ez[e] = v;
+        if (hl) ezl[e] = v;
     }
     __syncthreads();
     double acc = 0.0;
     for (int k = threadIdx.x; k <= N; k += blockDim.x) {
         double e[16];
-        for (int a = 0; a < nz; ++a) e[a] = ez[(size_t)k * nz + a];
+        if (hl) { for (int a = 0; a < nz; ++a) e[a] = ezl[(size_t)k * nz + a]; }
+        else { for (int a = 0; a < nz; ++a) e[a] = ez[(size_t)k * nz + a]; }
         for (int a = 0; a < nz; ++a)
-            for (int b = 0; b < nz; ++b) acc = fma(e[a] * c.Qz[a * nz + b], e[b], acc);
+            for (int b = 0; b < nz; ++b) acc = fma(e[a] * (hl ? (double)Qzl[a * nz + b] : (double)c.Qz[a * nz + b]), e[b], acc);
         if (k == N && c.Qzf) {
             for (int a = 0; a < nz; ++a) e[a] += (q.z ? q.z[(size_t)k * nz + a] : 0.0) - (q.zf ? q.zf[a] : 0.0);
             for (int a = 0; a < nz; ++a)
-                for (int b = 0; b < nz; ++b) acc = fma(e[a] * c.Qzf[a * nz + b], e[b], acc);
+                for (int b = 0; b < nz; ++b) acc = fma(e[a] * (hl ? (double)Qfl[a * nz + b] : (double)c.Qzf[a * nz + b]), e[b], acc);
         }
         if (k < N) {
             double ue[16];
             for (int a = 0; a < m; ++a) ue[a] = u[(size_t)k * m + a] - (q.ud ? q.ud[(size_t)k * m + a] : 0.0);
             for (int a = 0; a < m; ++a)
-                for (int b = 0; b < m; ++b) acc = fma(ue[a] * c.R[a * m + b], ue[b], acc);
+                for (int b = 0; b < m; ++b) acc = fma(ue[a] * (hl ? (double)Rl[a * m + b] : (double)c.R[a * m + b]), ue[b], acc);
         }
         if (d.tr) acc += q.omega * s[k];
     }
     return wg::reduce(acc, 0, L.red);
 }
+__host__ __device__ inline size_t objective_lds_doubles(const QPDims &d) { return (size_t)d.nz * d.n + 2 * (size_t)d.nz * d.nz + (size_t)d.m * d.m + (size_t)(d.N + 1) * d.nz; }
 
 // The QP as the SCP loop needs it: condensed interior point, states by a rollout of the minimiser, objective, trust-region
 // test.  Returns 0 when the result IS the minimiser of the full QP (converged, inside the trust region); anything else
@@ -2082,7 +2092,7 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     else J = qp::objective(d0, c, q, w.x, w.u, w.s, Lq);
 #else
     // (the output matrix behind the trajectory copy when the Theta^T area has the room: always at the shipped shapes)
-    const bool hfit = (size_t)(N + 1 + d0.nz) * n <= (size_t)d0.NK * (16 * (size_t)d0.KT + 1);
+    const bool hfit = (size_t)(N + 1) * n + objective_lds_doubles(d0) <= (size_t)d0.NK * (16 * (size_t)d0.KT + 1);
     J = objective_par(d0, c, q, (clptr)xs, w.u, w.s, w.ez, Lq, hfit, xs + (size_t)(N + 1) * n);
 #endif
     bool inside = true;
