@@ -275,6 +275,40 @@ def test_forced_hand_over_gives_the_same_solve(N, batch, zero_copy, monkeypatch)
     assert rel(f[2], a[2]) <= 1e-6 and rel(f[3], a[3]) <= 1e-6, (rel(f[2], a[2]), rel(f[3], a[3]))
 
 
+@pytest.mark.parametrize('delta0', [1.0, 4.0])
+def test_binding_trust_region_qps_follow_the_oracle(delta0, monkeypatch):
+    """QPs whose trust region BINDS, chosen rather than waited for: with delta0 = 1 or 4 (instead of the reference's 1e4, gusto.py:142-147)
+    the minimiser of the QP without its trust-region rows leaves the region, the lean kernel hands the rollout to the fused kernel and
+    the full QP (trust-region rows active: the stage-wise Riccati interior point) is solved from there on.  delta0 = 1: the step stays
+    outside the region by more than epsilon in every iteration (omega x 5 each time: gusto.py:383-402); delta0 = 4: binding QPs whose
+    steps are accepted, delta halved on the way.  The numpy statement takes the same route (condensed attempt, then oracle.riccati_ipm)
+    -- its calls are counted: at least five binding QPs -- and the GPU's (J, delta, omega) trace must follow it to 1e-6, the
+    trajectories to 1e-4."""
+    import workloads as wl
+    from oracle import gusto as ogusto, riccati_ipm as ripm
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2()
+    B, cap = 2, 6
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, B, 2, 1354)
+    g = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+              x_char=xc, f_char=fc, convg_thresh=1e-3, batch=B, max_trace=32, max_gusto_iters=cap, delta0=delta0, first_solve_cap=cap)
+    g.solve_batch(x0, u_init, x_init, z=z)
+    info = g.kernel_info
+    assert info['family'] == 'lean' and 1 <= info['handed_over'] <= B, info     # rollouts left the lean kernel for the full QP
+    assert (g.status == 0).all(), g.status
+    calls = []
+    real = ripm.solve
+    monkeypatch.setattr(ripm, 'solve', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    model = dict(w['tab'], w_q=1.0, w_v=0.0)
+    ref = ogusto.solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], w['N'], w['dt'], w['Qz'], w['R'], x0[0], u_init[0], x_init[0], z=z[0],
+                       U=(w['UA'], w['Ub']), X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, qp_solver='condensed_ipm',
+                       max_gusto_iters=cap, delta0=delta0)
+    assert len(calls) >= 5, len(calls)
+    compare(g, 0, ref, 'binding trust region')
+    assert all(t[1] <= delta0 for t in ref[3])                                  # the trust region never grew back
+
+
 @pytest.mark.parametrize('N', [5, 50])
 def test_keep_solver_state_across_solves_same_results(N):
     """`GuSTO(keep_solver_state=True)` -- the reference's warm_start=True semantics: its persistent cvxpy problem starts every QP, also the
