@@ -6,7 +6,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 R=$ROOT/soft-robot-control_amd/csrc
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -mllvm -disable-machine-licm"      # (the flags of csrc/Makefile for lean.o)
 mkdir -p $ROOT/gpurun_variants /tmp/leanprof/csrc /tmp/include
 rm -f $ROOT/gpurun_variants/libsofacontrol_hip_prof.so          # never leave a stale library behind a failed compile
 cp $ROOT/include/*.h /tmp/include/                              # common.h includes "../../include/sofacontrol_hip.h"

@@ -9,7 +9,7 @@ TAG=${1:?usage: build_lean_dev.sh <tag> [flags]}; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 R=$ROOT/soft-robot-control_amd/csrc
 V='-DSRH_LEAN_VARIANTS(X)=X(4,60,4,50,7,4)X(8,60,1,50,24,0)'
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -mllvm -disable-machine-licm"      # (the flags of csrc/Makefile for lean.o)
 D=/tmp/leandev/$TAG/csrc
 mkdir -p $ROOT/gpurun_variants $D /tmp/leandev/include /tmp/include
 cp $ROOT/include/*.h /tmp/leandev/include/            # common.h includes "../../include/sofacontrol_hip.h"
