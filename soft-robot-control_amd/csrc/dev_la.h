@@ -4,6 +4,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The thread index as the kernels' inlined phases read it: through an asm statement the optimiser cannot look into, so that nothing
+// derived from it (the LDS / global addresses of "my" elements in every phase) is loop invariant in its eyes.  Hoisted out of the
+// interior-point loop those values -- hundreds of them in a kernel that is one inlined body -- were spilled and reloaded at every phase
+// boundary (1040 B of scratch per lane in the C2 kernel, reloads that miss L2 under the 4096-rollout launch); recomputing them is one or
+// two VALU instructions each: 364 B of scratch, C2 45.7 -> 39.5 ms per 4096 rollouts, one rollout 0.92 -> 0.83 ms per SCP iteration
+// (round 5; -DSRH_PLAIN_TID: the plain register read, for A/B).  Same arithmetic, same results.
+#ifndef SRH_PLAIN_TID
+__device__ __forceinline__ unsigned srh_tid_now() { unsigned t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#define SRH_TID srh_tid_now()
+#else
+#define SRH_TID threadIdx.x
+#endif
+
 // Address-space qualified pointers.  Generic pointers make hipcc emit FLAT loads/stores (slow path for
 // LDS, and they tie up both memory counters); typing LDS and global buffers explicitly gives ds_* and
 // global_* instructions even across non-inlined calls.
@@ -21,7 +34,7 @@ using liptr = li_t *;
 
 namespace wg {
 
-__device__ __forceinline__ int tid() { return threadIdx.x; }
+__device__ __forceinline__ int tid() { return SRH_TID; }
 __device__ __forceinline__ int nthr() { return blockDim.x; }
 
 // ---- reductions over the workgroup (scratch: >= 16 doubles of LDS) ---------------------------
@@ -40,7 +53,7 @@ __device__ __forceinline__ double dpp_mov(double v) {
 __device__ __forceinline__ double xor16(double v) {
     const unsigned lo = __double2loint(v), hi = __double2hiint(v);
     const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    const bool odd = (threadIdx.x >> 4) & 1;
+    const bool odd = (SRH_TID >> 4) & 1;
     return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
 }
 template <int G>
@@ -82,9 +95,9 @@ __device__ __forceinline__ double wave_min(double v) { return wave_reduce<2>(v);
 // op: 0 sum, 1 max, 2 min.  Result broadcast to every thread.  Deterministic (fixed tree).
 __device__ inline double reduce(double v, int op, lptr scratch) {
     double w = op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v));
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), nw = (blockDim.x + 63) >> 6;
     __syncthreads();  // scratch may still be read from a previous reduction
-    if ((threadIdx.x & 63) == 0) scratch[wave] = w;
+    if ((SRH_TID & 63) == 0) scratch[wave] = w;
     __syncthreads();
     double r = scratch[0];
     for (int i = 1; i < nw; ++i) r = op == 0 ? r + scratch[i] : (op == 1 ? fmax(r, scratch[i]) : fmin(r, scratch[i]));
@@ -97,7 +110,7 @@ template <typename MP, typename AP>
 __device__ inline void matTvec(lptr y, MP M, int ldm, int rows, int len, clptr v, AP add, lptr part) {
     // threads = (slice, j): slice s handles rows s, s+S, ...
     const int S = max(1, (int)blockDim.x / len);
-    const int j = threadIdx.x % len, s = threadIdx.x / len;
+    const int j = SRH_TID % len, s = SRH_TID / len;
     double acc = 0.0;
     if (s < S) {
 #pragma unroll 4
@@ -105,10 +118,10 @@ __device__ inline void matTvec(lptr y, MP M, int ldm, int rows, int len, clptr v
         part[s * len + j] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < len) {
-        double r = add ? add[threadIdx.x] : 0.0;
-        for (int q = 0; q < S; ++q) r += part[q * len + threadIdx.x];
-        y[threadIdx.x] = r;
+    if (SRH_TID < len) {
+        double r = add ? add[SRH_TID] : 0.0;
+        for (int q = 0; q < S; ++q) r += part[q * len + SRH_TID];
+        y[SRH_TID] = r;
     }
     __syncthreads();
 }
@@ -118,7 +131,7 @@ __device__ inline void matTvec(lptr y, MP M, int ldm, int rows, int len, clptr v
 // round-off in a nearly singular matrix is retried with a growing diagonal shift (inexact Newton step;
 // the interior-point iteration corrects it).
 __device__ inline bool chol_factor(clptr Q, lptr Lbuf, int m, liptr flag, bool allow_shift = false) {
-    if (threadIdx.x == 0) {
+    if (SRH_TID == 0) {
         bool ok = false;
         double dmax = 0.0;
         for (int i = 0; i < m; ++i) dmax = fmax(dmax, fabs(Q[i * m + i]));
@@ -227,7 +240,7 @@ typedef double qp_d4 __attribute__((ext_vector_type(4)));
 // D reg q of lane l is C[row = (l>>4) + 4q][col = l&15].
 __device__ __forceinline__ void mfma_atb(lptr C, int ldc, clptr Lm, clptr Rm, int K, int MT, int NTl, int ld, int vrows,
                                          int srows = 1 << 30) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), lane = SRH_TID & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
     for (int t0 = wave; t0 < ntiles; t0 += 2 * nw) {

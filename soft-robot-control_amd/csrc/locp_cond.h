@@ -127,7 +127,7 @@ __device__ __forceinline__ int tile_index(int I, int J, int KT) { return I * KT 
 // one-load-per-trip loop would pay).
 __device__ __forceinline__ void g_times(const QPDims &d, const QCWork &w, Lds &L, clptr uv, lptr yv) {
     constexpr int CH = 16, CW = 128;
-    const int ldG = qc_ldg(d), m = d.m, po = d.po, nm = d.N * m, tid = threadIdx.x, nt = blockDim.x;
+    const int ldG = qc_ldg(d), m = d.m, po = d.po, nm = d.N * m, tid = SRH_TID, nt = blockDim.x;
     const int G = nt / CW, col = tid % CW, grp = tid / CW;
     const int cc = col < ldG ? col : ldG - 1;
     int rmax = (cc / po + 1) * m;                          // rows (j,b) with j <= col / po reach this column
@@ -156,7 +156,7 @@ __device__ __forceinline__ void g_times(const QPDims &d, const QCWork &w, Lds &L
 
 // out1[row] = sum_i GT[row][i] y1[i]  (and out2 with y2 when y2 != null): 8 lanes per row, 16 independent loads each
 __device__ __forceinline__ void gT_times(const QPDims &d, const QCWork &w, Lds &L, clptr y1, clptr y2, lptr out1, lptr out2) {
-    const int ldG = qc_ldg(d), m = d.m, po = d.po, nm = d.N * m, tid = threadIdx.x, nt = blockDim.x;
+    const int ldG = qc_ldg(d), m = d.m, po = d.po, nm = d.N * m, tid = SRH_TID, nt = blockDim.x;
     const int g8 = tid & 7;
     for (int r0 = 0; r0 < nm; r0 += nt / 8) {              // uniform trip count
         const int r = r0 + (tid >> 3), rc = r < nm ? r : nm - 1;
@@ -188,7 +188,7 @@ template <int MSEL, int NSEL>
 __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, const QPDyn &dyn, cgptr x, QCWork &w, Lds &L) {
     const int N = d.N, n = d.n, m = d.m, po = d.po, ld = d.ld, KT = d.KT, ldG = qc_ldg(d), ldT = ldG + 1;
     const int nk = d.NK, NPa = d.NPa;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    const int tid = SRH_TID, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     for (int e = tid; e < ldG; e += nt) {
         double v = 0.0;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
 // ------------------------------------------------------------------ per-stage pieces of a Newton system
 // gu (N m), gy (ldG) from the row weights `wrow` = rho (right-hand side) or lam (dual residual), read from L2
 __device__ __forceinline__ void gradients(const QPDims &d, const QPConst &c, const QPData &q, Lds &L, cgptr wrow, lptr gu, lptr gy) {
-    const int N = d.N, m = d.m, po = d.po, nz = d.nz, ldG = qc_ldg(d), tid = threadIdx.x, nt = blockDim.x;
+    const int N = d.N, m = d.m, po = d.po, nz = d.nz, ldG = qc_ldg(d), tid = SRH_TID, nt = blockDim.x;
     for (int e = tid; e < ldG; e += nt) {
         double g = 0.0;
         if (e < N * po) {
@@ -317,7 +317,7 @@ __device__ __forceinline__ void tri_inverse(lptr A, int m) {
 // D_j = 2R + U.A^T D_u U.A -> Ld_j^-1 (diagD: the reciprocal square roots of its diagonal);  S_k = S*_k + T^T D_x T -> Ls_k.
 // Returns false when one of them is not positive definite.  Dw = the weights D (L2).
 __device__ __forceinline__ bool stage_factors(const QPDims &d, const QPConst &c, cgptr Dw, Lds &L) {
-    const int N = d.N, m = d.m, po = d.po, tid = threadIdx.x, nt = blockDim.x;
+    const int N = d.N, m = d.m, po = d.po, tid = SRH_TID, nt = blockDim.x;
     cgptr Du = Dw + (size_t)N * d.RX;
     if (tid == 0) L.flag[0] = 1;
     __syncthreads();
@@ -371,7 +371,7 @@ __device__ __forceinline__ void gram(const QPDims &d, const QCWork &w, Lds &L) {
     constexpr int MB = PIPE ? MSEL : 16;                                   // bound of the register block
     constexpr int IT = PIPE ? (SR / MB * 128 + 511) / 512 : 1;             // (stage, column) items per thread and slab
     const int N = d.N, m = d.m, po = d.po, KT = d.KT, ldG = qc_ldg(d), NP = N * po;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    const int tid = SRH_TID, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int cj = SR / m > 0 ? SR / m : 1;        // stages per slab
     const int rows_used = (cj * m + 3) & ~3;
@@ -570,7 +570,7 @@ __device__ __forceinline__ void chol16_steps(double (&a)[16], double (&b)[16], d
 template <bool STORE_T = true, int NPC = 16>
 __device__ __forceinline__ bool chol16(lptr T, lptr Rinv) {
     static_assert(NPC >= 1 && NPC <= 16, "chol16: 1 <= NPC <= 16");
-    const int lane = threadIdx.x & 63, c = lane & 15, grp = lane >> 4;
+    const int lane = SRH_TID & 63, c = lane & 15, grp = lane >> 4;
     double a[16], b[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a[r] = T[r * TS + c]; b[r] = r == c ? 1.0 : 0.0; }
@@ -603,7 +603,7 @@ __device__ __forceinline__ void tile_update(lptr T, clptr Ra, clptr Rb, int l16,
 // Right-looking over tile rows.  Wave 0 owns the critical path: it updates the next diagonal tile first and factors it
 // while the other waves finish the trailing update of the step.
 __device__ __forceinline__ bool tile_cholesky(const QPDims &d, Lds &L) {
-    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
+    const int KT = d.KT, tid = SRH_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     if (wave == 0) {
         const bool ok = chol16(L.B, L.Rinv);
@@ -653,7 +653,7 @@ __device__ __forceinline__ bool tile_cholesky(const QPDims &d, Lds &L) {
 // ---- products with the factor (tile rows / columns over the waves; vectors of 16 KT entries in LDS)
 // out = R x   (R upper: tile row J needs tiles (J, J') for J' >= J)
 __device__ __forceinline__ void r_times(const QPDims &d, Lds &L, clptr x, lptr out) {
-    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
+    const int KT = d.KT, tid = SRH_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int c = lane & 15, part = lane >> 4;
     for (int J = wave; J < KT; J += nw) {
         double acc = 0.0;
@@ -670,7 +670,7 @@ __device__ __forceinline__ void r_times(const QPDims &d, Lds &L, clptr x, lptr o
 }
 // out = R^T x   (tile column J needs tiles (I, J) for I <= J)
 __device__ __forceinline__ void rT_times(const QPDims &d, Lds &L, clptr x, lptr out) {
-    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
+    const int KT = d.KT, tid = SRH_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int c = lane & 15, part = lane >> 4;
     for (int J = wave; J < KT; J += nw) {
         double acc = 0.0;
@@ -688,7 +688,7 @@ __device__ __forceinline__ void rT_times(const QPDims &d, Lds &L, clptr x, lptr 
 
 // v <- K^-1 v (in place, LDS vector of 16 KT entries) by wave 0; ends with a barrier
 __device__ __forceinline__ void k_solve(const QPDims &d, Lds &L, lptr v) {
-    const int KT = d.KT, tid = threadIdx.x, lane = tid & 63;
+    const int KT = d.KT, tid = SRH_TID, lane = tid & 63;
     if (tid < 64) {
         const int c = lane & 15, part = lane >> 4;
         // forward: R^T z = v
@@ -745,7 +745,7 @@ __device__ __forceinline__ void k_solve(const QPDims &d, Lds &L, lptr v) {
 
 // r_j <- D_j^-1 r_j   (in place on an LDS u-space vector)
 __device__ __forceinline__ void dinv_apply(const QPDims &d, Lds &L, lptr r) {
-    const int m = d.m, tid = threadIdx.x, nt = blockDim.x;
+    const int m = d.m, tid = SRH_TID, nt = blockDim.x;
     if (d.diagD) {
         for (int e = tid; e < d.N * m; e += nt) { const double s = L.Ldi[e]; r[e] *= s * s; }
     } else if (tid < d.N) {
@@ -769,7 +769,7 @@ __device__ __forceinline__ void dinv_apply(const QPDims &d, Lds &L, lptr r) {
 enum { LS_FWD = 0, LS_TR = 1, LS_INV = 2, LS_INVT = 3 };
 template <int OP>
 __device__ __forceinline__ void ls_apply(const QPDims &d, Lds &L, clptr in, lptr out) {
-    const int N = d.N, po = d.po, ldG = qc_ldg(d), tid = threadIdx.x, nt = blockDim.x;
+    const int N = d.N, po = d.po, ldG = qc_ldg(d), tid = SRH_TID, nt = blockDim.x;
     if (tid < N) {
         clptr Lk = L.Ls + (size_t)tid * po * po;
         double v[4] = {0.0, 0.0, 0.0, 0.0}, o[4] = {0.0, 0.0, 0.0, 0.0};
@@ -813,7 +813,7 @@ __device__ __forceinline__ void ls_apply(const QPDims &d, Lds &L, clptr in, lptr
 // two parts are not), and only then amplified by D^-1 -- algebraically equivalent short-cuts through (K - I) lose the
 // cancellation and leave the dual residual at 1e-7.
 __device__ __forceinline__ void newton_solve(const QPDims &d, QCWork &qw, Lds &L, clptr gyd, double *rd, Prof &pf) {
-    const int nm = d.N * d.m, ldG = qc_ldg(d), tid = threadIdx.x, nt = blockDim.x;
+    const int nm = d.N * d.m, ldG = qc_ldg(d), tid = SRH_TID, nt = blockDim.x;
     QC_SUB(pf, 8);
     gT_times(d, qw, L, L.ya, gyd, L.du, gyd ? L.tc : (lptr) nullptr);            // du (scratch) = G^T gy; tc = G^T gyd
     QC_SUB(pf, 9);
@@ -855,7 +855,7 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, QCWork &qw, Lds &L
 template <int MSEL, int NSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                      lptr smem, QPLds &Lq, int *iters_out, QPWork &wout) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     QPDims d = dfull;                               // the QP without its trust-region rows
     d.tr = 0;
     d.nrx = d.nX;

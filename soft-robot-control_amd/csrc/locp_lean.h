@@ -132,7 +132,7 @@ struct Waves {
         } else {
             target += nw;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if ((threadIdx.x & 63) == 0) {
+            if ((SRH_TID & 63) == 0) {
                 __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { if (sleepy) __builtin_amdgcn_s_sleep(1); }
             }
@@ -142,14 +142,14 @@ struct Waves {
     }
 };
 __device__ __forceinline__ Waves<false> all_waves() {
-    return Waves<false>{(int)threadIdx.x, (int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), (int)blockDim.x >> 6, (liptr) nullptr, 0, false};
+    return Waves<false>{(int)SRH_TID, (int)blockDim.x, __builtin_amdgcn_readfirstlane((int)SRH_TID >> 6), (int)blockDim.x >> 6, (liptr) nullptr, 0, false};
 }
 // the two halves of an 8-wave workgroup by SIMD: set (w >> 1) & 1, wave (w & 1) + 2 (w >> 2) inside it; ctr0: the arrival counter
 // of set 1 (set 0 synchronises through the counters of tile_cholesky_set)
 __device__ __forceinline__ int half_of_wave(int w) { return (w >> 1) & 1; }
 __device__ __forceinline__ Waves<true> half_waves(liptr ctr0) {
-    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), which = half_of_wave(w), lw = (w & 1) + 2 * (w >> 2);
-    return Waves<true>{lw * 64 + ((int)threadIdx.x & 63), 256, lw, 4, ctr0, 0, which == 1};      // (only set 1 calls sync(): one counter)
+    const int w = __builtin_amdgcn_readfirstlane((int)SRH_TID >> 6), which = half_of_wave(w), lw = (w & 1) + 2 * (w >> 2);
+    return Waves<true>{lw * 64 + ((int)SRH_TID & 63), 256, lw, 4, ctr0, 0, which == 1};      // (only set 1 calls sync(): one counter)
 }
 
 // ------------------------------------------------------------------ rollout x_{k+1} = A_k x_k + B_k u_k + d_k  (u null: zero inputs)
@@ -164,7 +164,7 @@ __device__ __forceinline__ Waves<true> half_waves(liptr ctr0) {
 template <int MSEL, int NSEL, bool XS = false>
 __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr x0, cgptr u, gptr x, Lds &L, lptr xs = nullptr) {
     const int N = d.N, n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, nk = d.NK;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tid = SRH_TID, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l = lane & 15, il = l >> 3, sl = l & 7;
     const int i_lo = 8 * wave + 2 * (lane >> 4) + il;                 // + 64 per row block (n_x > 64: a second pass)
     constexpr bool ONE_BLOCK = NSEL > 0 && NSEL <= 64;
@@ -213,7 +213,7 @@ template <int MSEL, int NSEL>
 __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, const QPDyn &dyn, cgptr x, gptr gh, Lds &L) {
     const int N = d.N, n = d.n, m = d.m, po = d.po, ld = d.ld, KT = d.KT, ldG = 16 * d.KT, ldT = ldG + 1;
     const int nk = d.NK, NPa = d.NPa, NP = N * po, j0 = d.lean_j0;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    const int tid = SRH_TID, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     for (int e = tid; e < ldG; e += nt) {
         double v = 0.0;
@@ -492,7 +492,7 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     static_assert(MSEL == 4 || MSEL == 8, "lean Gram: n_u = 4 or 8");
     constexpr int M = MSEL, SPS = M / 4;                       // k-steps per stage
     const int N = d.N, KT = d.KT, NP = g.NP;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tid = SRH_TID, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l16 = lane & 15, kk = lane >> 4;
     const int goff0 = goff(g.j0, M, NP);
     lptr w2 = L.tc;                                            // 1 / D per packed row
@@ -656,13 +656,13 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
 // No early exit on a failed pivot (NaNs are harmless, the caller tests L.flag[1] after the halves have joined).
 __device__ __forceinline__ void set_signal(liptr c) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((SRH_TID & 63) == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // SLEEP: the workers' waits (one row behind wave 0, long): s_sleep between polls -- same time as polling back to back
 // (58.7 vs 58.7-59.2 ms per 4096 rollouts), fewer instructions issued beside the wave that factorises
 template <bool SLEEP = false>
 __device__ __forceinline__ void set_wait(liptr c, int v) {
-    if ((threadIdx.x & 63) == 0) { while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) { if (SLEEP) __builtin_amdgcn_s_sleep(4); } }
+    if ((SRH_TID & 63) == 0) { while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) { if (SLEEP) __builtin_amdgcn_s_sleep(4); } }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -754,7 +754,7 @@ __device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const
 // scaling in the middle is one tile per wave.  (An explicit inverse T = R^-1 with x = T T^T v was measured as well: 2.5 k
 // clocks per solve, but its residual costs the interior point an iteration on some QPs -- slower overall.)
 __device__ __forceinline__ void unit_tiles(const QPDims &d, Lds &L) {
-    const int KT = d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int KT = d.KT, tid = SRH_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l16 = lane & 15, kk = lane >> 4, noff = KT * (KT - 1) / 2;
     for (int t = wave; t < noff; t += 8) {
         int tt = t, I = 0;
@@ -779,7 +779,7 @@ __device__ __forceinline__ void unit_tiles(const QPDims &d, Lds &L) {
 template <int KTC>
 __device__ __forceinline__ void k_solve_unit_impl(const QPDims &d, Lds &L, lptr v) {
     constexpr int KMAX = KTC > 0 ? KTC : 8;
-    const int KT = KTC > 0 ? KTC : d.KT, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int KT = KTC > 0 ? KTC : d.KT, tid = SRH_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c = lane >> 2, part = lane & 3;
     if (wave == 0) {                                                     // y = Uh^-T v
         double acc[KMAX];
@@ -897,7 +897,7 @@ __device__ __forceinline__ void newton_front(const QPDims &d, const GP &g, Lds &
 
 template <int MSEL, class GP>
 __device__ __forceinline__ void newton_back(const QPDims &d, const GP &g, Lds &L, Prof &pf) {
-    const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = threadIdx.x, nt = blockDim.x;
+    const int N = d.N, nm = N * d.m, ldG = 16 * d.KT, tid = SRH_TID, nt = blockDim.x;
     k_solve_unit(d, L, L.yc);
     // yd = Ls (ks v) per output stage: out_0 = L00 v0, out_1 = L10 v0 + L11 v1.
     // dy: with w = ks v the solved system reads (I + Ls^T Ky Ls) w = Ls^T yb, Ky = G D^-1 G^T, yb = G t, so that
@@ -943,7 +943,7 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, const GP &g, Lds &
 template <int MSEL, int NSEL>
 __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                    Lds &L, QPLds &Lq, int *iters_out, QPWork &wout, long long *prof) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
     d.nrx = d.nX;
@@ -1176,9 +1176,9 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
 __device__ __forceinline__ void reduce2(double &a, int opa, double &b, int opb, lptr scratch) {
     auto wr = [](double v, int op) { return op == 0 ? wg::wave_sum(v) : (op == 1 ? wg::wave_max(v) : wg::wave_min(v)); };
     const double wa = wr(a, opa), wb = wr(b, opb);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), nw = blockDim.x >> 6;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { scratch[wave] = wa; scratch[8 + wave] = wb; }
+    if ((SRH_TID & 63) == 0) { scratch[wave] = wa; scratch[8 + wave] = wb; }
     __syncthreads();
     auto comb = [](double x, double y, int op) { return op == 0 ? x + y : (op == 1 ? fmax(x, y) : fmin(x, y)); };
     double ra = scratch[0], rb = scratch[8];
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     // (GustoPar::poison_warm, SRH_LEAN_POISON_WARM=1 at plan creation) that makes the warm attempt fail so that the caller's cold
     // retry runs under a test
     const bool warm = warm_mode != 0, poison = warm_mode == 2;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
     d.nrx = d.nX;
@@ -1574,7 +1574,7 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
                                         Lds &L, int *iters_out, QPWork &wout, long long *prof, int warm_mode = 0) {
     static_assert(MSEL == 4 || MSEL == 8, "one-wave interior point: n_u = 4 or 8");
     const bool warm = warm_mode != 0, poison = warm_mode == 2;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
     d.nrx = d.nX;
@@ -2010,12 +2010,12 @@ __device__ __forceinline__ double objective_par(const QPDims &d, const QPConst &
     // phase's n_z^2 + n_u^2 products then read LDS as well (from global memory: one dependent load per product on a handful of threads)
     lptr Hl = hs, Qzl = Hl + (size_t)nz * n, Qfl = Qzl + nz * nz, Rl = Qfl + nz * nz, ezl = Rl + m * m;
     if (hl) {
-        for (int e = threadIdx.x; e < nz * n; e += blockDim.x) Hl[e] = c.H[e];
-        for (int e = threadIdx.x; e < nz * nz; e += blockDim.x) { Qzl[e] = c.Qz[e]; Qfl[e] = c.Qzf ? c.Qzf[e] : 0.0; }
-        for (int e = threadIdx.x; e < m * m; e += blockDim.x) Rl[e] = c.R[e];
+        for (int e = SRH_TID; e < nz * n; e += blockDim.x) Hl[e] = c.H[e];
+        for (int e = SRH_TID; e < nz * nz; e += blockDim.x) { Qzl[e] = c.Qz[e]; Qfl[e] = c.Qzf ? c.Qzf[e] : 0.0; }
+        for (int e = SRH_TID; e < m * m; e += blockDim.x) Rl[e] = c.R[e];
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < (N + 1) * nz; e += blockDim.x) {
+    for (int e = SRH_TID; e < (N + 1) * nz; e += blockDim.x) {
         const int k = e / nz, a = e - k * nz;
         double v = q.z ? -q.z[e] : 0.0;
         if (hl) { for (int j = 0; j < n; ++j) v = fma(Hl[a * n + j], x[(size_t)k * n + j], v); }
@@ -2025,7 +2025,7 @@ __device__ __forceinline__ double objective_par(const QPDims &d, const QPConst &
     }
     __syncthreads();
     double acc = 0.0;
-    for (int k = threadIdx.x; k <= N; k += blockDim.x) {
+    for (int k = SRH_TID; k <= N; k += blockDim.x) {
         double e[16];
         if (hl) { for (int a = 0; a < nz; ++a) e[a] = ezl[(size_t)k * nz + a]; }
         else { for (int a = 0; a < nz; ++a) e[a] = ez[(size_t)k * nz + a]; }
@@ -2054,7 +2054,7 @@ __host__ __device__ inline size_t objective_lds_doubles(const QPDims &d) { retur
 template <int MSEL, int NSEL, int GXSEL, int NST = 0, int J0SEL = 0>
 __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                         Lds &L, double *J_out, int *iters_out, QPWork &wout, long long *prof, int warm = 0) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     QPLds Lq{};
     Lq.v1 = L.v1; Lq.v2 = L.v2; Lq.Qu = L.Qu; Lq.part = L.part; Lq.red = L.red; Lq.idxl = L.idxl; Lq.flag = L.flag;
     int it = 0;
