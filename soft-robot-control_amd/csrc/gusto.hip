@@ -11,7 +11,7 @@ namespace {
 // (descending) gives the workgroup -> rollout map of the next launch.  Results do not depend on the order.
 __global__ __launch_bounds__(1024) void lpt_order_kernel(const int32_t *__restrict__ key, int64_t batch, int32_t *__restrict__ order) {
     __shared__ int cnt[1024];
-    const int tid = threadIdx.x;
+    const int tid = SRH_TID;
     cnt[tid] = 0;
     __syncthreads();
     for (int64_t i = tid; i < batch; i += 1024) atomicAdd(&cnt[1023 - min(max(key[i], 0), 1023)], 1);
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     qp_lds_carve(L, (lptr)smem, d, NTHREADS);          // qp::solve fills the constants of the layout it uses
     const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     gptr base = (gptr)(b.work + p * b.work_stride);
     QPWork w;

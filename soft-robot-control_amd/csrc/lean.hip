@@ -40,10 +40,10 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     if constexpr (NST > 0) d.tr = 1;                   // GuSTO always carries the trust region
     ql::Lds L;
     ql::lds_carve(L, (lptr)smem, d, NTHREADS);
-    if (threadIdx.x == 0) L.flag[2] = 0;               // no condensation in LDS yet (ql::ipm)
+    if (SRH_TID == 0) L.flag[2] = 0;               // no condensation in LDS yet (ql::ipm)
     const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     gptr base = (gptr)(b.work + p * b.work_stride);
     QPWork w;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
     fix_problem<MSEL, GXSEL, NST, J0SEL, NXR>(d);
     ql::Lds L;
     ql::lds_carve(L, (lptr)smem, d, NTHREADS);
-    if (threadIdx.x == 0) L.flag[2] = 0;
+    if (SRH_TID == 0) L.flag[2] = 0;
     const size_t p = blockIdx.x;
     const size_t N = d.N, n = d.n, m = d.m;
     QPWork w;
@@ -331,20 +331,20 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
     double J = 0.0;
     int it = 0;
     const int st = ql::solve_qp<MSEL, NSEL, GXSEL, NST, J0SEL>(d, c, dyn, q, wbase, L, &J, &it, w, prof);
-    if (q.dbg && threadIdx.x == 0) {
+    if (q.dbg && SRH_TID == 0) {
         q.dbg[8 * 61] = 2.0; q.dbg[8 * 61 + 1] = (double)st; q.dbg[8 * 61 + 2] = (double)it; q.dbg[8 * 61 + 3] = st == 100 ? 0.0 : 1.0;
 #ifdef SRH_PROFILE
         for (int i = 0; i < 8; ++i) { q.dbg[8 * 60 + i] = (double)prof[i]; q.dbg[8 * 59 + i] = (double)prof[8 + i]; }
 #endif
     }
     if (st != 0) {
-        if (threadIdx.x == 0) { b.status[p] = LEAN_PENDING; b.iters[p] = it; if (b.handed_over) atomicAdd(b.handed_over, 1); }
+        if (SRH_TID == 0) { b.status[p] = LEAN_PENDING; b.iters[p] = it; if (b.handed_over) atomicAdd(b.handed_over, 1); }
         return;
     }
-    for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
-    for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
-    for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
-    if (threadIdx.x == 0) { b.J[p] = J; b.status[p] = 0; b.iters[p] = it; }
+    for (int e = SRH_TID; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
+    for (int e = SRH_TID; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
+    for (int e = SRH_TID; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
+    if (SRH_TID == 0) { b.J[p] = J; b.status[p] = 0; b.iters[p] = it; }
 }
 
 // instantiated shapes: the reference's 4- and 8-cable robots at the benchmark's r = 30 with the row layout their drivers use

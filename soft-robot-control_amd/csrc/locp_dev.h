@@ -174,7 +174,7 @@ __device__ inline void qp_lds_carve(QPLds &L, lptr base, const QPDims &d, int nt
 
 // one-off per kernel: constants into LDS, zero the padding of the MFMA operands
 __device__ inline void qp_lds_init(QPLds &L, const QPDims &d, const QPConst &c) {
-    const int tid = threadIdx.x, nt = blockDim.x, n = d.n, ld = d.ld;
+    const int tid = SRH_TID, nt = blockDim.x, n = d.n, ld = d.ld;
     // the whole carve starts from zeros (the MFMA operands rely on zero padding; later rounds of a launch inherit the
     // LDS of the previous workgroup), and the BARRIER below orders the zeroing before the constant rows written next
     // by other threads -- without it a late zeroing thread could wipe a Cq / XA entry: an inexact Hessian the
@@ -238,12 +238,12 @@ __device__ __forceinline__ int xrows_of(const QPDims &d, int k) { return d.nrx +
 template <typename F>
 __device__ __forceinline__ void for_rows(const QPDims &d, F f) {
     const int nxr = d.N * d.RX;
-    for (int e = threadIdx.x; e < nxr; e += blockDim.x) {
+    for (int e = SRH_TID; e < nxr; e += blockDim.x) {
         const int k = e / d.RX + 1, r = e - (k - 1) * d.RX;
         if (r < xrows_of(d, k)) f(e, false, k, r);
     }
     const int nur = d.N * d.nU;
-    for (int e = threadIdx.x; e < nur; e += blockDim.x) {
+    for (int e = SRH_TID; e < nur; e += blockDim.x) {
         const int k = e / d.nU, r = e - k * d.nU;
         f(nxr + e, true, k, r);
     }
@@ -269,15 +269,15 @@ __device__ __forceinline__ double row_h(const QPDims &d, const QPConst &c, const
 // ------------------------------------------------------------------ rollout x = f(u)
 __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, const QPData &q, cgptr u, gptr x, QPLds &L) {
     const int n = d.n, m = d.m;
-    for (int e = threadIdx.x; e < n; e += blockDim.x) { L.v1[e] = q.x0[e]; x[e] = q.x0[e]; }
+    for (int e = SRH_TID; e < n; e += blockDim.x) { L.v1[e] = q.x0[e]; x[e] = q.x0[e]; }
     __syncthreads();
     for (int k = 0; k < d.N; ++k) {
         const size_t i = (size_t)L.idxl[k];
-        for (int e = threadIdx.x; e < m; e += blockDim.x) L.Qu[e] = u[(size_t)k * m + e];
+        for (int e = SRH_TID; e < m; e += blockDim.x) L.Qu[e] = u[(size_t)k * m + e];
         __syncthreads();
         wg::matTvec(L.v2, dyn.AT + i * n * n, n, n, n, L.v1, dyn.d + i * n, L.part);
         wg::matTvec(L.v2, dyn.BT + i * m * n, n, m, n, L.Qu, (clptr)L.v2, L.part);
-        for (int e = threadIdx.x; e < n; e += blockDim.x) { L.v1[e] = L.v2[e]; x[(size_t)(k + 1) * n + e] = L.v2[e]; }
+        for (int e = SRH_TID; e < n; e += blockDim.x) { L.v1[e] = L.v2[e]; x[(size_t)(k + 1) * n + e] = L.v2[e]; }
         __syncthreads();
     }
 }
@@ -286,7 +286,7 @@ __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, const
 __device__ __forceinline__ double slack0(const QPDims &d, const QPConst &c, const QPData &q, QPLds &L) {
     if (!d.tr) return 0.0;
     double v = 0.0;
-    for (int e = threadIdx.x; e < d.n; e += blockDim.x) v = fmax(v, fabs(c.xs[e] * (q.x0[e] - q.xk[e])));
+    for (int e = SRH_TID; e < d.n; e += blockDim.x) v = fmax(v, fabs(c.xs[e] * (q.x0[e] - q.xk[e])));
     v = wg::reduce(v, 1, L.red);
     return fmax(0.0, v - q.delta);
 }
@@ -296,7 +296,7 @@ __device__ __forceinline__ double objective(const QPDims &d, const QPConst &c, c
                                        cgptr s, QPLds &L) {
     double acc = 0.0;
     const int n = d.n, nz = d.nz, m = d.m;
-    for (int k = threadIdx.x; k <= d.N; k += blockDim.x) {
+    for (int k = SRH_TID; k <= d.N; k += blockDim.x) {
         double e[16];
         for (int a = 0; a < nz; ++a) {
             double v = q.z ? -q.z[(size_t)k * nz + a] : 0.0;
@@ -327,14 +327,14 @@ __device__ __forceinline__ double objective(const QPDims &d, const QPConst &c, c
 __device__ __forceinline__ void stage_prepass(const QPDims &d, const QPConst &c, const QPData &q, QPWork &w, bool with_dual) {
     const int n = d.n, nz = d.nz, m = d.m, N = d.N;
     // e_k = H x_k - z_k
-    for (int e = threadIdx.x; e < (N + 1) * nz; e += blockDim.x) {
+    for (int e = SRH_TID; e < (N + 1) * nz; e += blockDim.x) {
         const int k = e / nz, a = e - k * nz;
         double v = q.z ? -q.z[e] : 0.0;
         for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], w.x[(size_t)k * n + j], v);
         w.ez[e] = v;
     }
     __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), lane = SRH_TID & 63, nw = blockDim.x >> 6;
     for (int k = 1 + wave; k <= N; k += nw) {
         cgptr Dk = w.D + (size_t)(k - 1) * d.RX, rk = w.rho + (size_t)(k - 1) * d.RX;
         cgptr lk = w.lam + (size_t)(k - 1) * d.RX;
@@ -393,13 +393,13 @@ __device__ __forceinline__ void stage_prepass(const QPDims &d, const QPConst &c,
     }
     // input stages
     cgptr Du = w.D + (size_t)N * d.RX, ru = w.rho + (size_t)N * d.RX, lu = w.lam + (size_t)N * d.RX;
-    for (int e = threadIdx.x; e < N * m * m; e += blockDim.x) {
+    for (int e = SRH_TID; e < N * m * m; e += blockDim.x) {
         const int k = e / (m * m), ab = e - k * m * m, a = ab / m, b = ab - a * m;
         double v = c.R2[ab];
         for (int r = 0; r < d.nU; ++r) v = fma(c.UA[r * m + a] * Du[(size_t)k * d.nU + r], c.UA[r * m + b], v);
         w.Huu[e] = v;
     }
-    for (int e = threadIdx.x; e < N * m; e += blockDim.x) {
+    for (int e = SRH_TID; e < N * m; e += blockDim.x) {
         const int k = e / m, a = e - k * m;
         double v = 0.0;
         for (int b = 0; b < m; ++b) v = fma(c.R2[a * m + b], w.u[(size_t)k * m + b] - (q.ud ? q.ud[(size_t)k * m + b] : 0.0), v);
@@ -423,7 +423,7 @@ using wg::mfma_atb;
 template <int NR>
 __device__ __forceinline__ void mfma_acc(qp_d4 (&acc)[NR], clptr Lm, clptr Rm, int K, int MT, int NTl, int ld) {
     static_assert(NR % 2 == 0, "tiles are processed in pairs");
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), lane = SRH_TID & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
 #pragma unroll
@@ -451,7 +451,7 @@ __device__ __forceinline__ void mfma_acc(qp_d4 (&acc)[NR], clptr Lm, clptr Rm, i
 // C rows < srows of the accumulated tiles (no barrier inside)
 template <int NR>
 __device__ __forceinline__ void mfma_put(const qp_d4 (&acc)[NR], lptr C, int ldc, int MT, int NTl, int srows) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), lane = SRH_TID & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     const int ntiles = MT * NTl;
 #pragma unroll
@@ -491,7 +491,7 @@ __device__ __forceinline__ double stage_hess(const QPDims &d, const QPConst &c, 
 // exactly symmetric in the added terms.  Column n / n+1 of the right panel receive pv / adj (rows < n).
 template <int M, bool SPLIT>
 __device__ __forceinline__ bool stage_gain_t(const QPDims &d, QPWork &w, QPLds &L, int k, bool extras) {
-    const int n = d.n, ld = d.ld, NK = d.NK, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, ld = d.ld, NK = d.NK, tid = SRH_TID, nt = blockDim.x;
     const int wb = SPLIT ? 0 : NK;            // first extra row of the right panel
     double Lr[M * M], inv[M];
     double dmax = 0.0;
@@ -581,7 +581,7 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
         default: break;
     }
     // m > 8: factor once in LDS (thread 0), per-column solves from LDS
-    const int n = d.n, m = d.m, ld = d.ld, NK = d.NK, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, m = d.m, ld = d.ld, NK = d.NK, tid = SRH_TID, nt = blockDim.x;
     const int wb = SPLIT ? 0 : NK;
     if (!wg::chol_factor(L.Quu, L.Lc, m, L.flag, true)) return false;
     for (int j = tid; j <= n; j += nt) {
@@ -636,7 +636,7 @@ __device__ __forceinline__ bool stage_gain(const QPDims &d, QPWork &w, QPLds &L,
 // has one after its own stage loads anyway; the vector sweeps only pay it on a reload).  Which region the panel holds
 // is tracked in a per-thread copy (L.psel, identical in every thread): no LDS flag, no barrier to protect it.
 __device__ __forceinline__ bool panel_load(const QPDims &d, const QPDyn &dyn, QPLds &L, int k) {
-    const int n = d.n, m = d.m, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, m = d.m, ld = d.ld, tid = SRH_TID, nt = blockDim.x;
     // both values are the same in every lane: readfirstlane moves them to scalar registers, the branch below (and the
     // caller's barrier on it) is then a scalar branch, not exec-mask control flow
     const int sel = __builtin_amdgcn_readfirstlane(L.idxl[k]);
@@ -655,7 +655,7 @@ __device__ __forceinline__ bool panel_load(const QPDims &d, const QPDyn &dyn, QP
 
 // y[j] = sum_{i<n} AB[i][j] v[i], j < n + m      ( [A^T v ; B^T v] )
 __device__ __forceinline__ void panel_T_vec(const QPDims &d, QPLds &L, clptr v, lptr y) {
-    const int n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, tid = SRH_TID, nt = blockDim.x;
     const int S = nt / NPa > 0 ? nt / NPa : 1;
     const int col = tid % NPa, sl = tid / NPa;
     if (sl < S) {
@@ -683,7 +683,7 @@ __device__ __forceinline__ void panel_T_vec(const QPDims &d, QPLds &L, clptr v, 
 //   Qu is parked in kff[k] and turned into kff = -Quu^-1 Qu for all stages at once after the sweep.
 template <int MSEL, int NSEL>
 __device__ __forceinline__ void vector_sweep_back(const QPDims &d, const QPDyn &dyn, QPWork &w, QPLds &L) {
-    const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = SRH_TID, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     constexpr int NP = 2;                                   // column passes of 64: n <= 128
     lptr pv = L.pv, pn = L.v3;
@@ -755,7 +755,7 @@ __device__ __forceinline__ void vector_sweep_back(const QPDims &d, const QPDyn &
 //   dx_{k+1} = [A | B] xu  (lane (c, g) of 8 x 8: columns g, g + 8, ..).  The slack steps follow after the sweep.
 template <int MSEL, int NSEL>
 __device__ __forceinline__ void vector_sweep_fwd(const QPDims &d, const QPDyn &dyn, QPWork &w, QPLds &L) {
-    const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, m = d.m, N = d.N, ld = d.ld, tid = SRH_TID, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6, nm = n + m;
     for (int e = tid; e < n; e += nt) { L.v1[e] = 0.0; w.dx[e] = 0.0; }
     __syncthreads();
@@ -845,7 +845,7 @@ template <bool SPLIT, int MSEL, int NSEL>
 __device__ __forceinline__ bool riccati_solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, QPWork &w, QPLds &L,
                                      bool full, bool with_dual, double *rd_out) {
     const int n = d.n, m = MSEL > 0 ? MSEL : d.m, N = d.N, ld = d.ld, NK = d.NK, NPa = d.NPa, n16 = (d.n + 15) & ~15;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
     const int xoff = d.tr ? 2 * n + 1 : 0;
     double rd = 0.0;
@@ -1072,7 +1072,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
     // (t = max(-g(u), floor), lam = max(lam, floor), no starting system); a warm attempt that fails is repeated cold.
     // pass_out: -1 condensed path, 0 relaxed Riccati pass, 1 full QP -- what produced the result.
     constexpr double WARM_FLOOR = 1e-2;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     int status = 1, it = 0;
     if (pass_out) *pass_out = -1;
     double J = 0.0;

@@ -12,7 +12,7 @@ constexpr int NT = 512;
 // C (M x N) = alpha * op(A) * op(B) + beta * C0 ; op = transpose flag.  Ends with __syncthreads().
 template <bool TA, bool TB, typename CP, typename AP, typename BP>
 __device__ inline void mm(CP C, int ldc, AP A, int lda, BP B, int ldb, int M, int N, int K) {
-    for (int e = threadIdx.x; e < M * N; e += blockDim.x) {
+    for (int e = SRH_TID; e < M * N; e += blockDim.x) {
         const int i = e / N, j = e - i * N;
         double acc = 0.0;
         int k = 0;
@@ -77,10 +77,10 @@ __device__ inline bool lqr_gain(LqrLds &L, AP A, BP B, RP R, int n, int m) {
     mm<false, false>(L.W, n, L.P, n, A, n, n, n, n);        // W = P A
     mm<false, false>(L.PB, m, L.P, n, B, m, n, m, n);       // PB = P B
     mm<true, false>(L.Quu, m, B, m, L.PB, m, m, m, n);      // B^T P B
-    for (int e = threadIdx.x; e < m * m; e += blockDim.x) L.Quu[e] += R[e];
+    for (int e = SRH_TID; e < m * m; e += blockDim.x) L.Quu[e] += R[e];
     mm<true, false>(L.Kt, n, B, m, L.W, n, m, n, n);        // B^T P A
     if (!chol16(L.Quu, L.Lc, m, L.flag)) return false;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) wg::chol_solve_neg(L.Lc, m, L.Kt + j, n, L.Kk + j, n);
+    for (int j = SRH_TID; j < n; j += blockDim.x) wg::chol_solve_neg(L.Lc, m, L.Kt + j, n, L.Kk + j, n);
     __syncthreads();
     return true;
 }
@@ -94,16 +94,16 @@ __global__ __launch_bounds__(NT) void tvlqr_kernel(const double *A, const double
     lqr_carve(L, (lptr)smem, n, m);
     cgptr Ag = (cgptr)A, Bg = (cgptr)B, Qg = (cgptr)Q, Rg = (cgptr)R;
     gptr Kg = (gptr)K, Pg = (gptr)P;
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) { L.P[e] = Qg[e]; if (Pg) Pg[(size_t)steps * n * n + e] = Qg[e]; }
+    for (int e = SRH_TID; e < n * n; e += blockDim.x) { L.P[e] = Qg[e]; if (Pg) Pg[(size_t)steps * n * n + e] = Qg[e]; }
     __syncthreads();
     int st = 0;
     for (int i = steps - 1; i >= 0; --i) {
         const size_t sel = idx ? (size_t)idx[i] : (size_t)i;
         cgptr Ai = Ag + sel * n * n, Bi = Bg + sel * n * m;
         if (!lqr_gain(L, Ai, Bi, Rg, n, m)) { st = 2; break; }
-        for (int e = threadIdx.x; e < m * n; e += blockDim.x) Kg[(size_t)i * m * n + e] = L.Kk[e];
+        for (int e = SRH_TID; e < m * n; e += blockDim.x) Kg[(size_t)i * m * n + e] = L.Kk[e];
         // Acl = A + B K (into T) ; P = Q + K^T R K + Acl^T P Acl
-        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        for (int e = SRH_TID; e < n * n; e += blockDim.x) {
             const int r = e / n, c = e - r * n;
             double v = Ai[e];
             for (int a = 0; a < m; ++a) v = fma(Bi[r * m + a], L.Kk[a * n + c], v);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NT) void tvlqr_kernel(const double *A, const double
         mm<false, false>(L.W, n, L.P, n, L.T, n, n, n, n);          // W = P Acl
         mm<false, false>(L.Kt, n, Rg, m, L.Kk, n, m, n, m);         // R K
         // new P (reads T, W, Kk, Kt; writes P only)
-        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        for (int e = SRH_TID; e < n * n; e += blockDim.x) {
             const int r = e / n, c = e - r * n;
             double v = Qg[e];
             for (int a = 0; a < m; ++a) v = fma(L.Kk[a * n + r], L.Kt[a * n + c], v);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void tvlqr_kernel(const double *A, const double
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *status = st;
+    if (SRH_TID == 0) *status = st;
 }
 
 // ------------------------------------------------------------------ fixed-point DARE (lqr.py:6-21)
@@ -135,27 +135,27 @@ __global__ __launch_bounds__(NT) void dare_fp_kernel(const double *A, const doub
     lqr_carve(L, (lptr)smem, n, m);
     const size_t p = blockIdx.x;
     cgptr Ag = (cgptr)A + p * n * n, Bg = (cgptr)B + p * n * m, Qg = (cgptr)Q, Rg = (cgptr)R;
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) L.P[e] = 0.0;
+    for (int e = SRH_TID; e < n * n; e += blockDim.x) L.P[e] = 0.0;
     __syncthreads();
     // L = solve(R + B'PB, B'PA) with P = 0 (no sign): zeros; L_old = inf
     bool first = true;
     int it = 0;
     // BK holds the previous gain (m x n) -- needs m*n <= n*m doubles
-    for (int e = threadIdx.x; e < m * n; e += blockDim.x) L.BK[e] = 0.0;
+    for (int e = SRH_TID; e < m * n; e += blockDim.x) L.BK[e] = 0.0;
     __syncthreads();
     while (it < max_iter) {
         // gain of the current P:  Kk = -(R + B'PB)^-1 B'PA  ; W = P A, Kt = B'PA
         if (!lqr_gain(L, Ag, Bg, Rg, n, m)) break;
         if (!first) {
             double d2 = 0.0;
-            for (int e = threadIdx.x; e < m * n; e += blockDim.x) { const double d = L.Kk[e] - L.BK[e]; d2 = fma(d, d, d2); }
+            for (int e = SRH_TID; e < m * n; e += blockDim.x) { const double d = L.Kk[e] - L.BK[e]; d2 = fma(d, d, d2); }
             d2 = wg::reduce(d2, 0, L.red);
             if (sqrt(d2) <= tol) break;
         }
         first = false;
-        for (int e = threadIdx.x; e < m * n; e += blockDim.x) L.BK[e] = L.Kk[e];
+        for (int e = SRH_TID; e < m * n; e += blockDim.x) L.BK[e] = L.Kk[e];
         // P <- A'PA - A'PB (R+B'PB)^-1 B'PA + Q = A'W + (B'PA)' Kk + Q
-        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        for (int e = SRH_TID; e < n * n; e += blockDim.x) {
             const int r = e / n, c = e - r * n;
             double v = Qg[e];
             for (int k = 0; k < n; ++k) v = fma(Ag[k * n + r], L.W[k * n + c], v);
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(NT) void dare_fp_kernel(const double *A, const doub
             L.T[e] = v;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < n * n; e += blockDim.x) L.P[e] = L.T[e];
+        for (int e = SRH_TID; e < n * n; e += blockDim.x) L.P[e] = L.T[e];
         __syncthreads();
         ++it;
     }
-    for (int e = threadIdx.x; e < m * n; e += blockDim.x) Lout[p * m * n + e] = L.Kk[e];
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) Pout[p * n * n + e] = L.P[e];
-    if (threadIdx.x == 0 && iters) iters[p] = it;
+    for (int e = SRH_TID; e < m * n; e += blockDim.x) Lout[p * m * n + e] = L.Kk[e];
+    for (int e = SRH_TID; e < n * n; e += blockDim.x) Pout[p * n * n + e] = L.P[e];
+    if (SRH_TID == 0 && iters) iters[p] = it;
 }
 
 // ------------------------------------------------------------------ DARE by structure-preserving doubling
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT) void dare_sda_kernel(const double *A, const dou
                                                       int *status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t p = blockIdx.x;
-    const int ld = n | 1, tid = threadIdx.x, nt = blockDim.x;
+    const int ld = n | 1, tid = SRH_TID, nt = blockDim.x;
     const size_t nn = (size_t)n * ld;
     double *wk = work + p * (7 * nn);
     double *gA = wk, *gG = wk + nn;
@@ -335,7 +335,7 @@ template <int M>
 __device__ __forceinline__ bool ilqr_gain_t(LqrLds &L, int n) {
     double Lr[M * M], inv[M];
     if (!wg::chol_reg<M>(L.Quu, M, 0.0, Lr, inv)) return false;
-    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
+    for (int j = SRH_TID; j <= n; j += blockDim.x) {
         if (j < n) wg::chol_solve_neg_reg<M>(Lr, inv, L.BK + j, n, L.Kk + j, n);
         else wg::chol_solve_neg_reg<M>(Lr, inv, L.u2, 1, L.u1, 1);
     }
@@ -356,7 +356,7 @@ __device__ __forceinline__ bool ilqr_gain(LqrLds &L, int n, int m) {
         default: break;
     }
     if (!chol16(L.Quu, L.Lc, m, L.flag)) return false;
-    for (int j = threadIdx.x; j <= n; j += blockDim.x) {
+    for (int j = SRH_TID; j <= n; j += blockDim.x) {
         if (j < n) wg::chol_solve_neg(L.Lc, m, L.BK + j, n, L.Kk + j, n);
         else wg::chol_solve_neg(L.Lc, m, L.u2, 1, L.u1, 1);
     }
@@ -401,7 +401,7 @@ struct IlqrOp {
 
 __device__ __forceinline__ void ilqr_mm(lptr C, int ldc, const IlqrOp &Lo, const IlqrOp &Ro, int K, int MT, int NTl, int vrows,
                                         int srows) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), lane = SRH_TID & 63, nw = blockDim.x >> 6;
     const int l16 = lane & 15, kk = lane >> 4;
     for (int t = wave; t < MT * NTl; t += nw) {
         const int ti = t / NTl, tj = t - ti * NTl;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
     cgptr zref = MODEL == 0 ? T.z_ref : S.z_ref;
     const size_t lstride = (size_t)n * n + (size_t)n * m + n;
     const size_t p = blockIdx.x;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     cgptr x0 = (cgptr)a.x0 + p * n, ztar = (cgptr)a.z_target + p * (size_t)(N + 1) * nz;
     cgptr Qg = (cgptr)a.Q, Rg = (cgptr)a.R, Qfg = (cgptr)a.Qf;
     gptr X = (gptr)a.x + p * (size_t)(N + 1) * n, U = (gptr)a.u + p * (size_t)N * m;

@@ -28,10 +28,10 @@ __global__ __launch_bounds__(NTHREADS) void locp_kernel(QPDims d, QPConst c, Loc
     double J;
     int it;
     const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, wbase, L, &J, &it, true, w);
-    for (int e = threadIdx.x; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
-    for (int e = threadIdx.x; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
-    for (int e = threadIdx.x; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
-    if (threadIdx.x == 0) { b.J[p] = J; b.status[p] = st; b.iters[p] = it; }
+    for (int e = SRH_TID; e < (N + 1) * n; e += blockDim.x) b.x[p * (N + 1) * n + e] = w.x[e];
+    for (int e = SRH_TID; e < N * m; e += blockDim.x) b.u[p * N * m + e] = w.u[e];
+    for (int e = SRH_TID; e <= N; e += blockDim.x) b.s[p * (N + 1) + e] = w.s[e];
+    if (SRH_TID == 0) { b.J[p] = J; b.status[p] = st; b.iters[p] = it; }
 }
 
 
@@ -39,7 +39,7 @@ __global__ void transpose_batch_kernel(const double *__restrict__ src, int64_t c
                                        double *__restrict__ dst) {
     const int64_t b = blockIdx.x;
     if (b >= count) return;
-    for (int e = threadIdx.x; e < rows * cols; e += blockDim.x) {
+    for (int e = SRH_TID; e < rows * cols; e += blockDim.x) {
         const int i = e / cols, j = e - i * cols;
         dst[b * rows * cols + (size_t)j * rows + i] = src[b * rows * cols + e];
     }

@@ -36,14 +36,14 @@ __device__ inline void basis(const int *__restrict__ ex, const int *__restrict__
                              lptr phi, lptr D) {
     for (int d = 0; d < order; ++d) {
         const int j0 = lv[d], j1 = lv[d + 1];
-        for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        for (int j = j0 + SRH_TID; j < j1; j += blockDim.x) {
             const int pj = par[j];
             phi[j] = (pj < 0 ? 1.0 : phi[pj]) * x[var[j]];
         }
         __syncthreads();
     }
     if (D != nullptr) {
-        for (int e = threadIdx.x; e < nmon * dim; e += blockDim.x) {
+        for (int e = SRH_TID; e < nmon * dim; e += blockDim.x) {
             const int q = dm[e];
             D[e] = q == -1 ? 0.0 : (double)ex[e] * (q == -2 ? 1.0 : phi[q]);
         }
@@ -73,7 +73,7 @@ __device__ __forceinline__ double dot8(AP a, int sa, BP b, int sb, int K) {
 // In-place Gauss-Jordan inverse with partial pivoting of the n x n matrix M (LDS, leading dimension ld);
 // Minv (LDS, ld) receives the inverse.  piv: LDS int scratch (2).  All threads; ends with a sync.
 __device__ inline void inverse(lptr M, lptr Minv, int n, int ld, liptr piv) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = SRH_TID, nt = blockDim.x;
     for (int e = tid; e < n * n; e += nt) Minv[(e / n) * ld + e % n] = (e / n == e % n) ? 1.0 : 0.0;
     __syncthreads();
     for (int k = 0; k < n; ++k) {
@@ -121,7 +121,7 @@ __device__ inline void inverse(lptr M, lptr Minv, int n, int ld, liptr piv) {
 // operations in the same order as in `inverse` (bit-identical results), and two matrices can be inverted side by side on two
 // waves.  Pivot: first maximum of |M[i][k]|, i >= k, as the sequential scan of `inverse`.
 __device__ inline void inverse_wave(lptr M, lptr Minv, int n, int ld) {
-    const int lane = threadIdx.x & 63;
+    const int lane = SRH_TID & 63;
     auto wsync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -239,7 +239,7 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
 // d = f - A x - B u, then discretised per `mode`.  A (n x lda), Bm (n x m), d (n) in LDS.  Ends with a sync.
 __device__ inline void linearize(const SsmDev &S, int mode, double dt, clptr x, clptr u, Work &w, lptr A, int lda,
                                  lptr Bm, lptr d) {
-    const int n = S.n, m = S.m, tid = threadIdx.x, nt = blockDim.x;
+    const int n = S.n, m = S.m, tid = SRH_TID, nt = blockDim.x;
     const bool dm = mode == SSM_DISCRETE_MAP;
     cgptr Rc = dm ? S.Rd : S.R, Bg = dm ? S.Bd : S.Bc;
     basis(S.er, S.pr, S.vr, S.dmr, S.lvr, S.order_r, S.nr, n, x, w.phi, w.D);
@@ -266,7 +266,7 @@ __device__ inline void linearize(const SsmDev &S, int mode, double dt, clptr x, 
 
 // (A, B, d) continuous -> discrete per `mode` (ssm.py:279-301), in place.  Ends with a sync.
 __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w, lptr A, int lda, lptr Bm, lptr d) {
-    const int n = S.n, m = S.m, tid = threadIdx.x, nt = blockDim.x;
+    const int n = S.n, m = S.m, tid = SRH_TID, nt = blockDim.x;
     if (mode == SSM_CONT || mode == SSM_DISCRETE_MAP) return;
     if (mode == SSM_FE) {                                       // I + dt A, dt B, dt d
         for (int e = tid; e < n * n; e += nt) {
@@ -296,7 +296,7 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
     SSM_DLAP(0);
     // M2 = inv(I - h A) and M4 = inv(A_c): independent, one wave each (a single-wave workgroup does them in turn)
     if (n <= 64) {
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (blockDim.x + 63) >> 6;
+        const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), nw = (blockDim.x + 63) >> 6;
         if (wave == 0) inverse_wave(w.M1, w.M2, n, ld);
         if (wave == (nw > 1 ? 1 : 0)) inverse_wave(w.M3, w.M4, n, ld);
         __syncthreads();
@@ -347,7 +347,7 @@ __device__ inline void discretize(const SsmDev &S, int mode, double dt, Work &w,
 // z = C_map(x) = W phi_s(x) (no z_ref); optional observer Jacobian Hj = W Dphi_s (no x n) and c = z - Hj x
 // (ssm.py:220-235).  Ends with a sync.
 __device__ inline void observe(const SsmDev &S, clptr x, Work &w, lptr z, lptr Hj, lptr c) {
-    const int n = S.n, no = S.no, tid = threadIdx.x, nt = blockDim.x;
+    const int n = S.n, no = S.no, tid = SRH_TID, nt = blockDim.x;
     basis(S.es, S.ps, S.vs, S.dms, S.lvs, S.order_s, S.ns, no, x, w.phi, Hj != nullptr ? w.D : (lptr) nullptr);
     for (int i = tid; i < no; i += nt) {
         z[i] = dot8(S.Wc + (size_t)i * S.ns, 1, w.phi, 1, S.ns);
@@ -411,7 +411,7 @@ inline int jacobian_list_cap(const int *E, int nr, int n) {
 
 // copy the tables (all threads; ends with a sync)
 __device__ inline void stage(SsmLds &T, lptr base, const SsmDev &S, bool discrete_map, int jcap = 0) {
-    const int n = S.n, no = S.no, nr = S.nr, ns = S.ns, tid = threadIdx.x, nt = blockDim.x;
+    const int n = S.n, no = S.no, nr = S.nr, ns = S.ns, tid = SRH_TID, nt = blockDim.x;
     T.jcap = jcap;
     T.R = base; T.W = T.R + (size_t)n * nr; T.Bg = T.W + (size_t)no * ns;
     liptr ip = (liptr)(T.Bg + (size_t)n * 16);
@@ -447,7 +447,7 @@ __device__ inline void basis_l(const liptr ex, const liptr par, const liptr var,
                                int dim, clptr x, lptr phi, lptr D) {
     for (int d = 0; d < order; ++d) {
         const int j0 = lv[d], j1 = lv[d + 1];
-        for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        for (int j = j0 + SRH_TID; j < j1; j += blockDim.x) {
             const int pj = par[j];
             phi[j] = (pj < 0 ? 1.0 : phi[pj]) * x[var[j]];
         }
@@ -455,7 +455,7 @@ __device__ inline void basis_l(const liptr ex, const liptr par, const liptr var,
     }
     if (D != nullptr) {
         const int tot = nmon * dim, nt = blockDim.x;
-        for (int e0 = threadIdx.x; e0 < tot; e0 += 4 * nt) {          // four entries per trip: their table look-ups overlap
+        for (int e0 = SRH_TID; e0 < tot; e0 += 4 * nt) {          // four entries per trip: their table look-ups overlap
             int q[4], ee[4];
             double pv[4];
 #pragma unroll
@@ -472,7 +472,7 @@ __device__ inline void basis_l(const liptr ex, const liptr par, const liptr var,
 // continuous Jacobians + affine remainder from the LDS tables (the front part of `linearize`); ends with a sync
 __device__ inline void jacobians_l(const SsmDev &S, const SsmLds &T, bool dm, clptr x, clptr u, Work &w, lptr A, int lda, lptr Bm,
                                    lptr d) {
-    const int n = S.n, m = S.m, nr = S.nr, tid = threadIdx.x, nt = blockDim.x;
+    const int n = S.n, m = S.m, nr = S.nr, tid = SRH_TID, nt = blockDim.x;
     clptr Bg = T.Bg;
     if (T.jcap > 0) {
         // Round 5: only the structural non-zeros of d phi / d x.  A[i][j] = sum_k R[i][k] D[k][j] runs over the monomials that
@@ -587,7 +587,7 @@ __device__ inline void jacobians_l(const SsmDev &S, const SsmLds &T, bool dm, cl
 
 // z = W phi_s(x) from the LDS tables (no Jacobian); ends with a sync
 __device__ inline void observe_l(const SsmDev &S, const SsmLds &T, clptr x, Work &w, lptr z) {
-    const int no = S.no, ns = S.ns, tid = threadIdx.x, nt = blockDim.x;
+    const int no = S.no, ns = S.ns, tid = SRH_TID, nt = blockDim.x;
     basis_l(T.es, T.ps, T.vs, T.dms, T.lvs, S.order_s, ns, no, x, w.phi, (lptr) nullptr);
     const int g8 = tid & 7;
     for (int o0 = 0; o0 < no; o0 += nt / 8) {

@@ -23,7 +23,7 @@ namespace tpwl {
 // global, x = [v; q]).  Executed by ONE wave (64 lanes); every lane returns the index.
 template <typename XP>
 __device__ inline int nearest_wave(const TpwlDev &T, XP x) {
-    const int lane = threadIdx.x & 63;
+    const int lane = SRH_TID & 63;
     double best = INFINITY;
     int besti = 0x7fffffff;
     // sum_j (tab[j][i] - x[xoff + j])^2 in the order j = 0, 1, ...: eight table / state loads are requested before the
@@ -72,7 +72,7 @@ __device__ inline int nearest_wave(const TpwlDev &T, XP x) {
 // ds_bpermute per state (6-8 k clocks; 60 k per SCP iteration at C2).  Same sums in the same order, same first minimum.
 template <typename XP, typename IP>
 __device__ inline void nearest_many(const TpwlDev &T, XP X, int ldx, int count, IP idx) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(SRH_TID >> 6), nw = blockDim.x >> 6, lane = SRH_TID & 63;
     if (T.w_v == 0.0 && T.P <= 64 && T.r <= 32 && count >= 2 * nw) {            // (fewer states than two rounds: the table load does not pay)
         const int r = T.r;
         const bool live = lane < T.P;
