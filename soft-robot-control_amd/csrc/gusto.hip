@@ -41,8 +41,10 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     qp_lds_carve(L, (lptr)smem, d, NTHREADS);          // qp::solve fills the constants of the layout it uses
     const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
-    const int tid = SRH_TID, nt = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    int tid = SRH_TID;                                 // re-read at the top of every SCP iteration (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6;
+    int lane = tid & 63;
     gptr base = (gptr)(b.work + p * b.work_stride);
     QPWork w;
     qp_carve(w, base, d);
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
 
     QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
+        tid = SRH_TID; lane = tid & 63;
         QPData q{x0, xk, (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr), (cgptr)(b.zf ? b.zf + p * nz : nullptr),
                  (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
         double J;

@@ -855,7 +855,8 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, QCWork &qw, Lds &L
 template <int MSEL, int NSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                      lptr smem, QPLds &Lq, int *iters_out, QPWork &wout) {
-    const int tid = SRH_TID, nt = blockDim.x;
+    int tid = SRH_TID;                                       // re-read at the top of every interior-point iteration (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
     QPDims d = dfull;                               // the QP without its trust-region rows
     d.tr = 0;
     d.nrx = d.nX;
@@ -924,6 +925,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
     double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
     bool near_opt = false;
     while (true) {
+        tid = SRH_TID;
         QC_LAP(7);
         // ---------------- rows: weights D and gradient shifts rho of this Newton system -> L2 for the stage sums
         double musum = 0.0, rpm = 0.0;

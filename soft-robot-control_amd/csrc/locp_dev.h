@@ -1072,7 +1072,8 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
     // (t = max(-g(u), floor), lam = max(lam, floor), no starting system); a warm attempt that fails is repeated cold.
     // pass_out: -1 condensed path, 0 relaxed Riccati pass, 1 full QP -- what produced the result.
     constexpr double WARM_FLOOR = 1e-2;
-    const int tid = SRH_TID, nt = blockDim.x;
+    int tid = SRH_TID;                                       // re-read at the top of every interior-point iteration (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
     int status = 1, it = 0;
     if (pass_out) *pass_out = -1;
     double J = 0.0;
@@ -1189,6 +1190,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
             mode = PRED;
         }
         while (true) {
+            tid = SRH_TID;
             // ---------------- rows: weights D and gradient shifts rho for this Newton system
             if (mode != CORR) {
                 rows_apply(d, c, w.x, w.s, w.u, w.rg);

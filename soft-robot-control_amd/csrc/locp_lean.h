@@ -943,7 +943,8 @@ __device__ __forceinline__ void newton_solve(const QPDims &d, const GP &g, Lds &
 template <int MSEL, int NSEL>
 __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                    Lds &L, QPLds &Lq, int *iters_out, QPWork &wout, long long *prof) {
-    const int tid = SRH_TID, nt = blockDim.x;
+    int tid = SRH_TID;                                       // re-read at the top of every interior-point iteration (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
     d.nrx = d.nX;
@@ -1026,6 +1027,7 @@ __device__ __forceinline__ int ipm(const QPDims &dfull, const QPConst &c, const 
     double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
     bool near_opt = false;
     while (true) {
+        tid = SRH_TID;
         QL_LAP(7);
         double musum = 0.0, rpm = 0.0;
 #pragma unroll
@@ -1200,7 +1202,8 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     // (GustoPar::poison_warm, SRH_LEAN_POISON_WARM=1 at plan creation) that makes the warm attempt fail so that the caller's cold
     // retry runs under a test
     const bool warm = warm_mode != 0, poison = warm_mode == 2;
-    const int tid = SRH_TID, nt = blockDim.x;
+    int tid = SRH_TID;                                       // re-read at the top of every interior-point iteration (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
     d.nrx = d.nX;
@@ -1333,6 +1336,7 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
         mode = PRED;
     }
     while (true) {
+        tid = SRH_TID;
         QB_LAP(7);
         // ---------------- rows -> weights, gradient shifts, and their per-stage sums, all in place
         double musum = 0.0, rpm = 0.0;
@@ -1574,7 +1578,8 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
                                         Lds &L, int *iters_out, QPWork &wout, long long *prof, int warm_mode = 0) {
     static_assert(MSEL == 4 || MSEL == 8, "one-wave interior point: n_u = 4 or 8");
     const bool warm = warm_mode != 0, poison = warm_mode == 2;
-    const int tid = SRH_TID, nt = blockDim.x;
+    int tid = SRH_TID;                                       // re-read at the top of every interior-point iteration (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
     QPDims d = dfull;
     d.tr = 0;
     d.nrx = d.nX;
@@ -1717,6 +1722,7 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
             mode = PRED;
         }
         while (true) {
+            tid = SRH_TID;
             // ---------------- rows -> weights, gradient shifts, per-stage sums
             double musum = 0.0, rpm = 0.0;
             double Du[2] = {0.0, 0.0}, rhu[2] = {0.0, 0.0}, Dx = 0.0, rhx = 0.0;
