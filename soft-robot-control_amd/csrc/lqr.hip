@@ -472,7 +472,8 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
     cgptr zref = MODEL == 0 ? T.z_ref : S.z_ref;
     const size_t lstride = (size_t)n * n + (size_t)n * m + n;
     const size_t p = blockIdx.x;
-    const int tid = SRH_TID, nt = blockDim.x;
+    int tid = SRH_TID;                                  // re-read at the top of every stage of the passes (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
     cgptr x0 = (cgptr)a.x0 + p * n, ztar = (cgptr)a.z_target + p * (size_t)(N + 1) * nz;
     cgptr Qg = (cgptr)a.Q, Rg = (cgptr)a.R, Qfg = (cgptr)a.Qf;
     gptr X = (gptr)a.x + p * (size_t)(N + 1) * n, U = (gptr)a.u + p * (size_t)N * m;
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
         for (int e = tid; e < n; e += nt) { L.v1[e] = x0[e]; xo[e] = x0[e]; }
         __syncthreads();
         for (int t = 0; t < N; ++t) {
+            tid = SRH_TID;
             FP_T0();
             // u_t = u_prev + alpha k + K (x - x_prev)
             if (tid < m) {
@@ -776,6 +778,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
             };
             bool restart = false;
             for (int t = N - 1; t >= 0; --t) {
+                tid = SRH_TID;
                 cgptr Ag, Bg;
                 if constexpr (MODEL == 0) {
                     const size_t i = (size_t)idx[t];
@@ -839,6 +842,7 @@ __global__ __launch_bounds__(NTH) void ilqr_kernel(TpwlDev T, SsmDev S, IlqrArgs
             bool restart = false;
             int psel = -1;                                     // TPWL region whose [A | B] is in the panel
             for (int t = N - 1; t >= 0; --t) {
+                tid = SRH_TID;
                 cgptr Ag, Bg;
                 bool load_panel = true;
                 if constexpr (MODEL == 0) {
