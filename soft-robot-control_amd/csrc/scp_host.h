@@ -67,15 +67,16 @@ static void jacobi_eig(std::vector<double> A, int n, std::vector<double> &w, std
 // Gram tile tasks of the lean kernels: tile row I (KT - I upper tiles, k-steps = min(N, 8 (I + 1)) m / 4 each) is cut into chunks
 // of at most 4 tiles that share the A operand; the chunks go to the waves longest first onto the least loaded wave (waves w and
 // w + 4 share a SIMD and its MFMA pipe: a quarter of the partner's load counts).  The cost of a chunk of nJ tiles over ks k-steps
-// is what the per-wave clocks of the profile build say (round 5, C2: t ~ 0.064 nJ ks + 0.034 ks + 0.16 nJ k clocks -- the MFMAs,
-// the operand loads + 1 / D product of a k-step, the epilogue of a tile): in MFMA units nJ ks + 0.53 ks + 2.5 nJ.  The chunk size
+// is what the per-wave clocks of the profile build say (round 5, C2, on the kernel without scratch: t ~ 0.034 nJ ks + 0.07 ks +
+// 0.75 nJ k clocks -- the MFMAs, the operand loads + 1 / D product of a k-step, the epilogue of a tile; the MFMA pipe of a SIMD is shared
+// by its two waves and is not what a wave waits for): in MFMA units nJ ks + 2.1 ks + 22 nJ.  The chunk size
 // of every tile row is searched exhaustively (4^KT greedy assignments, KT <= 8: milliseconds at plan creation) for the smallest
 // maximum load -- the one-size rule of round 4 left the busiest wave 24 % above the mean.  Output: nw x 4 x {I, J0, nJ, 0}.
 static bool lean_gram_schedule(int N, int m, int KT, int nw, std::vector<int> &out) {
     struct Task { int I, J0, nJ; double cost; };
     if (KT < 1 || KT > 8 || nw < 1 || nw > 16) return false;
     auto ksteps = [&](int I) { return std::min(N, 8 * (I + 1)) * (m / 4); };
-    auto cost = [&](int I, int nJ) { const double ks = ksteps(I); return nJ * ks + 0.53 * ks + 2.5 * nJ; };
+    auto cost = [&](int I, int nJ) { const double ks = ksteps(I); return nJ * ks + 2.1 * ks + 22.0 * nJ; };
     double best_max = 0.0, best_sum = 0.0;
     bool have = false;
     std::vector<Task> tasks;
