@@ -69,7 +69,7 @@ struct QPConst {                       // shared by the whole batch (HBM/L2 resi
     cgptr Sc, ScN;                     // (po x po): 2 H^T Qz H = C_o^T Sc C_o (+ the terminal 2 H^T Qzf H for ScN)
     cgptr Tx, Txf;                     // (nX x po), (nXf x po): X.A = Tx C_o, Xf.A = Txf C_o
     cgptr Cz2, Czf2;                   // (po x nz): C_o H^T 2 Qz, C_o H^T 2 Qzf
-    cgiptr gram_sched;                 // lean kernels: tile tasks of the Gram product, 8 waves x 4 tasks x {I, J0, nJ, 0}
+    cgiptr gram_sched;                 // lean kernels: tile tasks of the Gram product, ql::GRAM_TASKS x {I, J0, nJ, 0}, longest first (pulled by the waves)
 };
 
 struct QPDyn {                         // stage dynamics: matrix k at base + idx[k]*size (idx null: k)

@@ -44,6 +44,7 @@ constexpr int YPAD = 48;               // zeros behind the y-space vectors that 
 // condense(): item slots per wave.  A stage has at most KT * (NPa / 16) MFMA items spread over the 8 waves; the host only
 // enables the lean path when they fit (scp_host.h:build_consts) -- an item past the last slot would silently never be written.
 constexpr int CONDENSE_SLOTS = 5;
+constexpr int GRAM_TASKS = 32;         // entries of QPConst::gram_sched ({I, J0, nJ, 0}, longest first, nJ = 0 behind the last one)
 __host__ __device__ inline bool condense_fits(const QPDims &d, int nwaves) { return d.KT * (d.NPa / 16) <= nwaves * CONDENSE_SLOTS; }
 
 struct Sizes { size_t regX, thetaT, tiles, rinv, nm4, gt, ldi, ls, ldG, ua, tx, ld, idx; };
@@ -502,24 +503,25 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
 #else
 #define GR_LAP(i) ((void)0)
 #endif
+    // The tile tasks are PULLED: the list (longest first, scp_host.h) goes into LDS beside a counter, a wave that has finished a task
+    // takes the next one -- the static assignment of round 5a left the busiest wave 40 % behind the first one to finish whatever
+    // cost model placed the tasks (the waves of a SIMD share its MFMA pipe, the L2 head of G is slower than its LDS tail, ...).
+    // The list lives in the reduction scratch of the products (L.part: free during the Gram fill).  Which wave computes a tile
+    // does not change its bits.
+    liptr tl = (liptr)L.part;                                  // [0] next task, [4 + 4 t ..] = {I, J0, nJ, 0} of task t
+    if (tid < GRAM_TASKS * 4) tl[4 + tid] = c.gram_sched[tid];
+    if (tid == 0) tl[0] = 0;
     for (int e = tid; e < N * M; e += nt) { const double s = L.Ldi[e]; w2[e] = s * s; }
     __syncthreads();
     GR_LAP(0);
-    // this wave's tasks: all descriptors requested at once (one L2 latency instead of one per task)
-    int tI[4], tJ0[4], tnJ[4];
-#pragma unroll
-    for (int slot = 0; slot < 4; ++slot) {
-        cgiptr task = c.gram_sched + (wave * 4 + slot) * 4;
-        tI[slot] = task[0]; tJ0[slot] = task[1]; tnJ[slot] = task[2];
-    }
-#pragma unroll
-    for (int slot = 0; slot < 4; ++slot) {
-        tI[slot] = __builtin_amdgcn_readfirstlane(tI[slot]); tJ0[slot] = __builtin_amdgcn_readfirstlane(tJ0[slot]);
-        tnJ[slot] = __builtin_amdgcn_readfirstlane(tnJ[slot]);
-    }
-    GR_LAP(1);
-    for (int slot = 0; slot < 4; ++slot) {
-        const int I = tI[slot], J0 = tJ0[slot], nJ = tnJ[slot];
+    while (true) {
+        int tnext = 0;
+        if (lane == 0) tnext = __hip_atomic_fetch_add(tl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tnext = __builtin_amdgcn_readfirstlane(tnext);
+        if (tnext >= GRAM_TASKS) break;
+        const int I = __builtin_amdgcn_readfirstlane(tl[4 + 4 * tnext]), J0 = __builtin_amdgcn_readfirstlane(tl[5 + 4 * tnext]),
+                  nJ = __builtin_amdgcn_readfirstlane(tl[6 + 4 * tnext]);
+        GR_LAP(1);
         if (nJ == 0) break;
         wg::qp_d4 acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         const int jend = min(N, 8 * (I + 1));                  // stages with 2 j < 16 (I + 1)
@@ -621,16 +623,16 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
     }
     __syncthreads();
     GR_LAP(4);
-    // ---- symmetric scaling to a unit diagonal (see qpc::gram for why it matters): every wave scales the tiles it wrote
-    for (int slot = 0; slot < 4; ++slot) {
-        const int I = tI[slot], J0 = tJ0[slot], nJ = tnJ[slot];
-        if (nJ == 0) break;
-        for (int t = 0; t < nJ; ++t) {
-            lptr T = L.B + (size_t)qpc::tile_index(I, J0 + t, KT) * TSZ;
-            const double sc = L.ks[16 * (J0 + t) + l16];
+    // ---- symmetric scaling to a unit diagonal (see qpc::gram for why it matters): the upper tiles over the waves
+    for (int t = wave, I = 0, rowlen = KT; t < KT * (KT + 1) / 2; t += nt >> 6) {
+        int tt = t;
+        I = 0; rowlen = KT;
+        while (tt >= rowlen) { tt -= rowlen; ++I; --rowlen; }
+        const int J = I + tt;
+        lptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ;
+        const double sc = L.ks[16 * J + l16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int r = kk + 4 * q; T[r * TS + l16] *= L.ks[16 * I + r] * sc; }
-        }
+        for (int q = 0; q < 4; ++q) { const int r = kk + 4 * q; T[r * TS + l16] *= L.ks[16 * I + r] * sc; }
     }
     __syncthreads();
     GR_LAP(5);

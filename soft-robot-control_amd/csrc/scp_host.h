@@ -71,7 +71,7 @@ static void jacobi_eig(std::vector<double> A, int n, std::vector<double> &w, std
 // 0.75 nJ k clocks -- the MFMAs, the operand loads + 1 / D product of a k-step, the epilogue of a tile; the MFMA pipe of a SIMD is shared
 // by its two waves and is not what a wave waits for): in MFMA units nJ ks + 2.1 ks + 22 nJ.  The chunk size
 // of every tile row is searched exhaustively (4^KT greedy assignments, KT <= 8: milliseconds at plan creation) for the smallest
-// maximum load -- the one-size rule of round 4 left the busiest wave 24 % above the mean.  Output: nw x 4 x {I, J0, nJ, 0}.
+// maximum load -- the one-size rule of round 4 left the busiest wave 24 % above the mean.  Output: GRAM_TASKS x {I, J0, nJ, 0}, longest first, zeros behind the last task.
 static bool lean_gram_schedule(int N, int m, int KT, int nw, std::vector<int> &out) {
     struct Task { int I, J0, nJ; double cost; };
     if (KT < 1 || KT > 8 || nw < 1 || nw > 16) return false;
@@ -91,7 +91,7 @@ static bool lean_gram_schedule(int N, int m, int KT, int nw, std::vector<int> &o
             cd >>= 2;
             for (int J = I; J < KT; J += per) { const int nJ = std::min(per, KT - J); tasks.push_back({I, J, nJ, cost(I, nJ)}); }
         }
-        if ((int)tasks.size() > 4 * nw) continue;
+        if ((int)tasks.size() > 4 * nw || (int)tasks.size() >= ql::GRAM_TASKS) continue;
         std::stable_sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) { return a.cost > b.cost; });
         double load[16] = {0.0};
         int cnt[16] = {0};
@@ -114,7 +114,13 @@ static bool lean_gram_schedule(int N, int m, int KT, int nw, std::vector<int> &o
         if (!ok) continue;
         double mx = 0.0, sum = 0.0;
         for (int w = 0; w < nw; ++w) { mx = std::max(mx, load[w]); sum += load[w]; }
-        if (!have || mx < best_max - 1e-9 || (mx < best_max + 1e-9 && sum < best_sum - 1e-9)) { have = true; best_max = mx; best_sum = sum; out = cur; }
+        if (!have || mx < best_max - 1e-9 || (mx < best_max + 1e-9 && sum < best_sum - 1e-9)) {
+            have = true; best_max = mx; best_sum = sum;
+            // what the kernel gets: the chunks of this cut, longest first -- its waves PULL them (ql::gram); the greedy assignment above
+            // only ranks the cuts
+            out.assign((size_t)ql::GRAM_TASKS * 4, 0);
+            for (size_t t = 0; t < tasks.size(); ++t) { out[4 * t] = tasks[t].I; out[4 * t + 1] = tasks[t].J0; out[4 * t + 2] = tasks[t].nJ; }
+        }
     }
     return have;
 }
