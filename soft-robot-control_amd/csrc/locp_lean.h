@@ -668,7 +668,7 @@ __device__ __forceinline__ void set_wait(liptr c, int v) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void panel_tile(Lds &L, int KT, int J, int Jp, int l16, int kk) {      // R_JJ' = Rinv_J^T K_JJ'
+__device__ __forceinline__ wg::qp_d4 panel_tile(Lds &L, int KT, int J, int Jp, int l16, int kk) {      // R_JJ' = Rinv_J^T K_JJ' (returned as well)
     clptr Ri = L.Rinv + (size_t)J * TSZ;
     lptr T = L.B + (size_t)qpc::tile_index(J, Jp, KT) * TSZ;
     double av[4], bv[4];
@@ -677,6 +677,18 @@ __device__ __forceinline__ void panel_tile(Lds &L, int KT, int J, int Jp, int l1
     wg::qp_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) T[(kk + 4 * qd) * TS + l16] = acc[qd];
+    return acc;
+}
+// T <- T - P^T P with P in the registers panel_tile() returned: the accumulator layout of the MFMA (lane (l16, kk): rows kk + 4 q) IS its
+// operand layout (k-step s: row 4 s + kk) -- the same products in the same order as qpc::tile_update(T, P, P), without reading P back
+__device__ __forceinline__ void tile_update_reg(lptr T, const wg::qp_d4 &P, int l16, int kk) {
+    wg::qp_d4 acc;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) acc[qd] = T[(kk + 4 * qd) * TS + l16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[s], P[s], acc, 0, 0, 0);
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) T[(kk + 4 * qd) * TS + l16] = acc[qd];
 }
@@ -699,14 +711,13 @@ __device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const
         for (int J = 0; J + 1 < KT; ++J) {
             set_wait(Fnext, 2 * J);                               // (J, J + 1) and (J + 1, J + 1) carry the updates of row J - 1
             TC_LAP(0);
-            panel_tile(L, KT, J, J + 1, l16, kk);
+            const wg::qp_d4 P = panel_tile(L, KT, J, J + 1, l16, kk);
             TC_LAP(1);
             set_signal(Fpanel);
             TC_LAP(4);
-            clptr Ra = L.B + (size_t)qpc::tile_index(J, J + 1, KT) * TSZ;
             lptr T = L.B + (size_t)qpc::tile_index(J + 1, J + 1, KT) * TSZ;
             __builtin_amdgcn_wave_barrier();
-            qpc::tile_update(T, Ra, Ra, l16, kk);
+            tile_update_reg(T, P, l16, kk);
             __builtin_amdgcn_wave_barrier();
             TC_LAP(2);
             ok = qpc::chol16<false>(T, L.Rinv + (size_t)(J + 1) * TSZ) && ok;
