@@ -1642,7 +1642,7 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
     int status = 1, it = 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (wave == 0) {
-        const int lane = tid, i16 = lane & 15, kk = lane >> 4;
+        int lane = tid, i16 = lane & 15, kk = lane >> 4;          // re-derived at the top of every iteration (SRH_TID)
         const int S = nm >> 2;                                     // k-steps of the products with G (n_u is a multiple of 4)
         // ---- G in registers, twice: by input row (gR) and in the MFMA operand layout (gM)
         const bool isu = lane < nm;
@@ -1735,7 +1735,7 @@ __device__ __forceinline__ int ipm_wave(const QPDims &dfull, const QPConst &c, c
             mode = PRED;
         }
         while (true) {
-            tid = SRH_TID;
+            tid = SRH_TID; lane = tid; i16 = lane & 15; kk = lane >> 4;
             // ---------------- rows -> weights, gradient shifts, per-stage sums
             double musum = 0.0, rpm = 0.0;
             double Du[2] = {0.0, 0.0}, rhu[2] = {0.0, 0.0}, Dx = 0.0, rhx = 0.0;
