@@ -147,21 +147,22 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                     for (int r = lane; r < n; r += 64) {
                         double fk = T.dc[ia * n + r], fl = 0.0, f = T.dc[ib * n + r];
                         cgptr Ak = T.AcT + ia * n * n, An = T.AcT + ib * n * n;
-                        for (int c0 = 0; c0 < n; c0 += 16) {
-                            double av[16], anv[16];
+                        constexpr int CH = same ? 32 : 16;           // columns in flight (registers: one matrix or two)
+                        for (int c0 = 0; c0 < n; c0 += CH) {
+                            double av[CH], anv[same ? 1 : CH];
 #pragma unroll
-                            for (int qq = 0; qq < 16; ++qq) {
+                            for (int qq = 0; qq < CH; ++qq) {
                                 const int cc = c0 + qq < n ? c0 + qq : n - 1;
                                 av[qq] = Ak[(size_t)cc * n + r];
                                 if constexpr (!same) anv[qq] = An[(size_t)cc * n + r];
                             }
 #pragma unroll
-                            for (int qq = 0; qq < 16; ++qq) {
+                            for (int qq = 0; qq < CH; ++qq) {
                                 if (c0 + qq < n) {
                                     const double xo = xo_[c0 + qq], xn = xn_[c0 + qq];
                                     fk = fma(av[qq], xo, fk);
                                     fl = fma(av[qq], xn - xo, fl);
-                                    f = fma(same ? av[qq] : anv[qq], xn, f);
+                                    f = fma(same ? av[qq] : anv[same ? 0 : qq], xn, f);
                                 }
                             }
                         }
@@ -216,8 +217,13 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
                     for (int e = tid; e < (N + 1) * d.nX; e += nt) {
                         const int k = e / d.nX, r = e - k * d.nX;
                         double v = -c.Xb[r];
-                        if (xal) { for (int j = 0; j < n; ++j) v = fma(XAl[r * n + j], Xn[(size_t)k * n + j], v); }
-                        else { for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], Xn[(size_t)k * n + j], v); }
+                        if (xal) {
+#pragma unroll 12
+                            for (int j = 0; j < n; ++j) v = fma(XAl[r * n + j], Xn[(size_t)k * n + j], v);
+                        } else {
+#pragma unroll 12
+                            for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], Xn[(size_t)k * n + j], v);
+                        }
                         vr[e] = fmax(v, 0.0);
                     }
                     __syncthreads();

@@ -2037,8 +2037,13 @@ __device__ __forceinline__ double objective_par(const QPDims &d, const QPConst &
     for (int e = SRH_TID; e < (N + 1) * nz; e += blockDim.x) {
         const int k = e / nz, a = e - k * nz;
         double v = q.z ? -q.z[e] : 0.0;
-        if (hl) { for (int j = 0; j < n; ++j) v = fma(Hl[a * n + j], x[(size_t)k * n + j], v); }
-        else { for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], x[(size_t)k * n + j], v); }
+        if (hl) {
+#pragma unroll 12
+            for (int j = 0; j < n; ++j) v = fma(Hl[a * n + j], x[(size_t)k * n + j], v);       // (twelve products' reads in flight: a thread walks 60 of them)
+        } else {
+#pragma unroll 12
+            for (int j = 0; j < n; ++j) v = fma(c.H[a * n + j], x[(size_t)k * n + j], v);
+        }
         ez[e] = v;
         if (hl) ezl[e] = v;
     }

@@ -26,20 +26,20 @@ __device__ inline int nearest_wave(const TpwlDev &T, XP x) {
     const int lane = SRH_TID & 63;
     double best = INFINITY;
     int besti = 0x7fffffff;
-    // sum_j (tab[j][i] - x[xoff + j])^2 in the order j = 0, 1, ...: eight table / state loads are requested before the
+    // sum_j (tab[j][i] - x[xoff + j])^2 in the order j = 0, 1, ...: sixteen table / state loads are requested before the
     // first FMA (a rolled load -> FMA loop pays the L2 latency r times per point; same sums, same order)
     auto sqdist = [&](cgptr tab, int xoff, int i) {
         double sq = 0.0;
-        for (int j0 = 0; j0 < T.r; j0 += 8) {
-            double tv[8], xv[8];
+        for (int j0 = 0; j0 < T.r; j0 += 16) {
+            double tv[16], xv[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 16; ++q) {
                 const int j = j0 + q < T.r ? j0 + q : T.r - 1;
                 tv[q] = tab[j * T.P + i];
                 xv[q] = x[xoff + j];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 16; ++q) {
                 if (j0 + q < T.r) { const double e = tv[q] - xv[q]; sq = fma(e, e, sq); }
             }
         }
