@@ -537,7 +537,10 @@ __device__ __forceinline__ void gram(const QPDims &d, const QPConst &c, const GP
             constexpr int nj = decltype(NJ)::value;
             int R = goff(jb, M, NP) + kk * (NP - 2 * jb) - 2 * jb + ia;           // R(jb, b = kk) + column of the A operand
             int dl = M * (NP - 2 * jb) - 2 * kk - 2;
-            constexpr int UN = 4 / SPS;                                      // stages per full trip: 4 k-steps
+#ifndef SRH_GRAM_KS
+#define SRH_GRAM_KS 4
+#endif
+            constexpr int UN = SRH_GRAM_KS / SPS;                            // stages per full trip: SRH_GRAM_KS k-steps
             auto trip = [&](int j0, auto UNS) {                              // UNS stages = UNS * SPS k-steps
                 constexpr int uns = decltype(UNS)::value, KS = uns * SPS;
                 double av[KS], bv[KS][nj];
