@@ -327,6 +327,66 @@ def scp_c5(_lib, rank, world, dist, total=256, max_iters=5, cpu=False):
                              'how': 'distributed.gather_rollout_costs: all_gather of the per-rollout optimal LOCP values (sgusto_plan_costs)'}}
 
 
+def scp_c2_r36(_lib, total=1024, max_iters=5, cpu_rollouts=64):
+    """C2 at the size of the reference's SHIPPED Diamond basis (examples/diamond/pod_model.pkl: r = 36, n_x = 72): the fixed-layout lean
+    instantiation <4, 72, 4, 50, 18, 4> and the split-panel fused kernel behind it; `total` rollouts, host buffers, best of 3 calls;
+    the native CPU twin on the first `cpu_rollouts` of them, all usable cores."""
+    import workloads as wl
+    from scipy.interpolate import interp1d
+    from sofacontrol_amd.mor.pod import POD
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2(r=36)
+    N, m, r, dt = w['N'], w['m'], w['r'], w['dt']
+    rom = POD(dict(U=w['U'], q_ref=w['q_ref'], v_ref=w['v_ref']))
+    tp, gm = build_model(w, 1354)
+    xc, fc = gm.get_characteristic_vals()
+    X = wl.snapshots(w['q_ref'], total, seed=2)
+    x0 = np.concatenate((np.zeros((total, r)), rom.compute_RO_state(qf=X)), axis=1)
+    u_init = np.zeros((total, N, m))
+    x_init, _ = tp.rollout(x0, u_init, dt)
+    zi = interp1d(w['t'], w['z'], axis=0, bounds_error=False, fill_value=(w['z'][0], w['z'][-1]))
+    z = np.stack([zi(b * (10.0 / total) + dt * np.arange(N + 1)) for b in range(total)])
+    g = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']), x_char=xc,
+              f_char=fc, convg_thresh=1e-3, batch=total, max_trace=0, max_gusto_iters=max_iters, first_solve_cap=max_iters)
+    _lib.sync()
+    els = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        g.solve_batch(x0, u_init, x_init, z=z)
+        els.append(time.perf_counter() - t0)
+    el, its = min(els), float(g.iters.sum())
+    g1 = GuSTO(gm, N, dt, w['Qz'], w['R'], x0[0], u_init[0], x_init[0], z=z[0], U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+               x_char=xc, f_char=fc, convg_thresh=1e-3, max_trace=0, max_gusto_iters=max_iters, first_solve_cap=max_iters)
+    per = []
+    for b in range(8):
+        bb = b * (total // 8)
+        t0 = time.perf_counter()
+        g1.solve(x0[bb], u_init[bb], x_init[bb], z=z[bb])
+        per.append((time.perf_counter() - t0) / max(1, int(g1.iters[0])))
+    cpu_entry = 'no twin run'
+    try:
+        from oracle import cpu_twin
+        model = dict(w['tab'], w_q=1.0, w_v=0.0)
+        ncpu, nb = usable_cpus(), min(total, cpu_rollouts)
+        t0 = time.perf_counter()
+        _, _, itc, _ = cpu_twin.gusto_solve(model, w['Ad'], w['Bd'], w['dd'], w['H'], N, dt, w['Qz'], w['R'], x0[:nb], u_init[:nb], x_init[:nb], z=z[:nb],
+                                            U=(w['UA'], w['Ub']), X=(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3,
+                                            max_gusto_iters=max_iters, threads=ncpu, algo='condensed')
+        tc = time.perf_counter() - t0
+        cpu_entry = {'what': 'native CPU twin (same algorithm), %d rollouts on %d threads' % (nb, ncpu), 'seconds': tc,
+                     'iterations_per_s': float(itc.sum()) / tc, 'iterations_equal_gpu': bool((itc == g.iters[:nb]).all()),
+                     'gpu_over_cpu_throughput': (its / el) / (float(itc.sum()) / tc)}
+    except Exception as exc:
+        cpu_entry = {'error': repr(exc)}
+    return {'workload': 'C2 at the shipped Diamond basis size: r = 36 (n_x = 72, n_u = 4), N = 50, dt = %g, U box + X box; %d rollouts, cap %d, '
+                        'host buffers; best of 3 calls' % (dt, total, max_iters),
+            'iterations_per_s': its / el, 'ms': el * 1e3, 'ms_all_calls': [e * 1e3 for e in els], 'iterations': its,
+            'ms_per_scp_iteration_one_rollout_median': sorted(per)[4] * 1e3,
+            'not_converged': int((g.status != 0).sum()), 'kernel': g.kernel_info['kernel'],
+            'rollouts_handed_to_fused_kernel': int(g.kernel_info['handed_over']), 'cpu': cpu_entry}
+
+
 def scp_single_rollout(w, gm, tp, xc, fc, x0, x_init, z, max_iters):
     """The reference's actual use: ONE receding-horizon solve at a time (scp/ros.py:94-127), C2 shape.  Wall time of
     GuSTO.solve through the host-pointer API (PCIe copies inside), per SCP iteration and per solve, against the replan
@@ -753,6 +813,11 @@ def secondary(L, _lib, rank, world, dist):
             out['scp_c5_weak'] = scp_c5(_lib, rank, world, dist, total=256 * world)
     except Exception as exc:
         out['scp_c5'] = {'error': repr(exc)}
+    if world == 1:
+        try:
+            out['scp_c2_r36'] = scp_c2_r36(_lib)
+        except Exception as exc:
+            out['scp_c2_r36'] = {'error': repr(exc)}
     return out
 
 
