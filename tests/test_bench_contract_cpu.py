@@ -7,10 +7,59 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest_log():
+    logs = sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if re.fullmatch(r'r\d+[a-z]?_bench\.log', f)),
+                  key=lambda f: (int(re.match(r'r(\d+)', f).group(1)), f))
+    return os.path.join(ROOT, 'profiles', logs[-1])
+
+
 def _last_line():
-    logs = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if re.fullmatch(r'r\d+[a-z]_bench\.log', f))
-    line = [l for l in open(os.path.join(ROOT, 'profiles', logs[-1])) if l.startswith('{"metric"')][-1]
+    line = [l for l in open(_newest_log()) if l.startswith('{"metric"')][-1]
     return json.loads(line)
+
+
+def test_committed_bench_line_is_small_enough_for_the_driver():
+    """Round 5 lost its record to a 20 KB line (the driver keeps a tail of stdout).  From round 6 on the LAST stdout line of
+    the committed run must parse alone and stay under bench.MAX_LINE; the full record sits on an earlier line."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    name = _newest_log()
+    if int(re.match(r'r(\d+)', os.path.basename(name)).group(1)) < 6:
+        import pytest
+        pytest.skip('no round-6 bench log committed yet')
+    lines = [l.rstrip('\n') for l in open(name) if l.strip()]
+    last = [l for l in lines if l.startswith('{')][-1]
+    assert last == lines[-1] or not lines[-1].startswith(('{', 'BENCH_DETAIL'))
+    assert len(last) <= bench.MAX_LINE == 4096
+    d = json.loads(last)
+    assert 'secondary' not in d and d['roofline']['frac'] > 0 and d['cpu_baseline']['value'] > 0
+    full = [l for l in lines if l.startswith('BENCH_DETAIL ')]
+    assert full and 'secondary' in json.loads(full[-1].split(' ', 1)[1])
+
+
+def test_compact_line_of_a_full_record_survives_a_4k_tail():
+    """The printing path of a real run (bench.emit) fed with round 5's 20 KB record through the stub device: the last stdout
+    line alone is the driver's line -- every contract key, roofline, cpu_baseline, parity_sample -- in < 4096 characters."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update({'SRH_BENCH_STUB_DEVICE': '1', 'SRH_BENCH_STUB_RECORD': os.path.join(ROOT, 'profiles', 'r05_bench.log')})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    tail = out.stdout[-4096:]                      # what a driver that keeps 4 KB of stdout would hold
+    last = tail.strip().splitlines()[-1]
+    assert len(last) < 4096 and last.startswith('{"metric"')
+    d = json.loads(last)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity_sample'):
+        assert k in d, k
+    assert 'secondary' not in d
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline'])
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-4
+    full = [l for l in out.stdout.splitlines() if l.startswith('BENCH_DETAIL ')]
+    assert len(full) == 1 and 'secondary' in json.loads(full[0].split(' ', 1)[1])
 
 
 def test_bench_line_schema():
@@ -28,7 +77,7 @@ def test_bench_line_schema():
         assert d['metric'] == base['metric'] or base['metric'] in d['metric'] or d['metric'] in base['metric']
     r = d['roofline']
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and (r['traffic'] is None or r['traffic'] > 0)
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4 and (r['traffic'] is None or r['traffic'] > 0)
     c = d['cpu_baseline']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
     assert d['value'] > 0 and d['ms_per_step'] > 0

@@ -1,8 +1,10 @@
 """profiles/<tag>_kernel_resource_usage.txt from the device assembly the build keeps next to every object (csrc/<unit>.s,
 tools/hipcc_guarded.sh): the .amdhsa metadata of every kernel -- registers, scratch, spills, LDS -- one line per instantiation.
-Usage: python3 tools/kernel_resource_usage.py r04"""
+Usage: python3 tools/kernel_resource_usage.py r06"""
 import glob, os, re, subprocess, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+if len(sys.argv) < 2:
+    raise SystemExit('usage: python3 tools/kernel_resource_usage.py <round tag, e.g. r06>  (no default: a default once overwrote an older round\'s file)')
+TAG = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = ['# .amdhsa kernel metadata of soft-robot-control_amd/csrc/*.s (hipcc -O3 --offload-arch=gfx950, ROCm 7.2), %s tree; one line per kernel instantiation' % TAG,
        '# lean kernels: <n_u, n_x, GX lanes per stage (0: general rows), fixed horizon (0: run time), first resident stage, state rows>',

@@ -1,4 +1,5 @@
 cd /tmp; export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/../.." && pwd)}"; export GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $R/gpurun_out/pmc_l2a -o a -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > $R/gpurun_out/pmc_l2a.log 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/gpurun_out/pmc_l2b -o b -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > $R/gpurun_out/pmc_l2b.log 2>&1

@@ -9,7 +9,7 @@ timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "py
 timeout 900 python bench.py > $O/bench.log 2> $O/bench.err; echo "bench rc $?"
 bash tools/prof_round.sh $TAG > $O/prof_round.log 2>&1; echo "prof rc $?"; tail -2 $O/prof_round.log
 timeout 600 python tools/probes/lean_phase_clocks.py $O/lean_phase_clocks.json > $O/phase.log 2>&1
-python tools/probes/summarise_phase_clocks.py profiles/r05a_lean_phase_clocks_raw.json $O/lean_phase_clocks.json $O/${TAG}_lean_phase_clocks.json
+python tools/probes/summarise_phase_clocks.py ${PHASE_RAW:-profiles/${TAG}a_lean_phase_clocks_raw.json} $O/lean_phase_clocks.json $O/${TAG}_lean_phase_clocks.json
 timeout 300 python tools/determinism_probe.py c2 > $O/determinism.log 2>&1; tail -3 $O/determinism.log
 timeout 300 python tools/time_c3.py > $O/time_c3.log 2>&1; tail -6 $O/time_c3.log
 mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null; ls gpurun_out/profiles_$TAG
