@@ -96,6 +96,11 @@ int srom_lift_dev(srom_t *h, int which, const double *Xr_dev, int64_t B, int64_t
 int srom_reduce_matrix(srom_t *h, const double *M, int64_t ncols, int left, int right, double *out);
 int srom_reduce_matrix_dev(srom_t *h, const double *M_dev, int64_t ncols, int left, int right,
                            double *out_dev, void *stream);
+/* The same U^T M U for `count` dense n_f x n_f matrices in one call: TPWLSnapshotData.add_point reduces K, D, M and S of one
+ * linearisation point back to back (tpwl/tpwl_utils.py:96-103 -> pod.py:56-72); groups of four share ONE launch pair.  M / out:
+ * arrays of `count` pointers (row-major n_f x n_f in, r x r out). */
+int srom_reduce_matrices(srom_t *h, const double *const *M, int count, double *const *out);
+int srom_reduce_matrices_dev(srom_t *h, const double *const *M_dev, int count, double *const *out_dev, void *stream);
 
 /* Snapshot Gramian G = S S^T, S (n_s x n_f) row-major, G (n_s x n_s): the method-of-snapshots route
  * to compute_POD (pod.py:181-200: sigma_i = sqrt(eig_i(G)), U = S^T W Sigma^-1).  With S sharded by

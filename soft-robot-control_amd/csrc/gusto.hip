@@ -56,6 +56,23 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     giptr idx2 = idx + N;
 
     cgptr x0 = (cgptr)(b.x0 + p * n);
+    cgptr zp = (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr);
+    cgptr zfp = (cgptr)(b.zf ? b.zf + p * nz : nullptr);
+    cgptr udp = (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr);
+    if (b.host_args) {
+        // zero-copy solve: the arguments sit in pinned host memory -- work on copies in the work block (mode 2: the lean kernel made them)
+        gptr x0c = base + gw.x0c, zc = base + gw.zc, zfc = base + gw.zfc, udc = base + gw.udc;
+        if (b.mode != 2) {
+            for (int e = tid; e < n; e += nt) x0c[e] = x0[e];
+            if (zp) for (int e = tid; e < (N + 1) * nz; e += nt) zc[e] = zp[e];
+            if (zfp) for (int e = tid; e < nz; e += nt) zfc[e] = zfp[e];
+            if (udp) for (int e = tid; e < N * m; e += nt) udc[e] = udp[e];
+        }
+        x0 = (cgptr)x0c;
+        if (zp) zp = (cgptr)zc;
+        if (zfp) zfp = (cgptr)zfc;
+        if (udp) udp = (cgptr)udc;
+    }
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
     bool converged = false;
@@ -80,8 +97,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     QPDyn dyn{T.Ad, T.AdT, T.Bd, T.BdT, T.dd, (cgiptr)idx};
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
         tid = SRH_TID; lane = tid & 63;
-        QPData q{x0, xk, (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr), (cgptr)(b.zf ? b.zf + p * nz : nullptr),
-                 (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
+        QPData q{x0, xk, zp, zfp, udp, delta, omega, (gptr)nullptr};
         double J;
         int qit;
         GU_LAP(1);
@@ -435,7 +451,8 @@ static int solve_dev_impl(sgusto_plan_t *pl, const double *x0, const double *u_i
     SRH_REQUIRE(!pl->pending || (pl->astream && stream == (void *)pl->astream && pl->launching),
                 "sgusto_plan_solve_dev: an asynchronous request is in flight on this plan (call sgusto_plan_solve_end first)");
     GustoBatch b{x0, u_init, x_init, z, zf, u_des, pl->fs.as<double>(), xopt, uopt, zopt, iters, status, trace,
-                 pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>(), 0, pl->handed.as<int32_t>(), pl->Jopt.as<double>()};
+                 pl->work.as<double>(), pl->work_stride, nullptr, pl->last_iters.as<int32_t>(), 0, pl->handed.as<int32_t>(), pl->Jopt.as<double>(),
+                 phase != 0 ? 1 : 0};        // phases 1 / 2 = the zero-copy host path: pinned host arguments
     if (pl->have_last && pl->batch > 256 && pl->use_lpt) {      // more rollouts than CUs: order matters
         lpt_order_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pl->last_iters.as<int32_t>(), pl->batch, pl->order.as<int32_t>());
         b.order = pl->order.as<int32_t>();

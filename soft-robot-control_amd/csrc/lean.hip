@@ -57,14 +57,20 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
 
     cgptr x0 = (cgptr)(b.x0 + p * n);
     cgptr zp = (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr);
-    if constexpr (NST < 0) {
-        // short horizons are solved one at a time through the zero-copy host path (gusto.hip): x0 and the target would be read
-        // across PCIe by every QP -- keep copies in the work block
-        gptr x0c = base + gw.x0c, zc = base + gw.zc;
+    cgptr zfp = (cgptr)(b.zf ? b.zf + p * nz : nullptr);
+    cgptr udp = (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr);
+    if (NST < 0 || b.host_args) {
+        // zero-copy solves (gusto.hip) pass pinned HOST pointers: x0, the targets and the desired inputs would be read across PCIe by every
+        // QP and interior-point iteration -- keep copies in the work block (the fused kernel finds them there when it resumes a rollout)
+        gptr x0c = base + gw.x0c, zc = base + gw.zc, zfc = base + gw.zfc, udc = base + gw.udc;
         for (int e = tid; e < n; e += nt) x0c[e] = x0[e];
         if (zp) for (int e = tid; e < (N + 1) * nz; e += nt) zc[e] = zp[e];
+        if (zfp) for (int e = tid; e < nz; e += nt) zfc[e] = zfp[e];
+        if (udp) for (int e = tid; e < N * m; e += nt) udc[e] = udp[e];
         x0 = (cgptr)x0c;
         if (zp) zp = (cgptr)zc;
+        if (zfp) zfp = (cgptr)zfc;
+        if (udp) udp = (cgptr)udc;
     }
     for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = b.x_init[p * (size_t)(N + 1) * n + e];
     for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
@@ -80,8 +86,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     int itr = 0, status = 0;
     while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
         tid = SRH_TID; lane = tid & 63;
-        QPData q{x0, xk, zp, (cgptr)(b.zf ? b.zf + p * nz : nullptr),
-                 (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr), delta, omega, (gptr)nullptr};
+        QPData q{x0, xk, zp, zfp, udp, delta, omega, (gptr)nullptr};
         double J;
         int qit;
         GU_LAP(1);

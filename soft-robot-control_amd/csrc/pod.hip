@@ -17,6 +17,7 @@
 //   * small B (closed-loop single vector, pod.py:51-52 via tpwl/controllers.py:96) uses split-K over
 //     workgroups with a fixed-order second-stage reduction (deterministic, no atomics).
 #include "common.h"
+#include <vector>
 #include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -50,6 +51,7 @@ struct ProjArgs {
     int r;
     int nchunks, chunks_per_split;
     const double *Urows;  // UTMU only: the basis, row-major (n_f x r)
+    const double *Xm[4];  // UTMU only: the matrices of one launch (blockIdx.z selects; srom_reduce_matrices_dev), Xm[0] == X
 };
 
 __global__ void pack_u_kernel(const double *__restrict__ U, int64_t n_f, int r, int NTF, int NQ, int nchunks,
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = blockIdx.z;
-    const double *X = a.X + (int64_t)blk * a.x_blk_off;
+    const double *X = UTMU ? a.Xm[blk] : a.X + (int64_t)blk * a.x_blk_off;
     const double *ref = blk ? a.ref1 : a.ref0;
     const int c0 = blockIdx.y * a.chunks_per_split;
     const int c1 = min(c0 + a.chunks_per_split, a.nchunks);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
             }
         }
         __syncthreads();
-        double *P = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (LDP * LDP);
+        double *P = a.partial + (((int64_t)blk * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (LDP * LDP);
         for (int t = wave; t < NTT * NTT; t += 4) {
             const int ti = t / NTT, tj = t - ti * NTT;
             d4 pa = d4{0.0, 0.0, 0.0, 0.0};
@@ -359,7 +361,10 @@ __global__ void splitk_reduce_wave_kernel(const double *__restrict__ partial, in
 // measured at 14 us: the device-scope release / acquire around the arrival counter write back and invalidate L2; a
 // sector-wise form (one wave per eight consecutive entries, whole 64-byte sectors per lane) measured the same 5.2 us:
 // the time is the kernel boundary itself (write-back of the partials, launch, first misses), not the access pattern.
-__global__ void utmu_reduce_kernel(const double *__restrict__ partial, int nwg, int ldp, int r, double *__restrict__ out) {
+struct UtmuOuts { double *out[4]; };
+__global__ void utmu_reduce_kernel(const double *__restrict__ partial_all, int nwg, int ldp, int r, UtmuOuts outs) {
+    const double *__restrict__ partial = partial_all + (int64_t)blockIdx.y * nwg * ldp * ldp;      // blockIdx.y: matrix of the launch
+    double *__restrict__ out = outs.out[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (idx >= r * r) return;
@@ -932,6 +937,53 @@ static int atb_dev(srom *h, const double *T, int64_t ldt, int c, double *out, in
     return SRH_OK;
 }
 
+// U^T M_i U for up to four n_f x n_f matrices in ONE launch pair: every workgroup turns its tile of T = M_i U into an r x r partial
+// U[rows]^T T (proj_kernel<..., UTMU>, blockIdx.z = i), then one reduction launch sums the partials of every matrix in a fixed order.
+// The caller of the reference reduces K, D, M and S of the same linearisation point back to back (tpwl/tpwl_utils.py:96-103): four
+// matrices per launch pay the launch ramp, the epilogue every workgroup reaches at the same moment and the second launch once.
+static int utmu_one_pass(srom *h, const double *const *Ms, int count, double *const *outs, hipStream_t s) {
+    SRH_REQUIRE(count >= 1 && count <= 4, "utmu_one_pass: 1..4 matrices per launch");
+    ProjArgs a{};
+    a.X = Ms[0]; a.ldx = h->n_f; a.ufrag = h->ufrag.as<double>(); a.B = h->n_f; a.n_f = h->n_f; a.r = h->r;
+    a.nchunks = h->nchunks; a.Urows = h->U.as<double>();
+    bool vec2 = h->n_f % 2 == 0;
+    for (int i = 0; i < 4; ++i) {
+        a.Xm[i] = Ms[i < count ? i : 0];
+        vec2 = vec2 && ((reinterpret_cast<uintptr_t>(a.Xm[i]) & 15) == 0);
+    }
+    const int64_t rowtiles = srh::cdiv(h->n_f, ROWS_WG);
+    int ksplit = proj_ksplit(h, h->n_f, 1, &a.chunks_per_split);
+    if (const char *e = getenv("SRH_UTMU_KSPLIT")) {       // A/B: K-slices per row tile (default: ~512 workgroups)
+        const int want = std::max(1, std::min(atoi(e), h->nchunks));
+        a.chunks_per_split = (int)srh::cdiv(h->nchunks, want);
+        ksplit = (int)srh::cdiv(h->nchunks, a.chunks_per_split);
+    }
+    const int ldp = 16 * (h->NTF + (h->NQ ? 1 : 0));
+    const int nwg = (int)(rowtiles * ksplit);
+    int rc = ensure_work(h, sizeof(double) * (size_t)count * nwg * ldp * ldp);
+    if (rc) return rc;
+    a.partial = h->work.as<double>();
+    dim3 grid((unsigned)rowtiles, (unsigned)ksplit, (unsigned)count);
+    switch (4 * h->NTF + h->NQ) {
+#define SRH_UTMU_CASE(F, Q) case 4 * F + Q: rc = launch_utmu<F, Q>(a, vec2, grid, s); break;
+        SRH_UTMU_CASE(0, 1) SRH_UTMU_CASE(0, 2) SRH_UTMU_CASE(0, 3)
+        SRH_UTMU_CASE(1, 0) SRH_UTMU_CASE(1, 1) SRH_UTMU_CASE(1, 2) SRH_UTMU_CASE(1, 3)
+        SRH_UTMU_CASE(2, 0) SRH_UTMU_CASE(2, 1) SRH_UTMU_CASE(2, 2) SRH_UTMU_CASE(2, 3)
+        SRH_UTMU_CASE(3, 0) SRH_UTMU_CASE(3, 1) SRH_UTMU_CASE(3, 2) SRH_UTMU_CASE(3, 3)
+        SRH_UTMU_CASE(4, 0)
+#undef SRH_UTMU_CASE
+        default:
+            srh::set_error("srom_reduce_matrix_dev: no kernel for r = %d", h->r);
+            return SRH_EINVAL;
+    }
+    if (rc) return rc;
+    UtmuOuts uo{};
+    for (int i = 0; i < 4; ++i) uo.out[i] = outs[i < count ? i : 0];
+    utmu_reduce_kernel<<<dim3((unsigned)srh::cdiv(h->r * h->r, 4), (unsigned)count), 256, 0, s>>>(a.partial, nwg, ldp, h->r, uo);
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+
 int srom_reduce_matrix_dev(srom_t *h, const double *M, int64_t ncols, int left, int right, double *out,
                            void *stream) {
     SRH_REQUIRE(h && M && out, "srom_reduce_matrix_dev: null argument");
@@ -948,39 +1000,9 @@ int srom_reduce_matrix_dev(srom_t *h, const double *M, int64_t ncols, int left, 
         // one pass over M: every workgroup turns its tile of T = M U into an r x r partial U[rows]^T T; then one small
         // reduction over the partials (SRH_UTMU_TWO_PASS: the older T-through-HBM path, kept for A/B timing)
         if (!getenv("SRH_UTMU_TWO_PASS")) {
-            ProjArgs a{};
-            a.X = M; a.ldx = ncols; a.ufrag = h->ufrag.as<double>(); a.B = h->n_f; a.n_f = h->n_f; a.r = h->r;
-            a.nchunks = h->nchunks; a.Urows = h->U.as<double>();
-            const int64_t rowtiles = srh::cdiv(h->n_f, ROWS_WG);
-            int ksplit = proj_ksplit(h, h->n_f, 1, &a.chunks_per_split);
-            if (const char *e = getenv("SRH_UTMU_KSPLIT")) {       // A/B: K-slices per row tile (default: ~512 workgroups)
-                const int want = std::max(1, std::min(atoi(e), h->nchunks));
-                a.chunks_per_split = (int)srh::cdiv(h->nchunks, want);
-                ksplit = (int)srh::cdiv(h->nchunks, a.chunks_per_split);
-            }
-            const int ldp = 16 * (h->NTF + (h->NQ ? 1 : 0));
-            const int nwg = (int)(rowtiles * ksplit);
-            int rc = ensure_work(h, sizeof(double) * (size_t)nwg * ldp * ldp);
-            if (rc) return rc;
-            a.partial = h->work.as<double>();
-            const bool vec2 = ((reinterpret_cast<uintptr_t>(M) & 15) == 0) && (ncols % 2 == 0);
-            dim3 grid((unsigned)rowtiles, (unsigned)ksplit, 1);
-            switch (4 * h->NTF + h->NQ) {
-#define SRH_UTMU_CASE(F, Q) case 4 * F + Q: rc = launch_utmu<F, Q>(a, vec2, grid, s); break;
-                SRH_UTMU_CASE(0, 1) SRH_UTMU_CASE(0, 2) SRH_UTMU_CASE(0, 3)
-                SRH_UTMU_CASE(1, 0) SRH_UTMU_CASE(1, 1) SRH_UTMU_CASE(1, 2) SRH_UTMU_CASE(1, 3)
-                SRH_UTMU_CASE(2, 0) SRH_UTMU_CASE(2, 1) SRH_UTMU_CASE(2, 2) SRH_UTMU_CASE(2, 3)
-                SRH_UTMU_CASE(3, 0) SRH_UTMU_CASE(3, 1) SRH_UTMU_CASE(3, 2) SRH_UTMU_CASE(3, 3)
-                SRH_UTMU_CASE(4, 0)
-#undef SRH_UTMU_CASE
-                default:
-                    srh::set_error("srom_reduce_matrix_dev: no kernel for r = %d", h->r);
-                    return SRH_EINVAL;
-            }
-            if (rc) return rc;
-            utmu_reduce_kernel<<<(unsigned)srh::cdiv(h->r * h->r, 4), 256, 0, s>>>(a.partial, nwg, ldp, h->r, out);
-            SRH_CHECK_HIP(hipGetLastError());
-            return SRH_OK;
+            const double *Ms[1] = {M};
+            double *outs[1] = {out};
+            return utmu_one_pass(h, Ms, 1, outs, s);
         }
         // T = M U (n_f x r) streamed once from HBM and stored, then U^T T (r x r)
         size_t tbytes = sizeof(double) * (size_t)h->n_f * h->r;
@@ -1020,6 +1042,40 @@ int srom_reduce_matrix(srom_t *h, const double *M, int64_t ncols, int left, int 
     if ((rc = srom_reduce_matrix_dev(h, dM.as<double>(), ncols, left, right, dO.as<double>(), nullptr))) return rc;
     SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
     return dO.download(out, obytes);
+}
+
+/* POD.compute_RO_matrix(left = right = True) for `count` n_f x n_f matrices at once: the K, D, M, S of one TPWL point
+ * (tpwl/tpwl_utils.py:96-103).  Groups of four share a launch pair (utmu_one_pass). */
+int srom_reduce_matrices_dev(srom_t *h, const double *const *M_dev, int count, double *const *out_dev, void *stream) {
+    SRH_REQUIRE(h && M_dev && out_dev && count >= 1, "srom_reduce_matrices_dev: null argument / no matrix");
+    for (int i = 0; i < count; ++i) SRH_REQUIRE(M_dev[i] && out_dev[i], "srom_reduce_matrices_dev: null matrix %d", i);
+    if (getenv("SRH_UTMU_TWO_PASS")) {
+        for (int i = 0; i < count; ++i) { int rc = srom_reduce_matrix_dev(h, M_dev[i], h->n_f, 1, 1, out_dev[i], stream); if (rc) return rc; }
+        return SRH_OK;
+    }
+    for (int i0 = 0; i0 < count; i0 += 4) {
+        int rc = utmu_one_pass(h, M_dev + i0, std::min(4, count - i0), out_dev + i0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return SRH_OK;
+}
+
+int srom_reduce_matrices(srom_t *h, const double *const *M, int count, double *const *out) {
+    SRH_REQUIRE(h && M && out && count >= 1, "srom_reduce_matrices: null argument / no matrix");
+    const size_t mb = sizeof(double) * (size_t)h->n_f * h->n_f, ob = sizeof(double) * (size_t)h->r * h->r;
+    std::vector<srh::DevBuf> dM((size_t)count), dO((size_t)count);
+    std::vector<const double *> mp((size_t)count);
+    std::vector<double *> op((size_t)count);
+    int rc;
+    for (int i = 0; i < count; ++i) {
+        SRH_REQUIRE(M[i] && out[i], "srom_reduce_matrices: null matrix %d", i);
+        if ((rc = dM[i].upload(M[i], mb)) || (rc = dO[i].alloc(ob))) return rc;
+        mp[i] = dM[i].as<double>(); op[i] = dO[i].as<double>();
+    }
+    if ((rc = srom_reduce_matrices_dev(h, mp.data(), count, op.data(), nullptr))) return rc;
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    for (int i = 0; i < count; ++i) if ((rc = dO[i].download(out[i], ob))) return rc;
+    return SRH_OK;
 }
 
 }  // extern "C"

@@ -25,6 +25,7 @@ struct GustoBatch {
     int mode;                           // fused kernel: 0 = solve every rollout, 2 = only those a lean launch handed over
     int32_t *handed_over;               // lean kernel: counts the rollouts it hands to the fused kernel (or null)
     double *Jopt;                       // per rollout: LOCP optimal value of the solution returned (the last accepted step), or null
+    int host_args;                      // x0, z, zf, ud point into pinned host memory (zero-copy solve): the kernels keep copies in the work block
 };
 
 struct LocpBatch {
@@ -46,7 +47,7 @@ constexpr int GUSTO_REC = 10;           // doubles of the resume record behind t
                                         // converged QP of the previous solve: GustoPar::warm_across)
 
 // offsets (doubles) of the SCP loop's own arrays inside a rollout's work block
-struct GustoWork { size_t xk, uk, acc, idx, rec, x0c, zc, end; };
+struct GustoWork { size_t xk, uk, acc, idx, rec, x0c, zc, zfc, udc, end; };
 __host__ __device__ inline GustoWork gusto_work(const QPDims &d) {
     GustoWork g;
     const size_t N = d.N, n = d.n, m = d.m;
@@ -55,9 +56,11 @@ __host__ __device__ inline GustoWork gusto_work(const QPDims &d) {
     g.acc = g.uk + N * m;
     g.idx = g.acc + 2 * N;
     g.rec = g.idx + (2 * N + 1) / 2;
-    g.x0c = g.rec + GUSTO_REC;                  // short-horizon lean kernels: copies of x0 and of the target (the arguments may sit in
-    g.zc = g.x0c + n;                           // host memory: zero-copy solves, gusto.hip)
-    g.end = g.zc + (N + 1) * d.nz;
+    g.x0c = g.rec + GUSTO_REC;                  // copies of x0, the targets and the desired inputs: the arguments of a zero-copy solve sit in
+    g.zc = g.x0c + n;                           // pinned HOST memory (gusto.hip) and every QP / interior-point iteration reads them
+    g.zfc = g.zc + (N + 1) * d.nz;              // (GustoBatch::host_args; the short-horizon lean kernels copy x0 and z always)
+    g.udc = g.zfc + d.nz;
+    g.end = g.udc + N * m;
     return g;
 }
 

@@ -112,6 +112,30 @@ class POD:
                                                  _lib.dptr(out)), 'srom_reduce_matrix')
         return out[:, 0] if (vec and left and not right) else out
 
+    def compute_RO_matrices(self, matrices):
+        """U^T M U (pod.py:56-72 with left = right = True) for several n_f x n_f matrices in one call: TPWLSnapshotData.add_point
+        reduces K, D, M and S of one linearisation point back to back (tpwl/tpwl_utils.py:96-103) -- groups of four share one
+        launch pair (srom_reduce_matrices).  Returns a list of r x r arrays, one per input, same arithmetic as compute_RO_matrix."""
+        try:
+            from scipy.sparse import coo_matrix
+        except Exception:
+            coo_matrix = ()
+        n_f, r = self.U.shape
+        dense = []
+        for matrix in matrices:
+            if not (isinstance(matrix, np.ndarray) or (coo_matrix and isinstance(matrix, coo_matrix))):
+                raise RuntimeError('Matrix is not numpy ndarray or sparse coo_matrix')
+            M = np.ascontiguousarray(matrix.toarray() if not isinstance(matrix, np.ndarray) else matrix, dtype=np.float64)
+            if M.shape != (n_f, n_f):
+                raise RuntimeError('matrix must be n_f x n_f')
+            dense.append(M)
+        outs = [np.empty((r, r)) for _ in dense]
+        if dense:
+            PP = C.POINTER(C.c_double) * len(dense)
+            _lib.check(_lib.lib().srom_reduce_matrices(self._h, PP(*[_lib.dptr(M) for M in dense]), C.c_int(len(dense)),
+                                                       PP(*[_lib.dptr(o) for o in outs])), 'srom_reduce_matrices')
+        return outs
+
     def get_info(self):
         """pod.py:74-78."""
         return {'q_ref': self.q_ref, 'v_ref': self.v_ref, 'U': self.U, 'type': 'POD'}

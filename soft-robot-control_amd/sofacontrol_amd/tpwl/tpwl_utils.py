@@ -70,8 +70,14 @@ class TPWLSnapshotData(scutils.SnapshotData):
             store['dt'] = point.dt
         self.saved_tpwl_steps.append(point.t)
         print('Time: {}, Number of points saved: {}'.format(point.t, len(self.saved_tpwl_steps)))
+        # the two-sided reductions of a point (K, D, M, S: tpwl_utils.py:96-103 of the reference, one after the other) in ONE call when
+        # the ROM offers it: four n_f x n_f matrices share a launch pair (POD.compute_RO_matrices); same values as one by one
+        both = [(key, attr) for key, attr, how in _REDUCTIONS if how == 'both']
+        batched = {}
+        if hasattr(self.rom, 'compute_RO_matrices') and len(both) > 1:
+            batched = dict(zip((k for k, _ in both), self.rom.compute_RO_matrices([getattr(point, a) for _, a in both])))
         for key, attr, how in _REDUCTIONS:
-            store[key].append(self._reduce[how](getattr(point, attr)))
+            store[key].append(batched[key] if key in batched else self._reduce[how](getattr(point, attr)))
         if self.config.save_continuous_TPWL:
             self.add_continuous_TPWL()
         if self.config.save_discrete_TPWL:

@@ -275,6 +275,44 @@ def test_forced_hand_over_gives_the_same_solve(N, batch, zero_copy, monkeypatch)
     assert rel(f[2], a[2]) <= 1e-6 and rel(f[3], a[3]) <= 1e-6, (rel(f[2], a[2]), rel(f[3], a[3]))
 
 
+def test_handed_over_zero_copy_solve_is_not_slower_than_the_copying_form(monkeypatch):
+    """A zero-copy solve passes pinned HOST pointers to the kernels (gusto.hip).  The N = 50 lean kernels and the fused kernel used to
+    read x0 / z / zf / u_des across PCIe in every QP and interior-point iteration -- unbounded for exactly the slow solves (round-5
+    advice); they now work on copies in the work block (GustoBatch::host_args).  One C2 rollout, SCP iteration 1 forced to the fused
+    kernel (Riccati path, ~20 interior-point iterations over the target): the zero-copy form must not take longer than the copying
+    form (generous 1.3x for timer noise; it should be faster by the saved runtime calls) and must return the same solve."""
+    import time
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2(N=50, dt=0.05)
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, 1, 2, 1354)
+    monkeypatch.setenv('SRH_LEAN_FORCE_HANDOVER', '1')
+    g = GuSTO(gm, 50, 0.05, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+              x_char=xc, f_char=fc, convg_thresh=1e-3, batch=1, max_trace=0, max_gusto_iters=5)
+    monkeypatch.delenv('SRH_LEAN_FORCE_HANDOVER', raising=False)
+    out, ms = {}, {}
+    for tag in ('zero_copy', 'copying', 'zero_copy', 'copying'):
+        if tag == 'copying':
+            monkeypatch.setenv('SRH_GUSTO_NO_ZEROCOPY', '1')
+        else:
+            monkeypatch.delenv('SRH_GUSTO_NO_ZEROCOPY', raising=False)
+        g.solve_batch(x0, u_init, x_init, z=z)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            g.solve_batch(x0, u_init, x_init, z=z)
+            ts.append(time.perf_counter() - t0)
+        ms[tag] = min(ts) * 1e3
+        assert int(g.kernel_info['handed_over']) == 1
+        out[tag] = (g.iters.copy(), g.xopt.copy(), g.uopt.copy())
+    monkeypatch.delenv('SRH_GUSTO_NO_ZEROCOPY', raising=False)
+    print('handed-over C2 solve: zero-copy %.3f ms, copying %.3f ms' % (ms['zero_copy'], ms['copying']))
+    assert (out['zero_copy'][0] == out['copying'][0]).all()
+    assert rel(out['zero_copy'][1], out['copying'][1]) <= 1e-9 and rel(out['zero_copy'][2], out['copying'][2]) <= 1e-9
+    assert ms['zero_copy'] <= 1.3 * ms['copying'], ms
+
+
 @pytest.mark.parametrize('delta0', [1.0, 4.0])
 def test_binding_trust_region_qps_follow_the_oracle(delta0, monkeypatch):
     """QPs whose trust region BINDS, chosen rather than waited for: with delta0 = 1 or 4 (instead of the reference's 1e4, gusto.py:142-147)

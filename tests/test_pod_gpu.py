@@ -149,6 +149,26 @@ def test_reduce_matrix_one_pass_shapes(n_f, r, monkeypatch):
     close(got, rom.compute_RO_matrix(M), rtol=1e-12)
 
 
+@pytest.mark.parametrize('n_f,r,count', [(300, 8, 4), (1000, 30, 3), (777, 36, 6), (4884, 30, 4)])
+def test_reduce_matrices_batch_equals_one_by_one(n_f, r, count):
+    """K, D, M, S of one TPWL point in ONE call (srom_reduce_matrices: groups of four share a launch pair, blockIdx.z = matrix):
+    the same partials and the same reduction order per matrix as the single-matrix form -- bit-identical -- and the oracle's
+    U^T M U to rounding.  count = 6: a full group and a group of two; count = 3: a ragged group."""
+    from sofacontrol_amd.mor.pod import POD
+    U, q_ref, v_ref = make_rom(n_f, r)
+    rom = POD(dict(U=U, q_ref=q_ref, v_ref=v_ref))
+    rng = np.random.default_rng(n_f + r + count)
+    Ms = [rng.standard_normal((n_f, n_f)) * (1.0 + 10.0 * i) for i in range(count)]
+    got = rom.compute_RO_matrices(Ms)
+    assert len(got) == count
+    for M, g in zip(Ms, got):
+        assert g.shape == (r, r)
+        assert np.array_equal(g, rom.compute_RO_matrix(M))
+        close(g, opod.reduce_matrix(U, M), rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        rom.compute_RO_matrices([Ms[0][:, :-1]])
+
+
 def test_projection_round_trip_full_size():
     """BASELINE size property test: lifting then projecting is the identity on the reduced space
     (U orthonormal), and projection is linear -- independent of any CPU result."""

@@ -171,6 +171,65 @@ def test_wait_states_in_front_of_inline_asm_dpp_reads(tmp_path):
     assert text.count('s_nop 1') == 1 and text.count('s_nop 0') == 2
 
 
+def test_exec_write_mfma_result_and_label_rules_of_the_dpp_guard(tmp_path):
+    """The three orderings the round-5 advice found unchecked: (1) a VALU write of EXEC (v_cmpx) followed by an asm DPP op needs FIVE
+    wait states; (2) an MFMA / DGEMM result read by an asm VALU instruction needs the MAI -> VALU wait states the compiler applies to
+    its own instructions only (the tool asks for 19 behind the f64 16x16x4, 8 behind the f64 4x4x4); (3) behind a label the other
+    predecessors of the block are unknown: an asm consumer of a possible transcendental result waits inside its own block, and the
+    fall-through predecessor in the text is still examined.  --fix pads every one of them; the re-scan is clean."""
+    dpp = _dpp_tool()
+    body = HEAD + '''	v_cmpx_gt_f64_e32 v[10:11], v[12:13]
+	v_mov_b32_e32 v20, v21
+	;;#ASMSTART
+	v_mov_b64_dpp v[2:3], v[38:39] row_newbcast:1 row_mask:0xf bank_mask:0xf
+	;;#ASMEND
+	s_nop 7
+	s_nop 7
+	s_nop 7
+	v_mfma_f64_16x16x4_f64 v[40:47], v[50:51], v[52:53], v[40:47]
+	v_mov_b32_e32 v22, v23
+	v_mov_b32_e32 v24, v25
+	;;#ASMSTART
+	v_mul_f64 v[60:61], v[42:43], v[42:43]
+	;;#ASMEND
+	s_nop 7
+	s_nop 7
+	s_nop 7
+	v_mfma_f64_4x4x4_4b_f64 v[70:71], v[50:51], v[52:53], v[70:71]
+	;;#ASMSTART
+	v_add_f64 v[70:71], v[62:63], v[62:63]
+	;;#ASMEND
+	s_nop 7
+	s_nop 7
+	s_nop 7
+	v_rsq_f64_e32 v[36:37], v[2:3]
+.LBB0_7:
+	;;#ASMSTART
+	v_mul_f64 v[64:65], v[36:37], v[36:37]
+	;;#ASMEND
+	s_endpgm
+'''
+    p = write(tmp_path, body)
+    found, _ = dpp.scan(open(p).read().splitlines(True), False)
+    got = [(f[2].split()[0], f[3]) for f in found]
+    # (1) one instruction stands between the v_cmpx and the DPP op: 4 of the 5 wait states are missing; (2) two instructions behind the
+    # 16x16x4: 17 of 19; the asm write of the 4x4x4's destination right behind it: 8; (3) the asm multiply at the label: the fall-through
+    # predecessor IS the transcendental (1)
+    assert got == [('v_mov_b64_dpp', 4), ('v_mul_f64', 17), ('v_add_f64', 8), ('v_mul_f64', 1)], got
+    assert dpp.main([p]) == 1 and dpp.main(['--fix', p]) == 0 and dpp.main([p]) == 0
+    # a label alone (no transcendental in the text before it) still makes an asm VALU instruction wait: unknown predecessors
+    body2 = HEAD + '''	v_mov_b32_e32 v22, v23
+.LBB0_9:
+	;;#ASMSTART
+	v_mul_f64 v[64:65], v[36:37], v[36:37]
+	;;#ASMEND
+	s_endpgm
+'''
+    p2 = write(tmp_path, body2)
+    found2, _ = dpp.scan(open(p2).read().splitlines(True), False)
+    assert [(f[2].split()[0], f[3]) for f in found2] == [('v_mul_f64', 1)]
+
+
 def test_shipped_device_assembly_is_clean():
     units = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
     asms = [u[:-4] + '.s' for u in units]

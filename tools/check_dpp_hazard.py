@@ -14,8 +14,18 @@ For every function of a `-S` output, in program order inside a basic block:
     VGPR sources may have been written by a VALU instruction less than 2 wait states before;
   * any VALU instruction that reads a VGPR written by a transcendental instruction less than 1 wait state before, when one of
     the two is inside an asm region (both compiler-made: the compiler has already dealt with it).
-A label resets the history CONSERVATIVELY: what precedes it in the text counts as the predecessor, and a DPP instruction
-closer than two instructions behind a label that is a branch target is given its wait states inside its own block.
+  * a VALU instruction that WRITES EXEC (v_cmpx_*; any VALU with `exec` as its destination) followed by an asm DPP instruction:
+    FIVE wait states (gfx9 / CDNA "VALU writes EXEC -> VALU DPP op");
+  * an MFMA / DGEMM result (v_mfma_*, v_smfmac_*, v_dot*) read -- or overwritten -- by a VALU instruction inside an asm region:
+    the MAI -> VALU wait states are applied by the compiler to ITS instructions only.  The tool asks for the largest figure of
+    LLVM's hazard recogniser for the instruction class on gfx90a / gfx940 / gfx950 (f64 16x16x4: 19, f64 4x4x4: 8, any other
+    MFMA: 19) -- nops in a place that never occurs in the shipped kernels cost nothing, a short count would.
+A label does not reset the history: what precedes it in the text is the fall-through predecessor and is still examined; the
+OTHER predecessors of a branch target are unknown, so a consumer closer to the label than its rule's distance is given the
+missing wait states inside its own block (DPP: 2; EXEC -> DPP: 5, only in functions that contain a VALU write of EXEC at
+all; asm VALU behind a possible transcendental: 1; asm VALU behind a possible MFMA: the full distance, but only when some
+MFMA of the same function writes a register the asm instruction touches -- otherwise no path can carry the hazard).  A case `--fix` cannot pad (it never gives up on one: an s_nop can always be placed in
+front of the consumer) would be reported by the re-scan and fails the build.
 `--fix` inserts the missing `s_nop`; without it the tool lists the places and exits 1.  Usage: check_dpp_hazard.py [--fix] file.s [...]
 """
 import re
@@ -28,6 +38,18 @@ DPP_CTRL = re.compile(r'\b(row_newbcast|row_shl|row_shr|row_ror|row_mirror|row_h
 TRANS = re.compile(r'^v_(rsq|rcp|sqrt|exp|log|sin|cos|rcp_iflag|rsq_clamp)_')
 VREG = re.compile(r'v\[(\d+):(\d+)\]|\bv(\d+)\b')
 NO_VDST = re.compile(r'^v_(cmp|cmpx|readlane|readfirstlane|nop)')
+MAI = re.compile(r'^v_(mfma|smfmac|dot)')
+HIST = 24                           # instructions of history kept: the longest rule looks 19 wait states back
+
+
+def mai_wait(op):
+    if op.startswith('v_mfma_f64_4x4x4'):
+        return 8
+    return 19
+
+
+def writes_exec(op, dst_txt):
+    return op.startswith('v_cmpx') or (op.startswith('v_') and re.search(r'\bexec(_lo|_hi)?\b', dst_txt) is not None)
 
 
 def vregs(text):
@@ -57,8 +79,26 @@ def scan(lines, fix):
     """returns (findings, new_lines)"""
     findings, out = [], []
     in_asm = False
-    hist = []                       # per issued instruction since the block start: (wait states it stands for, vgprs written by VALU, is transcendental, in asm)
+    # per issued instruction of the function, oldest first: (wait states it stands for, vgprs written by VALU, kind, in asm, opcode)
+    # kind: '' plain, 'trans', 'exec' (VALU write of EXEC), 'mai', 'label'
+    hist = []
     func = None
+    func_has_vexec = {}
+    func_mai_dst = {}
+    cur = None
+    for raw in lines:                 # first pass: which functions contain a VALU write of EXEC at all
+        line = raw.rstrip('\n')
+        if FUNC.match(line):
+            cur = line.split(':')[0]
+            func_has_vexec[cur] = False
+            func_mai_dst[cur] = set()
+        m = INSTR.match(line)
+        if m and cur is not None and m.group(1).startswith('v_'):
+            d, _ = split_operands(m.group(2))
+            if writes_exec(m.group(1), d):
+                func_has_vexec[cur] = True
+            if MAI.match(m.group(1)):
+                func_mai_dst[cur] |= vregs(d)
     for ln, raw in enumerate(lines, 1):
         line = raw.rstrip('\n')
         if FUNC.match(line):
@@ -68,7 +108,7 @@ def scan(lines, fix):
         elif ';;#ASMEND' in line:
             in_asm = False
         if LABEL.match(line):
-            hist = [(0, set(), False, False, 'label')]
+            hist.append((0, set(), 'label', False, 'label'))
         m = INSTR.match(line)
         if not m or m.group(1).startswith('.') or func is None:
             out.append(raw)
@@ -76,7 +116,7 @@ def scan(lines, fix):
         op, ops = m.group(1), m.group(2)
         if op == 's_nop':
             n = int(ops.split()[0], 0) + 1 if ops else 1
-            hist.append((n, set(), False, in_asm, op))
+            hist.append((n, set(), '', in_asm, op))
             out.append(raw)
             continue
         is_valu = op.startswith('v_')
@@ -86,33 +126,51 @@ def scan(lines, fix):
         need = 0
         if is_valu:
             srcs = vregs(src_txt)
+            touched = srcs | (vregs(dst_txt) if not NO_VDST.match(op) else set())
             dpp_here = in_asm and DPP_CTRL.search(ops) is not None
             dist = 0                              # wait states between a producer and this instruction
-            at_label = False
-            for ws, wr, trans, asm_p, pop in reversed(hist):
-                if pop == 'label':
-                    at_label = True
-                    break
+            label_dist = None                     # wait states between the nearest label in front and this instruction
+            for ws, wr, kind, asm_p, pop in reversed(hist):
+                if kind == 'label':
+                    if label_dist is None:
+                        label_dist = dist
+                    continue
                 if dpp_here and wr & srcs and dist < 2:
                     need = max(need, 2 - dist)
-                if trans and (asm_p or in_asm) and wr & srcs and dist < 1 and not TRANS.match(op):
+                if dpp_here and kind == 'exec' and dist < 5:
+                    need = max(need, 5 - dist)
+                if kind == 'trans' and (asm_p or in_asm) and wr & srcs and dist < 1 and not TRANS.match(op):
                     need = max(need, 1 - dist)
+                if kind == 'mai' and in_asm and wr & touched and dist < mai_wait(pop):
+                    need = max(need, mai_wait(pop) - dist)
                 dist += ws
-                if dist >= 2:
+                if dist >= 19:
                     break
-            if dpp_here and at_label and dist < 2:
-                need = max(need, 2 - dist)        # the block before a branch target is unknown: wait inside this block
+            if label_dist is not None:
+                # the other predecessors of a branch target are unknown: wait inside this block
+                if dpp_here and label_dist < 2:
+                    need = max(need, 2 - label_dist)
+                if dpp_here and func_has_vexec.get(func) and label_dist < 5:
+                    need = max(need, 5 - label_dist)
+                if in_asm and not TRANS.match(op) and label_dist < 1:
+                    need = max(need, 1)
+                if in_asm and label_dist < 19 and touched & func_mai_dst.get(func, set()):
+                    need = max(need, 19 - label_dist)
         if need:
             findings.append((func, ln, op + ' ' + ops, need))
             if fix:
-                out.append('\ts_nop %d\n' % (need - 1))
-                hist.append((need, set(), False, in_asm, 's_nop'))
+                out.append('\ts_nop %d\n' % (min(need, 16) - 1))
+                hist.append((min(need, 16), set(), '', in_asm, 's_nop'))
+                if need > 16:
+                    out.append('\ts_nop %d\n' % (need - 16 - 1))
+                    hist.append((need - 16, set(), '', in_asm, 's_nop'))
         wr = set()
         if is_valu and not NO_VDST.match(op):
             wr = vregs(dst_txt)
-        hist.append((1, wr, bool(TRANS.match(op)), in_asm, op))
-        if len(hist) > 8:
-            hist = hist[-8:]
+        kind = 'trans' if TRANS.match(op) else ('exec' if is_valu and writes_exec(op, dst_txt) else ('mai' if MAI.match(op) else ''))
+        hist.append((1, wr, kind, in_asm, op))
+        if len(hist) > HIST:
+            hist = hist[-HIST:]
         out.append(raw)
     return findings, out
 

@@ -12,6 +12,15 @@ LL=${LLVM_BIN:-/opt/rocm/lib/llvm/bin}
 ARCH=${ARCH:-gfx950}
 HERE=$(cd "$(dirname "$0")" && pwd)
 B=${OBJ%.o}
+# The two repair rules were written against -- and validated on -- the code generator of ONE compiler: HIP 7.2 (AMD clang 22.0.0git,
+# roc-7.2.0).  Another major.minor may place spills / PHI copies / hazards differently: the rules might neither find nor fix what it
+# does.  Refuse to build with it unless told that the result will be checked by other means (make check-spills + the GPU tests).
+VALIDATED_HIP="7.2"
+HIPV=$($HIPCC --version 2>/dev/null | sed -n 's/^HIP version: \([0-9]*\.[0-9]*\).*/\1/p' | head -n1)
+if [ "$HIPV" != "$VALIDATED_HIP" ] && [ "${SRH_GUARD_UNCHECKED:-0}" != "1" ]; then
+    echo "hipcc_guarded.sh: HIP version '$HIPV' != $VALIDATED_HIP, the version the assembly repair rules (check_spill_exec.py, check_dpp_hazard.py) were validated against; set SRH_GUARD_UNCHECKED=1 to build anyway" >&2
+    exit 3
+fi
 $HIPCC "$@" --cuda-device-only -S "$SRC" -o "$B.s" 2> >(grep -v 'argument unused during compilation' >&2)
 python3 "$HERE/check_spill_exec.py" --fix "$B.s"
 python3 "$HERE/check_dpp_hazard.py" --fix "$B.s"
