@@ -731,7 +731,8 @@ def secondary(L, _lib, rank, world, dist):
         out['ssm_gusto_rti'] = {'cpu': 'no twin: the CPU twin has no SSM + GuSTO loop (its GuSTO is the nearest-point TPWL one); the numpy oracle of this '
                                        'loop (oracle.gusto.solve_generic) is a correctness statement, not a timing',
                                 'workload': 'SSM (n_x = 6, n_u = 4, cubic) + GuSTO real-time iteration: N = 3, dt = 0.02, max_gusto_iters = 0 '
-                                            '(one QP per call), U box; host loop around the device QP (the model is not TPWL), host buffers',
+                                            '(one QP per call), U box; %s, host buffers' % ('the whole solve in one launch of csrc/gusto_ssm.hip' if getattr(g6, '_ssm', False) else 'host loop around the device QP'),
+                                'kernel': g6.kernel_info['kernel'] if getattr(g6, '_ssm', False) else 'host loop + ' + str((g6.locp.kernel_info or {}).get('kernel')),
                                 'ms_median': ts6[len(ts6) // 2] * 1e3, 'ms_p95': ts6[int(len(ts6) * 0.95)] * 1e3,
                                 'budget_ms': 40.0, 'within_budget': bool(ts6[int(len(ts6) * 0.95)] * 1e3 <= 40.0)}
     except Exception as exc:

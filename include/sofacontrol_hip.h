@@ -427,6 +427,26 @@ int sgusto_plan_set_max_iters(sgusto_plan_t *plan, int max_gusto_iters);   /* gu
  * GuSTO.solve -- from the previous solution).  on = 1: the first QP of a solve starts from the minimiser and multipliers the same rollout's
  * previous solve ended with (lean kernels; later QPs of a solve always do).  Default 0: every solve starts cold (what bench.py times). */
 int sgusto_plan_set_warm_across(sgusto_plan_t *plan, int on);
+/* GuSTO on an SSM polynomial model (sofacontrol/scp/models/ssm.py + sofacontrol/SSM/ssm.py:198-235), the whole solve -- analytic
+ * linearisation of the dynamics and of the output map along the trajectory, the LOCP QP with per-stage output maps (locp.py:231-245,
+ * 312-329), the tests and the acceptance rules of gusto.py:371-473 -- inside ONE kernel launch per call: the loop the reference's
+ * hardware driver runs every control period (examples/hardware/diamond_SSM.py:353-361).  `prob`: the QP in the augmented state
+ * [x ; zeta] (n_x = n + n_o, H = [0 I], x_scale = 0 on zeta) when the model's output map is nonlinear, else the plain QP with the
+ * constant H; `mode`: discretisation as sssm_linearize; Hm (n_z x n): model.H of zopt = H xopt (gusto.py:486); XA / Xb (nX x n): the state
+ * polyhedron as GuSTO.state_constraints_violated applies it to the states (gusto.py:185-201), or NULL.  Arrays as sgusto_solve with
+ * n_x = the model's n.  status: 0 ok, 1 a QP could not be solved, 2 omega > omega_max, 3 max iterations. */
+typedef struct sgusto_ssm_plan sgusto_ssm_plan_t;
+int sgusto_ssm_plan_create(sgusto_ssm_plan_t **plan, sssm_t *model, const slocp_problem *prob, const sgusto_params *par, double dt,
+                           int mode, int64_t batch, const double *f_char, const double *Hm, int nX, const double *XA, const double *Xb,
+                           int max_trace);
+int sgusto_ssm_plan_destroy(sgusto_ssm_plan_t *plan);
+int sgusto_ssm_plan_set_max_iters(sgusto_ssm_plan_t *plan, int max_gusto_iters);
+int sgusto_ssm_plan_solve(sgusto_ssm_plan_t *plan, const double *x0, const double *u_init, const double *x_init, const double *z,
+                          const double *u_des, double *xopt, double *uopt, double *zopt, int32_t *iters, int32_t *status, double *trace);
+int sgusto_ssm_plan_solve_dev(sgusto_ssm_plan_t *plan, const double *x0_dev, const double *u_init_dev, const double *x_init_dev,
+                              const double *z_dev, const double *u_des_dev, double *xopt_dev, double *uopt_dev, double *zopt_dev,
+                              int32_t *iters_dev, int32_t *status_dev, double *trace_dev, void *stream);
+
 /* Which kernel instantiation a solve of this plan launches: split (1: split W panel, n_x > 64), n_u_fixed / n_x_fixed
  * = the compile-time n_u / n_x of the instantiation (0: that extent is a run-time value; 0, 0 = the all-sizes
  * kernel).  For tests and bench records: parity is claimed per instantiation. */

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
     int itr = 0, status = 0;
     bool tr_hot = false;                               // expect the trust region to bind in the next QP (see qp::solve, full_first)
     bool warm_relaxed = false;                         // the previous QP ended in the relaxed Riccati pass (qp::solve, warm)
+    bool warm_full = false;                            // the previous QP ended in the full pass (trust-region rows): qp::solve, warm_full
     if (b.mode == 2) {
         // only the rollouts a lean launch (lean.hip) could not finish: xk, uk, idx are where it left them
         if (rec[0] != 1.0) return;
@@ -102,8 +103,10 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         int qit;
         GU_LAP(1);
         int qpass = -1;
-        const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w, tr_hot, warm_relaxed, &qpass);
+        const int st = qp::solve<SPLIT, MSEL, NSEL>(d, c, dyn, q, base, L, &J, &qit, true, w, tr_hot, warm_relaxed, &qpass,
+                                                    warm_full && tr_hot && par.warm_full != 0);
         warm_relaxed = st == 0 && qpass == 0;        // the next QP's relaxed Riccati pass may start from this one's (u, lambda)
+        warm_full = st == 0 && qpass == 1;           // ... and its full pass from this one's (u, s, lambda) when it goes there directly
         GU_LAP(2);
         if (st != 0) { status = 1; break; }          // gusto.py:357-365: keep the previous iterate
         // trust region test (gusto.py:174-183)
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_kernel(QPDims d, QPConst c, Tp
         if (b.trace && itr < par.max_trace && tid == 0) {
             double *tr = b.trace + (p * par.max_trace + itr) * 4;
             tr[0] = J; tr[1] = d_cur; tr[2] = o_cur; tr[3] = rho_k;
+            if (par.poison_warm & 2) tr[3] = (double)(qit + 1000 * (qpass + 1));     // debug (SRH_GUSTO_TRACE_QIT=1): interior-point iterations + 1000 (pass + 1)
         }
         // the next QP keeps this linearisation point when the step was rejected (smaller delta or larger omega, same relaxed
         // minimiser): if this one already ended on the boundary of its trust region the next one is certain to bind
@@ -358,8 +362,9 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
     QPDims &d = pl->C.dims;
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
                        par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace, 0,
-                       (getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0) |
-                       (getenv("SRH_LEAN_FORCE_HANDOVER") != nullptr ? (atoi(getenv("SRH_LEAN_FORCE_HANDOVER")) + 1) << 4 : 0)};
+                       (getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0) | (getenv("SRH_GUSTO_TRACE_QIT") != nullptr ? 2 : 0) |
+                       (getenv("SRH_LEAN_FORCE_HANDOVER") != nullptr ? (atoi(getenv("SRH_LEAN_FORCE_HANDOVER")) + 1) << 4 : 0),
+                       getenv("SRH_GUSTO_WARM_FULL") != nullptr ? 1 : 0};
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
     size_t doubles = gusto_work(d).end;
     doubles = (doubles + 3) & ~(size_t)3;

@@ -1,0 +1,498 @@
+// GuSTO on an SSM polynomial model, the whole solve inside ONE kernel launch: the loop the reference's hardware driver runs every
+// control period (examples/hardware/diamond_SSM.py:353-361: N = 3, max_gusto_iters = 0 -- one QP per call, a 40 ms budget).
+// Reference: sofacontrol/scp/gusto.py:283-487 (loop), sofacontrol/scp/models/ssm.py (adapter), sofacontrol/SSM/ssm.py:198-235
+// (Jacobians of the polynomial maps, observer linearisation), sofacontrol/scp/locp.py:231-245, 312-329 (the QP with per-stage
+// output maps z_k = H_k x_k + c_k).
+//
+// Rounds 2-5 served this model through a host loop: per SCP iteration two batched linearisation calls, an upload of the horizon,
+// the QP kernel, a download, three more device calls for the model-accuracy test -- ~1.2 ms of round trips around a 6-state,
+// 3-stage QP.  Here one workgroup per rollout does what gusto.hip's kernel does for a TPWL model, with the table gather replaced by
+// the analytic linearisation of ssm_dev.h:
+//   linearise   (A_k, B_k, d_k) = discretised Jacobians of f = R phi(x) + B u at (xbar_k, ubar_k), k < N  (ssm::linearize), and
+//               (H_k, c_k) = observer linearisation at xbar_k, k <= N (ssm::observe).  The QP kernel has ONE constant performance
+//               matrix, so the stage outputs are carried as extra states (the layout the host path has used since round 2,
+//               sofacontrol_amd/scp/locp.py:_init_augmented): xa_k = [x_k ; zeta_k], zeta_{k+1} = H_{k+1}(A_k x_k + B_k u_k + d_k)
+//               + c_{k+1}, H_a = [0 I], zero trust-region scale on zeta -- the same QP in (x, u, s).
+//   QP          qp::solve (locp_dev.h / locp_cond.h) on the per-stage matrices just written to the rollout's work block
+//   tests       trust region, model accuracy (continuous Jacobians at the old and at the new point, gusto.py:203-223), state rows,
+//               convergence, acceptance -- gusto.py:371-473 with the same rules and order as gusto_kernel.
+// The linearisation scratch and the QP's layouts share the workgroup's LDS (they never live at the same time).
+#include "scp_types.h"
+#include "ssm_host.h"
+
+#include <memory>
+
+namespace {
+
+struct SsmGustoBatch {
+    const double *x0, *u_init, *x_init, *z, *ud;
+    const double *fs;                   // 1 / |f_char| (n)
+    const double *Hm;                   // model.H (n_z x n): zopt = H xopt (gusto.py:486)
+    const double *XA, *Xb;              // the state polyhedron as GuSTO.state_constraints_violated applies it (nXv x n), or null
+    int nXv;
+    double *xopt, *uopt, *zopt;
+    int32_t *iters, *status;
+    double *trace;
+    double *work;
+    size_t work_stride;
+    int n;                              // model state dimension (the QP's state: n + n_obs)
+    int mode;                           // discretisation of the model (SSM_FE ... SSM_DISCRETE_MAP)
+    double *Jopt;
+    int host_args;                      // the arguments sit in pinned host memory (zero-copy solve): copies in the work block
+};
+
+// offsets (doubles) of the SCP loop's arrays behind the QP's own work arrays
+struct SsmGustoWork { size_t xk, uk, A, AT, B, BT, dd, xka, x0a, acc, x0c, zc, udc, end; };
+__host__ __device__ inline SsmGustoWork ssm_gusto_work(const QPDims &d, int n) {
+    SsmGustoWork g;
+    const size_t N = d.N, na = d.n, m = d.m;
+    g.xk = qp_work_doubles(d);
+    g.uk = g.xk + (N + 1) * n;
+    g.A = g.uk + N * m;
+    g.AT = g.A + N * na * na;
+    g.B = g.AT + N * na * na;
+    g.BT = g.B + N * na * m;
+    g.dd = g.BT + N * na * m;
+    g.xka = g.dd + N * na;
+    g.x0a = g.xka + (N + 1) * na;
+    g.acc = g.x0a + na;
+    g.x0c = g.acc + 2 * N;
+    g.zc = g.x0c + n;
+    g.udc = g.zc + (N + 1) * d.nz;
+    g.end = g.udc + N * m;
+    return g;
+}
+
+__host__ __device__ inline size_t ssm_gusto_scratch_doubles(const SsmDev &S) {
+    const size_t n = S.n, m = S.m, no = S.no;
+    return ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns) + 2 * (n + m) + 2 * (n * n + n * m + n) + 2 * no + no * n + 8;
+}
+
+// GXL > 0: the QP without its trust-region rows runs on the lean one-wave interior point first (ql::ipm_wave: K is one 16 x 16 tile at the
+// driver's N = 3, 31 k clocks per interior-point iteration against 70 k of the eight-wave forms -- DESIGN.md section 13); qp::solve takes over
+// when that minimiser leaves the trust region or the interior point does not converge.  GXL = lanes per stage for the state rows (ql::ipm_box).
+template <bool SPLIT, int MSEL, int GXL>
+__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    qp::specialise<MSEL, 0>(d);
+    long long prof[32] = {0};
+    QPLds L;
+    qp_lds_carve(L, (lptr)smem, d, NTHREADS);
+    const size_t p = blockIdx.x;
+    const int N = d.N, na = d.n, m = d.m, nz = d.nz, n = b.n, no = na - n;       // no = 0: linear output map (model.H), else S.no
+    int tid = SRH_TID;
+    const int nt = blockDim.x;
+    gptr base = (gptr)(b.work + p * b.work_stride);
+    QPWork w;
+    qp_carve(w, base, d);
+    const SsmGustoWork gw = ssm_gusto_work(d, n);
+    gptr xk = base + gw.xk, uk = base + gw.uk, Ag = base + gw.A, ATg = base + gw.AT, Bg = base + gw.B, BTg = base + gw.BT;
+    gptr ddg = base + gw.dd, xka = base + gw.xka, x0a = base + gw.x0a, accb = base + gw.acc;
+    // linearisation scratch (aliases the QP's LDS; qp::solve re-initialises its layout when it finds `ready` false)
+    ssm::Work sw;
+    ssm::carve(sw, (lptr)smem, S);
+    lptr xs = (lptr)smem + ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns);
+    lptr us = xs + n, Al = us + m, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m, zs = dl + n, cs = zs + S.no, Hl = cs + S.no;
+    lptr A2 = Hl + (size_t)S.no * n, B2 = A2 + (size_t)n * n, d2 = B2 + (size_t)n * m, x2 = d2 + n, u2 = x2 + n;
+    lptr red = (lptr)smem + red_off;        // reduction scratch behind both layouts
+
+    cgptr x0 = (cgptr)(b.x0 + p * n);
+    cgptr zp = (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr);
+    cgptr udp = (cgptr)(b.ud ? b.ud + p * (size_t)N * m : nullptr);
+    if (b.host_args) {
+        gptr x0c = base + gw.x0c, zc = base + gw.zc, udc = base + gw.udc;
+        for (int e = tid; e < n; e += nt) x0c[e] = x0[e];
+        if (zp) for (int e = tid; e < (N + 1) * nz; e += nt) zc[e] = zp[e];
+        if (udp) for (int e = tid; e < N * m; e += nt) udc[e] = udp[e];
+        x0 = (cgptr)x0c;
+        if (zp) zp = (cgptr)zc;
+        if (udp) udp = (cgptr)udc;
+    }
+    for (int e = tid; e < (N + 1) * n; e += nt) xk[e] = b.x_init[p * (size_t)(N + 1) * n + e];
+    for (int e = tid; e < N * m; e += nt) uk[e] = b.u_init[p * (size_t)N * m + e];
+    __syncthreads();
+
+    // (A, B, d)_k and (H, c)_k of the trajectory (xk, uk) -> the augmented per-stage matrices of the QP, both orientations
+    auto linearise_all = [&]() {
+        if (no > 0) {
+            for (int e = tid; e < n; e += nt) xs[e] = xk[e];
+            __syncthreads();
+            ssm::observe(S, xs, sw, zs, Hl, cs);
+            for (int e = tid; e < na; e += nt) {
+                double v0, vk;
+                if (e < n) { v0 = x0[e]; vk = xs[e]; }
+                else {
+                    v0 = cs[e - n];
+                    for (int j = 0; j < n; ++j) v0 = fma(Hl[(e - n) * n + j], x0[j], v0);
+                    vk = cs[e - n];
+                    for (int j = 0; j < n; ++j) vk = fma(Hl[(e - n) * n + j], xs[j], vk);
+                }
+                x0a[e] = v0; xka[e] = vk;
+            }
+        } else {
+            for (int e = tid; e < n; e += nt) { x0a[e] = x0[e]; xka[e] = xk[e]; }
+        }
+        __syncthreads();
+        for (int k = 0; k < N; ++k) {
+            for (int e = tid; e < n; e += nt) xs[e] = xk[(size_t)k * n + e];
+            for (int e = tid; e < m; e += nt) us[e] = uk[(size_t)k * m + e];
+            __syncthreads();
+            ssm::linearize(S, b.mode, par.dt, xs, us, sw, Al, n, Bl, dl);
+            if (no > 0) {
+                for (int e = tid; e < n; e += nt) xs[e] = xk[(size_t)(k + 1) * n + e];
+                __syncthreads();
+                ssm::observe(S, xs, sw, zs, Hl, cs);
+            }
+            gptr Ak = Ag + (size_t)k * na * na, ATk = ATg + (size_t)k * na * na, Bk = Bg + (size_t)k * na * m, BTk = BTg + (size_t)k * na * m;
+            for (int e = tid; e < na * na; e += nt) {
+                const int i = e / na, j = e - i * na;
+                double v = 0.0;
+                if (j < n) {
+                    if (i < n) v = Al[i * n + j];
+                    else for (int l = 0; l < n; ++l) v = fma(Hl[(i - n) * n + l], Al[l * n + j], v);
+                }
+                Ak[e] = v; ATk[(size_t)j * na + i] = v;
+            }
+            for (int e = tid; e < na * m; e += nt) {
+                const int i = e / m, j = e - i * m;
+                double v = 0.0;
+                if (i < n) v = Bl[i * m + j];
+                else for (int l = 0; l < n; ++l) v = fma(Hl[(i - n) * n + l], Bl[l * m + j], v);
+                Bk[e] = v; BTk[(size_t)j * na + i] = v;
+            }
+            for (int i = tid; i < na; i += nt) {
+                double v;
+                if (i < n) v = dl[i];
+                else { v = 0.0; for (int l = 0; l < n; ++l) v = fma(Hl[(i - n) * n + l], dl[l], v); v += cs[i - n]; }
+                ddg[(size_t)k * na + i] = v;
+                double xv;
+                if (i < n) xv = xk[(size_t)(k + 1) * n + i];
+                else { xv = cs[i - n]; for (int l = 0; l < n; ++l) xv = fma(Hl[(i - n) * n + l], xs[l], xv); }
+                xka[(size_t)(k + 1) * na + i] = xv;
+            }
+            __syncthreads();
+        }
+    };
+    linearise_all();
+
+    QPDyn dyn{(cgptr)Ag, (cgptr)ATg, (cgptr)Bg, (cgptr)BTg, (cgptr)ddg, (cgiptr)nullptr};
+    double delta = par.delta0, omega = par.omega0;
+    double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
+    bool converged = false, tr_hot = false;
+    int itr = 0, status = 0;
+    while (itr <= par.max_iters && !converged && omega <= par.omega_max) {
+        tid = SRH_TID;
+        QPData q{(cgptr)x0a, (cgptr)xka, zp, (cgptr)nullptr, udp, delta, omega, (gptr)nullptr};
+        double J;
+        int qit, qpass = -1;
+        __syncthreads();
+        int st = -1;
+        if constexpr (GXL > 0) {
+            if (!tr_hot) {
+                ql::Lds LL;
+                ql::lds_carve(LL, (lptr)smem, d, NTHREADS);
+                if (tid == 0) LL.flag[2] = 0;              // (the LDS was used by the linearisation: nothing condensed is left)
+                __syncthreads();
+                st = ql::solve_qp<MSEL, 0, GXL, -1, 0>(d, c, dyn, q, base, LL, &J, &qit, w, prof, 0);
+                __syncthreads();
+            }
+        }
+        if (st != 0) {
+            qp_lds_carve(L, (lptr)smem, d, NTHREADS);      // the linearisation / the tests / the lean attempt used the LDS: the QP starts from its own layout
+            st = qp::solve<SPLIT, MSEL, 0>(d, c, dyn, q, base, L, &J, &qit, true, w, tr_hot || st == 100, false, &qpass);
+        }
+        if (st != 0) { status = 1; break; }                // gusto.py:357-365: keep the previous iterate
+        __syncthreads();
+        // trust region (gusto.py:174-183) on the model's own states
+        double md = 0.0;
+        for (int e = tid; e < (N + 1) * n; e += nt) {
+            const int k = e / n, j = e - k * n;
+            md = fmax(md, fabs(c.xs[j] * (w.x[(size_t)k * na + j] - xk[e])));
+        }
+        md = wg::reduce(md, 1, red);
+        const bool tr_ok = !(md - delta > par.epsilon);
+        const bool on_boundary = md >= delta * (1.0 - 1e-9);
+        bool new_solution = false;
+        double rho_k = -1.0;
+        const double d_cur = delta, o_cur = omega;
+        if (tr_ok) {
+            // model accuracy (gusto.py:203-223): f = A x + B u + d with the CONTINUOUS Jacobians at each point (models/ssm.py:35-54)
+            for (int i = 0; i < N; ++i) {
+                for (int e = tid; e < n; e += nt) { xs[e] = xk[(size_t)i * n + e]; x2[e] = w.x[(size_t)i * na + e]; }
+                for (int e = tid; e < m; e += nt) { us[e] = uk[(size_t)i * m + e]; u2[e] = w.u[(size_t)i * m + e]; }
+                __syncthreads();
+                ssm::linearize(S, SSM_CONT, 0.0, xs, us, sw, Al, n, Bl, dl);
+                ssm::linearize(S, SSM_CONT, 0.0, x2, u2, sw, A2, n, B2, d2);
+                if (tid == 0) {
+                    double e2 = 0.0, a2 = 0.0;
+                    for (int r = 0; r < n; ++r) {
+                        double fk = 0.0, fl = 0.0, f = 0.0;
+                        for (int j = 0; j < n; ++j) {
+                            fk = fma(Al[r * n + j], xs[j], fk);
+                            fl = fma(Al[r * n + j], x2[j] - xs[j], fl);
+                            f = fma(A2[r * n + j], x2[j], f);
+                        }
+                        double bk = 0.0, bl = 0.0, bf = 0.0;
+                        for (int j = 0; j < m; ++j) {
+                            bk = fma(Bl[r * m + j], us[j], bk);
+                            bl = fma(Bl[r * m + j], u2[j] - us[j], bl);
+                            bf = fma(B2[r * m + j], u2[j], bf);
+                        }
+                        const double fkv = fk + bk + dl[r], fv = f + bf + d2[r];
+                        const double fa = fkv + fl + bl;
+                        const double fsr = b.fs[r];
+                        const double de = fsr * (fv - fa), da = fsr * fa;
+                        e2 = fma(de, de, e2);
+                        a2 = fma(da, da, a2);
+                    }
+                    accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2);
+                }
+                __syncthreads();
+            }
+            double err = 0.0, app = 0.0;
+            for (int i = 0; i < N; ++i) { err += accb[2 * i]; app += accb[2 * i + 1]; }
+            rho_k = err / (J + app);
+            if (rho_k > par.rho && itr != 1) {
+                delta = par.beta_fail * delta;
+            } else {
+                if (d_prev == delta && o_prev == omega && J_prev <= J) delta = par.beta_fail * delta;
+                d_prev = delta; J_prev = J; o_prev = omega;
+                // state-constraint violation (gusto.py:185-201): X applied to the states, all k = 0..N
+                double viol = 0.0;
+                if (b.nXv > 0) {
+                    for (int k = tid; k <= N; k += nt) {
+                        double v2 = 0.0;
+                        for (int r = 0; r < b.nXv; ++r) {
+                            double v = -b.Xb[r];
+                            for (int j = 0; j < n; ++j) v = fma(b.XA[(size_t)r * n + j], w.x[(size_t)k * na + j], v);
+                            v = fmax(v, 0.0);
+                            v2 = fma(v, v, v2);
+                        }
+                        viol = fmax(viol, sqrt(v2));
+                    }
+                    viol = wg::reduce(viol, 1, red);
+                }
+                const bool X_ok = !(viol > par.epsilon);
+                if (!X_ok) omega = par.gamma_fail * omega;
+                // convergence (gusto.py:150-161)
+                double ds = 0.0;
+                for (int k = tid; k <= N; k += nt) {
+                    double v2 = 0.0;
+                    for (int j = 0; j < n; ++j) {
+                        const double e = c.xs[j] * (w.x[(size_t)k * na + j] - xk[(size_t)k * n + j]);
+                        v2 = fma(e, e, v2);
+                    }
+                    ds += sqrt(v2);
+                }
+                ds = wg::reduce(ds, 0, red);
+                const double dsol = (1.0 / N) * ((1.0 / n) * ds);
+                converged = (dsol <= par.convg_thresh) && X_ok;
+                new_solution = true;
+            }
+        } else {
+            omega = par.gamma_fail * omega;
+        }
+        if (b.trace && itr < par.max_trace && tid == 0) {
+            double *tr = b.trace + (p * par.max_trace + itr) * 4;
+            tr[0] = J; tr[1] = d_cur; tr[2] = o_cur; tr[3] = rho_k;
+        }
+        tr_hot = on_boundary && !new_solution;
+        ++itr;
+        if (new_solution) {
+            __syncthreads();
+            for (int e = tid; e < (N + 1) * n; e += nt) { const int k = e / n, j = e - k * n; xk[e] = w.x[(size_t)k * na + j]; }
+            for (int e = tid; e < N * m; e += nt) uk[e] = w.u[e];
+            __syncthreads();
+            if (par.max_iters >= 1) linearise_all();          // gusto.py:458-473
+        }
+    }
+    if (status == 0) {
+        if (omega > par.omega_max) status = 2;
+        else if (itr - 1 > par.max_iters) status = 3;
+    }
+    __syncthreads();
+    for (int e = tid; e < (N + 1) * n; e += nt) b.xopt[p * (size_t)(N + 1) * n + e] = xk[e];
+    for (int e = tid; e < N * m; e += nt) b.uopt[p * (size_t)N * m + e] = uk[e];
+    for (int e = tid; e < (N + 1) * nz; e += nt) {
+        const int k = e / nz, a = e - k * nz;
+        double v = 0.0;
+        for (int j = 0; j < n; ++j) v = fma(b.Hm[a * n + j], xk[(size_t)k * n + j], v);
+        b.zopt[p * (size_t)(N + 1) * nz + e] = v;
+    }
+    if (tid == 0) { b.iters[p] = itr; b.status[p] = status; if (b.Jopt) b.Jopt[p] = J_prev; }
+}
+
+}  // namespace
+
+struct sgusto_ssm_plan {
+    sssm *model = nullptr;
+    QPConstHost C;
+    GustoPar par{};
+    int64_t batch = 0;
+    int n = 0, mode = 0, nXv = 0, max_trace = 0;
+    srh::DevBuf fs, Hm, XA, Xb, work, Jopt;
+    size_t work_stride = 0, lds = 0;
+    int red_off = 0;
+    int lean_gx = 0;                    // > 0: the lean one-wave interior point runs first (template argument GXL of the kernel)
+    char *pin = nullptr;                // one pinned, device-visible block: [inputs | outputs]
+    size_t pin_bytes = 0;
+    bool solved = false;
+    ~sgusto_ssm_plan() { if (pin) (void)hipHostFree(pin); }
+};
+
+namespace {
+struct SsmPin { size_t x0, u_init, x_init, z, ud, xopt, uopt, zopt, iters, status, trace, total; };
+SsmPin ssm_pin_layout(const sgusto_ssm_plan *pl) {
+    const QPDims &d = pl->C.dims;
+    const size_t N = d.N, n = pl->n, m = d.m, nz = d.nz, B = pl->batch, D = sizeof(double);
+    SsmPin L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 63) & ~(size_t)63; return at; };
+    L.x0 = take(D * B * n); L.u_init = take(D * B * N * m); L.x_init = take(D * B * (N + 1) * n); L.z = take(D * B * (N + 1) * nz);
+    L.ud = take(D * B * N * m); L.xopt = take(D * B * (N + 1) * n); L.uopt = take(D * B * N * m); L.zopt = take(D * B * (N + 1) * nz);
+    L.iters = take(sizeof(int32_t) * B); L.status = take(sizeof(int32_t) * B); L.trace = take(D * B * (size_t)std::max(1, pl->max_trace) * 4);
+    L.total = o;
+    return L;
+}
+
+int ssm_gusto_launch(sgusto_ssm_plan *pl, const SsmGustoBatch &b, hipStream_t st) {
+    const QPDims &d = pl->C.dims;
+    bool launched = false;
+#define X(SP, M, GX) if (!launched && (d.split != 0) == SP && (M == 0 || d.m == M) && pl->lean_gx == GX) { \
+        SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_ssm_kernel<SP, M, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds)); \
+        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off); launched = true; }
+    X(false, 4, 1) X(false, 4, 2) X(false, 8, 1) X(false, 4, 0) X(false, 8, 0) X(false, 0, 0) X(true, 0, 0)
+#undef X
+    SRH_REQUIRE(launched, "sgusto_ssm: no kernel variant");
+    SRH_CHECK_HIP(hipGetLastError());
+    return SRH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+/* GuSTO(SSMGuSTO(model), ...) as a resident plan (gusto.py:54-147 + models/ssm.py): `prob` is the QP in the AUGMENTED state
+ * [x ; zeta] (n_x = n + n_obs, H = [0 I], x_scale zero on zeta: sofacontrol_amd/scp/locp.py) when the model's output map is nonlinear
+ * (n_obs = the model's n_o), or the plain QP (n_x = n) with the constant H otherwise; `mode` = discretisation (sssm_linearize);
+ * Hm (n_z x n) = model.H for zopt; XA / Xb (nX x n) = the state polyhedron as gusto.py:185-201 applies it to the states, or NULL. */
+int sgusto_ssm_plan_create(sgusto_ssm_plan_t **out, sssm_t *model, const slocp_problem *prob, const sgusto_params *par, double dt, int mode,
+                           int64_t batch, const double *f_char, const double *Hm, int nX, const double *XA, const double *Xb, int max_trace) {
+    SRH_REQUIRE(out && model && prob && par && Hm, "sgusto_ssm_plan_create: null argument");
+    SRH_REQUIRE(batch > 0 && max_trace >= 0, "sgusto_ssm_plan_create: bad batch / max_trace");
+    SRH_REQUIRE(prob->n_u == model->m, "sgusto_ssm_plan_create: n_u %d != the model's %d", prob->n_u, model->m);
+    SRH_REQUIRE(prob->n_x == model->n || prob->n_x == model->n + model->no,
+                "sgusto_ssm_plan_create: the QP's state has %d entries; the model has n = %d states (+ %d outputs when they are carried)",
+                prob->n_x, model->n, model->no);
+    SRH_REQUIRE(prob->Qzf == nullptr && prob->ndU == 0, "sgusto_ssm_plan_create: terminal cost / rate rows are not on this path");
+    SRH_REQUIRE(mode >= SSM_FE && mode <= SSM_DISCRETE_MAP, "sgusto_ssm_plan_create: mode %d", mode);
+    SRH_REQUIRE(mode != SSM_DISCRETE_MAP || model->has_discrete, "sgusto_ssm_plan_create: the model has no discrete map");
+    SRH_REQUIRE(nX == 0 || (XA && Xb), "sgusto_ssm_plan_create: nX > 0 needs XA and Xb");
+    std::unique_ptr<sgusto_ssm_plan> pl(new sgusto_ssm_plan());
+    pl->model = model;
+    pl->batch = batch;
+    pl->n = model->n;
+    pl->mode = mode;
+    pl->nXv = nX;
+    pl->max_trace = max_trace;
+    int rc = build_consts(prob, pl->C);
+    if (rc) return rc;
+    QPDims &d = pl->C.dims;
+    // the lean one-wave interior point when the problem has its shape (lean.hip: lean_matches for NST < 0) and an instantiation exists
+    {
+        const int RXa = d.nX + d.nXf, gx = RXa == 0 ? 1 : (RXa <= 2 ? 2 : (RXa <= 4 ? 4 : 8));
+        const bool shape = d.lean == 2 && d.KT == 1 && d.N * d.m <= 64 && d.N * gx <= 64 && d.lean_j0 == 0 && d.po == 2 && !d.split;
+        const bool inst = (d.m == 4 && (gx == 1 || gx == 2)) || (d.m == 8 && gx == 1);
+        pl->lean_gx = (shape && inst && !getenv("SRH_GUSTO_SSM_NO_LEAN")) ? gx : 0;
+    }
+    pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
+                       par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace, 0, 0, 0};
+    const size_t n = model->n, nz = d.nz;
+    size_t doubles = (ssm_gusto_work(d, (int)n).end + 3) & ~(size_t)3;
+    d.qc_off = (long long)doubles;
+    doubles += qc_work_doubles(d);
+    pl->work_stride = (doubles + 3) & ~(size_t)3;
+    const SsmDev S = model->view();
+    const size_t a = qp_kernel_lds_bytes(d), s2 = ssm_gusto_scratch_doubles(S) * sizeof(double);
+    const size_t a2 = pl->lean_gx ? lean_kernel_lds_bytes(d) : 0;
+    const size_t body = (std::max(std::max(a, a2), s2) + 15) & ~(size_t)15;
+    pl->red_off = (int)(body / sizeof(double));
+    pl->lds = srh::lds_request(body + 16 * sizeof(double));
+    SRH_REQUIRE(pl->lds <= 160 * 1024, "sgusto_ssm_plan_create: %zu bytes of LDS needed, 160 KiB available", pl->lds);
+    std::vector<double> fs(n, 1.0);
+    if (f_char) for (size_t i = 0; i < n; ++i) fs[i] = 1.0 / fabs(f_char[i]);
+    if ((rc = pl->fs.upload(fs.data(), sizeof(double) * n)) || (rc = pl->Hm.upload(Hm, sizeof(double) * nz * n)) ||
+        (rc = pl->work.alloc(sizeof(double) * pl->work_stride * batch)) || (rc = pl->Jopt.alloc(sizeof(double) * batch)))
+        return rc;
+    if (nX > 0 && ((rc = pl->XA.upload(XA, sizeof(double) * nX * n)) || (rc = pl->Xb.upload(Xb, sizeof(double) * nX)))) return rc;
+    SRH_CHECK_HIP(hipMemset(pl->work.p, 0, sizeof(double) * pl->work_stride * batch));
+    const SsmPin PL = ssm_pin_layout(pl.get());
+    SRH_CHECK_HIP(hipHostMalloc((void **)&pl->pin, PL.total, hipHostMallocDefault));
+    pl->pin_bytes = PL.total;
+    *out = pl.release();
+    return SRH_OK;
+}
+
+int sgusto_ssm_plan_destroy(sgusto_ssm_plan_t *pl) { delete pl; return SRH_OK; }
+
+int sgusto_ssm_plan_set_max_iters(sgusto_ssm_plan_t *pl, int max_gusto_iters) {
+    SRH_REQUIRE(pl, "sgusto_ssm_plan_set_max_iters: null plan");
+    pl->par.max_iters = max_gusto_iters;
+    return SRH_OK;
+}
+
+/* Device-pointer form (asynchronous on `stream`): x0 (batch x n), u_init (batch x N x n_u), x_init (batch x (N+1) x n),
+ * z (batch x (N+1) x n_z) or NULL, u_des or NULL -> xopt, uopt, zopt, iters, status, trace (batch x max_trace x 4) or NULL. */
+int sgusto_ssm_plan_solve_dev(sgusto_ssm_plan_t *pl, const double *x0, const double *u_init, const double *x_init, const double *z,
+                              const double *u_des, double *xopt, double *uopt, double *zopt, int32_t *iters, int32_t *status, double *trace,
+                              void *stream) {
+    SRH_REQUIRE(pl && x0 && u_init && x_init && xopt && uopt && zopt && iters && status, "sgusto_ssm_plan_solve_dev: null argument");
+    SsmGustoBatch b{x0, u_init, x_init, z, u_des, pl->fs.as<double>(), pl->Hm.as<double>(), pl->nXv ? pl->XA.as<double>() : nullptr,
+                    pl->nXv ? pl->Xb.as<double>() : nullptr, pl->nXv, xopt, uopt, zopt, iters, status, trace, pl->work.as<double>(),
+                    pl->work_stride, pl->n, pl->mode, pl->Jopt.as<double>(), 0};
+    GustoPar keep = pl->par;
+    if (!trace) pl->par.max_trace = 0;
+    const int rc = ssm_gusto_launch(pl, b, (hipStream_t)stream);
+    pl->par = keep;
+    pl->solved = rc == SRH_OK;
+    return rc;
+}
+
+/* Host-pointer form: the arguments go through the plan's pinned block (memcpy in, ONE launch, ONE stream synchronisation, memcpy
+ * out) -- the kernel copies what it reads more than once into its work block. */
+int sgusto_ssm_plan_solve(sgusto_ssm_plan_t *pl, const double *x0, const double *u_init, const double *x_init, const double *z,
+                          const double *u_des, double *xopt, double *uopt, double *zopt, int32_t *iters, int32_t *status, double *trace) {
+    SRH_REQUIRE(pl && x0 && u_init && x_init && xopt && uopt && zopt, "sgusto_ssm_plan_solve: null argument");
+    const QPDims &d = pl->C.dims;
+    const size_t N = d.N, n = pl->n, m = d.m, nz = d.nz, B = pl->batch, D = sizeof(double);
+    const SsmPin PL = ssm_pin_layout(pl);
+    char *dp = nullptr;
+    SRH_CHECK_HIP(hipHostGetDevicePointer((void **)&dp, pl->pin, 0));
+    memcpy(pl->pin + PL.x0, x0, D * B * n);
+    memcpy(pl->pin + PL.u_init, u_init, D * B * N * m);
+    memcpy(pl->pin + PL.x_init, x_init, D * B * (N + 1) * n);
+    if (z) memcpy(pl->pin + PL.z, z, D * B * (N + 1) * nz);
+    if (u_des) memcpy(pl->pin + PL.ud, u_des, D * B * N * m);
+    auto dv = [&](size_t off) { return reinterpret_cast<double *>(dp + off); };
+    const bool want_trace = trace != nullptr && pl->max_trace > 0;
+    SsmGustoBatch b{dv(PL.x0), dv(PL.u_init), dv(PL.x_init), z ? dv(PL.z) : nullptr, u_des ? dv(PL.ud) : nullptr, pl->fs.as<double>(),
+                    pl->Hm.as<double>(), pl->nXv ? pl->XA.as<double>() : nullptr, pl->nXv ? pl->Xb.as<double>() : nullptr, pl->nXv,
+                    dv(PL.xopt), dv(PL.uopt), dv(PL.zopt), reinterpret_cast<int32_t *>(dp + PL.iters), reinterpret_cast<int32_t *>(dp + PL.status),
+                    want_trace ? dv(PL.trace) : nullptr, pl->work.as<double>(), pl->work_stride, pl->n, pl->mode, pl->Jopt.as<double>(), 1};
+    GustoPar keep = pl->par;
+    if (!want_trace) pl->par.max_trace = 0;
+    if (want_trace) for (size_t i = 0; i < B * (size_t)pl->max_trace * 4; ++i) reinterpret_cast<double *>(pl->pin + PL.trace)[i] = NAN;
+    const int rc = ssm_gusto_launch(pl, b, nullptr);
+    pl->par = keep;
+    if (rc) return rc;
+    SRH_CHECK_HIP(hipStreamSynchronize(nullptr));
+    pl->solved = true;
+    memcpy(xopt, pl->pin + PL.xopt, D * B * (N + 1) * n);
+    memcpy(uopt, pl->pin + PL.uopt, D * B * N * m);
+    memcpy(zopt, pl->pin + PL.zopt, D * B * (N + 1) * nz);
+    if (iters) memcpy(iters, pl->pin + PL.iters, sizeof(int32_t) * B);
+    if (status) memcpy(status, pl->pin + PL.status, sizeof(int32_t) * B);
+    if (want_trace) memcpy(trace, pl->pin + PL.trace, D * B * (size_t)pl->max_trace * 4);
+    return SRH_OK;
+}
+
+}  // extern "C"

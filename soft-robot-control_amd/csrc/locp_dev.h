@@ -1066,7 +1066,12 @@ namespace qp {
 template <bool SPLIT, int MSEL, int NSEL>
 __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
                                      QPLds &L, double *J_out, int *iters_out, bool prescreen, QPWork &wout, bool full_first = false,
-                                     bool warm = false, int *pass_out = nullptr) {
+                                     bool warm = false, int *pass_out = nullptr, bool warm_full = false) {
+    // warm_full (round 6): the caller's PREVIOUS QP was finished by the FULL pass (trust-region rows active) and this one goes
+    // straight to the full pass as well (full_first) -- a rejected SCP step: same linearisation, delta halved or omega raised,
+    // gusto.py:383-402 / locp.py:139-141 `update(full=False)` -- so w.u, w.s and w.lam of the full layout still hold that QP's
+    // minimiser and multipliers: start from them like the relaxed pass does (the tail of an uncapped solve is one rollout's chain of
+    // such QPs: 22 interior-point iterations each from the cold start).  A warm attempt that fails is repeated cold.
     // warm (round 4, as ql::ipm_box): the caller's PREVIOUS QP was finished by the relaxed Riccati pass below, so w.u and
     // w.lam of that layout still hold its minimiser and multipliers -- the relaxed pass of this QP starts from them
     // (t = max(-g(u), floor), lam = max(lam, floor), no starting system); a warm attempt that fails is repeated cold.
@@ -1144,8 +1149,8 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
         qp_carve(w, work_base, d);
         wout = w;
         if (pass_out) *pass_out = pass;
-        const bool warm_now = warm && npass == 2 && pass == 0;
-        warm = false;                                  // (a repeated pass starts cold)
+        const bool warm_now = (warm && npass == 2 && pass == 0) || (warm_full && npass == 2 && pass == 1 && first_pass == 1);
+        warm = false; warm_full = false;               // (a repeated pass starts cold)
         const int N = d.N, n = d.n, m = d.m;
         w.tprof = q.dbg ? q.dbg + 8 * 63 : (gptr)nullptr;
 #ifdef SRH_PROFILE
@@ -1155,7 +1160,7 @@ __device__ __forceinline__ int solve(const QPDims &dfull, const QPConst &c, cons
 #endif
         const double s0 = slack0(dfull, c, q, L);
         if (!warm_now) for (int e = tid; e < N * m; e += nt) w.u[e] = 0.0;
-        for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
+        for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : ((warm_now && d.tr) ? fmax(w.s[e], 0.0) : 0.0);
         for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
         __syncthreads();
         rollout(d, dyn, q, w.u, w.x, L);

@@ -953,6 +953,13 @@ static int utmu_one_pass(srom *h, const double *const *Ms, int count, double *co
     }
     const int64_t rowtiles = srh::cdiv(h->n_f, ROWS_WG);
     int ksplit = proj_ksplit(h, h->n_f, 1, &a.chunks_per_split);
+    if (count > 1) {
+        // several matrices per launch: as many K-slices as keep ALL workgroups of the launch resident at once (two per CU: 512) --
+        // measured at n_f = 4884, r = 30, four matrices: 3 slices (468 workgroups) 183 us, 4 (624) 236 us, 6 (936) 196 us, 13 (2028) 222 us
+        const int want = (int)std::max<int64_t>(1, std::min<int64_t>(h->nchunks, 512 / (rowtiles * count)));
+        a.chunks_per_split = (int)srh::cdiv(h->nchunks, want);
+        ksplit = (int)srh::cdiv(h->nchunks, a.chunks_per_split);
+    }
     if (const char *e = getenv("SRH_UTMU_KSPLIT")) {       // A/B: K-slices per row tile (default: ~512 workgroups)
         const int want = std::max(1, std::min(atoi(e), h->nchunks));
         a.chunks_per_split = (int)srh::cdiv(h->nchunks, want);

@@ -377,6 +377,10 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             int j0 = -1;
             for (int t = 0; t <= N; ++t)
                 if (ql::lds_doubles(d, NTHREADS, t) * sizeof(double) <= (size_t)160 * 1024) { j0 = t; break; }
+            // A/B knob (read when the constants are built): SRH_LEAN_J0=k keeps the packed rows of the stages < k in the L2 block even
+            // where the LDS has room for them -- with SRH_LEAN_NO_FIXED=1 (run-time layouts) this measures what streaming G from L2
+            // costs the interior point (round 6: the price of any layout that gives up LDS for a second resident workgroup)
+            if (const char *e = getenv("SRH_LEAN_J0")) { if (j0 >= 0) j0 = std::min(N - 1, std::max(j0, atoi(e))); }
             std::vector<int> sched;
             // (the SCP loop of the lean GuSTO kernel stages both trajectories in the K-tile area between two QPs: csrc/lean.hip)
             const bool stage_fits = j0 >= 0 && ql::sizes(d, NTHREADS, j0).regX >= (size_t)2 * (N + 1) * n + (size_t)2 * N * m + (size_t)pr->nX * n;

@@ -4,9 +4,12 @@ For a TPWL model (scp/models/tpwl.py adapter) the whole `solve` -- nearest-point
 trajectory, the LOCP QP (Riccati interior point), trust-region / model-accuracy / convergence tests
 and re-linearisation -- runs inside ONE persistent HIP kernel (csrc/gusto.hip: gusto_kernel), one
 workgroup per rollout; `batch` independent rollouts (different x0 / targets, same model) can be solved
-by one launch with `GuSTO.solve_batch`.  Any other TemplateModel falls back to the reference's host
-loop around the device QP (`LOCP`), i.e. still no CPU arithmetic for the QP."""
+by one launch with `GuSTO.solve_batch`.  An SSM polynomial model (scp/models/ssm.py adapter: the reference's hardware loop,
+examples/hardware/diamond_SSM.py:353-361) has its own persistent kernel (csrc/gusto_ssm.hip: analytic linearisation of the
+dynamics and of the output map inside the loop).  Any other TemplateModel -- a user's Python dynamics, weighting-mode TPWL,
+input-rate rows -- runs the SCP rules on the host around the device QP (`LOCP`): still no CPU arithmetic for the QP."""
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -14,6 +17,7 @@ import numpy as np
 from .. import _lib
 from .locp import LOCP, make_problem
 from .models.tpwl import TPWLGuSTO
+from .models.ssm import SSMGuSTO
 
 #### Default variables for GuSTO (gusto.py:12-22) ####
 DELTA0 = 1e4
@@ -72,11 +76,19 @@ class GuSTO:
         # input-rate constraints couple the stages: they go through the generic loop around the (augmented) device QP
         self._fused = (isinstance(model, TPWLGuSTO) and not self.nonlinear_observer and dU is None and
                        getattr(model.dyn_sys, 'tpwl_method', 'nn') == 'nn')
+        # an SSM model: the whole solve in csrc/gusto_ssm.hip (no terminal cost, no rate rows; the state polyhedron is applied to the
+        # states by the reference's own test, gusto.py:185-201, so its matrix must have n_x columns)
+        self._ssm = (isinstance(model, SSMGuSTO) and dU is None and Qzf is None and Xf is None and
+                     (X is None or np.asarray(X.A).shape[1] == self.n_x) and hasattr(model.dyn_sys, 'handle') and
+                     not os.environ.get('SRH_GUSTO_SSM_HOST_LOOP'))          # (that knob: the host loop, for A/B runs and tests)
         self._plan = C.c_void_p()
         self.trace = None
         self.iters = None
         self.status = None
-        if self._fused:
+        if self._ssm:
+            self._create_ssm_plan(model, N, dt, Qz, R, U, X)
+            self._fused = True
+        elif self._fused:
             prob, self._keep = make_problem(N, model.H, Qz, R, Qzf, U, X, Xf, dU, None, True)
             par = self._params(MAX_ITERS)
             xc, fc = _lib.f64(self.x_char), _lib.f64(self.f_char)
@@ -95,10 +107,31 @@ class GuSTO:
         else:
             self.solve_batch(x0, u_init, x_init, z, zf, u)
         self.max_gusto_iters = user_max_iters
-        if self._fused:
+        if self._ssm:
+            pass                                     # (solve_batch sets the cap of every call)
+        elif self._fused:
             _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(user_max_iters))), 'set_max_iters')
             if self.keep_solver_state:
                 _lib.check(_lib.lib().sgusto_plan_set_warm_across(self._plan, C.c_int(1)), 'set_warm_across')
+
+    def _create_ssm_plan(self, model, N, dt, Qz, R, U, X):
+        """The resident plan of csrc/gusto_ssm.hip.  With a nonlinear output map the QP is posed in the augmented state [x ; zeta]
+        (LOCP._init_augmented: H_a = [0 I], X on zeta, zero trust-region scale on zeta) -- the same problem data the host loop
+        handed to the QP kernel; the kernel fills the per-stage matrices itself."""
+        sys_ = model.dyn_sys
+        proto = LOCP(N, model.H, Qz, R, Qzf=None, U=U, X=X, Xf=None, dU=None, x_char=self.x_char,
+                     nonlinear_observer=self.nonlinear_observer)
+        self._keep = (proto, proto._prob, proto._keep)
+        Hm = _lib.f64(np.asarray(model.H).reshape(self.n_z, self.n_x))
+        fc = _lib.f64(self.f_char)
+        nX = 0 if X is None else int(np.asarray(X.A).shape[0])
+        XA = None if X is None else _lib.f64(np.asarray(X.A).reshape(nX, self.n_x))
+        Xb = None if X is None else _lib.f64(np.asarray(X.b).reshape(nX))
+        par = self._params(MAX_ITERS)
+        _lib.check(_lib.lib().sgusto_ssm_plan_create(C.byref(self._plan), sys_.handle, C.byref(proto._prob), C.byref(par),
+                                                     C.c_double(dt), C.c_int(sys_._mode()), C.c_int64(self.batch), _lib.dptr(fc),
+                                                     _lib.dptr(Hm), C.c_int(nX), _lib.dptr(XA), _lib.dptr(Xb),
+                                                     C.c_int(self.max_trace)), 'sgusto_ssm_plan_create')
 
     def _params(self, max_iters):
         return _lib.SGustoParams(float(self.delta0), float(self.omega0), float(self.rho), float(self.beta_fail),
@@ -108,7 +141,7 @@ class GuSTO:
     def __del__(self):
         try:
             if self._plan:
-                _lib.lib().sgusto_plan_destroy(self._plan)
+                (_lib.lib().sgusto_ssm_plan_destroy if self._ssm else _lib.lib().sgusto_plan_destroy)(self._plan)
                 self._plan = C.c_void_p()
         except Exception:
             pass
@@ -121,7 +154,7 @@ class GuSTO:
     def variant(self):
         """(split panel, compile-time n_u, compile-time n_x) of the kernel instantiation this plan launches; zeros mean
         run-time extents ((False, 0, 0) = the all-sizes kernel).  None for the host-loop models."""
-        if not self._fused:
+        if not self._fused or self._ssm:
             return None
         sp, mu, nx = C.c_int(), C.c_int(), C.c_int()
         _lib.check(_lib.lib().sgusto_plan_variant(self._plan, C.byref(sp), C.byref(mu), C.byref(nx)), 'sgusto_plan_variant')
@@ -131,7 +164,7 @@ class GuSTO:
     def costs(self):
         """(batch,) optimal LOCP value of the solution every rollout of the last solve returned (sgusto_plan_costs; fused
         TPWL plans only): what a sharded batch gathers to pick its best rollout (distributed.gather_rollout_costs)."""
-        if not self._fused:
+        if not self._fused or self._ssm:
             raise NotImplementedError('GuSTO.costs: per-rollout costs are kept by the resident TPWL plan only')
         J = np.empty(self.batch)
         _lib.check(_lib.lib().sgusto_plan_costs(self._plan, _lib.dptr(J)), 'sgusto_plan_costs')
@@ -142,6 +175,8 @@ class GuSTO:
         """What the last solve of this plan launched (sgusto_plan_info): the kernel family, the template arguments of
         the instantiation -- the name a rocprof trace shows, e.g. 'lean<4, 60, 4, 50, 7, 4>' for BASELINE C2 -- and how
         many rollouts the lean kernel handed to the fused one.  The host-loop models report their LOCP plan's kernels."""
+        if self._ssm:
+            return {'family': 'ssm', 'kernel': 'gusto_ssm_kernel', 'lean': None, 'fused': None, 'handed_over': 0}
         if not self._fused:
             return self.locp.kernel_info
         info = _lib.SrhKernelInfo()
@@ -216,7 +251,7 @@ class GuSTO:
         """`batch` independent rollouts in one launch: x0 (B,n_x), u_init (B,N,n_u), x_init (B,N+1,n_x),
         z (B,N+1,n_z) ..."""
         if not self._fused:
-            raise RuntimeError('solve_batch needs a TPWLGuSTO model')
+            raise RuntimeError('solve_batch needs a TPWLGuSTO or SSMGuSTO model (a resident device plan)')
         B, N, n, m, nz = self.batch, self.N, self.n_x, self.n_u, self.n_z
         f = _lib.f64
         x0 = f(np.asarray(x0).reshape(B, n)); u_init = f(np.asarray(u_init).reshape(B, N, m))
@@ -227,6 +262,16 @@ class GuSTO:
         xo = np.empty((B, N + 1, n)); uo = np.empty((B, N, m)); zo = np.empty((B, N + 1, nz))
         iters = np.empty(B, dtype=np.int32); status = np.empty(B, dtype=np.int32)
         trace = np.full((B, self.max_trace, 4), np.nan) if self.max_trace > 0 else None
+        if self._ssm:
+            _lib.check(_lib.lib().sgusto_ssm_plan_set_max_iters(self._plan, C.c_int(int(self.max_gusto_iters))), 'set_max_iters')
+            t0 = time.time()
+            _lib.check(_lib.lib().sgusto_ssm_plan_solve(self._plan, _lib.dptr(x0), _lib.dptr(u_init), _lib.dptr(x_init), _lib.dptr(z),
+                                                        _lib.dptr(u), _lib.dptr(xo), _lib.dptr(uo), _lib.dptr(zo), _lib.iptr(iters),
+                                                        _lib.iptr(status), _lib.dptr(trace)), 'sgusto_ssm_plan_solve')
+            self.locp_solve_time = time.time() - t0
+            self.iters, self.status, self.trace = iters, status, trace
+            self.xopt, self.uopt, self.zopt = xo, uo, zo
+            return xo, uo, zo
         _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(self.max_gusto_iters))), 'set_max_iters')
         t0 = time.time()
         _lib.check(_lib.lib().sgusto_plan_solve(self._plan, _lib.dptr(x0), _lib.dptr(u_init), _lib.dptr(x_init),
@@ -242,7 +287,7 @@ class GuSTO:
     def solve_begin(self, x0, u_init, x_init, z=None, zf=None, u=None):
         """Enqueue one solve (same arguments as `solve` / `solve_batch`) and return immediately; `solve_done()` polls,
         `solve_end()` waits and installs the result like `solve` does.  (scp/ros.py:183-223 `send_request(wait=False)`.)"""
-        if not self._fused:
+        if not self._fused or self._ssm:
             raise RuntimeError('asynchronous solves need the fused TPWL plan')
         B, N, n, m, nz = self.batch, self.N, self.n_x, self.n_u, self.n_z
         f = _lib.f64
@@ -307,70 +352,64 @@ class GuSTO:
             return
         self._solve_host_loop(x0, u_init, x_init, z, zf, u)
 
+    # ---- generic models: the SCP rules on the host, the QP on the device
+    def _linearise(self):
+        """Stage matrices (and output maps) of the current iterate (gusto.py:225-251)."""
+        dyn = self.get_traj_dynamics(self.x_k, self.u_k)
+        obs = self.get_observer_linearizations(self.x_k, self.u_k) if self.nonlinear_observer else (None, None)
+        return dyn, obs
+
+    def _judge(self, st, J, x_new, u_new, itr):
+        """One transition of the (J, delta, omega) state machine the kernels and oracle/gusto.py share (gusto.py:371-428, SURVEY
+        appendix B).  `st` holds delta, omega and the previous accepted (J, delta, omega); returns (accepted, converged, rho_k)."""
+        _, inside = self.is_in_trust_region(x_new, st['delta'])
+        if not inside:                                   # step leaves the trust region: harder penalty, same QP data
+            st['omega'] *= self.gamma_fail
+            return False, False, -1.0
+        rho_k = self.compute_accuracy(x_new, u_new, J)
+        if rho_k > self.rho and itr != 1:                # model too inaccurate over this step: shrink, same QP data
+            st['delta'] *= self.beta_fail
+            return False, False, rho_k
+        if st['prev'] == (st['delta'], st['omega']) and st['J_prev'] <= J:
+            st['delta'] *= self.beta_fail
+        st['prev'], st['J_prev'] = (st['delta'], st['omega']), J
+        _, feasible = self.state_constraints_violated(x_new)
+        if not feasible:
+            st['omega'] *= self.gamma_fail
+        _, settled = self.is_converged(x_new, u_new)
+        return True, settled and feasible, rho_k
+
     def _solve_host_loop(self, x0, u_init, x_init, z, zf, u):
-        """The reference's loop (gusto.py:283-487) around the device QP, for generic models."""
-        t_locp = 0.0
-        itr = 0
-        self.u_k = u_init
-        self.x_k = x_init
-        A_d, B_d, d_d = self.get_traj_dynamics(self.x_k, self.u_k)
-        H_d, c_d = self.get_observer_linearizations(self.x_k, self.u_k) if self.nonlinear_observer else (None, None)
-        new_solution = True
-        Jstar_prev = delta_prev = omega_prev = np.inf
-        converged = False
-        delta, omega = self.delta0, self.omega0
-        log = []
-        while self.is_valid_iteration(itr) and not converged and omega <= self.omega_max:
-            self.locp.update(A_d, B_d, d_d, x0, self.x_k, delta, omega, z=z, zf=zf, u=u, full=new_solution,
-                             Hd=H_d, cd=c_d)
-            new_solution = False
-            Jstar, success, stats = self.locp.solve()
-            if not success:
+        """GuSTO.solve for a generic TemplateModel (gusto.py:283-487): linearise -> device QP -> `_judge` -> accept / re-linearise."""
+        self.x_k, self.u_k = x_init, u_init
+        (A_d, B_d, d_d), (H_d, c_d) = self._linearise()
+        st = {'delta': self.delta0, 'omega': self.omega0, 'prev': (np.inf, np.inf), 'J_prev': np.inf}
+        fresh, done, itr, t_locp, log = True, False, 0, 0.0, []
+        while self.is_valid_iteration(itr) and not done and st['omega'] <= self.omega_max:
+            self.locp.update(A_d, B_d, d_d, x0, self.x_k, st['delta'], st['omega'], z=z, zf=zf, u=u, full=fresh, Hd=H_d, cd=c_d)
+            fresh = False
+            J, ok, stats = self.locp.solve()
+            if not ok:                                   # gusto.py:357-365: report, keep the last accepted iterate
                 print('Iteration {} of problem cannot be solved, see solver status for more information'.format(itr))
-                self.xopt = np.copy(self.x_k)
-                self.uopt = np.copy(self.u_k)
-                if self.nonlinear_observer:
-                    self.zopt = self.model.dyn_sys.C_map(self.xopt.T)
-                else:
-                    self.zopt = np.transpose(self.model.H @ self.xopt.T)
+                self.xopt, self.uopt = np.copy(self.x_k), np.copy(self.u_k)
+                self.zopt = (self.model.dyn_sys.C_map(self.xopt.T) if self.nonlinear_observer
+                             else np.transpose(self.model.H @ self.xopt.T))
                 return
             t_locp += stats.solve_time
-            x_next, u_next, _ = self.locp.get_solution()
-            e_tr, tr_satisfied = self.is_in_trust_region(x_next, delta)
-            rho_k = -1.0
-            log.append([Jstar, delta, omega, rho_k])          # (J, delta, omega, rho) per QP, like the fused kernel's trace
-            if tr_satisfied:
-                rho_k = self.compute_accuracy(x_next, u_next, Jstar)
-                log[-1][3] = rho_k
-                if rho_k > self.rho and itr != 1:
-                    delta = self.beta_fail * delta
-                else:
-                    if delta_prev == delta and omega_prev == omega and Jstar_prev <= Jstar:
-                        delta = self.beta_fail * delta
-                    delta_prev, Jstar_prev, omega_prev = delta, Jstar, omega
-                    max_violation, X_satisfied = self.state_constraints_violated(x_next)
-                    if not X_satisfied:
-                        omega = self.gamma_fail * omega
-                    dsol, converged = self.is_converged(x_next, u_next)
-                    if not X_satisfied:
-                        converged = False
-                    new_solution = True
-            else:
-                omega = self.gamma_fail * omega
+            x_new, u_new, _ = self.locp.get_solution()
+            row = [J, st['delta'], st['omega'], -1.0]   # (J, delta, omega, rho) per QP, like the kernels' trace
+            fresh, done, row[3] = self._judge(st, J, x_new, u_new, itr)
+            log.append(row)
             itr += 1
-            if new_solution:
-                self.x_k = x_next.copy()
-                self.u_k = u_next.copy()
+            if fresh:
+                self.x_k, self.u_k = x_new.copy(), u_new.copy()
                 if self.max_gusto_iters >= 1:
-                    A_d, B_d, d_d = self.get_traj_dynamics(self.x_k, self.u_k)
-                    if self.nonlinear_observer:
-                        H_d, c_d = self.get_observer_linearizations(self.x_k, self.u_k)
-        if omega > self.omega_max:
+                    (A_d, B_d, d_d), (H_d, c_d) = self._linearise()
+        if st['omega'] > self.omega_max:
             print('omega > omega_max, solution did not converge')
         if not self.is_valid_iteration(itr - 1):
             print('Max iterations, solution did not converge')
-        self.xopt = np.copy(self.x_k)
-        self.uopt = np.copy(self.u_k)
+        self.xopt, self.uopt = np.copy(self.x_k), np.copy(self.u_k)
         self.zopt = np.transpose(self.model.H @ self.xopt.T)
         self.locp_solve_time = t_locp
         self.iters = np.array([itr], dtype=np.int32)

@@ -77,7 +77,8 @@ class GuSTOSolverNode():
     # ---- the same request split into enqueue / poll / collect (the client's wait=False path)
     @property
     def supports_async(self):
-        return bool(getattr(self.gusto, '_fused', False)) and self.gusto.batch == 1
+        return (bool(getattr(self.gusto, '_fused', False)) and not getattr(self.gusto, '_ssm', False)
+                and self.gusto.batch == 1)
 
     def gusto_callback_begin(self, t0, x0):
         z, zf, u = self.get_target(t0)

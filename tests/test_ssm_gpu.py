@@ -87,9 +87,14 @@ def test_batched_rollout_vs_oracle():
         close(X[b], xo, 1e-10); close(Z[b], zo, 1e-10)
 
 
+@pytest.mark.parametrize('path', ['device', 'host'])
 @pytest.mark.parametrize('with_X', [False, True])
-def test_gusto_ssm_nonlinear_observer(with_X):
-    """GuSTO over SSMGuSTO: per-stage observer linearisation in the QP (locp.py:231-245, 312-329)."""
+def test_gusto_ssm_nonlinear_observer(with_X, path, monkeypatch):
+    """GuSTO over SSMGuSTO: per-stage observer linearisation in the QP (locp.py:231-245, 312-329).  `device`: the whole solve in
+    one launch of csrc/gusto_ssm.hip (round 6); `host`: the SCP rules on the host around the device QP (SRH_GUSTO_SSM_HOST_LOOP=1,
+    what every other TemplateModel runs).  Both against oracle.gusto.solve_generic: equal iteration counts, equal trajectories."""
+    if path == 'host':
+        monkeypatch.setenv('SRH_GUSTO_SSM_HOST_LOOP', '1')
     from sofacontrol_amd.scp.models.ssm import SSMGuSTO
     from sofacontrol_amd.scp.gusto import GuSTO
     from sofacontrol_amd.utils import HyperRectangle, Polyhedron
@@ -108,7 +113,7 @@ def test_gusto_ssm_nonlinear_observer(with_X):
     if with_X:
         X = Polyhedron(np.array([[1.0, 0, 0, 0], [-1.0, 0, 0, 0]]), np.array([0.5, 0.5]))
     g = GuSTO(gm, N, dt, Qz, R, x0, u_init, x_init, z=z, U=U, X=X, verbose=0, max_gusto_iters=6, convg_thresh=1e-4)
-    assert not g._fused and g.nonlinear_observer
+    assert g._ssm == (path == 'device') and g._fused == (path == 'device') and g.nonlinear_observer
     xopt, uopt, zopt, _ = g.get_solution()
 
     def dyn_d(x, u):
@@ -124,6 +129,61 @@ def test_gusto_ssm_nonlinear_observer(with_X):
     assert len(tr) == int(g.iters[0])
     close(xopt, xo, 1e-6); close(uopt, uo, 1e-5)
     np.testing.assert_array_equal(zopt, np.zeros((N + 1, n)))        # gusto.py:483 with H = 0 (ssm.py:69)
+    # the (J, delta, omega, rho) trace of every SCP iteration follows the oracle's too
+    got = g.trace[0, :len(tr)]
+    close(got[:, :3], np.asarray(tr)[:, :3], 1e-6)
+
+
+def test_gusto_ssm_real_time_iteration_device_equals_host_loop(monkeypatch):
+    """The reference's hardware loop (examples/hardware/diamond_SSM.py:353-361: n_x = 6, n_u = 4, N = 3, dt = 0.02,
+    max_gusto_iters = 0 -- one QP per call) on the device path and on the host loop: same plans over a sequence of receding-horizon
+    calls (the constructor's solve runs the default cap of 500, gusto.py:142-147), batched device solves equal the single ones."""
+    from sofacontrol_amd.scp.models.ssm import SSMGuSTO
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import HyperRectangle
+    n, m, N, dt = 6, 4, 3, 0.02
+    model = ossm.synthetic(n, m, 3, 2, seed=96)
+    rng = np.random.default_rng(12)
+    Qz = np.zeros((n, n)); Qz[0, 0] = Qz[1, 1] = 100.0
+    R = 0.003 * np.eye(m)
+    U = HyperRectangle([1500.0] * m, [0.0] * m)
+    x0s = 0.05 * rng.standard_normal((4, n))
+    z = np.tile(np.array([0.02, -0.01, 0, 0, 0, 0.0]), (N + 1, 1))
+    res = {}
+    for path in ('device', 'host'):
+        if path == 'host':
+            monkeypatch.setenv('SRH_GUSTO_SSM_HOST_LOOP', '1')
+        else:
+            monkeypatch.delenv('SRH_GUSTO_SSM_HOST_LOOP', raising=False)
+        s = product_ssm(model, discr='be')
+        gm = SSMGuSTO(s)
+        u0 = np.zeros((N, m))
+        xi, _ = s.rollout(x0s[0], u0, dt)
+        g = GuSTO(gm, N, dt, Qz, R, x0s[0], u0, xi, z=z, U=U, verbose=0, max_gusto_iters=0, convg_thresh=1e-3)
+        assert g._ssm == (path == 'device')
+        out = [(g.xopt.copy(), g.uopt.copy(), int(g.iters[0]))]
+        for b in range(1, 4):
+            xi, _ = s.rollout(x0s[b], out[-1][1], dt)
+            g.solve(x0s[b], out[-1][1], xi, z, None, None)
+            assert int(g.iters[0]) == 1
+            out.append((g.xopt.copy(), g.uopt.copy(), 1))
+        res[path] = out
+    for a, b in zip(res['device'], res['host']):
+        assert a[2] == b[2]
+        close(a[0], b[0], 1e-7); close(a[1], b[1], 1e-6)
+    # a batch of four rollouts in one launch equals four single solves
+    monkeypatch.delenv('SRH_GUSTO_SSM_HOST_LOOP', raising=False)
+    s = product_ssm(model, discr='be')
+    gm = SSMGuSTO(s)
+    u0 = np.zeros((4, N, m))
+    xi = np.stack([s.rollout(x0s[b], u0[b], dt)[0] for b in range(4)])
+    zb = np.tile(z, (4, 1, 1))
+    gb = GuSTO(gm, N, dt, Qz, R, x0s, u0, xi, z=zb, U=U, verbose=0, max_gusto_iters=3, convg_thresh=1e-3, batch=4, first_solve_cap=3)
+    g1 = GuSTO(gm, N, dt, Qz, R, x0s[0], u0[0], xi[0], z=z, U=U, verbose=0, max_gusto_iters=3, convg_thresh=1e-3, first_solve_cap=3)
+    for b in range(4):
+        g1.solve(x0s[b], u0[b], xi[b], z, None, None)
+        assert int(g1.iters[0]) == int(gb.iters[b])
+        close(gb.xopt[b], g1.xopt, 1e-12); close(gb.uopt[b], g1.uopt, 1e-12)
 
 
 ILQR_SSM_CASES = dict(h0=('be', 20, False), hw=('be', 40, True), fe=('fe', 25, True))

@@ -16,8 +16,13 @@ mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG
 python - <<'PY'
 import json
 import os
-l=open('gpurun_out/%s/bench.log' % os.environ['TAG']).read().strip().splitlines()[-1]
-d=json.loads(l)
-print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline', d['roofline'], 'vs', d.get('vs_baseline'))
-print('c5', {k:v for k,v in d['secondary']['scp_c5'].items() if k in ('ms','ms_all_calls','constructor_s (plan creation + first solve at first_solve_cap = 5)')})
+lines=open('gpurun_out/%s/bench.log' % os.environ['TAG']).read().strip().splitlines()
+d=json.loads(lines[-1])
+assert len(lines[-1]) <= 4096, len(lines[-1])
+print('value', d['value'], 'ms/step', d['ms_per_step'], 'roofline', d['roofline'], 'vs', d.get('vs_baseline'), 'line bytes', len(lines[-1]))
+full=[l for l in lines if l.startswith('BENCH_DETAIL ')]
+if full:
+    sec=json.loads(full[-1].split(' ', 1)[1]).get('secondary', {})
+    print('c5', {k:v for k,v in sec.get('scp_c5', {}).items() if k in ('ms','ms_all_calls')})
+    print('ssm_gusto_rti', {k:v for k,v in sec.get('ssm_gusto_rti', {}).items() if k in ('ms_median','ms_p95','kernel')})
 PY

@@ -63,3 +63,7 @@ for b in order:
           '(min delta %.3g, max omega %.3g); handed over %s' % (b, int(g1.iters[0]), it[b], int(g1.status[0]), min(ts) * 1e3,
                                                                   min(ts) * 1e3 / int(g1.iters[0]), small, tr[:, 1].min(), tr[:, 2].max(),
                                                                   g1.kernel_info['handed_over']))
+    if os.environ.get('SRH_GUSTO_TRACE_QIT'):
+        print('   per SCP iteration [interior-point iterations + 1000 (pass + 1); lean iterations show rho]:', ' '.join('%g' % v for v in tr[:, 3]))
+        print('   delta:', ' '.join('%.3g' % v for v in tr[:, 1]))
+        print('   omega:', ' '.join('%.3g' % v for v in tr[:, 2]))
