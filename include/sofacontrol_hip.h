@@ -441,6 +441,7 @@ int sgusto_ssm_plan_create(sgusto_ssm_plan_t **plan, sssm_t *model, const slocp_
                            int max_trace);
 int sgusto_ssm_plan_destroy(sgusto_ssm_plan_t *plan);
 int sgusto_ssm_plan_set_max_iters(sgusto_ssm_plan_t *plan, int max_gusto_iters);
+int sgusto_ssm_plan_set_warm_across(sgusto_ssm_plan_t *plan, int on);   /* as sgusto_plan_set_warm_across (locp.py:181) */
 int sgusto_ssm_plan_solve(sgusto_ssm_plan_t *plan, const double *x0, const double *u_init, const double *x_init, const double *z,
                           const double *u_des, double *xopt, double *uopt, double *zopt, int32_t *iters, int32_t *status, double *trace);
 int sgusto_ssm_plan_solve_dev(sgusto_ssm_plan_t *plan, const double *x0_dev, const double *u_init_dev, const double *x_init_dev,

@@ -42,7 +42,7 @@ struct SsmGustoBatch {
 };
 
 // offsets (doubles) of the SCP loop's arrays behind the QP's own work arrays
-struct SsmGustoWork { size_t xk, uk, A, AT, B, BT, dd, xka, x0a, acc, x0c, zc, udc, end; };
+struct SsmGustoWork { size_t xk, uk, A, AT, B, BT, dd, xka, x0a, acc, x0c, zc, udc, Ac, fk, rec, end; };
 __host__ __device__ inline SsmGustoWork ssm_gusto_work(const QPDims &d, int n) {
     SsmGustoWork g;
     const size_t N = d.N, na = d.n, m = d.m;
@@ -59,7 +59,10 @@ __host__ __device__ inline SsmGustoWork ssm_gusto_work(const QPDims &d, int n) {
     g.x0c = g.acc + 2 * N;
     g.zc = g.x0c + n;
     g.udc = g.zc + (N + 1) * d.nz;
-    g.end = g.udc + N * m;
+    g.Ac = g.udc + N * m;                       // continuous Jacobians and f of the current iterate (model-accuracy test, table path)
+    g.fk = g.Ac + N * (size_t)n * n;
+    g.rec = g.fk + N * (size_t)n;               // [0] = 1: w.u / w.lam hold a converged lean QP of this rollout's previous solve (warm_across)
+    g.end = g.rec + 4;
     return g;
 }
 
@@ -72,7 +75,7 @@ __host__ __device__ inline size_t ssm_gusto_scratch_doubles(const SsmDev &S) {
 // driver's N = 3, 31 k clocks per interior-point iteration against 70 k of the eight-wave forms -- DESIGN.md section 13); qp::solve takes over
 // when that minimiser leaves the trust region or the interior point does not converge.  GXL = lanes per stage for the state rows (ql::ipm_box).
 template <bool SPLIT, int MSEL, int GXL>
-__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off) {
+__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off, int tab_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     qp::specialise<MSEL, 0>(d);
     long long prof[32] = {0};
@@ -95,6 +98,34 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
     lptr us = xs + n, Al = us + m, Bl = Al + (size_t)n * n, dl = Bl + (size_t)n * m, zs = dl + n, cs = zs + S.no, Hl = cs + S.no;
     lptr A2 = Hl + (size_t)S.no * n, B2 = A2 + (size_t)n * n, d2 = B2 + (size_t)n * m, x2 = d2 + n, u2 = x2 + n;
     lptr red = (lptr)smem + red_off;        // reduction scratch behind both layouts
+    // The model's coefficient and exponent tables in LDS behind everything else, staged ONCE per launch (ssm::stage, as the iLQR kernel does):
+    // with the rows of R read from L2 inside latency-bound dot products one linearisation is ~25 k clocks, from LDS a few thousand; the
+    // real-time iteration of the hardware driver does N of them + N + 1 observer linearisations + N dynamics evaluations per call.
+    // Only for the fe / be / bil discretisations (they and the model-accuracy test share the continuous coefficients); tab_off = 0: global path.
+    const bool tab = tab_off > 0;
+    SsmLds T{};
+    if (tab) ssm::stage(T, (lptr)smem + tab_off, S, false, 0);
+    gptr Acg = base + gw.Ac, fkg = base + gw.fk;
+    // z = C(x), H = dC/dx, c = z - H x at xs (ssm::observe with the tables in LDS)
+    auto observe_tab = [&]() {
+        const int ns = S.ns, sno = S.no;
+        ssm::basis_l(T.es, T.ps, T.vs, T.dms, T.lvs, S.order_s, ns, sno, xs, sw.phi, sw.D);
+        for (int e = tid; e < sno * (n + 1); e += nt) {
+            const int i = e / (n + 1), j = e - i * (n + 1);
+            clptr wr = T.W + (size_t)i * ns;
+            double acc = 0.0;
+            if (j < n) for (int k = 0; k < ns; ++k) acc = fma(wr[k], sw.D[(size_t)k * sno + j], acc);
+            else for (int k = 0; k < ns; ++k) acc = fma(wr[k], sw.phi[k], acc);
+            if (j < n) Hl[i * n + j] = acc; else zs[i] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < sno; i += nt) {
+            double sx = 0.0;
+            for (int k = 0; k < n; ++k) sx = fma(Hl[i * n + k], xs[k], sx);
+            cs[i] = zs[i] - sx;
+        }
+        __syncthreads();
+    };
 
     cgptr x0 = (cgptr)(b.x0 + p * n);
     cgptr zp = (cgptr)(b.z ? b.z + p * (size_t)(N + 1) * nz : nullptr);
@@ -117,7 +148,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
         if (no > 0) {
             for (int e = tid; e < n; e += nt) xs[e] = xk[e];
             __syncthreads();
-            ssm::observe(S, xs, sw, zs, Hl, cs);
+            if (tab) observe_tab(); else ssm::observe(S, xs, sw, zs, Hl, cs);
             for (int e = tid; e < na; e += nt) {
                 double v0, vk;
                 if (e < n) { v0 = x0[e]; vk = xs[e]; }
@@ -137,11 +168,19 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
             for (int e = tid; e < n; e += nt) xs[e] = xk[(size_t)k * n + e];
             for (int e = tid; e < m; e += nt) us[e] = uk[(size_t)k * m + e];
             __syncthreads();
-            ssm::linearize(S, b.mode, par.dt, xs, us, sw, Al, n, Bl, dl);
+            if (tab) {
+                ssm::jacobians_l(S, T, false, xs, us, sw, Al, n, Bl, dl);          // continuous (A, B, d) and f(xbar_k, ubar_k) in sw.f
+                for (int e = tid; e < n * n; e += nt) Acg[(size_t)k * n * n + e] = Al[e];
+                for (int e = tid; e < n; e += nt) fkg[(size_t)k * n + e] = sw.f[e];
+                __syncthreads();
+                ssm::discretize(S, b.mode, par.dt, sw, Al, n, Bl, dl);
+            } else {
+                ssm::linearize(S, b.mode, par.dt, xs, us, sw, Al, n, Bl, dl);
+            }
             if (no > 0) {
                 for (int e = tid; e < n; e += nt) xs[e] = xk[(size_t)(k + 1) * n + e];
                 __syncthreads();
-                ssm::observe(S, xs, sw, zs, Hl, cs);
+                if (tab) observe_tab(); else ssm::observe(S, xs, sw, zs, Hl, cs);
             }
             gptr Ak = Ag + (size_t)k * na * na, ATk = ATg + (size_t)k * na * na, Bk = Bg + (size_t)k * na * m, BTk = BTg + (size_t)k * na * m;
             for (int e = tid; e < na * na; e += nt) {
@@ -173,9 +212,15 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
             __syncthreads();
         }
     };
+    long long lap0 = clock64(), lap_lin = 0, lap_qp = 0, lap_tests = 0;
     linearise_all();
+    lap_lin += clock64() - lap0;
 
     QPDyn dyn{(cgptr)Ag, (cgptr)ATg, (cgptr)Bg, (cgptr)BTg, (cgptr)ddg, (cgiptr)nullptr};
+    gptr rec = base + gw.rec;
+    // have_warm: the work block holds the minimiser and multipliers of a converged lean QP -- of this solve, or (warm_across: the reference's
+    // warm_start=True keeps its solver state between solves, locp.py:181) of the rollout's previous solve
+    bool have_warm = GXL > 0 && par.warm_across != 0 && rec[0] == 1.0;
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
     bool converged = false, tr_hot = false;
@@ -186,6 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
         double J;
         int qit, qpass = -1;
         __syncthreads();
+        lap0 = clock64();
         int st = -1;
         if constexpr (GXL > 0) {
             if (!tr_hot) {
@@ -193,16 +239,25 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
                 ql::lds_carve(LL, (lptr)smem, d, NTHREADS);
                 if (tid == 0) LL.flag[2] = 0;              // (the LDS was used by the linearisation: nothing condensed is left)
                 __syncthreads();
-                st = ql::solve_qp<MSEL, 0, GXL, -1, 0>(d, c, dyn, q, base, LL, &J, &qit, w, prof, 0);
-                __syncthreads();
+                for (int attempt = 0; attempt < 2; ++attempt) {      // a warm start that does not reach the tolerances is repeated cold (lean.hip)
+                    const bool warm = have_warm && attempt == 0;
+                    st = ql::solve_qp<MSEL, 0, GXL, -1, 0>(d, c, dyn, q, base, LL, &J, &qit, w, prof, warm ? 1 : 0);
+                    __syncthreads();
+                    if (st == 0 || st == 100 || !warm) break;
+                    if (tid == 0) LL.flag[2] = 0;
+                    __syncthreads();
+                }
+                have_warm = st == 0;
             }
         }
         if (st != 0) {
+            have_warm = false;                             // (qp::solve carves the work block its own way)
             qp_lds_carve(L, (lptr)smem, d, NTHREADS);      // the linearisation / the tests / the lean attempt used the LDS: the QP starts from its own layout
             st = qp::solve<SPLIT, MSEL, 0>(d, c, dyn, q, base, L, &J, &qit, true, w, tr_hot || st == 100, false, &qpass);
         }
         if (st != 0) { status = 1; break; }                // gusto.py:357-365: keep the previous iterate
         __syncthreads();
+        lap_qp += clock64() - lap0; lap0 = clock64();
         // trust region (gusto.py:174-183) on the model's own states
         double md = 0.0;
         for (int e = tid; e < (N + 1) * n; e += nt) {
@@ -221,6 +276,33 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
                 for (int e = tid; e < n; e += nt) { xs[e] = xk[(size_t)i * n + e]; x2[e] = w.x[(size_t)i * na + e]; }
                 for (int e = tid; e < m; e += nt) { us[e] = uk[(size_t)i * m + e]; u2[e] = w.u[(size_t)i * m + e]; }
                 __syncthreads();
+                if (tab) {
+                    // f at the new point = R phi(x) + B u straight from the tables; the Jacobians and f of the old point are the ones the
+                    // linearisation of this iterate stored (same point: gusto.py:212 re-evaluates them)
+                    ssm::basis_l(T.er, T.pr, T.vr, T.dmr, T.lvr, S.order_r, S.nr, n, x2, sw.phi, (lptr) nullptr);
+                    // one lane per row of f (n <= 64: the first wave), the two sums of squares by a wave reduction
+                    if (tid < 64) {
+                        double de = 0.0, da = 0.0;
+                        if (tid < n) {
+                            const int r = tid;
+                            clptr rr = T.R + (size_t)r * S.nr;
+                            double f0 = 0.0, f1 = 0.0, fl = 0.0;
+                            int k = 0;
+                            for (; k + 1 < S.nr; k += 2) { f0 = fma(rr[k], sw.phi[k], f0); f1 = fma(rr[k + 1], sw.phi[k + 1], f1); }
+                            if (k < S.nr) f0 = fma(rr[k], sw.phi[k], f0);
+                            double bf = 0.0, bl = 0.0;
+                            for (int j = 0; j < m; ++j) { bf = fma(T.Bg[r * m + j], u2[j], bf); bl = fma(T.Bg[r * m + j], u2[j] - us[j], bl); }
+                            for (int j = 0; j < n; ++j) fl = fma(Acg[(size_t)i * n * n + r * n + j], x2[j] - xs[j], fl);
+                            const double fv = (f0 + f1) + bf, fa = fkg[(size_t)i * n + r] + fl + bl;
+                            const double fsr = b.fs[r];
+                            de = fsr * (fv - fa); da = fsr * fa;
+                        }
+                        const double e2 = wg::wave_sum(de * de), a2 = wg::wave_sum(da * da);
+                        if (tid == 0) { accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2); }
+                    }
+                    __syncthreads();
+                    continue;
+                }
                 ssm::linearize(S, SSM_CONT, 0.0, xs, us, sw, Al, n, Bl, dl);
                 ssm::linearize(S, SSM_CONT, 0.0, x2, u2, sw, A2, n, B2, d2);
                 if (tid == 0) {
@@ -295,6 +377,10 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
         if (b.trace && itr < par.max_trace && tid == 0) {
             double *tr = b.trace + (p * par.max_trace + itr) * 4;
             tr[0] = J; tr[1] = d_cur; tr[2] = o_cur; tr[3] = rho_k;
+            if (par.poison_warm & 2) {                     // debug (SRH_GUSTO_TRACE_QIT=1): shader clocks of the phases + interior-point iterations
+                lap_tests += clock64() - lap0;
+                tr[0] = (double)lap_lin; tr[1] = (double)lap_qp; tr[2] = (double)lap_tests; tr[3] = (double)(qit + 1000 * (qpass + 1));
+            }
         }
         tr_hot = on_boundary && !new_solution;
         ++itr;
@@ -319,7 +405,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
         for (int j = 0; j < n; ++j) v = fma(b.Hm[a * n + j], xk[(size_t)k * n + j], v);
         b.zopt[p * (size_t)(N + 1) * nz + e] = v;
     }
-    if (tid == 0) { b.iters[p] = itr; b.status[p] = status; if (b.Jopt) b.Jopt[p] = J_prev; }
+    if (tid == 0) { rec[0] = have_warm ? 1.0 : 0.0; b.iters[p] = itr; b.status[p] = status; if (b.Jopt) b.Jopt[p] = J_prev; }
 }
 
 }  // namespace
@@ -332,7 +418,7 @@ struct sgusto_ssm_plan {
     int n = 0, mode = 0, nXv = 0, max_trace = 0;
     srh::DevBuf fs, Hm, XA, Xb, work, Jopt;
     size_t work_stride = 0, lds = 0;
-    int red_off = 0;
+    int red_off = 0, tab_off = 0;       // (doubles) reduction scratch / model tables behind the aliased layouts (tab_off = 0: tables stay in L2)
     int lean_gx = 0;                    // > 0: the lean one-wave interior point runs first (template argument GXL of the kernel)
     char *pin = nullptr;                // one pinned, device-visible block: [inputs | outputs]
     size_t pin_bytes = 0;
@@ -360,7 +446,7 @@ int ssm_gusto_launch(sgusto_ssm_plan *pl, const SsmGustoBatch &b, hipStream_t st
     bool launched = false;
 #define X(SP, M, GX) if (!launched && (d.split != 0) == SP && (M == 0 || d.m == M) && pl->lean_gx == GX) { \
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_ssm_kernel<SP, M, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds)); \
-        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off); launched = true; }
+        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off, pl->tab_off); launched = true; }
     X(false, 4, 1) X(false, 4, 2) X(false, 8, 1) X(false, 4, 0) X(false, 8, 0) X(false, 0, 0) X(true, 0, 0)
 #undef X
     SRH_REQUIRE(launched, "sgusto_ssm: no kernel variant");
@@ -405,7 +491,7 @@ int sgusto_ssm_plan_create(sgusto_ssm_plan_t **out, sssm_t *model, const slocp_p
         pl->lean_gx = (shape && inst && !getenv("SRH_GUSTO_SSM_NO_LEAN")) ? gx : 0;
     }
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
-                       par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace, 0, 0, 0};
+                       par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace, 0, getenv("SRH_GUSTO_TRACE_QIT") != nullptr ? 2 : 0, 0};
     const size_t n = model->n, nz = d.nz;
     size_t doubles = (ssm_gusto_work(d, (int)n).end + 3) & ~(size_t)3;
     d.qc_off = (long long)doubles;
@@ -416,7 +502,13 @@ int sgusto_ssm_plan_create(sgusto_ssm_plan_t **out, sssm_t *model, const slocp_p
     const size_t a2 = pl->lean_gx ? lean_kernel_lds_bytes(d) : 0;
     const size_t body = (std::max(std::max(a, a2), s2) + 15) & ~(size_t)15;
     pl->red_off = (int)(body / sizeof(double));
-    pl->lds = srh::lds_request(body + 16 * sizeof(double));
+    size_t total = body + 16 * sizeof(double);
+    const size_t tabs = (ssm::lds_tab_doubles(S.n, S.no, S.nr, S.ns, 0) + 8) * sizeof(double);
+    if (mode != SSM_DISCRETE_MAP && model->n <= 64 && total + tabs <= (size_t)160 * 1024 && !getenv("SRH_GUSTO_SSM_NO_TABLES")) {
+        pl->tab_off = (int)(total / sizeof(double));
+        total += tabs;
+    }
+    pl->lds = srh::lds_request(total);
     SRH_REQUIRE(pl->lds <= 160 * 1024, "sgusto_ssm_plan_create: %zu bytes of LDS needed, 160 KiB available", pl->lds);
     std::vector<double> fs(n, 1.0);
     if (f_char) for (size_t i = 0; i < n; ++i) fs[i] = 1.0 / fabs(f_char[i]);
@@ -433,6 +525,14 @@ int sgusto_ssm_plan_create(sgusto_ssm_plan_t **out, sssm_t *model, const slocp_p
 }
 
 int sgusto_ssm_plan_destroy(sgusto_ssm_plan_t *pl) { delete pl; return SRH_OK; }
+
+/* sgusto_plan_set_warm_across for the SSM plan: the first QP of a solve starts from the minimiser / multipliers the rollout's previous solve left
+ * (the reference's warm_start=True, locp.py:181); only where the lean one-wave interior point runs. */
+int sgusto_ssm_plan_set_warm_across(sgusto_ssm_plan_t *pl, int on) {
+    SRH_REQUIRE(pl, "sgusto_ssm_plan_set_warm_across: null plan");
+    pl->par.warm_across = (on && pl->lean_gx > 0) ? 1 : 0;
+    return SRH_OK;
+}
 
 int sgusto_ssm_plan_set_max_iters(sgusto_ssm_plan_t *pl, int max_gusto_iters) {
     SRH_REQUIRE(pl, "sgusto_ssm_plan_set_max_iters: null plan");

@@ -107,8 +107,9 @@ class GuSTO:
         else:
             self.solve_batch(x0, u_init, x_init, z, zf, u)
         self.max_gusto_iters = user_max_iters
-        if self._ssm:
-            pass                                     # (solve_batch sets the cap of every call)
+        if self._ssm:                                # (solve_batch sets the cap of every call)
+            if self.keep_solver_state:
+                _lib.check(_lib.lib().sgusto_ssm_plan_set_warm_across(self._plan, C.c_int(1)), 'set_warm_across')
         elif self._fused:
             _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(user_max_iters))), 'set_max_iters')
             if self.keep_solver_state:

@@ -41,8 +41,9 @@ x06 = np.zeros(n6)
 u6 = np.zeros((N3, m4))
 xi6, _ = s6.rollout(x06, u6, dt2)
 z6 = np.tile(np.array([0.02, -0.01, 0, 0, 0, 0.0]), (N3 + 1, 1))
+KEEP = '--keep' in sys.argv          # keep_solver_state=True: the reference's warm_start semantics across calls
 if B == 1:
-    g6 = GuSTO(gm6, N3, dt2, Qz6, R6, x06, u6, xi6, z=z6, U=U, verbose=0, max_gusto_iters=0, convg_thresh=1e-3)
+    g6 = GuSTO(gm6, N3, dt2, Qz6, R6, x06, u6, xi6, z=z6, U=U, verbose=0, max_gusto_iters=0, convg_thresh=1e-3, keep_solver_state=KEEP)
     call = lambda: g6.solve(x06, u6, xi6, z6, None, None)
 else:
     xb, ub, xib, zb = np.tile(x06, (B, 1)), np.tile(u6, (B, 1, 1)), np.tile(xi6, (B, 1, 1)), np.tile(z6, (B, 1, 1))
@@ -54,6 +55,8 @@ for _ in range(200):
     call()
     ts.append(time.perf_counter() - t0)
 ts = np.sort(np.array(ts[20:])) * 1e3
-print('SSM GuSTO real-time iteration, batch %d, path %s: median %.3f ms, p95 %.3f ms, min %.3f ms per call; iters %s; kernel %s' %
-      (B, 'device' if getattr(g6, '_ssm', False) else 'host loop', np.median(ts), ts[int(len(ts) * 0.95)], ts[0], g6.iters[:4],
+print('SSM GuSTO real-time iteration%s, batch %d, path %s: median %.3f ms, p95 %.3f ms, min %.3f ms per call; iters %s; kernel %s' %
+      (' (solver state kept)' if KEEP else '', B, 'device' if getattr(g6, '_ssm', False) else 'host loop', np.median(ts), ts[int(len(ts) * 0.95)], ts[0], g6.iters[:4],
        g6.kernel_info))
+if os.environ.get('SRH_GUSTO_TRACE_QIT') and g6.trace is not None:
+    print('   shader clocks of the last call: linearise %.0f, QP %.0f, tests %.0f; interior-point iterations + 1000 (pass + 1): %.0f' % tuple(g6.trace[0, 0]))
