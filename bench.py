@@ -485,7 +485,7 @@ def scp_reference_horizons(tip_node=1354):
                     tk.append(time.perf_counter() - t0)
                     ik.append(int(gk.iters[0]))
                 perk = sorted(t / max(1, i) for t, i in zip(tk, ik))
-                out[key]['keep_solver_state'] = {'what': 'GuSTO(keep_solver_state=True): solver state kept across solves like the reference\'s warm_start=True',
+                out[key]['keep_solver_state'] = {'honoured_by_the_kernels': bool(gk.solver_state_kept), 'what': 'GuSTO(keep_solver_state=True): solver state kept across solves like the reference\'s warm_start=True',
                                                  'ms_per_scp_iteration_median': perk[len(perk) // 2] * 1e3, 'ms_per_solve_median': sorted(tk)[len(tk) // 2] * 1e3,
                                                  'scp_iterations_equal_cold': bool(ik == its)}
                 # the same `reps` problems as ONE batched launch (one workgroup each, concurrently): where the GPU overtakes a host core
@@ -742,8 +742,28 @@ def secondary(L, _lib, rank, world, dist):
             tw6.sort()
         except Exception:
             tw6 = None
-        out['ssm_gusto_rti'] = {'cpu': 'no twin: the CPU twin has no SSM + GuSTO loop (its GuSTO is the nearest-point TPWL one); the numpy oracle of this '
-                                       'loop (oracle.gusto.solve_generic) is a correctness statement, not a timing',
+        cpu6 = 'no compiled twin of this loop (the CPU twin\'s GuSTO is the nearest-point TPWL one)'
+        if rank == 0 and world == 1:
+            try:      # the reference-shaped CPU path: the numpy statement of the same loop (python loop + numpy, exact KKT solve of the QP)
+                from oracle import gusto as ogusto, ssm as ossm
+                om = ossm.make_model(n6, m4, 3, 2, mdl['R'], mdl['B'], mdl['W'], mdl['V'], mdl['z_ref'], rd_coeff=mdl['Rd'], Bd=mdl['Bd'])
+                def dyn_d6(x, u):
+                    return ossm.jacobians(om, x, u, dt2, 'be')
+                def dyn_c6(x, u):
+                    A, B_, d_ = ossm.continuous_jacobians(om, x, u)
+                    return A @ x + B_ @ u + d_, A, B_
+                tn6 = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    xo6, uo6, _, tr6 = ogusto.solve_generic(dyn_d6, dyn_c6, np.zeros((n6, n6)), N3, dt2, Qz6, R6, x06, u6, xi6, z=z6,
+                                                            U=(np.kron(np.eye(m4), np.array([[1.0], [-1.0]])), np.tile([1500.0, 0.0], m4)),
+                                                            obs_lin=lambda x: ossm.observer_jacobians(om, x), convg_thresh=1e-3, max_gusto_iters=0)
+                    tn6.append(time.perf_counter() - t0)
+                cpu6 = {'what': 'numpy statement of the same loop (oracle.gusto.solve_generic: python loop, exact KKT solve of the QP), one call',
+                        'ms': min(tn6) * 1e3, 'max_rel_u_vs_gpu': float(np.abs(uo6 - g6.uopt).max() / max(1e-12, np.abs(uo6).max()))}
+            except Exception as exc:
+                cpu6 = {'error': repr(exc)}
+        out['ssm_gusto_rti'] = {'cpu': cpu6,
                                 'workload': 'SSM (n_x = 6, n_u = 4, cubic) + GuSTO real-time iteration: N = 3, dt = 0.02, max_gusto_iters = 0 '
                                             '(one QP per call), U box; %s, host buffers' % ('the whole solve in one launch of csrc/gusto_ssm.hip' if getattr(g6, '_ssm', False) else 'host loop around the device QP'),
                                 'kernel': g6.kernel_info['kernel'] if getattr(g6, '_ssm', False) else 'host loop + ' + str((g6.locp.kernel_info or {}).get('kernel')),

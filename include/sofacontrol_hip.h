@@ -427,6 +427,9 @@ int sgusto_plan_set_max_iters(sgusto_plan_t *plan, int max_gusto_iters);   /* gu
  * GuSTO.solve -- from the previous solution).  on = 1: the first QP of a solve starts from the minimiser and multipliers the same rollout's
  * previous solve ended with (lean kernels; later QPs of a solve always do).  Default 0: every solve starts cold (what bench.py times). */
 int sgusto_plan_set_warm_across(sgusto_plan_t *plan, int on);
+/* *active = 1 iff the flag above is set AND this plan's kernels honour it (lean kernels with the box-row interior point); fused-only
+ * plans and general-row lean variants start every solve cold whatever was requested. */
+int sgusto_plan_warm_across_active(const sgusto_plan_t *plan, int *active);
 /* GuSTO on an SSM polynomial model (sofacontrol/scp/models/ssm.py + sofacontrol/SSM/ssm.py:198-235), the whole solve -- analytic
  * linearisation of the dynamics and of the output map along the trajectory, the LOCP QP with per-stage output maps (locp.py:231-245,
  * 312-329), the tests and the acceptance rules of gusto.py:371-473 -- inside ONE kernel launch per call: the loop the reference's

@@ -417,6 +417,16 @@ int sgusto_plan_set_warm_across(sgusto_plan_t *pl, int on) {
     return SRH_OK;
 }
 
+/* Whether a plan can honour sgusto_plan_set_warm_across: only the lean kernels with the box-row interior point (GX > 0) keep the
+ * minimiser / multipliers of a rollout's last QP in its work block; fused-only plans, the general-row lean variants and
+ * SRH_GUSTO_NO_LEAN plans start every solve cold whatever the flag says (and so does a rollout whose previous solve was handed to
+ * the fused kernel).  *active = 1: requested AND honoured. */
+int sgusto_plan_warm_across_active(const sgusto_plan_t *pl, int *active) {
+    SRH_REQUIRE(pl && active, "sgusto_plan_warm_across_active: null argument");
+    *active = (pl->par.warm_across != 0 && pl->lean && pl->lean_args[2] > 0) ? 1 : 0;
+    return SRH_OK;
+}
+
 int sgusto_plan_set_max_iters(sgusto_plan_t *pl, int max_gusto_iters) {
     SRH_REQUIRE(pl, "sgusto_plan_set_max_iters: null plan");
     pl->par.max_iters = max_gusto_iters;

@@ -114,6 +114,10 @@ class GuSTO:
             _lib.check(_lib.lib().sgusto_plan_set_max_iters(self._plan, C.c_int(int(user_max_iters))), 'set_max_iters')
             if self.keep_solver_state:
                 _lib.check(_lib.lib().sgusto_plan_set_warm_across(self._plan, C.c_int(1)), 'set_warm_across')
+                if not self.solver_state_kept:
+                    import warnings
+                    warnings.warn('GuSTO(keep_solver_state=True): this plan\'s kernels (%s) start every solve cold -- only the lean kernels '
+                                  'with box input rows keep the solver state between solves' % self.kernel_info['kernel'])
 
     def _create_ssm_plan(self, model, N, dt, Qz, R, U, X):
         """The resident plan of csrc/gusto_ssm.hip.  With a nonlinear output map the QP is posed in the augmented state [x ; zeta]
@@ -150,6 +154,17 @@ class GuSTO:
     @property
     def plan(self):
         return self._plan
+
+    @property
+    def solver_state_kept(self):
+        """True when keep_solver_state was requested AND the plan's kernels honour it (sgusto_plan_warm_across_active)."""
+        if not self.keep_solver_state or not self._fused:
+            return False
+        if self._ssm:
+            return True
+        a = C.c_int(0)
+        _lib.check(_lib.lib().sgusto_plan_warm_across_active(self._plan, C.byref(a)), 'sgusto_plan_warm_across_active')
+        return bool(a.value)
 
     @property
     def variant(self):
