@@ -1260,7 +1260,7 @@ def main():
     # HBM traffic of the same kernel at the same shape from PMC counters (separate rocprofv3 --pmc passes,
     # corrected as MI355X_MICROARCH.md prescribes; summary committed under profiles/)
     traffic, traffic_source = None, None
-    for name in ('r05_proj_pmc.json', 'r04_proj_pmc.json', 'r03_proj_pmc.json', 'r02_proj_pmc.json'):
+    for name in ('r06_proj_pmc.json', 'r05_proj_pmc.json', 'r04_proj_pmc.json', 'r03_proj_pmc.json', 'r02_proj_pmc.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if pmc.get('algorithmic_bytes_per_launch') == alg_bytes:

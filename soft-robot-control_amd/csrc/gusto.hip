@@ -357,12 +357,13 @@ int sgusto_plan_create(sgusto_plan_t **out, stpwl_t *h, const slocp_problem *pro
     if (x_char) for (int i = 0; i < h->n; ++i) xs[i] = 1.0 / fabs(x_char[i]);
     if (f_char) for (int i = 0; i < h->n; ++i) fs[i] = 1.0 / fabs(f_char[i]);
     if (x_char) p2.x_scale = xs.data();
-    int rc = build_consts(&p2, pl->C);
+    // (more rollouts than CUs: the half-size lean workgroup where the problem has its shape -- two rollouts per CU)
+    int rc = build_consts(&p2, pl->C, batch > 256);
     if (rc) { delete pl; return rc; }
     QPDims &d = pl->C.dims;
     pl->par = GustoPar{par->delta0, par->omega0, par->rho, par->beta_fail, par->gamma_fail, par->epsilon,
                        par->omega_max, par->convg_thresh, dt, par->max_gusto_iters, max_trace, 0,
-                       (getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0) | (getenv("SRH_GUSTO_TRACE_QIT") != nullptr ? 2 : 0) |
+                       (getenv("SRH_LEAN_POISON_WARM") != nullptr ? 1 : 0) | (getenv("SRH_GUSTO_TRACE_QIT") != nullptr ? 2 : 0) | (getenv("SRH_LEAN_SERIAL_WAVE") != nullptr ? 4 : 0) |
                        (getenv("SRH_LEAN_FORCE_HANDOVER") != nullptr ? (atoi(getenv("SRH_LEAN_FORCE_HANDOVER")) + 1) << 4 : 0),
                        getenv("SRH_GUSTO_WARM_FULL") != nullptr ? 1 : 0};
     const size_t N = d.N, n = d.n, m = d.m, nz = d.nz;
@@ -522,7 +523,7 @@ int sgusto_plan_info(sgusto_plan_t *pl, srh_kernel_info *info) {
 #undef X
     info->lds_bytes_lean = pl->lean ? (int32_t)pl->lean_lds : 0;
     info->lds_bytes_fused = (int32_t)pl->lds;
-    info->threads = NTHREADS;
+    info->threads = (pl->lean && d.lean_half) ? 256 : NTHREADS;      // (the half-size lean workgroup: two rollouts per CU)
     info->handed_over = -1;
     if (pl->solved) {
         // the last solve may sit on a caller's non-blocking stream (sgusto_plan_solve_dev): wait for the device, as

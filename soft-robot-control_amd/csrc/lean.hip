@@ -25,11 +25,16 @@ __device__ __forceinline__ void fix_problem(QPDims &d) {
         d.N = NST; d.po = 2; d.KT = (2 * NST + 15) / 16;
         d.nU = 2 * MSEL; d.nX = NXR; d.nXf = 0; d.nz = 6;
         d.cond = 1; d.diagD = 1; d.lean = 2; d.lean_j0 = J0SEL;
+        d.lean_half = (J0SEL == NST) ? 1 : 0;           // the half-size workgroup: 256 threads, <= 80 KB of LDS (locp_lean.h: ipm_box4)
     }
 }
 
+// threads of an instantiation: 256 for the half-size layouts (NST > 0 and J0SEL == NST: two workgroups per CU), else NTHREADS
+// (second launch bound: two waves per SIMD -- implied by 512 threads, what lets two 256-thread workgroups share a CU: <= 256 registers)
+constexpr int lean_threads(int nst, int j0) { return (nst > 0 && j0 == nst) ? 256 : NTHREADS; }
+
 template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>
-__global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
+__global__ __launch_bounds__(lean_threads(NST, J0SEL), 2) void gusto_lean_kernel(QPDims d, QPConst c, TpwlDev T, GustoPar par, GustoBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long prof[32] = {0};
 #ifdef SRH_PROFILE
@@ -38,10 +43,11 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
     qp::specialise<MSEL, NSEL>(d);
     fix_problem<MSEL, GXSEL, NST, J0SEL, NXR>(d);
     if constexpr (NST > 0) d.tr = 1;                   // GuSTO always carries the trust region
-    ql::Lds L;
-    ql::lds_carve(L, (lptr)smem, d, NTHREADS);
-    if (SRH_TID == 0) L.flag[2] = 0;               // no condensation in LDS yet (ql::ipm)
     const size_t p = b.order ? (size_t)b.order[blockIdx.x] : (size_t)blockIdx.x;
+    ql::Lds L;
+    ql::lds_carve(L, (lptr)smem, d, lean_threads(NST, J0SEL), (gptr)(b.work + p * b.work_stride));
+    if (SRH_TID == 0) L.flag[2] = 0;               // no condensation in LDS yet (ql::ipm)
+    ql::serial_wave_pick(L, (par.poison_warm & 4) != 0);
     const int N = d.N, n = d.n, m = d.m, nz = d.nz;
     int tid = SRH_TID;                                 // re-read at the top of every SCP iteration (dev_la.h: SRH_TID)
     const int nt = blockDim.x;
@@ -325,15 +331,16 @@ __global__ __launch_bounds__(NTHREADS) void gusto_lean_kernel(QPDims d, QPConst 
 }
 
 template <int MSEL, int NSEL, int GXSEL, int NST, int J0SEL, int NXR>
-__global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c, LocpBatch b) {
+__global__ __launch_bounds__(lean_threads(NST, J0SEL), 2) void locp_lean_kernel(QPDims d, QPConst c, LocpBatch b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long prof[32] = {0};
     qp::specialise<MSEL, NSEL>(d);
     fix_problem<MSEL, GXSEL, NST, J0SEL, NXR>(d);
-    ql::Lds L;
-    ql::lds_carve(L, (lptr)smem, d, NTHREADS);
-    if (SRH_TID == 0) L.flag[2] = 0;
     const size_t p = blockIdx.x;
+    ql::Lds L;
+    ql::lds_carve(L, (lptr)smem, d, lean_threads(NST, J0SEL), (gptr)(b.work + p * b.work_stride));
+    if (SRH_TID == 0) L.flag[2] = 0;
+    ql::serial_wave_pick(L);
     const size_t N = d.N, n = d.n, m = d.m;
     QPWork w;
     gptr wbase = (gptr)(b.work + p * b.work_stride);
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(NTHREADS) void locp_lean_kernel(QPDims d, QPConst c
 // N = 50, no state rows; the Diamond at its shipped r = 36 basis), then the run-time-horizon forms
 // (a development build may pass its own, shorter list: tools/build_lean_dev.sh compiles the benchmark layouts only)
 #ifndef SRH_LEAN_VARIANTS
-#define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) X(4, 72, 4, 50, 18, 4) \
+#define SRH_LEAN_VARIANTS(X) X(4, 60, 4, 50, 50, 4) X(4, 60, 4, 50, 7, 4) X(8, 60, 1, 50, 24, 0) X(4, 72, 4, 50, 18, 4) \
     X(4, 60, 4, -1, 0, 0) X(4, 60, 1, -1, 0, 0) X(4, 72, 4, -1, 0, 0) X(8, 60, 1, -1, 0, 0) \
     X(4, 60, 4, 0, 0, 0) X(4, 60, 1, 0, 0, 0) X(8, 60, 1, 0, 0, 0) X(4, 72, 4, 0, 0, 0) X(4, 60, 0, 0, 0, 0) X(8, 60, 0, 0, 0, 0) X(4, 0, 0, 0, 0, 0) X(8, 0, 0, 0, 0, 0)
 #endif
@@ -381,6 +388,9 @@ inline int lean_gx(const QPDims &d) {
 inline bool lean_matches(const QPDims &d, bool allow_fixed, int msel, int nsel, int gx, int nst, int j0, int nxr) {
     if (d.m != msel || (nsel != 0 && d.n != nsel)) return false;
     if (!(gx == 0 || gx == lean_gx(d))) return false;
+    // a problem laid out for the half-size workgroup (scp_host.h: SRH_LEAN_HALF=1) runs its own instantiations only, and nothing else runs them
+    const bool half_inst = nst > 0 && j0 == nst;
+    if ((d.lean_half != 0) != half_inst) return false;
     if (nst == 0) return true;
     // nst < 0: the short-horizon form (ql::ipm_wave): K is one tile, one lane per input and per state-row slot, the whole packed
     // G in LDS; SRH_LEAN_NO_WAVE=1 at plan creation skips it (A/B runs, tests of both forms)
@@ -420,7 +430,7 @@ int lean_launch_gusto(int variant, const QPDims &d, const QPConst &c, const Tpwl
                       size_t lds, hipStream_t stream) {
     QPDims dd = d;
     int idx = 0;
-#define X(M, NX, GX, NST, J0, NXR) if (idx++ == variant) { if (GX == 0) dd.lean = 1; gusto_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+#define X(M, NX, GX, NST, J0, NXR) if (idx++ == variant) { if (GX == 0) dd.lean = 1; gusto_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, lean_threads(NST, J0), lds, stream>>>(dd, c, T, par, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
     SRH_REQUIRE(false, "lean kernels: no variant %d", variant);
@@ -430,7 +440,7 @@ int lean_launch_gusto(int variant, const QPDims &d, const QPConst &c, const Tpwl
 int lean_launch_locp(int variant, const QPDims &d, const QPConst &c, const LocpBatch &b, unsigned grid, size_t lds, hipStream_t stream) {
     QPDims dd = d;
     int idx = 0;
-#define X(M, NX, GX, NST, J0, NXR) if (idx++ == variant) { if (GX == 0) dd.lean = 1; locp_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, NTHREADS, lds, stream>>>(dd, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
+#define X(M, NX, GX, NST, J0, NXR) if (idx++ == variant) { if (GX == 0) dd.lean = 1; locp_lean_kernel<M, NX, GX, NST, J0, NXR><<<grid, lean_threads(NST, J0), lds, stream>>>(dd, c, b); SRH_CHECK_HIP(hipGetLastError()); return SRH_OK; }
     SRH_LEAN_VARIANTS(X)
 #undef X
     SRH_REQUIRE(false, "lean kernels: no variant %d", variant);

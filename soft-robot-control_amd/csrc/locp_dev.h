@@ -36,6 +36,9 @@ struct QPDims {
     int diagD;          // 1: 2R + U.A^T D U.A is diagonal for every weight vector D (R diagonal, one entry per U.A row)
     int lean;           // 1: the lean condensed kernels (locp_lean.h: packed G resident in LDS) serve this problem
     int lean_j0;        // first stage whose packed G^T rows live in LDS (the stages before it stay in the L2 block)
+    int lean_half;      // 1: the HALF-SIZE lean workgroup (round 6): 256 threads, <= 80 KB of LDS, so that two rollouts share a CU -- every packed
+                        // row of G in the L2 block (lean_j0 = N), inverses of the diagonal tiles in place of the tiles, Theta^T condensed in
+                        // two column passes (ql::sizes / lds_carve / condense; lean.hip: the <.., N, N, ..> instantiations)
     int ls_pd;          // 1 (p_o = 2): the constant output blocks S*_k are positive definite, so every S_k = S*_k + T^T D_x T has an
                         // invertible Cholesky factor Ls_k -- the lean Newton solve then gets dy from the solved system itself
                         // (ql::newton_back) instead of a second product with G

@@ -37,7 +37,17 @@ using qpc::Prof;
 struct Lds : qpc::Lds {
     lptr Gt;           // packed G^T rows of the stages j >= j0
     lptr panel;        // [A | B] panel while condensing (aliases Rinv / the u-space temporaries)
+    // half-size layout (QPDims::lean_half): the free response yf and the region sequence of the condensation live in the problem's L2
+    // block behind the packed G (read once per QP), Rinv == B marks "inverse of a diagonal tile in the tile's own place" (rinv_tile)
+    gptr yfg;
+    giptr goffg;
+    int ypad;          // zeros behind ya / yd / yg (gT_times): 48, or 24 when a pass has 32 rows (256 threads)
+    int ldTc;          // row pitch of Theta^T while condensing: 16 KT + 1, or the widest column pass + 1
 };
+// inverse of the J-th diagonal tile of the factor
+__device__ __forceinline__ lptr rinv_tile(const Lds &L, int J, int KT) {
+    return L.Rinv == L.B ? L.B + (size_t)qpc::tile_index(J, J, KT) * TSZ : L.Rinv + (size_t)J * TSZ;
+}
 
 __host__ __device__ inline int goff(int j, int m, int NP) { return m * (j * NP - j * (j - 1)); }     // p_o = 2
 constexpr int YPAD = 48;               // zeros behind the y-space vectors that feed gT_times (see there)
@@ -47,54 +57,76 @@ constexpr int CONDENSE_SLOTS = 5;
 constexpr int GRAM_TASKS = 32;         // entries of QPConst::gram_sched ({I, J0, nJ, 0}, longest first, nJ = 0 behind the last one)
 __host__ __device__ inline bool condense_fits(const QPDims &d, int nwaves) { return d.KT * (d.NPa / 16) <= nwaves * CONDENSE_SLOTS; }
 
-struct Sizes { size_t regX, thetaT, tiles, rinv, nm4, gt, ldi, ls, ldG, ua, tx, ld, idx; };
+struct Sizes { size_t regX, thetaT, tiles, rinv, nm4, gt, ldi, ls, ldG, ua, tx, ld, idx, ypad, ldTc, nyv, nvv, nidx; };
+// first column tile of the second condensation pass of the half-size layout (pass A: tiles [T, KT), pass B: [0, T))
+__host__ __device__ inline int half_split_tile(int KT) { return KT / 2; }
 __host__ __device__ inline Sizes sizes(const QPDims &d, int nthreads, int j0) {
     Sizes s;
+    const bool half = d.lean_half != 0;
     const size_t nk = (size_t)d.NK, nm = (size_t)d.N * d.m;
     s.ldG = 16 * (size_t)d.KT;
     s.nm4 = (nm + 3) & ~(size_t)3;
-    s.thetaT = nk * (s.ldG + 1);
+    s.ldTc = half ? 16 * (size_t)(d.KT - half_split_tile(d.KT)) + 1 : s.ldG + 1;
+    s.thetaT = nk * s.ldTc;
     s.tiles = (size_t)d.KT * (d.KT + 1) / 2 * TSZ;
-    s.rinv = (size_t)d.KT * TSZ;
+    s.rinv = half ? 0 : (size_t)d.KT * TSZ;
     const size_t a = s.thetaT + nk * d.ld, b = s.tiles + s.rinv + 3 * s.nm4 + (size_t)nthreads;
     s.regX = ((a > b ? a : b) + 3) & ~(size_t)3;
     const int NP = d.N * d.po;
     s.gt = ((size_t)(goff(d.N, d.m, NP) - goff(j0, d.m, NP)) + 3) & ~(size_t)3;
     s.ldi = s.nm4;
     s.ls = (size_t)d.N * d.po * d.po;
-    s.ua = ((size_t)d.nU * d.m + 3) & ~(size_t)3;
-    s.tx = ((size_t)(d.nX + d.nXf) * d.po + 3) & ~(size_t)3;
+    s.ua = half ? 0 : ((size_t)d.nU * d.m + 3) & ~(size_t)3;             // (ipm_box reads its row coefficients from global memory)
+    s.tx = half ? 0 : ((size_t)(d.nX + d.nXf) * d.po + 3) & ~(size_t)3;
     s.ld = ((size_t)d.ld + 3) & ~(size_t)3;
     s.idx = ((size_t)(d.N / 2 + 2) + 3) & ~(size_t)3;
+    s.ypad = half ? 24 : 48;
+    s.nyv = half ? 7 : 9;                   // y-space vectors of their own (half: yf in L2, yb shares yd's place)
+    s.nvv = half ? 0 : 2;                   // rollout vectors of their own (half: in du's place, dead while a rollout runs)
+    s.nidx = half ? 1 : 2;                  // int arrays of their own (half: goff in L2)
     return s;
 }
 __host__ __device__ inline size_t lds_doubles(const QPDims &d, int nthreads, int j0) {
     const Sizes s = sizes(d, nthreads, j0);
-    return s.regX + s.gt + s.ldi + s.ls + 2 * s.nm4 + 9 * s.ldG + 3 * 48 + s.ua + s.tx + 2 * s.ld + 16 + 16 + 4 + 2 * s.idx;
+    return s.regX + s.gt + s.ldi + s.ls + 2 * s.nm4 + s.nyv * s.ldG + 3 * s.ypad + s.ua + s.tx + s.nvv * s.ld + 16 + 16 + 4 + s.nidx * s.idx;
 }
-__device__ inline void lds_carve(Lds &L, lptr base, const QPDims &d, int nthreads) {
+// doubles of the half-size layout's homes in the L2 block behind the packed G: [pad (YPAD) | yf (16 KT) | goff (N ints)]
+__host__ __device__ inline size_t half_l2_off(const QPDims &d) { return (size_t)goff(d.N, d.m, d.N * d.po) + 48; }
+__device__ inline void lds_carve(Lds &L, lptr base, const QPDims &d, int nthreads, gptr work_base = nullptr) {
     const Sizes s = sizes(d, nthreads, d.lean_j0);
+    const bool half = d.lean_half != 0;
     lptr p = base;
     auto take = [&](size_t c) { lptr q = p; p += c; return q; };
     lptr X = take(s.regX);
     // interior-point view: K tiles | inverses of the diagonal tiles | u-space temporaries | reduction scratch
-    L.B = X; L.Rinv = X + s.tiles;
-    L.ta = L.Rinv + s.rinv; L.tb = L.ta + s.nm4; L.tc = L.tb + s.nm4; L.part = L.tc + s.nm4;
+    L.B = X; L.Rinv = half ? X : X + s.tiles;
+    L.ta = X + s.tiles + s.rinv; L.tb = L.ta + s.nm4; L.tc = L.tb + s.nm4; L.part = L.tc + s.nm4;
     // condensation view: Theta^T (in L.B) | [A | B] panel
     L.panel = X + s.thetaT;
     L.A = L.panel;
     L.Gt = take(s.gt);
     L.Ldi = take(s.ldi); L.Ls = take(s.ls);
     L.u = take(s.nm4); L.du = take(s.nm4);
-    L.y = take(s.ldG); L.dy = take(s.ldG); L.yf = take(s.ldG);
-    // ya, yd, yg feed gT_times: YPAD zeros behind each (written once by ipm, never touched again)
-    L.ya = take(s.ldG + 48); L.yd = take(s.ldG + 48); L.yg = take(s.ldG + 48);
-    L.yb = take(s.ldG); L.yc = take(s.ldG); L.ks = take(s.ldG);
+    L.y = take(s.ldG); L.dy = take(s.ldG);
+    L.yf = half ? (lptr) nullptr : take(s.ldG);
+    // ya, yd, yg feed gT_times: `ypad` zeros behind each (written once by ipm, never touched again)
+    L.ya = take(s.ldG + s.ypad); L.yd = take(s.ldG + s.ypad); L.yg = take(s.ldG + s.ypad);
+    L.yb = half ? L.yd : take(s.ldG);          // (yb = G t is dead once yc = ks Ls^T yb is formed; yd is written behind the K solve)
+    L.yc = take(s.ldG); L.ks = take(s.ldG);
     L.UA = take(s.ua); L.Tx = take(s.tx);
-    L.v1 = take(s.ld); L.v2 = take(s.ld); L.Qu = take(16); L.red = take(16);
+    if (half) { L.v1 = L.du; L.v2 = L.du + s.ld; } else { L.v1 = take(s.ld); L.v2 = take(s.ld); }
+    L.Qu = take(16); L.red = take(16);
     L.flag = (liptr)take(4);
     L.idxl = (liptr)take(s.idx);
-    L.goff = (liptr)take(s.idx);
+    L.goff = half ? (liptr) nullptr : (liptr)take(s.idx);
+    L.ypad = (int)s.ypad;
+    L.ldTc = (int)s.ldTc;
+    L.yfg = nullptr; L.goffg = nullptr;
+    if (half && work_base != nullptr) {
+        gptr hb = work_base + d.qc_off + half_l2_off(d);
+        L.yfg = hb;
+        L.goffg = (giptr)(hb + s.ldG);
+    }
 }
 
 // packed G^T: head rows in the problem's L2 block, the rest in LDS
@@ -147,10 +179,26 @@ __device__ __forceinline__ Waves<false> all_waves() {
 }
 // the two halves of an 8-wave workgroup by SIMD: set (w >> 1) & 1, wave (w & 1) + 2 (w >> 2) inside it; ctr0: the arrival counter
 // of set 1 (set 0 synchronises through the counters of tile_cholesky_set)
+// (a 4-wave workgroup -- the half-size layout, one wave per SIMD -- splits 2 + 2: waves 0, 1 and waves 2, 3)
+// The one-wave phases of a 4-wave workgroup (tile factorisations, block substitutions) run on its SERIAL WAVE: wave 0, or wave 2 when the
+// workgroup finds its wave 0 in the second wave slot of its SIMD -- i.e. when another workgroup got to this CU first (two half-size
+// workgroups share a CU, one wave of each per SIMD: with both serial chains on wave 0 they would share ONE SIMD's issue slots while three
+// SIMDs idle).  serial_wave_pick() is called once per kernel by every wave; the choice is kept in L.Qu[15].
+__device__ __forceinline__ void serial_wave_pick(Lds &L, bool enable = true) {
+    if (SRH_TID == 0) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID [3:0]: wave slot inside the SIMD
+        L.Qu[15] = (enable && blockDim.x == 256 && (slot & 1u)) ? 2.0 : 0.0;
+    }
+}
+__device__ __forceinline__ int serial_wave(const Lds &L) {
+    return blockDim.x == 256 ? __builtin_amdgcn_readfirstlane((int)L.Qu[15]) : 0;
+}
 __device__ __forceinline__ int half_of_wave(int w) { return (w >> 1) & 1; }
-__device__ __forceinline__ Waves<true> half_waves(liptr ctr0) {
-    const int w = __builtin_amdgcn_readfirstlane((int)SRH_TID >> 6), which = half_of_wave(w), lw = (w & 1) + 2 * (w >> 2);
-    return Waves<true>{lw * 64 + ((int)SRH_TID & 63), 256, lw, 4, ctr0, 0, which == 1};      // (only set 1 calls sync(): one counter)
+__device__ __forceinline__ Waves<true> half_waves(liptr ctr0, int sw = 0) {
+    const int w = __builtin_amdgcn_readfirstlane((int)SRH_TID >> 6) ^ sw, which = half_of_wave(w);
+    const bool four = blockDim.x == 256;
+    const int lw = four ? (w & 1) : (w & 1) + 2 * (w >> 2), sz = four ? 2 : 4;
+    return Waves<true>{lw * 64 + ((int)SRH_TID & 63), sz * 64, lw, sz, ctr0, 0, which == 1};      // (only set 1 calls sync(): one counter)
 }
 
 // ------------------------------------------------------------------ rollout x_{k+1} = A_k x_k + B_k u_k + d_k  (u null: zero inputs)
@@ -162,13 +210,14 @@ __device__ __forceinline__ Waves<true> half_waves(liptr ctr0) {
 // XS: the trajectory is ALSO written to xs (LDS: the start of the Theta^T area, free during a rollout) for the tests that follow it --
 // objective, trust region, and the SCP loop's tests in the GuSTO kernel.  (A flag, not a null test: the area starts at LDS offset 0,
 // which is what a null pointer of address space 3 compares equal to.)
-template <int MSEL, int NSEL, bool XS = false>
+template <int MSEL, int NSEL, bool XS = false, int WG = 8>
 __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr x0, cgptr u, gptr x, Lds &L, lptr xs = nullptr) {
     const int N = d.N, n = d.n, m = d.m, ld = d.ld, NPa = d.NPa, nk = d.NK;
     const int tid = SRH_TID, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l = lane & 15, il = l >> 3, sl = l & 7;
-    const int i_lo = 8 * wave + 2 * (lane >> 4) + il;                 // + 64 per row block (n_x > 64: a second pass)
-    constexpr bool ONE_BLOCK = NSEL > 0 && NSEL <= 64;
+    const int i_lo = 8 * wave + 2 * (lane >> 4) + il;                 // + 8 rows per wave per row block (n_x > 64, or a 4-wave workgroup: more passes)
+    constexpr int rows_pass = 8 * WG;
+    constexpr bool ONE_BLOCK = NSEL > 0 && NSEL <= rows_pass;
     const int vlen = (int)(((size_t)ld + 3) & ~(size_t)3);
     lptr va = L.v1, vb = L.v2;
     for (int e = tid; e < nk * ld; e += nt) L.panel[e] = 0.0;
@@ -185,7 +234,7 @@ __device__ __forceinline__ void rollout(const QPDims &d, const QPDyn &dyn, cgptr
     for (int k = 0; k < N; ++k) {
         const int sel = __builtin_amdgcn_readfirstlane(L.idxl[k]);
         const double un = (tid < m && u && k + 1 < N) ? u[(size_t)(k + 1) * m + tid] : 0.0;
-        for (int ib = 0; ib < (ONE_BLOCK ? 1 : n); ib += 64) {
+        for (int ib = 0; ib < (ONE_BLOCK ? 1 : n); ib += rows_pass) {
             const int i = i_lo + ib, ic = i < n ? i : n - 1;
             const double dk = dyn.d[(size_t)sel * n + ic];
             clptr row = L.panel + ic * ld + 2 * sl;
@@ -290,6 +339,98 @@ __device__ __forceinline__ void condense(const QPDims &d, const QPConst &c, cons
             (void)qp::panel_load(d, dyn, P, j - 1);
         }
         __syncthreads();
+    }
+}
+
+// The condensation for the half-size layout (QPDims::lean_half): Theta^T has room for about half of its N p_o columns (Lds::ldTc), so the
+// adjoint recursion runs twice -- pass A over the column tiles [T, KT) from stage N - 1 down, pass B over the tiles [0, T) from the last stage
+// that still reaches them (columns < 16 T are "born" at the stages j <= (16 T - 1) / p_o) -- each with the products of condense() restricted
+// to its tiles.  1.5 x the MFMA work of the one-pass form; G goes to the L2 block whole (lean_j0 = N), yf and the pad behind G as well.
+template <int MSEL, int NSEL>
+__device__ __forceinline__ void condense_half(const QPDims &d, const QPConst &c, const QPDyn &dyn, cgptr x, gptr gh, Lds &L) {
+    const int N = d.N, n = d.n, m = d.m, po = d.po, ld = d.ld, KT = d.KT, ldG = 16 * d.KT, ldT = L.ldTc;
+    const int nk = d.NK, NPa = d.NPa, NP = N * po;
+    const int tid = SRH_TID, nt = blockDim.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;
+    const int l16 = lane & 15, kk = lane >> 4;
+    for (int e = tid; e < ldG; e += nt) {
+        double v = 0.0;
+        if (e < NP) {
+            const int k = e / po + 1, a = e - (k - 1) * po;
+            for (int j = 0; j < n; ++j) v = fma(c.Co[(size_t)a * n + j], x[(size_t)k * n + j], v);
+        }
+        L.yfg[e] = v;
+    }
+    for (int e = tid; e < nk * ld; e += nt) L.panel[e] = 0.0;
+    // gT_times runs its lanes past the end of a row (times zeros of y): finite values behind the last row
+    for (int e = tid; e < YPAD; e += nt) gh[goff(N, m, NP) + e] = 0.0;
+    QPLds P{};
+    P.AB = L.panel; P.idxl = L.idxl; P.psel = -1;
+    const int MT = NPa >> 4;
+    const int KS = (n + 3) >> 2;
+    const int Tsplit = half_split_tile(KT);
+    constexpr int KSMAX = NSEL > 0 ? (NSEL + 3) / 4 : 32;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int T0 = pass == 0 ? Tsplit : 0, T1 = pass == 0 ? KT : Tsplit;
+        if (T1 <= T0) continue;
+        const int c0 = 16 * T0, c1 = min(16 * T1, NP);                  // this pass's columns [c0, c1)
+        const int jstart = min(N - 1, (c1 - 1) / po);                   // the last stage that reaches them
+        __syncthreads();
+        for (int e = tid; e < nk * ldT; e += nt) L.B[e] = 0.0;
+        __syncthreads();
+        (void)qp::panel_load(d, dyn, P, jstart);
+        for (int e = tid; e < po * n; e += nt) {
+            const int a = e / n, r = e - a * n, i = jstart * po + a;
+            if (i >= c0 && i < c1) L.B[r * ldT + (i - c0)] = c.Co[(size_t)a * n + r];
+        }
+        __syncthreads();
+        for (int j = jstart; j >= 0; --j) {
+            const int t_first = max(T0, (j * po) >> 4);
+            const int count = (T1 - t_first) * MT;
+            const int len = NP - po * j, gj = goff(j, m, NP);
+            constexpr int RMAX = CONDENSE_SLOTS;             // item slots per wave: (T1 - T0) MT <= 4 * 5 items over 4 waves (scp_host.h)
+            wg::qp_d4 acc[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                acc[r] = {0.0, 0.0, 0.0, 0.0};
+                const int it = wave + nw * r;
+                if (it < count) {
+                    const int ti = t_first + it / MT, ci = it - (it / MT) * MT;
+                    double aop[KSMAX], bop[KSMAX];
+#pragma unroll
+                    for (int s = 0; s < KSMAX; ++s) {
+                        aop[s] = s < KS ? L.panel[(4 * s + kk) * ld + 16 * ci + l16] : 0.0;
+                        bop[s] = s < KS ? L.B[(4 * s + kk) * ldT + 16 * (ti - T0) + l16] : 0.0;
+                    }
+#pragma unroll
+                    for (int s = 0; s < KSMAX; ++s)
+                        if (s < KS) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s], bop[s], acc[r], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const int it = wave + nw * r;
+                if (it < count) {
+                    const int ti = t_first + it / MT, ci = it - (it / MT) * MT;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 16 * ci + kk + 4 * q, i = 16 * ti + l16;
+                        if (i >= po * j && i < c1) {                 // columns of the output stages k > j ("born") inside this pass
+                            if (row < n) L.B[row * ldT + (i - c0)] = acc[r][q];
+                            else if (row < n + m) gh[gj + (row - n) * len + (i - po * j)] = acc[r][q];
+                        }
+                    }
+                }
+            }
+            if (j > 0) {
+                for (int e = tid; e < po * n; e += nt) {
+                    const int a = e / n, r = e - a * n, i = (j - 1) * po + a;
+                    if (i >= c0 && i < c1) L.B[r * ldT + (i - c0)] = c.Co[(size_t)a * n + r];
+                }
+                (void)qp::panel_load(d, dyn, P, j - 1);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -672,7 +813,7 @@ __device__ __forceinline__ void set_wait(liptr c, int v) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ wg::qp_d4 panel_tile(Lds &L, int KT, int J, int Jp, int l16, int kk) {      // R_JJ' = Rinv_J^T K_JJ' (returned as well)
-    clptr Ri = L.Rinv + (size_t)J * TSZ;
+    clptr Ri = rinv_tile(L, J, KT);
     lptr T = L.B + (size_t)qpc::tile_index(J, Jp, KT) * TSZ;
     double av[4], bv[4];
 #pragma unroll
@@ -707,7 +848,7 @@ __device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const
 #else
 #define TC_LAP(i) ((void)0)
 #endif
-        bool ok = qpc::chol16<false>(L.B, L.Rinv);
+        bool ok = qpc::chol16<false>(L.B, rinv_tile(L, 0, KT));
         TC_LAP(3);
         set_signal(Frinv);
         TC_LAP(4);
@@ -723,7 +864,7 @@ __device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const
             tile_update_reg(T, P, l16, kk);
             __builtin_amdgcn_wave_barrier();
             TC_LAP(2);
-            ok = qpc::chol16<false>(T, L.Rinv + (size_t)(J + 1) * TSZ) && ok;
+            ok = qpc::chol16<false>(T, rinv_tile(L, J + 1, KT)) && ok;
             TC_LAP(3);
             set_signal(Frinv);
             TC_LAP(4);
@@ -772,12 +913,12 @@ __device__ __forceinline__ void tile_cholesky_set(const QPDims &d, Lds &L, const
 __device__ __forceinline__ void unit_tiles(const QPDims &d, Lds &L) {
     const int KT = d.KT, tid = SRH_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l16 = lane & 15, kk = lane >> 4, noff = KT * (KT - 1) / 2;
-    for (int t = wave; t < noff; t += 8) {
+    for (int t = wave; t < noff; t += (int)(blockDim.x >> 6)) {
         int tt = t, I = 0;
         while (tt >= KT - 1 - I) { tt -= KT - 1 - I; ++I; }
         const int J = I + 1 + tt;
         lptr T = L.B + (size_t)qpc::tile_index(I, J, KT) * TSZ;
-        clptr Ri = L.Rinv + (size_t)I * TSZ;
+        clptr Ri = rinv_tile(L, I, KT);
         double av[4], bv[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { av[s] = Ri[l16 * TS + 4 * s + kk]; bv[s] = T[(4 * s + kk) * TS + l16]; }
@@ -797,7 +938,8 @@ __device__ __forceinline__ void k_solve_unit_impl(const QPDims &d, Lds &L, lptr 
     constexpr int KMAX = KTC > 0 ? KTC : 8;
     const int KT = KTC > 0 ? KTC : d.KT, tid = SRH_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c = lane >> 2, part = lane & 3;
-    if (wave == 0) {                                                     // y = Uh^-T v
+    const int sw = serial_wave(L);
+    if (wave == sw) {                                                    // y = Uh^-T v
         double acc[KMAX];
 #pragma unroll
         for (int J = 0; J < KMAX; ++J) acc[J] = 0.0;
@@ -820,9 +962,8 @@ __device__ __forceinline__ void k_solve_unit_impl(const QPDims &d, Lds &L, lptr 
         }
     }
     __syncthreads();
-    if (wave < KT) {                                                     // w_J = Rinv_J (Rinv_J^T y_J)
-        const int J = wave;
-        clptr Ri = L.Rinv + (size_t)J * TSZ;
+    for (int J = wave; J < KT; J += (int)(blockDim.x >> 6)) {            // w_J = Rinv_J (Rinv_J^T y_J): a tile per wave (4-wave workgroups: two rounds)
+        clptr Ri = rinv_tile(L, J, KT);
         double t = 0.0;
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) t = fma(Ri[(4 * part + kq) * TS + c], v[16 * J + 4 * part + kq], t);
@@ -838,7 +979,7 @@ __device__ __forceinline__ void k_solve_unit_impl(const QPDims &d, Lds &L, lptr 
         if (part == 0) v[16 * J + c] = w;
     }
     __syncthreads();
-    if (wave == 0) {                                                     // x = Uh^-1 w
+    if (wave == sw) {                                                    // x = Uh^-1 w
         double acc[KMAX];
 #pragma unroll
         for (int J = 0; J < KMAX; ++J) acc[J] = 0.0;
@@ -1567,6 +1708,328 @@ __device__ __forceinline__ int ipm_box(const QPDims &dfull, const QPConst &c, co
     return status;
 }
 
+// ------------------------------------------------------------------ ipm_box for the HALF-SIZE workgroup (4 waves, <= 80 KB of LDS)
+// The same iteration as ipm_box() -- same starting points, weights, stopping rule, warm start, same phase order -- for a workgroup of 256
+// threads that shares its CU with a second rollout (QPDims::lean_half, lean.hip: the <.., N, N, ..> instantiations).  What differs:
+//   * a thread owns BOTH an input (its two box rows) and a state-row slot (ipm_box gives them to different threads: N m + N GX <= 512);
+//     the per-stage sums of the state rows are the same DPP sums over GX adjacent lanes;
+//   * the free response yf and the region sequence of the condensation come from the problem's L2 block (Lds::yfg / goffg), every packed
+//     row of G from there as well (lean_j0 = N), the inverses of the diagonal tiles sit in the tiles' own places (rinv_tile);
+//   * the condensation runs in two column passes (condense_half), rollouts take two row passes (rollout<.., WG = 4>).
+// Sums over rows are taken in another order than ipm_box's (reduce2 over 4 waves, two roles per thread): rounding-level differences.
+template <int MSEL, int NSEL, int GX, int NST = 0, int J0SEL = 0>
+__device__ __forceinline__ int ipm_box4(const QPDims &dfull, const QPConst &c, const QPDyn &dyn, const QPData &q, gptr work_base,
+                                        Lds &L, int *iters_out, QPWork &wout, long long *prof, int warm_mode = 0) {
+    const bool warm = warm_mode != 0, poison = warm_mode == 2;
+    int tid = SRH_TID;                                       // re-read at the top of every interior-point iteration (dev_la.h: SRH_TID)
+    const int nt = blockDim.x;
+    QPDims d = dfull;
+    d.tr = 0;
+    d.nrx = d.nX;
+    d.RX = d.nrx + d.nXf;
+    d.NR = d.N * d.RX + d.N * d.nU;
+    d.ng = d.N * d.nrx + d.nXf + d.N * d.nU;
+    QPWork w;
+    qp_carve(w, work_base, d);
+    wout = w;
+    gptr gh = work_base + dfull.qc_off;
+    const int N = d.N, m = d.m, nm = N * m, ldG = 16 * d.KT, NP = 2 * N, nz = d.nz;
+    GPackT<NST, J0SEL> g{(cgptr)gh, (clptr)(L.Gt), d.lean_j0, m, NP};
+    Prof pf;
+    constexpr double WARM_FLOOR = 1e-2;
+    if (warm) { for (int e = tid; e < nm; e += nt) L.u[e] = w.u[e]; }
+    else { for (int e = tid; e < nm; e += nt) { w.u[e] = 0.0; L.u[e] = 0.0; } }
+    for (int e = tid; e < ldG + L.ypad; e += nt) { L.ya[e] = 0.0; L.yd[e] = 0.0; L.yg[e] = 0.0; }     // padding stays zero for good
+    for (int e = tid; e <= N; e += nt) w.s[e] = 0.0;
+    for (int k = tid; k < N; k += nt) L.idxl[k] = dyn.idx ? dyn.idx[k] : k;
+    if (tid < 5) L.flag[3 + tid] = 0;                          // counters of the two wave sets (Waves, tile_cholesky_set)
+    __syncthreads();
+    bool reuse = false;
+    if (dyn.idx != nullptr) {
+        int same = L.flag[2];
+        for (int k = tid; k < N; k += nt) same = same && (L.goffg[k] == L.idxl[k]);
+        if (tid == 0) L.flag[3] = 1;
+        __syncthreads();
+        if (!same) L.flag[3] = 0;
+        __syncthreads();
+        reuse = L.flag[3] != 0;
+        __syncthreads();
+        if (tid == 0) L.flag[3] = 0;                           // tile_cholesky_set's early-tile counter from here on
+    }
+    if (!reuse) {
+        rollout<MSEL, NSEL, false, 4>(d, dyn, q.x0, (cgptr) nullptr, w.x, L);
+        condense_half<MSEL, NSEL>(d, c, dyn, w.x, gh, L);
+        for (int k = tid; k < N; k += nt) L.goffg[k] = L.idxl[k];
+        if (tid == 0) L.flag[2] = 1;
+        __syncthreads();
+    }
+    if (warm) {                                               // y = y_free + G u
+        __syncthreads();
+        g_times<MSEL>(d, g, L, L.u, L.dy);
+        for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yfg[e] + L.dy[e]; }
+        __syncthreads();
+        for (int e = tid; e < ldG; e += nt) L.dy[e] = 0.0;
+    } else {
+        for (int e = tid; e < ldG; e += nt) { L.y[e] = L.yfg[e]; L.dy[e] = 0.0; }
+    }
+    __syncthreads();
+    // ---- this thread's rows: the two box rows of input `tid`, and one state-row slot
+    const bool isu = tid < nm;
+    const bool isx = tid < N * GX;
+    const int ku = isu ? tid / m : 0, bu = isu ? tid - ku * m : 0;
+    const int kx = isx ? tid / GX + 1 : 1, rx = isx ? tid - (kx - 1) * GX : 0;        // stage 1..N, row slot
+    const int nrk = d.nX + (kx == N ? d.nXf : 0);
+    const bool xrow = isx && rx < nrk;                                               // the slot holds a state row
+    const bool xlead = isx && rx == 0;                                               // first lane of the stage group
+    double cu[2] = {0.0, 0.0}, hu[2] = {0.0, 0.0}, cx[2] = {0.0, 0.0}, hx = 0.0;
+    if (isu) {
+        cu[0] = c.UA[(size_t)(2 * bu) * m + bu]; cu[1] = c.UA[(size_t)(2 * bu + 1) * m + bu];
+        hu[0] = c.Ub[2 * bu]; hu[1] = c.Ub[2 * bu + 1];
+    }
+    if (xrow) {
+        cgptr T = rx < d.nX ? c.Tx + (size_t)rx * 2 : c.Txf + (size_t)(rx - d.nX) * 2;
+        cx[0] = T[0]; cx[1] = T[1];
+        hx = rx < d.nX ? c.Xb[rx] : c.Xfb[rx - d.nX];
+    }
+    const double r2bb = isu ? c.R2[bu * m + bu] : 0.0;
+    const double udv = (isu && q.ud) ? q.ud[(size_t)ku * m + bu] : 0.0;
+    double gc0 = 0.0, gc1 = 0.0, s00 = 0.0, s01 = 0.0, s11 = 0.0;
+    if (xlead) {
+        cgptr S = (kx == N) ? c.ScN : c.Sc;
+        s00 = S[0]; s01 = S[1]; s11 = S[3];
+        if (q.z) for (int b = 0; b < nz; ++b) { gc0 = fma(-c.Cz2[b], q.z[(size_t)kx * nz + b], gc0); gc1 = fma(-c.Cz2[nz + b], q.z[(size_t)kx * nz + b], gc1); }
+        if (kx == N && c.Qzf && q.zf) for (int b = 0; b < nz; ++b) { gc0 = fma(-c.Czf2[b], q.zf[b], gc0); gc1 = fma(-c.Czf2[nz + b], q.zf[b], gc1); }
+    }
+    const int lsu = 2 * tid, lsx = 2 * nm + (kx - 1) * (d.nX + d.nXf) + rx;           // this thread's rows in w.lam (layout of ipm_box)
+    double tu[2] = {0.0, 0.0}, lu[2] = {0.0, 0.0}, gu[2] = {0.0, 0.0}, ru[2] = {0.0, 0.0}, dtu[2] = {0.0, 0.0}, dlu[2] = {0.0, 0.0};
+    double txr = 0.0, lxr = 0.0, gxr = 0.0, rcx = 0.0, dtx = 0.0, dlx = 0.0;
+    auto yval = [&](clptr vy) -> double { return fma(cx[1], vy[(kx - 1) * 2 + 1], cx[0] * vy[(kx - 1) * 2]); };
+    int status = 1, it = 0;
+    enum { INIT = 0, PRED = 1, CORR = 2 };
+    int mode = INIT;
+    double mu = 0.0, rp = 0.0, sig = 0.0, sd = 1.0, sp = 1.0, dreg = 0.0;
+    bool near_opt = false;
+    const bool ya_const = d.nX + d.nXf == 0;                  // no state rows: L.ya is the same in the predictor and the corrector (newton_front)
+    auto scales = [&]() {                                     // residual scales and the dual regularisation (once per QP)
+        for (int e = tid; e < d.n; e += nt) {
+            double gq = 0.0;
+            if (q.z) for (int a = 0; a < nz; ++a) gq = fma(c.HtQz2[e * nz + a], -q.z[nz + a], gq);
+            sd = fmax(sd, fabs(gq));
+        }
+        for (int e = tid; e < d.nU; e += nt) sp = fmax(sp, fabs(c.Ub[e]));
+        reduce2(sd, 1, sp, 1, L.red);
+        sd = fmax(sd, q.omega);
+        sp = fmax(sp, fabs(q.delta));
+        dreg = d.reg / sd;
+    };
+    if (warm && d.ng > 0) {
+        if (isu) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                tu[s2] = fmax(-(cu[s2] * L.u[tid] - hu[s2]), WARM_FLOOR);
+                lu[s2] = poison ? INFINITY : fmax(w.lam[lsu + s2], WARM_FLOOR);
+            }
+        }
+        if (xrow) {
+            txr = fmax(-(yval(L.y) - hx), WARM_FLOOR);
+            lxr = poison ? INFINITY : fmax(w.lam[lsx], WARM_FLOOR);
+        }
+        scales();
+        mode = PRED;
+    }
+    while (true) {
+        tid = SRH_TID;
+        // ---------------- rows -> weights, gradient shifts, and their per-stage sums, all in place
+        double musum = 0.0, rpm = 0.0;
+        double Du[2] = {0.0, 0.0}, rhu[2] = {0.0, 0.0}, Dx = 0.0, rhx = 0.0;
+        if (isu) {
+            const double uv = L.u[tid];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (mode == INIT) {
+                    Du[s2] = 1.0; rhu[s2] = cu[s2] * uv - hu[s2]; lu[s2] = 0.0;
+                } else if (mode == PRED) {
+                    const double gq = cu[s2] * uv - hu[s2], t = tu[s2], lam = lu[s2], rg = gq + t;
+                    gu[s2] = rg;
+                    Du[s2] = lam / (t + dreg * lam);
+                    rhu[s2] = Du[s2] * (rg + dreg * lam);
+                    musum += lam * t;
+                    rpm = fmax(rpm, fabs(rg));
+                } else {
+                    const double t = tu[s2], lam = lu[s2], rc = lam * t + dtu[s2] * dlu[s2] - sig * mu;
+                    ru[s2] = rc;
+                    rhu[s2] = lam + (lam * gu[s2] - rc) / (t + dreg * lam);
+                }
+            }
+        }
+        if (xrow) {
+            if (mode == INIT) {
+                Dx = 1.0; rhx = yval(L.y) - hx; lxr = 0.0;
+            } else if (mode == PRED) {
+                const double gq = yval(L.y) - hx, t = txr, lam = lxr, rg = gq + t;
+                gxr = rg;
+                Dx = lam / (t + dreg * lam);
+                rhx = Dx * (rg + dreg * lam);
+                musum += lam * t;
+                rpm = fmax(rpm, fabs(rg));
+            } else {
+                const double t = txr, lam = lxr, rc = lam * t + dtx * dlx - sig * mu;
+                rcx = rc;
+                rhx = lam + (lam * gxr - rc) / (t + dreg * lam);
+            }
+        }
+        if (isu) {
+            const double du0 = r2bb * (L.u[tid] - udv);
+            if (mode != CORR) {
+                double v = fma(cu[0] * Du[0], cu[0], r2bb);
+                v = fma(cu[1] * Du[1], cu[1], v);
+                L.Ldi[tid] = 1.0 / sqrt(v);
+            }
+            L.ta[tid] = fma(cu[1], rhu[1], fma(cu[0], rhu[0], du0));
+            if (mode == PRED) L.tb[tid] = fma(cu[1], lu[1], fma(cu[0], lu[0], du0));
+        }
+        if (isx) {                                           // whole stage groups: the DPP sums see every lane of a group
+            const double y0 = L.y[(kx - 1) * 2], y1 = L.y[(kx - 1) * 2 + 1];
+            if (mode != CORR) {
+                const double a00 = gsum<GX>(cx[0] * Dx * cx[0]), a01 = gsum<GX>(cx[0] * Dx * cx[1]), a11 = gsum<GX>(cx[1] * Dx * cx[1]);
+                if (xlead) {
+                    const double S00 = s00 + a00, S01 = s01 + a01, S11 = s11 + a11;
+                    const double dmax = fmax(fabs(S00), fabs(S11));
+                    const double l00 = S00 > 1e-14 * dmax ? sqrt(S00) : 0.0;
+                    const double l10 = l00 > 0.0 ? S01 / l00 : 0.0;
+                    const double v = fma(-l10, l10, S11);
+                    const double l11 = v > 1e-14 * dmax ? sqrt(v) : 0.0;
+                    lptr Lk = L.Ls + (size_t)(kx - 1) * 4;
+                    Lk[0] = l00; Lk[1] = 0.0; Lk[2] = l10; Lk[3] = l11;
+                }
+            }
+            const double r0 = gsum<GX>(cx[0] * rhx), r1 = gsum<GX>(cx[1] * rhx);
+            double l0 = 0.0, l1 = 0.0;
+            if (mode == PRED) { l0 = gsum<GX>(cx[0] * (xrow ? lxr : 0.0)); l1 = gsum<GX>(cx[1] * (xrow ? lxr : 0.0)); }
+            if (xlead) {
+                const double c0 = fma(s01, y1, s00 * y0) + gc0, c1 = fma(s11, y1, s01 * y0) + gc1;
+                L.ya[(kx - 1) * 2] = c0 + r0; L.ya[(kx - 1) * 2 + 1] = c1 + r1;
+                if (mode == PRED) { L.yg[(kx - 1) * 2] = c0 + l0; L.yg[(kx - 1) * 2 + 1] = c1 + l1; }
+            }
+        }
+        if (mode == PRED) {
+            reduce2(musum, 0, rpm, 1, L.red);
+            mu = musum / d.ng;
+            rp = rpm;
+        }
+        __syncthreads();
+        // ---------------- Newton system
+        double rd = 0.0;
+        bool ok = true;
+        if (mode != CORR) {
+            gram<MSEL>(d, c, g, L);
+            // the factorisation (waves 0-1: a chain of one-wave 16 x 16 factorisations) beside the half of the Newton solve that
+            // does not need the factor (waves 2-3), see Waves
+            const clptr gyd = mode == PRED ? (clptr)L.yg : (clptr) nullptr;
+            const int sw = serial_wave(L);
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6) ^ sw;
+            auto W = half_waves(L.flag + 4, sw);
+            if (half_of_wave(wv) == 0) tile_cholesky_set(d, L, W, L.flag + 5, L.flag + 3);
+            else newton_front<MSEL, true>(d, g, L, gyd, W, pf, ya_const && mode == PRED);
+            __syncthreads();
+            ok = L.flag[1] != 0;
+            if (tid < 5) L.flag[3 + tid] = 0;
+            if (gyd) rd = L.Qu[0];
+            if (ok) unit_tiles(d, L);
+            if (ok) newton_back<MSEL>(d, g, L, pf);
+        } else {
+            newton_solve<MSEL>(d, g, L, (clptr) nullptr, &rd, pf, ya_const);
+        }
+        // ---------------- use the direction
+        if (mode == INIT) {
+            if (!ok) { status = 2; break; }
+            for (int e = tid; e < nm; e += nt) L.u[e] += L.du[e];
+            for (int e = tid; e < ldG; e += nt) L.y[e] += L.dy[e];
+            __syncthreads();
+            if (d.ng == 0) { status = 0; break; }
+            double zmin = INFINITY, zmax = -INFINITY;
+            if (isu) {
+                const double uv = L.u[tid];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) { gu[s2] = cu[s2] * uv - hu[s2]; zmin = fmin(zmin, gu[s2]); zmax = fmax(zmax, gu[s2]); }
+            }
+            if (xrow) { gxr = yval(L.y) - hx; zmin = fmin(zmin, gxr); zmax = fmax(zmax, gxr); }
+            reduce2(zmin, 2, zmax, 1, L.red);
+            const double sh_t = zmax >= 0.0 ? 1.0 + zmax : 0.0, sh_l = zmin <= 0.0 ? 1.0 - zmin : 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { tu[s2] = -gu[s2] + sh_t; lu[s2] = gu[s2] + sh_l; }
+            txr = -gxr + sh_t; lxr = gxr + sh_l;
+            scales();
+            mode = PRED;
+            continue;
+        }
+        double amax = 1e300, dummy = 0.0;
+        if (ok) {
+            if (isu) {
+                const double duv = L.du[tid];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const double t = tu[s2], lam = lu[s2], rga = gu[s2] + cu[s2] * duv;
+                    const double dl = ((mode == PRED ? -lam * t : -ru[s2]) + lam * rga) / (t + dreg * lam);
+                    const double dtv = -rga + dreg * dl;
+                    dlu[s2] = dl; dtu[s2] = dtv;
+                    if (dtv < 0.0) amax = fmin(amax, -t / dtv);
+                    if (dl < 0.0) amax = fmin(amax, -lam / dl);
+                }
+            }
+            if (xrow) {
+                const double t = txr, lam = lxr, rga = gxr + yval(L.dy);
+                const double dl = ((mode == PRED ? -lam * t : -rcx) + lam * rga) / (t + dreg * lam);
+                const double dtv = -rga + dreg * dl;
+                dlx = dl; dtx = dtv;
+                if (dtv < 0.0) amax = fmin(amax, -t / dtv);
+                if (dl < 0.0) amax = fmin(amax, -lam / dl);
+            }
+        }
+        reduce2(amax, 2, dummy, 0, L.red);
+        if (mode == PRED) {
+            if (!ok) { status = near_opt ? 0 : 2; break; }
+            if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
+            if (!(rd == rd)) { status = near_opt ? 0 : 6; break; }
+            const double ltol = fmax(d.tol, 1e-9);
+            if (rd <= ltol * sd && rp <= ltol * sp && mu <= d.tol) { status = 0; break; }
+            near_opt = (rd <= 1e-8 * sd && rp <= 1e-8 * sp && mu <= 1e-8);
+            if (it >= d.max_iter) { status = 1; break; }
+            const double a_aff = fmin(1.0, amax);
+            double ma = 0.0;
+            if (isu) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) ma += (lu[s2] + a_aff * dlu[s2]) * (tu[s2] + a_aff * dtu[s2]);
+            }
+            if (xrow) ma += (lxr + a_aff * dlx) * (txr + a_aff * dtx);
+            reduce2(ma, 0, dummy, 0, L.red);
+            const double mu_aff = ma / d.ng;
+            sig = mu > 0.0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+            mode = CORR;
+            continue;
+        }
+        if (!ok) { status = 2; break; }
+        const double a = fmin(1.0, 0.99 * amax);
+        for (int e = tid; e < nm; e += nt) L.u[e] += a * L.du[e];
+        for (int e = tid; e < ldG; e += nt) L.y[e] += a * L.dy[e];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { tu[s2] += a * dtu[s2]; lu[s2] += a * dlu[s2]; }
+        txr += a * dtx; lxr += a * dlx;
+        __syncthreads();
+        ++it;
+        mode = PRED;
+    }
+    __syncthreads();
+    for (int e = tid; e < nm; e += nt) w.u[e] = L.u[e];
+    if (status == 0) {                                        // what the next QP of this solve starts from (warm)
+        if (isu) { w.lam[lsu] = lu[0]; w.lam[lsu + 1] = lu[1]; }
+        if (xrow) w.lam[lsx] = lxr;
+    }
+    __syncthreads();
+    if (iters_out) *iters_out = it;
+    return status;
+}
+
 // ------------------------------------------------------------------ short horizons: the interior point on ONE wave
 // The reference's closed-loop drivers replan N = 5 (examples/diamond/diamond.py:309-316) and N = 3 (examples/hardware/diamond.py:
 // 393-399): N p_o <= 16 outputs -- K is ONE 16 x 16 tile -- and N n_u <= 64 inputs.  ipm_box() spends ~80 k clocks per interior-point
@@ -2089,7 +2552,10 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     // GXSEL > 0: box-structured input rows, rows next to their sums, GXSEL lanes per stage for the state rows (one variant per
     // kernel: both interior points in one kernel thrash the instruction cache -- measured -8 % on everything)
     // NST < 0: the short-horizon instantiations (one tile of K): the interior point on one wave
+    // NST > 0 and J0SEL == NST: the half-size workgroup (4 waves, every packed row of G in L2)
+    constexpr bool HALFWG = NST > 0 && J0SEL == NST;
     if constexpr (NST < 0) st = ipm_wave<MSEL, NSEL, GXSEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof, warm);
+    else if constexpr (HALFWG) st = ipm_box4<MSEL, NSEL, GXSEL, NST, J0SEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof, warm);
     else if constexpr (GXSEL > 0) st = ipm_box<MSEL, NSEL, GXSEL, NST, J0SEL>(dfull, c, dyn, q, work_base, L, &it, wout, prof, warm);
     else st = ipm<MSEL, NSEL>(dfull, c, dyn, q, work_base, L, Lq, &it, wout, prof);
     if (iters_out) *iters_out = it;
@@ -2106,7 +2572,7 @@ __device__ __forceinline__ int solve_qp(const QPDims &dfull, const QPConst &c, c
     for (int e = tid; e <= N; e += nt) w.s[e] = (e == 0) ? s0 : 0.0;
     __syncthreads();
     lptr xs = L.B;                                        // (N + 1) n_x doubles at the start of the Theta^T area: free from here on
-    rollout<MSEL, NSEL, true>(d0, dyn, q.x0, (cgptr)w.u, w.x, L, xs);
+    rollout<MSEL, NSEL, true, HALFWG ? 4 : 8>(d0, dyn, q.x0, (cgptr)w.u, w.x, L, xs);
     __syncthreads();
 #ifdef SRH_PROFILE
     { const long long now_ = clock64(); prof[22] += now_ - tail_last; tail_last = now_; }

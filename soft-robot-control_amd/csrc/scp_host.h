@@ -125,7 +125,9 @@ static bool lean_gram_schedule(int N, int m, int KT, int nw, std::vector<int> &o
     return have;
 }
 
-int build_consts(const slocp_problem *pr, QPConstHost &C) {
+// want_half: the caller's batch is larger than the chip has CUs -- lay the problem out for the half-size lean workgroup where it fits (two
+// rollouts per CU: throughput; a single rollout is faster on the full-size workgroup).  SRH_LEAN_HALF=1 / 0 in the environment overrides.
+int build_consts(const slocp_problem *pr, QPConstHost &C, bool want_half = false) {
     SRH_REQUIRE(pr && pr->H && pr->Qz && pr->R, "LOCP: H, Qz and R are required");
     const int N = pr->N, n = pr->n_x, m = pr->n_u, nz = pr->n_z;
     SRH_REQUIRE(N >= 1 && n >= 1 && n <= 128 && m >= 1 && m <= 16 && nz >= 1 && nz <= 16,
@@ -195,7 +197,7 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
     d.max_iter = 60;
     d.tol = 1e-12;
     d.reg = 1e-8;
-    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0; d.diagD = 0; d.lean = 0; d.lean_j0 = 0; d.ls_pd = 0;
+    d.cond = 0; d.po = 0; d.KT = 0; d.qc_off = 0; d.diagD = 0; d.lean = 0; d.lean_j0 = 0; d.ls_pd = 0; d.lean_half = 0;
     std::vector<double> Qx(n * n), QxN(n * n), Ht2(n * nz), Htf2(n * nz, 0.0), R2(m * m), xs(n, 1.0);
     std::vector<double> QzH(nz * n), QzfH(nz * n, 0.0);
     for (int a = 0; a < nz; ++a)
@@ -381,10 +383,30 @@ int build_consts(const slocp_problem *pr, QPConstHost &C) {
             // where the LDS has room for them -- with SRH_LEAN_NO_FIXED=1 (run-time layouts) this measures what streaming G from L2
             // costs the interior point (round 6: the price of any layout that gives up LDS for a second resident workgroup)
             if (const char *e = getenv("SRH_LEAN_J0")) { if (j0 >= 0) j0 = std::min(N - 1, std::max(j0, atoi(e))); }
+            // The half-size workgroup (round 6; chosen for batches above the CU count, SRH_LEAN_HALF=0 / 1 overrides): 256 threads and <= 80 KB of LDS so that TWO
+            // rollouts share a CU -- every packed row of G in the L2 block (j0 = N), a thread owns an input and a state-row slot
+            // (ql::ipm_box4), Theta^T condensed in two column passes.  Only where the layout fits and lean.hip has the instantiation.
+            bool half = false;
+            if (const char *eh = getenv("SRH_LEAN_HALF")) want_half = atoi(eh) != 0;
+            // (only the shapes lean.hip instantiates the half-size kernels for: BASELINE C2 -- Diamond r = 30, N = 50, U box, 4 state rows)
+            const bool half_shape = m == 4 && n == 60 && N == 50 && pr->nX == 4 && pr->nXf == 0 && pr->n_z == 6 && d.po == 2;
+            if (want_half && half_shape && j0 >= 0 && j0 < N && pr->nU == 2 * m) {
+                QPDims dh = d;
+                dh.lean_half = 1; dh.lean_j0 = N;
+                const int RXh = pr->nX + pr->nXf, GXh = RXh == 0 ? 1 : (RXh <= 2 ? 2 : (RXh <= 4 ? 4 : 8));
+                const int MTh = dh.NPa / 16, wide = dh.KT - ql::half_split_tile(dh.KT);
+                const ql::Sizes sh = ql::sizes(dh, 256, N);
+                half = ql::lds_doubles(dh, 256, N) * sizeof(double) <= (size_t)80 * 1024 && wide * MTh <= 4 * ql::CONDENSE_SLOTS &&
+                       N * m <= 256 && N * GXh <= 256 && RXh <= 8 && (N * m) % GXh == 0 &&
+                       sh.regX >= (size_t)2 * (N + 1) * n + (size_t)2 * N * m + (size_t)pr->nX * n &&
+                       ql::half_l2_off(dh) + 16 * (size_t)dh.KT + (size_t)(N / 2 + 2) <= qc_work_doubles(dh);
+                if (half) { d.lean_half = 1; j0 = N; }
+            }
             std::vector<int> sched;
             // (the SCP loop of the lean GuSTO kernel stages both trajectories in the K-tile area between two QPs: csrc/lean.hip)
-            const bool stage_fits = j0 >= 0 && ql::sizes(d, NTHREADS, j0).regX >= (size_t)2 * (N + 1) * n + (size_t)2 * N * m + (size_t)pr->nX * n;
-            if (j0 >= 0 && j0 < N && stage_fits && ql::condense_fits(d, NTHREADS / 64) && lean_gram_schedule(N, m, d.KT, NTHREADS / 64, sched)) {
+            const int lthreads = half ? 256 : NTHREADS;
+            const bool stage_fits = j0 >= 0 && ql::sizes(d, lthreads, j0).regX >= (size_t)2 * (N + 1) * n + (size_t)2 * N * m + (size_t)pr->nX * n;
+            if (j0 >= 0 && (j0 < N || half) && stage_fits && (half || ql::condense_fits(d, NTHREADS / 64)) && lean_gram_schedule(N, m, d.KT, lthreads / 64, sched)) {
                 d.lean = 1;
                 d.lean_j0 = j0;
 
@@ -418,6 +440,7 @@ inline size_t qp_kernel_lds_bytes(const QPDims &d) {
     return srh::lds_request(std::max(a, b));
 }
 inline size_t lean_kernel_lds_bytes(const QPDims &d) {
+    if (d.lean_half) return ql::lds_doubles(d, 256, d.lean_j0) * sizeof(double);       // (<= 80 KB by construction: a multiple of 32 bytes, two per CU)
     return srh::lds_request(ql::lds_doubles(d, NTHREADS, d.lean_j0) * sizeof(double));
 }
 

@@ -10,6 +10,8 @@ struct GustoPar {
                                         // (the reference's `warm_start=True`: its cvxpy problem keeps the solver state between solves, locp.py:181)
     int poison_warm;                    // test knobs of the lean kernel, read when the plan is created.  bit 0 (SRH_LEAN_POISON_WARM=1): every warm-started
                                         // QP fails and is repeated cold; bits 4.. (SRH_LEAN_FORCE_HANDOVER=k): k + 1, SCP iteration k is handed to the fused kernel
+                                        // bit 1 (SRH_GUSTO_TRACE_QIT=1): trace slot 3 = interior-point iterations; bit 2 (SRH_LEAN_SERIAL_WAVE=1): the half-size
+                                        // lean workgroup picks its serial wave by its wave slot (ql::serial_wave_pick; measured: see DESIGN.md section 15)
     int warm_full;                      // fused kernel, OFF unless SRH_GUSTO_WARM_FULL=1 at plan creation: a full (trust-region-active) QP behind a rejected
                                         // step starts from the previous one's (u, s, lambda).  Built and measured in round 6: the
                                         // uncapped tail's full QPs keep their 18-40 interior-point iterations -- the active set of the slack rows moves with

@@ -90,6 +90,67 @@ def test_fused_gusto_diamond_c2_matches_oracle():
     run_case(wl.diamond_c2(), 1354, B=6, seed=2, variant=(False, 4, 60), what='C2', lean=(4, 60, 4, 50, 7, 4), capped_stays_lean=True)
 
 
+def test_half_size_lean_workgroup_c2_matches_oracle_and_the_full_size_kernel(monkeypatch):
+    """The half-size lean workgroup (round 6: 256 threads, <= 80 KB of LDS, every packed row of G in L2, a thread owns an input AND a
+    state-row slot, two-pass condensation -- two rollouts per CU; chosen by itself for batches above the CU count, SRH_LEAN_HALF=1 here):
+    instantiation <4, 60, 4, 50, 50, 4>.  Same acceptance as the full-size C2 case (uncapped and capped solves against oracle.gusto,
+    identical SCP iteration counts and (J, delta, omega) traces), and the same trajectories as the full-size kernel to 1e-8; a
+    keep_solver_state solve (warm start of the first QP from the previous solve) and a forced hand-over go through it as well."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2()
+    monkeypatch.setenv('SRH_LEAN_HALF', '1')
+    gh = run_case(w, 1354, B=6, seed=2, variant=(False, 4, 60), what='C2 half-size workgroup', lean=(4, 60, 4, 50, 50, 4), capped_stays_lean=True)
+    assert gh.kernel_info['lds_bytes_lean'] <= 80 * 1024
+    xh, uh, ih = gh.xopt.copy(), gh.uopt.copy(), gh.iters.copy()
+    monkeypatch.setenv('SRH_LEAN_HALF', '0')
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, 6, 2, 1354)
+    kw = dict(z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, batch=6,
+              max_trace=0, max_gusto_iters=5, first_solve_cap=5)
+    gf = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, **kw)
+    assert gf.kernel_info['lean'] == (4, 60, 4, 50, 7, 4)
+    gf.solve_batch(x0, u_init, x_init, z=z)
+    assert (gf.iters == ih).all()
+    assert rel(xh, gf.xopt) <= 1e-8 and rel(uh, gf.uopt) <= 1e-8, (rel(xh, gf.xopt), rel(uh, gf.uopt))
+    # solver state kept between solves, and a forced hand-over of SCP iteration 1 to the fused kernel (512 threads, its own layout)
+    monkeypatch.setenv('SRH_LEAN_HALF', '1')
+    gk = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, keep_solver_state=True, **kw)
+    assert gk.kernel_info['lean'] == (4, 60, 4, 50, 50, 4) and gk.solver_state_kept
+    gk.solve_batch(x0, u_init, x_init, z=z)
+    gk.solve_batch(x0, u_init, x_init, z=z)
+    assert (gk.iters == ih).all() and rel(gk.xopt, xh) <= 1e-7 and rel(gk.uopt, uh) <= 1e-7
+    monkeypatch.setenv('SRH_LEAN_FORCE_HANDOVER', '1')
+    go = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, **kw)
+    monkeypatch.delenv('SRH_LEAN_FORCE_HANDOVER', raising=False)
+    go.solve_batch(x0, u_init, x_init, z=z)
+    assert int(go.kernel_info['handed_over']) == int((ih >= 2).sum()) > 0
+    assert (go.iters == ih).all() and rel(go.xopt, xh) <= 1e-6 and rel(go.uopt, uh) <= 1e-6
+
+
+def test_half_size_lean_workgroup_is_chosen_for_batches_above_the_cu_count():
+    """Plan creation picks the layout by batch size: up to 256 rollouts the full-size workgroup (one rollout per CU is faster for each
+    of them), above that the half-size one (two per CU: throughput).  300 C2 rollouts, capped solves: both layouts give the same SCP
+    iteration counts and trajectories; the first 2 rollouts against the oracle."""
+    import workloads as wl
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import Polyhedron
+    w = wl.diamond_c2()
+    B = 300
+    gm, xc, fc, x0, u_init, x_init, z = problem(w, B, 2, 1354)
+    kw = dict(U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']), x_char=xc, f_char=fc, convg_thresh=1e-3, max_gusto_iters=5,
+              first_solve_cap=5)
+    g = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0, u_init, x_init, z=z, batch=B, max_trace=16, **kw)
+    assert g.kernel_info['lean'] == (4, 60, 4, 50, 50, 4), g.kernel_info
+    g2 = GuSTO(gm, w['N'], w['dt'], w['Qz'], w['R'], x0[:200], u_init[:200], x_init[:200], z=z[:200], batch=200, max_trace=0, **kw)
+    assert g2.kernel_info['lean'] == (4, 60, 4, 50, 7, 4), g2.kernel_info
+    assert (g.status == 0).all() and (g2.status == 0).all()
+    assert (g.iters[:200] == g2.iters).all()
+    assert rel(g.xopt[:200], g2.xopt) <= 1e-8 and rel(g.uopt[:200], g2.uopt) <= 1e-8
+    for b in range(2):
+        compare(g, b, oracle_solve(w, xc, fc, x0[b], u_init[b], x_init[b], z[b], 5), 'C2 half-size, batch 300')
+
+
 def test_fused_gusto_trunk_c5_matches_oracle():
     import workloads as wl
     w = wl.trunk_c5()

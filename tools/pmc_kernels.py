@@ -20,6 +20,16 @@ dM = _lib.DeviceBuffer.from_array(np.random.default_rng(0).standard_normal((n_f,
 for _ in range(6):
     _lib.check(L.srom_reduce_matrix_dev(rom.handle, dM.ptr, C.c_int64(n_f), 1, 1, dP.ptr, None), 'reduce')
 _lib.sync()
+# four matrices in one launch pair (srom_reduce_matrices_dev: K, D, M, S of one TPWL point)
+Ms = [dM] + [_lib.DeviceBuffer.from_array(np.random.default_rng(1 + i).standard_normal((n_f, n_f))) for i in range(3)]
+Ps = [_lib.DeviceBuffer(r * r * 8) for _ in range(4)]
+PP = C.c_void_p * 4
+mp, op = PP(*[b.ptr for b in Ms]), PP(*[b.ptr for b in Ps])
+for _ in range(6):
+    _lib.check(L.srom_reduce_matrices_dev(rom.handle, mp, 4, op, None), 'reduce4')
+_lib.sync()
+for b in Ms[1:]:
+    b.free()
 n_s, nf2 = 10000, 6250
 dS = _lib.DeviceBuffer.from_array(np.random.default_rng(7).standard_normal((n_s, nf2))); dG = _lib.DeviceBuffer(n_s * n_s * 8)
 for _ in range(4):

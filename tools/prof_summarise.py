@@ -82,7 +82,27 @@ if fv and wvv:
 
 # the one-pass U^T M U of tools/pmc_kernels.py (M 4884 x 4884; the UTMU instantiation of the projection kernel + its reduction)
 selu = lambda rs, pat: [float(r['Counter_Value']) for r in rs if pat in r['Kernel_Name']]
-fu, wu = selu(f, 'true, true>'), selu(wv, 'true, true>')
+# tools/pmc_kernels.py launches the UTMU instantiation six times with one matrix, then six times with four (blockIdx.z = matrix): split by dispatch order
+def _split(rs):
+    u = sorted((r for r in rs if 'true, true>' in r['Kernel_Name']), key=lambda r: int(r['Dispatch_Id']))
+    grids = [int(r['Grid_Size']) for r in u]
+    if len(set(grids)) < 2:
+        return [float(r['Counter_Value']) for r in u], []
+    first = grids[0]
+    return [float(r['Counter_Value']) for r in u if int(r['Grid_Size']) == first], [float(r['Counter_Value']) for r in u if int(r['Grid_Size']) != first]
+_ug = [0, 1]
+_one = lambda rs, pat, big: _split(rs)[1 if big else 0]
+fu, wu = _one(f, 'true, true>', False), _one(wv, 'true, true>', False)
+f4, w4 = (_one(f, 'true, true>', True), _one(wv, 'true, true>', True)) if len(_ug) > 1 else ([], [])
+if f4 and w4:
+    fm4, wm4 = statistics.median(f4), statistics.median(w4)
+    json.dump({'kernel': 'proj_kernel<..., UTMU> with blockIdx.z = matrix (srom_reduce_matrices_dev, four matrices) -- the streaming launch of the pair',
+               'workload': 'four M 4884 x 4884 f64, r = 30 (tools/pmc_kernels.py)', 'FETCH_SIZE_KiB_median': fm4, 'WRITE_SIZE_KiB_median': wm4,
+               'fetch_correction': 'x2 (gfx950 wide coalesced reads, MI355X_MICROARCH.md HBM section)',
+               'traffic_bytes_per_launch': (2 * fm4 + wm4) * 1024, 'algorithmic_bytes_per_launch': 4 * 8 * (4884 * 4884 + 2 * 4884 * 30 + 30 * 30),
+               'traffic_over_algorithmic': (2 * fm4 + wm4) * 1024 / (4 * 8 * (4884 * 4884 + 2 * 4884 * 30 + 30 * 30)), 'launches_sampled': len(f4),
+               'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_round.sh), ' + TAG + ' tree'},
+              open(os.path.join(P, TAG + '_utmu4_pmc.json'), 'w'), indent=1)
 if fu and wu:
     fm, wm = statistics.median(fu), statistics.median(wu)
     fr, wr = selu(f, 'utmu_reduce_kernel'), selu(wv, 'utmu_reduce_kernel')
