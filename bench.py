@@ -575,6 +575,17 @@ def pod_shapes(L, _lib, B=65536):
                   reps=300)
         out['utmu_r%d' % r] = {'us': t * 1e6, 'gbs': 8.0 * n_f * n_f / t / 1e9, 'frac_of_hbm_peak': 8.0 * n_f * n_f / t / 8e12,
                                'what': 'U^T M U, M 4884 x 4884 f64 resident, one pass + one reduction launch'}
+        # K, D, M, S of one TPWL point in one launch pair (srom_reduce_matrices_dev; tpwl/tpwl_utils.py:96-103): four n_f x n_f windows of the batch buffer
+        dP4 = [_lib.DeviceBuffer(r * r * 8) for _ in range(4)]
+        PP = C.c_void_p * 4
+        mp = PP(*[C.c_void_p(dX.ptr.value + i * n_f * n_f * 8) for i in range(4)])
+        op = PP(*[b.ptr for b in dP4])
+        t = timed(lambda: _lib.check(L.srom_reduce_matrices_dev(rom.handle, mp, 4, op, None), 'reduce4'), reps=100)
+        alg4 = 4 * 8.0 * (n_f * n_f + 2 * n_f * r + r * r)
+        out['utmu4_r%d' % r] = {'us': t * 1e6, 'us_per_matrix': t * 1e6 / 4, 'gbs': alg4 / t / 1e9, 'frac_of_hbm_peak': alg4 / t / 8e12,
+                                'what': 'U^T M U of FOUR 4884 x 4884 f64 matrices in one launch pair (K, D, M, S of a TPWL point)'}
+        for b in dP4:
+            b.free()
         dP.free()
         dXr.free()
     dX.free()
