@@ -725,12 +725,12 @@ def secondary(L, _lib, rank, world, dist):
                                     B=mat(mdl['B']), rd_coeff=mat(mdl['Rd']), Bd=mat(mdl['Bd'])),
                          params=dict(state_dim=sc(n6), input_dim=sc(m4), output_dim=sc(n6), SSM_order=sc(2), ROM_order=sc(3)))
         gm6 = SSMGuSTO(s6)
-        Qz6 = np.zeros((n6, n6)); Qz6[0, 0] = Qz6[1, 1] = 100.0
+        Qz6 = np.zeros((n6, n6)); Qz6[0, 0] = Qz6[1, 1] = Qz6[2, 2] = 100.0      # x, y, z of the end effector (diamond_SSM.py:322-326)
         R6 = 0.003 * np.eye(m4)
         x06 = np.zeros(n6)
         u6 = np.zeros((N3, m4))
         xi6, _ = s6.rollout(x06, u6, dt2)
-        z6 = np.tile(np.array([0.02, -0.01, 0, 0, 0, 0.0]), (N3 + 1, 1))
+        z6 = np.tile(np.array([0.02, -0.01, 0.015, 0, 0, 0.0]), (N3 + 1, 1))
         g6 = GuSTO(gm6, N3, dt2, Qz6, R6, x06, u6, xi6, z=z6, U=HyperRectangle([1500.0] * m4, [0.0] * m4), verbose=0,
                    max_gusto_iters=0, convg_thresh=1e-3, warm_start=True)
         ts6 = []
@@ -775,7 +775,7 @@ def secondary(L, _lib, rank, world, dist):
             except Exception as exc:
                 cpu6 = {'error': repr(exc)}
         out['ssm_gusto_rti'] = {'cpu': cpu6,
-                                'workload': 'SSM (n_x = 6, n_u = 4, cubic) + GuSTO real-time iteration: N = 3, dt = 0.02, max_gusto_iters = 0 '
+                                'workload': 'SSM (n_x = 6, n_u = 4, cubic) + GuSTO real-time iteration with the driver\'s cost (three tip coordinates): N = 3, dt = 0.02, max_gusto_iters = 0 '
                                             '(one QP per call), U box; %s, host buffers' % ('the whole solve in one launch of csrc/gusto_ssm.hip' if getattr(g6, '_ssm', False) else 'host loop around the device QP'),
                                 'kernel': g6.kernel_info['kernel'] if getattr(g6, '_ssm', False) else 'host loop + ' + str((g6.locp.kernel_info or {}).get('kernel')),
                                 'ms_median': ts6[len(ts6) // 2] * 1e3, 'ms_p95': ts6[int(len(ts6) * 0.95)] * 1e3,

@@ -19,6 +19,7 @@
 // The linearisation scratch and the QP's layouts share the workgroup's LDS (they never live at the same time).
 #include "scp_types.h"
 #include "ssm_host.h"
+#include "locp_dense_u.h"
 
 #include <memory>
 
@@ -42,7 +43,7 @@ struct SsmGustoBatch {
 };
 
 // offsets (doubles) of the SCP loop's arrays behind the QP's own work arrays
-struct SsmGustoWork { size_t xk, uk, A, AT, B, BT, dd, xka, x0a, acc, x0c, zc, udc, Ac, fk, rec, end; };
+struct SsmGustoWork { size_t xk, uk, A, AT, B, BT, dd, xka, x0a, acc, x0c, zc, udc, Ac, fk, rec, lamd, end; };
 __host__ __device__ inline SsmGustoWork ssm_gusto_work(const QPDims &d, int n) {
     SsmGustoWork g;
     const size_t N = d.N, na = d.n, m = d.m;
@@ -62,7 +63,8 @@ __host__ __device__ inline SsmGustoWork ssm_gusto_work(const QPDims &d, int n) {
     g.Ac = g.udc + N * m;                       // continuous Jacobians and f of the current iterate (model-accuracy test, table path)
     g.fk = g.Ac + N * (size_t)n * n;
     g.rec = g.fk + N * (size_t)n;               // [0] = 1: w.u / w.lam hold a converged lean QP of this rollout's previous solve (warm_across)
-    g.end = g.rec + 4;
+    g.lamd = g.rec + 4;                         // 64 multipliers of the dense one-wave QP (qdu::solve) for its warm start
+    g.end = g.lamd + 64;
     return g;
 }
 
@@ -75,7 +77,7 @@ __host__ __device__ inline size_t ssm_gusto_scratch_doubles(const SsmDev &S) {
 // driver's N = 3, 31 k clocks per interior-point iteration against 70 k of the eight-wave forms -- DESIGN.md section 13); qp::solve takes over
 // when that minimiser leaves the trust region or the interior point does not converge.  GXL = lanes per stage for the state rows (ql::ipm_box).
 template <bool SPLIT, int MSEL, int GXL>
-__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off, int tab_off) {
+__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off, int tab_off, int dense_u) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     qp::specialise<MSEL, 0>(d);
     long long prof[32] = {0};
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
     gptr rec = base + gw.rec;
     // have_warm: the work block holds the minimiser and multipliers of a converged lean QP -- of this solve, or (warm_across: the reference's
     // warm_start=True keeps its solver state between solves, locp.py:181) of the rollout's previous solve
-    bool have_warm = GXL > 0 && par.warm_across != 0 && rec[0] == 1.0;
+    bool have_warm = (GXL > 0 || dense_u) && par.warm_across != 0 && rec[0] == 1.0;
+    gptr lamd = base + gw.lamd;
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
     bool converged = false, tr_hot = false;
@@ -233,8 +236,17 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
         __syncthreads();
         lap0 = clock64();
         int st = -1;
+        if (dense_u && !tr_hot) {
+            // N n_u <= 16: the QP without its trust-region rows in the space of the inputs on one wave, whatever the cost's rank (locp_dense_u.h)
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                const bool warm = have_warm && attempt == 0;
+                st = qdu::solve(d, c, dyn, q, w, (lptr)smem, lamd, &J, &qit, warm ? 1 : 0);
+                if (st == 0 || st == 100 || !warm) break;
+            }
+            have_warm = st == 0;
+        }
         if constexpr (GXL > 0) {
-            if (!tr_hot) {
+            if (!tr_hot && !dense_u) {
                 ql::Lds LL;
                 ql::lds_carve(LL, (lptr)smem, d, NTHREADS);
                 if (tid == 0) LL.flag[2] = 0;              // (the LDS was used by the linearisation: nothing condensed is left)
@@ -420,6 +432,7 @@ struct sgusto_ssm_plan {
     size_t work_stride = 0, lds = 0;
     int red_off = 0, tab_off = 0;       // (doubles) reduction scratch / model tables behind the aliased layouts (tab_off = 0: tables stay in L2)
     int lean_gx = 0;                    // > 0: the lean one-wave interior point runs first (template argument GXL of the kernel)
+    int dense_u = 0;                    // 1: the dense one-wave QP in the space of the inputs runs first (N n_u <= 16: qdu::solve)
     char *pin = nullptr;                // one pinned, device-visible block: [inputs | outputs]
     size_t pin_bytes = 0;
     bool solved = false;
@@ -446,7 +459,7 @@ int ssm_gusto_launch(sgusto_ssm_plan *pl, const SsmGustoBatch &b, hipStream_t st
     bool launched = false;
 #define X(SP, M, GX) if (!launched && (d.split != 0) == SP && (M == 0 || d.m == M) && pl->lean_gx == GX) { \
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_ssm_kernel<SP, M, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds)); \
-        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off, pl->tab_off); launched = true; }
+        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off, pl->tab_off, pl->dense_u); launched = true; }
     X(false, 4, 1) X(false, 4, 2) X(false, 8, 1) X(false, 4, 0) X(false, 8, 0) X(false, 0, 0) X(true, 0, 0)
 #undef X
     SRH_REQUIRE(launched, "sgusto_ssm: no kernel variant");
@@ -499,8 +512,11 @@ int sgusto_ssm_plan_create(sgusto_ssm_plan_t **out, sssm_t *model, const slocp_p
     pl->work_stride = (doubles + 3) & ~(size_t)3;
     const SsmDev S = model->view();
     const size_t a = qp_kernel_lds_bytes(d), s2 = ssm_gusto_scratch_doubles(S) * sizeof(double);
+    pl->dense_u = (qdu::applies(d) && prob->Qzf == nullptr && !getenv("SRH_GUSTO_SSM_NO_DENSE")) ? 1 : 0;
+    if (pl->dense_u) pl->lean_gx = 0;               // (one one-wave QP per kernel: the instantiation without the lean interior point is the smaller one)
     const size_t a2 = pl->lean_gx ? lean_kernel_lds_bytes(d) : 0;
-    const size_t body = (std::max(std::max(a, a2), s2) + 15) & ~(size_t)15;
+    const size_t a3 = pl->dense_u ? qdu::lds_doubles(d) * sizeof(double) : 0;
+    const size_t body = (std::max(std::max(std::max(a, a2), a3), s2) + 15) & ~(size_t)15;
     pl->red_off = (int)(body / sizeof(double));
     size_t total = body + 16 * sizeof(double);
     const size_t tabs = (ssm::lds_tab_doubles(S.n, S.no, S.nr, S.ns, 0) + 8) * sizeof(double);
@@ -530,7 +546,7 @@ int sgusto_ssm_plan_destroy(sgusto_ssm_plan_t *pl) { delete pl; return SRH_OK; }
  * (the reference's warm_start=True, locp.py:181); only where the lean one-wave interior point runs. */
 int sgusto_ssm_plan_set_warm_across(sgusto_ssm_plan_t *pl, int on) {
     SRH_REQUIRE(pl, "sgusto_ssm_plan_set_warm_across: null plan");
-    pl->par.warm_across = (on && pl->lean_gx > 0) ? 1 : 0;
+    pl->par.warm_across = (on && (pl->lean_gx > 0 || pl->dense_u)) ? 1 : 0;
     return SRH_OK;
 }
 

@@ -134,6 +134,45 @@ def test_gusto_ssm_nonlinear_observer(with_X, path, monkeypatch):
     close(got[:, :3], np.asarray(tr)[:, :3], 1e-6)
 
 
+@pytest.mark.parametrize('qp', ['dense', 'fused'])
+def test_gusto_ssm_three_cost_outputs_follow_the_oracle(qp, monkeypatch):
+    """The cost of the reference's SSM hardware driver weighs THREE outputs (examples/hardware/diamond_SSM.py:322-326): no p_o = 2 output
+    space for the lean one-wave interior point.  `dense`: the QP in the space of the inputs on one wave (csrc/locp_dense_u.h: N n_u <= 16);
+    `fused`: qp::solve (SRH_GUSTO_SSM_NO_DENSE=1).  n_x = 6, n_u = 4, N = 3, U box, up to 4 SCP iterations: iteration counts, (J, delta,
+    omega) trace and trajectories of oracle.gusto.solve_generic; with the solver state kept between solves the second solve of the same
+    problem returns the same plan."""
+    from sofacontrol_amd.scp.models.ssm import SSMGuSTO
+    from sofacontrol_amd.scp.gusto import GuSTO
+    from sofacontrol_amd.utils import HyperRectangle
+    if qp == 'fused':
+        monkeypatch.setenv('SRH_GUSTO_SSM_NO_DENSE', '1')
+    n, m, N, dt = 6, 4, 3, 0.02
+    model = ossm.synthetic(n, m, 3, 2, seed=96)
+    s = product_ssm(model, discr='be')
+    gm = SSMGuSTO(s)
+    rng = np.random.default_rng(5)
+    x0 = 0.05 * rng.standard_normal(n)
+    u_init = np.zeros((N, m))
+    x_init, _ = s.rollout(x0, u_init, dt)
+    Qz = np.zeros((n, n)); Qz[0, 0] = Qz[1, 1] = Qz[2, 2] = 100.0
+    R = 1e-3 * np.eye(m)
+    z = np.tile(ossm.observe(model, x0) + np.array([0.02, -0.01, 0.015, 0, 0, 0]), (N + 1, 1))
+    U = HyperRectangle([3.0] * m, [-1.0] * m)
+    g = GuSTO(gm, N, dt, Qz, R, x0, u_init, x_init, z=z, U=U, verbose=0, max_gusto_iters=4, convg_thresh=1e-5, keep_solver_state=True)
+    assert g._ssm and g.solver_state_kept
+    xo, uo, _, tr = ogusto.solve_generic(lambda x, u: ossm.jacobians(model, x, u, dt, 'be'),
+                                         lambda x, u: (lambda A, B, d: (A @ x + B @ u + d, A, B))(*ossm.continuous_jacobians(model, x, u)),
+                                         np.zeros((n, n)), N, dt, Qz, R, x0, u_init, x_init, z=z, U=(U.A, U.b),
+                                         obs_lin=lambda x: ossm.observer_jacobians(model, x), convg_thresh=1e-5, max_gusto_iters=4)
+    assert len(tr) == int(g.iters[0])
+    close(g.xopt, xo, 1e-6); close(g.uopt, uo, 1e-5)
+    close(g.trace[0, :len(tr), :3], np.asarray(tr)[:, :3], 1e-6)
+    first = (g.xopt.copy(), g.uopt.copy(), int(g.iters[0]))
+    g.solve(x0, u_init, x_init, z, None, None)              # warm: first QP from the previous solve's minimiser and multipliers
+    assert int(g.iters[0]) == first[2]
+    close(g.xopt, first[0], 1e-7); close(g.uopt, first[1], 1e-6)
+
+
 def test_gusto_ssm_real_time_iteration_device_equals_host_loop(monkeypatch):
     """The reference's hardware loop (examples/hardware/diamond_SSM.py:353-361: n_x = 6, n_u = 4, N = 3, dt = 0.02,
     max_gusto_iters = 0 -- one QP per call) on the device path and on the host loop: same plans over a sequence of receding-horizon

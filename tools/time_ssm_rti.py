@@ -35,12 +35,14 @@ s6 = SSMDynamics(mdl['z_ref'].copy(), discrete=False, discr_method='be',
                  params=dict(state_dim=sc(n6), input_dim=sc(m4), output_dim=sc(n6), SSM_order=sc(2), ROM_order=sc(3)))
 gm6 = SSMGuSTO(s6)
 Qz6 = np.zeros((n6, n6)); Qz6[0, 0] = Qz6[1, 1] = 100.0
+if '--three' in sys.argv:          # the driver's own cost: x, y, z of the end effector (examples/hardware/diamond_SSM.py:322-326)
+    Qz6[2, 2] = 100.0
 R6 = 0.003 * np.eye(m4)
 U = HyperRectangle([1500.0] * m4, [0.0] * m4)
 x06 = np.zeros(n6)
 u6 = np.zeros((N3, m4))
 xi6, _ = s6.rollout(x06, u6, dt2)
-z6 = np.tile(np.array([0.02, -0.01, 0, 0, 0, 0.0]), (N3 + 1, 1))
+z6 = np.tile(np.array([0.02, -0.01, 0.015 if '--three' in sys.argv else 0.0, 0, 0, 0.0]), (N3 + 1, 1))
 KEEP = '--keep' in sys.argv          # keep_solver_state=True: the reference's warm_start semantics across calls
 if B == 1:
     g6 = GuSTO(gm6, N3, dt2, Qz6, R6, x06, u6, xi6, z=z6, U=U, verbose=0, max_gusto_iters=0, convg_thresh=1e-3, keep_solver_state=KEEP)
