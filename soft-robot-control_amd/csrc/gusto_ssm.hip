@@ -73,11 +73,138 @@ __host__ __device__ inline size_t ssm_gusto_scratch_doubles(const SsmDev &S) {
     return ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns) + 2 * (n + m) + 2 * (n * n + n * m + n) + 2 * no + no * n + 8;
 }
 
+// The model's maps for ONE WAVE (lanes 0..63, tables in LDS, no workgroup barrier): the N linearisations and N + 1 observer linearisations of a
+// trajectory are independent of each other and each is far too small for a workgroup (n = 6: 36 Jacobian entries over 83 monomials), so
+// every wave takes one of them -- ssm_dev.h's workgroup forms cost ~25 barriers per stage, taken one stage after the other.  Same formulas
+// as ssm::basis_l / jacobians_l / discretize / observe; sums over the monomials in another split (rounding-level differences).
+namespace ssmw {
+__device__ __forceinline__ void fence() { ql::wave_fence(); }
+__device__ inline void basis(const liptr ex, const liptr par, const liptr var, const liptr dm, const int *lv, int order, int nmon, int dim,
+                             clptr x, lptr phi, lptr D, int lane) {
+    for (int dg = 0; dg < order; ++dg) {
+        for (int j = lv[dg] + lane; j < lv[dg + 1]; j += 64) { const int pj = par[j]; phi[j] = (pj < 0 ? 1.0 : phi[pj]) * x[var[j]]; }
+        fence();
+    }
+    if (D != nullptr) {
+        for (int e = lane; e < nmon * dim; e += 64) { const int qd = dm[e]; D[e] = qd == -1 ? 0.0 : (double)ex[e] * (qd >= 0 ? phi[qd] : 1.0); }
+        fence();
+    }
+}
+// continuous (A, B, d) of f = R phi(x) + B u at (x, u); w.f = f(x, u)
+__device__ inline void jacobians(const SsmDev &S, const SsmLds &T, clptr x, clptr u, ssm::Work &w, lptr A, lptr Bm, lptr d, int lane) {
+    const int n = S.n, m = S.m, nr = S.nr;
+    basis(T.er, T.pr, T.vr, T.dmr, T.lvr, S.order_r, nr, n, x, w.phi, w.D, lane);
+    const int g4 = lane & 3;
+    for (int o0 = 0; o0 < n * (n + 1); o0 += 16) {
+        const int o = o0 + (lane >> 2);
+        const bool live = o < n * (n + 1);
+        const int i = live ? o / (n + 1) : 0, j = live ? o - i * (n + 1) : 0;
+        double acc = 0.0;
+        if (live) {
+            clptr r = T.R + (size_t)i * nr;
+            clptr bb = j < n ? w.D + j : w.phi;
+            const int bs = j < n ? n : 1;
+            for (int k = g4; k < nr; k += 4) acc = fma(r[k], bb[(size_t)k * bs], acc);
+        }
+        acc = wg::group_sum<4>(acc);
+        if (g4 == 0 && live) { if (j < n) A[i * n + j] = acc; else w.f[i] = acc; }
+    }
+    for (int e = lane; e < n * m; e += 64) Bm[e] = T.Bg[e];
+    fence();
+    for (int i = lane; i < n; i += 64) {
+        double ax = 0.0, bu = 0.0;
+        for (int k = 0; k < n; ++k) ax = fma(A[i * n + k], x[k], ax);
+        for (int k = 0; k < m; ++k) bu = fma(T.Bg[i * m + k], u[k], bu);
+        const double f = w.f[i] + bu;
+        d[i] = f - ax - bu;
+        w.f[i] = f;
+    }
+    fence();
+}
+// (A, B, d) continuous -> discrete, in place (ssm.py:279-301; ssm::discretize)
+__device__ inline void discretize(const SsmDev &S, int mode, double dt, ssm::Work &w, lptr A, lptr Bm, lptr d, int lane) {
+    const int n = S.n, m = S.m;
+    if (mode == SSM_CONT || mode == SSM_DISCRETE_MAP) return;
+    if (mode == SSM_FE) {
+        for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e % n; A[e] = (i == j ? 1.0 : 0.0) + dt * A[e]; }
+        for (int e = lane; e < n * m; e += 64) Bm[e] = dt * Bm[e];
+        for (int e = lane; e < n; e += 64) d[e] = dt * d[e];
+        fence();
+        return;
+    }
+    const int ld = n | 1;
+    const double h = mode == SSM_BE ? dt : 0.5 * dt;
+    for (int e = lane; e < n * n; e += 64) {
+        const int i = e / n, j = e % n;
+        w.M1[i * ld + j] = (i == j ? 1.0 : 0.0) - h * A[e];
+        w.M3[i * ld + j] = A[e];
+    }
+    fence();
+    ssm::inverse_wave(w.M1, w.M2, n, ld);
+    ssm::inverse_wave(w.M3, w.M4, n, ld);
+    fence();
+    if (mode == SSM_BIL) {
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e % n;
+            double sacc = 0.0;
+            for (int k = 0; k < n; ++k) sacc = fma((i == k ? 1.0 : 0.0) + h * A[i * n + k], w.M2[k * ld + j], sacc);
+            w.M1[i * ld + j] = sacc;
+        }
+        fence();
+        for (int e = lane; e < n * n; e += 64) w.M2[(e / n) * ld + e % n] = w.M1[(e / n) * ld + e % n];
+        fence();
+    }
+    for (int e = lane; e < n * n; e += 64) {                      // M3 = sep = inv(A_c) (A_d - I)
+        const int i = e / n, j = e % n;
+        double sacc = 0.0;
+        for (int k = 0; k < n; ++k) sacc = fma(w.M4[i * ld + k], w.M2[k * ld + j] - (k == j ? 1.0 : 0.0), sacc);
+        w.M3[i * ld + j] = sacc;
+    }
+    fence();
+    for (int e = lane; e < n * n; e += 64) A[e] = w.M2[(e / n) * ld + e % n];
+    for (int i = lane; i < n; i += 64) {
+        double sacc = 0.0;
+        for (int k = 0; k < n; ++k) sacc = fma(w.M3[i * ld + k], d[k], sacc);
+        w.f[i] = sacc;
+    }
+    for (int e = lane; e < n * m; e += 64) {
+        const int i = e / m, j = e % m;
+        double sacc = 0.0;
+        for (int k = 0; k < n; ++k) sacc = fma(w.M3[i * ld + k], Bm[k * m + j], sacc);
+        w.M1[i * ld + j] = sacc;
+    }
+    fence();
+    for (int e = lane; e < n * m; e += 64) Bm[e] = w.M1[(e / m) * ld + e % m];
+    for (int e = lane; e < n; e += 64) d[e] = w.f[e];
+    fence();
+}
+// z = C(x), H = dC/dx (no x n), c = z - H x  (ssm.py:220-235)
+__device__ inline void observe(const SsmDev &S, const SsmLds &T, clptr x, ssm::Work &w, lptr z, lptr Hj, lptr cc, int lane) {
+    const int n = S.n, ns = S.ns, no = S.no;
+    basis(T.es, T.ps, T.vs, T.dms, T.lvs, S.order_s, ns, no, x, w.phi, w.D, lane);
+    for (int e = lane; e < no * (n + 1); e += 64) {
+        const int i = e / (n + 1), j = e - i * (n + 1);
+        clptr wr = T.W + (size_t)i * ns;
+        double acc = 0.0;
+        if (j < n) for (int k = 0; k < ns; ++k) acc = fma(wr[k], w.D[(size_t)k * no + j], acc);
+        else for (int k = 0; k < ns; ++k) acc = fma(wr[k], w.phi[k], acc);
+        if (j < n) Hj[i * n + j] = acc; else z[i] = acc;
+    }
+    fence();
+    for (int i = lane; i < no; i += 64) {
+        double sx = 0.0;
+        for (int k = 0; k < n; ++k) sx = fma(Hj[i * n + k], x[k], sx);
+        cc[i] = z[i] - sx;
+    }
+    fence();
+}
+}  // namespace ssmw
+
 // GXL > 0: the QP without its trust-region rows runs on the lean one-wave interior point first (ql::ipm_wave: K is one 16 x 16 tile at the
 // driver's N = 3, 31 k clocks per interior-point iteration against 70 k of the eight-wave forms -- DESIGN.md section 13); qp::solve takes over
 // when that minimiser leaves the trust region or the interior point does not converge.  GXL = lanes per stage for the state rows (ql::ipm_box).
 template <bool SPLIT, int MSEL, int GXL>
-__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off, int tab_off, int dense_u) {
+__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off, int tab_off, int dense_u, int task_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     qp::specialise<MSEL, 0>(d);
     long long prof[32] = {0};
@@ -146,7 +273,84 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
     __syncthreads();
 
     // (A, B, d)_k and (H, c)_k of the trajectory (xk, uk) -> the augmented per-stage matrices of the QP, both orientations
+    // task t < N: linearisation of stage t; task N + k: observer linearisation at xbar_k (k = 0..N).  Scratch of task t at smem + t * task_stride:
+    // [ssm::Work | x (n) | u (m) | LIN: A (n n), B (n m), d (n)  /  OBS: H (no n), c (no), z (no)]
+    const size_t wdb = ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns);
+    auto task_base = [&](int t) { return (lptr)smem + (size_t)t * task_stride; };
+    auto linearise_par = [&]() {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nt >> 6, lane = tid & 63;
+        const int ntask = no > 0 ? 2 * N + 1 : N;
+        for (int t = wave; t < ntask; t += nwv) {
+            lptr tb = task_base(t);
+            ssm::Work tw;
+            ssm::carve(tw, tb, S);
+            lptr tx = tb + wdb, tu = tx + n, r0 = tu + m;
+            if (t < N) {
+                for (int e = lane; e < n; e += 64) tx[e] = xk[(size_t)t * n + e];
+                for (int e = lane; e < m; e += 64) tu[e] = uk[(size_t)t * m + e];
+                ssmw::fence();
+                lptr tA = r0, tB = tA + (size_t)n * n, td = tB + (size_t)n * m;
+                ssmw::jacobians(S, T, tx, tu, tw, tA, tB, td, lane);
+                for (int e = lane; e < n * n; e += 64) Acg[(size_t)t * n * n + e] = tA[e];
+                for (int e = lane; e < n; e += 64) fkg[(size_t)t * n + e] = tw.f[e];
+                ssmw::fence();
+                ssmw::discretize(S, b.mode, par.dt, tw, tA, tB, td, lane);
+            } else {
+                const int k = t - N;
+                for (int e = lane; e < n; e += 64) tx[e] = xk[(size_t)k * n + e];
+                ssmw::fence();
+                lptr tH = r0, tc = tH + (size_t)S.no * n, tz = tc + S.no;
+                ssmw::observe(S, T, tx, tw, tz, tH, tc, lane);
+            }
+        }
+        __syncthreads();
+        // the augmented stage matrices from the tasks' results
+        auto Hof = [&](int k) { return task_base(N + k) + wdb + n + m; };                    // H_k; c_k behind it
+        for (int e = tid; e < na; e += nt) {
+            double v0, vk;
+            if (e < n) { v0 = x0[e]; vk = xk[e]; }
+            else {
+                clptr H0 = Hof(0), c0 = H0 + (size_t)S.no * n;
+                v0 = c0[e - n]; vk = c0[e - n];
+                for (int j = 0; j < n; ++j) { v0 = fma(H0[(e - n) * n + j], x0[j], v0); vk = fma(H0[(e - n) * n + j], xk[j], vk); }
+            }
+            x0a[e] = v0; xka[e] = vk;
+        }
+        for (int e = tid; e < N * na * na; e += nt) {
+            const int k = e / (na * na), r = e - k * na * na, i = r / na, j = r - i * na;
+            clptr tA = task_base(k) + wdb + n + m;
+            double v = 0.0;
+            if (j < n) {
+                if (i < n) v = tA[i * n + j];
+                else { clptr Hn = Hof(k + 1); for (int l = 0; l < n; ++l) v = fma(Hn[(i - n) * n + l], tA[l * n + j], v); }
+            }
+            Ag[e] = v; ATg[(size_t)k * na * na + (size_t)j * na + i] = v;
+        }
+        for (int e = tid; e < N * na * m; e += nt) {
+            const int k = e / (na * m), r = e - k * na * m, i = r / m, j = r - i * m;
+            clptr tB = task_base(k) + wdb + n + m + (size_t)n * n;
+            double v = 0.0;
+            if (i < n) v = tB[i * m + j];
+            else { clptr Hn = Hof(k + 1); for (int l = 0; l < n; ++l) v = fma(Hn[(i - n) * n + l], tB[l * m + j], v); }
+            Bg[e] = v; BTg[(size_t)k * na * m + (size_t)j * na + i] = v;
+        }
+        for (int e = tid; e < N * na; e += nt) {
+            const int k = e / na, i = e - k * na;
+            clptr td = task_base(k) + wdb + n + m + (size_t)n * n + (size_t)n * m;
+            double v, xv;
+            if (i < n) { v = td[i]; xv = xk[(size_t)(k + 1) * n + i]; }
+            else {
+                clptr Hn = Hof(k + 1), cn = Hn + (size_t)S.no * n;
+                v = cn[i - n]; xv = cn[i - n];
+                for (int l = 0; l < n; ++l) { v = fma(Hn[(i - n) * n + l], td[l], v); xv = fma(Hn[(i - n) * n + l], xk[(size_t)(k + 1) * n + l], xv); }
+            }
+            ddg[e] = v;
+            xka[(size_t)(k + 1) * na + i] = xv;
+        }
+        __syncthreads();
+    };
     auto linearise_all = [&]() {
+        if (tab && task_stride > 0) { linearise_par(); return; }
         if (no > 0) {
             for (int e = tid; e < n; e += nt) xs[e] = xk[e];
             __syncthreads();
@@ -284,7 +488,39 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
         const double d_cur = delta, o_cur = omega;
         if (tr_ok) {
             // model accuracy (gusto.py:203-223): f = A x + B u + d with the CONTINUOUS Jacobians at each point (models/ssm.py:35-54)
-            for (int i = 0; i < N; ++i) {
+            if (tab && task_stride > 0) {
+                // one wave per stage: monomials at the new point, f = R phi + B u on one lane per row, against the stored (A, B, f) of the old point
+                const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nt >> 6, lane = tid & 63;
+                for (int i = wave; i < N; i += nwv) {
+                    lptr tb = task_base(i);
+                    ssm::Work tw;
+                    ssm::carve(tw, tb, S);
+                    lptr txo = tb + wdb, tuo = txo + n, txn = tuo + m, tun = txn + n;
+                    for (int e = lane; e < n; e += 64) { txo[e] = xk[(size_t)i * n + e]; txn[e] = w.x[(size_t)i * na + e]; }
+                    for (int e = lane; e < m; e += 64) { tuo[e] = uk[(size_t)i * m + e]; tun[e] = w.u[(size_t)i * m + e]; }
+                    ssmw::fence();
+                    ssmw::basis(T.er, T.pr, T.vr, T.dmr, T.lvr, S.order_r, S.nr, n, txn, tw.phi, (lptr) nullptr, lane);
+                    double de = 0.0, da = 0.0;
+                    if (lane < n) {
+                        const int r = lane;
+                        clptr rr = T.R + (size_t)r * S.nr;
+                        double f0 = 0.0, f1 = 0.0, fl = 0.0;
+                        int k = 0;
+                        for (; k + 1 < S.nr; k += 2) { f0 = fma(rr[k], tw.phi[k], f0); f1 = fma(rr[k + 1], tw.phi[k + 1], f1); }
+                        if (k < S.nr) f0 = fma(rr[k], tw.phi[k], f0);
+                        double bf = 0.0, bl = 0.0;
+                        for (int j = 0; j < m; ++j) { bf = fma(T.Bg[r * m + j], tun[j], bf); bl = fma(T.Bg[r * m + j], tun[j] - tuo[j], bl); }
+                        for (int j = 0; j < n; ++j) fl = fma(Acg[(size_t)i * n * n + r * n + j], txn[j] - txo[j], fl);
+                        const double fv = (f0 + f1) + bf, fa = fkg[(size_t)i * n + r] + fl + bl;
+                        const double fsr = b.fs[r];
+                        de = fsr * (fv - fa); da = fsr * fa;
+                    }
+                    const double e2 = wg::wave_sum(de * de), a2 = wg::wave_sum(da * da);
+                    if (lane == 0) { accb[2 * i] = par.dt * sqrt(e2); accb[2 * i + 1] = par.dt * sqrt(a2); }
+                }
+                __syncthreads();
+            }
+            for (int i = (tab && task_stride > 0) ? N : 0; i < N; ++i) {
                 for (int e = tid; e < n; e += nt) { xs[e] = xk[(size_t)i * n + e]; x2[e] = w.x[(size_t)i * na + e]; }
                 for (int e = tid; e < m; e += nt) { us[e] = uk[(size_t)i * m + e]; u2[e] = w.u[(size_t)i * m + e]; }
                 __syncthreads();
@@ -433,6 +669,7 @@ struct sgusto_ssm_plan {
     int red_off = 0, tab_off = 0;       // (doubles) reduction scratch / model tables behind the aliased layouts (tab_off = 0: tables stay in L2)
     int lean_gx = 0;                    // > 0: the lean one-wave interior point runs first (template argument GXL of the kernel)
     int dense_u = 0;                    // 1: the dense one-wave QP in the space of the inputs runs first (N n_u <= 16: qdu::solve)
+    int task_stride = 0;                // > 0 (doubles): one wave per linearisation task, each with its own LDS scratch of this size
     char *pin = nullptr;                // one pinned, device-visible block: [inputs | outputs]
     size_t pin_bytes = 0;
     bool solved = false;
@@ -459,7 +696,7 @@ int ssm_gusto_launch(sgusto_ssm_plan *pl, const SsmGustoBatch &b, hipStream_t st
     bool launched = false;
 #define X(SP, M, GX) if (!launched && (d.split != 0) == SP && (M == 0 || d.m == M) && pl->lean_gx == GX) { \
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_ssm_kernel<SP, M, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds)); \
-        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off, pl->tab_off, pl->dense_u); launched = true; }
+        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off, pl->tab_off, pl->dense_u, pl->task_stride); launched = true; }
     X(false, 4, 1) X(false, 4, 2) X(false, 8, 1) X(false, 4, 0) X(false, 8, 0) X(false, 0, 0) X(true, 0, 0)
 #undef X
     SRH_REQUIRE(launched, "sgusto_ssm: no kernel variant");
@@ -521,6 +758,20 @@ int sgusto_ssm_plan_create(sgusto_ssm_plan_t **out, sssm_t *model, const slocp_p
     size_t total = body + 16 * sizeof(double);
     const size_t tabs = (ssm::lds_tab_doubles(S.n, S.no, S.nr, S.ns, 0) + 8) * sizeof(double);
     if (mode != SSM_DISCRETE_MAP && model->n <= 64 && total + tabs <= (size_t)160 * 1024 && !getenv("SRH_GUSTO_SSM_NO_TABLES")) {
+        // one wave per linearisation task when 2 N + 1 scratch areas fit in front of the tables (they alias the QP's layouts like the rest)
+        const size_t nn = model->n, mm = model->m, noo = model->no;
+        size_t stride = ssm::work_doubles(S.n, S.m, S.no, S.nr, S.ns) + 2 * (nn + mm) + std::max(nn * nn + nn * mm + nn, noo * nn + 2 * noo) + 4;
+        stride = (stride + 3) & ~(size_t)3;
+        const size_t ntask = d.n > model->n ? 2 * (size_t)d.N + 1 : (size_t)d.N;
+        size_t need = ntask * stride * sizeof(double);
+        if (!getenv("SRH_GUSTO_SSM_SERIAL_LIN") && std::max(total, need + 16 * sizeof(double)) + tabs <= (size_t)160 * 1024) {
+            pl->task_stride = (int)stride;
+            if (need + 16 * sizeof(double) > total) {
+                const size_t body2 = (need + 15) & ~(size_t)15;
+                pl->red_off = (int)(body2 / sizeof(double));
+                total = body2 + 16 * sizeof(double);
+            }
+        }
         pl->tab_off = (int)(total / sizeof(double));
         total += tabs;
     }
