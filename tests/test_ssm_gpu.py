@@ -173,6 +173,39 @@ def test_gusto_ssm_three_cost_outputs_follow_the_oracle(qp, monkeypatch):
     close(g.xopt, first[0], 1e-7); close(g.uopt, first[1], 1e-6)
 
 
+def test_gusto_ssm_without_inequality_rows(monkeypatch):
+    """No U, no X: the QP of every SCP iteration is an equality-constrained least-squares problem -- the one-wave QP in the space of the
+    inputs returns its unit-weight Newton point (no interior-point iteration), the fused path the same; both equal the oracle."""
+    from sofacontrol_amd.scp.models.ssm import SSMGuSTO
+    from sofacontrol_amd.scp.gusto import GuSTO
+    n, m, N, dt = 6, 4, 3, 0.02
+    model = ossm.synthetic(n, m, 3, 2, seed=96)
+    rng = np.random.default_rng(8)
+    x0 = 0.05 * rng.standard_normal(n)
+    u_init = np.zeros((N, m))
+    Qz = np.zeros((n, n)); Qz[0, 0] = Qz[1, 1] = Qz[2, 2] = 100.0
+    R = 1e-2 * np.eye(m)
+    res = {}
+    for qp in ('dense', 'fused'):
+        if qp == 'fused':
+            monkeypatch.setenv('SRH_GUSTO_SSM_NO_DENSE', '1')
+        s = product_ssm(model, discr='be')
+        gm = SSMGuSTO(s)
+        x_init, _ = s.rollout(x0, u_init, dt)
+        z = np.tile(ossm.observe(model, x0) + np.array([0.01, -0.01, 0.005, 0, 0, 0]), (N + 1, 1))
+        g = GuSTO(gm, N, dt, Qz, R, x0, u_init, x_init, z=z, verbose=0, max_gusto_iters=3, convg_thresh=1e-6)
+        assert g._ssm
+        res[qp] = (g.xopt.copy(), g.uopt.copy(), int(g.iters[0]))
+    monkeypatch.delenv('SRH_GUSTO_SSM_NO_DENSE', raising=False)
+    xo, uo, _, tr = ogusto.solve_generic(lambda x, u: ossm.jacobians(model, x, u, dt, 'be'),
+                                         lambda x, u: (lambda A, B, d: (A @ x + B @ u + d, A, B))(*ossm.continuous_jacobians(model, x, u)),
+                                         np.zeros((n, n)), N, dt, Qz, R, x0, u_init, x_init, z=z,
+                                         obs_lin=lambda x: ossm.observer_jacobians(model, x), convg_thresh=1e-6, max_gusto_iters=3)
+    for qp in ('dense', 'fused'):
+        assert res[qp][2] == len(tr), (qp, res[qp][2], len(tr))
+        close(res[qp][0], xo, 1e-6); close(res[qp][1], uo, 1e-5)
+
+
 def test_gusto_ssm_real_time_iteration_device_equals_host_loop(monkeypatch):
     """The reference's hardware loop (examples/hardware/diamond_SSM.py:353-361: n_x = 6, n_u = 4, N = 3, dt = 0.02,
     max_gusto_iters = 0 -- one QP per call) on the device path and on the host loop: same plans over a sequence of receding-horizon
