@@ -1113,7 +1113,10 @@ def main():
     torch.cuda.init()
     if world > 1 or os.environ.get('SRH_FORCE_DIST') == '1':
         import torch.distributed as dist
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        try:        # bind the process group to this rank's GPU (no device guessing from the global rank in barrier / the first collective)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        except TypeError:
+            dist.init_process_group('nccl', rank=rank, world_size=world)
 
     import workloads as wl
     from sofacontrol_amd import _lib
