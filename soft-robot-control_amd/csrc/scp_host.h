@@ -440,7 +440,7 @@ inline size_t qp_kernel_lds_bytes(const QPDims &d) {
     return srh::lds_request(std::max(a, b));
 }
 inline size_t lean_kernel_lds_bytes(const QPDims &d) {
-    if (d.lean_half) return ql::lds_doubles(d, 256, d.lean_j0) * sizeof(double);       // (<= 80 KB by construction: a multiple of 32 bytes, two per CU)
+    if (d.lean_half) return srh::lds_request(ql::lds_doubles(d, 256, d.lean_j0) * sizeof(double));     // (<= 80 KB by construction; whole allocation granules: 81 920 B, two per CU)
     return srh::lds_request(ql::lds_doubles(d, NTHREADS, d.lean_j0) * sizeof(double));
 }
 
