@@ -390,7 +390,8 @@ int build_consts(const slocp_problem *pr, QPConstHost &C, bool want_half = false
             if (const char *eh = getenv("SRH_LEAN_HALF")) want_half = atoi(eh) != 0;
             // (only the shapes lean.hip instantiates the half-size kernels for: BASELINE C2 -- Diamond r = 30, N = 50, U box, 4 state rows)
             const bool half_shape = m == 4 && n == 60 && N == 50 && pr->nX == 4 && pr->nXf == 0 && pr->n_z == 6 && d.po == 2;
-            if (want_half && half_shape && j0 >= 0 && j0 < N && pr->nU == 2 * m) {
+            // (the half-size kernels exist as fixed-layout instantiations only: SRH_LEAN_NO_FIXED=1 rules them out with the other fixed layouts)
+            if (want_half && half_shape && getenv("SRH_LEAN_NO_FIXED") == nullptr && j0 >= 0 && j0 < N && pr->nU == 2 * m) {
                 QPDims dh = d;
                 dh.lean_half = 1; dh.lean_j0 = N;
                 const int RXh = pr->nX + pr->nXf, GXh = RXh == 0 ? 1 : (RXh <= 2 ? 2 : (RXh <= 4 ? 4 : 8));
