@@ -1254,10 +1254,54 @@ def main():
             horizons = scp_reference_horizons() if rank == 0 else None
         except Exception as exc:
             cl, single, horizons = {'error': repr(exc)}, None, None
+        layout_ab = None
+        if rank == 0 and world == 1:
+            # the SCP launch of the timed step with the OTHER lean layout (SRH_LEAN_HALF read at plan creation): the full-size workgroup
+            # (512 threads, 160 KB, one rollout per CU) beside the half-size one the plan picks for batches above the CU count
+            try:
+                def scp_ms(plan, reps=3):
+                    ts = []
+                    for _ in range(reps):
+                        _lib.sync()
+                        t0 = time.perf_counter()
+                        _lib.check(L.sgusto_plan_solve_dev(plan, d['x0'].ptr, d['u_init'].ptr, d['x_init'].ptr, d['z'].ptr, None, None,
+                                                           o['xopt'].ptr, o['uopt'].ptr, o['zopt'].ptr, o['iters'].ptr, o['status'].ptr, None, None), 'gusto')
+                        _lib.sync()
+                        ts.append(time.perf_counter() - t0)
+                    return min(ts[1:]) * 1e3
+                ms_this = scp_ms(gusto.plan)
+                it_this = int(o['iters'].to_array((R_,), dtype=np.int32).sum())
+                prev = os.environ.get('SRH_LEAN_HALF')
+                other_half = 0 if kinfo['lean'] and kinfo['lean'][3] == kinfo['lean'][4] else 1
+                os.environ['SRH_LEAN_HALF'] = str(other_half)
+                try:
+                    g2 = GuSTO(gm, N, dt, w['Qz'], w['R'], x0, u_init, x_init, z=z, U=Polyhedron(w['UA'], w['Ub']), X=Polyhedron(w['XA'], w['Xb']),
+                               x_char=xc, f_char=fc, convg_thresh=1e-3, batch=R_, max_trace=0, max_gusto_iters=args.max_gusto_iters,
+                               first_solve_cap=args.max_gusto_iters)
+                finally:
+                    if prev is None:
+                        os.environ.pop('SRH_LEAN_HALF', None)
+                    else:
+                        os.environ['SRH_LEAN_HALF'] = prev
+                ms_other = scp_ms(g2.plan)
+                it_other = int(o['iters'].to_array((R_,), dtype=np.int32).sum())
+                k2 = g2.kernel_info
+                layout_ab = {'what': 'sgusto_plan_solve_dev of the %d rollouts alone (no projection), best of 2 after a warm-up call, same inputs: the layout the '
+                                     'plan picked against the other one' % R_,
+                             'picked': {'kernel': kinfo['kernel'], 'threads': kinfo.get('threads'), 'lds_bytes': kinfo.get('lds_bytes_lean'), 'ms': ms_this,
+                                        'scp_iterations_per_s': it_this / (ms_this * 1e-3)},
+                             'other': {'kernel': k2['kernel'], 'threads': k2.get('threads'), 'lds_bytes': k2.get('lds_bytes_lean'), 'ms': ms_other,
+                                       'scp_iterations_per_s': it_other / (ms_other * 1e-3)},
+                             'scp_iterations_equal': bool(it_this == it_other), 'picked_over_other': ms_other / ms_this}
+                del g2
+            except Exception as exc:
+                layout_ab = {'error': repr(exc)}
         for b in list(d.values()) + list(o.values()) + [dX, dXr]:
             b.free()
         try:
             sec = secondary(L, _lib, rank, world, dist)
+            if layout_ab is not None:
+                sec['scp_lean_layout_ab'] = layout_ab
             if cl is not None:
                 sec['closed_loop_step'] = cl
             if single is not None:
