@@ -156,3 +156,27 @@ def test_bench_two_ranks_exit_code_when_a_rank_dies():
     out = _run_stub({'SRH_BENCH_STUB_FAIL_RANK': '1'}, timeout=200)
     assert out.returncode != 0
     assert not [l for l in out.stdout.strip().splitlines() if l.startswith('{"stub"')]
+
+
+def test_compact_line_without_a_cpu_leg_and_with_failed_legs():
+    """The driver's line of a multi-GPU run has no cpu_baseline / parity_sample (rank 0 at N = 1 only), a failed CPU leg is reported as a
+    short error -- and whatever a secondary grew into never reaches the line."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.loads([l for l in open(os.path.join(ROOT, 'profiles', 'r05_bench.log')) if l.startswith('{"metric"')][-1])
+    multi = {k: v for k, v in rec.items() if k not in ('cpu_baseline', 'parity_sample')}
+    multi.update(n_gpus=8, vs_baseline=None, secondary={'blob': 'x' * 100000})
+    d = json.loads(bench.compact_line(multi))
+    assert 'cpu_baseline' not in d and 'parity_sample' not in d and 'secondary' not in d and 'vs_baseline_definition' not in d
+    assert d['n_gpus'] == 8 and d['roofline']['frac'] > 0 and d['config']['workload']
+    failed = dict(rec, cpu_baseline={'error': 'RuntimeError(' + 'y' * 5000 + ')'})
+    text = bench.compact_line(failed)
+    assert len(text) < bench.MAX_LINE and len(json.loads(text)['cpu_baseline']['error']) <= 300
+    # a workload description that outgrows the budget sheds the optional parts, never a contract key
+    fat = dict(rec)
+    fat['config'] = dict(rec['config'], workload='w' * 2500)
+    d = json.loads(bench.compact_line(fat))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
