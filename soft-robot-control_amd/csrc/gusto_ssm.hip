@@ -428,6 +428,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
     // warm_start=True keeps its solver state between solves, locp.py:181) of the rollout's previous solve
     bool have_warm = (GXL > 0 || dense_u) && par.warm_across != 0 && rec[0] == 1.0;
     gptr lamd = base + gw.lamd;
+    double qdbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};              // phase clocks of the last dense one-wave QP (SRH_GUSTO_TRACE_QIT=1: trace row 1)
     double delta = par.delta0, omega = par.omega0;
     double J_prev = INFINITY, d_prev = INFINITY, o_prev = INFINITY;
     bool converged = false, tr_hot = false;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
             // N n_u <= 16: the QP without its trust-region rows in the space of the inputs on one wave, whatever the cost's rank (locp_dense_u.h)
             for (int attempt = 0; attempt < 2; ++attempt) {
                 const bool warm = have_warm && attempt == 0;
-                st = qdu::solve(d, c, dyn, q, w, (lptr)smem, lamd, &J, &qit, warm ? 1 : 0);
+                st = qdu::solve(d, c, dyn, q, w, (lptr)smem, lamd, &J, &qit, warm ? 1 : 0, qdbg);
                 if (st == 0 || st == 100 || !warm) break;
             }
             have_warm = st == 0;
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c
             if (par.poison_warm & 2) {                     // debug (SRH_GUSTO_TRACE_QIT=1): shader clocks of the phases + interior-point iterations
                 lap_tests += clock64() - lap0;
                 tr[0] = (double)lap_lin; tr[1] = (double)lap_qp; tr[2] = (double)lap_tests; tr[3] = (double)(qit + 1000 * (qpass + 1));
+                if (par.max_trace >= 4) for (int i = 0; i < 10; ++i) tr[4 + i] = qdbg[i];     // rows 1..3 of the trace (a one-iteration solve leaves them free)
             }
         }
         tr_hot = on_boundary && !new_solution;

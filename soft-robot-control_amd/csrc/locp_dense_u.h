@@ -21,45 +21,73 @@ namespace qdu {
 constexpr int NU = 16;                 // inputs of the QP (N n_u <= 16): one tile
 constexpr int NYM = 48;                // N n_z <= 48
 constexpr int TS = qpc::TS;
+constexpr int CS = 17;                 // row stride of C in LDS (odd: lane = row reads without bank conflicts)
 
-__host__ __device__ inline bool applies(const QPDims &d) {
-    return d.N * d.m <= NU && d.N * d.nz <= NYM && d.N * (d.nU + d.nX) <= 64 && d.nXf == 0 && d.n <= 64 && d.N <= 8 && d.nz <= 16 && d.m <= 16;
+// LDS copies of the per-stage [A_k | B_k | d_k], of H and of X.A: the set-up's dot products would otherwise wait for L2 once per term
+__host__ __device__ inline size_t stage_doubles(const QPDims &d) {
+    return (size_t)d.N * d.n * (d.n + d.m + 1) + (size_t)d.nz * d.n + (size_t)d.nX * d.n;
 }
-// LDS doubles: S (2 x n x 16) | G (NYM x 16) | C (64 x 16) | Hq, M, Rinv tiles (3 x 16 x 17) | xf ((N + 1) n) | vectors
+__host__ __device__ inline bool applies(const QPDims &d) {
+    return d.N * d.m <= NU && d.N * d.nz <= NYM && d.N * (d.nU + d.nX) <= 64 && d.nXf == 0 && d.n <= 64 && d.N <= 8 && d.nz <= 16 && d.m <= 16 &&
+           stage_doubles(d) <= 6144;            // the stage matrices, H and X.A are staged in LDS (48 KB at most): small models
+}
+// LDS doubles: S (2 x n x 16) | G (NYM x 16) | C (64 x 17) | W = Qb G (NYM x 16) | Hq, M, Rinv tiles (3 x 16 x 17) | xf ((N + 1) n) | vectors
 __host__ __device__ inline size_t lds_doubles(const QPDims &d) {
-    return 2 * (size_t)d.n * 16 + (size_t)NYM * 16 + 64 * 16 + 3 * 16 * TS + (size_t)(d.N + 1) * d.n + NYM + 8 * 64 + 16;
+    return 2 * (size_t)d.n * 16 + 2 * (size_t)NYM * 16 + 64 * CS + 3 * 16 * TS + (size_t)(d.N + 1) * d.n + NYM + 8 * 64 + 16 + stage_doubles(d);
 }
 
 // returns 0: w.x / w.u hold the minimiser of the FULL QP (converged, inside the trust region), J_out its objective; 100: the minimiser of
 // the relaxed QP leaves the trust region; anything else: interior point not converged.  `lam` (64 doubles of the rollout's work block): the
 // multipliers of the last converged solve (warm != 0 starts from w.u and them).
 __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QPDyn &dyn, const QPData &q, QPWork &w, lptr lds, gptr lam,
-                                     double *J_out, int *it_out, int warm) {
+                                     double *J_out, int *it_out, int warm, double *dbg = nullptr) {
     const int tid = SRH_TID;
     const int N = d.N, n = d.n, m = d.m, nz = d.nz, nu = N * m, ny = N * nz, nrU = N * d.nU, nr = nrU + N * d.nX;
-    lptr Sa = lds, Sb = Sa + (size_t)n * 16, Gl = Sb + (size_t)n * 16, Cl = Gl + (size_t)NYM * 16, Hl = Cl + 64 * 16, Tl = Hl + 16 * TS,
-         Rl = Tl + 16 * TS, xf = Rl + 16 * TS, ey = xf + (size_t)(N + 1) * n, ul = ey + NYM, dul = ul + 64, rhs = dul + 64, tv = rhs + 64,
-         rhol = tv + 64, laml = rhol + 64, sdl = laml + 64, scl = sdl + 64, res = scl + 64;
+    // the arrays of the interior point first, at compile-time offsets from one base (one address register, the rest in the instructions'
+    // offset fields); the arrays whose size follows the model (set-up and tail only) behind them
+    lptr Gl = lds, Cl = Gl + NYM * 16, Hl = Cl + 64 * CS, Tl = Hl + 16 * TS, Rl = Tl + 16 * TS, ey = Rl + 16 * TS, ul = ey + NYM, dul = ul + 64,
+         rhs = dul + 64, tv = rhs + 64, rhol = tv + 64, laml = rhol + 64, sdl = laml + 64, scl = sdl + 64, res = scl + 64, Wl = res + 16;
+    lptr Sa = Wl + NYM * 16, Sb = Sa + (size_t)n * 16, xf = Sb + (size_t)n * 16;
+    lptr Asl = xf + (size_t)(N + 1) * n, Bsl = Asl + (size_t)N * n * n, dsl = Bsl + (size_t)N * n * m, Hsl = dsl + (size_t)N * n, Xsl = Hsl + (size_t)nz * n;
     int status = 1, it = 0;
     double Jv = 0.0;
+#ifndef QDU_CLOCKS
+#define QDU_CLOCKS 0                   // 1: phase clocks of the solve through res[4..13] / dbg (22 more scalar registers: a measuring build only)
+#endif
+#if QDU_CLOCKS
+    long long lp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lc = clock64();
+#define QDU_LAP(i) do { const long long now_ = clock64(); lp[i] += now_ - lc; lc = now_; } while (0)
+#else
+#define QDU_LAP(i) do { } while (0)
+#endif
     if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
         const int lane = tid, l16 = lane & 15, kk = lane >> 4;
         auto fence = [&]() { ql::wave_fence(); };
-        auto Ak = [&](int k) { return dyn.A + dyn.sel(k) * (size_t)n * n; };
-        auto Bk = [&](int k) { return dyn.B + dyn.sel(k) * (size_t)n * m; };
-        auto dk = [&](int k) { return dyn.d + dyn.sel(k) * (size_t)n; };
+        // the stage matrices, H and X.A into LDS (coalesced, all loads in flight at once)
+        for (int k = 0; k < N; ++k) {
+            cgptr Ag = dyn.A + dyn.sel(k) * (size_t)n * n, Bg = dyn.B + dyn.sel(k) * (size_t)n * m, dg = dyn.d + dyn.sel(k) * (size_t)n;
+            for (int e = lane; e < n * n; e += 64) Asl[(size_t)k * n * n + e] = Ag[e];
+            for (int e = lane; e < n * m; e += 64) Bsl[(size_t)k * n * m + e] = Bg[e];
+            for (int e = lane; e < n; e += 64) dsl[(size_t)k * n + e] = dg[e];
+        }
+        for (int e = lane; e < nz * n; e += 64) Hsl[e] = c.H[e];
+        for (int e = lane; e < d.nX * n; e += 64) Xsl[e] = c.XA[e];
+        auto Ak = [&](int k) { return (clptr)(Asl + (size_t)k * n * n); };
+        auto Bk = [&](int k) { return (clptr)(Bsl + (size_t)k * n * m); };
+        auto dk = [&](int k) { return (clptr)(dsl + (size_t)k * n); };
         // ---- free response xf_k (u = 0) and the sensitivities S_k = d x_k / d u (n x 16, column e = (stage j, input b)), stage by stage;
         //      G rows (k, a) = H S_k, state rows of stage k = X.A S_k
         for (int e = lane; e < n; e += 64) xf[e] = q.x0[e];
         for (int e = lane; e < n * 16; e += 64) Sa[e] = 0.0;
-        for (int e = lane; e < 64 * 16; e += 64) Cl[e] = 0.0;
+        for (int e = lane; e < 64 * CS; e += 64) Cl[e] = 0.0;
         for (int e = lane; e < NYM * 16; e += 64) Gl[e] = 0.0;
         fence();
         lptr Sc = Sa, Sn = Sb;
         for (int k = 0; k < N; ++k) {
-            cgptr A = Ak(k), B = Bk(k), dd = dk(k);
+            clptr A = Ak(k), B = Bk(k), dd = dk(k);
             for (int i = lane; i < n; i += 64) {
                 double v = dd[i];
+#pragma unroll 4
                 for (int j = 0; j < n; ++j) v = fma(A[(size_t)i * n + j], xf[(size_t)k * n + j], v);
                 xf[(size_t)(k + 1) * n + i] = v;
             }
@@ -67,6 +95,7 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             for (int i = kk; i < n; i += 4) {
                 double v = 0.0;
                 if (l16 < nu) {
+#pragma unroll 4
                     for (int j = 0; j < n; ++j) v = fma(A[(size_t)i * n + j], Sc[j * 16 + l16], v);
                     if (l16 / m == k) v += B[(size_t)i * m + (l16 - k * m)];
                 }
@@ -75,13 +104,15 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             fence();
             for (int a = kk; a < nz; a += 4) {                             // G rows of stage k + 1
                 double v = 0.0;
-                for (int j = 0; j < n; ++j) v = fma(c.H[(size_t)a * n + j], Sn[j * 16 + l16], v);
+#pragma unroll 4
+                for (int j = 0; j < n; ++j) v = fma(Hsl[(size_t)a * n + j], Sn[j * 16 + l16], v);
                 Gl[(k * nz + a) * 16 + l16] = v;
             }
             for (int r = kk; r < d.nX; r += 4) {                           // state rows of stage k + 1
                 double v = 0.0;
-                for (int j = 0; j < n; ++j) v = fma(c.XA[(size_t)r * n + j], Sn[j * 16 + l16], v);
-                Cl[(nrU + k * d.nX + r) * 16 + l16] = v;
+#pragma unroll 4
+                for (int j = 0; j < n; ++j) v = fma(Xsl[(size_t)r * n + j], Sn[j * 16 + l16], v);
+                Cl[(nrU + k * d.nX + r) * CS + l16] = v;
             }
             lptr t_ = Sc; Sc = Sn; Sn = t_;
             fence();
@@ -89,37 +120,36 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
         // input rows: U.A on the inputs of their stage
         for (int e = lane; e < nrU * 16; e += 64) {
             const int r = e >> 4, col = e & 15, k = r / d.nU, rr = r - k * d.nU;
-            Cl[e] = (col < nu && col / m == k) ? c.UA[(size_t)rr * m + (col - k * m)] : 0.0;
+            Cl[r * CS + col] = (col < nu && col / m == k) ? c.UA[(size_t)rr * m + (col - k * m)] : 0.0;
         }
         // output errors of the free response, e_y = H xf_k - z_k (k = 1..N), and the constant of the objective (k = 0)
         for (int e = lane; e < ny; e += 64) {
             const int k = e / nz + 1, a = e - (k - 1) * nz;
             double v = q.z ? -q.z[(size_t)k * nz + a] : 0.0;
-            for (int j = 0; j < n; ++j) v = fma(c.H[(size_t)a * n + j], xf[(size_t)k * n + j], v);
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) v = fma(Hsl[(size_t)a * n + j], xf[(size_t)k * n + j], v);
             ey[e] = v;
         }
         fence();
-        // ---- this lane's row (coefficients, right-hand side), its slice of C in the MFMA operand layout, Hq in the accumulator layout
+        QDU_LAP(0);
+        // ---- this lane's row (right-hand side; its coefficients and the MFMA operand slice of C stay in LDS: 32 registers per lane that the
+        //      kernel around this function does not have), Hq in the accumulator layout
         const bool isrow = lane < nr;
-        double cR[16], hr = 0.0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cR[e] = Cl[lane * 16 + e];
+        double hr = 0.0;
         if (lane < nrU) hr = c.Ub[lane % d.nU];
         else if (isrow) {
             const int rl = lane - nrU, k = rl / d.nX + 1, rr = rl - (k - 1) * d.nX;
             double v = c.Xb[rr];
-            for (int j = 0; j < n; ++j) v = fma(-c.XA[(size_t)rr * n + j], xf[(size_t)k * n + j], v);
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) v = fma(-Xsl[(size_t)rr * n + j], xf[(size_t)k * n + j], v);
             hr = v;
         }
-        double cM[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) cM[s] = Cl[(4 * s + kk) * 16 + l16];
         // W = Qb G (column l16, rows of this lane's k-group), Hq[i][l16] = 2 (sum_ya G[ya][i] W[ya] + R)
         for (int ya = kk; ya < ny; ya += 4) {
             const int k = ya / nz, a = ya - k * nz;
             double v = 0.0;
             for (int b = 0; b < nz; ++b) v = fma(c.Qz[a * nz + b], Gl[(k * nz + b) * 16 + l16], v);
-            Cl[ya * 16 + l16] = v;                                        // (C's LDS copy is dead: W borrows its place)
+            Wl[ya * 16 + l16] = v;
         }
         fence();
         wg::qp_d4 hq;
@@ -127,7 +157,7 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
         for (int qd = 0; qd < 4; ++qd) {
             const int i = kk + 4 * qd;
             double v = 0.0;
-            for (int ya = 0; ya < ny; ++ya) v = fma(Gl[ya * 16 + i], Cl[ya * 16 + l16], v);
+            for (int ya = 0; ya < ny; ++ya) v = fma(Gl[ya * 16 + i], Wl[ya * 16 + l16], v);
             if (i < nu && l16 < nu && i / m == l16 / m) v += c.R[(i % m) * m + (l16 % m)];
             hq[qd] = (i < nu && l16 < nu) ? 2.0 * v : 0.0;
             Hl[i * TS + l16] = hq[qd];
@@ -136,7 +166,7 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
         double g0 = 0.0;
         if (lane < nu) {
             double v = 0.0;
-            for (int ya = 0; ya < ny; ++ya) v = fma(Cl[ya * 16 + lane], ey[ya], v);        // (Qb G)^T e_y = G^T Qb e_y  (Qz symmetric)
+            for (int ya = 0; ya < ny; ++ya) v = fma(Wl[ya * 16 + lane], ey[ya], v);        // (Qb G)^T e_y = G^T Qb e_y  (Qz symmetric)
             if (q.ud) { const int k = lane / m, b = lane - k * m; for (int b2 = 0; b2 < m; ++b2) v = fma(-c.R[b * m + b2], q.ud[(size_t)k * m + b2], v); }
             g0 = 2.0 * v;
         }
@@ -153,13 +183,13 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
         auto row_dot = [&](clptr v) -> double {                            // c_row . v
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) { s0 = fma(cR[e], v[e], s0); s1 = fma(cR[e + 1], v[e + 1], s1); }
+            for (int e = 0; e < 16; e += 2) { s0 = fma(Cl[lane * CS + e], v[e], s0); s1 = fma(Cl[lane * CS + e + 1], v[e + 1], s1); }
             return s0 + s1;
         };
         auto ct_times = [&](clptr rv) -> double {                          // (C^T rv)[l16] on every lane; rv: 64 row values in LDS
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int s = 0; s < 16; s += 2) { a0 = fma(cM[s], rv[4 * s + kk], a0); a1 = fma(cM[s + 1], rv[4 * (s + 1) + kk], a1); }
+            for (int s = 0; s < 16; s += 2) { a0 = fma(Cl[(4 * s + kk) * CS + l16], rv[4 * s + kk], a0); a1 = fma(Cl[(4 * s + 4 + kk) * CS + l16], rv[4 * (s + 1) + kk], a1); }
             double a = a0 + a1;
             a += __shfl_xor(a, 16, 64);
             a += __shfl_xor(a, 32, 64);
@@ -170,7 +200,7 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             wg::qp_d4 acc = hq;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const double av = cM[s] * sdl[4 * s + kk];
+                const double av = Cl[(4 * s + kk) * CS + l16] * sdl[4 * s + kk];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, acc, 0, 0, 0);
             }
 #pragma unroll
@@ -208,6 +238,7 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             if (part == 0) dul[cI] = x * scl[cI];
             fence();
         };
+        QDU_LAP(1);
         // ---- the interior point (ql::ipm_box's iteration)
         constexpr double WARM_FLOOR = 1e-2;
         const double ng = (double)nr;
@@ -255,7 +286,9 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             rhol[lane] = rho;
             if (mode == PRED) laml[lane] = isrow ? lr : 0.0;
             fence();
+            QDU_LAP(6);
             if (mode == PRED) { mu = wg::wave_sum(musum) / ng; rp = wg::wave_max(rpm); }
+            QDU_LAP(7);
             // gradient of the cost at u, right-hand side, dual residual
             const double gcost = hq_times(ul) + g0;
             const double ctr = ct_times(rhol);
@@ -266,8 +299,11 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             }
             if (lane < 16) rhs[lane] = lane < nu ? -(gcost + ctr) : 0.0;
             fence();
+            QDU_LAP(8);
             if (mode != CORR) ok = factor();
+            QDU_LAP(3);
             if (ok) msolve();
+            QDU_LAP(4);
             if (mode == INIT) {
                 if (!ok) { status = 2; break; }
                 if (lane < 16) ul[lane] += dul[lane];
@@ -292,6 +328,7 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
                 if (dl < 0.0) amax = fmin(amax, -lr / dl);
             }
             amax = wg::wave_min(amax);
+            QDU_LAP(9);
             if (mode == PRED) {
                 if (!ok) { status = near_opt ? 0 : 2; break; }
                 if (!(mu == mu)) { status = near_opt ? 0 : 5; break; }
@@ -315,15 +352,17 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             ++it;
             mode = PRED;
         }
+        QDU_LAP(2);
         // ---- results: u, the multipliers for the next warm start, the trajectory by a rollout of the minimiser, the objective
         if (lane < nu) w.u[lane] = ul[lane];
         if (status == 0 && isrow) lam[lane] = lr;
         for (int e = lane; e < n; e += 64) { xf[e] = q.x0[e]; w.x[e] = q.x0[e]; }
         fence();
         for (int k = 0; k < N; ++k) {
-            cgptr A = Ak(k), B = Bk(k), dd = dk(k);
+            clptr A = Ak(k), B = Bk(k), dd = dk(k);
             for (int i = lane; i < n; i += 64) {
                 double v = dd[i];
+#pragma unroll 4
                 for (int j = 0; j < n; ++j) v = fma(A[(size_t)i * n + j], xf[(size_t)k * n + j], v);
                 for (int b = 0; b < m; ++b) v = fma(B[(size_t)i * m + b], ul[k * m + b], v);
                 xf[(size_t)(k + 1) * n + i] = v;
@@ -338,7 +377,8 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             double e[16];
             for (int a = 0; a < nz; ++a) {
                 double v = q.z ? -q.z[(size_t)k * nz + a] : 0.0;
-                for (int j = 0; j < n; ++j) v = fma(c.H[(size_t)a * n + j], xf[(size_t)k * n + j], v);
+#pragma unroll 4
+                for (int j = 0; j < n; ++j) v = fma(Hsl[(size_t)a * n + j], xf[(size_t)k * n + j], v);
                 e[a] = v;
             }
             for (int a = 0; a < nz; ++a) for (int b = 0; b < nz; ++b) acc = fma(e[a] * c.Qz[a * nz + b], e[b], acc);
@@ -361,7 +401,12 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
             Jv += q.omega * s0;
             if (status == 0 && !(md <= q.delta)) status = 100;
         }
-        if (lane == 0) { res[0] = (double)status; res[1] = (double)it; res[2] = Jv; }
+        QDU_LAP(5);
+        if (lane == 0) { res[0] = (double)status; res[1] = (double)it; res[2] = Jv;
+#if QDU_CLOCKS
+            for (int i = 0; i < 10; ++i) res[4 + i] = (double)lp[i];
+#endif
+        }
     }
     __syncthreads();
     status = (int)res[0];
@@ -370,7 +415,11 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
     __syncthreads();
     if (J_out) *J_out = Jv;
     if (it_out) *it_out = it;
+#if QDU_CLOCKS
+    if (dbg) for (int i = 0; i < 10; ++i) dbg[i] = res[4 + i];
+#endif
     return status;
 }
 
+#undef QDU_LAP
 }  // namespace qdu

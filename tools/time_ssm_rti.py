@@ -62,3 +62,8 @@ print('SSM GuSTO real-time iteration%s, batch %d, path %s: median %.3f ms, p95 %
        g6.kernel_info))
 if os.environ.get('SRH_GUSTO_TRACE_QIT') and g6.trace is not None:
     print('   shader clocks of the last call: linearise %.0f, QP %.0f, tests %.0f; interior-point iterations + 1000 (pass + 1): %.0f' % tuple(g6.trace[0, 0]))
+    if np.isfinite(g6.trace[0, 1, 0]) and g6.trace[0, 1, 0] > 0:      # a library built with -DQDU_CLOCKS=1 (locp_dense_u.h)
+        print('   dense one-wave QP clocks: set-up (free response, sensitivities) %.0f, rows + Hessian %.0f, interior point outside the solves %.0f, '
+              'factorisations %.0f, solves %.0f, tail (rollout, objective) %.0f' % tuple(np.concatenate((g6.trace[0, 1], g6.trace[0, 2, :2]))))
+        print('   ... the interior point outside the solves, by part: row arithmetic to the fence %.0f, mu / r_p reductions %.0f, gradient + C^T products + r_d %.0f, '
+              'step lengths (after the solve) %.0f, rest %.0f' % tuple(list(np.concatenate((g6.trace[0, 2, 2:], g6.trace[0, 3, :2]))) + [g6.trace[0, 1, 2]]))
