@@ -203,8 +203,12 @@ __device__ inline void observe(const SsmDev &S, const SsmLds &T, clptr x, ssm::W
 // GXL > 0: the QP without its trust-region rows runs on the lean one-wave interior point first (ql::ipm_wave: K is one 16 x 16 tile at the
 // driver's N = 3, 31 k clocks per interior-point iteration against 70 k of the eight-wave forms -- DESIGN.md section 13); qp::solve takes over
 // when that minimiser leaves the trust region or the interior point does not converge.  GXL = lanes per stage for the state rows (ql::ipm_box).
+// Four waves per rollout (one per SIMD): each gets the 512 registers of its SIMD lane, so what the register allocator cannot keep lands in the
+// accumulation registers instead of in scratch memory -- the models here are small (n <= 64, N <= 8), none of the phases has work for eight waves.
+// The LDS layouts stay those of an NTHREADS workgroup (the host sizes them that way).
+constexpr int SSM_THREADS = 256;
 template <bool SPLIT, int MSEL, int GXL>
-__global__ __launch_bounds__(NTHREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off, int tab_off, int dense_u, int task_stride) {
+__global__ __launch_bounds__(SSM_THREADS) void gusto_ssm_kernel(QPDims d, QPConst c, SsmDev S, GustoPar par, SsmGustoBatch b, int red_off, int tab_off, int dense_u, int task_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     qp::specialise<MSEL, 0>(d);
     long long prof[32] = {0};
@@ -698,7 +702,7 @@ int ssm_gusto_launch(sgusto_ssm_plan *pl, const SsmGustoBatch &b, hipStream_t st
     bool launched = false;
 #define X(SP, M, GX) if (!launched && (d.split != 0) == SP && (M == 0 || d.m == M) && pl->lean_gx == GX) { \
         SRH_CHECK_HIP(hipFuncSetAttribute((const void *)gusto_ssm_kernel<SP, M, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds)); \
-        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, NTHREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off, pl->tab_off, pl->dense_u, pl->task_stride); launched = true; }
+        gusto_ssm_kernel<SP, M, GX><<<(unsigned)pl->batch, SSM_THREADS, pl->lds, st>>>(d, pl->C.view(), pl->model->view(), pl->par, b, pl->red_off, pl->tab_off, pl->dense_u, pl->task_stride); launched = true; }
     X(false, 4, 1) X(false, 4, 2) X(false, 8, 1) X(false, 4, 0) X(false, 8, 0) X(false, 0, 0) X(true, 0, 0)
 #undef X
     SRH_REQUIRE(launched, "sgusto_ssm: no kernel variant");
