@@ -197,12 +197,19 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
         };
         // M = Hq + C^T diag(sdl^2) C, Jacobi-scaled, factored: Rl = inverse of the factor, scl = the scaling; returns the pivots' verdict
         auto factor = [&]() -> bool {
-            wg::qp_d4 acc = hq;
+            // four independent accumulation chains (a dependent MFMA waits out the 64-cycle pipeline of the one before it)
+            wg::qp_d4 acc = hq, acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const double av = Cl[(4 * s + kk) * CS + l16] * sdl[4 * s + kk];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, acc, 0, 0, 0);
+            for (int s = 0; s < 16; s += 4) {
+                const double a0 = Cl[(4 * s + kk) * CS + l16] * sdl[4 * s + kk], a1 = Cl[(4 * s + 4 + kk) * CS + l16] * sdl[4 * s + 4 + kk];
+                const double a2 = Cl[(4 * s + 8 + kk) * CS + l16] * sdl[4 * s + 8 + kk], a3 = Cl[(4 * s + 12 + kk) * CS + l16] * sdl[4 * s + 12 + kk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc3, 0, 0, 0);
             }
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) acc[qd] = (acc[qd] + acc1[qd]) + (acc2[qd] + acc3[qd]);
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int i = kk + 4 * qd;
@@ -269,7 +276,7 @@ __device__ __forceinline__ int solve(const QPDims &d, const QPConst &c, const QP
         while (true) {
             double Dw = 0.0, rho = 0.0, musum = 0.0, rpm = 0.0;
             if (isrow) {
-                const double gq = row_dot(ul) - hr;
+                const double gq = mode != CORR ? row_dot(ul) - hr : 0.0;          // (the corrector's rows use the predictor's residuals)
                 if (mode == INIT) { Dw = 1.0; rho = gq; lr = 0.0; }
                 else if (mode == PRED) {
                     rg = gq + tr_;
