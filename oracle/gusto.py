@@ -132,8 +132,12 @@ def _loop(get_traj, model, H, N, dt, Qz, R, x0, u_init, x_init, z, u_des, Qzf, z
         else:
             qp = olocp.build_qp(N, H, Qz, R, A_k, B_k, d_k, x0, xk, delta, omega, z=z, u_des=u_des,
                                 Qzf=Qzf, zf=zf, U=U, X=X, Xf=Xf, dU=dU, x_scale=xs, Hd=H_k, cd=c_k)
-            w = qp_solver(qp)
-            J = olocp.objective(qp, w)
+            if par.get('input_nullspace') is not None:
+                # locp.py:258-261: the objective (and with it the J of the accuracy ratio, gusto.py:405-420) carries the term
+                w, J, _ = olocp.solve_with_nullspace(qp, par['input_nullspace'])
+            else:
+                w = qp_solver(qp)
+                J = olocp.objective(qp, w)
             x_next, u_next, _ = olocp.split(qp, w)
         new_solution = False
         rho_k = -1.0

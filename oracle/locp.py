@@ -347,3 +347,123 @@ def solve_osqp(qp, eps_abs=1e-5, eps_rel=1e-5, max_iter=10000, rho=0.1, sigma=1e
     w = D * x
     ydual = Ev * y / cscale
     return w, (ydual[:ne], ydual[ne:]), dict(iters=it, status=status)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# input_nullspace (locp.py:70-71, 258-261): J += || tile(input_nullspace, N) @ u ||_2 -- NOT squared.  np.tile repeats
+# the array along its last axis, so a vector v (n_u,) gives the scalar |sum_k v . u_k| (the use the reference's driver
+# sketches: "nullspace of V^T H", diamond_SSM.py:258-259) and a matrix M (k x n_u) gives || M sum_k u_k ||_2.
+# ---------------------------------------------------------------------------------------------------------------
+def nullspace_rows(qp, input_nullspace):
+    """tile(input_nullspace, N) as a (k x nw) matrix acting on the stacked w (zero outside the u block)."""
+    M = np.atleast_2d(np.asarray(input_nullspace, dtype=float))
+    N, n, m = qp.N, qp.n, qp.m
+    W = np.zeros((M.shape[0], qp.Pq.shape[0]))
+    W[:, (N + 1) * n:(N + 1) * n + N * m] = np.tile(M, N)
+    return W
+
+
+def nullspace_term(qp, input_nullspace, w):
+    """The value locp.py:261 adds to the objective."""
+    return float(np.linalg.norm(nullspace_rows(qp, input_nullspace) @ w))
+
+
+def add_abs_epigraph(qp, input_nullspace):
+    """One-row input_nullspace: |a' w| = min t s.t. a' w <= t, -a' w <= t -- the SAME problem as a QP with one more
+    variable (appended behind the slacks; zero Hessian, unit cost).  Returns the extended QPData."""
+    W = nullspace_rows(qp, input_nullspace)
+    assert W.shape[0] == 1, 'the epigraph form is a QP for a single row only'
+    nw = qp.Pq.shape[0]
+    q2 = QPData()
+    q2.N, q2.n, q2.m, q2.ns = qp.N, qp.n, qp.m, qp.ns
+    q2.Pq = sp.bmat([[qp.Pq, None], [None, sp.csc_matrix((1, 1))]], format='csc')
+    q2.c, q2.c0 = np.concatenate((qp.c, [1.0])), qp.c0
+    q2.E, q2.e = sp.hstack((qp.E, sp.csc_matrix((qp.E.shape[0], 1))), format='csc'), qp.e
+    rows = sp.csc_matrix(np.vstack((np.append(W[0], -1.0), np.append(-W[0], -1.0))))
+    q2.G = sp.vstack((sp.hstack((qp.G, sp.csc_matrix((qp.G.shape[0], 1)))), rows), format='csc')
+    q2.h = np.concatenate((qp.h, [0.0, 0.0]))
+    return q2
+
+
+def nullspace_certificate(qp, input_nullspace, w, mu):
+    """Sufficient optimality conditions of  min f(w) + ||W w||_2  for a feasible w and a multiplier mu of the norm
+    (||v|| = max_{||mu|| <= 1} mu' v): ||mu|| <= 1, w minimises f + mu' W w over the feasible set (checked by an exact solve of that
+    QP), and the gap ||W w|| - mu' W w is zero.  For every feasible w':  f(w') + ||W w'|| >= f(w') + mu' W w' >= f(w) + mu' W w
+    = f(w) + ||W w|| - gap, so `gap` bounds the suboptimality of w.  Returns dict(mu_norm, gap, inner_dw, inner_dJ)."""
+    import copy
+    W = nullspace_rows(qp, input_nullspace)
+    mu = np.atleast_1d(np.asarray(mu, dtype=float))
+    q2 = copy.copy(qp)
+    q2.c = qp.c + W.T @ mu
+    wi, _, info = solve_exact(q2)
+    assert info['status'] == 'optimal', info
+    g = W @ w
+    return dict(mu_norm=float(np.linalg.norm(mu)), gap=float(np.linalg.norm(g) - mu @ g),
+                inner_dw=float(np.abs(wi - w).max()), inner_dJ=float(objective(q2, w) - objective(q2, wi)))
+
+
+def solve_with_nullspace(qp, input_nullspace, tol=1e-10, max_outer=60):
+    """min f(w) + ||W w||_2 over the QP's feasible set; returns w (without auxiliary variables), the objective, info (with the
+    multiplier `mu` of the norm).
+    One row: the epigraph QP (exact).  Several rows (a second-order-cone term), by cases:
+      (A) the optimum sits in the kink W w = 0: the QP with those equality rows; optimal iff their multiplier nu has ||nu|| <= 1
+          (0 in grad f + W' d||.||(0));
+      (B) otherwise the norm is smooth at the optimum: Newton's method on f + ||W w|| -- the second-order model of the norm at w_i is
+          ghat' W w + w' Hphi w / 2 with Hphi = W' (I - ghat ghat') W / ||g|| (Hphi w_i = 0), a convex QP per step, exact line
+          search by bisection on the segment to its minimiser (the feasible set is convex)."""
+    import copy
+    W = nullspace_rows(qp, input_nullspace)
+    k = W.shape[0]
+    nw = qp.Pq.shape[0]
+    if k == 1:
+        w2, (y2, lam2), info = solve_exact(add_abs_epigraph(qp, input_nullspace))
+        w = w2[:nw]
+        return w, objective(qp, w) + float(np.linalg.norm(W @ w)), dict(info, gap=abs(w2[nw] - abs(float(W[0] @ w))),
+                                                                        mu=np.array([lam2[-2] - lam2[-1]]))
+    # (A)
+    qa = copy.copy(qp)
+    qa.E = sp.vstack((qp.E, sp.csc_matrix(W)), format='csc')
+    qa.e = np.concatenate((qp.e, np.zeros(k)))
+    try:
+        wa, (ya, _), ia = solve_exact(qa)
+        nu = ya[-k:]
+        if ia['status'] == 'optimal' and np.linalg.norm(nu) <= 1.0 + 1e-9:
+            return wa, objective(qp, wa) + float(np.linalg.norm(W @ wa)), dict(ia, case='kink', mu=nu)
+    except RuntimeError:
+        pass                                            # (the rows can be infeasible together with the constraints: case B then)
+    # (B)
+    w, _, info = solve_exact(qp)
+    phi = lambda w_: objective(qp, w_) + float(np.linalg.norm(W @ w_))
+    for it in range(max_outer):
+        g = W @ w
+        ng = float(np.linalg.norm(g))
+        if ng <= 1e-9 * max(1.0, float(np.abs(w).max()) * float(np.abs(W).max())):
+            # the iterates run into the kink although (A) found ||nu|| > 1: the multipliers of W w = 0 are not unique there (active
+            # rows of the QP span the same directions) -- a degenerate instance this restatement does not resolve
+            raise RuntimeError('solve_with_nullspace: degenerate kink (W w -> 0 with non-unique multipliers)')
+        gh = g / ng
+        qn = copy.copy(qp)
+        qn.Pq = (qp.Pq + sp.csc_matrix(0.5 * (W.T @ (np.eye(k) - np.outer(gh, gh)) @ W) / ng)).tocsc()
+        qn.c = qp.c + W.T @ gh
+        wn, _, info = solve_exact(qn)
+        assert info['status'] == 'optimal', info
+        d = wn - w
+        lo, hi = 0.0, 1.0                               # minimiser of the convex phi(w + a d) on [0, 1] by its derivative's sign
+        dphi = lambda a: float(d @ (2.0 * (qp.Pq @ (w + a * d)) + qp.c) + (W @ d) @ (W @ (w + a * d)) / np.linalg.norm(W @ (w + a * d)))
+        if dphi(1.0) <= 0.0:
+            a = 1.0
+        else:
+            for _ in range(60):
+                a = 0.5 * (lo + hi)
+                if dphi(a) > 0.0:
+                    hi = a
+                else:
+                    lo = a
+            a = 0.5 * (lo + hi)
+        w_new = w + a * d
+        done = phi(w) - phi(w_new) <= tol * max(1.0, abs(phi(w)))
+        w = w_new
+        if done:
+            break
+    g = W @ w
+    return w, phi(w), dict(info, case='smooth', outer=it + 1, mu=g / np.linalg.norm(g))

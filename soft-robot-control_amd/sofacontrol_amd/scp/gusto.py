@@ -73,12 +73,14 @@ class GuSTO:
         self.x_k = None
         self.u_k = None
         self.nonlinear_observer = model.nonlinear_observer
-        # input-rate constraints couple the stages: they go through the generic loop around the (augmented) device QP
-        self._fused = (isinstance(model, TPWLGuSTO) and not self.nonlinear_observer and dU is None and
+        # input-rate constraints couple the stages: they go through the generic loop around the (augmented) device QP; so does the
+        # input_nullspace term (locp.py:258-261: a norm over the whole input sequence, LOCP._solve_nullspace)
+        nullspace = kwargs.get('input_nullspace') is not None
+        self._fused = (isinstance(model, TPWLGuSTO) and not self.nonlinear_observer and dU is None and not nullspace and
                        getattr(model.dyn_sys, 'tpwl_method', 'nn') == 'nn')
         # an SSM model: the whole solve in csrc/gusto_ssm.hip (no terminal cost, no rate rows; the state polyhedron is applied to the
         # states by the reference's own test, gusto.py:185-201, so its matrix must have n_x columns)
-        self._ssm = (isinstance(model, SSMGuSTO) and dU is None and Qzf is None and Xf is None and
+        self._ssm = (isinstance(model, SSMGuSTO) and dU is None and Qzf is None and Xf is None and not nullspace and
                      (X is None or np.asarray(X.A).shape[1] == self.n_x) and hasattr(model.dyn_sys, 'handle') and
                      not os.environ.get('SRH_GUSTO_SSM_HOST_LOOP'))          # (that knob: the host loop, for A/B runs and tests)
         self._plan = C.c_void_p()

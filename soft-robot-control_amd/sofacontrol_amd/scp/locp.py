@@ -4,6 +4,7 @@ The reference builds the QP in cvxpy and hands it to OSQP/GUROBI; here `solve()`
 Riccati-structured interior-point kernel (csrc/locp_dev.h).  Same problem data (locp.py:218-342), same
 `update / solve / get_solution` protocol, `J*` without the 1/2 factor like cvxpy reports it."""
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -83,17 +84,14 @@ class LOCP:
         self.x_scale = np.ones(self.n_x) if x_char is None else 1. / np.abs(x_char)
         self.tr_active = kwargs.pop('is_tr_active', True)
         self._du_aug = False
+        self._init_nullspace(kwargs.pop('input_nullspace', None))
         if self.nonlinear_observer:
             self._init_augmented(N, Qz, R, Qzf, U, X, Xf, dU, kwargs)
             return
         if dU is not None:
-            if kwargs.pop('input_nullspace', None) is not None:
-                raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
             self.solver_args = kwargs
             self._init_rate_augmented(N, Qz, R, Qzf, U, X, Xf, dU)
             return
-        if kwargs.pop('input_nullspace', None) is not None:
-            raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
         self.solver_args = kwargs      # OSQP/GUROBI settings have no meaning here; kept for signature parity
         self._prob, self._keep = make_problem(N, self.H, Qz, R, Qzf, U, X, Xf, dU, self.x_scale, self.tr_active)
         self._data = None
@@ -106,8 +104,6 @@ class LOCP:
         H_a = [0 I], X_a = [0 X.A], Xf_a = [Xf.A 0], zero trust-region scale on zeta -- the same QP in
         (x, u, s) after eliminating zeta."""
         from ..utils import Polyhedron
-        if kwargs.pop('input_nullspace', None) is not None:
-            raise NotImplementedError('input_nullspace (a second-order-cone term, locp.py:259-261) is not a QP')
         if Qzf is not None and np.any(self.H != 0):
             raise NotImplementedError('terminal cost through a non-zero constant H together with a nonlinear '
                                       'observer (locp.py:251-252) is not covered')
@@ -216,8 +212,125 @@ class LOCP:
         self._delta = np.array([float(delta)])
         self._omega = np.array([float(omega)])
 
+    def _init_nullspace(self, input_nullspace):
+        """locp.py:70-71, 258-261: J += || tile(input_nullspace, N) @ u ||_2 (not squared).  np.tile repeats along the last axis: a
+        vector v gives |sum_k v . u_k|, a matrix M (k x n_u) gives || M sum_k u_k ||_2.  Not a QP -- but
+        ||g|| = max_{||mu|| <= 1} mu' g, and for a fixed mu the term is LINEAR in u, i.e. a shift of the desired input of the same
+        device QP:  (u - ud)' R (u - ud) + c' u = (u - ud + R^-1 c / 2)' R (.) + c' ud - c' R^-1 c / 4  with c = M' mu.  solve()
+        maximises the concave dual over the unit ball (_solve_nullspace); every evaluation is one solve of the resident plan."""
+        self.input_nullspace = input_nullspace
+        self._ns = None
+        if input_nullspace is None:
+            return
+        M = np.atleast_2d(np.asarray(input_nullspace, dtype=np.float64))
+        if M.ndim != 2 or M.shape[1] != self.n_u:
+            raise ValueError('input_nullspace: expected (n_u,) or (k, n_u), got %s' % (np.shape(input_nullspace),))
+        R = np.asarray(self.R, dtype=np.float64)
+        try:
+            np.linalg.cholesky(R)
+        except np.linalg.LinAlgError:
+            raise ValueError('input_nullspace needs a positive definite R (the term becomes a shift of the desired input)')
+        self._ns = dict(M=M, Rinv=np.linalg.inv(R))
+        self.nullspace_stats = None
+
+    def _solve_nullspace(self):
+        """Dual maximisation of the input_nullspace term.  g(mu) = M sum_k u*_k(mu) is the gradient of the concave dual d(mu) =
+        min_u f(u) + mu' M sum_k u_k; the duality gap ||g|| - mu' g of the pair (u*(mu), mu) bounds the suboptimality of u*(mu)
+        (every u*(mu) is feasible), so the loop stops on it.  One row: g is a monotone scalar function of mu in [-1, 1] -- the end
+        point on the side of g(0), or a bracketed secant / bisection root.  Several rows: projected gradient ascent on the unit
+        ball with Barzilai-Borwein steps and a monotone safeguard (the dual of a QP is piecewise quadratic)."""
+        ns = self._ns
+        M, Rinv = ns['M'], ns['Rinv']
+        N, m = self.N, self.n_u
+        k = M.shape[0]
+        d = self._data
+        ud = np.zeros((N, m)) if d.get('u') is None else np.asarray(d['u'], dtype=np.float64).reshape(N, m)
+        tol = float(os.environ.get('SRH_NULLSPACE_TOL', 1e-10))
+        calls = [0]
+        t_solve = [0.0]
+
+        def evaluate(mu):
+            c = M.T @ mu
+            J, ok, st = self._solve_once(_lib.f64(np.ravel(ud - 0.5 * (Rinv @ c))))
+            calls[0] += 1
+            if not ok:
+                return None
+            t_solve[0] += st.solve_time
+            x, u, sl = self._sol
+            su = u.sum(axis=0)
+            g = M @ su
+            f = J - float(c @ su) + float(c @ ud.sum(axis=0)) - 0.25 * N * float(c @ Rinv @ c)     # the cost without the term
+            ng = float(np.linalg.norm(g))
+            return dict(mu=mu, g=g, f=f, primal=f + ng, dual=f + float(mu @ g), gap=ng - float(mu @ g), sol=self._sol, iters=st.num_iters)
+
+        def good(e):
+            return e['gap'] <= tol * max(1.0, abs(e['primal']))
+
+        best = e0 = evaluate(np.zeros(k))
+        if e0 is None:
+            return np.inf, False, None
+        if not good(e0):
+            if k == 1:
+                s0 = 1.0 if e0['g'][0] > 0 else -1.0
+                e1 = evaluate(np.array([s0]))
+                if e1 is None:
+                    return np.inf, False, None
+                if e1['gap'] < best['gap']:
+                    best = e1
+                if not good(e1) and e1['g'][0] * s0 < 0:            # the sign of g changes inside: its root is the optimum
+                    lo, hi = e0, e1
+                    for it in range(60):
+                        a, b, ga, gb = lo['mu'][0], hi['mu'][0], lo['g'][0], hi['g'][0]
+                        t = a - ga * (b - a) / (gb - ga)              # secant point of the bracket; bisection every third step
+                        if it % 3 == 2 or not (min(a, b) < t < max(a, b)):
+                            t = 0.5 * (a + b)
+                        e = evaluate(np.array([t]))
+                        if e is None:
+                            return np.inf, False, None
+                        if e['gap'] < best['gap']:
+                            best = e
+                        if good(e) or abs(b - a) <= 1e-15:
+                            break
+                        if e['g'][0] * s0 > 0:
+                            lo = e
+                        else:
+                            hi = e
+            else:
+                proj = lambda v: v / max(1.0, float(np.linalg.norm(v)))
+                cur = e0
+                step = 1.0 / max(float(np.linalg.norm(e0['g'])), 1e-300)      # the first step reaches the sphere
+                for it in range(200):
+                    mu_n = proj(cur['mu'] + step * cur['g'])
+                    e = evaluate(mu_n)
+                    if e is None:
+                        return np.inf, False, None
+                    if e['dual'] < cur['dual'] - 1e-12 * max(1.0, abs(cur['dual'])):
+                        step *= 0.25                                           # overshoot: the dual must not fall
+                        continue
+                    if e['gap'] < best['gap']:
+                        best = e
+                    if good(e):
+                        break
+                    dm, dg = e['mu'] - cur['mu'], e['g'] - cur['g']
+                    curv = -float(dm @ dg)
+                    if curv > 0:
+                        step = float(dm @ dm) / curv                           # Barzilai-Borwein
+                    elif float(np.linalg.norm(dm)) == 0.0:
+                        break                                                  # pinned on the sphere with g along mu: optimal
+                    cur = e
+        self._sol = best['sol']
+        self.nullspace_stats = dict(mu=best['mu'], gap=best['gap'], qp_solves=calls[0], term=float(np.linalg.norm(best['g'])))
+        return best['primal'], True, _Stats(t_solve[0], best['iters'])
+
     def solve(self):
         """locp.py:175-190: returns (Jstar, success, stats)."""
+        if self._ns is not None:
+            return self._solve_nullspace()
+        return self._solve_once(None)
+
+    def _solve_once(self, u_des):
+        """One solve of the resident QP; u_des (flat N n_u, or None: the desired input of update()) -- the only per-solve change the
+        input_nullspace loop makes."""
         d = self._data
         N, n, m = self.N, self.n_x, self.n_u
         if self.nonlinear_observer:
@@ -240,7 +353,7 @@ class LOCP:
         _lib.check(L.slocp_plan_solve(self._plan, _lib.dptr(d['Ad']) if fresh else None, _lib.dptr(d['Bd']) if fresh else None,
                                       _lib.dptr(d['dd']) if fresh else None, _lib.dptr(d['x0']),
                                       _lib.dptr(d['xk']) if fresh else None, _lib.dptr(self._delta), _lib.dptr(self._omega),
-                                      _lib.dptr(d['z']), _lib.dptr(d['zf']), _lib.dptr(d['u']), _lib.dptr(x), _lib.dptr(u),
+                                      _lib.dptr(d['z']), _lib.dptr(d['zf']), _lib.dptr(d['u'] if u_des is None else u_des), _lib.dptr(x), _lib.dptr(u),
                                       _lib.dptr(s), _lib.dptr(J), _lib.iptr(status), _lib.iptr(iters)), 'slocp_plan_solve')
         self._resident = d
         t1 = time.time()

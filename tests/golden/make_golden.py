@@ -839,6 +839,8 @@ def ref_locp_values(case, pts, warm_start):
         kw['is_tr_active'] = False
     if nl:
         kw['nonlinear_observer'] = True
+    if case.get('input_nullspace') is not None:
+        kw['input_nullspace'] = case['input_nullspace']
     (lo, _) = quiet(rlocp.LOCP, case['N'], case['H'], case['Qz'], case['R'], Qzf=case.get('Qzf'), U=poly(case.get('U')),
                     X=poly(case.get('X')), Xf=poly(case.get('Xf')), dU=poly(case.get('dU')), verbose=False,
                     warm_start=warm_start, x_char=1.0 / case['x_scale'], **kw)
@@ -887,6 +889,31 @@ def g14_locp(out):
     np.savez_compressed(os.path.join(out, 'g14_locp.npz'), **res)
 
 
+def g21_locp_nullspace(out):
+    """The reference's objective WITH its input_nullspace term (locp.py:70-71, 258-261), evaluated by the reference's own locp.py
+    (through the evaluating cvxpy stand-in) at seeded points and at the oracle's optimum, for qp_cases.NULLSPACE_CASES: a vector
+    (|sum_k v . u_k|) and a matrix (|| M sum_k u_k ||_2), each with the optimum where the norm is smooth and inside its kink."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import qp_cases
+    res = {}
+    for name in qp_cases.NULLSPACE_CASES:
+        case, ns = qp_cases.nullspace_case(name)
+        pts = qp_cases.g14_points('nullspace_' + name, case)
+        kw = dict(case)
+        qp = olocp.build_qp(kw.pop('N'), kw.pop('H'), kw.pop('Qz'), kw.pop('R'), kw.pop('Ad'), kw.pop('Bd'), kw.pop('dd'),
+                            kw.pop('x0'), kw.pop('xk'), kw.pop('delta'), kw.pop('omega'), **kw)
+        w, J, info = olocp.solve_with_nullspace(qp, ns)
+        cert = olocp.nullspace_certificate(qp, ns, w, info['mu'])
+        assert cert['mu_norm'] <= 1 + 1e-9 and abs(cert['gap']) <= 1e-9 and abs(cert['inner_dJ']) <= 1e-7, (name, cert)
+        pts.append(olocp.split(qp, w))
+        J1, R1 = ref_locp_values(dict(case, input_nullspace=ns), pts, True)
+        J2, R2 = ref_locp_values(dict(case, input_nullspace=ns), pts, False)
+        assert np.array_equal(J1, J2) and np.array_equal(R1, R2), name
+        res[name + '_J'], res[name + '_res'], res[name + '_wopt'], res[name + '_mu'] = J1, R1, w, np.atleast_1d(info['mu'])
+        res[name + '_Jopt'] = np.array(J)
+    np.savez_compressed(os.path.join(out, 'g21_locp_nullspace.npz'), **res)
+
+
 def g19_preprocess(out):
     """process_snapshots / compute_kmeans_centroids of the imported reference (pod.py:157-178, 207-216; sklearn is a
     dependency of the reference and is installed in the build container) on small seeded snapshot sets."""
@@ -908,7 +935,7 @@ def g19_preprocess(out):
 
 GENERATORS = dict(g19_preprocess=g19_preprocess, g20_ilqr_switches=g20_ilqr_switches, g1_pod=g1_pod, g3_tpwl=g3_tpwl, g4_riccati=g4_riccati, g6_gusto=g6_gusto, g8_controllers=g8_controllers,
                   g9_ekf=g9_ekf, g10_ssm=g10_ssm, g11_ilqr_ssm=g11_ilqr_ssm, g12_assembly=g12_assembly,
-                  g13_controllers2=g13_controllers2, g14_locp=g14_locp, g15_ssm_controllers=g15_ssm_controllers,
+                  g13_controllers2=g13_controllers2, g14_locp=g14_locp, g21_locp_nullspace=g21_locp_nullspace, g15_ssm_controllers=g15_ssm_controllers,
                   g16_dubins=g16_dubins, g17_ssm_hardware=g17_ssm_hardware, g18_pod_shipped=g18_pod_shipped)
 
 if __name__ == '__main__':

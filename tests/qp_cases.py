@@ -92,6 +92,32 @@ def g14_case(name):
     return case
 
 
+# input_nullspace (locp.py:70-71, 258-261): a vector gives |sum_k v . u_k|, a matrix || M sum_k u_k ||_2; small weights leave the
+# optimum where the norm is smooth, large ones pull it into the kink (M sum_k u_k = 0).  (kind, weight, seed of the base case)
+NULLSPACE_CASES = {
+    'vec_smooth': ('vec', 1e-3, 50),
+    'vec_kink': ('vec', 10.0, 51),
+    'mat_smooth': ('mat', 1e-3, 52),
+    'mat_kink': ('mat', 1.0, 53),
+}
+
+
+def nullspace_case(name):
+    """(case for oracle.locp.build_qp, input_nullspace) of a NULLSPACE_CASES entry: the g14 'u_des' shape with its own seed."""
+    kind, weight, seed = NULLSPACE_CASES[name]
+    case, info = make_case(seed=seed)
+    n, m = case['Bd'][0].shape
+    rng = np.random.default_rng(900 + seed)
+    case['u_des'] = rng.uniform(0, 50, (case['N'], m))
+    if kind == 'vec':
+        ns = weight * rng.standard_normal(m)
+    else:
+        ns = np.zeros((2, m))                     # rows e_i - e_{i+1}: the inputs may stay equal and positive inside the kink
+        for i in range(2):
+            ns[i, i], ns[i, i + 1] = weight, -weight
+    return case, ns
+
+
 def g14_points(name, case, count=10):
     """Seeded evaluation points (x, u, s): random, around the trust-region centre, with nonnegative slacks."""
     N = case['N']

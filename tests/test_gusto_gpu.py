@@ -248,3 +248,40 @@ def test_gusto_with_input_rate_constraints(golden):
     assert int(gu.iters[0]) == len(tr)
     assert rel(xo, xe) <= 1e-4 and rel(uo, ue) <= 1e-4
     assert np.abs(np.diff(uo, axis=0)).max() <= 20.0 * (1 + 1e-6)
+
+
+@pytest.mark.parametrize('weight', [2e-4, 0.05])
+def test_gusto_with_input_nullspace_term(golden, weight):
+    """GuSTO(input_nullspace=v) (locp.py:70-71, 258-261; the driver's sketch: diamond_SSM.py:258-259): the norm couples every
+    stage's input, so the solve runs the generic loop around LOCP's dual maximisation; the objective that enters the
+    model-accuracy ratio carries the term.  Same iterates as the restated loop (oracle: epigraph QP per iteration).  The small
+    weight leaves |sum_k v . u_k| > 0, the large one drives it to zero."""
+    from oracle import tpwl as otpwl, gusto as ogusto
+    from sofacontrol_amd.scp.gusto import GuSTO
+    g, gm = setup(golden)
+    model, U_, q_ref, v_ref, Hf = golden_problem(4, 3, 7, 20, 30, q_scale=0.05)
+    tp = gm.dyn_sys
+    N, dt = 10, 0.05
+    Ad, Bd, dd = np.stack(tp.A_d), np.stack(tp.B_d), np.stack(tp.d_d)
+    H = np.asarray(tp.H)
+    from scipy.interpolate import interp1d
+    z = interp1d(g['t'], g['zt'], axis=0)(dt * np.arange(N + 1))
+    x0 = np.zeros(8); u_init = np.zeros((N, 3))
+    x_init = otpwl.rollout(model, Ad, Bd, dd, x0, u_init)
+    v = weight * np.array([0.6, -0.5, 0.62])
+    gu = GuSTO(gm, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, U=Poly(g['U_A'], g['U_b']), input_nullspace=v,
+               x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, max_gusto_iters=3)
+    assert not gu._fused
+    gu.solve(x0, u_init, x_init, z=z)
+    xo, uo, zo, _ = gu.get_solution()
+    xe, ue, ze, tr = ogusto.solve(model, Ad, Bd, dd, H, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z,
+                                  U=(g['U_A'], g['U_b']), x_char=g['x_char'], f_char=g['f_char'],
+                                  convg_thresh=1e-3, max_gusto_iters=3, input_nullspace=v)
+    assert int(gu.iters[0]) == len(tr)
+    assert rel(xo, xe) <= 1e-4 and rel(uo, ue) <= 1e-4
+    term = abs(float(v @ uo.sum(axis=0)))
+    # and the term did something: the solve without it ends elsewhere
+    x2, u2, _, _ = ogusto.solve(model, Ad, Bd, dd, H, N, dt, g['Qz'], g['R'], x0, u_init, x_init, z=z, U=(g['U_A'], g['U_b']),
+                                x_char=g['x_char'], f_char=g['f_char'], convg_thresh=1e-3, max_gusto_iters=3)
+    assert abs(float(v @ u2.sum(axis=0))) > term + 1e-6
+    assert (term <= 1e-6) == (weight > 0.01), term

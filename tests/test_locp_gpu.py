@@ -332,3 +332,51 @@ def test_resident_locp_plan_keeps_the_horizon_and_takes_device_pointers():
     assert ost.to_array((1,), dtype=np.int32)[0] == 0 and oJ.to_array((1,))[0] == ref2[0]
     assert np.array_equal(ox.to_array((N + 1, n)), ref2[1]) and np.array_equal(ou.to_array((N, m)), ref2[2])
     L.slocp_plan_destroy(plan)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# input_nullspace (locp.py:70-71, 258-261): J += || tile(input_nullspace, N) @ u ||_2 -- a norm, not a square
+@pytest.mark.parametrize('name', ['vec_smooth', 'vec_kink', 'mat_smooth', 'mat_kink'])
+def test_locp_input_nullspace_term(name):
+    """LOCP(input_nullspace=...) -- dual maximisation around the device QP (LOCP._solve_nullspace) -- against the optimum that the
+    reference's own objective was evaluated at (golden g21, generated through the reference's locp.py) and the oracle's duality
+    certificate: the returned multiplier has norm <= 1, the returned inputs minimise the QP with that multiplier's linear cost
+    (exact oracle solve), and the gap ||g|| - mu' g is zero -- together sufficient for global optimality."""
+    import os
+    import qp_cases
+    from sofacontrol_amd.scp.locp import LOCP
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g21_locp_nullspace.npz'))
+    case, ns = qp_cases.nullspace_case(name)
+    kw = dict(case)
+    qp = olocp.build_qp(kw.pop('N'), kw.pop('H'), kw.pop('Qz'), kw.pop('R'), kw.pop('Ad'), kw.pop('Bd'), kw.pop('dd'),
+                        kw.pop('x0'), kw.pop('xk'), kw.pop('delta'), kw.pop('omega'), **kw)
+    xe, ue, se = olocp.split(qp, g[name + '_wopt'])
+    Je = float(g[name + '_Jopt'])
+    locp = LOCP(case['N'], case['H'], case['Qz'], case['R'], U=Poly(*case['U']), X=Poly(*case['X']), x_char=1. / case['x_scale'],
+                input_nullspace=ns)
+    locp.update(list(case['Ad']), list(case['Bd']), list(case['dd']), case['x0'], case['xk'], case['delta'], case['omega'],
+                z=case['z'], u=case['u_des'])
+    J, ok, stats = locp.solve()
+    assert ok
+    x, u, s = locp.get_solution()
+    st = locp.nullspace_stats
+    assert abs(J - Je) <= 1e-7 * max(1.0, abs(Je)), (J, Je, st)
+    assert rel(x, xe) <= 1e-4 and rel(u, ue) <= 2e-3                      # (flat input directions: see the module docstring)
+    w = qp_cases.g14_pack(case, x, u, s)
+    assert J == pytest.approx(olocp.objective(qp, w) + olocp.nullspace_term(qp, ns, w), rel=1e-9)      # J is the reference's objective
+    cert = olocp.nullspace_certificate(qp, ns, w, st['mu'])
+    assert cert['mu_norm'] <= 1 + 1e-12 and cert['gap'] <= 1e-8 * max(1.0, abs(Je)) and abs(cert['inner_dJ']) <= 1e-6, (cert, st)
+    kink = name.endswith('kink')
+    assert (st['term'] <= 1e-6) == kink
+    assert st['qp_solves'] <= (40 if kink else 3 if name.startswith('vec') else 40), st
+    # dynamics hold along the returned trajectory
+    for k in range(case['N']):
+        np.testing.assert_allclose(x[k + 1], case['Ad'][k] @ x[k] + case['Bd'][k] @ u[k] + case['dd'][k], rtol=0, atol=1e-12)
+
+
+def test_locp_input_nullspace_argument_checks():
+    from sofacontrol_amd.scp.locp import LOCP
+    with pytest.raises(ValueError, match='input_nullspace'):
+        LOCP(3, np.eye(2), np.eye(2), np.eye(3), input_nullspace=np.ones(2))                 # n_u = 3
+    with pytest.raises(ValueError, match='positive definite'):
+        LOCP(3, np.eye(2), np.eye(2), np.zeros((3, 3)), input_nullspace=np.ones(3))

@@ -355,6 +355,46 @@ def test_locp_statement_matches_reference_locp_py(golden, name):
     assert r[n_eq_dyn:-qp.n].max(initial=0.0) <= 1e-7                                     # every inequality
 
 
+@pytest.mark.parametrize('name', sorted(qp_cases.NULLSPACE_CASES))
+def test_locp_input_nullspace_statement_and_optimum_match_reference_locp_py(golden, name):
+    """g21: the objective of the reference's own locp.py WITH its input_nullspace term (locp.py:70-71, 258-261; vector and matrix)
+    at ten seeded points and at the optimum; the oracle's solve (epigraph QP for a vector; kink / Newton cases for a matrix)
+    reproduces the stored optimum and passes the duality certificate."""
+    from oracle import locp as olocp
+    g = golden('g21_locp_nullspace')
+    case, ns = qp_cases.nullspace_case(name)
+    pts = qp_cases.g14_points('nullspace_' + name, case)
+    ws = [qp_cases.g14_pack(case, *p) for p in pts] + [g[name + '_wopt']]
+    Jr, Rr = g[name + '_J'], g[name + '_res']
+    for i, w in enumerate(ws):
+        J, res, qp = qp_cases.g14_oracle_values(case, w)
+        J += olocp.nullspace_term(qp, ns, w)
+        np.testing.assert_allclose(J, Jr[i], rtol=1e-12, atol=1e-12 * max(1.0, abs(Jr[i])))
+        np.testing.assert_allclose(res, Rr[i], rtol=0, atol=1e-12 * max(1.0, np.abs(Rr[i]).max()))
+    w, J, info = olocp.solve_with_nullspace(qp, ns)
+    assert J == pytest.approx(float(g[name + '_Jopt']), rel=1e-9)
+    assert J == pytest.approx(float(Jr[-1]), rel=1e-9)                                    # the reference's own value at that point
+    cert = olocp.nullspace_certificate(qp, ns, w, info['mu'])
+    assert cert['mu_norm'] <= 1 + 1e-9 and abs(cert['gap']) <= 1e-9 and abs(cert['inner_dJ']) <= 1e-7, cert
+    kink = name.endswith('kink')
+    assert (olocp.nullspace_term(qp, ns, w) <= 1e-7) == kink and (cert['mu_norm'] < 0.5) == kink
+    # a seeded feasible perturbation along the inputs never does better (convexity: a local check is a global one)
+    N, n, m = qp.N, qp.n, qp.m
+    rng = np.random.default_rng(5)
+    Ad, Bd, dd = case['Ad'], case['Bd'], case['dd']
+    x, u, sl = olocp.split(qp, w)
+    for _ in range(5):
+        u2 = np.clip(u + 1e-3 * rng.standard_normal(u.shape), 0.0, 800.0)
+        x2 = [np.asarray(case['x0'], dtype=float)]
+        for k in range(N):
+            x2.append(Ad[k] @ x2[-1] + Bd[k] @ u2[k] + dd[k])
+        x2 = np.array(x2)
+        s2 = np.maximum(0.0, np.max(np.abs(case['x_scale'] * (x2 - case['xk'])), axis=1) - case['delta'])
+        w2 = qp_cases.g14_pack(case, x2, u2, s2)
+        if (qp.G @ w2 - qp.h).max() <= 1e-12:
+            assert olocp.objective(qp, w2) + olocp.nullspace_term(qp, ns, w2) >= J - 1e-9
+
+
 @pytest.mark.parametrize('tag', ['discrete', 'be', 'fe'])
 def test_ssm_oracle_on_the_shipped_model(golden, tag):
     """oracle.ssm on the reference's shipped Diamond SSM model and recorded inputs (golden g17: the reference's own
