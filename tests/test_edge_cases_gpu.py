@@ -186,7 +186,8 @@ def test_device_eigh_rocsolver_path():
 
 
 def test_device_eigh_above_jacobi_limit():
-    """n = 2100 > 2048: the size-based dispatch itself picks rocSOLVER (no environment override)."""
+    """n = 2100 > 2048: the size-based dispatch itself picks rocSOLVER (no environment override; the block Jacobi if the library
+    does not load)."""
     from sofacontrol_amd.mor.pod import _device_eigh
     n = 2100
     rng = np.random.default_rng(n)
@@ -196,6 +197,29 @@ def test_device_eigh_above_jacobi_limit():
     we = np.linalg.eigvalsh(G)
     np.testing.assert_allclose(w, we, rtol=0, atol=1e-11 * np.abs(we).max())
     np.testing.assert_allclose(G @ W[:, -8:], W[:, -8:] * w[-8:], atol=1e-10 * np.abs(we).max())
+
+
+@pytest.mark.parametrize('n', [129, 300, 1000, 2100])
+def test_device_eigh_block_jacobi(n):
+    """SRH_EIGH_BLOCK=1 (and any box where rocSOLVER does not load): the library-free two-sided block Jacobi of csrc/eigh.hip --
+    64-wide blocks, 128 x 128 pair problems in LDS, the step applied as chained MFMA products.  Full spectrum and eigenvectors
+    against numpy (mor/pod.py:181-200 returns the whole spectrum); sizes that are not multiples of 128 pad with rows that never mix."""
+    from sofacontrol_amd.mor.pod import _device_eigh
+    rng = np.random.default_rng(n)
+    k = min(n + 3, 700)                                   # (n = 1000, 2100: rank-deficient -- a 300+-fold zero eigenvalue)
+    S = rng.standard_normal((n, k)) * np.logspace(0, -3, k)
+    G = S @ S.T
+    os.environ['SRH_EIGH_BLOCK'] = '1'
+    try:
+        w, W = _device_eigh(G)
+    finally:
+        del os.environ['SRH_EIGH_BLOCK']
+    we = np.linalg.eigvalsh(G)
+    scale = np.abs(we).max()
+    assert np.all(np.diff(w) >= 0)
+    np.testing.assert_allclose(w, we, rtol=0, atol=1e-11 * scale)
+    np.testing.assert_allclose(W.T @ W, np.eye(n), atol=2e-11)
+    np.testing.assert_allclose(G @ W, W * w, atol=1e-10 * scale)
 
 
 def test_new_entry_points_reject_bad_arguments():
