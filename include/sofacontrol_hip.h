@@ -182,6 +182,14 @@ int stpwl_weights(stpwl_t *h, const double *X, int64_t B, double beta, double *W
  * W (B x P) optional output of the weights */
 int stpwl_linearize_weighted(stpwl_t *h, const double *X, int64_t B, double beta, double *A, double *Bm,
                              double *d, double *W);
+/* TPWL.discretize_dynamics (tpwl.py:272-297; zoh: sofacontrol/utils.py:302-335 zoh_affine) for `batch` continuous affine models
+ * xdot = A x + B u + d at once: the stored points of pre_discretize (tpwl.py:299-322), the blended model of weighting-mode TPWL
+ * (tpwl.py:244-250).  method: 0 fe, 1 be, 2 bil, 3 zoh.  A (batch x n x n), B (batch x n x m), d (batch x n) -> same shapes.
+ * SRH_ENUMERIC if a model's I - c A is singular. */
+int stpwl_discretize(int method, int n, int m, int64_t batch, const double *A, const double *B, const double *d, double dt,
+                     double *Ad, double *Bd, double *dd);
+int stpwl_discretize_dev(int method, int n, int m, int64_t batch, const double *A_dev, const double *B_dev, const double *d_dev,
+                         double dt, double *Ad_dev, double *Bd_dev, double *dd_dev, void *stream);
 /* TPWL.rollout (tpwl.py:193-216) for `batch` independent rollouts:
  * x0 (batch x n_x), U (batch x N x n_u) -> X (batch x (N+1) x n_x), Z (batch x (N+1) x n_z) or NULL */
 int stpwl_rollout(stpwl_t *h, const double *x0, const double *U, int N, int64_t batch, double *X,

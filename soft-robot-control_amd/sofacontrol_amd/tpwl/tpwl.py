@@ -1,11 +1,11 @@
 """TPWL piecewise-affine reduced model on MI355X -- surface of sofacontrol/tpwl/tpwl.py (TPWL,
 TPWLATV).  The point tables live in HBM; nearest-point search, table gather and rollouts are HIP
-kernels (csrc/tpwl.hip).  Discretisation of the P stored points (pre_discretize, one-off per dt,
-tpwl.py:299-322) is done once on the host (zoh needs a matrix exponential) and uploaded."""
+kernels (csrc/tpwl.hip).  Discretisation -- of the P stored points (pre_discretize, one-off per dt, tpwl.py:299-322) and of the
+blended model that weighting mode re-discretises at every state (tpwl.py:244-250) -- is a batched kernel too (csrc/discretize.hip:
+Gauss-Jordan for be / bil, scaling and squaring with the [13/13] Pade approximant for zoh)."""
 import ctypes as C
 
 import numpy as np
-from scipy.linalg import expm
 
 from .. import _lib
 from .. import utils as scutils
@@ -14,17 +14,6 @@ from ..mor import pod
 DISCR_METHOD = 'zoh'
 TPWL_METHOD = 'nn'
 DISCR_DICT = {'fe': 'forward Euler', 'be': 'implicit Euler', 'bil': 'bilinear transform', 'zoh': 'zero-order hold'}
-
-
-def zoh_affine(A, B, d, dt):
-    """sofacontrol/utils.py:302-335: expm([[A, B, d], [0, 0, 0]] dt)."""
-    n, m = B.shape
-    M = np.zeros((n + m + 1, n + m + 1))
-    M[:n, :n] = A
-    M[:n, n:n + m] = B
-    M[:n, n + m] = d
-    Z = expm(M * dt)
-    return Z[:n, :n], Z[:n, n:n + m], Z[:n, n + m]
 
 
 class TPWL:
@@ -110,7 +99,7 @@ class TPWL:
             raise RuntimeError('tpwl method should be nn to pre-discretize')
         if tables is None:
             Ac, Bc, dc = self._tabs[3], self._tabs[4], self._tabs[5]
-            A_d, B_d, d_d = zip(*[self.discretize_dynamics(Ac[i], Bc[i], dc[i], dt) for i in range(self.num_points)])
+            A_d, B_d, d_d = self.discretize_batch(Ac, Bc, dc, dt)
         else:
             A_d, B_d, d_d = tables
         Ad, Bd, dd = _lib.f64(np.stack(A_d)), _lib.f64(np.stack(B_d)), _lib.f64(np.stack(d_d))
@@ -283,8 +272,7 @@ class TPWLATV(TPWL):
                                                            _lib.dptr(B), _lib.dptr(d), _lib.dptr(W)),
                        'stpwl_linearize_weighted')
             if dt is not None:
-                for b in range(Bn):
-                    A[b], B[b], d[b] = self.discretize_dynamics(A[b], B[b], d[b], dt)
+                A, B, d = self.discretize_batch(A, B, d, dt)          # the blended models of the whole batch in one launch
             return A, B, d, W
         h = self.handle_for(dt)
         X = np.ascontiguousarray(X, dtype=np.float64)
@@ -296,22 +284,24 @@ class TPWLATV(TPWL):
                    'stpwl_linearize')
         return A, B, d, idx
 
+    def discretize_batch(self, A_c, B_c, d_c, dt):
+        """tpwl.py:272-297 for a stack of models (B, n, n), (B, n, m), (B, n) in one launch of csrc/discretize.hip: fe / be / bil by
+        one Gauss-Jordan elimination per model, zoh (utils.py:302-335) by scaling and squaring with the [13/13] Pade approximant."""
+        methods = {'fe': 0, 'be': 1, 'bil': 2, 'zoh': 3}
+        if self.discr_method not in methods:
+            raise RuntimeError('self.discr_method must be in [fe, be, bil, zoh]')
+        A = _lib.f64(np.asarray(A_c)); Bm = _lib.f64(np.asarray(B_c)); d = _lib.f64(np.asarray(d_c))
+        Bn, n, m = A.shape[0], A.shape[-1], Bm.shape[-1]
+        Ad = np.empty((Bn, n, n)); Bd = np.empty((Bn, n, m)); dd = np.empty((Bn, n))
+        _lib.check(_lib.lib().stpwl_discretize(C.c_int(methods[self.discr_method]), C.c_int(n), C.c_int(m), C.c_int64(Bn), _lib.dptr(A),
+                                               _lib.dptr(Bm), _lib.dptr(d), C.c_double(float(dt)), _lib.dptr(Ad), _lib.dptr(Bd),
+                                               _lib.dptr(dd)), 'stpwl_discretize')
+        return Ad, Bd, dd
+
     def discretize_dynamics(self, A_c, B_c, d_c, dt):
-        """tpwl.py:272-297 -- one-off host computation per stored point."""
-        I = np.eye(A_c.shape[0])
-        if self.discr_method == 'fe':
-            return I + dt * A_c, dt * B_c, dt * d_c
-        elif self.discr_method == 'be':
-            A_d = np.linalg.inv(I - dt * A_c)
-            sep = np.linalg.inv(A_c) @ (A_d - I)
-            return A_d, sep @ B_c, sep @ d_c
-        elif self.discr_method == 'bil':
-            A_d = (I + 0.5 * dt * A_c) @ np.linalg.inv(I - 0.5 * dt * A_c)
-            sep = np.linalg.inv(A_c) @ (A_d - I)
-            return A_d, sep @ B_c, sep @ d_c
-        elif self.discr_method == 'zoh':
-            return zoh_affine(A_c, B_c, d_c, dt)
-        raise RuntimeError('self.discr_method must be in [fe, be, bil, zoh]')
+        """tpwl.py:272-297 for one model (on the device: discretize_batch)."""
+        A_d, B_d, d_d = self.discretize_batch(np.asarray(A_c)[None], np.asarray(B_c)[None], np.asarray(d_c)[None], dt)
+        return A_d[0], B_d[0], d_d[0]
 
     def pre_discretize(self, dt):
         """tpwl.py:299-322: discretise all stored points, keep them as lists (reference attribute
@@ -320,13 +310,9 @@ class TPWLATV(TPWL):
             raise RuntimeError('tpwl method should be nn to pre-discretize')
         print('Performing pre-discretization using {} of TPWL model with dt = {:.3f}'
               .format(DISCR_DICT[self.discr_method], dt))
-        self.A_d, self.B_d, self.d_d = [], [], []
         Ac, Bc, dc = self._tabs[3], self._tabs[4], self._tabs[5]
-        for i in range(self.num_points):
-            A_d, B_d, d_d = self.discretize_dynamics(Ac[i], Bc[i], dc[i], dt)
-            self.A_d.append(A_d)
-            self.B_d.append(B_d)
-            self.d_d.append(d_d)
+        A_d, B_d, d_d = self.discretize_batch(Ac, Bc, dc, dt)           # all stored points in one launch
+        self.A_d, self.B_d, self.d_d = list(A_d), list(B_d), list(d_d)
         if float(dt) not in self._dt_handles:          # (a handle created earlier for this dt holds the same tables)
             self.handle_for(dt, tables=(self.A_d, self.B_d, self.d_d))
         self.pre_discretized_dt = dt

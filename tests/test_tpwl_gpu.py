@@ -138,3 +138,54 @@ def test_weighting_gusto_host_loop():
     xo, uo, _, tr = ogusto.solve_generic(dyn_d, dyn_c, H, N, dt, Qz, R, x0, u_init, x_init, z=z, x_char=xc, f_char=fc,
                                          convg_thresh=1e-3, max_gusto_iters=4)
     close(xopt, xo, 1e-6); close(uopt, uo, 1e-5)
+
+
+@pytest.mark.parametrize('method', ['fe', 'be', 'bil', 'zoh'])
+@pytest.mark.parametrize('n,m,batch', [(8, 3, 5), (60, 4, 7), (72, 8, 3), (10, 8, 2)])
+def test_device_discretisation_matches_the_reference_formulas(method, n, m, batch):
+    """csrc/discretize.hip (stpwl_discretize) against the restated reference formulas (oracle.tpwl.discretize: tpwl.py:272-297 with
+    its two inverses; zoh through scipy.linalg.expm as utils.py:302-335 does): second-order FEM-like models [[-D, -K], [I, 0]] with
+    stiff and soft modes, so that zoh needs several squarings and be / bil pivot."""
+    import ctypes as C
+    from sofacontrol_amd import _lib
+    rng = np.random.default_rng(1000 * n + m)
+    h = n // 2
+    A = np.zeros((batch, n, n)); B = rng.standard_normal((batch, n, m)); d = rng.standard_normal((batch, n))
+    for b in range(batch):
+        Q, _ = np.linalg.qr(rng.standard_normal((h, h)))
+        K = Q @ np.diag(np.logspace(0, 4.5, h)) @ Q.T                     # stiffness spectrum over 4.5 decades
+        D = 0.02 * K + 0.5 * np.eye(h)
+        A[b, :h, :h], A[b, :h, h:], A[b, h:, :h] = -D, -K, np.eye(h)
+    B[:, h:] = 0.0
+    dt = 0.05
+    Ad = np.empty_like(A); Bd = np.empty_like(B); dd = np.empty_like(d)
+    code = {'fe': 0, 'be': 1, 'bil': 2, 'zoh': 3}[method]
+    _lib.check(_lib.lib().stpwl_discretize(C.c_int(code), C.c_int(n), C.c_int(m), C.c_int64(batch), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d),
+                                           C.c_double(dt), _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)), 'stpwl_discretize')
+    for b in range(batch):
+        Ae, Be, de = otpwl.discretize(A[b], B[b], d[b], dt, method)
+        tol = 1e-15 if method == 'fe' else 1e-10            # (be / bil: the reference's inv(A) route loses cond(A) eps ~ 1e-11 itself)
+        close(Ad[b], Ae, tol); close(Bd[b], Be, tol); close(dd[b], de, tol)
+    if method == 'zoh':
+        # a size-independent property: the exponential of twice the step is the square of the exponential
+        Ad2 = np.empty_like(A); Bd2 = np.empty_like(B); dd2 = np.empty_like(d)
+        _lib.check(_lib.lib().stpwl_discretize(C.c_int(3), C.c_int(n), C.c_int(m), C.c_int64(batch), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d),
+                                               C.c_double(2 * dt), _lib.dptr(Ad2), _lib.dptr(Bd2), _lib.dptr(dd2)), 'stpwl_discretize')
+        close(Ad2, Ad @ Ad, 1e-11)
+        close(Bd2, Ad @ Bd + Bd, 1e-11)
+
+
+def test_device_discretisation_reports_a_singular_model():
+    import ctypes as C
+    from sofacontrol_amd import _lib
+    A = 2.0 * np.eye(4)[None]                                    # I - dt A = 0 at dt = 0.5
+    B = np.ones((1, 4, 2)); d = np.ones((1, 4))
+    Ad = np.empty_like(A); Bd = np.empty_like(B); dd = np.empty_like(d)
+    rc = _lib.lib().stpwl_discretize(C.c_int(1), C.c_int(4), C.c_int(2), C.c_int64(1), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d),
+                                     C.c_double(0.5), _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd))
+    assert rc != 0
+    with pytest.raises(Exception, match='singular'):
+        _lib.check(rc, 'stpwl_discretize')
+    rc = _lib.lib().stpwl_discretize(C.c_int(7), C.c_int(4), C.c_int(2), C.c_int64(1), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d),
+                                     C.c_double(0.05), _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd))
+    assert rc != 0
