@@ -223,18 +223,17 @@ class SSMDynamics(SSM):
         return np.squeeze(H @ x) + np.squeeze(c)
 
     def discretize_dynamics(self, A_c, B_c, d_c, dt):
-        """ssm.py:279-301 on caller-supplied matrices (host helper; the device path discretises in-kernel)."""
-        I = np.eye(A_c.shape[0])
-        if self.discr_method == 'fe':
-            return I + dt * A_c, dt * B_c, dt * d_c
-        elif self.discr_method == 'be':
-            A_d = np.linalg.inv(I - dt * A_c)
-        elif self.discr_method == 'bil':
-            A_d = (I + 0.5 * dt * A_c) @ np.linalg.inv(I - 0.5 * dt * A_c)
-        else:
+        """ssm.py:279-301 on caller-supplied matrices (csrc/discretize.hip; the model's own path discretises in-kernel)."""
+        methods = {'fe': 0, 'be': 1, 'bil': 2}
+        if self.discr_method not in methods:
             raise RuntimeError('self.discr_method must be in [fe, be, bil, zoh]')
-        sep = np.linalg.inv(A_c) @ (A_d - I)
-        return A_d, sep @ B_c, sep @ d_c
+        A = _lib.f64(np.asarray(A_c)); B = _lib.f64(np.asarray(B_c)); d = _lib.f64(np.asarray(d_c).reshape(-1))
+        n, m = B.shape
+        Ad = np.empty((n, n)); Bd = np.empty((n, m)); dd = np.empty(n)
+        _lib.check(_lib.lib().stpwl_discretize(C.c_int(methods[self.discr_method]), C.c_int(n), C.c_int(m), C.c_int64(1), _lib.dptr(A),
+                                               _lib.dptr(B), _lib.dptr(d), C.c_double(float(dt)), _lib.dptr(Ad), _lib.dptr(Bd),
+                                               _lib.dptr(dd)), 'stpwl_discretize')
+        return Ad, Bd, dd
 
     @staticmethod
     def update_dynamics(x, u, A_d, B_d, d_d):

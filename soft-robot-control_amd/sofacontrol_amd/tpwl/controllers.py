@@ -287,9 +287,8 @@ class scp(TemplateController):
 
     def _point_gains(self, cost, dt):
         tab = self.dyn_sys.tpwl_dict
-        disc = [self.dyn_sys.discretize_dynamics(tab['A_c'][i], tab['B_c'][i], tab['d_c'][i], dt)[:2]
-                for i in range(self.dyn_sys.num_points)]
-        gains, _ = dare_batch(np.stack([a for a, _ in disc]), np.stack([b for _, b in disc]), cost.Q, cost.R)
+        Ad, Bd, _ = self.dyn_sys.discretize_batch(np.stack(tab['A_c']), np.stack(tab['B_c']), np.stack(tab['d_c']), dt)   # one launch
+        gains, _ = dare_batch(Ad, Bd, cost.Q, cost.R)
         return list(gains)
 
     # tape views under the reference's attribute names

@@ -184,21 +184,22 @@ def extract_AB_d(S, K, H, dt):
 
 
 def zoh_linear(A, B, dt):
-    """sofacontrol/utils.py:302-320: exact zero-order-hold discretisation, expm([[A, B], [0, 0]] dt).  One-off host
-    computation per stored TPWL point."""
-    from scipy.linalg import expm
-    n, m = B.shape
-    M = np.zeros((n + m, n + m))
-    M[:n, :n] = A
-    M[:n, n:] = B
-    Z = expm(M * dt)
-    return Z[:n, :n], Z[:n, n:]
+    """sofacontrol/utils.py:302-320: exact zero-order-hold discretisation, expm([[A, B], [0, 0]] dt) -- on the device
+    (csrc/discretize.hip: scaling and squaring, [13/13] Pade approximant)."""
+    A_d, B_d, _ = zoh_affine(A, B, np.zeros(np.shape(A)[0]), dt)
+    return A_d, B_d
 
 
 def zoh_affine(A, B, d, dt):
-    """sofacontrol/utils.py:323-335: the affine term rides along as one more input column."""
-    A_d, B_ext = zoh_linear(A, np.hstack((B, np.expand_dims(d, axis=-1))), dt)
-    return A_d, B_ext[:, :-1], B_ext[:, -1]
+    """sofacontrol/utils.py:323-335: expm([[A, B, d], [0, 0, 0]] dt); the affine term rides along as one more input column."""
+    import ctypes as C
+    from . import _lib
+    A = _lib.f64(np.asarray(A)); B = _lib.f64(np.asarray(B)); d = _lib.f64(np.asarray(d).reshape(-1))
+    n, m = B.shape
+    Ad = np.empty((n, n)); Bd = np.empty((n, m)); dd = np.empty(n)
+    _lib.check(_lib.lib().stpwl_discretize(C.c_int(3), C.c_int(n), C.c_int(m), C.c_int64(1), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d),
+                                           C.c_double(float(dt)), _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)), 'stpwl_discretize')
+    return Ad, Bd, dd
 
 
 def sparse_list_to_np_array(matrix_list):
