@@ -592,6 +592,48 @@ def pod_shapes(L, _lib, B=65536):
     return out
 
 
+def model_prep(_lib):
+    """Round-6 kernels off the SCP path, each beside the host routine the reference calls for it: time discretisation of one horizon of
+    blended TPWL models (tpwl.py:244-250, 272-297: scipy.linalg.expm / numpy inverses per model) and the full-spectrum eigh of a
+    2048-snapshot Gramian without a vendor library (mor/pod.py:181-200: numpy SVD)."""
+    import ctypes as C
+    from sofacontrol_amd.mor.pod import _device_eigh
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import tpwl as otpwl
+    rng = np.random.default_rng(0)
+    n, m, batch, h = 60, 4, 51, 30
+    A = np.zeros((batch, n, n)); B = rng.standard_normal((batch, n, m)); d = rng.standard_normal((batch, n))
+    for b in range(batch):
+        Q, _ = np.linalg.qr(rng.standard_normal((h, h)))
+        K = Q @ np.diag(np.logspace(0, 4.5, h)) @ Q.T
+        A[b, :h, :h], A[b, :h, h:], A[b, h:, :h] = -(0.02 * K + 0.5 * np.eye(h)), -K, np.eye(h)
+    Ad = np.empty_like(A); Bd = np.empty_like(B); dd = np.empty_like(d)
+    res = {'discretize': {'workload': '51 affine models, n_x = 60, n_u = 4 (one horizon of a weighting-mode TPWL linearisation), dt = 0.05, host buffers'}}
+    for name, code in (('be', 1), ('bil', 2), ('zoh', 3)):
+        ts = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            _lib.check(_lib.lib().stpwl_discretize(C.c_int(code), C.c_int(n), C.c_int(m), C.c_int64(batch), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d),
+                                                   C.c_double(0.05), _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)), 'stpwl_discretize')
+            ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        worst = 0.0
+        for b in range(batch):
+            Ae, Be, de = otpwl.discretize(A[b], B[b], d[b], 0.05, name)
+            worst = max(worst, float(np.abs(Ad[b] - Ae).max() / max(1.0, np.abs(Ae).max())))
+        res['discretize'][name] = {'ms': min(ts[1:]) * 1e3, 'cpu_ms': (time.perf_counter() - t0) * 1e3, 'max_rel_A_vs_cpu': worst}
+    ns = 2048
+    S = rng.standard_normal((ns, ns + 3)) * np.logspace(0, -3, ns + 3)
+    G = S @ S.T
+    _device_eigh(G[:256, :256])
+    t0 = time.perf_counter(); w, W = _device_eigh(G); t1 = time.perf_counter()
+    t2 = time.perf_counter(); we, We = np.linalg.eigh(G); t3 = time.perf_counter()
+    res['eigh_2048'] = {'kernel': 'block Jacobi (csrc/eigh.hip: bj_sub_kernel, bj_update_a_kernel, bj_update_v_kernel), eigenvectors included',
+                        'ms': (t1 - t0) * 1e3, 'cpu_ms_numpy_eigh': (t3 - t2) * 1e3, 'blas_threads': int(os.environ.get('OPENBLAS_NUM_THREADS', '0') or 0),
+                        'max_rel_w_vs_cpu': float(np.abs(w - we).max() / np.abs(we).max())}
+    return res
+
+
 def secondary(L, _lib, rank, world, dist):
     import workloads as wl
     """Secondary metrics of SURVEY.md section 8(d), measured outside the timed region of the headline metric:
@@ -855,6 +897,11 @@ def secondary(L, _lib, rank, world, dist):
         out['pod_shapes'] = pod_shapes(L, _lib)
     except Exception as exc:
         out['pod_shapes'] = {'error': repr(exc)}
+    if world == 1:
+        try:
+            out['model_prep'] = model_prep(_lib)
+        except Exception as exc:
+            out['model_prep'] = {'error': repr(exc)}
     try:
         out['scp_c5'] = scp_c5(_lib, rank, world, dist, cpu=(world == 1 and rank == 0))
         if world == 1:       # what one GPU of an 8-GPU node gets of the 256 rollouts
