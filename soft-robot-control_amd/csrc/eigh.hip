@@ -1,6 +1,6 @@
 // Symmetric eigendecomposition of the snapshot Gramian on the device (method-of-snapshots POD,
 // sofacontrol/mor/pod.py:181-200 takes a thin SVD instead) and selection of the kept modes.
-// n_s <= 128: one-workgroup Jacobi in LDS; n_s <= 1024: the same Jacobi over HBM, two launches per step; n_s <= 2048: the
+// n_s <= 128: one-workgroup Jacobi in LDS; n_s <= 256: the same Jacobi over HBM, two launches per step; n_s <= 2048: the
 // block Jacobi below; larger: rocSOLVER's dsyevd, resolved at run time with dlopen so that the library does not depend on it (its first load in a process
 // takes minutes on a cold box) -- and where it cannot be loaded, or under SRH_EIGH_BLOCK=1, a two-sided block Jacobi on the
 // MFMA pipe (round 6; no library).
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_eigh_kernel(double *__restrict_
 // pair 0 = (ne-1, s), pair i = ((s+i) mod (ne-1), (s-i) mod (ne-1)).  ~10 sweeps x (n-1) steps x 2 launches: tens of
 // milliseconds at n = 1000 -- against minutes for the first rocSOLVER / rocBLAS load of a process on a cold box.
 constexpr int JAC_GRID_MAX = 2048;
-constexpr int JAC_BLOCK_MIN = 1024;      // above: the block Jacobi further down (SRH_EIGH_BLOCK=0: the scalar form up to 2048)
+constexpr int JAC_BLOCK_MIN = 256;       // above: the block Jacobi further down (SRH_EIGH_BLOCK=0: the scalar form up to 2048)
 
 __device__ __forceinline__ void jac_pair(int i, int step, int ne, int &p, int &q) {
     const int m = ne - 1;
@@ -316,33 +316,39 @@ int jacobi_grid(double *G_dev, int n, double *w_dev, hipStream_t st) {
 // two chained 128^3 products per tile on the f64 MFMA pipe with the tile in LDS (`bj_update_a_kernel`, `bj_update_v_kernel`).
 // Per step 2 n^2 x 128 x 2 flops instead of the n^2 x 8 bytes of traffic PER ROTATION of the scalar form: the scalar form at n = 10 000
 // would move 32 TB per sweep.  Pairs whose off-diagonal block is already at the rounding floor are skipped (identity, flag 0).
-constexpr int BJ_B = 64, BJ_P = 2 * BJ_B, BJ_LD = BJ_P + 16;        // ld = 144: (4 s + kk) ld + l16 hits 32 different 8-byte banks per half wave
-constexpr int BJ_NT = 512;
+// Pair size P (template): 128 (64-wide blocks; Qt of the pair problem in L2) or 64 (32-wide blocks: S AND Qt of the pair problem in LDS,
+// an inner sweep of 63 steps at LDS latency -- 7 x faster than the 127 steps of the larger pair with Qt behind L2, for twice as many
+// outer steps of half the flops each).  The update kernels run P / 16 waves (one 16-row strip each), tile row stride P + 16 doubles:
+// (4 s + kk) ld + l16 hits 32 different 8-byte banks per half wave.
 typedef double bj_d4 __attribute__((ext_vector_type(4)));
+constexpr int BJ_SUB_NT = 512;
 
-__device__ __forceinline__ int bj_index(int blk_p, int blk_q, int k) { return (k < BJ_B ? blk_p : blk_q) * BJ_B + (k & (BJ_B - 1)); }
+template <int P>
+__device__ __forceinline__ int bj_index(int blk_p, int blk_q, int k) { return (k < P / 2 ? blk_p : blk_q) * (P / 2) + (k & (P / 2 - 1)); }
 
-__global__ __launch_bounds__(BJ_NT) void bj_sub_kernel(const double *__restrict__ A, int ne, int nb, int step, double *__restrict__ Qt_all,
+template <int P>
+__global__ __launch_bounds__(BJ_SUB_NT) void bj_sub_kernel(const double *__restrict__ A, int ne, int nb, int step, double *__restrict__ Qt_all,
                                                        int *__restrict__ flags, int *__restrict__ perm_all, int order, int inner_max) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int n = BJ_P, h = BJ_P / 2, ld = BJ_P + 1;
+    constexpr int n = P, h = P / 2, ld = P + 1;
+    constexpr bool QLDS = P <= 64;             // Qt beside S in LDS
     const int tid = threadIdx.x, nt = blockDim.x;
-    int P, Q;
-    jac_pair(blockIdx.x, step, nb, P, Q);
+    int Pb, Qb;
+    jac_pair(blockIdx.x, step, nb, Pb, Qb);
     lptr S = (lptr)smem;                       // n x ld
     lptr cs = S + (size_t)n * ld;              // (c, s) per pair
     lptr red = cs + 2 * h;                     // 64
     liptr pq = (liptr)(red + 64);              // (p, q) per pair
-    double *Qt = Qt_all + (size_t)blockIdx.x * n * n;
+    double *Qg = Qt_all + (size_t)blockIdx.x * n * n;
     int *perm = perm_all + (size_t)blockIdx.x * n;
     lptr d0 = cs;                              // the diagonal before the rotations (cs is free until the first step)
     double off2 = 0.0, dg2 = 0.0;
     for (int i = tid; i < n; i += nt) perm[i] = i;
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e % n;
-        const double v = A[(size_t)bj_index(P, Q, i) * ne + bj_index(P, Q, j)];
+        const double v = A[(size_t)bj_index<P>(Pb, Qb, i) * ne + bj_index<P>(Pb, Qb, j)];
         S[i * ld + j] = v;
-        Qt[e] = (i == j) ? 1.0 : 0.0;
+        Qg[e] = (i == j) ? 1.0 : 0.0;
         if (i == j) dg2 = fma(v, v, dg2); else off2 = fma(v, v, off2);
     }
     off2 = wg::reduce(off2, 0, red);
@@ -354,7 +360,10 @@ __global__ __launch_bounds__(BJ_NT) void bj_sub_kernel(const double *__restrict_
     if (tid == 0) flags[blockIdx.x] = 1;
     __syncthreads();
     lptr dsave = red + 64 + h;                 // (behind pq)
+    lptr Ql = dsave + n;                       // P <= 64: Qt in LDS (n x ld)
     for (int i = tid; i < n; i += nt) dsave[i] = S[i * ld + i];
+    if (QLDS)
+        for (int e = tid; e < n * n; e += nt) Ql[(e / n) * ld + e % n] = (e / n == e % n) ? 1.0 : 0.0;
     __syncthreads();
     // inner sweeps (inner_max, default ONE).  Measured at n = 3000 (graded random Gramian): solving the sub-problem to the rounding
     // floor (up to 10 inner sweeps) does not buy outer sweeps -- 19 against 21 -- and costs 0.6 ms per inner sweep: 4.6 s against
@@ -389,15 +398,21 @@ __global__ __launch_bounds__(BJ_NT) void bj_sub_kernel(const double *__restrict_
                 S[q * ld + pj] = cj * b10 - sj * b11;
                 S[q * ld + qj] = sj * b10 + cj * b11;
             }
-            // rows of Qt (L2): independent iterations, loads issued four pairs deep
+            // rows of Qt (LDS, or L2: independent iterations, loads issued four pairs deep)
 #pragma unroll 4
             for (int e = tid; e < h * n; e += nt) {
                 const int i = e / n, k = e % n;
                 const int p = pq[2 * i], q = pq[2 * i + 1];
                 const double c = cs[2 * i], sn = cs[2 * i + 1];
-                const double vp = Qt[p * n + k], vq = Qt[q * n + k];
-                Qt[p * n + k] = c * vp - sn * vq;
-                Qt[q * n + k] = sn * vp + c * vq;
+                if (QLDS) {
+                    const double vp = Ql[p * ld + k], vq = Ql[q * ld + k];
+                    Ql[p * ld + k] = c * vp - sn * vq;
+                    Ql[q * ld + k] = sn * vp + c * vq;
+                } else {
+                    const double vp = Qg[p * n + k], vq = Qg[q * n + k];
+                    Qg[p * n + k] = c * vp - sn * vq;
+                    Qg[q * n + k] = sn * vp + c * vq;
+                }
             }
             __syncthreads();
         }
@@ -410,6 +425,10 @@ __global__ __launch_bounds__(BJ_NT) void bj_sub_kernel(const double *__restrict_
         o2 = wg::reduce(o2, 0, red);
         d2 = wg::reduce(d2, 0, red);
         if (o2 <= 1e-30 * d2) break;
+    }
+    if (QLDS) {
+        __syncthreads();
+        for (int e = tid; e < n * n; e += nt) Qg[e] = Ql[(e / n) * ld + e % n];
     }
     // which eigenpair goes to which index of the pair.  order 1: position i, whose diagonal entry was the r-th largest before the
     // rotations, receives the r-th largest eigenvalue -- the block analogue of the scalar method's small angle (no exchange): Qt stays
@@ -441,92 +460,98 @@ __global__ __launch_bounds__(BJ_NT) void bj_sub_kernel(const double *__restrict_
 }
 
 // T[16 w + kk + 4 q][16 ct + l16] = sum_k Qt[16 w + l16'][k] X[k][16 ct + l16]: wave w's 16-row strip of Qt X for the tile X in LDS
-// (row stride BJ_LD); the strip of Qt sits in registers (the MFMA A operand: lane (l16, kk) holds Qt[16 w + l16][4 s + kk], s < 32)
+// (row stride P + 16); the strip of Qt sits in registers (the MFMA A operand: lane (l16, kk) holds Qt[16 w + l16][4 s + kk], s < 32)
+template <int P>
 __device__ __forceinline__ void bj_strip_product(const double *__restrict__ Qt, const int *__restrict__ perm, lptr X, int wave, int l16, int kk,
-                                                 bj_d4 (&acc)[8]) {
-    double qa[32];
+                                                 bj_d4 (&acc)[P / 16]) {
+    constexpr int LD = P + 16;
+    double qa[P / 4];
     const int row = perm[16 * wave + l16];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) qa[s] = Qt[(size_t)row * BJ_P + 4 * s + kk];
+    for (int s = 0; s < P / 4; ++s) qa[s] = Qt[(size_t)row * P + 4 * s + kk];
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) acc[ct] = {0.0, 0.0, 0.0, 0.0};
+    for (int ct = 0; ct < P / 16; ++ct) acc[ct] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-    for (int s = 0; s < 32; ++s) {
+    for (int s = 0; s < P / 4; ++s) {
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], X[(4 * s + kk) * BJ_LD + 16 * ct + l16], acc[ct], 0, 0, 0);
+        for (int ct = 0; ct < P / 16; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], X[(4 * s + kk) * LD + 16 * ct + l16], acc[ct], 0, 0, 0);
     }
 }
 
 // one tile (pair i, pair j), i <= j, of A <- Qt_i A Qt_j' and its mirror
-__global__ __launch_bounds__(BJ_NT) void bj_update_a_kernel(double *__restrict__ A, int ne, int nb, int step, const double *__restrict__ Qt_all,
+template <int P>
+__global__ __launch_bounds__(P * 4) void bj_update_a_kernel(double *__restrict__ A, int ne, int nb, int step, const double *__restrict__ Qt_all,
                                                             const int *__restrict__ flags, const int *__restrict__ perm_all) {
     const int pi = blockIdx.y, pj = blockIdx.x;
     if (pi > pj || (flags[pi] == 0 && flags[pj] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LD = P + 16;
     lptr X = (lptr)smem;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, kk = lane >> 4;
     int Pi, Qi, Pj, Qj;
     jac_pair(pi, step, nb, Pi, Qi);
     jac_pair(pj, step, nb, Pj, Qj);
-    for (int e = tid; e < BJ_P * BJ_P; e += BJ_NT) {
-        const int k = e >> 7, t = e & (BJ_P - 1);
-        X[k * BJ_LD + t] = A[(size_t)bj_index(Pi, Qi, k) * ne + bj_index(Pj, Qj, t)];
+    for (int e = tid; e < P * P; e += P * 4) {
+        const int k = e / P, t = e % P;
+        X[k * LD + t] = A[(size_t)bj_index<P>(Pi, Qi, k) * ne + bj_index<P>(Pj, Qj, t)];
     }
     __syncthreads();
-    bj_d4 acc[8];
-    bj_strip_product(Qt_all + (size_t)pi * BJ_P * BJ_P, perm_all + (size_t)pi * BJ_P, X, wave, l16, kk, acc);       // T1 = Qt_i X
+    bj_d4 acc[P / 16];
+    bj_strip_product<P>(Qt_all + (size_t)pi * P * P, perm_all + (size_t)pi * P, X, wave, l16, kk, acc);       // T1 = Qt_i X
     __syncthreads();
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)                                                     // Y = T1' over X
+    for (int ct = 0; ct < P / 16; ++ct)                                                     // Y = T1' over X
 #pragma unroll
-        for (int q = 0; q < 4; ++q) X[(16 * ct + l16) * BJ_LD + 16 * wave + kk + 4 * q] = acc[ct][q];
+        for (int q = 0; q < 4; ++q) X[(16 * ct + l16) * LD + 16 * wave + kk + 4 * q] = acc[ct][q];
     __syncthreads();
-    bj_strip_product(Qt_all + (size_t)pj * BJ_P * BJ_P, perm_all + (size_t)pj * BJ_P, X, wave, l16, kk, acc);       // out' = Qt_j T1'
+    bj_strip_product<P>(Qt_all + (size_t)pj * P * P, perm_all + (size_t)pj * P, X, wave, l16, kk, acc);       // out' = Qt_j T1'
     __syncthreads();
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)                                                     // out[r][c], r = 16 rt + l16, c = 16 w + kk + 4 q
+    for (int rt = 0; rt < P / 16; ++rt)                                                     // out[r][c], r = 16 rt + l16, c = 16 w + kk + 4 q
 #pragma unroll
-        for (int q = 0; q < 4; ++q) X[(16 * rt + l16) * BJ_LD + 16 * wave + kk + 4 * q] = acc[rt][q];
+        for (int q = 0; q < 4; ++q) X[(16 * rt + l16) * LD + 16 * wave + kk + 4 * q] = acc[rt][q];
     __syncthreads();
     if (pi == pj) {
-        for (int e = tid; e < BJ_P * BJ_P; e += BJ_NT) {
-            const int r = e >> 7, c = e & (BJ_P - 1);
-            A[(size_t)bj_index(Pi, Qi, r) * ne + bj_index(Pi, Qi, c)] = 0.5 * (X[r * BJ_LD + c] + X[c * BJ_LD + r]);
+        for (int e = tid; e < P * P; e += P * 4) {
+            const int r = e / P, c = e % P;
+            A[(size_t)bj_index<P>(Pi, Qi, r) * ne + bj_index<P>(Pi, Qi, c)] = 0.5 * (X[r * LD + c] + X[c * LD + r]);
         }
         return;
     }
-    for (int e = tid; e < BJ_P * BJ_P; e += BJ_NT) {
-        const int r = e >> 7, c = e & (BJ_P - 1);
-        A[(size_t)bj_index(Pi, Qi, r) * ne + bj_index(Pj, Qj, c)] = X[r * BJ_LD + c];
+    for (int e = tid; e < P * P; e += P * 4) {
+        const int r = e / P, c = e % P;
+        A[(size_t)bj_index<P>(Pi, Qi, r) * ne + bj_index<P>(Pj, Qj, c)] = X[r * LD + c];
     }
-    for (int e = tid; e < BJ_P * BJ_P; e += BJ_NT) {                                   // the mirror tile (rows of pair j)
-        const int c = e >> 7, r = e & (BJ_P - 1);
-        A[(size_t)bj_index(Pj, Qj, c) * ne + bj_index(Pi, Qi, r)] = X[r * BJ_LD + c];
+    for (int e = tid; e < P * P; e += P * 4) {                                   // the mirror tile (rows of pair j)
+        const int c = e / P, r = e % P;
+        A[(size_t)bj_index<P>(Pj, Qj, c) * ne + bj_index<P>(Pi, Qi, r)] = X[r * LD + c];
     }
 }
 
 // Vt[rows of pair i, 128 columns] <- Qt_i Vt[...]
-__global__ __launch_bounds__(BJ_NT) void bj_update_v_kernel(double *__restrict__ Vt, int ne, int nb, int step, const double *__restrict__ Qt_all,
+template <int P>
+__global__ __launch_bounds__(P * 4) void bj_update_v_kernel(double *__restrict__ Vt, int ne, int nb, int step, const double *__restrict__ Qt_all,
                                                             const int *__restrict__ flags, const int *__restrict__ perm_all) {
-    const int pi = blockIdx.y, c0 = blockIdx.x * BJ_P;
+    const int pi = blockIdx.y, c0 = blockIdx.x * P;
     if (flags[pi] == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LD = P + 16;
     lptr X = (lptr)smem;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l16 = lane & 15, kk = lane >> 4;
     int Pi, Qi;
     jac_pair(pi, step, nb, Pi, Qi);
-    for (int e = tid; e < BJ_P * BJ_P; e += BJ_NT) {
-        const int k = e >> 7, t = e & (BJ_P - 1);
-        X[k * BJ_LD + t] = Vt[(size_t)bj_index(Pi, Qi, k) * ne + c0 + t];
+    for (int e = tid; e < P * P; e += P * 4) {
+        const int k = e / P, t = e % P;
+        X[k * LD + t] = Vt[(size_t)bj_index<P>(Pi, Qi, k) * ne + c0 + t];
     }
     __syncthreads();
-    bj_d4 acc[8];
-    bj_strip_product(Qt_all + (size_t)pi * BJ_P * BJ_P, perm_all + (size_t)pi * BJ_P, X, wave, l16, kk, acc);
+    bj_d4 acc[P / 16];
+    bj_strip_product<P>(Qt_all + (size_t)pi * P * P, perm_all + (size_t)pi * P, X, wave, l16, kk, acc);
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
+    for (int ct = 0; ct < P / 16; ++ct)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Vt[(size_t)bj_index(Pi, Qi, 16 * wave + kk + 4 * q) * ne + c0 + 16 * ct + l16] = acc[ct][q];
+        for (int q = 0; q < 4; ++q) Vt[(size_t)bj_index<P>(Pi, Qi, 16 * wave + kk + 4 * q) * ne + c0 + 16 * ct + l16] = acc[ct][q];
 }
 
 // The ordering of the pair problems moves eigenpairs between positions, the padding's (eigenvalue 0, a unit vector in a padding
@@ -559,30 +584,31 @@ __global__ void bj_gather_kernel(const double *__restrict__ Vt, const int *__res
     if (k < n && rank[p] >= 0) G[(size_t)rank[p] * n + k] = Vt[(size_t)p * ne + k];
 }
 
-int jacobi_block(double *G_dev, int n, double *w_dev, hipStream_t st) {
-    const int ne = (n + BJ_P - 1) / BJ_P * BJ_P, nb = ne / BJ_B, np = nb / 2;
+template <int P>
+int jacobi_block_p(double *G_dev, int n, double *w_dev, hipStream_t st) {
+    const int ne = (n + P - 1) / P * P, nb = ne / (P / 2), np = nb / 2;
     srh::DevBuf A, Vt, Qt, flags, perm, part, rank;
     const int order = getenv("SRH_EIGH_BLOCK_ORDER") ? atoi(getenv("SRH_EIGH_BLOCK_ORDER")) : 2;
     const int inner_max = getenv("SRH_EIGH_BLOCK_INNER") ? atoi(getenv("SRH_EIGH_BLOCK_INNER")) : 1;
     int rc;
     if ((rc = A.alloc(sizeof(double) * (size_t)ne * ne)) || (rc = Vt.alloc(sizeof(double) * (size_t)ne * ne)) ||
-        (rc = Qt.alloc(sizeof(double) * (size_t)np * BJ_P * BJ_P)) || (rc = flags.alloc(sizeof(int) * np)) || (rc = perm.alloc(sizeof(int) * (size_t)np * BJ_P)) ||
+        (rc = Qt.alloc(sizeof(double) * (size_t)np * P * P)) || (rc = flags.alloc(sizeof(int) * np)) || (rc = perm.alloc(sizeof(int) * (size_t)np * P)) ||
         (rc = part.alloc(sizeof(double) * 2 * ne)) || (rc = rank.alloc(sizeof(int) * ne)))
         return rc;
-    const size_t lds_sub = srh::lds_request(sizeof(double) * ((size_t)BJ_P * (BJ_P + 1) + 2 * BJ_P + 64 + BJ_P) + sizeof(int) * BJ_P + 64);
-    const size_t lds_upd = srh::lds_request(sizeof(double) * (size_t)BJ_P * BJ_LD);
-    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)bj_sub_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub));
-    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)bj_update_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
-    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)bj_update_v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
+    const size_t lds_sub = srh::lds_request(sizeof(double) * ((size_t)P * (P + 1) * (P <= 64 ? 2 : 1) + 2 * P + 64 + P) + sizeof(int) * P + 64);
+    const size_t lds_upd = srh::lds_request(sizeof(double) * (size_t)P * (P + 16));
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)bj_sub_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sub));
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)bj_update_a_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
+    SRH_CHECK_HIP(hipFuncSetAttribute((const void *)bj_update_v_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
     jac_init_kernel<<<(unsigned)srh::cdiv((int64_t)ne * ne, 256), 256, 0, st>>>(G_dev, n, ne, A.as<double>(), Vt.as<double>());
     std::vector<double> hp(2 * (size_t)ne);
     double prev = INFINITY;
     bool done = false;
-    for (int sweep = 0; sweep < 40 && !done; ++sweep) {
+    for (int sweep = 0; sweep < 100 && !done; ++sweep) {      // (rank-deficient Gramians of several thousand snapshots: 40+ sweeps of the 64-pairs)
         for (int step = 0; step < nb - 1; ++step) {
-            bj_sub_kernel<<<(unsigned)np, BJ_NT, lds_sub, st>>>(A.as<double>(), ne, nb, step, Qt.as<double>(), flags.as<int>(), perm.as<int>(), order, inner_max);
-            bj_update_a_kernel<<<dim3((unsigned)np, (unsigned)np), BJ_NT, lds_upd, st>>>(A.as<double>(), ne, nb, step, Qt.as<double>(), flags.as<int>(), perm.as<int>());
-            bj_update_v_kernel<<<dim3((unsigned)(ne / BJ_P), (unsigned)np), BJ_NT, lds_upd, st>>>(Vt.as<double>(), ne, nb, step, Qt.as<double>(), flags.as<int>(), perm.as<int>());
+            bj_sub_kernel<P><<<(unsigned)np, BJ_SUB_NT, lds_sub, st>>>(A.as<double>(), ne, nb, step, Qt.as<double>(), flags.as<int>(), perm.as<int>(), order, inner_max);
+            bj_update_a_kernel<P><<<dim3((unsigned)np, (unsigned)np), P * 4, lds_upd, st>>>(A.as<double>(), ne, nb, step, Qt.as<double>(), flags.as<int>(), perm.as<int>());
+            bj_update_v_kernel<P><<<dim3((unsigned)(ne / P), (unsigned)np), P * 4, lds_upd, st>>>(Vt.as<double>(), ne, nb, step, Qt.as<double>(), flags.as<int>(), perm.as<int>());
         }
         jac_norms_kernel<<<(unsigned)ne, 256, 0, st>>>(A.as<double>(), ne, part.as<double>());
         SRH_CHECK_HIP(hipGetLastError());
@@ -604,6 +630,16 @@ int jacobi_block(double *G_dev, int n, double *w_dev, hipStream_t st) {
     SRH_CHECK_HIP(hipGetLastError());
     SRH_CHECK_HIP(hipStreamSynchronize(st));
     return SRH_OK;
+}
+
+
+// pair size: 64 up to SRH_EIGH_BLOCK_SWITCH (default 8192) snapshots, 128 above (SRH_EIGH_BLOCK_PAIR=64 / 128 forces one).  Measured
+// 64 / 128: 0.11 / 0.28 s at 1200, 0.28 / 0.54 s at 2048, 0.53 / 1.01 s at 3000, 2.2 / 3.5 s at 5000, 17.9 / 18.2 s at 10 000.
+int jacobi_block(double *G_dev, int n, double *w_dev, hipStream_t st) {
+    const char *force = getenv("SRH_EIGH_BLOCK_PAIR");
+    const int sw = getenv("SRH_EIGH_BLOCK_SWITCH") ? atoi(getenv("SRH_EIGH_BLOCK_SWITCH")) : 8192;
+    const int P = force ? atoi(force) : (n <= sw ? 64 : 128);
+    return P == 64 ? jacobi_block_p<64>(G_dev, n, w_dev, st) : jacobi_block_p<128>(G_dev, n, w_dev, st);
 }
 
 }  // namespace
@@ -634,7 +670,7 @@ int srom_eigh_dev(double *G_dev, int64_t n, double *w_dev, void *stream) {
     // SRH_EIGH_BLOCK=1: the library-free block Jacobi for every n > 128 (tests, boxes without rocSOLVER)
     const bool want_block = getenv("SRH_EIGH_BLOCK") && atoi(getenv("SRH_EIGH_BLOCK")) != 0 && !getenv("SRH_EIGH_ROCSOLVER");
     if (want_block && n > JAC_MAX) return jacobi_block(G_dev, (int)n, w_dev, (hipStream_t)stream);
-    // 1024 < n <= 2048: the block form has overtaken the scalar one (0.36 / 0.28 s at 1200, 1.37 / 0.55 s at 2048; 0.18 / 0.17 at 800)
+    // 256 < n <= 2048: the block form (pairs of 64) against the scalar one: 17 / 38 ms at 300, 42 / 105 ms at 600, 0.11 / 0.36 s at 1200, 0.28 / 1.37 s at 2048
     if (n > JAC_BLOCK_MIN && n <= JAC_GRID_MAX && !getenv("SRH_EIGH_ROCSOLVER") && !(getenv("SRH_EIGH_BLOCK") && atoi(getenv("SRH_EIGH_BLOCK")) == 0))
         return jacobi_block(G_dev, (int)n, w_dev, (hipStream_t)stream);
     if (n <= JAC_GRID_MAX && !getenv("SRH_EIGH_ROCSOLVER")) return jacobi_grid(G_dev, (int)n, w_dev, (hipStream_t)stream);
