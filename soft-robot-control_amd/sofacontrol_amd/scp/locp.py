@@ -298,18 +298,25 @@ class LOCP:
             else:
                 proj = lambda v: v / max(1.0, float(np.linalg.norm(v)))
                 cur = e0
+                stalled = 0
                 step = 1.0 / max(float(np.linalg.norm(e0['g'])), 1e-300)      # the first step reaches the sphere
                 for it in range(200):
                     mu_n = proj(cur['mu'] + step * cur['g'])
                     e = evaluate(mu_n)
                     if e is None:
                         return np.inf, False, None
-                    if e['dual'] < cur['dual'] - 1e-12 * max(1.0, abs(cur['dual'])):
-                        step *= 0.25                                           # overshoot: the dual must not fall
+                    # overshoot: the dual must not fall -- by more than what the QP solves resolve (their objectives carry ~1e-9
+                    # relative; near the optimum the differences are smaller than that and the gradient alone steers)
+                    if e['dual'] < cur['dual'] - 1e-8 * max(1.0, abs(cur['dual'])) and step > 1e-12:
+                        step *= 0.25
                         continue
+                    if e['gap'] < 0.9 * best['gap']:
+                        stalled = 0
+                    else:
+                        stalled += 1
                     if e['gap'] < best['gap']:
                         best = e
-                    if good(e):
+                    if good(e) or stalled > 12:                                # (stalled: the gap sits at what the QP solves resolve)
                         break
                     dm, dg = e['mu'] - cur['mu'], e['g'] - cur['g']
                     curv = -float(dm @ dg)
