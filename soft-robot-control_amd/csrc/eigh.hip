@@ -341,7 +341,6 @@ __global__ __launch_bounds__(BJ_SUB_NT) void bj_sub_kernel(const double *__restr
     liptr pq = (liptr)(red + 64);              // (p, q) per pair
     double *Qg = Qt_all + (size_t)blockIdx.x * n * n;
     int *perm = perm_all + (size_t)blockIdx.x * n;
-    lptr d0 = cs;                              // the diagonal before the rotations (cs is free until the first step)
     double off2 = 0.0, dg2 = 0.0;
     for (int i = tid; i < n; i += nt) perm[i] = i;
     for (int e = tid; e < n * n; e += nt) {
