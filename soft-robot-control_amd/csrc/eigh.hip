@@ -1,6 +1,6 @@
 // Symmetric eigendecomposition of the snapshot Gramian on the device (method-of-snapshots POD,
 // sofacontrol/mor/pod.py:181-200 takes a thin SVD instead) and selection of the kept modes.
-// n_s <= 128: one-workgroup Jacobi in LDS; n_s <= 256: the same Jacobi over HBM, two launches per step; n_s <= 2048: the
+// n_s <= 128: one-workgroup Jacobi in LDS; n_s <= 256: the same Jacobi over HBM, two launches per step; n_s <= 4096: the
 // block Jacobi below; larger: rocSOLVER's dsyevd, resolved at run time with dlopen so that the library does not depend on it (its first load in a process
 // takes minutes on a cold box) -- and where it cannot be loaded, or under SRH_EIGH_BLOCK=1, a two-sided block Jacobi on the
 // MFMA pipe (round 6; no library).
@@ -164,6 +164,8 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_eigh_kernel(double *__restrict_
 // milliseconds at n = 1000 -- against minutes for the first rocSOLVER / rocBLAS load of a process on a cold box.
 constexpr int JAC_GRID_MAX = 2048;
 constexpr int JAC_BLOCK_MIN = 256;       // above: the block Jacobi further down (SRH_EIGH_BLOCK=0: the scalar form up to 2048)
+constexpr int JAC_BLOCK_MAX = 4096;      // up to here the block Jacobi is the default: 0.28 s at 2048, 0.53 s at 3000 -- rocSOLVER is faster once
+                                         // resident (0.06 / 0.1 s), but its first load in a process costs up to two minutes
 
 __device__ __forceinline__ void jac_pair(int i, int step, int ne, int &p, int &q) {
     const int m = ne - 1;
@@ -670,10 +672,10 @@ int srom_eigh_dev(double *G_dev, int64_t n, double *w_dev, void *stream) {
     const bool want_block = getenv("SRH_EIGH_BLOCK") && atoi(getenv("SRH_EIGH_BLOCK")) != 0 && !getenv("SRH_EIGH_ROCSOLVER");
     if (want_block && n > JAC_MAX) return jacobi_block(G_dev, (int)n, w_dev, (hipStream_t)stream);
     // 256 < n <= 2048: the block form (pairs of 64) against the scalar one: 17 / 38 ms at 300, 42 / 105 ms at 600, 0.11 / 0.36 s at 1200, 0.28 / 1.37 s at 2048
-    if (n > JAC_BLOCK_MIN && n <= JAC_GRID_MAX && !getenv("SRH_EIGH_ROCSOLVER") && !(getenv("SRH_EIGH_BLOCK") && atoi(getenv("SRH_EIGH_BLOCK")) == 0))
+    if (n > JAC_BLOCK_MIN && n <= JAC_BLOCK_MAX && !getenv("SRH_EIGH_ROCSOLVER") && !(getenv("SRH_EIGH_BLOCK") && atoi(getenv("SRH_EIGH_BLOCK")) == 0))
         return jacobi_block(G_dev, (int)n, w_dev, (hipStream_t)stream);
     if (n <= JAC_GRID_MAX && !getenv("SRH_EIGH_ROCSOLVER")) return jacobi_grid(G_dev, (int)n, w_dev, (hipStream_t)stream);
-    // above 2048: rocSOLVER's dsyevd where it loads (tridiagonalisation + divide and conquer: ~30 x fewer flops than any Jacobi
+    // above 4096 (SRH_EIGH_BLOCK=0: above 2048): rocSOLVER's dsyevd where it loads (tridiagonalisation + divide and conquer: ~30 x fewer flops than any Jacobi
     // method -- 0.22 s against 3.0 s at n = 5000), the block Jacobi where it does not: the library is an accelerator, not a dependency
     Solver &s = solver();
     if (!s.ok) {

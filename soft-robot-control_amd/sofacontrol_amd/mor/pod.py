@@ -338,7 +338,7 @@ def compute_POD(snapshots, tol, rom_dim=None):
 def _compute_POD_dev(dS, n_s, n_f, tol, rom_dim=None):
     """compute_POD on a resident snapshot matrix (n_s x n_f, one snapshot per row)."""
     L = _lib.lib()
-    # everything stays in HBM: Gramian (MFMA kernel) -> eigh (Jacobi kernels; rocSOLVER above 2048 snapshots) -> mode selection -> U = S^T W Sigma^-1;
+    # everything stays in HBM: Gramian (MFMA kernel) -> eigh (Jacobi kernels; rocSOLVER above 4096 snapshots) -> mode selection -> U = S^T W Sigma^-1;
     # only the n_s eigenvalues cross to the host for the energy truncation
     dG, dw = _lib.DeviceBuffer(n_s * n_s * 8), _lib.DeviceBuffer(n_s * 8)
     _lib.check(L.srom_gramian_dev(dS.ptr, C.c_int64(n_s), C.c_int64(n_f), C.c_int64(n_f), dG.ptr, None), 'srom_gramian_dev')

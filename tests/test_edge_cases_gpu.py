@@ -186,8 +186,8 @@ def test_device_eigh_rocsolver_path():
 
 
 def test_device_eigh_above_jacobi_limit():
-    """n = 2100 > 2048: the size-based dispatch itself picks rocSOLVER (no environment override; the block Jacobi if the library
-    does not load)."""
+    """n = 2100 > 2048, the scalar Jacobi's limit: the size-based dispatch itself (no environment override) picks the block Jacobi up to
+    4096 snapshots, rocSOLVER above (the block Jacobi if the library does not load)."""
     from sofacontrol_amd.mor.pod import _device_eigh
     n = 2100
     rng = np.random.default_rng(n)
