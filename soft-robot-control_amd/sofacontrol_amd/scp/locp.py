@@ -272,29 +272,52 @@ class LOCP:
         if not good(e0):
             if k == 1:
                 s0 = 1.0 if e0['g'][0] > 0 else -1.0
-                e1 = evaluate(np.array([s0]))
-                if e1 is None:
-                    return np.inf, False, None
-                if e1['gap'] < best['gap']:
-                    best = e1
+                # expansion from mu = 0 towards the end point s0: the first trial is the Newton step of the dual with the input rows
+                # and the state cost ignored (d g / d mu = -N M R^-1 M' / 2: the inputs cannot respond more than that, so the trial
+                # stays short of the root), then secant extrapolations through the last two points, at least doubling
+                curv = 0.5 * N * float(M[0] @ Rinv @ M[0])
+                prev, e1 = e0, None
+                t = e0['g'][0] / curv if curv > 0 else s0
+                for it in range(8):
+                    t = s0 if abs(t) >= 1.0 or it == 7 else t
+                    e1 = evaluate(np.array([t]))
+                    if e1 is None:
+                        return np.inf, False, None
+                    if e1['gap'] < best['gap']:
+                        best = e1
+                    if good(e1) or e1['g'][0] * s0 < 0 or abs(t) >= 1.0:
+                        break
+                    dg = e1['g'][0] - prev['g'][0]
+                    step = -e1['g'][0] * (e1['mu'][0] - prev['mu'][0]) / dg if dg * s0 < 0 else 2.0 * (e1['mu'][0] - prev['mu'][0])
+                    if abs(step) < abs(e1['mu'][0] - prev['mu'][0]):
+                        step = 2.0 * (e1['mu'][0] - prev['mu'][0])
+                    prev, t = e1, e1['mu'][0] + 1.5 * step               # (overshoot: the aim is a sign change)
+                e0b = prev
                 if not good(e1) and e1['g'][0] * s0 < 0:            # the sign of g changes inside: its root is the optimum
-                    lo, hi = e0, e1
+                    # g is monotone and piecewise linear in mu (the active set of the QP is constant on each piece): the secant of the
+                    # bracket with the Illinois rule (an end point kept twice has its value halved) -- exact as soon as the bracket lies
+                    # inside one piece; a bisection step when the secant leaves the bracket or the bracket stops shrinking
+                    a, ga, b, gb = e0b['mu'][0], e0b['g'][0], e1['mu'][0], e1['g'][0]
+                    width = abs(b - a)
                     for it in range(60):
-                        a, b, ga, gb = lo['mu'][0], hi['mu'][0], lo['g'][0], hi['g'][0]
-                        t = a - ga * (b - a) / (gb - ga)              # secant point of the bracket; bisection every third step
-                        if it % 3 == 2 or not (min(a, b) < t < max(a, b)):
+                        t = (a * gb - b * ga) / (gb - ga)
+                        if not (min(a, b) < t < max(a, b)) or (it % 4 == 3 and abs(b - a) > 0.5 * width):
                             t = 0.5 * (a + b)
+                        if it % 4 == 3:
+                            width = abs(b - a)
                         e = evaluate(np.array([t]))
                         if e is None:
                             return np.inf, False, None
                         if e['gap'] < best['gap']:
                             best = e
-                        if good(e) or abs(b - a) <= 1e-15:
+                        gt = e['g'][0]
+                        if good(e) or abs(b - a) <= 1e-15 or gt == 0.0:
                             break
-                        if e['g'][0] * s0 > 0:
-                            lo = e
+                        if gt * gb < 0:
+                            a, ga = b, gb                               # the root is between the last two points
                         else:
-                            hi = e
+                            ga *= 0.5                                   # same side as before: Illinois
+                        b, gb = t, gt
             else:
                 proj = lambda v: v / max(1.0, float(np.linalg.norm(v)))
                 cur = e0

@@ -57,7 +57,7 @@ def test_dual_maximisation_of_the_nullspace_term_reaches_the_reference_optimum(g
     assert cert['mu_norm'] <= 1 + 1e-12 and cert['gap'] <= 1e-6 * max(1.0, abs(Je)) and abs(cert['inner_dJ']) <= 1e-6
     assert st['qp_solves'] == len(calls) <= 120
     if name == 'vec_smooth':
-        assert st['qp_solves'] == 2 and abs(st['mu'][0]) == 1.0              # mu = 0, then the end point on the side of g(0)
+        assert st['qp_solves'] <= 3 and abs(st['mu'][0]) == 1.0              # mu = 0, the Newton trial, the end point on the side of g(0)
     # every evaluation shifted the desired input by -R^-1 M' mu / 2, the same shift at every stage
     Rinv = np.linalg.inv(case['R'])
     shifts = [c - case['u_des'] for c in calls]
