@@ -294,6 +294,7 @@ int jacobi_grid(double *G_dev, int n, double *w_dev, hipStream_t st) {
         SRH_CHECK_HIP(hipStreamSynchronize(st));
         double off2 = 0.0, diag2 = 0.0;
         for (int i = 0; i < ne; ++i) { off2 += hp[2 * i]; diag2 += hp[2 * i + 1]; }
+        if (getenv("SRH_EIGH_TRACE")) fprintf(stderr, "scalar Jacobi n %d sweep %d: off^2 / diag^2 = %.3e\n", n, sweep, off2 / diag2);
         // converged, or stagnating at the rounding floor of a large matrix (n eps^2 relative)
         done = off2 <= 1e-30 * diag2 || (off2 <= 1e-26 * diag2 && off2 > 0.25 * prev);
         prev = off2;
