@@ -185,6 +185,22 @@ def test_device_eigh_rocsolver_path():
     np.testing.assert_allclose(G @ W, W * w, atol=1e-11 * max(1.0, np.abs(we).max()))
 
 
+def test_device_eigh_dispatch_boundaries():
+    """The size-based dispatch on both sides of its last boundary: 4096 snapshots run the block Jacobi (pairs of 64), 4100 the library
+    (rocSOLVER -- loaded by the test above in this process -- or, where it does not load, the block Jacobi); leading pairs and the spectrum
+    against numpy."""
+    from sofacontrol_amd.mor.pod import _device_eigh
+    for n in (4096, 4100):
+        rng = np.random.default_rng(n)
+        S = rng.standard_normal((n, 96)) * np.logspace(0, -2, 96)
+        G = S @ S.T + 1e-6 * np.eye(n)
+        w, W = _device_eigh(G)
+        we = np.linalg.eigvalsh(G)
+        np.testing.assert_allclose(w, we, rtol=0, atol=2e-11 * np.abs(we).max())
+        np.testing.assert_allclose(G @ W[:, -8:], W[:, -8:] * w[-8:], atol=1e-10 * np.abs(we).max())
+        np.testing.assert_allclose(W[:, -32:].T @ W[:, -32:], np.eye(32), atol=5e-11)
+
+
 def test_device_eigh_above_jacobi_limit():
     """n = 2100 > 2048, the scalar Jacobi's limit: the size-based dispatch itself (no environment override) picks the block Jacobi up to
     4096 snapshots, rocSOLVER above (the block Jacobi if the library does not load)."""

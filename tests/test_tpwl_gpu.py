@@ -189,3 +189,31 @@ def test_device_discretisation_reports_a_singular_model():
     rc = _lib.lib().stpwl_discretize(C.c_int(7), C.c_int(4), C.c_int(2), C.c_int64(1), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d),
                                      C.c_double(0.05), _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd))
     assert rc != 0
+
+
+def test_device_discretisation_edge_shapes():
+    """One state and one input (a 3 x 3 exponential padded to one tile), an empty batch, and a stiff model whose exponential needs ~17
+    squarings (|A| dt ~ 5e5): against scipy / the closed form."""
+    import ctypes as C
+    from scipy.linalg import expm
+    from sofacontrol_amd import _lib
+    L = _lib.lib()
+    A = np.array([[[-3.0]]]); B = np.array([[[2.0]]]); d = np.array([[0.5]])
+    Ad = np.empty_like(A); Bd = np.empty_like(B); dd = np.empty_like(d)
+    _lib.check(L.stpwl_discretize(C.c_int(3), C.c_int(1), C.c_int(1), C.c_int64(1), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d), C.c_double(0.1),
+                                  _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)), 'stpwl_discretize')
+    ea = np.exp(-0.3)
+    close(Ad, np.array([[[ea]]]), 1e-15); close(Bd, np.array([[[2.0 * (1 - ea) / 3.0]]]), 1e-15); close(dd, np.array([[0.5 * (1 - ea) / 3.0]]), 1e-15)
+    assert L.stpwl_discretize(C.c_int(3), C.c_int(1), C.c_int(1), C.c_int64(0), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d), C.c_double(0.1),
+                              _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)) == 0
+    rng = np.random.default_rng(9)
+    n, m = 12, 2
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = (Q @ np.diag(-np.logspace(0, 7, n)) @ Q.T)[None]                      # stable, stiff: eigenvalues -1 .. -1e7
+    B = rng.standard_normal((1, n, m)); d = rng.standard_normal((1, n))
+    Ad = np.empty_like(A); Bd = np.empty_like(B); dd = np.empty_like(d)
+    _lib.check(L.stpwl_discretize(C.c_int(3), C.c_int(n), C.c_int(m), C.c_int64(1), _lib.dptr(A), _lib.dptr(B), _lib.dptr(d), C.c_double(0.05),
+                                  _lib.dptr(Ad), _lib.dptr(Bd), _lib.dptr(dd)), 'stpwl_discretize')
+    M = np.zeros((n + m + 1, n + m + 1)); M[:n, :n] = A[0]; M[:n, n:n + m] = B[0]; M[:n, n + m] = d[0]
+    Z = expm(M * 0.05)
+    close(Ad[0], Z[:n, :n], 1e-9); close(Bd[0], Z[:n, n:n + m], 1e-9); close(dd[0], Z[:n, n + m], 1e-9)
